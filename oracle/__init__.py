@@ -1,0 +1,262 @@
+"""ctypes binding of the CPU oracle (oracle/vh_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (voxelhashing_demo_amd) never
+imports this module.  Parity status: see the header of vh_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libvh_oracle.so")
+
+SEM_REFERENCE = 0
+SEM_PINHOLE = 1
+FREE_BLOCK = -1
+POS_SENTINEL = 0x7FFFFFFF
+
+ENTRY_DTYPE = np.dtype([("pos", "<i4", (3,)), ("ptr", "<i4"), ("offset", "<i4")])
+VOXEL_DTYPE = np.dtype([("sdf", "<f4"), ("weight", "<f4")])
+assert ENTRY_DTYPE.itemsize == 20 and VOXEL_DTYPE.itemsize == 8
+
+
+class Params(C.Structure):
+    """HashTableParams, VoxelDataStructures.h:29-52 (176 bytes)."""
+    _fields_ = [
+        ("global_transform", C.c_float * 16),
+        ("inv_global_transform", C.c_float * 16),
+        ("numBuckets", C.c_uint32),
+        ("bucketSize", C.c_uint32),
+        ("attachedLinkedListSize", C.c_uint32),
+        ("numVoxelBlocks", C.c_uint32),
+        ("voxelBlockSize", C.c_int32),
+        ("voxelSize", C.c_float),
+        ("numOccupiedBlocks", C.c_uint32),
+        ("maxIntegrationDistance", C.c_float),
+        ("truncScale", C.c_float),
+        ("truncation", C.c_float),
+        ("integrationWeightSample", C.c_uint32),
+        ("integrationWeightMax", C.c_float),
+    ]
+
+
+assert C.sizeof(Params) == 176
+
+
+class FrameStats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "pixels_valid", "pixels_in_frustum", "inserted", "lock_losses", "bucket_full",
+        "heap_exhausted", "occupied", "voxels_updated")] + [("heap_counter", C.c_int32)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds)."""
+    src = os.path.join(_HERE, "vh_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src),
+                                              os.path.getmtime(os.path.join(_HERE, "vh_oracle.h"))):
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        ip = C.POINTER(C.c_int32)
+        L.vho_default_params.argtypes = [C.POINTER(Params)]
+        L.vho_create.restype = C.c_void_p
+        L.vho_create.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int]
+        L.vho_destroy.argtypes = [C.c_void_p]
+        L.vho_set_projection.argtypes = [C.c_void_p, fp]
+        L.vho_set_raycast_intrinsics.argtypes = [C.c_void_p] + [C.c_float] * 4
+        L.vho_set_pose.argtypes = [C.c_void_p, fp]
+        L.vho_reset_mutexes.argtypes = [C.c_void_p]
+        L.vho_alloc_blocks.argtypes = [C.c_void_p, fp]
+        L.vho_flatten.argtypes = [C.c_void_p]
+        L.vho_flatten.restype = C.c_int
+        L.vho_integrate_depth_map.argtypes = [C.c_void_p, fp]
+        L.vho_integrate.argtypes = [C.c_void_p, fp, fp, C.POINTER(FrameStats)]
+        L.vho_integrate.restype = C.c_int
+        L.vho_raycast.argtypes = [C.c_void_p, fp, C.c_float, C.c_float, fp]
+        L.vho_get_params.restype = C.POINTER(Params)
+        L.vho_get_params.argtypes = [C.c_void_p]
+        for name in ("vho_hash_table", "vho_compact_table", "vho_sdf_blocks"):
+            getattr(L, name).restype = C.c_void_p
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.vho_compact_count.argtypes = [C.c_void_p]
+        L.vho_compact_count.restype = C.c_int
+        L.vho_heap_counter.argtypes = [C.c_void_p]
+        L.vho_heap_counter.restype = C.c_int
+        L.vho_float2int_rz.argtypes = [C.c_float]
+        L.vho_float2int_rz.restype = C.c_int32
+        L.vho_hash.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_uint32]
+        L.vho_hash.restype = C.c_uint32
+        L.vho_world2voxel.argtypes = [fp, C.c_float, ip]
+        L.vho_voxel2block.argtypes = [ip, C.c_int32, ip]
+        L.vho_world2block.argtypes = [fp, C.c_float, C.c_int32, ip]
+        L.vho_invert4x4.argtypes = [fp, fp]
+        L.vho_mat4_mul_vec4.argtypes = [fp, fp, fp]
+        L.vho_project.argtypes = [fp, fp, ip]
+        L.vho_block_in_frustum.argtypes = [C.c_void_p, ip]
+        L.vho_block_in_frustum.restype = C.c_int
+        L.vho_launch_rank.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.vho_launch_rank.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def _fptr(a: np.ndarray):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def default_params(**overrides) -> Params:
+    p = Params()
+    lib().vho_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+# ---- scalar helpers (known-answer tests) ----
+def float2int_rz(x: float) -> int:
+    return int(lib().vho_float2int_rz(float(x)))
+
+
+def hash_block(x: int, y: int, z: int, num_buckets: int) -> int:
+    return int(lib().vho_hash(x, y, z, num_buckets))
+
+
+def world2voxel(p, voxel_size: float):
+    a = np.asarray(p, np.float32).copy()
+    out = (C.c_int32 * 3)()
+    lib().vho_world2voxel(_fptr(a), voxel_size, out)
+    return tuple(out)
+
+
+def voxel2block(v, block_size: int = 8):
+    a = (C.c_int32 * 3)(*[int(c) for c in v])
+    out = (C.c_int32 * 3)()
+    lib().vho_voxel2block(a, block_size, out)
+    return tuple(out)
+
+
+def world2block(p, voxel_size: float, block_size: int = 8):
+    a = np.asarray(p, np.float32).copy()
+    out = (C.c_int32 * 3)()
+    lib().vho_world2block(_fptr(a), voxel_size, block_size, out)
+    return tuple(out)
+
+
+def invert4x4(m) -> np.ndarray:
+    a = np.ascontiguousarray(np.asarray(m, np.float32).reshape(16))
+    out = np.empty(16, np.float32)
+    lib().vho_invert4x4(_fptr(a), _fptr(out))
+    return out.reshape(4, 4)
+
+
+def project(m, p):
+    a = np.ascontiguousarray(np.asarray(m, np.float32).reshape(9))
+    b = np.asarray(p, np.float32).copy()
+    out = (C.c_int32 * 2)()
+    lib().vho_project(_fptr(a), _fptr(b), out)
+    return tuple(out)
+
+
+def launch_rank(x: int, y: int, width: int) -> int:
+    return int(lib().vho_launch_rank(x, y, width))
+
+
+class OracleTable:
+    """Scalar CPU mirror of SDF_Hashtable (SDF_Hashtable.h:24-42)."""
+
+    def __init__(self, params: Params | None = None, width: int = 640, height: int = 480,
+                 semantics: int = SEM_REFERENCE):
+        self.params = params if params is not None else default_params()
+        self.width, self.height, self.semantics = width, height, semantics
+        self._h = lib().vho_create(C.byref(self.params), width, height, semantics)
+        if not self._h:
+            raise MemoryError("vho_create failed")
+        self.last_stats = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vho_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_projection(self, m):
+        a = np.ascontiguousarray(np.asarray(m, np.float32).reshape(9))
+        lib().vho_set_projection(self._h, _fptr(a))
+
+    def set_raycast_intrinsics(self, fx, fy, cx, cy):
+        lib().vho_set_raycast_intrinsics(self._h, fx, fy, cx, cy)
+
+    def integrate(self, pose, verts) -> int:
+        pose = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
+        verts = np.ascontiguousarray(verts, np.float32)
+        assert verts.size == self.width * self.height * 4
+        st = FrameStats()
+        occ = lib().vho_integrate(self._h, _fptr(pose), _fptr(verts), C.byref(st))
+        self.last_stats = st.as_dict()
+        return int(occ)
+
+    def raycast(self, pose, t_min: float = 0.1, t_max: float = 5.0) -> np.ndarray:
+        pose = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
+        out = np.zeros((self.height, self.width), np.float32)
+        lib().vho_raycast(self._h, _fptr(pose), t_min, t_max, _fptr(out))
+        return out
+
+    def block_in_frustum(self, block) -> bool:
+        a = (C.c_int32 * 3)(*[int(c) for c in block])
+        return bool(lib().vho_block_in_frustum(self._h, a))
+
+    # ---- views into the oracle's memory (copy before the table is destroyed) ----
+    def _n_entries(self):
+        return self.params.numBuckets * self.params.bucketSize
+
+    def hash_table(self) -> np.ndarray:
+        n = self._n_entries()
+        buf = (C.c_char * (n * 20)).from_address(lib().vho_hash_table(self._h))
+        return np.frombuffer(buf, dtype=ENTRY_DTYPE, count=n)
+
+    def compact(self) -> np.ndarray:
+        n = int(lib().vho_compact_count(self._h))
+        if n == 0:
+            return np.zeros(0, ENTRY_DTYPE)
+        buf = (C.c_char * (n * 20)).from_address(lib().vho_compact_table(self._h))
+        return np.frombuffer(buf, dtype=ENTRY_DTYPE, count=n)
+
+    def sdf_blocks(self) -> np.ndarray:
+        n = self.params.numVoxelBlocks * 512
+        buf = (C.c_char * (n * 8)).from_address(lib().vho_sdf_blocks(self._h))
+        return np.frombuffer(buf, dtype=VOXEL_DTYPE, count=n)
+
+    def heap_counter(self) -> int:
+        return int(lib().vho_heap_counter(self._h))
+
+    def allocated(self) -> np.ndarray:
+        t = self.hash_table()
+        return t[t["ptr"] != FREE_BLOCK]
+
+    def block_voxels(self, entry) -> np.ndarray:
+        ptr = int(entry["ptr"])
+        return self.sdf_blocks()[ptr:ptr + 512]

@@ -1,0 +1,545 @@
+/*
+ * vh_oracle.c -- scalar CPU restatement of the reference voxel-hashing path.
+ * TEST INFRASTRUCTURE ONLY; see vh_oracle.h for the parity status.
+ *
+ * Build: gcc -std=c99 -O2 -ffp-contract=off -fno-fast-math  (the reference is
+ * built with nvcc -fmad=false, CMakeLists.txt:23, so no FMA contraction is
+ * allowed anywhere in here).  x86-64 SSE arithmetic is IEEE binary32, the same
+ * as the GPU's fp32 + - * / with denormals on.
+ *
+ * Determinism rule: the reference's bucket race is resolved
+ * the way a sequential run of its own launch grid resolves it -- pixels are
+ * visited 16x16-tile-major (allocBlocks, VoxelUtils.cu:710-714), the first
+ * contender for a bucket in that order wins it for the frame.
+ */
+#include "vh_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+struct vho_table {
+    vho_params p;
+    int   width, height, semantics;
+    float proj[9];                 /* "kinectProjectionMatrix", VoxelUtils.cu:24 */
+    float rc_fx, rc_fy, rc_cx, rc_cy;
+
+    uint32_t  *heap;               /* PtrContainer, VoxelDataStructures.h:54-63 */
+    vho_entry *table;
+    vho_entry *compact;
+    int32_t   *mutex;
+    vho_voxel *blocks;
+    int32_t    heap_counter;
+    int32_t    compact_counter;
+
+    vho_frame_stats stats;
+};
+
+/* ------------------------------------------------------------------ */
+/* scalar helpers                                                      */
+/* ------------------------------------------------------------------ */
+
+/* float -> int as the GPU does it (cvt.rzi.s32.f32 / v_cvt_i32_f32):
+ * truncate toward zero, saturate, NaN -> 0.  Used wherever the reference
+ * writes int(f), make_int2(float,float) or __float2int_rz
+ * (helper_math.h:160-163, VoxelUtils.cu:353-354,776,799). */
+int32_t vho_float2int_rz(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return INT32_MAX;
+    if (x <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)x;
+}
+
+static int32_t wrap_mul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+static int32_t wrap_add(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+static int32_t wrap_sub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+
+/* calculateHash, VoxelUtils.cu:250-259.  The modulo is evaluated in unsigned
+ * arithmetic because numBuckets is unsigned (VoxelDataStructures.h:36); the
+ * res<0 fix-up is dead. */
+uint32_t vho_hash(int32_t x, int32_t y, int32_t z, uint32_t numBuckets)
+{
+    const int32_t p0 = 73856093, p1 = 19349669, p2 = 83492791;
+    uint32_t h = (uint32_t)(wrap_mul(x, p0) ^ wrap_mul(y, p1) ^ wrap_mul(z, p2));
+    return h % numBuckets;
+}
+
+/* world2Voxel, VoxelUtils.cu:280-287: true divide, then round half away from
+ * zero through copysignf(1,p)*0.5 and a truncating conversion. */
+void vho_world2voxel(const float p[3], float voxelSize, int32_t out[3])
+{
+    for (int k = 0; k < 3; ++k) {
+        float q = p[k] / voxelSize;
+        int32_t sgn = vho_float2int_rz(copysignf(1.0f, q));   /* make_int3(float..) */
+        float half = (float)((double)sgn * 0.5);              /* int * 0.5 -> double -> float */
+        out[k] = vho_float2int_rz(q + half);
+    }
+}
+
+/* voxel2Block, VoxelUtils.cu:266-278: floor division for negative voxels. */
+void vho_voxel2block(const int32_t v[3], int32_t size, int32_t out[3])
+{
+    for (int k = 0; k < 3; ++k) {
+        int32_t c = v[k];
+        if (c < 0) c = wrap_sub(c, size - 1);
+        out[k] = c / size;
+    }
+}
+
+/* world2Block, VoxelUtils.cu:306-309 */
+void vho_world2block(const float p[3], float voxelSize, int32_t blockSize, int32_t out[3])
+{
+    int32_t v[3];
+    vho_world2voxel(p, voxelSize, v);
+    vho_voxel2block(v, blockSize, out);
+}
+
+/* float4x4::operator*(float4), cuda_SimpleMatrixUtil.h:888-896: each row is
+ * summed left to right. */
+void vho_mat4_mul_vec4(const float m[16], const float v[4], float out[4])
+{
+    float r[4];
+    for (int i = 0; i < 4; ++i)
+        r[i] = m[4*i+0]*v[0] + m[4*i+1]*v[1] + m[4*i+2]*v[2] + m[4*i+3]*v[3];
+    memcpy(out, r, sizeof r);
+}
+
+/* float3x3::operator*(float3), cuda_SimpleMatrixUtil.h:482-488 */
+static void mat3_mul_vec3(const float m[9], const float v[3], float out[3])
+{
+    float r[3];
+    for (int i = 0; i < 3; ++i)
+        r[i] = m[3*i+0]*v[0] + m[3*i+1]*v[1] + m[3*i+2]*v[2];
+    memcpy(out, r, sizeof r);
+}
+
+/* float4x4::getInverse, cuda_SimpleMatrixUtil.h:944-1069: adjugate by cofactor
+ * expansion.  The table lists, for every output element, the six signed
+ * triple products in the order the reference sums them, so the fp32 result
+ * is the same bit pattern.  -a*b*c == -(a*b*c) and x - y == x + (-y) exactly. */
+static const signed char k_cof[16][6][4] = {
+    /* out  0 */ {{+1,5,10,15},{-1,5,11,14},{-1,9,6,15},{+1,9,7,14},{+1,13,6,11},{-1,13,7,10}},
+    /* out  1 */ {{-1,1,10,15},{+1,1,11,14},{+1,9,2,15},{-1,9,3,14},{-1,13,2,11},{+1,13,3,10}},
+    /* out  2 */ {{+1,1,6,15},{-1,1,7,14},{-1,5,2,15},{+1,5,3,14},{+1,13,2,7},{-1,13,3,6}},
+    /* out  3 */ {{-1,1,6,11},{+1,1,7,10},{+1,5,2,11},{-1,5,3,10},{-1,9,2,7},{+1,9,3,6}},
+    /* out  4 */ {{-1,4,10,15},{+1,4,11,14},{+1,8,6,15},{-1,8,7,14},{-1,12,6,11},{+1,12,7,10}},
+    /* out  5 */ {{+1,0,10,15},{-1,0,11,14},{-1,8,2,15},{+1,8,3,14},{+1,12,2,11},{-1,12,3,10}},
+    /* out  6 */ {{-1,0,6,15},{+1,0,7,14},{+1,4,2,15},{-1,4,3,14},{-1,12,2,7},{+1,12,3,6}},
+    /* out  7 */ {{+1,0,6,11},{-1,0,7,10},{-1,4,2,11},{+1,4,3,10},{+1,8,2,7},{-1,8,3,6}},
+    /* out  8 */ {{+1,4,9,15},{-1,4,11,13},{-1,8,5,15},{+1,8,7,13},{+1,12,5,11},{-1,12,7,9}},
+    /* out  9 */ {{-1,0,9,15},{+1,0,11,13},{+1,8,1,15},{-1,8,3,13},{-1,12,1,11},{+1,12,3,9}},
+    /* out 10 */ {{+1,0,5,15},{-1,0,7,13},{-1,4,1,15},{+1,4,3,13},{+1,12,1,7},{-1,12,3,5}},
+    /* out 11 */ {{-1,0,5,11},{+1,0,7,9},{+1,4,1,11},{-1,4,3,9},{-1,8,1,7},{+1,8,3,5}},
+    /* out 12 */ {{-1,4,9,14},{+1,4,10,13},{+1,8,5,14},{-1,8,6,13},{-1,12,5,10},{+1,12,6,9}},
+    /* out 13 */ {{+1,0,9,14},{-1,0,10,13},{-1,8,1,14},{+1,8,2,13},{+1,12,1,10},{-1,12,2,9}},
+    /* out 14 */ {{-1,0,5,14},{+1,0,6,13},{+1,4,1,14},{-1,4,2,13},{-1,12,1,6},{+1,12,2,5}},
+    /* out 15 */ {{+1,0,5,10},{-1,0,6,9},{-1,4,1,10},{+1,4,2,9},{+1,8,1,6},{-1,8,2,5}},
+};
+
+void vho_invert4x4(const float e[16], float out[16])
+{
+    float inv[16];
+    for (int o = 0; o < 16; ++o) {
+        float acc = 0.0f;
+        for (int k = 0; k < 6; ++k) {
+            const signed char *c = k_cof[o][k];
+            float t = (e[c[1]] * e[c[2]]) * e[c[3]];
+            if (c[0] < 0) t = -t;
+            acc = (k == 0) ? t : acc + t;
+        }
+        inv[o] = acc;
+    }
+    float det = e[0]*inv[0] + e[1]*inv[4] + e[2]*inv[8] + e[3]*inv[12];
+    float detr = 1.0f / det;
+    for (int i = 0; i < 16; ++i) out[i] = inv[i] * detr;
+}
+
+/* project, VoxelUtils.cu:770-777: M*p, three true divides by .z, implicit
+ * float->int in make_int2. */
+void vho_project(const float m[9], const float p[3], int32_t out[2])
+{
+    float q[3];
+    mat3_mul_vec3(m, p, q);
+    float qx = q[0] / q[2], qy = q[1] / q[2];
+    out[0] = vho_float2int_rz(qx);
+    out[1] = vho_float2int_rz(qy);
+}
+
+/* combineVoxel, VoxelUtils.cu:779-787 */
+void vho_combine_voxel(const vho_voxel *o, const vho_voxel *c, float wmax, vho_voxel *out)
+{
+    vho_voxel n;
+    n.sdf = ((o->sdf * o->weight) + (c->sdf * c->weight)) / (o->weight + c->weight);
+    n.weight = fminf(wmax, o->weight + c->weight);
+    *out = n;
+}
+
+/* Position of pixel (x,y) in the launch order of allocBlocksKernel's grid of
+ * 16x16 tiles (VoxelUtils.cu:610-611,710-712): blocks x-fastest then y,
+ * threads x-fastest then y. */
+uint32_t vho_launch_rank(int x, int y, int width)
+{
+    uint32_t tilesX = (uint32_t)((width + 15) / 16);
+    return (((uint32_t)(y >> 4) * tilesX + (uint32_t)(x >> 4)) << 8)
+         + ((uint32_t)(y & 15) << 4) + (uint32_t)(x & 15);
+}
+
+/* block2World, VoxelUtils.cu:289-304: block min corner, voxel corner (no +0.5) */
+static void block2world(const vho_table *t, const int32_t b[3], float out[3])
+{
+    for (int k = 0; k < 3; ++k) {
+        int32_t v = wrap_mul(b[k], t->p.voxelBlockSize);
+        out[k] = (float)v * t->p.voxelSize;
+    }
+}
+
+/* blockInFrustum, VoxelUtils.cu:344-359.
+ * REFERENCE: the block corner goes through global_transform (the author's own
+ * TODO at :348 notes it should be the inverse) and the image bounds are the
+ * only test.  PINHOLE: inverse pose, and the corner must be in front (z>0). */
+int vho_block_in_frustum(const vho_table *t, const int32_t block[3])
+{
+    float w[4], c[4], q[3];
+    block2world(t, block, w);
+    w[3] = 1.0f;
+    if (t->semantics == VHO_SEM_REFERENCE) {
+        vho_mat4_mul_vec4(t->p.global_transform, w, c);
+    } else {
+        vho_mat4_mul_vec4(t->p.inv_global_transform, w, c);
+        if (!(c[2] > 0.0f)) return 0;
+    }
+    mat3_mul_vec3(t->proj, c, q);
+    float qx = q[0] / q[2], qy = q[1] / q[2];
+    int32_t x = vho_float2int_rz(qx), y = vho_float2int_rz(qy);
+    return (x < t->width && x >= 0 && y < t->height && y >= 0);
+}
+
+/* ------------------------------------------------------------------ */
+/* lifecycle                                                           */
+/* ------------------------------------------------------------------ */
+
+/* common.h:39-50 as copied by SDF_Hashtable.cpp:62-73 */
+void vho_default_params(vho_params *p)
+{
+    static const float I[16] = {1,0,0,0, 0,1,0,0, 0,0,1,0, 0,0,0,1};
+    memset(p, 0, sizeof *p);
+    memcpy(p->global_transform, I, sizeof I);
+    memcpy(p->inv_global_transform, I, sizeof I);
+    p->numBuckets = 5000;
+    p->bucketSize = 5;
+    p->attachedLinkedListSize = 4;
+    p->numVoxelBlocks = 1000;
+    p->voxelBlockSize = 8;
+    p->voxelSize = 0.02f;
+    p->numOccupiedBlocks = 0;
+    p->maxIntegrationDistance = 4.0f;
+    p->truncScale = 0.01f;
+    p->truncation = 1.0f;
+    p->integrationWeightSample = 10;
+    p->integrationWeightMax = 255.0f;
+}
+
+static void reset_entries(vho_entry *e, size_t n)   /* resetHashTableKernel, :151-158 */
+{
+    for (size_t i = 0; i < n; ++i) {
+        e[i].offset = 0;
+        e[i].ptr = VHO_FREE_BLOCK;
+        e[i].pos[0] = e[i].pos[1] = e[i].pos[2] = VHO_POS_SENTINEL;
+    }
+}
+
+/* deviceAllocate + calculateKinectProjectionMatrix, VoxelUtils.cu:169-231.
+ * The compact table and the volume (GL buffers in the reference,
+ * SDFRenderer.cpp:34-61) are owned here and zero-initialised. */
+vho_table *vho_create(const vho_params *p, int width, int height, int semantics)
+{
+    if (p->voxelBlockSize != 8 || p->numBuckets == 0 || p->bucketSize == 0) return NULL;
+    vho_table *t = (vho_table *)calloc(1, sizeof *t);
+    if (!t) return NULL;
+    t->p = *p;
+    t->width = width;
+    t->height = height;
+    t->semantics = semantics;
+    size_t n = (size_t)p->numBuckets * p->bucketSize;
+    t->heap    = (uint32_t *)malloc(sizeof(uint32_t) * p->numVoxelBlocks);
+    t->table   = (vho_entry *)malloc(sizeof(vho_entry) * n);
+    t->compact = (vho_entry *)malloc(sizeof(vho_entry) * n);
+    t->mutex   = (int32_t *)calloc(p->numBuckets, sizeof(int32_t));
+    t->blocks  = (vho_voxel *)calloc((size_t)p->numVoxelBlocks * 512, sizeof(vho_voxel));
+    if (!t->heap || !t->table || !t->compact || !t->mutex || !t->blocks) {
+        vho_destroy(t);
+        return NULL;
+    }
+    reset_entries(t->table, n);
+    reset_entries(t->compact, n);
+    for (uint32_t i = 0; i < p->numVoxelBlocks; ++i) t->heap[i] = i;   /* resetHeapKernel */
+    t->heap_counter = (int32_t)p->numVoxelBlocks - 1;                    /* :207 */
+    t->compact_counter = 0;
+
+    /* common.h:7-10,15-16 scaled with the resolution */
+    const float sx = (float)width / 640.0f, sy = (float)height / 480.0f;
+    const float fx = 517.3f * sx, fy = 516.5f * sy, cx = 318.6f * sx, cy = 255.3f * sy;
+    const float KT[9] = {fx, 0, 0,  0, fy, 0,  cx, cy, 1};   /* intrinsicsTranspose read row-major */
+    const float K[9]  = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
+    memcpy(t->proj, semantics == VHO_SEM_REFERENCE ? KT : K, sizeof K);
+    t->rc_fx = fx; t->rc_fy = fy; t->rc_cx = cx; t->rc_cy = cy;
+    return t;
+}
+
+void vho_destroy(vho_table *t)
+{
+    if (!t) return;
+    free(t->heap); free(t->table); free(t->compact); free(t->mutex); free(t->blocks);
+    free(t);
+}
+
+void vho_set_projection(vho_table *t, const float m[9]) { memcpy(t->proj, m, 9 * sizeof(float)); }
+
+void vho_set_raycast_intrinsics(vho_table *t, float fx, float fy, float cx, float cy)
+{
+    t->rc_fx = fx; t->rc_fy = fy; t->rc_cx = cx; t->rc_cy = cy;
+}
+
+/* ------------------------------------------------------------------ */
+/* per-frame steps                                                     */
+/* ------------------------------------------------------------------ */
+
+/* SDF_Hashtable.cpp:15-18 */
+void vho_set_pose(vho_table *t, const float pose[16])
+{
+    float inv[16];
+    vho_invert4x4(pose, inv);
+    memcpy(t->p.global_transform, pose, sizeof inv);
+    memcpy(t->p.inv_global_transform, inv, sizeof inv);
+}
+
+/* resetHashTableMutexes, VoxelUtils.cu:146-149 */
+void vho_reset_mutexes(vho_table *t)
+{
+    memset(t->mutex, 0, sizeof(int32_t) * t->p.numBuckets);
+}
+
+/* allocSingleBlockInHeap, VoxelUtils.cu:328-334, with the exhaustion case
+ * defined (the reference reads heap[-1]): an empty heap refuses the request
+ * and leaves the counter alone. */
+static int32_t heap_pop(vho_table *t)
+{
+    if (t->heap_counter < 0) return -1;
+    int32_t addr = t->heap_counter--;
+    return (int32_t)t->heap[addr];
+}
+
+/* insertVoxelEntry, live part VoxelUtils.cu:421-456 */
+static void insert_entry(vho_table *t, const int32_t key[3])
+{
+    const uint32_t bs = t->p.bucketSize, nb = t->p.numBuckets;
+    const uint32_t h = vho_hash(key[0], key[1], key[2], nb);
+    const uint32_t start = h * bs;
+    int saw_free = 0;
+    for (uint32_t i = 0; i < bs; ++i) {
+        uint32_t idx = (start + i) % (nb * bs);
+        vho_entry *e = &t->table[idx];
+        if (e->pos[0] == key[0] && e->pos[1] == key[1] && e->pos[2] == key[2]
+            && e->ptr != VHO_FREE_BLOCK) return;                       /* already there */
+        if (e->ptr == VHO_FREE_BLOCK) {
+            saw_free = 1;
+            int32_t prev = t->mutex[h];                                /* atomicExch */
+            t->mutex[h] = VHO_LOCKED_BLOCK;
+            if (prev != VHO_LOCKED_BLOCK) {
+                int32_t blk = heap_pop(t);
+                if (blk < 0) { t->stats.heap_exhausted++; return; }
+                e->pos[0] = key[0]; e->pos[1] = key[1]; e->pos[2] = key[2];
+                e->offset = 0;
+                e->ptr = blk * 512;
+                t->stats.inserted++;
+                return;
+            }
+            /* bucket already locked this frame: the scan goes on and every
+             * later free slot loses the exchange again */
+        }
+    }
+    if (saw_free) t->stats.lock_losses++; else t->stats.bucket_full++;
+}
+
+/* allocBlocksKernel, VoxelUtils.cu:606-705, visited in launch order */
+void vho_alloc_blocks(vho_table *t, const float *verts)
+{
+    const int W = t->width, H = t->height;
+    const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+    for (int by = 0; by < tilesY; ++by)
+    for (int bx = 0; bx < tilesX; ++bx)
+    for (int ty = 0; ty < 16; ++ty)
+    for (int tx = 0; tx < 16; ++tx) {
+        const int x = bx * 16 + tx, y = by * 16 + ty;
+        if (x >= W || y >= H) continue;
+        const float *v = verts + 4 * ((size_t)y * W + x);
+        if (v[2] == 0.0f) continue;                                   /* :621 */
+        t->stats.pixels_valid++;
+        float g[4];
+        vho_mat4_mul_vec4(t->p.global_transform, v, g);               /* :622, w as stored */
+        int32_t key[3];
+        vho_world2block(g, t->p.voxelSize, t->p.voxelBlockSize, key); /* :636 */
+        if (!vho_block_in_frustum(t, key)) continue;                  /* :673 */
+        t->stats.pixels_in_frustum++;
+        insert_entry(t, key);
+    }
+}
+
+/* flattenKernel / flattenIntoBuffer, VoxelUtils.cu:719-768.  The order of the
+ * compact list is a race in the reference; here it is table order.  The
+ * redundant reset of the whole compact table (:757-758) is not repeated. */
+int vho_flatten(vho_table *t)
+{
+    const size_t n = (size_t)t->p.numBuckets * t->p.bucketSize;
+    int count = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const vho_entry *e = &t->table[i];
+        if (e->ptr != VHO_FREE_BLOCK && vho_block_in_frustum(t, e->pos))
+            t->compact[count++] = *e;
+    }
+    t->compact_counter = count;
+    t->p.numOccupiedBlocks = (uint32_t)count;
+    t->stats.occupied = (uint32_t)count;
+    return count;
+}
+
+/* integrateDepthMapKernel, VoxelUtils.cu:790-842 */
+void vho_integrate_depth_map(vho_table *t, const float *verts)
+{
+    const int W = t->width, H = t->height;
+    const float trunc = t->p.truncation;
+    for (int b = 0; b < t->compact_counter; ++b) {
+        const vho_entry *e = &t->compact[b];
+        int32_t base[3];
+        for (int k = 0; k < 3; ++k) base[k] = wrap_mul(e->pos[k], t->p.voxelBlockSize);  /* :793 */
+        for (int tz = 0; tz < 8; ++tz)
+        for (int ty = 0; ty < 8; ++ty)
+        for (int tx = 0; tx < 8; ++tx) {
+            const int32_t vi[3] = { wrap_add(base[0], tx), wrap_add(base[1], ty), wrap_add(base[2], tz) };
+            float pc[3];   /* camera-space point handed to project() */
+            if (t->semantics == VHO_SEM_REFERENCE) {
+                /* :797-800 -- the inverse pose is applied to the voxel INDEX, the
+                 * result is truncated back to an int index, then scaled to metres */
+                const float vf[4] = { (float)vi[0], (float)vi[1], (float)vi[2], 1.0f };
+                float r[4];
+                vho_mat4_mul_vec4(t->p.inv_global_transform, vf, r);
+                for (int k = 0; k < 3; ++k)
+                    pc[k] = (float)vho_float2int_rz(r[k]) * t->p.voxelSize;
+            } else {
+                const float wv[4] = { (float)vi[0] * t->p.voxelSize, (float)vi[1] * t->p.voxelSize,
+                                      (float)vi[2] * t->p.voxelSize, 1.0f };
+                float r[4];
+                vho_mat4_mul_vec4(t->p.inv_global_transform, wv, r);
+                pc[0] = r[0]; pc[1] = r[1]; pc[2] = r[2];
+            }
+            int32_t s[2];
+            vho_project(t->proj, pc, s);                                          /* :801 */
+            if (s[0] < 0 || s[0] >= W || s[1] < 0 || s[1] >= H) continue;         /* :803 */
+            const float depth = verts[4 * ((size_t)s[1] * W + s[0]) + 2];        /* :805 */
+            if (depth <= 0) continue;                                             /* :806 */
+            float sdf = depth - pc[2];                                            /* :813 */
+            if (sdf > -trunc) {                                                   /* :818 */
+                sdf = (sdf >= 0) ? fminf(trunc, sdf) : fmaxf(-trunc, sdf);        /* :819-824 */
+                const vho_voxel cur = { sdf, 0.1f };                              /* :829 */
+                vho_voxel *dst = &t->blocks[(size_t)e->ptr + (size_t)(tz * 64 + ty * 8 + tx)];  /* :836 */
+                vho_combine_voxel(dst, &cur, t->p.integrationWeightMax, dst);
+                t->stats.voxels_updated++;
+            }
+        }
+    }
+}
+
+/* SDF_Hashtable::integrate, SDF_Hashtable.cpp:11-40 */
+int vho_integrate(vho_table *t, const float pose[16], const float *verts, vho_frame_stats *stats)
+{
+    memset(&t->stats, 0, sizeof t->stats);
+    vho_set_pose(t, pose);
+    vho_reset_mutexes(t);
+    vho_alloc_blocks(t, verts);
+    int occ = vho_flatten(t);
+    if (occ > 0) vho_integrate_depth_map(t, verts);    /* :848 */
+    t->stats.heap_counter = t->heap_counter;
+    if (stats) *stats = t->stats;
+    return occ;
+}
+
+/* ------------------------------------------------------------------ */
+/* raycast (build spec; the reference's pass is disabled and broken,    */
+/* SDFRenderer.cpp:215-254, raycastSDF.frag:121-177)                   */
+/* ------------------------------------------------------------------ */
+
+/* getVoxelEntry4Block, live half VoxelUtils.cu:362-382: bucket scan, returns
+ * the entry index or -1. */
+static int64_t lookup_block(const vho_table *t, const int32_t key[3])
+{
+    const uint32_t bs = t->p.bucketSize;
+    const uint32_t h = vho_hash(key[0], key[1], key[2], t->p.numBuckets);
+    for (uint32_t i = 0; i < bs; ++i) {
+        const vho_entry *e = &t->table[(size_t)h * bs + i];
+        if (e->pos[0] == key[0] && e->pos[1] == key[1] && e->pos[2] == key[2]
+            && e->ptr != VHO_FREE_BLOCK) return (int64_t)h * bs + i;
+    }
+    return -1;
+}
+
+/* One ray per pixel from pose (camera->world) through the pinhole
+ * (fx,fy,cx,cy).  Samples sit at camera depth t_i = t_min + i*voxelSize;
+ * every sample is classified from the NEAREST voxel (world2Voxel, as the
+ * reference's shader samples un-interpolated, raycastSDF.frag:101-105).  A
+ * sample is valid when its block is in the table and its voxel has weight>0.
+ * The surface is the first pair of consecutive valid samples with
+ * sdf_prev > 0 >= sdf_cur; the reported camera depth interpolates linearly
+ * between them.  0 = no hit. */
+void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max, float *depth_out)
+{
+    const int W = t->width, H = t->height;
+    const float dt = t->p.voxelSize;
+    const int nsteps = vho_float2int_rz((t_max - t_min) / dt) + 1;
+    for (int v = 0; v < H; ++v)
+    for (int u = 0; u < W; ++u) {
+        const float dx = ((float)u - t->rc_cx) / t->rc_fx;
+        const float dy = ((float)v - t->rc_cy) / t->rc_fy;
+        int prev_valid = 0, have_key = 0;
+        float prev_sdf = 0.0f, prev_t = 0.0f, hit = 0.0f;
+        int32_t ckey[3] = {0, 0, 0};
+        int64_t cidx = -1;
+        for (int i = 0; i < nsteps; ++i) {
+            const float tt = t_min + (float)i * dt;
+            const float pc[4] = { dx * tt, dy * tt, tt, 1.0f };
+            float pw[4];
+            vho_mat4_mul_vec4(pose, pc, pw);
+            int32_t vox[3], key[3];
+            vho_world2voxel(pw, t->p.voxelSize, vox);
+            vho_voxel2block(vox, t->p.voxelBlockSize, key);
+            if (!have_key || key[0] != ckey[0] || key[1] != ckey[1] || key[2] != ckey[2]) {
+                ckey[0] = key[0]; ckey[1] = key[1]; ckey[2] = key[2];
+                cidx = lookup_block(t, key);
+                have_key = 1;
+            }
+            if (cidx < 0) { prev_valid = 0; continue; }
+            const int32_t lx = wrap_sub(vox[0], wrap_mul(key[0], 8));
+            const int32_t ly = wrap_sub(vox[1], wrap_mul(key[1], 8));
+            const int32_t lz = wrap_sub(vox[2], wrap_mul(key[2], 8));
+            const vho_voxel s = t->blocks[(size_t)t->table[cidx].ptr + (size_t)(lz * 64 + ly * 8 + lx)];
+            if (!(s.weight > 0.0f)) { prev_valid = 0; continue; }
+            if (prev_valid && prev_sdf > 0.0f && s.sdf <= 0.0f) {
+                hit = prev_t + (dt * prev_sdf) / (prev_sdf - s.sdf);
+                break;
+            }
+            prev_valid = 1; prev_sdf = s.sdf; prev_t = tt;
+        }
+        depth_out[(size_t)v * W + u] = hit;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* accessors                                                           */
+/* ------------------------------------------------------------------ */
+const vho_params *vho_get_params(const vho_table *t) { return &t->p; }
+vho_entry *vho_hash_table(vho_table *t) { return t->table; }
+vho_entry *vho_compact_table(vho_table *t) { return t->compact; }
+int vho_compact_count(const vho_table *t) { return t->compact_counter; }
+vho_voxel *vho_sdf_blocks(vho_table *t) { return t->blocks; }
+int vho_heap_counter(const vho_table *t) { return t->heap_counter; }
+const vho_frame_stats *vho_last_stats(const vho_table *t) { return &t->stats; }

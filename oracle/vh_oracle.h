@@ -1,0 +1,125 @@
+/*
+ * vh_oracle.h -- CPU oracle for the voxel-hashing TSDF fusion hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a scalar C restatement of the reference
+ * algorithm (nilspin/VoxelHashing_demo, VoxelUtils.cu + SDF_Hashtable.cpp).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or call it; the product (libvoxelhash_hip.so) never does.
+ *
+ * PARITY STATUS: "parity unpinned" in the formal sense -- the reference ships
+ * no tests, golden vectors or fixtures for this path and
+ * cannot be built in this image (needs nvcc, the CUDA runtime, OpenGL 4.3,
+ * SDL2, GLM; building it would require stand-ins for CUDA headers, which is
+ * not allowed).  The oracle is anchored instead on the values SURVEY.md /
+ * BASELINE.md recorded from a host emulation of the unmodified reference
+ * source during the survey ([probe] values: hash KATs, rounding KATs, and the
+ * block / voxel counts of two sphere scenes); tests/test_oracle_anchors.py
+ * checks every one of them.
+ *
+ * Each function cites the reference file:line it follows (paths relative to
+ * /root/reference).
+ */
+#ifndef VH_ORACLE_H
+#define VH_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VHO_FREE_BLOCK   (-1)          /* VoxelUtils.cu:19 */
+#define VHO_LOCKED_BLOCK (-2)          /* VoxelUtils.cu:20 */
+#define VHO_POS_SENTINEL 0x7fffffff    /* (int)+inf on a saturating GPU cvt, VoxelUtils.cu:157 */
+
+/* projection / transform semantics */
+#define VHO_SEM_REFERENCE 0   /* bit-faithful quirks: K^T, global_transform in the frustum
+                                 test, inverse pose applied in voxel-index units */
+#define VHO_SEM_PINHOLE   1   /* physically meaningful: K, inverse pose in the frustum test
+                                 (+ z > 0), inverse pose applied in metres */
+
+/* VoxelDataStructures.h:12-17 -- 8 bytes */
+typedef struct { float sdf; float weight; } vho_voxel;
+
+/* VoxelDataStructures.h:20-26 -- 20 bytes, align 4 */
+typedef struct { int32_t pos[3]; int32_t ptr; int32_t offset; } vho_entry;
+
+/* VoxelDataStructures.h:29-52 -- 176 bytes; matrices row-major */
+typedef struct {
+    float    global_transform[16];
+    float    inv_global_transform[16];
+    uint32_t numBuckets;
+    uint32_t bucketSize;
+    uint32_t attachedLinkedListSize;
+    uint32_t numVoxelBlocks;
+    int32_t  voxelBlockSize;
+    float    voxelSize;
+    uint32_t numOccupiedBlocks;
+    float    maxIntegrationDistance;
+    float    truncScale;
+    float    truncation;
+    uint32_t integrationWeightSample;
+    float    integrationWeightMax;
+} vho_params;
+
+typedef struct {
+    uint32_t pixels_valid;       /* verts with z != 0 */
+    uint32_t pixels_in_frustum;  /* ... whose block passes blockInFrustum */
+    uint32_t inserted;           /* entries inserted this frame */
+    uint32_t lock_losses;        /* contenders that met a locked bucket */
+    uint32_t bucket_full;        /* pixels whose bucket had no free slot and no match */
+    uint32_t heap_exhausted;     /* insertions refused because the heap was empty */
+    uint32_t occupied;           /* compact count (allocated AND in frustum) */
+    uint32_t voxels_updated;     /* voxels written by the TSDF update */
+    int32_t  heap_counter;       /* heap counter after the frame */
+} vho_frame_stats;
+
+typedef struct vho_table vho_table;
+
+/* ---- lifecycle (SDF_Hashtable.cpp:60-81, VoxelUtils.cu:169-231) ---- */
+void       vho_default_params(vho_params *p);   /* common.h:39-50 values */
+vho_table *vho_create(const vho_params *p, int width, int height, int semantics);
+void       vho_destroy(vho_table *t);
+void       vho_set_projection(vho_table *t, const float m[9]);  /* row-major 3x3 */
+void       vho_set_raycast_intrinsics(vho_table *t, float fx, float fy, float cx, float cy);
+
+/* ---- per-frame steps (SDF_Hashtable.cpp:11-40) ---- */
+void vho_set_pose(vho_table *t, const float pose[16]);          /* + cofactor inverse */
+void vho_reset_mutexes(vho_table *t);                            /* VoxelUtils.cu:146-149 */
+void vho_alloc_blocks(vho_table *t, const float *verts);         /* VoxelUtils.cu:606-716 */
+int  vho_flatten(vho_table *t);                                  /* VoxelUtils.cu:719-768 */
+void vho_integrate_depth_map(vho_table *t, const float *verts);  /* VoxelUtils.cu:790-852 */
+/* all of the above in the reference's order; returns the occupied count */
+int  vho_integrate(vho_table *t, const float pose[16], const float *verts,
+                   vho_frame_stats *stats);
+
+/* ---- raycast (build spec; self-pinned) ---- */
+void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max,
+                 float *depth_out /* W*H */);
+
+/* ---- accessors ---- */
+const vho_params *vho_get_params(const vho_table *t);
+vho_entry        *vho_hash_table(vho_table *t);      /* numBuckets*bucketSize entries */
+vho_entry        *vho_compact_table(vho_table *t);   /* first vho_compact_count valid */
+int               vho_compact_count(const vho_table *t);
+vho_voxel        *vho_sdf_blocks(vho_table *t);      /* numVoxelBlocks*512 voxels */
+int               vho_heap_counter(const vho_table *t);
+const vho_frame_stats *vho_last_stats(const vho_table *t);
+
+/* ---- scalar helpers, exported for known-answer tests ---- */
+int32_t  vho_float2int_rz(float x);                               /* GPU cvt semantics */
+uint32_t vho_hash(int32_t x, int32_t y, int32_t z, uint32_t numBuckets);
+void     vho_world2voxel(const float p[3], float voxelSize, int32_t out[3]);
+void     vho_voxel2block(const int32_t v[3], int32_t blockSize, int32_t out[3]);
+void     vho_world2block(const float p[3], float voxelSize, int32_t blockSize, int32_t out[3]);
+void     vho_invert4x4(const float m[16], float out[16]);
+void     vho_mat4_mul_vec4(const float m[16], const float v[4], float out[4]);
+void     vho_project(const float m[9], const float p[3], int32_t out[2]);
+int      vho_block_in_frustum(const vho_table *t, const int32_t block[3]);
+void     vho_combine_voxel(const vho_voxel *o, const vho_voxel *c, float wmax, vho_voxel *out);
+uint32_t vho_launch_rank(int x, int y, int width);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
