@@ -1,0 +1,60 @@
+/*
+ * SDF_Hashtable.h -- C++ host facade with the reference's class interface
+ * (SDF_Hashtable.h:24-42 / SDF_Hashtable.cpp) on top of the C-ABI in
+ * voxelhash.h.  Source-compatible for the hot path:
+ *
+ *     SDF_Hashtable table;                       // common.h defaults
+ *     table.integrate(pose, d_verts, d_normals); // SDF_Hashtable.cpp:11-40
+ *
+ * The GL interop members (registerGLtoCUDA / unmapCUDApointers,
+ * SDF_Hashtable.cpp:42-58) are kept as no-ops: the compact table, its counter
+ * and the SDF volume are library-owned device buffers.  raycast() stands in
+ * for SDFRenderer::render(const glm::mat4&) (SDFRenderer.h:38).
+ */
+#ifndef SDF_HASHTABLE_H
+#define SDF_HASHTABLE_H
+
+#include "voxelhash.h"
+
+/* row-major 4x4, the only part of cuda_SimpleMatrixUtil.h:800-1100 the path uses */
+struct float4x4 {
+    float entries[16];
+    float4x4() {}
+    explicit float4x4(const float values[16]) { for (int i = 0; i < 16; ++i) entries[i] = values[i]; }
+    void setIdentity() { for (int i = 0; i < 16; ++i) entries[i] = (i % 5 == 0) ? 1.0f : 0.0f; }
+    float &operator()(int r, int c) { return entries[4 * r + c]; }
+    float operator()(int r, int c) const { return entries[4 * r + c]; }
+};
+
+class SDFRenderer;   /* not part of this build; kept so signatures compile */
+
+class SDF_Hashtable {
+    vh_context *ctx_;
+    HashTableParams h_hashtableParams;
+
+public:
+    SDF_Hashtable();                                   /* common.h:39-50, 640x480, REFERENCE semantics */
+    SDF_Hashtable(const HashTableParams &params, int width, int height, int semantics);
+    ~SDF_Hashtable();
+    SDF_Hashtable(const SDF_Hashtable &) = delete;
+    SDF_Hashtable &operator=(const SDF_Hashtable &) = delete;
+
+    void integrate(const float4x4 &deltaT, const vh_float4 *d_verts, const vh_float4 *d_normals);
+    /* any 16-byte {x,y,z,w} float4 (HIP's float4 included) is accepted as is */
+    template <class F4>
+    void integrate(const float4x4 &deltaT, const F4 *d_verts, const F4 *d_normals)
+    {
+        static_assert(sizeof(F4) == sizeof(vh_float4), "vertex map elements must be 16-byte float4");
+        integrate(deltaT, reinterpret_cast<const vh_float4 *>(d_verts), reinterpret_cast<const vh_float4 *>(d_normals));
+    }
+    void raycast(const float4x4 &pose, float *d_depth_out, float zNear = 0.1f, float zFar = 5.0f);
+    void registerGLtoCUDA(SDFRenderer &) {}
+    void unmapCUDApointers() {}
+
+    int occupiedBlockCount();                          /* synchronises */
+    void setStream(void *hipStream);
+    vh_context *context() { return ctx_; }
+    const HashTableParams &params() const { return h_hashtableParams; }
+};
+
+#endif

@@ -1,0 +1,242 @@
+/*
+ * voxelhash.h -- C-ABI of libvoxelhash_hip.so: the MI355X (gfx950) voxel-hashing
+ * TSDF fusion path.  Plain C, plain pointers and sizes; no torch / C++ types.
+ *
+ * The library replaces the CUDA launcher layer of nilspin/VoxelHashing_demo
+ * (VoxelUtils.h:5-13, implemented in VoxelUtils.cu) that SDF_Hashtable.cpp
+ * binds to.  Two surfaces are exported:
+ *
+ *   1. vh_*  -- the explicit-context API (one table per context, one context
+ *      per GPU, explicit stream, int status returns).  Everything else is
+ *      built on it.
+ *   2. the reference's own nine names (section "drop-in names" below) acting
+ *      on a process-global default context, so that SDF_Hashtable.cpp links
+ *      against this library unchanged apart from passing params by pointer.
+ *
+ * Device pointers are `hipMalloc`-class addresses (torch CUDA tensors'
+ * data_ptr() qualify).  All device work is enqueued on the context's stream
+ * and is asynchronous unless a function says it synchronises.
+ *
+ * Paths in citations are relative to the reference checkout.
+ */
+#ifndef VOXELHASH_H
+#define VOXELHASH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ */
+/* records -- layout identical to VoxelDataStructures.h                */
+/* ------------------------------------------------------------------ */
+
+/* VoxelDataStructures.h:12-17; 8 bytes */
+typedef struct Voxel { float sdf; float weight; } Voxel;
+
+/* VoxelDataStructures.h:20-26; 20 bytes, 4-byte aligned (the __align__(16)
+ * placed before `struct` is ignored by the compilers) */
+typedef struct VoxelEntry {
+    int32_t pos[3];   /* int3 pos: block coordinate */
+    int32_t ptr;      /* first voxel index of the block in the volume, -1 = free */
+    int32_t offset;   /* linked-list offset; always 0 (list code is dead) */
+} VoxelEntry;
+
+/* VoxelDataStructures.h:29-52; 176 bytes.  Matrices are row-major float4x4. */
+typedef struct HashTableParams {
+    float    global_transform[16];
+    float    inv_global_transform[16];
+    uint32_t numBuckets;
+    uint32_t bucketSize;
+    uint32_t attachedLinkedListSize;   /* unused (dead list code) */
+    uint32_t numVoxelBlocks;
+    int32_t  voxelBlockSize;           /* must be 8 */
+    float    voxelSize;
+    uint32_t numOccupiedBlocks;
+    float    maxIntegrationDistance;   /* unused by the reference kernels */
+    float    truncScale;               /* unused by the reference kernels */
+    float    truncation;
+    uint32_t integrationWeightSample;  /* unused by the reference kernels */
+    float    integrationWeightMax;
+} HashTableParams;
+
+/* float4 as CUDA/HIP lay it out */
+typedef struct vh_float4 { float x, y, z, w; } vh_float4;
+
+/* VoxelDataStructures.h:54-63 -- raw device pointers of one table.  The bucket
+ * lock is an 8-byte epoch-stamped claim word per bucket instead of the
+ * reference's memset-per-frame int (see DESIGN.md "bucket lock"). */
+typedef struct PtrContainer {
+    uint32_t   *d_heap;
+    VoxelEntry *d_hashTable;
+    VoxelEntry *d_compactifiedHashTable;
+    uint64_t   *d_hashTableBucketMutex;
+    Voxel      *d_SDFBlocks;
+    int32_t    *d_heapCounter;
+    int32_t    *d_compactifiedHashCounter;
+} PtrContainer;
+
+#define VH_FREE_BLOCK   (-1)          /* VoxelUtils.cu:19 */
+#define VH_POS_SENTINEL 0x7fffffff    /* free-slot pos, VoxelUtils.cu:157 on a saturating cvt */
+
+/* ------------------------------------------------------------------ */
+/* status codes (the reference exits the process on any CUDA error,    */
+/* helper_cuda.h:966-977; this ABI returns a code instead)             */
+/* ------------------------------------------------------------------ */
+enum {
+    VH_OK = 0,
+    VH_ERR_INVALID_ARGUMENT = 1,
+    VH_ERR_NO_DEVICE = 2,        /* no usable HIP device */
+    VH_ERR_OUT_OF_MEMORY = 3,
+    VH_ERR_HIP = 4,              /* any other HIP runtime failure; see vh_last_error() */
+    VH_ERR_NOT_INITIALISED = 5   /* drop-in call before deviceAllocate() */
+};
+
+/* projection / transform semantics */
+enum {
+    VH_SEM_REFERENCE = 0,  /* bit-faithful to the reference, quirks included: the projection
+                              matrix is K transposed (common.h:16 through
+                              cuda_SimpleMatrixUtil.h:316-320), blockInFrustum uses
+                              global_transform (VoxelUtils.cu:348), the inverse pose is applied
+                              to voxel indices and truncated (VoxelUtils.cu:797-800) */
+    VH_SEM_PINHOLE = 1     /* physically meaningful variant used for benchmarks: K, inverse
+                              pose in the frustum test plus z > 0, inverse pose in metres */
+};
+
+typedef struct vh_config {
+    HashTableParams params;   /* as filled by SDF_Hashtable.cpp:62-73 */
+    int32_t width;            /* depth image size; the reference hard-wires 640x480 */
+    int32_t height;
+    int32_t semantics;        /* VH_SEM_* */
+    int32_t device;           /* HIP device ordinal, -1 = current device */
+} vh_config;
+
+typedef struct vh_counters {
+    int32_t  occupied;          /* entries in the compact table (last flatten) */
+    int32_t  heap_counter;      /* index of the top free heap slot; -1 = heap empty */
+    uint32_t allocated_total;   /* blocks handed out since creation */
+    uint32_t heap_exhausted;    /* insertions refused because the heap was empty */
+    uint32_t candidates;        /* contenders recorded by the last allocBlocks */
+    uint32_t epoch;             /* bucket-lock epoch (= frames since creation) */
+} vh_counters;
+
+/* per-kernel device time, accumulated while profiling is on (HIP events on
+ * the context's stream) */
+typedef struct vh_kernel_times {
+    uint64_t launches;          /* frames accumulated */
+    double   alloc_claim_ms;
+    double   alloc_commit_ms;
+    double   flatten_ms;
+    double   integrate_ms;
+    double   raycast_ms;
+    uint64_t raycast_launches;
+} vh_kernel_times;
+
+typedef struct vh_context vh_context;
+
+/* what vh_download copies */
+enum {
+    VH_BUF_HASH_TABLE = 0,   /* numBuckets*bucketSize VoxelEntry */
+    VH_BUF_COMPACT = 1,      /* numBuckets*bucketSize VoxelEntry (first `occupied` valid) */
+    VH_BUF_SDF_BLOCKS = 2,   /* numVoxelBlocks*512 Voxel */
+    VH_BUF_HEAP = 3          /* numVoxelBlocks uint32 */
+};
+
+/* ------------------------------------------------------------------ */
+/* explicit-context API                                                */
+/* ------------------------------------------------------------------ */
+
+void vh_default_params(HashTableParams *p);          /* common.h:39-50 */
+const char *vh_error_string(int code);
+const char *vh_last_error(void);                     /* text of the last failure on this thread */
+int  vh_device_count(void);                          /* 0 when no GPU is present */
+
+/* SDF_Hashtable::SDF_Hashtable + deviceAllocate + calculateKinectProjectionMatrix
+ * (SDF_Hashtable.cpp:60-81, VoxelUtils.cu:169-231).  Also owns the compact
+ * table, its counter and the zero-initialised SDF volume, which the reference
+ * borrows from OpenGL (SDFRenderer.cpp:34-61). */
+int vh_create(const vh_config *cfg, vh_context **out);
+int vh_destroy(vh_context *ctx);                     /* deviceFree, VoxelUtils.cu:213-222 */
+
+int vh_set_stream(vh_context *ctx, void *hip_stream);   /* NULL = default stream */
+int vh_set_projection(vh_context *ctx, const float m[9]);            /* row-major 3x3 */
+int vh_set_raycast_intrinsics(vh_context *ctx, float fx, float fy, float cx, float cy);
+
+/* SDF_Hashtable.cpp:15-21: stores the pose and its cofactor inverse
+ * (cuda_SimpleMatrixUtil.h:944-1069, same summation order, fp32, on the host) */
+int vh_set_pose(vh_context *ctx, const float pose[16]);
+
+int vh_reset_mutexes(vh_context *ctx);               /* resetHashTableMutexes: bumps the epoch */
+int vh_alloc_blocks(vh_context *ctx, const vh_float4 *d_verts, const vh_float4 *d_normals);
+/* flattenIntoBuffer: with occupied_out != NULL it synchronises the stream and
+ * returns the count like the reference does; with NULL it stays asynchronous */
+int vh_flatten(vh_context *ctx, int32_t *occupied_out);
+int vh_integrate_depth_map(vh_context *ctx, const vh_float4 *d_verts);
+
+/* SDF_Hashtable::integrate (SDF_Hashtable.cpp:11-40) as one asynchronous call:
+ * pose -> epoch bump -> allocBlocks -> flatten -> integrateDepthMap, no host
+ * synchronisation and no device->host copy. */
+int vh_integrate(vh_context *ctx, const float pose[16],
+                 const vh_float4 *d_verts, const vh_float4 *d_normals);
+
+/* Stand-in for SDFRenderer::render (SDFRenderer.cpp:210-255): one ray per pixel
+ * from `pose`, camera depth of the first +/- zero crossing into d_depth_out
+ * (width*height floats, 0 = no hit).  Spec: DESIGN.md "raycast". */
+int vh_raycast(vh_context *ctx, const float pose[16], float t_min, float t_max,
+               float *d_depth_out);
+
+int vh_synchronize(vh_context *ctx);
+int vh_get_counters(vh_context *ctx, vh_counters *out);              /* synchronises */
+int vh_get_params(vh_context *ctx, HashTableParams *out);
+int vh_get_device_pointers(vh_context *ctx, PtrContainer *out);
+int vh_download(vh_context *ctx, int which, void *host_dst, size_t bytes);  /* synchronises */
+
+/* test hook: evaluates the device scalar helpers on n points; writes 8 int32 per
+ * point: block x,y,z, hash, blockInFrustum, project() x,y, float->int of .w */
+int vh_debug_eval(vh_context *ctx, const vh_float4 *d_points, int32_t n, int32_t *d_out);
+
+int vh_set_profiling(vh_context *ctx, int enabled);
+int vh_get_kernel_times(vh_context *ctx, vh_kernel_times *out, int reset);  /* synchronises */
+
+/* ---- bucket-range sharding (multi-GPU; DESIGN.md "sharding") ---- */
+
+/* Restrict this context to the buckets [lo, hi) of a logical table of
+ * params.numBuckets buckets; only those buckets' storage is allocated. */
+int vh_create_shard(const vh_config *cfg, uint32_t bucket_lo, uint32_t bucket_hi,
+                    vh_context **out);
+/* Per pixel: block key of the surface point, frustum-tested and de-duplicated
+ * per wavefront.  Appends {x,y,z,rank} int4 records, binned by owning shard
+ * (owner = hash / buckets_per_shard), into d_keys[shard * capacity + i] and
+ * the per-shard counts into d_counts[num_shards]. */
+int vh_generate_keys(vh_context *ctx, const vh_float4 *d_verts, int32_t num_shards,
+                     int32_t *d_keys, int32_t capacity, int32_t *d_counts);
+/* Insert n {x,y,z,rank} records (n read from *d_count on the device) into this
+ * shard with the same one-winner-per-bucket-per-epoch rule. */
+int vh_insert_keys(vh_context *ctx, const int32_t *d_keys, const int32_t *d_count,
+                   int32_t max_keys);
+
+/* ------------------------------------------------------------------ */
+/* drop-in names (VoxelUtils.h:5-13); process-global default context    */
+/* ------------------------------------------------------------------ */
+/* The reference declares these with `const HashTableParams&`; a C++ reference
+ * is a pointer at the ABI level, so the C declarations take a pointer.
+ * Errors follow the reference convention: message on stderr + exit(1).
+ * mapGLobjectsToCUDApointers (VoxelUtils.h:13) is not carried over: the
+ * compact table / counter / volume are library-owned device buffers. */
+void updateConstantHashTableParams(const HashTableParams *params);
+void deviceAllocate(const HashTableParams *params);
+void deviceFree(void);
+void resetHashTableMutexes(const HashTableParams *params);
+void allocBlocks(const vh_float4 *verts, const vh_float4 *normals);
+int  flattenIntoBuffer(const HashTableParams *params);
+void calculateKinectProjectionMatrix(void);
+void integrateDepthMap(const HashTableParams *params, const vh_float4 *verts);
+/* the default context behind the drop-in names (NULL before deviceAllocate) */
+vh_context *vh_default_context(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXELHASH_H */

@@ -1,0 +1,142 @@
+"""ctypes loader for libvoxelhash_hip.so (the C-ABI declared in include/voxelhash.h).
+
+There is no CPU fallback: if the HIP library is missing the import of anything
+that needs it raises, and on a machine without a GPU `vh_create` returns
+VH_ERR_NO_DEVICE which is surfaced as an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvoxelhash_hip.so")
+FACADE_PATH = os.path.join(_HERE, "lib", "libsdf_hashtable.so")
+
+VH_OK = 0
+SEM_REFERENCE = 0
+SEM_PINHOLE = 1
+BUF_HASH_TABLE, BUF_COMPACT, BUF_SDF_BLOCKS, BUF_HEAP = 0, 1, 2, 3
+FREE_BLOCK = -1
+
+
+class HashTableParams(C.Structure):
+    """VoxelDataStructures.h:29-52 (176 bytes)."""
+    _fields_ = [
+        ("global_transform", C.c_float * 16),
+        ("inv_global_transform", C.c_float * 16),
+        ("numBuckets", C.c_uint32),
+        ("bucketSize", C.c_uint32),
+        ("attachedLinkedListSize", C.c_uint32),
+        ("numVoxelBlocks", C.c_uint32),
+        ("voxelBlockSize", C.c_int32),
+        ("voxelSize", C.c_float),
+        ("numOccupiedBlocks", C.c_uint32),
+        ("maxIntegrationDistance", C.c_float),
+        ("truncScale", C.c_float),
+        ("truncation", C.c_float),
+        ("integrationWeightSample", C.c_uint32),
+        ("integrationWeightMax", C.c_float),
+    ]
+
+
+class Config(C.Structure):
+    _fields_ = [("params", HashTableParams), ("width", C.c_int32), ("height", C.c_int32),
+                ("semantics", C.c_int32), ("device", C.c_int32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("occupied", C.c_int32), ("heap_counter", C.c_int32), ("allocated_total", C.c_uint32),
+                ("heap_exhausted", C.c_uint32), ("candidates", C.c_uint32), ("epoch", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("alloc_claim_ms", C.c_double), ("alloc_commit_ms", C.c_double),
+                ("flatten_ms", C.c_double), ("integrate_ms", C.c_double), ("raycast_ms", C.c_double),
+                ("raycast_launches", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class PtrContainer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "d_heap", "d_hashTable", "d_compactifiedHashTable", "d_hashTableBucketMutex", "d_SDFBlocks",
+        "d_heapCounter", "d_compactifiedHashCounter")]
+
+
+assert C.sizeof(HashTableParams) == 176
+
+# every symbol include/voxelhash.h declares: (restype, argtypes)
+_vp, _i32, _u32, _f = C.c_void_p, C.c_int32, C.c_uint32, C.c_float
+_fp = C.POINTER(C.c_float)
+SIGNATURES = {
+    "vh_default_params": (None, [C.POINTER(HashTableParams)]),
+    "vh_error_string": (C.c_char_p, [C.c_int]),
+    "vh_last_error": (C.c_char_p, []),
+    "vh_device_count": (C.c_int, []),
+    "vh_create": (C.c_int, [C.POINTER(Config), C.POINTER(_vp)]),
+    "vh_destroy": (C.c_int, [_vp]),
+    "vh_set_stream": (C.c_int, [_vp, _vp]),
+    "vh_set_projection": (C.c_int, [_vp, _fp]),
+    "vh_set_raycast_intrinsics": (C.c_int, [_vp, _f, _f, _f, _f]),
+    "vh_set_pose": (C.c_int, [_vp, _fp]),
+    "vh_reset_mutexes": (C.c_int, [_vp]),
+    "vh_alloc_blocks": (C.c_int, [_vp, _vp, _vp]),
+    "vh_flatten": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "vh_integrate_depth_map": (C.c_int, [_vp, _vp]),
+    "vh_integrate": (C.c_int, [_vp, _fp, _vp, _vp]),
+    "vh_raycast": (C.c_int, [_vp, _fp, _f, _f, _vp]),
+    "vh_synchronize": (C.c_int, [_vp]),
+    "vh_get_counters": (C.c_int, [_vp, C.POINTER(Counters)]),
+    "vh_get_params": (C.c_int, [_vp, C.POINTER(HashTableParams)]),
+    "vh_get_device_pointers": (C.c_int, [_vp, C.POINTER(PtrContainer)]),
+    "vh_download": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
+    "vh_debug_eval": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "vh_set_profiling": (C.c_int, [_vp, C.c_int]),
+    "vh_get_kernel_times": (C.c_int, [_vp, C.POINTER(KernelTimes), C.c_int]),
+    "vh_create_shard": (C.c_int, [C.POINTER(Config), _u32, _u32, C.POINTER(_vp)]),
+    "vh_generate_keys": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
+    "vh_insert_keys": (C.c_int, [_vp, _vp, _vp, _i32]),
+    "updateConstantHashTableParams": (None, [C.POINTER(HashTableParams)]),
+    "deviceAllocate": (None, [C.POINTER(HashTableParams)]),
+    "deviceFree": (None, []),
+    "resetHashTableMutexes": (None, [C.POINTER(HashTableParams)]),
+    "allocBlocks": (None, [_vp, _vp]),
+    "flattenIntoBuffer": (C.c_int, [C.POINTER(HashTableParams)]),
+    "calculateKinectProjectionMatrix": (None, []),
+    "integrateDepthMap": (None, [C.POINTER(HashTableParams), _vp]),
+    "vh_default_context": (_vp, []),
+}
+
+_lib = None
+
+
+class VoxelHashError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VoxelHashError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, where: str):
+    if rc != VH_OK:
+        L = load()
+        raise VoxelHashError(f"{where}: {L.vh_error_string(rc).decode()} ({L.vh_last_error().decode()})")

@@ -1,0 +1,725 @@
+// vh_api.hip -- the C-ABI of libvoxelhash_hip.so (include/voxelhash.h): context
+// lifecycle, per-frame orchestration (SDF_Hashtable.cpp:11-40 without its four
+// device syncs and two D2H reads), and the reference's drop-in names.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vh_kernels.hip"
+
+using namespace vh;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *what, hipError_t e = hipSuccess)
+{
+    g_last_error = what;
+    if (e != hipSuccess) {
+        g_last_error += ": ";
+        g_last_error += hipGetErrorString(e);
+    }
+    return code;
+}
+
+#define VH_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess)                                                     \
+            return fail(e_ == hipErrorOutOfMemory ? VH_ERR_OUT_OF_MEMORY : VH_ERR_HIP, #call, e_); \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct PhaseEvents {
+    hipEvent_t ev[5];   // before claim, after claim, after commit, after flatten, after integrate
+};
+
+struct vh_context {
+    HashTableParams params;
+    FrameParams fp;
+    DevPtrs dp;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t numEntries = 0;         // owned entries
+    uint32_t ownedBuckets = 0;
+    float rc_fx = 0, rc_fy = 0, rc_cx = 0, rc_cy = 0;
+    bool profiling = false;
+    std::vector<PhaseEvents> frameEvents;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> raycastEvents;
+    vh_kernel_times times{};
+    int integrateGrid = 2048;
+};
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// host math: float4x4::getInverse, cuda_SimpleMatrixUtil.h:944-1069.  The table
+// lists, per output element, the six signed triple products in the order the
+// reference sums them, so the fp32 result has the same bits (this translation
+// unit is built with -ffp-contract=off).
+// ---------------------------------------------------------------------------
+static const signed char k_cof[16][6][4] = {
+    {{+1,5,10,15},{-1,5,11,14},{-1,9,6,15},{+1,9,7,14},{+1,13,6,11},{-1,13,7,10}},
+    {{-1,1,10,15},{+1,1,11,14},{+1,9,2,15},{-1,9,3,14},{-1,13,2,11},{+1,13,3,10}},
+    {{+1,1,6,15},{-1,1,7,14},{-1,5,2,15},{+1,5,3,14},{+1,13,2,7},{-1,13,3,6}},
+    {{-1,1,6,11},{+1,1,7,10},{+1,5,2,11},{-1,5,3,10},{-1,9,2,7},{+1,9,3,6}},
+    {{-1,4,10,15},{+1,4,11,14},{+1,8,6,15},{-1,8,7,14},{-1,12,6,11},{+1,12,7,10}},
+    {{+1,0,10,15},{-1,0,11,14},{-1,8,2,15},{+1,8,3,14},{+1,12,2,11},{-1,12,3,10}},
+    {{-1,0,6,15},{+1,0,7,14},{+1,4,2,15},{-1,4,3,14},{-1,12,2,7},{+1,12,3,6}},
+    {{+1,0,6,11},{-1,0,7,10},{-1,4,2,11},{+1,4,3,10},{+1,8,2,7},{-1,8,3,6}},
+    {{+1,4,9,15},{-1,4,11,13},{-1,8,5,15},{+1,8,7,13},{+1,12,5,11},{-1,12,7,9}},
+    {{-1,0,9,15},{+1,0,11,13},{+1,8,1,15},{-1,8,3,13},{-1,12,1,11},{+1,12,3,9}},
+    {{+1,0,5,15},{-1,0,7,13},{-1,4,1,15},{+1,4,3,13},{+1,12,1,7},{-1,12,3,5}},
+    {{-1,0,5,11},{+1,0,7,9},{+1,4,1,11},{-1,4,3,9},{-1,8,1,7},{+1,8,3,5}},
+    {{-1,4,9,14},{+1,4,10,13},{+1,8,5,14},{-1,8,6,13},{-1,12,5,10},{+1,12,6,9}},
+    {{+1,0,9,14},{-1,0,10,13},{-1,8,1,14},{+1,8,2,13},{+1,12,1,10},{-1,12,2,9}},
+    {{-1,0,5,14},{+1,0,6,13},{+1,4,1,14},{-1,4,2,13},{-1,12,1,6},{+1,12,2,5}},
+    {{+1,0,5,10},{-1,0,6,9},{-1,4,1,10},{+1,4,2,9},{+1,8,1,6},{-1,8,2,5}},
+};
+
+static void invert4x4(const float e[16], float out[16])
+{
+    float inv[16];
+    for (int o = 0; o < 16; ++o) {
+        float acc = 0.0f;
+        for (int k = 0; k < 6; ++k) {
+            const signed char *c = k_cof[o][k];
+            float t = (e[c[1]] * e[c[2]]) * e[c[3]];
+            if (c[0] < 0) t = -t;
+            acc = (k == 0) ? t : acc + t;
+        }
+        inv[o] = acc;
+    }
+    const float det = e[0] * inv[0] + e[1] * inv[4] + e[2] * inv[8] + e[3] * inv[12];
+    const float detr = 1.0f / det;
+    for (int i = 0; i < 16; ++i) out[i] = inv[i] * detr;
+}
+
+// ---------------------------------------------------------------------------
+// small exported helpers
+// ---------------------------------------------------------------------------
+extern "C" void vh_default_params(HashTableParams *p)
+{
+    static const float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memset(p, 0, sizeof *p);
+    std::memcpy(p->global_transform, I, sizeof I);
+    std::memcpy(p->inv_global_transform, I, sizeof I);
+    p->numBuckets = 5000;              // common.h:39-50
+    p->bucketSize = 5;
+    p->attachedLinkedListSize = 4;
+    p->numVoxelBlocks = 1000;
+    p->voxelBlockSize = 8;
+    p->voxelSize = 0.02f;
+    p->numOccupiedBlocks = 0;
+    p->maxIntegrationDistance = 4.0f;
+    p->truncScale = 0.01f;
+    p->truncation = 1.0f;
+    p->integrationWeightSample = 10;
+    p->integrationWeightMax = 255.0f;
+}
+
+extern "C" const char *vh_error_string(int code)
+{
+    switch (code) {
+        case VH_OK: return "ok";
+        case VH_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case VH_ERR_NO_DEVICE: return "no usable HIP device";
+        case VH_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case VH_ERR_HIP: return "HIP runtime error";
+        case VH_ERR_NOT_INITIALISED: return "deviceAllocate() has not been called";
+        default: return "unknown error";
+    }
+}
+
+extern "C" const char *vh_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int vh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// lifecycle
+// ---------------------------------------------------------------------------
+static void default_projection(vh_context *c)
+{
+    // common.h:7-10 scaled with the resolution; REFERENCE keeps the transposed
+    // matrix the reference actually uploads (common.h:16 read row-major by
+    // cuda_SimpleMatrixUtil.h:316-320 at VoxelUtils.cu:227)
+    const float sx = (float)c->fp.width / 640.0f, sy = (float)c->fp.height / 480.0f;
+    const float fx = 517.3f * sx, fy = 516.5f * sy, cx = 318.6f * sx, cy = 255.3f * sy;
+    const float KT[9] = {fx, 0, 0, 0, fy, 0, cx, cy, 1};
+    const float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
+    std::memcpy(c->fp.proj, c->fp.semantics == VH_SEM_REFERENCE ? KT : K, sizeof K);
+    c->rc_fx = fx; c->rc_fy = fy; c->rc_cx = cx; c->rc_cy = cy;
+}
+
+static int free_buffers(vh_context *c)
+{
+    if (c->dp.heap) (void)hipFree(c->dp.heap);
+    if (c->dp.table) (void)hipFree(c->dp.table);
+    if (c->dp.compact) (void)hipFree(c->dp.compact);
+    if (c->dp.claim) (void)hipFree(c->dp.claim);
+    if (c->dp.blocks) (void)hipFree(c->dp.blocks);
+    if (c->dp.counters) (void)hipFree(c->dp.counters);
+    if (c->dp.candidates) (void)hipFree(c->dp.candidates);
+    c->dp = DevPtrs{};
+    return VH_OK;
+}
+
+static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_context **out)
+{
+    if (!cfg || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const HashTableParams &p = cfg->params;
+    if (p.voxelBlockSize != 8) return fail(VH_ERR_INVALID_ARGUMENT, "voxelBlockSize must be 8");
+    if (p.numBuckets == 0 || p.bucketSize == 0 || p.numVoxelBlocks == 0 || !(p.voxelSize > 0.0f))
+        return fail(VH_ERR_INVALID_ARGUMENT, "numBuckets, bucketSize, numVoxelBlocks and voxelSize must be positive");
+    if (cfg->width <= 0 || cfg->height <= 0 || (uint64_t)cfg->width * cfg->height > (1u << 24))
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad image size");
+    if (cfg->semantics != VH_SEM_REFERENCE && cfg->semantics != VH_SEM_PINHOLE)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad semantics");
+    if (lo >= hi || hi > p.numBuckets) return fail(VH_ERR_INVALID_ARGUMENT, "bad bucket range");
+    if ((uint64_t)p.numVoxelBlocks * kBlockVoxels > 0x7fffffffull)
+        return fail(VH_ERR_INVALID_ARGUMENT, "numVoxelBlocks*512 must fit the int ptr field");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(VH_ERR_NO_DEVICE, "hipGetDeviceCount");
+    int dev = cfg->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return fail(VH_ERR_NO_DEVICE, "hipGetDevice");
+    if (dev >= ndev) return fail(VH_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+
+    vh_context *c = new vh_context();
+    c->device = dev;
+    DeviceGuard guard(dev);
+    if (!guard.ok) { delete c; return fail(VH_ERR_NO_DEVICE, "hipSetDevice"); }
+    c->params = p;
+    c->params.numOccupiedBlocks = 0;
+    FrameParams &fp = c->fp;
+    std::memcpy(fp.T, p.global_transform, sizeof fp.T);
+    std::memcpy(fp.Tinv, p.inv_global_transform, sizeof fp.Tinv);
+    fp.voxelSize = p.voxelSize;
+    fp.truncation = p.truncation;
+    fp.weightMax = p.integrationWeightMax;
+    fp.width = cfg->width;
+    fp.height = cfg->height;
+    fp.semantics = cfg->semantics;
+    fp.numBuckets = p.numBuckets;
+    fp.bucketSize = p.bucketSize;
+    fp.bucketLo = lo;
+    fp.bucketHi = hi;
+    fp.numVoxelBlocks = p.numVoxelBlocks;
+    fp.epoch = 0;
+    default_projection(c);
+
+    c->ownedBuckets = hi - lo;
+    c->numEntries = (size_t)c->ownedBuckets * p.bucketSize;
+    const size_t npix = (size_t)cfg->width * cfg->height;
+    DevPtrs &dp = c->dp;
+    dp = DevPtrs{};
+    dp.candCapacity = (uint32_t)npix;
+
+#define VH_ALLOC(ptr, bytes)                                               \
+    do {                                                                   \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));               \
+        if (e_ != hipSuccess) {                                            \
+            free_buffers(c);                                               \
+            delete c;                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? VH_ERR_OUT_OF_MEMORY : VH_ERR_HIP, "hipMalloc " #ptr, e_); \
+        }                                                                  \
+    } while (0)
+    VH_ALLOC(dp.heap, sizeof(uint32_t) * (size_t)p.numVoxelBlocks);
+    VH_ALLOC(dp.table, sizeof(VoxelEntry) * c->numEntries);
+    VH_ALLOC(dp.compact, sizeof(VoxelEntry) * c->numEntries);
+    VH_ALLOC(dp.claim, sizeof(unsigned long long) * (size_t)c->ownedBuckets);
+    VH_ALLOC(dp.blocks, sizeof(Voxel) * (size_t)p.numVoxelBlocks * kBlockVoxels);
+    VH_ALLOC(dp.counters, sizeof(int32_t) * kNumCounters);
+    VH_ALLOC(dp.candidates, sizeof(int4) * npix);
+#undef VH_ALLOC
+
+    // deviceAllocate, VoxelUtils.cu:183-208 (+ the compact table and the zeroed
+    // volume the reference leaves to OpenGL)
+    hipStream_t s = nullptr;
+    const int g = 2048;
+    reset_table_kernel<<<g, 256, 0, s>>>(dp.table, c->numEntries);
+    reset_table_kernel<<<g, 256, 0, s>>>(dp.compact, c->numEntries);
+    reset_heap_kernel<<<g, 256, 0, s>>>(dp.heap, p.numVoxelBlocks);
+    hipError_t e = hipMemsetAsync(dp.claim, 0, sizeof(unsigned long long) * (size_t)c->ownedBuckets, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dp.blocks, 0, sizeof(Voxel) * (size_t)p.numVoxelBlocks * kBlockVoxels, s);
+    int32_t h_counters[kNumCounters] = {0};
+    h_counters[kHeapCounter] = (int32_t)p.numVoxelBlocks - 1;               // :207
+    if (e == hipSuccess) e = hipMemcpyAsync(dp.counters, h_counters, sizeof h_counters, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        free_buffers(c);
+        delete c;
+        return fail(VH_ERR_HIP, "table initialisation", e);
+    }
+    *out = c;
+    return VH_OK;
+}
+
+extern "C" int vh_create(const vh_config *cfg, vh_context **out)
+{
+    if (!cfg) return fail(VH_ERR_INVALID_ARGUMENT, "null config");
+    return create_impl(cfg, 0, cfg->params.numBuckets, out);
+}
+
+extern "C" int vh_create_shard(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_context **out)
+{
+    return create_impl(cfg, lo, hi, out);
+}
+
+static void drop_events(vh_context *c)
+{
+    for (auto &f : c->frameEvents)
+        for (auto &ev : f.ev) (void)hipEventDestroy(ev);
+    c->frameEvents.clear();
+    for (auto &p : c->raycastEvents) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    c->raycastEvents.clear();
+}
+
+extern "C" int vh_destroy(vh_context *c)
+{
+    if (!c) return VH_OK;
+    DeviceGuard guard(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drop_events(c);
+    free_buffers(c);
+    delete c;
+    return VH_OK;
+}
+
+extern "C" int vh_set_stream(vh_context *c, void *stream)
+{
+    if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    c->stream = (hipStream_t)stream;
+    return VH_OK;
+}
+
+extern "C" int vh_set_projection(vh_context *c, const float m[9])
+{
+    if (!c || !m) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    std::memcpy(c->fp.proj, m, 9 * sizeof(float));
+    return VH_OK;
+}
+
+extern "C" int vh_set_raycast_intrinsics(vh_context *c, float fx, float fy, float cx, float cy)
+{
+    if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    c->rc_fx = fx; c->rc_fy = fy; c->rc_cx = cx; c->rc_cy = cy;
+    return VH_OK;
+}
+
+extern "C" int vh_set_pose(vh_context *c, const float pose[16])
+{
+    if (!c || !pose) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    std::memcpy(c->fp.T, pose, sizeof c->fp.T);
+    invert4x4(pose, c->fp.Tinv);                        // SDF_Hashtable.cpp:15
+    std::memcpy(c->params.global_transform, c->fp.T, sizeof c->fp.T);
+    std::memcpy(c->params.inv_global_transform, c->fp.Tinv, sizeof c->fp.Tinv);
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// per-frame steps
+// ---------------------------------------------------------------------------
+extern "C" int vh_reset_mutexes(vh_context *c)
+{
+    if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    // The reference memsets 4*numBuckets bytes every frame (VoxelUtils.cu:146-149).
+    // Claim words carry the epoch in their upper half, so starting a new epoch
+    // invalidates every lock at once.  After 2^32-1 frames the words are cleared
+    // for real and the epoch restarts.
+    if (c->fp.epoch == 0xffffffffu) {
+        DeviceGuard guard(c->device);
+        VH_HIP(hipMemsetAsync(c->dp.claim, 0, sizeof(unsigned long long) * (size_t)c->ownedBuckets, c->stream));
+        c->fp.epoch = 0;
+    }
+    c->fp.epoch += 1;
+    return VH_OK;
+}
+
+static inline int grid_for(size_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
+
+static int launch_alloc(vh_context *c, const vh_float4 *verts, PhaseEvents *pe)
+{
+    const int npix = c->fp.width * c->fp.height;
+    if (pe) VH_HIP(hipEventRecord(pe->ev[0], c->stream));
+    alloc_claim_kernel<false><<<grid_for(npix, 256), 256, 0, c->stream>>>(
+        c->fp, c->dp, reinterpret_cast<const float4 *>(verts), 1, nullptr, 0, nullptr, 0u);
+    if (pe) VH_HIP(hipEventRecord(pe->ev[1], c->stream));
+    alloc_commit_kernel<<<32, 256, 0, c->stream>>>(c->fp, c->dp);
+    if (pe) VH_HIP(hipEventRecord(pe->ev[2], c->stream));
+    return VH_OK;
+}
+
+static int launch_flatten(vh_context *c, PhaseEvents *pe)
+{
+    flatten_kernel<<<grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane), kFlattenThreads, 0, c->stream>>>(
+        c->fp, c->dp, (uint32_t)c->numEntries);
+    if (pe) VH_HIP(hipEventRecord(pe->ev[3], c->stream));
+    return VH_OK;
+}
+
+static int launch_integrate(vh_context *c, const vh_float4 *verts, PhaseEvents *pe)
+{
+    integrate_kernel<<<c->integrateGrid, 256, 0, c->stream>>>(c->fp, c->dp, reinterpret_cast<const float4 *>(verts));
+    if (pe) VH_HIP(hipEventRecord(pe->ev[4], c->stream));
+    return VH_OK;
+}
+
+extern "C" int vh_alloc_blocks(vh_context *c, const vh_float4 *verts, const vh_float4 *normals)
+{
+    (void)normals;   // loaded into a dead variable by the reference (VoxelUtils.cu:631)
+    if (!c || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (c->fp.epoch == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
+    DeviceGuard guard(c->device);
+    int rc = launch_alloc(c, verts, nullptr);
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_flatten(vh_context *c, int32_t *occupied_out)
+{
+    if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    DeviceGuard guard(c->device);
+    VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));   // :760
+    int rc = launch_flatten(c, nullptr);
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    if (occupied_out) {
+        int32_t n = 0;
+        VH_HIP(hipMemcpyAsync(&n, c->dp.counters + kCompactCount, sizeof n, hipMemcpyDeviceToHost, c->stream));
+        VH_HIP(hipStreamSynchronize(c->stream));                                               // :765
+        *occupied_out = n;
+        c->params.numOccupiedBlocks = (uint32_t)n;
+    }
+    return VH_OK;
+}
+
+extern "C" int vh_integrate_depth_map(vh_context *c, const vh_float4 *verts)
+{
+    if (!c || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(c->device);
+    int rc = launch_integrate(c, verts, nullptr);
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4 *verts, const vh_float4 *normals)
+{
+    (void)normals;
+    if (!c || !pose || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(c->device);
+    int rc = vh_set_pose(c, pose);
+    if (rc == VH_OK) rc = vh_reset_mutexes(c);
+    if (rc != VH_OK) return rc;
+    PhaseEvents *pe = nullptr;
+    if (c->profiling) {
+        PhaseEvents f;
+        for (auto &ev : f.ev) VH_HIP(hipEventCreate(&ev));
+        c->frameEvents.push_back(f);
+        pe = &c->frameEvents.back();
+    }
+    // alloc_commit re-arms the compact counter, so no memset node is needed here
+    if ((rc = launch_alloc(c, verts, pe)) != VH_OK) return rc;
+    if ((rc = launch_flatten(c, pe)) != VH_OK) return rc;
+    if ((rc = launch_integrate(c, verts, pe)) != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, float t_max, float *d_depth_out)
+{
+    if (!c || !pose || !d_depth_out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (!(t_max > t_min)) return fail(VH_ERR_INVALID_ARGUMENT, "t_max must exceed t_min");
+    DeviceGuard guard(c->device);
+    FrameParams fp = c->fp;
+    std::memcpy(fp.T, pose, sizeof fp.T);
+    const float q = (t_max - t_min) / fp.voxelSize;
+    int nsteps = (q >= 2147483648.0f) ? 0x7fffffff : (int)q;
+    nsteps += 1;
+    dim3 grid((fp.width + 15) / 16, (fp.height + 15) / 16);
+    std::pair<hipEvent_t, hipEvent_t> evs{};
+    if (c->profiling) {
+        VH_HIP(hipEventCreate(&evs.first));
+        VH_HIP(hipEventCreate(&evs.second));
+        VH_HIP(hipEventRecord(evs.first, c->stream));
+    }
+    raycast_kernel<<<grid, 256, 0, c->stream>>>(fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx, c->rc_cy, t_min, nsteps,
+                                                 d_depth_out);
+    if (c->profiling) {
+        VH_HIP(hipEventRecord(evs.second, c->stream));
+        c->raycastEvents.push_back(evs);
+    }
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// sharding
+// ---------------------------------------------------------------------------
+extern "C" int vh_generate_keys(vh_context *c, const vh_float4 *verts, int32_t num_shards, int32_t *d_keys,
+                                int32_t capacity, int32_t *d_counts)
+{
+    if (!c || !verts || !d_keys || !d_counts || num_shards <= 0 || capacity <= 0)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(c->device);
+    const int npix = c->fp.width * c->fp.height;
+    VH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)num_shards, c->stream));
+    alloc_claim_kernel<true><<<grid_for(npix, 256), 256, 0, c->stream>>>(
+        c->fp, c->dp, reinterpret_cast<const float4 *>(verts), num_shards, reinterpret_cast<int4 *>(d_keys), capacity,
+        d_counts, 0u);
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_insert_keys(vh_context *c, const int32_t *d_keys, const int32_t *d_count, int32_t max_keys)
+{
+    if (!c || !d_keys || !d_count || max_keys < 0) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    if (c->fp.epoch == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
+    DeviceGuard guard(c->device);
+    int grid = grid_for((size_t)max_keys, 256);
+    if (grid < 1) grid = 1;
+    if (grid > 1024) grid = 1024;
+    claim_keys_kernel<<<grid, 256, 0, c->stream>>>(c->fp, c->dp, reinterpret_cast<const int4 *>(d_keys), d_count,
+                                                   max_keys);
+    alloc_commit_kernel<<<32, 256, 0, c->stream>>>(c->fp, c->dp);
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// queries
+// ---------------------------------------------------------------------------
+extern "C" int vh_synchronize(vh_context *c)
+{
+    if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    DeviceGuard guard(c->device);
+    VH_HIP(hipStreamSynchronize(c->stream));
+    return VH_OK;
+}
+
+extern "C" int vh_get_counters(vh_context *c, vh_counters *out)
+{
+    if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(c->device);
+    int32_t h[kNumCounters];
+    VH_HIP(hipMemcpyAsync(h, c->dp.counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    VH_HIP(hipStreamSynchronize(c->stream));
+    out->occupied = h[kCompactCount];
+    out->heap_counter = h[kHeapCounter];
+    out->allocated_total = (uint32_t)h[kAllocatedTotal];
+    out->heap_exhausted = (uint32_t)h[kHeapExhausted];
+    out->candidates = (uint32_t)h[kLastCandidates];
+    out->epoch = c->fp.epoch;
+    c->params.numOccupiedBlocks = (uint32_t)h[kCompactCount];
+    return VH_OK;
+}
+
+extern "C" int vh_get_params(vh_context *c, HashTableParams *out)
+{
+    if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    *out = c->params;
+    return VH_OK;
+}
+
+extern "C" int vh_get_device_pointers(vh_context *c, PtrContainer *out)
+{
+    if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    out->d_heap = c->dp.heap;
+    out->d_hashTable = c->dp.table;
+    out->d_compactifiedHashTable = c->dp.compact;
+    out->d_hashTableBucketMutex = reinterpret_cast<uint64_t *>(c->dp.claim);
+    out->d_SDFBlocks = c->dp.blocks;
+    out->d_heapCounter = c->dp.counters + kHeapCounter;
+    out->d_compactifiedHashCounter = c->dp.counters + kCompactCount;
+    return VH_OK;
+}
+
+extern "C" int vh_download(vh_context *c, int which, void *dst, size_t bytes)
+{
+    if (!c || !dst) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    const void *src = nullptr;
+    size_t avail = 0;
+    switch (which) {
+        case VH_BUF_HASH_TABLE: src = c->dp.table; avail = sizeof(VoxelEntry) * c->numEntries; break;
+        case VH_BUF_COMPACT: src = c->dp.compact; avail = sizeof(VoxelEntry) * c->numEntries; break;
+        case VH_BUF_SDF_BLOCKS: src = c->dp.blocks; avail = sizeof(Voxel) * (size_t)c->params.numVoxelBlocks * kBlockVoxels; break;
+        case VH_BUF_HEAP: src = c->dp.heap; avail = sizeof(uint32_t) * (size_t)c->params.numVoxelBlocks; break;
+        default: return fail(VH_ERR_INVALID_ARGUMENT, "unknown buffer id");
+    }
+    if (bytes > avail) return fail(VH_ERR_INVALID_ARGUMENT, "download larger than the buffer");
+    DeviceGuard guard(c->device);
+    VH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    VH_HIP(hipStreamSynchronize(c->stream));
+    return VH_OK;
+}
+
+extern "C" int vh_set_profiling(vh_context *c, int enabled)
+{
+    if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    c->profiling = enabled != 0;
+    return VH_OK;
+}
+
+extern "C" int vh_get_kernel_times(vh_context *c, vh_kernel_times *out, int reset)
+{
+    if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(c->device);
+    VH_HIP(hipStreamSynchronize(c->stream));
+    for (auto &f : c->frameEvents) {
+        float ms[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 4; ++k) VH_HIP(hipEventElapsedTime(&ms[k], f.ev[k], f.ev[k + 1]));
+        c->times.alloc_claim_ms += ms[0];
+        c->times.alloc_commit_ms += ms[1];
+        c->times.flatten_ms += ms[2];
+        c->times.integrate_ms += ms[3];
+        c->times.launches += 1;
+    }
+    for (auto &p : c->raycastEvents) {
+        float ms = 0;
+        VH_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+        c->times.raycast_ms += ms;
+        c->times.raycast_launches += 1;
+    }
+    drop_events(c);
+    *out = c->times;
+    if (reset) c->times = vh_kernel_times{};
+    return VH_OK;
+}
+
+// test hook: scalar helpers evaluated on the device (8 int32 per point:
+// block x,y,z, hash, inFrustum, screen x,y, f2i_rz(w))
+extern "C" int vh_debug_eval(vh_context *c, const vh_float4 *d_points, int32_t n, int32_t *d_out)
+{
+    if (!c || !d_points || !d_out || n < 0) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(c->device);
+    if (n == 0) return VH_OK;
+    debug_eval_kernel<<<grid_for((size_t)n, 256), 256, 0, c->stream>>>(c->fp, reinterpret_cast<const float4 *>(d_points), n,
+                                                                       d_out);
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// drop-in names (VoxelUtils.h:5-13) on a process-global context
+// ---------------------------------------------------------------------------
+static vh_context *g_default = nullptr;
+static HashTableParams g_default_params;
+static bool g_have_params = false;
+
+[[noreturn]] static void die(const char *where, int rc)
+{
+    // checkCudaErrors convention, helper_cuda.h:966-977
+    std::fprintf(stderr, "voxelhash: %s failed: %s (%s)\n", where, vh_error_string(rc), vh_last_error());
+    std::exit(EXIT_FAILURE);
+}
+
+extern "C" vh_context *vh_default_context(void) { return g_default; }
+
+extern "C" void updateConstantHashTableParams(const HashTableParams *params)
+{
+    // VoxelUtils.cu:87-91.  There is no __constant__ copy to refresh: kernels
+    // receive the frame parameters by value.  The pose and the occupied count
+    // are taken over.
+    if (!params) die("updateConstantHashTableParams", VH_ERR_INVALID_ARGUMENT);
+    g_default_params = *params;
+    g_have_params = true;
+    if (g_default) {
+        std::memcpy(g_default->fp.T, params->global_transform, sizeof g_default->fp.T);
+        std::memcpy(g_default->fp.Tinv, params->inv_global_transform, sizeof g_default->fp.Tinv);
+        std::memcpy(g_default->params.global_transform, params->global_transform, sizeof g_default->fp.T);
+        std::memcpy(g_default->params.inv_global_transform, params->inv_global_transform, sizeof g_default->fp.T);
+        g_default->params.numOccupiedBlocks = params->numOccupiedBlocks;
+    }
+}
+
+extern "C" void deviceAllocate(const HashTableParams *params)
+{
+    if (!params) die("deviceAllocate", VH_ERR_INVALID_ARGUMENT);
+    if (g_default) { vh_destroy(g_default); g_default = nullptr; }
+    vh_config cfg;
+    cfg.params = *params;
+    cfg.width = 640;          // common.h:17-18
+    cfg.height = 480;
+    cfg.semantics = VH_SEM_REFERENCE;
+    cfg.device = -1;
+    if (const char *s = std::getenv("VOXELHASH_SEMANTICS"))
+        if (std::strcmp(s, "pinhole") == 0) cfg.semantics = VH_SEM_PINHOLE;
+    int rc = vh_create(&cfg, &g_default);
+    if (rc != VH_OK) die("deviceAllocate", rc);
+}
+
+extern "C" void deviceFree(void)
+{
+    if (g_default) { vh_destroy(g_default); g_default = nullptr; }
+}
+
+extern "C" void resetHashTableMutexes(const HashTableParams *params)
+{
+    (void)params;
+    if (!g_default) die("resetHashTableMutexes", VH_ERR_NOT_INITIALISED);
+    int rc = vh_reset_mutexes(g_default);
+    if (rc != VH_OK) die("resetHashTableMutexes", rc);
+}
+
+extern "C" void allocBlocks(const vh_float4 *verts, const vh_float4 *normals)
+{
+    if (!g_default) die("allocBlocks", VH_ERR_NOT_INITIALISED);
+    int rc = vh_alloc_blocks(g_default, verts, normals);
+    if (rc == VH_OK) rc = vh_synchronize(g_default);     // the reference syncs after the launch (:715)
+    if (rc != VH_OK) die("allocBlocks", rc);
+}
+
+extern "C" int flattenIntoBuffer(const HashTableParams *params)
+{
+    (void)params;
+    if (!g_default) die("flattenIntoBuffer", VH_ERR_NOT_INITIALISED);
+    int32_t n = 0;
+    int rc = vh_flatten(g_default, &n);
+    if (rc != VH_OK) die("flattenIntoBuffer", rc);
+    return n;
+}
+
+extern "C" void calculateKinectProjectionMatrix(void)
+{
+    if (!g_default) die("calculateKinectProjectionMatrix", VH_ERR_NOT_INITIALISED);
+    default_projection(g_default);                       // VoxelUtils.cu:224-231
+}
+
+extern "C" void integrateDepthMap(const HashTableParams *params, const vh_float4 *verts)
+{
+    if (!g_default) die("integrateDepthMap", VH_ERR_NOT_INITIALISED);
+    if (params && params->numOccupiedBlocks == 0) return;          // :848
+    int rc = vh_integrate_depth_map(g_default, verts);
+    if (rc == VH_OK) rc = vh_synchronize(g_default);               // :850
+    if (rc != VH_OK) die("integrateDepthMap", rc);
+}

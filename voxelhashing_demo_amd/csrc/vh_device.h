@@ -1,0 +1,161 @@
+// vh_device.h -- device-side records and scalar helpers of the voxel-hashing path
+// (gfx950 only).  Every helper states the reference line it reproduces; the file
+// is compiled with -ffp-contract=off because the reference is built with
+// nvcc -fmad=false (CMakeLists.txt:23): no multiply-add may be fused.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/voxelhash.h"
+
+static_assert(sizeof(Voxel) == 8, "Voxel must stay 8 bytes (VoxelDataStructures.h:12-17)");
+static_assert(sizeof(VoxelEntry) == 20, "VoxelEntry must stay 20 bytes (VoxelDataStructures.h:20-26)");
+static_assert(sizeof(HashTableParams) == 176, "HashTableParams must stay 176 bytes");
+
+namespace vh {
+
+constexpr int kWave = 64;
+constexpr int kBlockVoxels = 512;          // 8^3, the *512 literals of VoxelUtils.cu:449
+constexpr int kEntryDwords = 5;            // 20-byte VoxelEntry
+
+// device counters (one int32 array per context)
+enum Counter : int {
+    kHeapCounter = 0,      // index of the top free heap slot (VoxelUtils.cu:207)
+    kCompactCount = 1,     // d_compactifiedHashCounter
+    kCandCount = 2,        // contenders recorded by the running allocBlocks
+    kAllocatedTotal = 3,
+    kHeapExhausted = 4,
+    kLastCandidates = 5,
+    kCommitTicket = 6,
+    kNumCounters = 8
+};
+
+// Everything a kernel needs about the frame, passed by value in the kernel
+// argument segment (the reference uploads it to __constant__ memory twice per
+// frame, SDF_Hashtable.cpp:21,33).
+struct FrameParams {
+    float T[16];          // global_transform  (camera -> world), row-major
+    float Tinv[16];       // inv_global_transform
+    float proj[9];        // "kinectProjectionMatrix", VoxelUtils.cu:24
+    float voxelSize;
+    float truncation;
+    float weightMax;
+    int32_t width, height;
+    int32_t semantics;
+    uint32_t numBuckets;  // logical table size (hash modulus)
+    uint32_t bucketSize;
+    uint32_t bucketLo;    // this context owns buckets [bucketLo, bucketHi)
+    uint32_t bucketHi;
+    uint32_t numVoxelBlocks;
+    uint32_t epoch;       // bucket-lock epoch of this frame (>= 1)
+};
+
+struct DevPtrs {
+    uint32_t *heap;
+    VoxelEntry *table;        // (bucketHi-bucketLo)*bucketSize entries
+    VoxelEntry *compact;
+    unsigned long long *claim;  // one epoch-stamped claim word per owned bucket
+    Voxel *blocks;
+    int32_t *counters;        // Counter[]
+    int4 *candidates;         // {x,y,z,rank} of this frame's contenders
+    uint32_t candCapacity;
+};
+
+struct int3_ { int x, y, z; };
+
+// float -> int exactly as CUDA's cvt.rzi.s32.f32 (what int(f), make_int2(float,
+// float) and __float2int_rz compile to in the reference): truncate, saturate,
+// NaN -> 0.  v_cvt_i32_f32 has the same contract on gfx950.
+__device__ __forceinline__ int f2i_rz(float x)
+{
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// calculateHash, VoxelUtils.cu:250-259 (unsigned modulo)
+__device__ __forceinline__ uint32_t hash_block(int x, int y, int z, uint32_t numBuckets)
+{
+    const uint32_t h = ((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349669u) ^ ((uint32_t)z * 83492791u);
+    return h % numBuckets;
+}
+
+// world2Voxel, VoxelUtils.cu:280-287: true divide, round half away from zero
+__device__ __forceinline__ int world2voxel1(float p, float voxelSize)
+{
+    const float q = p / voxelSize;
+    return f2i_rz(q + __builtin_copysignf(0.5f, q));
+}
+
+// voxel2Block, VoxelUtils.cu:266-278: floor division by 8
+__device__ __forceinline__ int voxel2block1(int v)
+{
+    if (v < 0) v = (int)((uint32_t)v - 7u);
+    return v / 8;
+}
+
+__device__ __forceinline__ int3_ world2block(float x, float y, float z, float voxelSize)
+{
+    int3_ b;
+    b.x = voxel2block1(world2voxel1(x, voxelSize));
+    b.y = voxel2block1(world2voxel1(y, voxelSize));
+    b.z = voxel2block1(world2voxel1(z, voxelSize));
+    return b;
+}
+
+// float4x4::operator*(float4), cuda_SimpleMatrixUtil.h:888-896, rows summed
+// left to right
+__device__ __forceinline__ float4 mat4_mul(const float *m, float x, float y, float z, float w)
+{
+    float4 r;
+    r.x = m[0] * x + m[1] * y + m[2] * z + m[3] * w;
+    r.y = m[4] * x + m[5] * y + m[6] * z + m[7] * w;
+    r.z = m[8] * x + m[9] * y + m[10] * z + m[11] * w;
+    r.w = m[12] * x + m[13] * y + m[14] * z + m[15] * w;
+    return r;
+}
+
+// project, VoxelUtils.cu:770-777: M*p, true divides by .z, implicit float->int
+__device__ __forceinline__ void project(const float *m, float x, float y, float z, int &sx, int &sy)
+{
+    const float qx = m[0] * x + m[1] * y + m[2] * z;
+    const float qy = m[3] * x + m[4] * y + m[5] * z;
+    const float qz = m[6] * x + m[7] * y + m[8] * z;
+    sx = f2i_rz(qx / qz);
+    sy = f2i_rz(qy / qz);
+}
+
+// blockInFrustum, VoxelUtils.cu:344-359 (REFERENCE) / corrected variant (PINHOLE)
+__device__ __forceinline__ bool block_in_frustum(const FrameParams &fp, int bx, int by, int bz)
+{
+    const float wx = (float)(int)((uint32_t)bx * 8u) * fp.voxelSize;   // block2World :289-304
+    const float wy = (float)(int)((uint32_t)by * 8u) * fp.voxelSize;
+    const float wz = (float)(int)((uint32_t)bz * 8u) * fp.voxelSize;
+    float4 c;
+    if (fp.semantics == VH_SEM_REFERENCE) {
+        c = mat4_mul(fp.T, wx, wy, wz, 1.0f);
+    } else {
+        c = mat4_mul(fp.Tinv, wx, wy, wz, 1.0f);
+        if (!(c.z > 0.0f)) return false;
+    }
+    int sx, sy;
+    project(fp.proj, c.x, c.y, c.z, sx, sy);
+    return sx < fp.width && sx >= 0 && sy < fp.height && sy >= 0;
+}
+
+// Position of pixel (x,y) in the launch order of the reference's grid of 16x16
+// tiles (VoxelUtils.cu:610-611,710-712).  The lowest rank contending for a
+// bucket wins it for the frame (SURVEY.md 8(c) determinism rule).
+__device__ __forceinline__ uint32_t launch_rank(int x, int y, int width)
+{
+    const uint32_t tilesX = (uint32_t)(width + 15) >> 4;
+    return ((((uint32_t)y >> 4) * tilesX + ((uint32_t)x >> 4)) << 8) + (((uint32_t)y & 15u) << 4) + ((uint32_t)x & 15u);
+}
+
+__device__ __forceinline__ unsigned long long claim_word(uint32_t epoch, uint32_t rank)
+{
+    return ((unsigned long long)epoch << 32) | (unsigned long long)(0xffffffffu - rank);
+}
+
+}  // namespace vh

@@ -1,0 +1,377 @@
+// vh_kernels.hip -- hand-written gfx950 kernels of the voxel-hashing TSDF path.
+//
+//   alloc_claim_kernel    per-pixel block key + wave-level run dedup + bucket probe;
+//                         contenders stake an epoch-stamped claim on their bucket
+//                         (allocBlocksKernel + the locking half of insertVoxelEntry,
+//                         VoxelUtils.cu:606-705, 418-456)
+//   alloc_commit_kernel   the contender that holds the claim writes the entry and
+//                         pops the heap (VoxelUtils.cu:447-453, 328-334)
+//   flatten_kernel        one coalesced walk over the VoxelEntry array, wave-ballot
+//                         compaction of allocated in-frustum entries
+//                         (flattenKernel, VoxelUtils.cu:719-749)
+//   integrate_kernel      one 8^3 block per workgroup pass, 16-byte-per-lane voxel
+//                         read-modify-write (integrateDepthMapKernel, VoxelUtils.cu:790-842)
+//   raycast_kernel        per-pixel march through the hash (stand-in for
+//                         SDFRenderer::render, SDFRenderer.cpp:210-255)
+//
+// All of it is integer/fp32 scalar work bound by HBM traffic and latency; there
+// is no contraction to hand to MFMA.
+#include "vh_device.h"
+
+namespace vh {
+
+// ---------------------------------------------------------------------------
+// bucket probe shared by the claim kernels
+// ---------------------------------------------------------------------------
+// Reads the bucket of `key` the way insertVoxelEntry scans it (VoxelUtils.cu:436-456):
+// present -> nothing to do; otherwise, if a free slot exists, stake a claim.
+// Allocated entries always form a prefix of the bucket (insertions take the
+// first free slot, nothing is ever deleted), so "present anywhere" equals the
+// reference's in-order scan.
+__device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz,
+                                                uint32_t h, uint32_t rank)
+{
+    const VoxelEntry *bucket = dp.table + (size_t)(h - fp.bucketLo) * fp.bucketSize;
+    bool has_free = false;
+    for (uint32_t i = 0; i < fp.bucketSize; ++i) {
+        const VoxelEntry e = bucket[i];
+        if (e.ptr == VH_FREE_BLOCK) {
+            has_free = true;
+            break;                       // prefix property: nothing allocated behind a free slot
+        }
+        if (e.pos[0] == kx && e.pos[1] == ky && e.pos[2] == kz) return;   // already allocated
+    }
+    if (!has_free) return;               // bucket full: the key is dropped (no overflow list)
+    atomicMax(dp.claim + (h - fp.bucketLo), claim_word(fp.epoch, rank));
+    const uint32_t slot = (uint32_t)atomicAdd(dp.counters + kCandCount, 1);
+    if (slot < dp.candCapacity) dp.candidates[slot] = make_int4(kx, ky, kz, (int)rank);
+}
+
+// ---------------------------------------------------------------------------
+// allocBlocks, phase 1
+// ---------------------------------------------------------------------------
+// One lane per pixel, row-major, so the float4 vertex map is read with 16-byte
+// coalesced loads (1 KiB per wave instruction).  Neighbouring pixels almost
+// always fall into the same 8^3 block, so each wave collapses runs of equal
+// keys to their first lane before touching the table: ~300 k pixels become a
+// few thousand bucket probes.  Within an image row the launch rank grows with
+// x, so the first lane of a run carries the run's lowest rank.
+//
+// kEmit: instead of probing, bin the surviving keys by owning shard (multi-GPU
+// key exchange, DESIGN.md "sharding").
+template <bool kEmit>
+__global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, const DevPtrs dp,
+                                                          const float4 *__restrict__ verts, int32_t numShards,
+                                                          int4 *__restrict__ outKeys, int32_t outCapacity,
+                                                          int32_t *__restrict__ outCounts, uint32_t rankBase)
+{
+    const int npix = fp.width * fp.height;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    bool want = false;
+    int kx = 0, ky = 0, kz = 0, px = 0, py = 0;
+    if (idx < npix) {
+        const float4 v = verts[idx];
+        py = idx / fp.width;
+        px = idx - py * fp.width;
+        if (v.z != 0.0f) {                                               // VoxelUtils.cu:621
+            const float4 g = mat4_mul(fp.T, v.x, v.y, v.z, v.w);         // :622, w as stored
+            const int3_ b = world2block(g.x, g.y, g.z, fp.voxelSize);    // :636
+            kx = b.x; ky = b.y; kz = b.z;
+            want = block_in_frustum(fp, kx, ky, kz);                     // :673
+        }
+    }
+    // run-length dedup across the wave
+    const int lane = threadIdx.x & (kWave - 1);
+    const int pkx = __shfl_up(kx, 1), pky = __shfl_up(ky, 1), pkz = __shfl_up(kz, 1);
+    const int ppy = __shfl_up(py, 1);
+    const int pwant = __shfl_up((int)want, 1);
+    const bool leader = want && (lane == 0 || !pwant || ppy != py || pkx != kx || pky != ky || pkz != kz);
+    if (!leader) return;
+
+    const uint32_t h = hash_block(kx, ky, kz, fp.numBuckets);
+    const uint32_t rank = rankBase + launch_rank(px, py, fp.width);
+    if constexpr (kEmit) {
+        const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
+        const uint32_t owner = h / perShard;
+        const int slot = atomicAdd(outCounts + owner, 1);
+        if (slot < outCapacity) outKeys[(size_t)owner * outCapacity + slot] = make_int4(kx, ky, kz, (int)rank);
+    } else {
+        if (h < fp.bucketLo || h >= fp.bucketHi) return;                 // not this shard's bucket
+        probe_and_claim(fp, dp, kx, ky, kz, h, rank);
+    }
+}
+
+// phase 1 for keys that arrived from other ranks
+__global__ __launch_bounds__(256) void claim_keys_kernel(const FrameParams fp, const DevPtrs dp,
+                                                         const int4 *__restrict__ keys,
+                                                         const int32_t *__restrict__ count, int32_t maxKeys)
+{
+    int n = *count;
+    if (n > maxKeys) n = maxKeys;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int4 k = keys[i];
+        const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
+        if (h < fp.bucketLo || h >= fp.bucketHi) continue;
+        probe_and_claim(fp, dp, k.x, k.y, k.z, h, (uint32_t)k.w);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// allocBlocks, phase 2
+// ---------------------------------------------------------------------------
+// Exactly one contender per bucket finds its own word in the claim array: the
+// one with the lowest launch rank, i.e. the thread a sequential run of the
+// reference grid would have let through the atomicExch (VoxelUtils.cu:444-445).
+// It takes the first free slot and pops the heap (top-down, :328-334).  An empty
+// heap refuses the insertion instead of reading heap[-1].
+__global__ __launch_bounds__(256) void alloc_commit_kernel(const FrameParams fp, const DevPtrs dp)
+{
+    int n = dp.counters[kCandCount];
+    if ((uint32_t)n > dp.candCapacity) n = (int)dp.candCapacity;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int4 k = dp.candidates[i];
+        const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
+        const uint32_t local = h - fp.bucketLo;
+        if (dp.claim[local] != claim_word(fp.epoch, (uint32_t)k.w)) continue;   // lost the bucket this frame
+        VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
+        for (uint32_t s = 0; s < fp.bucketSize; ++s) {
+            if (bucket[s].ptr != VH_FREE_BLOCK) continue;
+            const int addr = atomicSub(dp.counters + kHeapCounter, 1);
+            if (addr < 0) {                                   // heap empty: undo, refuse
+                atomicAdd(dp.counters + kHeapCounter, 1);
+                atomicAdd(dp.counters + kHeapExhausted, 1);
+                break;
+            }
+            VoxelEntry e;
+            e.pos[0] = k.x; e.pos[1] = k.y; e.pos[2] = k.z;
+            e.ptr = (int)(dp.heap[addr] * (uint32_t)kBlockVoxels);
+            e.offset = 0;
+            bucket[s] = e;
+            atomicAdd(dp.counters + kAllocatedTotal, 1);
+            break;
+        }
+    }
+    // the last workgroup to finish re-arms the per-frame counters
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(dp.counters + kCommitTicket, 1);
+        if (ticket == (int)gridDim.x - 1) {
+            dp.counters[kLastCandidates] = dp.counters[kCandCount];
+            dp.counters[kCandCount] = 0;
+            dp.counters[kCompactCount] = 0;
+            dp.counters[kCommitTicket] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// flattenIntoBuffer
+// ---------------------------------------------------------------------------
+// Only `ptr` decides whether an entry is live, and all but a few thousand of
+// the millions of entries are free, so every lane reads just the ptr dword of
+// its entries (stride 20 B: a wave instruction covers 1280 contiguous bytes,
+// every fetched line is fully consumed across the kEntriesPerLane loads).  The
+// rare live entries are re-read in full, frustum-tested and appended with one
+// atomic per wave (ballot + mbcnt prefix).  The reference also clears the whole
+// compact table first (VoxelUtils.cu:757-758, its own TODO calls it redundant);
+// that pass is dropped.
+constexpr int kFlattenThreads = 256;
+constexpr int kEntriesPerLane = 8;
+
+__global__ __launch_bounds__(kFlattenThreads) void flatten_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                  uint32_t numEntries)
+{
+    const uint32_t tile = blockIdx.x * (kFlattenThreads * kEntriesPerLane);
+    const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
+    int32_t ptrs[kEntriesPerLane];
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) {
+        const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
+        ptrs[j] = (e < numEntries) ? __builtin_nontemporal_load(words + (size_t)e * kEntryDwords + 3) : VH_FREE_BLOCK;
+    }
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) any |= (ptrs[j] != VH_FREE_BLOCK);
+    if (__ballot(any) == 0ull) return;
+
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) {
+        bool hit = false;
+        VoxelEntry ent;
+        if (ptrs[j] != VH_FREE_BLOCK) {
+            const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
+            ent = dp.table[e];
+            hit = block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);   // VoxelUtils.cu:732
+        }
+        const unsigned long long mask = __ballot(hit);
+        if (mask == 0ull) continue;
+        int base = 0;
+        const int leaderLane = __ffsll((long long)mask) - 1;
+        if (lane == leaderLane) base = atomicAdd(dp.counters + kCompactCount, __popcll(mask));
+        base = __shfl(base, leaderLane);
+        if (hit) {
+            const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+            dp.compact[base + prefix] = ent;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// integrateDepthMap
+// ---------------------------------------------------------------------------
+// A workgroup of 256 lanes owns one 8^3 block per pass: lane t updates voxels
+// 2t and 2t+1 (neighbours in x), so the block moves as 16-byte-per-lane
+// coalesced loads and stores (4 KiB in, 4 KiB out) instead of the reference's
+// 8-byte accesses.  The occupied count never leaves the device: the grid is a
+// fixed size and strides over the compact list.
+__device__ __forceinline__ bool tsdf_update(const FrameParams &fp, const float4 *__restrict__ verts, int vx, int vy,
+                                            int vz, float &sdfOut, float &wOut)
+{
+    float cx, cy, cz;
+    if (fp.semantics == VH_SEM_REFERENCE) {
+        // VoxelUtils.cu:797-800: inverse pose on the voxel INDEX, truncate, then metres
+        const float4 r = mat4_mul(fp.Tinv, (float)vx, (float)vy, (float)vz, 1.0f);
+        cx = (float)f2i_rz(r.x) * fp.voxelSize;
+        cy = (float)f2i_rz(r.y) * fp.voxelSize;
+        cz = (float)f2i_rz(r.z) * fp.voxelSize;
+    } else {
+        const float4 r = mat4_mul(fp.Tinv, (float)vx * fp.voxelSize, (float)vy * fp.voxelSize,
+                                  (float)vz * fp.voxelSize, 1.0f);
+        cx = r.x; cy = r.y; cz = r.z;
+    }
+    int sx, sy;
+    project(fp.proj, cx, cy, cz, sx, sy);                                        // :801
+    if (sx < 0 || sx >= fp.width || sy < 0 || sy >= fp.height) return false;     // :803
+    const float depth = verts[(size_t)sy * fp.width + sx].z;                     // :805
+    if (depth <= 0.0f) return false;                                             // :806
+    float sdf = depth - cz;                                                      // :813
+    if (!(sdf > -fp.truncation)) return false;                                   // :818
+    sdf = (sdf >= 0.0f) ? __builtin_fminf(fp.truncation, sdf) : __builtin_fmaxf(-fp.truncation, sdf);
+    // combineVoxel, :779-787, current sample {sdf, 0.1f} (:829)
+    const float ow = wOut, os = sdfOut;
+    sdfOut = ((os * ow) + (sdf * 0.1f)) / (ow + 0.1f);
+    wOut = __builtin_fminf(fp.weightMax, ow + 0.1f);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void integrate_kernel(const FrameParams fp, const DevPtrs dp,
+                                                        const float4 *__restrict__ verts)
+{
+    const int count = dp.counters[kCompactCount];
+    const int t = threadIdx.x;
+    const int lin = 2 * t;                       // linearizeVoxelPos: z*64 + y*8 + x  (:311-317)
+    const int tx = lin & 7, ty = (lin >> 3) & 7, tz = lin >> 6;
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {
+        const VoxelEntry e = dp.compact[b];
+        const int bx = (int)((uint32_t)e.pos[0] * 8u) + tx;     // block2Voxel + threadIdx (:793-796)
+        const int by = (int)((uint32_t)e.pos[1] * 8u) + ty;
+        const int bz = (int)((uint32_t)e.pos[2] * 8u) + tz;
+        float4 *cell = reinterpret_cast<float4 *>(dp.blocks + (size_t)e.ptr + lin);
+        float4 v = *cell;                        // {sdf0, w0, sdf1, w1}
+        const bool u0 = tsdf_update(fp, verts, bx, by, bz, v.x, v.y);
+        const bool u1 = tsdf_update(fp, verts, bx + 1, by, bz, v.z, v.w);
+        if (u0 || u1) *cell = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// raycast
+// ---------------------------------------------------------------------------
+// getVoxelEntry4Block, live half (VoxelUtils.cu:362-382)
+__device__ __forceinline__ int lookup_block(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz)
+{
+    const uint32_t h = hash_block(kx, ky, kz, fp.numBuckets);
+    if (h < fp.bucketLo || h >= fp.bucketHi) return VH_FREE_BLOCK;
+    const VoxelEntry *bucket = dp.table + (size_t)(h - fp.bucketLo) * fp.bucketSize;
+    for (uint32_t i = 0; i < fp.bucketSize; ++i) {
+        const VoxelEntry e = bucket[i];
+        if (e.ptr == VH_FREE_BLOCK) return VH_FREE_BLOCK;      // prefix property
+        if (e.pos[0] == kx && e.pos[1] == ky && e.pos[2] == kz) return e.ptr;
+    }
+    return VH_FREE_BLOCK;
+}
+
+// Spec (DESIGN.md "raycast", oracle/vh_oracle.c vho_raycast): samples at camera
+// depth t_i = tMin + i*voxelSize, nearest-voxel classification, first pair of
+// consecutive valid samples with sdf_prev > 0 >= sdf_cur, linear interpolation.
+// 16x16-pixel tiles: a wave is a 16x4 patch of neighbouring rays, which walk
+// the same blocks and keep the bucket / voxel lines hot in L2.
+__global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, const DevPtrs dp, float fx, float fy,
+                                                      float cx, float cy, float tMin, int nSteps,
+                                                      float *__restrict__ depthOut)
+{
+    const int u = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int v = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (u >= fp.width || v >= fp.height) return;
+    const float dx = ((float)u - cx) / fx;
+    const float dy = ((float)v - cy) / fy;
+    const float dt = fp.voxelSize;
+    bool prevValid = false, haveKey = false;
+    float prevSdf = 0.0f, prevT = 0.0f, hit = 0.0f;
+    int ckx = 0, cky = 0, ckz = 0, cptr = VH_FREE_BLOCK;
+    for (int i = 0; i < nSteps; ++i) {
+        const float tt = tMin + (float)i * dt;
+        const float4 pw = mat4_mul(fp.T, dx * tt, dy * tt, tt, 1.0f);
+        const int vx = world2voxel1(pw.x, fp.voxelSize);
+        const int vy = world2voxel1(pw.y, fp.voxelSize);
+        const int vz = world2voxel1(pw.z, fp.voxelSize);
+        const int kx = voxel2block1(vx), ky = voxel2block1(vy), kz = voxel2block1(vz);
+        if (!haveKey || kx != ckx || ky != cky || kz != ckz) {
+            ckx = kx; cky = ky; ckz = kz;
+            cptr = lookup_block(fp, dp, kx, ky, kz);
+            haveKey = true;
+        }
+        if (cptr == VH_FREE_BLOCK) { prevValid = false; continue; }
+        const int lx = (int)((uint32_t)vx - (uint32_t)kx * 8u);
+        const int ly = (int)((uint32_t)vy - (uint32_t)ky * 8u);
+        const int lz = (int)((uint32_t)vz - (uint32_t)kz * 8u);
+        const Voxel s = dp.blocks[(size_t)cptr + (size_t)(lz * 64 + ly * 8 + lx)];
+        if (!(s.weight > 0.0f)) { prevValid = false; continue; }
+        if (prevValid && prevSdf > 0.0f && s.sdf <= 0.0f) {
+            hit = prevT + (dt * prevSdf) / (prevSdf - s.sdf);
+            break;
+        }
+        prevValid = true; prevSdf = s.sdf; prevT = tt;
+    }
+    depthOut[(size_t)v * fp.width + u] = hit;
+}
+
+// ---------------------------------------------------------------------------
+// set-up kernels (deviceAllocate, VoxelUtils.cu:151-166)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reset_table_kernel(VoxelEntry *table, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        VoxelEntry e;
+        e.pos[0] = e.pos[1] = e.pos[2] = VH_POS_SENTINEL;
+        e.ptr = VH_FREE_BLOCK;
+        e.offset = 0;
+        table[i] = e;
+    }
+}
+
+__global__ __launch_bounds__(256) void reset_heap_kernel(uint32_t *heap, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) heap[i] = i;
+}
+
+// debug / known-answer hook: runs the scalar helpers on n points
+__global__ void debug_eval_kernel(const FrameParams fp, const float4 *__restrict__ pts, int n, int32_t *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const int3_ b = world2block(p.x, p.y, p.z, fp.voxelSize);
+    int sx, sy;
+    project(fp.proj, p.x, p.y, p.z, sx, sy);
+    int32_t *o = out + (size_t)i * 8;
+    o[0] = b.x; o[1] = b.y; o[2] = b.z;
+    o[3] = (int32_t)hash_block(b.x, b.y, b.z, fp.numBuckets);
+    o[4] = block_in_frustum(fp, b.x, b.y, b.z) ? 1 : 0;
+    o[5] = sx; o[6] = sy;
+    o[7] = f2i_rz(p.w);
+}
+
+}  // namespace vh

@@ -1,0 +1,187 @@
+"""Host-side mirror of the reference's SDF_Hashtable class (SDF_Hashtable.h:24-42)
+for Python callers: same entry points (integrate, plus raycast standing in for
+SDFRenderer::render), every call going straight through the C-ABI of
+libvoxelhash_hip.so.  torch is used only as the owner of device buffers and of
+the current stream; none of the path's arithmetic is done in torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+ENTRY_DTYPE = np.dtype([("pos", "<i4", (3,)), ("ptr", "<i4"), ("offset", "<i4")])
+VOXEL_DTYPE = np.dtype([("sdf", "<f4"), ("weight", "<f4")])
+
+
+def default_params(**overrides) -> L.HashTableParams:
+    """common.h:39-50 as copied by SDF_Hashtable.cpp:62-73, with overrides."""
+    p = L.HashTableParams()
+    L.load().vh_default_params(C.byref(p))
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _dev_ptr(t) -> int:
+    """Device address of a torch CUDA tensor (or a raw int address)."""
+    if isinstance(t, int):
+        return t
+    if t is None:
+        return 0
+    if not t.is_cuda or not t.is_contiguous():
+        raise ValueError("expected a contiguous CUDA tensor")
+    return t.data_ptr()
+
+
+def _pose16(pose):
+    a = np.ascontiguousarray(np.asarray(pose, dtype=np.float32).reshape(16))
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class SDFHashtable:
+    """One voxel-hash table on one GPU.
+
+    integrate(pose, verts, normals) == SDF_Hashtable::integrate (SDF_Hashtable.cpp:11-40);
+    raycast(pose) stands in for SDFRenderer::render (SDFRenderer.cpp:210-255).
+    """
+
+    def __init__(self, params: L.HashTableParams | None = None, width: int = 640, height: int = 480,
+                 semantics: int = L.SEM_REFERENCE, device: int = -1, bucket_range=None, stream=None):
+        self._lib = L.load()
+        self.params = params if params is not None else default_params()
+        self.width, self.height, self.semantics = width, height, semantics
+        cfg = L.Config(self.params, width, height, semantics, device)
+        h = C.c_void_p()
+        if bucket_range is None:
+            L.check(self._lib.vh_create(C.byref(cfg), C.byref(h)), "vh_create")
+            self.bucket_range = (0, self.params.numBuckets)
+        else:
+            lo, hi = bucket_range
+            L.check(self._lib.vh_create_shard(C.byref(cfg), lo, hi, C.byref(h)), "vh_create_shard")
+            self.bucket_range = (lo, hi)
+        self._h = h
+        if stream is not None:
+            self.set_stream(stream)
+
+    # ---- lifecycle ----
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream):
+        """`stream`: a torch.cuda.Stream, or a raw hipStream_t address."""
+        handle = stream if isinstance(stream, int) else stream.cuda_stream
+        L.check(self._lib.vh_set_stream(self._h, C.c_void_p(handle)), "vh_set_stream")
+
+    def set_projection(self, m):
+        a = np.ascontiguousarray(np.asarray(m, np.float32).reshape(9))
+        L.check(self._lib.vh_set_projection(self._h, a.ctypes.data_as(C.POINTER(C.c_float))), "vh_set_projection")
+
+    def set_raycast_intrinsics(self, fx, fy, cx, cy):
+        L.check(self._lib.vh_set_raycast_intrinsics(self._h, fx, fy, cx, cy), "vh_set_raycast_intrinsics")
+
+    # ---- the hot path ----
+    def integrate(self, pose, verts, normals=None):
+        """Asynchronous: pose -> lock epoch -> allocBlocks -> flatten -> integrateDepthMap."""
+        _, pp = _pose16(pose)
+        L.check(self._lib.vh_integrate(self._h, pp, _dev_ptr(verts), _dev_ptr(normals)), "vh_integrate")
+
+    def raycast(self, pose, out, t_min: float = 0.1, t_max: float = 5.0):
+        _, pp = _pose16(pose)
+        L.check(self._lib.vh_raycast(self._h, pp, t_min, t_max, _dev_ptr(out)), "vh_raycast")
+        return out
+
+    # ---- step-level entry points (VoxelUtils.h:5-13) ----
+    def set_pose(self, pose):
+        _, pp = _pose16(pose)
+        L.check(self._lib.vh_set_pose(self._h, pp), "vh_set_pose")
+
+    def reset_mutexes(self):
+        L.check(self._lib.vh_reset_mutexes(self._h), "vh_reset_mutexes")
+
+    def alloc_blocks(self, verts, normals=None):
+        L.check(self._lib.vh_alloc_blocks(self._h, _dev_ptr(verts), _dev_ptr(normals)), "vh_alloc_blocks")
+
+    def flatten(self, sync: bool = True):
+        if not sync:
+            L.check(self._lib.vh_flatten(self._h, None), "vh_flatten")
+            return None
+        n = C.c_int32()
+        L.check(self._lib.vh_flatten(self._h, C.byref(n)), "vh_flatten")
+        return n.value
+
+    def integrate_depth_map(self, verts):
+        L.check(self._lib.vh_integrate_depth_map(self._h, _dev_ptr(verts)), "vh_integrate_depth_map")
+
+    # ---- sharding ----
+    def generate_keys(self, verts, num_shards: int, keys_out, capacity: int, counts_out):
+        L.check(self._lib.vh_generate_keys(self._h, _dev_ptr(verts), num_shards, _dev_ptr(keys_out), capacity,
+                                           _dev_ptr(counts_out)), "vh_generate_keys")
+
+    def insert_keys(self, keys, count, max_keys: int):
+        L.check(self._lib.vh_insert_keys(self._h, _dev_ptr(keys), _dev_ptr(count), max_keys), "vh_insert_keys")
+
+    # ---- queries ----
+    def synchronize(self):
+        L.check(self._lib.vh_synchronize(self._h), "vh_synchronize")
+
+    def counters(self) -> dict:
+        c = L.Counters()
+        L.check(self._lib.vh_get_counters(self._h, C.byref(c)), "vh_get_counters")
+        return c.as_dict()
+
+    def device_pointers(self) -> L.PtrContainer:
+        p = L.PtrContainer()
+        L.check(self._lib.vh_get_device_pointers(self._h, C.byref(p)), "vh_get_device_pointers")
+        return p
+
+    @property
+    def num_entries(self) -> int:
+        lo, hi = self.bucket_range
+        return (hi - lo) * self.params.bucketSize
+
+    def _download(self, which, dtype, count):
+        out = np.empty(count, dtype)
+        if count:
+            L.check(self._lib.vh_download(self._h, which, out.ctypes.data_as(C.c_void_p), out.nbytes), "vh_download")
+        return out
+
+    def hash_table(self) -> np.ndarray:
+        return self._download(L.BUF_HASH_TABLE, ENTRY_DTYPE, self.num_entries)
+
+    def compact(self) -> np.ndarray:
+        n = self.counters()["occupied"]
+        return self._download(L.BUF_COMPACT, ENTRY_DTYPE, n)
+
+    def sdf_blocks(self) -> np.ndarray:
+        return self._download(L.BUF_SDF_BLOCKS, VOXEL_DTYPE, self.params.numVoxelBlocks * 512)
+
+    def heap(self) -> np.ndarray:
+        return self._download(L.BUF_HEAP, np.dtype("<u4"), self.params.numVoxelBlocks)
+
+    def allocated(self) -> np.ndarray:
+        t = self.hash_table()
+        return t[t["ptr"] != L.FREE_BLOCK]
+
+    def debug_eval(self, points, out):
+        L.check(self._lib.vh_debug_eval(self._h, _dev_ptr(points), points.shape[0], _dev_ptr(out)), "vh_debug_eval")
+
+    def set_profiling(self, on: bool):
+        L.check(self._lib.vh_set_profiling(self._h, int(on)), "vh_set_profiling")
+
+    def kernel_times(self, reset: bool = True) -> dict:
+        t = L.KernelTimes()
+        L.check(self._lib.vh_get_kernel_times(self._h, C.byref(t), int(reset)), "vh_get_kernel_times")
+        return t.as_dict()
