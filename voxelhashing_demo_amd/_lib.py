@@ -127,6 +127,14 @@ def load():
             raise VoxelHashError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  Importing
+        # torch first puts that copy in the process, and the loader then binds this library's
+        # NEEDED libamdhip64.so.7 to it (same SONAME) instead of opening /opt/rocm's second copy,
+        # which would fail to see the GPU.  Without torch the RUNPATH copy (/opt/rocm) is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
