@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the voxel-hashing TSDF path on MI355X (BASELINE.json metric).
+
+A step = one 640x480 depth frame taken through SDF_Hashtable::integrate
+(lock epoch -> allocBlocks -> flattenIntoBuffer -> integrateDepthMap) on the
+synthetic room of config C2; vertex maps and poses are resident in HBM before
+the timed region.  One JSON line on stdout (rank 0).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "C2": dict(width=640, height=480, frames=500, buckets=1 << 20, blocks=1 << 18, voxel=0.02,
+               desc="C2: synthetic 6x3x5 m room, 640x480 x 500-pose camera loop, 2^20 buckets x 5, "
+                    "2^18 voxel blocks, voxel 0.02 m, PINHOLE semantics"),
+    # BASELINE.json configs[2] (HBM-bound stress); selectable with --workload C3
+    "C3": dict(width=1280, height=960, frames=200, buckets=1 << 22, blocks=1 << 21, voxel=0.005,
+               desc="C3: synthetic room, 1280x960, 2^22 buckets x 5, 2^21 voxel blocks, voxel 0.005 m, "
+                    "PINHOLE semantics (200 distinct frames of the 2000-pose path resident)"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=0, help="distinct resident frames (default: workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU sample (0 = auto, about 15 s)")
+    ap.add_argument("--raycast-steps", type=int, default=50)
+    ap.add_argument("--profile-steps", type=int, default=200)
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import voxelhashing_demo_amd as V
+    from voxelhashing_demo_amd import _lib as L
+    from voxelhashing_demo_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    if world > 1:
+        from voxelhashing_demo_amd import dist as vdist
+        return vdist.bench_sharded(args, WORKLOADS[args.workload], rank, world, local_rank)
+
+    wl = WORKLOADS[args.workload]
+    Wd, Ht = wl["width"], wl["height"]
+    nframes = args.frames or wl["frames"]
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.Stream(device=dev)
+
+    # ---- inputs: rendered on the GPU, resident before timing ----
+    poses = synth.camera_loop(wl["frames"])[:nframes]
+    prims = synth.room_primitives()
+    verts = torch.empty((nframes, Ht, Wd, 4), dtype=torch.float32, device=dev)
+    for i in range(nframes):
+        verts[i] = synth.render_room_verts(poses[i], Wd, Ht, prims, device=dev)
+    torch.cuda.synchronize()
+
+    params = V.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
+    table = V.SDFHashtable(params, Wd, Ht, V.SEM_PINHOLE, device=local_rank, stream=stream)
+    lib, h = table._lib, table._h
+    pose_ptrs = [np.ascontiguousarray(p.reshape(16)).ctypes.data_as(C.POINTER(C.c_float)) for p in poses]
+    pose_keep = [np.ascontiguousarray(p.reshape(16)) for p in poses]
+    pose_ptrs = [p.ctypes.data_as(C.POINTER(C.c_float)) for p in pose_keep]
+    vert_ptrs = [verts[i].data_ptr() for i in range(nframes)]
+
+    def step(i):
+        k = i % nframes
+        rc = lib.vh_integrate(h, pose_ptrs[k], vert_ptrs[k], None)
+        if rc != 0:
+            L.check(rc, "vh_integrate")
+
+    for i in range(args.warmup):
+        step(i)
+    table.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    table.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fps = args.steps / elapsed
+    counters = table.counters()
+
+    # ---- per-kernel durations: HIP events on the path's own stream ----
+    nprof = args.profile_steps
+    table.set_profiling(True)
+    occ_sum = 0
+    for i in range(nprof):
+        step(args.warmup + args.steps + i)
+    kt = table.kernel_times(reset=True)
+    table.set_profiling(False)
+    occ = table.counters()["occupied"]
+    n_entries = table.num_entries
+    flatten_us = 1e3 * kt["flatten_ms"] / max(1, kt["launches"])
+    # algorithmic bytes of one flatten launch: one pass over the VoxelEntry
+    # array + the compact entries written
+    flatten_bytes = 20 * n_entries + 20 * occ
+    achieved = flatten_bytes / (flatten_us * 1e-6) / 1e9
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get(args.workload, {}).get("flatten_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel="flatten_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    bytes_per_launch=flatten_bytes, us_per_launch=round(flatten_us, 2))
+    kernels_us = {k[:-3] + "_us": round(1e3 * v / max(1, kt["launches"]), 2)
+                  for k, v in kt.items() if k.endswith("_ms") and k != "raycast_ms"}
+    # algorithmic bytes of the whole frame (SURVEY.md 8(d) B_frame; no mutex memset in this build)
+    keys = occ   # distinct in-frustum block keys of a frame ~ occupied blocks (not counted on the device)
+    b_frame = 16 * Wd * Ht + 4 * Wd * Ht + 20 * n_entries + 20 * occ + occ * (20 + 4096 + 4096) + 100 * keys
+    frame_gbs = b_frame * fps / 1e9
+
+    # ---- raycast Mpix/s (second half of the metric) ----
+    depth = torch.empty((Ht, Wd), dtype=torch.float32, device=dev)
+    dptr = depth.data_ptr()
+    for i in range(5):
+        lib.vh_raycast(h, pose_ptrs[i % nframes], 0.1, 5.0, dptr)
+    table.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.raycast_steps):
+        lib.vh_raycast(h, pose_ptrs[(7 * i) % nframes], 0.1, 5.0, dptr)
+    table.synchronize()
+    ray_s = time.perf_counter() - t1
+    raycast_mpix = args.raycast_steps * Wd * Ht / ray_s / 1e6 if args.raycast_steps else None
+
+    # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
+    cpu = None
+    if not args.no_cpu_baseline:
+        import oracle as O
+        op = O.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
+        ot = O.OracleTable(op, Wd, Ht, O.SEM_PINHOLE)
+        budget_s, nmax = 15.0, args.cpu_frames or 10 ** 9
+        done, spent = 0, 0.0
+        while done < nmax and (args.cpu_frames or spent < budget_s) and done < 5000:
+            k = done % nframes
+            v = verts[k].cpu().numpy()
+            c0 = time.perf_counter()
+            ot.integrate(poses[k], v)
+            spent += time.perf_counter() - c0
+            done += 1
+        cpu = dict(value=round(done / spent, 3), unit="frames/s", cores=1, kind="port",
+                   sample=f"first {done} frames of the same {args.workload} sequence, oracle/vh_oracle.c "
+                          f"(gcc -O2 -ffp-contract=off), 1 thread of {os.cpu_count()} host cores")
+        ot.close()
+
+    out = dict(
+        metric="frames/s TSDF-integrated, 640x480" if args.workload == "C2" else f"frames/s TSDF-integrated, {Wd}x{Ht}",
+        value=round(fps, 1), unit="frames/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
+        ms_per_step=round(1e3 * elapsed / args.steps, 5), higher_is_better=True, scaling="weak",
+        vs_baseline=None, dtype="f32", data="synthetic",
+        config=dict(workload=wl["desc"], resident_frames=nframes, semantics="pinhole",
+                    occupied_blocks=occ, allocated_blocks=counters["allocated_total"],
+                    keys_last_frame=keys),
+        roofline=roofline, cpu_baseline=cpu,
+        raycast_mpix_per_s=round(raycast_mpix, 1) if raycast_mpix else None,
+        kernels=kernels_us,
+        frame_algorithmic_bytes=b_frame, frame_algorithmic_gbs=round(frame_gbs, 1),
+        frame_frac_of_hbm_peak=round(frame_gbs / HBM_PEAK_GBS, 4),
+    )
+    print(json.dumps(out))
+    table.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,7 @@ SIGNATURES = {
     "vh_get_device_pointers": (C.c_int, [_vp, C.POINTER(PtrContainer)]),
     "vh_download": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
     "vh_debug_eval": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "vh_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "vh_set_profiling": (C.c_int, [_vp, C.c_int]),
     "vh_get_kernel_times": (C.c_int, [_vp, C.POINTER(KernelTimes), C.c_int]),
     "vh_create_shard": (C.c_int, [C.POINTER(Config), _u32, _u32, C.POINTER(_vp)]),

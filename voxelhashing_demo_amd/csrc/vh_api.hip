@@ -2,6 +2,7 @@
 // lifecycle, per-frame orchestration (SDF_Hashtable.cpp:11-40 without its four
 // device syncs and two D2H reads), and the reference's drop-in names.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -39,8 +40,15 @@ static int fail(int code, const char *what, hipError_t e = hipSuccess)
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
-struct PhaseEvents {
-    hipEvent_t ev[5];   // before claim, after claim, after commit, after flatten, after integrate
+// Profiling attaches a start/stop event pair to each dispatch (hipExtLaunchKernelGGL):
+// the pair carries the begin/end timestamps of that kernel alone, the same
+// quantity rocprofv3 --kernel-trace reports, without the inter-kernel gaps a
+// hipEventRecord pair would add.
+enum Phase : int { kPhaseClaim = 0, kPhaseCommit, kPhaseFlatten, kPhaseIntegrate, kPhaseRaycast, kNumPhases };
+
+struct TimedLaunch {
+    int phase;
+    hipEvent_t start, stop;
 };
 
 struct vh_context {
@@ -53,10 +61,11 @@ struct vh_context {
     uint32_t ownedBuckets = 0;
     float rc_fx = 0, rc_fy = 0, rc_cx = 0, rc_cy = 0;
     bool profiling = false;
-    std::vector<PhaseEvents> frameEvents;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> raycastEvents;
+    std::vector<TimedLaunch> timed;
+    uint64_t profiledFrames = 0;
     vh_kernel_times times{};
     int integrateGrid = 2048;
+    int flattenVariant = 1;        // 0: non-temporal ptr loads, 1: plain loads (measured 7 % faster, C2)
 };
 
 struct DeviceGuard {
@@ -296,11 +305,8 @@ extern "C" int vh_create_shard(const vh_config *cfg, uint32_t lo, uint32_t hi, v
 
 static void drop_events(vh_context *c)
 {
-    for (auto &f : c->frameEvents)
-        for (auto &ev : f.ev) (void)hipEventDestroy(ev);
-    c->frameEvents.clear();
-    for (auto &p : c->raycastEvents) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    c->raycastEvents.clear();
+    for (auto &t : c->timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
+    c->timed.clear();
 }
 
 extern "C" int vh_destroy(vh_context *c)
@@ -366,31 +372,45 @@ extern "C" int vh_reset_mutexes(vh_context *c)
 
 static inline int grid_for(size_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
 
-static int launch_alloc(vh_context *c, const vh_float4 *verts, PhaseEvents *pe)
+template <typename K, typename... Args>
+static int launch(vh_context *c, int phase, K kernel, dim3 grid, dim3 block, Args... args)
+{
+    if (!c->profiling) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, args...);
+        return VH_OK;
+    }
+    TimedLaunch t{phase, nullptr, nullptr};
+    VH_HIP(hipEventCreate(&t.start));
+    VH_HIP(hipEventCreate(&t.stop));
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, c->stream, t.start, t.stop, 0, args...);
+    c->timed.push_back(t);
+    return VH_OK;
+}
+
+static int launch_alloc(vh_context *c, const vh_float4 *verts)
 {
     const int npix = c->fp.width * c->fp.height;
-    if (pe) VH_HIP(hipEventRecord(pe->ev[0], c->stream));
-    alloc_claim_kernel<false><<<grid_for(npix, 256), 256, 0, c->stream>>>(
-        c->fp, c->dp, reinterpret_cast<const float4 *>(verts), 1, nullptr, 0, nullptr, 0u);
-    if (pe) VH_HIP(hipEventRecord(pe->ev[1], c->stream));
-    alloc_commit_kernel<<<32, 256, 0, c->stream>>>(c->fp, c->dp);
-    if (pe) VH_HIP(hipEventRecord(pe->ev[2], c->stream));
-    return VH_OK;
+    int rc = launch(c, kPhaseClaim, alloc_claim_kernel<false>, dim3(grid_for(npix, 256)), dim3(256), c->fp, c->dp,
+                    reinterpret_cast<const float4 *>(verts), (int32_t)1, (int4 *)nullptr, (int32_t)0,
+                    (int32_t *)nullptr, 0u);
+    if (rc != VH_OK) return rc;
+    return launch(c, kPhaseCommit, alloc_commit_kernel, dim3(32), dim3(256), c->fp, c->dp);
 }
 
-static int launch_flatten(vh_context *c, PhaseEvents *pe)
+static int launch_flatten(vh_context *c)
 {
-    flatten_kernel<<<grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane), kFlattenThreads, 0, c->stream>>>(
-        c->fp, c->dp, (uint32_t)c->numEntries);
-    if (pe) VH_HIP(hipEventRecord(pe->ev[3], c->stream));
-    return VH_OK;
+    const dim3 grid(grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane));
+    if (c->flattenVariant == 1)
+        return launch(c, kPhaseFlatten, flatten_kernel<false>, grid, dim3(kFlattenThreads), c->fp, c->dp,
+                      (uint32_t)c->numEntries);
+    return launch(c, kPhaseFlatten, flatten_kernel<true>, grid, dim3(kFlattenThreads), c->fp, c->dp,
+                  (uint32_t)c->numEntries);
 }
 
-static int launch_integrate(vh_context *c, const vh_float4 *verts, PhaseEvents *pe)
+static int launch_integrate(vh_context *c, const vh_float4 *verts)
 {
-    integrate_kernel<<<c->integrateGrid, 256, 0, c->stream>>>(c->fp, c->dp, reinterpret_cast<const float4 *>(verts));
-    if (pe) VH_HIP(hipEventRecord(pe->ev[4], c->stream));
-    return VH_OK;
+    return launch(c, kPhaseIntegrate, integrate_kernel, dim3(c->integrateGrid), dim3(256), c->fp, c->dp,
+                  reinterpret_cast<const float4 *>(verts));
 }
 
 extern "C" int vh_alloc_blocks(vh_context *c, const vh_float4 *verts, const vh_float4 *normals)
@@ -399,7 +419,7 @@ extern "C" int vh_alloc_blocks(vh_context *c, const vh_float4 *verts, const vh_f
     if (!c || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     if (c->fp.epoch == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
     DeviceGuard guard(c->device);
-    int rc = launch_alloc(c, verts, nullptr);
+    int rc = launch_alloc(c, verts);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -410,7 +430,7 @@ extern "C" int vh_flatten(vh_context *c, int32_t *occupied_out)
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     DeviceGuard guard(c->device);
     VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));   // :760
-    int rc = launch_flatten(c, nullptr);
+    int rc = launch_flatten(c);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     if (occupied_out) {
@@ -427,7 +447,7 @@ extern "C" int vh_integrate_depth_map(vh_context *c, const vh_float4 *verts)
 {
     if (!c || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(c->device);
-    int rc = launch_integrate(c, verts, nullptr);
+    int rc = launch_integrate(c, verts);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -441,17 +461,11 @@ extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4
     int rc = vh_set_pose(c, pose);
     if (rc == VH_OK) rc = vh_reset_mutexes(c);
     if (rc != VH_OK) return rc;
-    PhaseEvents *pe = nullptr;
-    if (c->profiling) {
-        PhaseEvents f;
-        for (auto &ev : f.ev) VH_HIP(hipEventCreate(&ev));
-        c->frameEvents.push_back(f);
-        pe = &c->frameEvents.back();
-    }
     // alloc_commit re-arms the compact counter, so no memset node is needed here
-    if ((rc = launch_alloc(c, verts, pe)) != VH_OK) return rc;
-    if ((rc = launch_flatten(c, pe)) != VH_OK) return rc;
-    if ((rc = launch_integrate(c, verts, pe)) != VH_OK) return rc;
+    if ((rc = launch_alloc(c, verts)) != VH_OK) return rc;
+    if ((rc = launch_flatten(c)) != VH_OK) return rc;
+    if ((rc = launch_integrate(c, verts)) != VH_OK) return rc;
+    if (c->profiling) c->profiledFrames += 1;
     VH_HIP(hipGetLastError());
     return VH_OK;
 }
@@ -467,18 +481,9 @@ extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, floa
     int nsteps = (q >= 2147483648.0f) ? 0x7fffffff : (int)q;
     nsteps += 1;
     dim3 grid((fp.width + 15) / 16, (fp.height + 15) / 16);
-    std::pair<hipEvent_t, hipEvent_t> evs{};
-    if (c->profiling) {
-        VH_HIP(hipEventCreate(&evs.first));
-        VH_HIP(hipEventCreate(&evs.second));
-        VH_HIP(hipEventRecord(evs.first, c->stream));
-    }
-    raycast_kernel<<<grid, 256, 0, c->stream>>>(fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx, c->rc_cy, t_min, nsteps,
-                                                 d_depth_out);
-    if (c->profiling) {
-        VH_HIP(hipEventRecord(evs.second, c->stream));
-        c->raycastEvents.push_back(evs);
-    }
+    int rc = launch(c, kPhaseRaycast, raycast_kernel, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx, c->rc_cy,
+                    t_min, nsteps, d_depth_out);
+    if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
 }
@@ -583,6 +588,14 @@ extern "C" int vh_download(vh_context *c, int which, void *dst, size_t bytes)
     return VH_OK;
 }
 
+extern "C" int vh_set_option(vh_context *c, const char *name, int value)
+{
+    if (!c || !name) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (std::strcmp(name, "flatten_variant") == 0) { c->flattenVariant = value; return VH_OK; }
+    if (std::strcmp(name, "integrate_grid") == 0 && value > 0) { c->integrateGrid = value; return VH_OK; }
+    return fail(VH_ERR_INVALID_ARGUMENT, "unknown option");
+}
+
 extern "C" int vh_set_profiling(vh_context *c, int enabled)
 {
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
@@ -595,21 +608,20 @@ extern "C" int vh_get_kernel_times(vh_context *c, vh_kernel_times *out, int rese
     if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(c->device);
     VH_HIP(hipStreamSynchronize(c->stream));
-    for (auto &f : c->frameEvents) {
-        float ms[4] = {0, 0, 0, 0};
-        for (int k = 0; k < 4; ++k) VH_HIP(hipEventElapsedTime(&ms[k], f.ev[k], f.ev[k + 1]));
-        c->times.alloc_claim_ms += ms[0];
-        c->times.alloc_commit_ms += ms[1];
-        c->times.flatten_ms += ms[2];
-        c->times.integrate_ms += ms[3];
-        c->times.launches += 1;
-    }
-    for (auto &p : c->raycastEvents) {
+    for (auto &t : c->timed) {
         float ms = 0;
-        VH_HIP(hipEventElapsedTime(&ms, p.first, p.second));
-        c->times.raycast_ms += ms;
-        c->times.raycast_launches += 1;
+        VH_HIP(hipEventElapsedTime(&ms, t.start, t.stop));
+        switch (t.phase) {
+            case kPhaseClaim: c->times.alloc_claim_ms += ms; break;
+            case kPhaseCommit: c->times.alloc_commit_ms += ms; break;
+            case kPhaseFlatten: c->times.flatten_ms += ms; break;
+            case kPhaseIntegrate: c->times.integrate_ms += ms; break;
+            case kPhaseRaycast: c->times.raycast_ms += ms; c->times.raycast_launches += 1; break;
+            default: break;
+        }
     }
+    c->times.launches += c->profiledFrames;
+    c->profiledFrames = 0;
     drop_events(c);
     *out = c->times;
     if (reset) c->times = vh_kernel_times{};

@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void alloc_commit_kernel(const FrameParams fp,
 constexpr int kFlattenThreads = 256;
 constexpr int kEntriesPerLane = 8;
 
+template <bool kNonTemporal>
 __global__ __launch_bounds__(kFlattenThreads) void flatten_kernel(const FrameParams fp, const DevPtrs dp,
                                                                   uint32_t numEntries)
 {
@@ -188,7 +189,9 @@ __global__ __launch_bounds__(kFlattenThreads) void flatten_kernel(const FramePar
 #pragma unroll
     for (int j = 0; j < kEntriesPerLane; ++j) {
         const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
-        ptrs[j] = (e < numEntries) ? __builtin_nontemporal_load(words + (size_t)e * kEntryDwords + 3) : VH_FREE_BLOCK;
+        const int32_t *w = words + (size_t)e * kEntryDwords + 3;
+        if (e >= numEntries) ptrs[j] = VH_FREE_BLOCK;
+        else ptrs[j] = kNonTemporal ? __builtin_nontemporal_load(w) : *w;
     }
     bool any = false;
 #pragma unroll

@@ -178,6 +178,9 @@ class SDFHashtable:
     def debug_eval(self, points, out):
         L.check(self._lib.vh_debug_eval(self._h, _dev_ptr(points), points.shape[0], _dev_ptr(out)), "vh_debug_eval")
 
+    def set_option(self, name: str, value: int):
+        L.check(self._lib.vh_set_option(self._h, name.encode(), int(value)), "vh_set_option")
+
     def set_profiling(self, on: bool):
         L.check(self._lib.vh_set_profiling(self._h, int(on)), "vh_set_profiling")
 
