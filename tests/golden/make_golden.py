@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory from the CPU oracle.
+
+The reference has no tests, golden vectors or runnable build, so
+these vectors are SELF-PINNED: produced by oracle/vh_oracle.c, whose agreement with the
+reference is anchored separately by tests/test_oracle_anchors.py (survey probe values).
+They freeze the oracle's behaviour and give the HIP path a committed target.
+
+  python tests/golden/make_golden.py      (rewrites kat_scalars.json and scenes.npz)
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import oracle as O  # noqa: E402
+from voxelhashing_demo_amd import synth  # noqa: E402
+
+NB = 1 << 17
+I4 = np.eye(4, dtype=np.float32)
+
+
+def scalar_kats():
+    rng = np.random.RandomState(11)
+    keys = [(2, 0, 8), (-6, -5, 10), (0, 0, 0), (-1, -1, -1), (2 ** 31 - 1, -2 ** 31, 12345)]
+    keys += [tuple(int(v) for v in rng.randint(-200, 200, 3)) for _ in range(20)]
+    hashes = [dict(key=k, buckets=nb, hash=O.hash_block(*k, nb)) for k in keys for nb in (5000, NB, 1 << 20)]
+    vs = float(np.float32(0.02))
+    pts = [(-0.31, 0.0, 0.009), (0.01, -0.01, 0.03), (-0.0, 0.0, 1e-30), (0.15, 0.16, 0.17), (-0.15, -0.16, -0.17),
+           (1e12, -1e12, float("nan")), (float("inf"), float("-inf"), 5.0)]
+    pts += [tuple(float(np.float32(v)) for v in rng.uniform(-4, 4, 3)) for _ in range(20)]
+    w2v = [dict(p=[repr(float(np.float32(c))) for c in p], voxel=O.world2voxel(p, vs), block=O.world2block(p, vs))
+           for p in pts]
+    v2b = [dict(v=v, block=O.voxel2block(v)) for v in [(-1, -8, -9), (0, 7, 8), (-2 ** 31, 2 ** 31 - 1, -7)]
+           + [tuple(int(c) for c in rng.randint(-100, 100, 3)) for _ in range(10)]]
+    f2i = [dict(x=repr(x), i=O.float2int_rz(x)) for x in
+           [0.0, -0.0, 2.9, -2.9, 3e9, -3e9, float("inf"), float("-inf"), float("nan"), 2147483520.0, -2147483648.0]]
+    mats = [synth.yaw_pose(5.0, (0.1, 0.0, 0.05)), synth.yaw_pose(-33.0, (1.0, -0.5, 2.0)), synth.camera_loop(500)[123]]
+    inv = [dict(m=[repr(float(c)) for c in m.reshape(-1)], inv_bits=[int(b) for b in O.invert4x4(m).reshape(-1).view(np.uint32)])
+           for m in mats]
+    KT, K = synth.K_matrix(transposed=True), synth.K_matrix()
+    proj = [dict(p=[repr(float(np.float32(c))) for c in p], kt=O.project(KT, p), k=O.project(K, p))
+            for p in [(0.3, -0.2, 1.7), (0.0, 0.0, 0.0), (-1.0, 0.5, 0.01), (2.0, 2.0, -1.0)] +
+            [tuple(rng.uniform(-2, 2, 3)) for _ in range(10)]]
+    return dict(hash=hashes, world2voxel=w2v, voxel2block=v2b, float2int_rz=f2i, invert4x4=inv, project=proj)
+
+
+def digest_scene(t):
+    """Order-independent summary of a table: allocated positions (sorted, with their slot),
+    compact positions, SHA-256 over the voxel bits of all blocks in position order."""
+    tab = t.hash_table()
+    alloc_idx = np.nonzero(tab["ptr"] != -1)[0]
+    pos = tab["pos"][alloc_idx]
+    order = np.lexsort((pos[:, 2], pos[:, 1], pos[:, 0]))
+    pos, slots = pos[order], alloc_idx[order]
+    vol = t.sdf_blocks()
+    h = hashlib.sha256()
+    for i in order:
+        p = int(tab["ptr"][alloc_idx[i]])
+        h.update(vol[p:p + 512].tobytes())
+    comp = t.compact()["pos"]
+    comp = comp[np.lexsort((comp[:, 2], comp[:, 1], comp[:, 0]))] if len(comp) else comp.reshape(0, 3)
+    first = int(tab["ptr"][alloc_idx[order[0]]]) if len(order) else 0
+    return dict(pos=pos.astype(np.int32), slots=slots.astype(np.int64), compact=comp.astype(np.int32),
+                sha=np.frombuffer(h.digest(), np.uint8), block0=vol[first:first + 512].copy().view(np.uint32).reshape(-1))
+
+
+SCENES = {
+    # name: (semantics, pose, scene, frames, overrides)
+    "inside_ref_f1": (0, I4, "inside", 1, {}),
+    "inside_ref_f2": (0, I4, "inside", 2, {}),
+    "outside_ref_f2": (0, I4, "outside", 2, {}),
+    "inside_pin_f2": (1, I4, "inside", 2, {}),
+    "outside_pin_f2": (1, I4, "outside", 2, {}),
+    "inside_ref_pose_f2": (0, synth.yaw_pose(5.0, (0.1, 0.0, 0.05)), "inside", 2, {}),
+    "inside_pin_pose_f2": (1, synth.yaw_pose(5.0, (0.1, 0.0, 0.05)), "inside", 2, {}),
+    "collision_64x2_f4": (1, I4, "inside", 4, dict(numBuckets=64, bucketSize=2, numVoxelBlocks=256)),
+    "saturate_f10": (1, I4, "inside", 10, dict(integrationWeightMax=0.55)),
+}
+
+
+def run_scene(name, table_factory):
+    sem, pose, scene, frames, over = SCENES[name]
+    kw = dict(numBuckets=NB, numVoxelBlocks=4096)
+    kw.update(over)
+    verts = synth.sphere_inside_scene() if scene == "inside" else synth.sphere_outside_scene()
+    t = table_factory(kw, sem)
+    for _ in range(frames):
+        t.integrate_np(pose, verts)
+    return t
+
+
+def main():
+    json.dump(scalar_kats(), open(os.path.join(HERE, "kat_scalars.json"), "w"), indent=0)
+    out = {}
+
+    class OT(O.OracleTable):
+        def integrate_np(self, pose, verts):
+            self.integrate(pose, verts)
+
+    for name in SCENES:
+        t = run_scene(name, lambda kw, sem: OT(O.default_params(**kw), 640, 480, sem))
+        for k, v in digest_scene(t).items():
+            out[f"{name}/{k}"] = v
+        if name == "inside_pin_f2":
+            d = t.raycast(I4, 0.1, 5.0)
+            out["raycast_inside_pin_f2/sha"] = np.frombuffer(hashlib.sha256(d.tobytes()).digest(), np.uint8)
+            out["raycast_inside_pin_f2/row240"] = d[240].view(np.uint32)
+        t.close()
+    np.savez_compressed(os.path.join(HERE, "scenes.npz"), **out)
+    print("wrote", os.path.getsize(os.path.join(HERE, "scenes.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""The drop-in boundary without a GPU: libvoxelhash_hip.so loads, exports every function
+include/voxelhash.h declares, keeps the reference's record layouts, and fails loudly
+(no CPU fallback) when no device is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "voxelhash.h")
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b(\w+)\s*\([^;{]*\)\s*;", src, flags=re.M)
+    return sorted(set(n for n in names if n not in ("defined",)))
+
+
+def test_header_declares_the_reference_names():
+    names = declared_functions()
+    # VoxelUtils.h:5-13 (mapGLobjectsToCUDApointers intentionally absent: no GL interop)
+    for n in ("updateConstantHashTableParams", "deviceAllocate", "deviceFree", "resetHashTableMutexes",
+              "allocBlocks", "flattenIntoBuffer", "calculateKinectProjectionMatrix", "integrateDepthMap"):
+        assert n in names
+    for n in ("vh_create", "vh_integrate", "vh_raycast", "vh_generate_keys", "vh_insert_keys"):
+        assert n in names
+    assert len(names) >= 35
+
+
+def test_library_exports_every_declared_symbol(vh):
+    from voxelhashing_demo_amd import _lib
+    L = C.CDLL(_lib.LIB_PATH)
+    missing = [n for n in declared_functions() if not hasattr(L, n)]
+    assert not missing, f"declared in voxelhash.h but not exported: {missing}"
+    # and the Python binding covers the same set
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+
+
+def test_record_layouts(vh):
+    from voxelhashing_demo_amd import _lib
+    assert C.sizeof(_lib.HashTableParams) == 176            # VoxelDataStructures.h:29-52
+    assert vh.ENTRY_DTYPE.itemsize == 20                    # :20-26, pos@0 ptr@12 offset@16
+    assert vh.ENTRY_DTYPE.fields["ptr"][1] == 12 and vh.ENTRY_DTYPE.fields["offset"][1] == 16
+    assert vh.VOXEL_DTYPE.itemsize == 8                     # :12-17
+    assert _lib.HashTableParams.numBuckets.offset == 128 and _lib.HashTableParams.integrationWeightMax.offset == 172
+
+
+def test_default_params_are_common_h(vh):
+    p = vh.default_params()
+    assert (p.numBuckets, p.bucketSize, p.attachedLinkedListSize, p.numVoxelBlocks) == (5000, 5, 4, 1000)
+    assert p.voxelBlockSize == 8 and p.numOccupiedBlocks == 0 and p.integrationWeightSample == 10
+    assert p.voxelSize == pytest.approx(0.02) and p.truncation == 1.0 and p.integrationWeightMax == 255.0
+    assert list(p.global_transform) == [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+
+
+def test_error_strings_and_argument_checks(vh):
+    L = vh.load()
+    assert L.vh_error_string(0) == b"ok"
+    assert b"device" in L.vh_error_string(2)
+    h = C.c_void_p()
+    assert L.vh_create(None, C.byref(h)) == 1              # VH_ERR_INVALID_ARGUMENT
+    assert L.vh_destroy(None) == 0
+    assert L.vh_integrate(None, None, None, None) == 1
+    assert L.vh_default_context() is None
+
+
+def test_fails_loudly_without_a_gpu(vh):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert vh.load().vh_device_count() == 0
+    with pytest.raises(vh.VoxelHashError, match="no usable HIP device"):
+        vh.SDFHashtable(vh.default_params())
+
+
+def test_facade_library_links(vh):
+    from voxelhashing_demo_amd import _lib
+    assert os.path.exists(_lib.FACADE_PATH)
+    # C++ class of include/SDF_Hashtable.h: the mangled members must be there
+    import subprocess
+    syms = subprocess.run(["nm", "-DC", _lib.FACADE_PATH], capture_output=True, text=True).stdout
+    for s in ("SDF_Hashtable::SDF_Hashtable()", "SDF_Hashtable::integrate(float4x4 const&, vh_float4 const*, vh_float4 const*)",
+              "SDF_Hashtable::raycast(float4x4 const&, float*, float, float)", "SDF_Hashtable::~SDF_Hashtable()"):
+        assert s in syms, s
