@@ -120,6 +120,7 @@ typedef struct vh_counters {
     uint32_t heap_exhausted;    /* insertions refused because the heap was empty */
     uint32_t candidates;        /* contenders recorded by the last allocBlocks */
     uint32_t epoch;             /* bucket-lock epoch (= frames since creation) */
+    uint32_t bin_overflow;      /* received key bins that exceeded their capacity (keys lost) */
 } vh_counters;
 
 /* per-kernel device time, accumulated while profiling is on (HIP events on
@@ -204,20 +205,34 @@ int vh_get_kernel_times(vh_context *ctx, vh_kernel_times *out, int reset);  /* s
 
 /* ---- bucket-range sharding (multi-GPU; DESIGN.md "sharding") ---- */
 
+/* A "multi-camera frame" generalises SDF_Hashtable::integrate to R cameras whose
+ * frames enter one logical table together: one lock epoch, all cameras'
+ * allocations first (camera order, then launch order, decides who wins a
+ * bucket), then flatten + TSDF update camera by camera.  With R = 1 it is the
+ * reference's integrate().  The table is cut into bucket ranges, one per GPU. */
+#define VH_MAX_CAMERAS 32
+#define VH_PACKET_HEADER_FLOATS 32   /* camera packet: pose[16], inverse[16], then W*H camera-z */
+
 /* Restrict this context to the buckets [lo, hi) of a logical table of
  * params.numBuckets buckets; only those buckets' storage is allocated. */
 int vh_create_shard(const vh_config *cfg, uint32_t bucket_lo, uint32_t bucket_hi,
                     vh_context **out);
-/* Per pixel: block key of the surface point, frustum-tested and de-duplicated
- * per wavefront.  Appends {x,y,z,rank} int4 records, binned by owning shard
- * (owner = hash / buckets_per_shard), into d_keys[shard * capacity + i] and
- * the per-shard counts into d_counts[num_shards]. */
-int vh_generate_keys(vh_context *ctx, const vh_float4 *d_verts, int32_t num_shards,
-                     int32_t *d_keys, int32_t capacity, int32_t *d_counts);
-/* Insert n {x,y,z,rank} records (n read from *d_count on the device) into this
- * shard with the same one-winner-per-bucket-per-epoch rule. */
-int vh_insert_keys(vh_context *ctx, const int32_t *d_keys, const int32_t *d_count,
-                   int32_t max_keys);
+/* Key generation half of allocBlocks for the pose set with vh_set_pose: per valid
+ * pixel the block key of the surface point, frustum-tested, runs of equal keys
+ * collapsed per wavefront.  Records are int4 {x,y,z,rank}, rank = camera_id<<24 |
+ * launch rank, binned by owning shard (owner = hash / ceil(numBuckets/num_shards)):
+ * bin s = d_bins[s*capacity*4 ...], record 0 = {count,0,0,0}, records 1..count the
+ * keys (count > capacity-1 = overflow).  d_packet (nullable) receives the camera
+ * packet: pose, inverse pose, camera-z plane (VH_PACKET_HEADER_FLOATS + W*H floats). */
+int vh_generate_keys(vh_context *ctx, const vh_float4 *d_verts, uint32_t camera_id,
+                     int32_t num_shards, int32_t *d_bins, int32_t capacity, float *d_packet);
+/* Insert the keys of num_bins received bins (same layout, contiguous) into this
+ * shard under the current lock epoch (call vh_reset_mutexes first). */
+int vh_insert_bins(vh_context *ctx, const int32_t *d_bins, int32_t num_bins, int32_t capacity);
+/* flatten + TSDF update of this shard for num_cams camera packets (contiguous,
+ * camera order): one walk over the shard's entries for all cameras, then one
+ * pass per visible block applying the cameras that see it in order. */
+int vh_integrate_packets(vh_context *ctx, int32_t num_cams, const float *d_packets);
 
 /* ------------------------------------------------------------------ */
 /* drop-in names (VoxelUtils.h:5-13); process-global default context    */

@@ -115,6 +115,15 @@ def lib():
         L.vho_block_in_frustum.restype = C.c_int
         L.vho_launch_rank.argtypes = [C.c_int, C.c_int, C.c_int]
         L.vho_launch_rank.restype = C.c_uint32
+        L.vho_create_shard.restype = C.c_void_p
+        L.vho_create_shard.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32]
+        L.vho_generate_keys.argtypes = [C.c_void_p, fp, C.c_uint32, C.c_int, ip, C.c_int]
+        L.vho_generate_keys.restype = C.c_int
+        L.vho_insert_bins.argtypes = [C.c_void_p, ip, C.c_int, C.c_int]
+        L.vho_insert_bins.restype = C.c_int
+        L.vho_write_packet.argtypes = [C.c_void_p, fp, fp]
+        L.vho_integrate_packets.argtypes = [C.c_void_p, C.c_int, fp]
+        L.vho_integrate_packets.restype = C.c_int
         _lib = L
     return _lib
 
@@ -187,13 +196,56 @@ class OracleTable:
     """Scalar CPU mirror of SDF_Hashtable (SDF_Hashtable.h:24-42)."""
 
     def __init__(self, params: Params | None = None, width: int = 640, height: int = 480,
-                 semantics: int = SEM_REFERENCE):
+                 semantics: int = SEM_REFERENCE, bucket_range=None):
         self.params = params if params is not None else default_params()
         self.width, self.height, self.semantics = width, height, semantics
-        self._h = lib().vho_create(C.byref(self.params), width, height, semantics)
+        self.bucket_range = tuple(bucket_range) if bucket_range else (0, self.params.numBuckets)
+        self._h = lib().vho_create_shard(C.byref(self.params), width, height, semantics, *self.bucket_range)
         if not self._h:
             raise MemoryError("vho_create failed")
         self.last_stats = None
+
+    # ---- step-level entry points ----
+    def set_pose(self, pose):
+        pose = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
+        lib().vho_set_pose(self._h, _fptr(pose))
+
+    def reset_mutexes(self):
+        lib().vho_reset_mutexes(self._h)
+
+    def alloc_blocks(self, verts):
+        lib().vho_alloc_blocks(self._h, _fptr(np.ascontiguousarray(verts, np.float32)))
+
+    def flatten(self) -> int:
+        return int(lib().vho_flatten(self._h))
+
+    def integrate_depth_map(self, verts):
+        lib().vho_integrate_depth_map(self._h, _fptr(np.ascontiguousarray(verts, np.float32)))
+
+    # ---- bucket-range sharding (build extension) ----
+    def packet_floats(self) -> int:
+        return 32 + self.width * self.height
+
+    def generate_keys(self, verts, camera_id: int, num_shards: int, capacity: int):
+        """(bins [num_shards, capacity, 4] int32, packet float32) for the pose set with set_pose()."""
+        verts = np.ascontiguousarray(verts, np.float32)
+        bins = np.zeros((num_shards, capacity, 4), np.int32)
+        worst = lib().vho_generate_keys(self._h, _fptr(verts), camera_id, num_shards,
+                                        bins.ctypes.data_as(C.POINTER(C.c_int32)), capacity)
+        if worst > capacity - 1:
+            raise OverflowError(f"key bin overflow: {worst} keys, capacity {capacity - 1}")
+        packet = np.empty(self.packet_floats(), np.float32)
+        lib().vho_write_packet(self._h, _fptr(verts), _fptr(packet))
+        return bins, packet
+
+    def insert_bins(self, bins) -> int:
+        bins = np.ascontiguousarray(bins, np.int32)
+        return int(lib().vho_insert_bins(self._h, bins.ctypes.data_as(C.POINTER(C.c_int32)), bins.shape[0],
+                                         bins.shape[1]))
+
+    def integrate_packets(self, packets) -> int:
+        packets = np.ascontiguousarray(packets, np.float32).reshape(-1, self.packet_floats())
+        return int(lib().vho_integrate_packets(self._h, packets.shape[0], _fptr(packets)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -231,7 +283,8 @@ class OracleTable:
 
     # ---- views into the oracle's memory (copy before the table is destroyed) ----
     def _n_entries(self):
-        return self.params.numBuckets * self.params.bucketSize
+        lo, hi = self.bucket_range
+        return (hi - lo) * self.params.bucketSize
 
     def hash_table(self) -> np.ndarray:
         n = self._n_entries()

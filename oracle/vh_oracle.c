@@ -23,6 +23,7 @@ struct vho_table {
     int   width, height, semantics;
     float proj[9];                 /* "kinectProjectionMatrix", VoxelUtils.cu:24 */
     float rc_fx, rc_fy, rc_cx, rc_cy;
+    uint32_t bucket_lo, bucket_hi;  /* this table owns buckets [lo, hi) of the logical table */
 
     uint32_t  *heap;               /* PtrContainer, VoxelDataStructures.h:54-63 */
     vho_entry *table;
@@ -254,18 +255,30 @@ static void reset_entries(vho_entry *e, size_t n)   /* resetHashTableKernel, :15
  * SDFRenderer.cpp:34-61) are owned here and zero-initialised. */
 vho_table *vho_create(const vho_params *p, int width, int height, int semantics)
 {
+    return vho_create_shard(p, width, height, semantics, 0, p->numBuckets);
+}
+
+/* A shard owns the buckets [lo, hi) of a logical table of numBuckets buckets
+ * (build extension for multi-GPU); keys that hash outside
+ * the range are ignored by insert / lookup. */
+vho_table *vho_create_shard(const vho_params *p, int width, int height, int semantics,
+                            uint32_t lo, uint32_t hi)
+{
     if (p->voxelBlockSize != 8 || p->numBuckets == 0 || p->bucketSize == 0) return NULL;
+    if (lo >= hi || hi > p->numBuckets) return NULL;
     vho_table *t = (vho_table *)calloc(1, sizeof *t);
     if (!t) return NULL;
     t->p = *p;
     t->width = width;
     t->height = height;
     t->semantics = semantics;
-    size_t n = (size_t)p->numBuckets * p->bucketSize;
+    t->bucket_lo = lo;
+    t->bucket_hi = hi;
+    size_t n = (size_t)(hi - lo) * p->bucketSize;
     t->heap    = (uint32_t *)malloc(sizeof(uint32_t) * p->numVoxelBlocks);
     t->table   = (vho_entry *)malloc(sizeof(vho_entry) * n);
     t->compact = (vho_entry *)malloc(sizeof(vho_entry) * n);
-    t->mutex   = (int32_t *)calloc(p->numBuckets, sizeof(int32_t));
+    t->mutex   = (int32_t *)calloc(hi - lo, sizeof(int32_t));
     t->blocks  = (vho_voxel *)calloc((size_t)p->numVoxelBlocks * 512, sizeof(vho_voxel));
     if (!t->heap || !t->table || !t->compact || !t->mutex || !t->blocks) {
         vho_destroy(t);
@@ -317,7 +330,7 @@ void vho_set_pose(vho_table *t, const float pose[16])
 /* resetHashTableMutexes, VoxelUtils.cu:146-149 */
 void vho_reset_mutexes(vho_table *t)
 {
-    memset(t->mutex, 0, sizeof(int32_t) * t->p.numBuckets);
+    memset(t->mutex, 0, sizeof(int32_t) * (t->bucket_hi - t->bucket_lo));
 }
 
 /* allocSingleBlockInHeap, VoxelUtils.cu:328-334, with the exhaustion case
@@ -334,11 +347,13 @@ static int32_t heap_pop(vho_table *t)
 static void insert_entry(vho_table *t, const int32_t key[3])
 {
     const uint32_t bs = t->p.bucketSize, nb = t->p.numBuckets;
-    const uint32_t h = vho_hash(key[0], key[1], key[2], nb);
+    const uint32_t hg = vho_hash(key[0], key[1], key[2], nb);
+    if (hg < t->bucket_lo || hg >= t->bucket_hi) return;               /* another shard's bucket */
+    const uint32_t h = hg - t->bucket_lo;
     const uint32_t start = h * bs;
     int saw_free = 0;
     for (uint32_t i = 0; i < bs; ++i) {
-        uint32_t idx = (start + i) % (nb * bs);
+        uint32_t idx = start + i;   /* (start+i) % N in the reference; never wraps */
         vho_entry *e = &t->table[idx];
         if (e->pos[0] == key[0] && e->pos[1] == key[1] && e->pos[2] == key[2]
             && e->ptr != VHO_FREE_BLOCK) return;                       /* already there */
@@ -391,7 +406,7 @@ void vho_alloc_blocks(vho_table *t, const float *verts)
  * redundant reset of the whole compact table (:757-758) is not repeated. */
 int vho_flatten(vho_table *t)
 {
-    const size_t n = (size_t)t->p.numBuckets * t->p.bucketSize;
+    const size_t n = (size_t)(t->bucket_hi - t->bucket_lo) * t->p.bucketSize;
     int count = 0;
     for (size_t i = 0; i < n; ++i) {
         const vho_entry *e = &t->table[i];
@@ -405,7 +420,14 @@ int vho_flatten(vho_table *t)
 }
 
 /* integrateDepthMapKernel, VoxelUtils.cu:790-842 */
+static void integrate_depth(vho_table *t, const float *depth_base, int stride);
+
 void vho_integrate_depth_map(vho_table *t, const float *verts)
+{
+    integrate_depth(t, verts + 2, 4);          /* verts[idx].z */
+}
+
+static void integrate_depth(vho_table *t, const float *depth_base, int stride)
 {
     const int W = t->width, H = t->height;
     const float trunc = t->p.truncation;
@@ -436,7 +458,7 @@ void vho_integrate_depth_map(vho_table *t, const float *verts)
             int32_t s[2];
             vho_project(t->proj, pc, s);                                          /* :801 */
             if (s[0] < 0 || s[0] >= W || s[1] < 0 || s[1] >= H) continue;         /* :803 */
-            const float depth = verts[4 * ((size_t)s[1] * W + s[0]) + 2];        /* :805 */
+            const float depth = depth_base[(size_t)stride * ((size_t)s[1] * W + s[0])];  /* :805 */
             if (depth <= 0) continue;                                             /* :806 */
             float sdf = depth - pc[2];                                            /* :813 */
             if (sdf > -trunc) {                                                   /* :818 */
@@ -474,7 +496,9 @@ int vho_integrate(vho_table *t, const float pose[16], const float *verts, vho_fr
 static int64_t lookup_block(const vho_table *t, const int32_t key[3])
 {
     const uint32_t bs = t->p.bucketSize;
-    const uint32_t h = vho_hash(key[0], key[1], key[2], t->p.numBuckets);
+    const uint32_t hg = vho_hash(key[0], key[1], key[2], t->p.numBuckets);
+    if (hg < t->bucket_lo || hg >= t->bucket_hi) return -1;
+    const uint32_t h = hg - t->bucket_lo;
     for (uint32_t i = 0; i < bs; ++i) {
         const vho_entry *e = &t->table[(size_t)h * bs + i];
         if (e->pos[0] == key[0] && e->pos[1] == key[1] && e->pos[2] == key[2]
@@ -532,6 +556,116 @@ void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max, f
         depth_out[(size_t)v * W + u] = hit;
     }
 }
+
+/* ------------------------------------------------------------------ */
+/* bucket-range sharding (build extension)         */
+/* ------------------------------------------------------------------ */
+
+/* Key generation half of allocBlocksKernel (VoxelUtils.cu:606-636,673) for the
+ * camera whose pose is set: every valid pixel whose block passes the frustum
+ * test yields {x,y,z,rank}, rank = camera_id<<24 | launch rank; runs of equal
+ * keys along an image row collapse to their first pixel.  Records are binned
+ * by owning shard: bin s = bins[s*capacity ...], record 0 is the header
+ * {count,0,0,0}, records 1..count the keys.  Returns the largest count (a
+ * count > capacity-1 means that bin overflowed). */
+int vho_generate_keys(vho_table *t, const float *verts, uint32_t camera_id, int num_shards,
+                      int32_t *bins, int capacity)
+{
+    const int W = t->width, H = t->height;
+    const uint32_t per = (t->p.numBuckets + (uint32_t)num_shards - 1u) / (uint32_t)num_shards;
+    int worst = 0;
+    for (int s = 0; s < num_shards; ++s) memset(bins + (size_t)4 * s * capacity, 0, 4 * sizeof(int32_t));
+    for (int y = 0; y < H; ++y) {
+        int have_prev = 0;
+        int32_t prev[3] = {0, 0, 0};
+        for (int x = 0; x < W; ++x) {
+            const float *v = verts + 4 * ((size_t)y * W + x);
+            int32_t key[3];
+            int want = 0;
+            if (v[2] != 0.0f) {
+                float g[4];
+                vho_mat4_mul_vec4(t->p.global_transform, v, g);
+                vho_world2block(g, t->p.voxelSize, t->p.voxelBlockSize, key);
+                want = vho_block_in_frustum(t, key);
+            }
+            if (!want) { have_prev = 0; continue; }
+            if (have_prev && key[0] == prev[0] && key[1] == prev[1] && key[2] == prev[2]) continue;
+            have_prev = 1; prev[0] = key[0]; prev[1] = key[1]; prev[2] = key[2];
+            const uint32_t h = vho_hash(key[0], key[1], key[2], t->p.numBuckets);
+            int32_t *bin = bins + (size_t)4 * (h / per) * capacity;
+            const int slot = ++bin[0];
+            if (slot > worst) worst = slot;
+            if (slot < capacity) {
+                int32_t *r = bin + 4 * slot;
+                r[0] = key[0]; r[1] = key[1]; r[2] = key[2];
+                r[3] = (int32_t)((camera_id << 24) | vho_launch_rank(x, y, W));
+            }
+        }
+    }
+    return worst;
+}
+
+typedef struct { int32_t k[4]; } key_rec;
+static int cmp_rank(const void *a, const void *b)
+{
+    const uint32_t ra = (uint32_t)((const key_rec *)a)->k[3], rb = (uint32_t)((const key_rec *)b)->k[3];
+    return (ra > rb) - (ra < rb);
+}
+
+/* Insert the keys of num_bins received bins under ONE lock epoch: contenders
+ * are served in rank order, which is what the min-rank claim of the HIP path
+ * resolves to.  Call vho_reset_mutexes first. */
+int vho_insert_bins(vho_table *t, const int32_t *bins, int num_bins, int capacity)
+{
+    size_t total = 0;
+    for (int b = 0; b < num_bins; ++b) {
+        int n = bins[(size_t)4 * b * capacity];
+        if (n > capacity - 1) n = capacity - 1;
+        total += (size_t)n;
+    }
+    key_rec *all = (key_rec *)malloc(sizeof(key_rec) * (total ? total : 1));
+    size_t m = 0;
+    for (int b = 0; b < num_bins; ++b) {
+        const int32_t *bin = bins + (size_t)4 * b * capacity;
+        int n = bin[0];
+        if (n > capacity - 1) n = capacity - 1;
+        for (int i = 1; i <= n; ++i) memcpy(all[m++].k, bin + 4 * i, sizeof(key_rec));
+    }
+    qsort(all, total, sizeof(key_rec), cmp_rank);
+    for (size_t i = 0; i < total; ++i) insert_entry(t, all[i].k);
+    free(all);
+    return (int)total;
+}
+
+/* Camera packet: 16 floats pose, 16 floats inverse pose, W*H camera-z plane. */
+void vho_write_packet(vho_table *t, const float *verts, float *packet)
+{
+    memcpy(packet, t->p.global_transform, 16 * sizeof(float));
+    memcpy(packet + 16, t->p.inv_global_transform, 16 * sizeof(float));
+    const size_t n = (size_t)t->width * t->height;
+    for (size_t i = 0; i < n; ++i) packet[32 + i] = verts[4 * i + 2];
+}
+
+/* For each camera packet in order: flatten against that camera's frustum and
+ * run the TSDF update from its depth plane -- the flatten/integrate half of
+ * SDF_Hashtable::integrate applied camera by camera to this shard. */
+int vho_integrate_packets(vho_table *t, int num_cams, const float *packets)
+{
+    const size_t stride = 32 + (size_t)t->width * t->height;
+    int total = 0;
+    for (int c = 0; c < num_cams; ++c) {
+        const float *pk = packets + stride * c;
+        memcpy(t->p.global_transform, pk, 16 * sizeof(float));
+        memcpy(t->p.inv_global_transform, pk + 16, 16 * sizeof(float));
+        int occ = vho_flatten(t);
+        if (occ > 0) integrate_depth(t, pk + 32, 1);
+        total += occ;
+    }
+    return total;
+}
+
+uint32_t vho_bucket_lo(const vho_table *t) { return t->bucket_lo; }
+uint32_t vho_bucket_hi(const vho_table *t) { return t->bucket_hi; }
 
 /* ------------------------------------------------------------------ */
 /* accessors                                                           */

@@ -97,6 +97,17 @@ int  vho_integrate(vho_table *t, const float pose[16], const float *verts,
 void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max,
                  float *depth_out /* W*H */);
 
+/* ---- bucket-range sharding (build extension for multi-GPU) ---- */
+vho_table *vho_create_shard(const vho_params *p, int width, int height, int semantics,
+                            uint32_t bucket_lo, uint32_t bucket_hi);
+int  vho_generate_keys(vho_table *t, const float *verts, uint32_t camera_id, int num_shards,
+                       int32_t *bins, int capacity);
+int  vho_insert_bins(vho_table *t, const int32_t *bins, int num_bins, int capacity);
+void vho_write_packet(vho_table *t, const float *verts, float *packet);
+int  vho_integrate_packets(vho_table *t, int num_cams, const float *packets);
+uint32_t vho_bucket_lo(const vho_table *t);
+uint32_t vho_bucket_hi(const vho_table *t);
+
 /* ---- accessors ---- */
 const vho_params *vho_get_params(const vho_table *t);
 vho_entry        *vho_hash_table(vho_table *t);      /* numBuckets*bucketSize entries */

@@ -24,7 +24,7 @@ def test_header_declares_the_reference_names():
     for n in ("updateConstantHashTableParams", "deviceAllocate", "deviceFree", "resetHashTableMutexes",
               "allocBlocks", "flattenIntoBuffer", "calculateKinectProjectionMatrix", "integrateDepthMap"):
         assert n in names
-    for n in ("vh_create", "vh_integrate", "vh_raycast", "vh_generate_keys", "vh_insert_keys"):
+    for n in ("vh_create", "vh_integrate", "vh_raycast", "vh_generate_keys", "vh_insert_bins", "vh_integrate_packets"):
         assert n in names
     assert len(names) >= 35
 

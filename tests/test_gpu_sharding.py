@@ -1,0 +1,75 @@
+"""Bucket-range shards on the GPU: R shard contexts on one device with the in-process
+exchange (the RCCL transport itself is covered by the gloo test and runs on the 8-GPU node);
+each shard must equal its slice of ONE unsharded oracle table after the same multi-camera frames."""
+import numpy as np
+import pytest
+
+from test_sharding_cpu import check_shard_against_full
+from voxelhashing_demo_amd import dist as vdist
+from voxelhashing_demo_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+W, H = 320, 240
+KW = dict(numBuckets=1 << 14, numVoxelBlocks=4096)
+
+
+def cameras(world, step):
+    prims = synth.room_primitives()
+    out = []
+    for r in range(world):
+        pose = synth.camera_loop(60, phase=vdist.camera_phase(r, world))[(5 * step) % 60]
+        out.append((pose, synth.render_room_verts(pose, W, H, prims).numpy()))
+    return out
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("sem", [0, 1])
+def test_hip_shards_equal_one_oracle_table(oracle, vh, torch_cuda, world, sem):
+    torch = torch_cuda
+    plan = vdist.ShardPlan(KW["numBuckets"], world)
+    shards = [vdist.HipShard(vh.default_params(**KW), W, H, sem, plan, r, W * H // 4) for r in range(world)]
+    full = oracle.OracleTable(oracle.default_params(**KW), W, H, sem)
+    for step in range(3):
+        cams = cameras(world, step)
+        d_verts = [torch.from_numpy(c[1]).cuda() for c in cams]
+        vdist.loopback_step(shards, [c[0] for c in cams], d_verts)
+        for sh in shards:
+            sh.table.synchronize()
+        vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+    total = 0
+    for r, sh in enumerate(shards):
+        lo, hi = plan.bucket_range(r)
+        total += check_shard_against_full(sh.table, full, lo, hi, 5)
+        c = sh.table.counters()
+        assert c["bin_overflow"] == 0 and c["heap_exhausted"] == 0
+    assert total == len(full.allocated())
+    if sem == 1:
+        assert total > 100
+    for sh in shards:
+        sh.table.close()
+
+
+def test_unsharded_gpu_multi_camera_frame_by_steps(oracle, vh, torch_cuda):
+    """The same multi-camera frame through the step-level entry points of one full table."""
+    torch = torch_cuda
+    gt = vh.SDFHashtable(vh.default_params(**KW), W, H, 1)
+    full = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+    for step in range(2):
+        cams = cameras(3, step)
+        vdist.reference_multi_camera_frame(gt, [c[0] for c in cams], [torch.from_numpy(c[1]).cuda() for c in cams])
+        gt.synchronize()
+        vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+    assert check_shard_against_full(gt, full, 0, KW["numBuckets"], 5) > 100
+
+
+def test_key_bin_overflow_is_reported(vh, torch_cuda):
+    torch = torch_cuda
+    plan = vdist.ShardPlan(KW["numBuckets"], 1)
+    sh = vdist.HipShard(vh.default_params(**KW), W, H, 1, plan, 0, 16)      # 15 keys per bin
+    pose, verts = cameras(1, 0)[0]
+    vdist.loopback_step([sh], [pose], [torch.from_numpy(verts).cuda()])
+    sh.table.synchronize()
+    c = sh.table.counters()
+    assert c["bin_overflow"] == 1
+    assert 0 < c["allocated_total"] <= 15

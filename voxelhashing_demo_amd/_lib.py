@@ -47,7 +47,8 @@ class Config(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [("occupied", C.c_int32), ("heap_counter", C.c_int32), ("allocated_total", C.c_uint32),
-                ("heap_exhausted", C.c_uint32), ("candidates", C.c_uint32), ("epoch", C.c_uint32)]
+                ("heap_exhausted", C.c_uint32), ("candidates", C.c_uint32), ("epoch", C.c_uint32),
+                ("bin_overflow", C.c_uint32)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -100,8 +101,9 @@ SIGNATURES = {
     "vh_set_profiling": (C.c_int, [_vp, C.c_int]),
     "vh_get_kernel_times": (C.c_int, [_vp, C.POINTER(KernelTimes), C.c_int]),
     "vh_create_shard": (C.c_int, [C.POINTER(Config), _u32, _u32, C.POINTER(_vp)]),
-    "vh_generate_keys": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
-    "vh_insert_keys": (C.c_int, [_vp, _vp, _vp, _i32]),
+    "vh_generate_keys": (C.c_int, [_vp, _vp, _u32, _i32, _vp, _i32, _vp]),
+    "vh_insert_bins": (C.c_int, [_vp, _vp, _i32, _i32]),
+    "vh_integrate_packets": (C.c_int, [_vp, _i32, _vp]),
     "updateConstantHashTableParams": (None, [C.POINTER(HashTableParams)]),
     "deviceAllocate": (None, [C.POINTER(HashTableParams)]),
     "deviceFree": (None, []),

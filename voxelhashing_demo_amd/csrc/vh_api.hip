@@ -195,6 +195,7 @@ static int free_buffers(vh_context *c)
     if (c->dp.blocks) (void)hipFree(c->dp.blocks);
     if (c->dp.counters) (void)hipFree(c->dp.counters);
     if (c->dp.candidates) (void)hipFree(c->dp.candidates);
+    if (c->dp.compactMask) (void)hipFree(c->dp.compactMask);
     c->dp = DevPtrs{};
     return VH_OK;
 }
@@ -267,6 +268,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     VH_ALLOC(dp.blocks, sizeof(Voxel) * (size_t)p.numVoxelBlocks * kBlockVoxels);
     VH_ALLOC(dp.counters, sizeof(int32_t) * kNumCounters);
     VH_ALLOC(dp.candidates, sizeof(int4) * npix);
+    VH_ALLOC(dp.compactMask, sizeof(uint32_t) * c->numEntries);
 #undef VH_ALLOC
 
     // deviceAllocate, VoxelUtils.cu:183-208 (+ the compact table and the zeroed
@@ -392,7 +394,7 @@ static int launch_alloc(vh_context *c, const vh_float4 *verts)
     const int npix = c->fp.width * c->fp.height;
     int rc = launch(c, kPhaseClaim, alloc_claim_kernel<false>, dim3(grid_for(npix, 256)), dim3(256), c->fp, c->dp,
                     reinterpret_cast<const float4 *>(verts), (int32_t)1, (int4 *)nullptr, (int32_t)0,
-                    (int32_t *)nullptr, 0u);
+                    (float *)nullptr, 0u);
     if (rc != VH_OK) return rc;
     return launch(c, kPhaseCommit, alloc_commit_kernel, dim3(32), dim3(256), c->fp, c->dp);
 }
@@ -491,32 +493,53 @@ extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, floa
 // ---------------------------------------------------------------------------
 // sharding
 // ---------------------------------------------------------------------------
-extern "C" int vh_generate_keys(vh_context *c, const vh_float4 *verts, int32_t num_shards, int32_t *d_keys,
-                                int32_t capacity, int32_t *d_counts)
+extern "C" int vh_generate_keys(vh_context *c, const vh_float4 *verts, uint32_t camera_id, int32_t num_shards,
+                                int32_t *d_bins, int32_t capacity, float *d_packet)
 {
-    if (!c || !verts || !d_keys || !d_counts || num_shards <= 0 || capacity <= 0)
+    if (!c || !verts || !d_bins || num_shards <= 0 || capacity < 2 || camera_id >= VH_MAX_CAMERAS)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     DeviceGuard guard(c->device);
     const int npix = c->fp.width * c->fp.height;
-    VH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)num_shards, c->stream));
+    // zero the header record of every bin
+    VH_HIP(hipMemset2DAsync(d_bins, sizeof(int4) * (size_t)capacity, 0, sizeof(int4), (size_t)num_shards, c->stream));
+    if (d_packet) write_packet_header_kernel<<<1, 32, 0, c->stream>>>(c->fp, d_packet);
     alloc_claim_kernel<true><<<grid_for(npix, 256), 256, 0, c->stream>>>(
-        c->fp, c->dp, reinterpret_cast<const float4 *>(verts), num_shards, reinterpret_cast<int4 *>(d_keys), capacity,
-        d_counts, 0u);
+        c->fp, c->dp, reinterpret_cast<const float4 *>(verts), num_shards, reinterpret_cast<int4 *>(d_bins), capacity,
+        d_packet ? d_packet + kPacketHeader : nullptr, camera_id << 24);
     VH_HIP(hipGetLastError());
     return VH_OK;
 }
 
-extern "C" int vh_insert_keys(vh_context *c, const int32_t *d_keys, const int32_t *d_count, int32_t max_keys)
+extern "C" int vh_insert_bins(vh_context *c, const int32_t *d_bins, int32_t num_bins, int32_t capacity)
 {
-    if (!c || !d_keys || !d_count || max_keys < 0) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    if (!c || !d_bins || num_bins <= 0 || capacity < 2) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     if (c->fp.epoch == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
     DeviceGuard guard(c->device);
-    int grid = grid_for((size_t)max_keys, 256);
-    if (grid < 1) grid = 1;
-    if (grid > 1024) grid = 1024;
-    claim_keys_kernel<<<grid, 256, 0, c->stream>>>(c->fp, c->dp, reinterpret_cast<const int4 *>(d_keys), d_count,
-                                                   max_keys);
-    alloc_commit_kernel<<<32, 256, 0, c->stream>>>(c->fp, c->dp);
+    int gx = grid_for((size_t)capacity, 256 * 4);
+    if (gx < 1) gx = 1;
+    int rc = launch(c, kPhaseClaim, claim_bins_kernel, dim3(gx, num_bins), dim3(256), c->fp, c->dp,
+                    reinterpret_cast<const int4 *>(d_bins), capacity);
+    if (rc == VH_OK) rc = launch(c, kPhaseCommit, alloc_commit_kernel, dim3(32), dim3(256), c->fp, c->dp);
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_integrate_packets(vh_context *c, int32_t num_cams, const float *d_packets)
+{
+    if (!c || !d_packets || num_cams <= 0 || num_cams > VH_MAX_CAMERAS)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(c->device);
+    const size_t stride = (size_t)kPacketHeader + (size_t)c->fp.width * c->fp.height;
+    VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));
+    int rc = launch(c, kPhaseFlatten, flatten_multi_kernel,
+                    dim3(grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane)), dim3(kFlattenThreads), c->fp,
+                    c->dp, (uint32_t)c->numEntries, num_cams, d_packets, stride);
+    if (rc == VH_OK)
+        rc = launch(c, kPhaseIntegrate, integrate_multi_kernel, dim3(c->integrateGrid), dim3(256), c->fp, c->dp,
+                    num_cams, d_packets, stride);
+    if (rc != VH_OK) return rc;
+    if (c->profiling) c->profiledFrames += 1;
     VH_HIP(hipGetLastError());
     return VH_OK;
 }
@@ -545,6 +568,7 @@ extern "C" int vh_get_counters(vh_context *c, vh_counters *out)
     out->heap_exhausted = (uint32_t)h[kHeapExhausted];
     out->candidates = (uint32_t)h[kLastCandidates];
     out->epoch = c->fp.epoch;
+    out->bin_overflow = (uint32_t)h[kBinOverflow];
     c->params.numOccupiedBlocks = (uint32_t)h[kCompactCount];
     return VH_OK;
 }

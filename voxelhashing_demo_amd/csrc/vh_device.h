@@ -28,6 +28,7 @@ enum Counter : int {
     kHeapExhausted = 4,
     kLastCandidates = 5,
     kCommitTicket = 6,
+    kBinOverflow = 7,      // a received key bin carried more keys than its capacity
     kNumCounters = 8
 };
 
@@ -60,7 +61,11 @@ struct DevPtrs {
     int32_t *counters;        // Counter[]
     int4 *candidates;         // {x,y,z,rank} of this frame's contenders
     uint32_t candCapacity;
+    uint32_t *compactMask;    // multi-camera frames: cameras that see compact entry i
 };
+
+// camera packet of the sharded path: 16 floats pose, 16 floats inverse, W*H camera-z plane
+constexpr int kPacketHeader = 32;
 
 struct int3_ { int x, y, z; };
 
@@ -127,21 +132,28 @@ __device__ __forceinline__ void project(const float *m, float x, float y, float 
 }
 
 // blockInFrustum, VoxelUtils.cu:344-359 (REFERENCE) / corrected variant (PINHOLE)
-__device__ __forceinline__ bool block_in_frustum(const FrameParams &fp, int bx, int by, int bz)
+// T / Tinv: the camera's pose and inverse (fp.T / fp.Tinv, or a camera packet's)
+__device__ __forceinline__ bool block_in_frustum(const FrameParams &fp, const float *T, const float *Tinv, int bx,
+                                                 int by, int bz)
 {
     const float wx = (float)(int)((uint32_t)bx * 8u) * fp.voxelSize;   // block2World :289-304
     const float wy = (float)(int)((uint32_t)by * 8u) * fp.voxelSize;
     const float wz = (float)(int)((uint32_t)bz * 8u) * fp.voxelSize;
     float4 c;
     if (fp.semantics == VH_SEM_REFERENCE) {
-        c = mat4_mul(fp.T, wx, wy, wz, 1.0f);
+        c = mat4_mul(T, wx, wy, wz, 1.0f);
     } else {
-        c = mat4_mul(fp.Tinv, wx, wy, wz, 1.0f);
+        c = mat4_mul(Tinv, wx, wy, wz, 1.0f);
         if (!(c.z > 0.0f)) return false;
     }
     int sx, sy;
     project(fp.proj, c.x, c.y, c.z, sx, sy);
     return sx < fp.width && sx >= 0 && sy < fp.height && sy >= 0;
+}
+
+__device__ __forceinline__ bool block_in_frustum(const FrameParams &fp, int bx, int by, int bz)
+{
+    return block_in_frustum(fp, fp.T, fp.Tinv, bx, by, bz);
 }
 
 // Position of pixel (x,y) in the launch order of the reference's grid of 16x16
@@ -153,9 +165,19 @@ __device__ __forceinline__ uint32_t launch_rank(int x, int y, int width)
     return ((((uint32_t)y >> 4) * tilesX + ((uint32_t)x >> 4)) << 8) + (((uint32_t)y & 15u) << 4) + ((uint32_t)x & 15u);
 }
 
+// Claim word of a contender: newer epochs beat stale words, and within an epoch the
+// lowest rank gives the largest word.  Once the winner has been served the word is
+// replaced by the epoch's largest value, so the bucket stays locked for the rest of
+// the epoch even if allocBlocks runs again before the next reset (the reference's
+// mutex is never released within a frame, VoxelUtils.cu:444-445).
 __device__ __forceinline__ unsigned long long claim_word(uint32_t epoch, uint32_t rank)
 {
-    return ((unsigned long long)epoch << 32) | (unsigned long long)(0xffffffffu - rank);
+    return ((unsigned long long)epoch << 32) | (unsigned long long)(0xfffffffeu - rank);
+}
+
+__device__ __forceinline__ unsigned long long consumed_word(uint32_t epoch)
+{
+    return ((unsigned long long)epoch << 32) | 0xffffffffull;
 }
 
 }  // namespace vh

@@ -62,8 +62,8 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
 template <bool kEmit>
 __global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, const DevPtrs dp,
                                                           const float4 *__restrict__ verts, int32_t numShards,
-                                                          int4 *__restrict__ outKeys, int32_t outCapacity,
-                                                          int32_t *__restrict__ outCounts, uint32_t rankBase)
+                                                          int4 *__restrict__ outBins, int32_t outCapacity,
+                                                          float *__restrict__ outDepth, uint32_t rankBase)
 {
     const int npix = fp.width * fp.height;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -71,6 +71,9 @@ __global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, 
     int kx = 0, ky = 0, kz = 0, px = 0, py = 0;
     if (idx < npix) {
         const float4 v = verts[idx];
+        if constexpr (kEmit) {
+            if (outDepth) outDepth[idx] = v.z;       // camera-z plane of the camera packet
+        }
         py = idx / fp.width;
         px = idx - py * fp.width;
         if (v.z != 0.0f) {                                               // VoxelUtils.cu:621
@@ -93,26 +96,12 @@ __global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, 
     if constexpr (kEmit) {
         const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
         const uint32_t owner = h / perShard;
-        const int slot = atomicAdd(outCounts + owner, 1);
-        if (slot < outCapacity) outKeys[(size_t)owner * outCapacity + slot] = make_int4(kx, ky, kz, (int)rank);
+        int4 *bin = outBins + (size_t)owner * outCapacity;        // record 0 = {count,0,0,0}
+        const int slot = atomicAdd(&bin[0].x, 1) + 1;
+        if (slot < outCapacity) bin[slot] = make_int4(kx, ky, kz, (int)rank);
     } else {
         if (h < fp.bucketLo || h >= fp.bucketHi) return;                 // not this shard's bucket
         probe_and_claim(fp, dp, kx, ky, kz, h, rank);
-    }
-}
-
-// phase 1 for keys that arrived from other ranks
-__global__ __launch_bounds__(256) void claim_keys_kernel(const FrameParams fp, const DevPtrs dp,
-                                                         const int4 *__restrict__ keys,
-                                                         const int32_t *__restrict__ count, int32_t maxKeys)
-{
-    int n = *count;
-    if (n > maxKeys) n = maxKeys;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int4 k = keys[i];
-        const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
-        if (h < fp.bucketLo || h >= fp.bucketHi) continue;
-        probe_and_claim(fp, dp, k.x, k.y, k.z, h, (uint32_t)k.w);
     }
 }
 
@@ -133,6 +122,7 @@ __global__ __launch_bounds__(256) void alloc_commit_kernel(const FrameParams fp,
         const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
         const uint32_t local = h - fp.bucketLo;
         if (dp.claim[local] != claim_word(fp.epoch, (uint32_t)k.w)) continue;   // lost the bucket this frame
+        dp.claim[local] = consumed_word(fp.epoch);                               // locked until the next epoch
         VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
         for (uint32_t s = 0; s < fp.bucketSize; ++s) {
             if (bucket[s].ptr != VH_FREE_BLOCK) continue;
@@ -229,25 +219,28 @@ __global__ __launch_bounds__(kFlattenThreads) void flatten_kernel(const FramePar
 // coalesced loads and stores (4 KiB in, 4 KiB out) instead of the reference's
 // 8-byte accesses.  The occupied count never leaves the device: the grid is a
 // fixed size and strides over the compact list.
-__device__ __forceinline__ bool tsdf_update(const FrameParams &fp, const float4 *__restrict__ verts, int vx, int vy,
-                                            int vz, float &sdfOut, float &wOut)
+// depth(x,y) = depthBase[stride*(y*W+x)]: stride 4 from &verts[0].z (float4 vertex map),
+// stride 1 for the camera-z plane of a camera packet.
+__device__ __forceinline__ bool tsdf_update(const FrameParams &fp, const float *Tinv,
+                                            const float *__restrict__ depthBase, int stride, int vx, int vy, int vz,
+                                            float &sdfOut, float &wOut)
 {
     float cx, cy, cz;
     if (fp.semantics == VH_SEM_REFERENCE) {
         // VoxelUtils.cu:797-800: inverse pose on the voxel INDEX, truncate, then metres
-        const float4 r = mat4_mul(fp.Tinv, (float)vx, (float)vy, (float)vz, 1.0f);
+        const float4 r = mat4_mul(Tinv, (float)vx, (float)vy, (float)vz, 1.0f);
         cx = (float)f2i_rz(r.x) * fp.voxelSize;
         cy = (float)f2i_rz(r.y) * fp.voxelSize;
         cz = (float)f2i_rz(r.z) * fp.voxelSize;
     } else {
-        const float4 r = mat4_mul(fp.Tinv, (float)vx * fp.voxelSize, (float)vy * fp.voxelSize,
+        const float4 r = mat4_mul(Tinv, (float)vx * fp.voxelSize, (float)vy * fp.voxelSize,
                                   (float)vz * fp.voxelSize, 1.0f);
         cx = r.x; cy = r.y; cz = r.z;
     }
     int sx, sy;
     project(fp.proj, cx, cy, cz, sx, sy);                                        // :801
     if (sx < 0 || sx >= fp.width || sy < 0 || sy >= fp.height) return false;     // :803
-    const float depth = verts[(size_t)sy * fp.width + sx].z;                     // :805
+    const float depth = depthBase[(size_t)stride * ((size_t)sy * fp.width + sx)];   // :805
     if (depth <= 0.0f) return false;                                             // :806
     float sdf = depth - cz;                                                      // :813
     if (!(sdf > -fp.truncation)) return false;                                   // :818
@@ -273,10 +266,119 @@ __global__ __launch_bounds__(256) void integrate_kernel(const FrameParams fp, co
         const int bz = (int)((uint32_t)e.pos[2] * 8u) + tz;
         float4 *cell = reinterpret_cast<float4 *>(dp.blocks + (size_t)e.ptr + lin);
         float4 v = *cell;                        // {sdf0, w0, sdf1, w1}
-        const bool u0 = tsdf_update(fp, verts, bx, by, bz, v.x, v.y);
-        const bool u1 = tsdf_update(fp, verts, bx + 1, by, bz, v.z, v.w);
+        const float *depthBase = reinterpret_cast<const float *>(verts) + 2;   // &verts[0].z
+        const bool u0 = tsdf_update(fp, fp.Tinv, depthBase, 4, bx, by, bz, v.x, v.y);
+        const bool u1 = tsdf_update(fp, fp.Tinv, depthBase, 4, bx + 1, by, bz, v.z, v.w);
         if (u0 || u1) *cell = v;
     }
+}
+
+// ---------------------------------------------------------------------------
+// multi-camera frame on a bucket-range shard
+// ---------------------------------------------------------------------------
+// phase 1 for key bins that arrived from the other ranks: bin b = bins[b*capacity..],
+// record 0 = {count,0,0,0}, records 1..count = {x,y,z,rank}.  One lock epoch for all
+// bins; rank = camera<<24 | launch rank, so cameras are served in order.
+__global__ __launch_bounds__(256) void claim_bins_kernel(const FrameParams fp, const DevPtrs dp,
+                                                         const int4 *__restrict__ bins, int32_t capacity)
+{
+    const int4 *bin = bins + (size_t)blockIdx.y * capacity;
+    int n = bin[0].x;
+    if (n > capacity - 1) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(dp.counters + kBinOverflow, 1);
+        n = capacity - 1;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int4 k = bin[1 + i];
+        const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
+        if (h < fp.bucketLo || h >= fp.bucketHi) continue;
+        probe_and_claim(fp, dp, k.x, k.y, k.z, h, (uint32_t)k.w);
+    }
+}
+
+// One walk over the shard's entries for ALL cameras of the step: a live entry is
+// tested against every camera's frustum and appended once, with the mask of the
+// cameras that see it.
+__global__ __launch_bounds__(kFlattenThreads) void flatten_multi_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                        uint32_t numEntries, int32_t numCams,
+                                                                        const float *__restrict__ packets,
+                                                                        size_t packetStride)
+{
+    const uint32_t tile = blockIdx.x * (kFlattenThreads * kEntriesPerLane);
+    const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
+    int32_t ptrs[kEntriesPerLane];
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) {
+        const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
+        ptrs[j] = (e < numEntries) ? words[(size_t)e * kEntryDwords + 3] : VH_FREE_BLOCK;
+    }
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) any |= (ptrs[j] != VH_FREE_BLOCK);
+    if (__ballot(any) == 0ull) return;
+
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) {
+        uint32_t seen = 0;
+        VoxelEntry ent;
+        if (ptrs[j] != VH_FREE_BLOCK) {
+            const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
+            ent = dp.table[e];
+            for (int c = 0; c < numCams; ++c) {
+                const float *pk = packets + packetStride * c;
+                if (block_in_frustum(fp, pk, pk + 16, ent.pos[0], ent.pos[1], ent.pos[2])) seen |= 1u << c;
+            }
+        }
+        const unsigned long long mask = __ballot(seen != 0u);
+        if (mask == 0ull) continue;
+        int base = 0;
+        const int leaderLane = __ffsll((long long)mask) - 1;
+        if (lane == leaderLane) base = atomicAdd(dp.counters + kCompactCount, __popcll(mask));
+        base = __shfl(base, leaderLane);
+        if (seen != 0u) {
+            const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+            dp.compact[slot] = ent;
+            dp.compactMask[slot] = seen;
+        }
+    }
+}
+
+// One 8^3 block per workgroup pass, the voxels stay in registers while the cameras
+// that see the block are applied in camera order (the running average is order
+// dependent): 4 KiB in, 4 KiB out per block whatever the number of cameras.
+__global__ __launch_bounds__(256) void integrate_multi_kernel(const FrameParams fp, const DevPtrs dp,
+                                                              int32_t numCams, const float *__restrict__ packets,
+                                                              size_t packetStride)
+{
+    const int count = dp.counters[kCompactCount];
+    const int lin = 2 * threadIdx.x;
+    const int tx = lin & 7, ty = (lin >> 3) & 7, tz = lin >> 6;
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {
+        const VoxelEntry e = dp.compact[b];
+        const uint32_t seen = dp.compactMask[b];
+        const int bx = (int)((uint32_t)e.pos[0] * 8u) + tx;
+        const int by = (int)((uint32_t)e.pos[1] * 8u) + ty;
+        const int bz = (int)((uint32_t)e.pos[2] * 8u) + tz;
+        float4 *cell = reinterpret_cast<float4 *>(dp.blocks + (size_t)e.ptr + lin);
+        float4 v = *cell;
+        bool dirty = false;
+        for (int c = 0; c < numCams; ++c) {
+            if (!((seen >> c) & 1u)) continue;
+            const float *pk = packets + packetStride * c;
+            dirty |= tsdf_update(fp, pk + 16, pk + kPacketHeader, 1, bx, by, bz, v.x, v.y);
+            dirty |= tsdf_update(fp, pk + 16, pk + kPacketHeader, 1, bx + 1, by, bz, v.z, v.w);
+        }
+        if (dirty) *cell = v;
+    }
+}
+
+// camera packet header: pose and inverse (the z plane is written by alloc_claim_kernel<true>)
+__global__ void write_packet_header_kernel(const FrameParams fp, float *packet)
+{
+    const int i = threadIdx.x;
+    if (i < 16) packet[i] = fp.T[i];
+    else if (i < 32) packet[i] = fp.Tinv[i - 16];
 }
 
 // ---------------------------------------------------------------------------

@@ -1,0 +1,262 @@
+"""Bucket-range sharding of one logical voxel-hash table across the GPUs of a node
+(SURVEY.md section 8(e)).
+
+One process per GPU; rank r owns the buckets [r*per, (r+1)*per) of the logical
+table -- the entries, the heap and the 4 KiB voxel blocks of every block key that
+hashes there -- and holds camera r.  A step is a *multi-camera frame*: one frame
+from every camera enters the table together.
+
+    1. every rank: vertex map -> block keys (wave-deduplicated, frustum-tested),
+       binned by owning rank, plus the camera packet (pose, inverse, camera-z plane)
+    2. one all-to-all of the fixed-capacity key bins (count in the bin header, so no
+       host synchronisation), one all-gather of the camera packets     [RCCL / xGMI]
+    3. every rank, on its shard: new lock epoch, insert the received keys (camera
+       order, then launch order, decides who wins a bucket), one walk over the shard
+       for all cameras, TSDF update of every visible block in camera order
+
+The per-rank logic (`sharded_step`) only talks to a *backend* (the HIP shard, or the
+CPU oracle shard in tests) and a *transport* (torch.distributed, or an in-process
+loop-back that plays all ranks in one process).  torch is transport and buffer owner only.
+"""
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------
+# plan
+# ----------------------------------------------------------------------------
+class ShardPlan:
+    """Bucket ranges of a logical table of `num_buckets` buckets cut over `world` ranks."""
+
+    def __init__(self, num_buckets: int, world: int):
+        if world < 1 or num_buckets < world:
+            raise ValueError("need at least one bucket per rank")
+        self.num_buckets, self.world = num_buckets, world
+        self.per_shard = (num_buckets + world - 1) // world      # owner(h) = h // per_shard
+
+    def bucket_range(self, rank: int):
+        lo = rank * self.per_shard
+        hi = min(self.num_buckets, lo + self.per_shard)
+        if lo >= hi:
+            raise ValueError(f"rank {rank} owns no bucket ({self.num_buckets} buckets over {self.world} ranks)")
+        return lo, hi
+
+    def owner(self, h: int) -> int:
+        return h // self.per_shard
+
+
+# ----------------------------------------------------------------------------
+# transports
+# ----------------------------------------------------------------------------
+class TorchDistTransport:
+    """torch.distributed collectives: backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_to_all_bins(self, send, recv):
+        """send/recv: [world, capacity, 4] int32; bin s of `send` goes to rank s."""
+        self.dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+        return recv
+
+    def all_gather_packets(self, packet, out):
+        """packet: [P] float32 -> out: [world, P], camera order = rank order."""
+        if packet.is_cuda:
+            self.dist.all_gather_into_tensor(out.view(-1), packet, group=self.group)
+        else:
+            self.dist.all_gather(list(out.unbind(0)), packet, group=self.group)
+        return out
+
+
+class LoopbackExchange:
+    """All ranks of a sharded run inside ONE process (tests, single-GPU emulation): every
+    virtual rank posts its send buffers, then each fetches what the collectives would deliver."""
+
+    def __init__(self, world: int):
+        self.world = world
+        self.bins = [None] * world
+        self.packets = [None] * world
+
+    def post(self, rank: int, bins, packet):
+        self.bins[rank], self.packets[rank] = bins, packet
+
+    def fetch(self, rank: int):
+        import torch
+        recv = torch.stack([self.bins[src][rank] for src in range(self.world)])      # all-to-all
+        packets = torch.stack(self.packets)                                            # all-gather
+        return recv.contiguous(), packets.contiguous()
+
+
+# ----------------------------------------------------------------------------
+# backends
+# ----------------------------------------------------------------------------
+class HipShard:
+    """This rank's shard on its GPU (libvoxelhash_hip.so through the C-ABI)."""
+
+    def __init__(self, params, width, height, semantics, plan: ShardPlan, rank: int, capacity: int,
+                 device=None, stream=None):
+        import torch
+
+        from .hashtable import SDFHashtable
+        self.torch = torch
+        self.plan, self.rank, self.capacity = plan, rank, capacity
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.table = SDFHashtable(params, width, height, semantics, device=self.device.index,
+                                  bucket_range=plan.bucket_range(rank), stream=stream)
+        self.packet_floats = 32 + width * height
+        R = plan.world
+        self.bins_send = torch.zeros((R, capacity, 4), dtype=torch.int32, device=self.device)
+        self.bins_recv = torch.zeros((R, capacity, 4), dtype=torch.int32, device=self.device)
+        self.packet = torch.zeros(self.packet_floats, dtype=torch.float32, device=self.device)
+        self.packets = torch.zeros((R, self.packet_floats), dtype=torch.float32, device=self.device)
+
+    def generate(self, pose, verts):
+        self.table.set_pose(pose)
+        self.table.generate_keys(verts, self.rank, self.plan.world, self.bins_send, self.capacity, self.packet)
+        return self.bins_send, self.packet
+
+    def apply(self, bins_recv, packets):
+        self.table.reset_mutexes()
+        self.table.insert_bins(bins_recv, bins_recv.shape[0], self.capacity)
+        self.table.integrate_packets(packets.shape[0], packets)
+
+
+class OracleShard:
+    """The same interface on the CPU oracle (tests only; numpy in, CPU tensors out)."""
+
+    def __init__(self, oracle_module, params, width, height, semantics, plan: ShardPlan, rank: int, capacity: int):
+        import torch
+        self.torch = torch
+        self.plan, self.rank, self.capacity = plan, rank, capacity
+        self.table = oracle_module.OracleTable(params, width, height, semantics, bucket_range=plan.bucket_range(rank))
+        self.packet_floats = 32 + width * height
+        R = plan.world
+        self.bins_recv = torch.zeros((R, capacity, 4), dtype=torch.int32)
+        self.packets = torch.zeros((R, self.packet_floats), dtype=torch.float32)
+
+    def generate(self, pose, verts):
+        self.table.set_pose(pose)
+        bins, packet = self.table.generate_keys(np.asarray(verts), self.rank, self.plan.world, self.capacity)
+        return self.torch.from_numpy(bins), self.torch.from_numpy(packet)
+
+    def apply(self, bins_recv, packets):
+        self.table.reset_mutexes()
+        self.table.insert_bins(bins_recv.numpy())
+        self.table.integrate_packets(packets.numpy())
+
+
+# ----------------------------------------------------------------------------
+# the step
+# ----------------------------------------------------------------------------
+def sharded_step(shard, transport: TorchDistTransport, pose, verts):
+    """One multi-camera frame from this rank's point of view."""
+    bins, packet = shard.generate(pose, verts)
+    recv = transport.all_to_all_bins(bins, shard.bins_recv)
+    packets = transport.all_gather_packets(packet, shard.packets)
+    shard.apply(recv, packets)
+
+
+def loopback_step(shards, poses, verts_list):
+    """The same step with every rank played in this process (no collective library)."""
+    ex = LoopbackExchange(len(shards))
+    for r, sh in enumerate(shards):
+        bins, packet = sh.generate(poses[r], verts_list[r])
+        ex.post(r, bins.clone(), packet.clone())
+    for r, sh in enumerate(shards):
+        recv, packets = ex.fetch(r)
+        sh.apply(recv, packets)
+
+
+def reference_multi_camera_frame(table, poses, verts_list):
+    """What a sharded step must equal, on ONE unsharded table with step-level calls:
+    one lock epoch, every camera's allocBlocks in camera order, then flatten + TSDF update
+    camera by camera.  `table`: OracleTable (numpy verts) or SDFHashtable (device verts)."""
+    table.reset_mutexes()
+    for pose, verts in zip(poses, verts_list):
+        table.set_pose(pose)
+        table.alloc_blocks(verts)
+    for pose, verts in zip(poses, verts_list):
+        table.set_pose(pose)
+        table.flatten()
+        table.integrate_depth_map(verts)
+
+
+def camera_phase(rank: int, world: int) -> float:
+    """Cameras start evenly spread on the loop (C4: 90 degrees apart)."""
+    return 2.0 * math.pi * rank / world
+
+
+# ----------------------------------------------------------------------------
+# bench (called by bench.py when WORLD_SIZE > 1)
+# ----------------------------------------------------------------------------
+def bench_sharded(args, wl, rank, world, local_rank):
+    import json
+
+    import torch
+    import torch.distributed as dist
+
+    from . import SEM_PINHOLE, default_params, synth
+
+    Wd, Ht = wl["width"], wl["height"]
+    nframes = min(args.frames or wl["frames"], 250)
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    plan = ShardPlan(wl["buckets"], world)
+    capacity = 4096
+    poses = synth.camera_loop(wl["frames"], phase=camera_phase(rank, world))[:nframes]
+    prims = synth.room_primitives()
+    verts = torch.empty((nframes, Ht, Wd, 4), dtype=torch.float32, device=dev)
+    for i in range(nframes):
+        verts[i] = synth.render_room_verts(poses[i], Wd, Ht, prims, device=dev)
+    torch.cuda.synchronize()
+    params = default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
+    transport = TorchDistTransport()
+    with torch.cuda.stream(stream):
+        shard = HipShard(params, Wd, Ht, SEM_PINHOLE, plan, rank, capacity, device=dev, stream=stream)
+
+        def step(i):
+            k = i % nframes
+            sharded_step(shard, transport, poses[k], verts[k])
+
+        for i in range(args.warmup):
+            step(i)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        shard.table.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    c = shard.table.counters()
+    stats = torch.tensor([c["occupied"], c["allocated_total"], c["bin_overflow"]], dtype=torch.int64, device=dev)
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        frames = args.steps * world
+        out = dict(
+            metric="frames/s TSDF-integrated, 640x480" if (Wd, Ht) == (640, 480) else f"frames/s TSDF-integrated, {Wd}x{Ht}",
+            value=round(frames / elapsed, 1), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+            ms_per_step=round(1e3 * elapsed / args.steps, 5), higher_is_better=True, scaling="weak",
+            vs_baseline=None, dtype="f32", data="synthetic",
+            config=dict(workload=f"C4-style: {world} virtual {Wd}x{Ht} cameras (one per GPU) into one scene, "
+                                 f"2^{int(math.log2(wl['buckets']))} buckets sharded by bucket range over {world} GPUs, "
+                                 "RCCL all-to-all of block keys + all-gather of depth packets per step, PINHOLE",
+                        frames_per_step=world, resident_frames=nframes, key_bin_capacity=capacity,
+                        occupied_blocks_all_ranks=int(stats[0]), allocated_blocks_all_ranks=int(stats[1]),
+                        key_bin_overflows=int(stats[2])),
+            roofline=None, cpu_baseline=None)
+        print(json.dumps(out))
+    shard.table.close()
+    dist.destroy_process_group()

@@ -126,12 +126,16 @@ class SDFHashtable:
         L.check(self._lib.vh_integrate_depth_map(self._h, _dev_ptr(verts)), "vh_integrate_depth_map")
 
     # ---- sharding ----
-    def generate_keys(self, verts, num_shards: int, keys_out, capacity: int, counts_out):
-        L.check(self._lib.vh_generate_keys(self._h, _dev_ptr(verts), num_shards, _dev_ptr(keys_out), capacity,
-                                           _dev_ptr(counts_out)), "vh_generate_keys")
+    def generate_keys(self, verts, camera_id: int, num_shards: int, bins_out, capacity: int, packet_out=None):
+        """Key bins [num_shards, capacity, 4] int32 (+ the camera packet) for the pose set with set_pose()."""
+        L.check(self._lib.vh_generate_keys(self._h, _dev_ptr(verts), camera_id, num_shards, _dev_ptr(bins_out),
+                                           capacity, _dev_ptr(packet_out)), "vh_generate_keys")
 
-    def insert_keys(self, keys, count, max_keys: int):
-        L.check(self._lib.vh_insert_keys(self._h, _dev_ptr(keys), _dev_ptr(count), max_keys), "vh_insert_keys")
+    def insert_bins(self, bins, num_bins: int, capacity: int):
+        L.check(self._lib.vh_insert_bins(self._h, _dev_ptr(bins), num_bins, capacity), "vh_insert_bins")
+
+    def integrate_packets(self, num_cams: int, packets):
+        L.check(self._lib.vh_integrate_packets(self._h, num_cams, _dev_ptr(packets)), "vh_integrate_packets")
 
     # ---- queries ----
     def synchronize(self):
