@@ -47,6 +47,10 @@ def parse_args():
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU sample (0 = auto, about 15 s)")
     ap.add_argument("--raycast-steps", type=int, default=50)
     ap.add_argument("--profile-steps", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=8,
+                    help="sharded path: frames per camera carried by one all-to-all / all-gather")
+    ap.add_argument("--sharded", action="store_true",
+                    help="force the bucket-range-sharded path (torch.distributed) even with one rank")
     return ap.parse_args()
 
 
@@ -68,10 +72,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.sharded:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    if world > 1:
         from voxelhashing_demo_amd import dist as vdist
         return vdist.bench_sharded(args, WORKLOADS[args.workload], rank, world, local_rank)
 

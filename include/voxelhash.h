@@ -221,18 +221,23 @@ int vh_create_shard(const vh_config *cfg, uint32_t bucket_lo, uint32_t bucket_hi
  * pixel the block key of the surface point, frustum-tested, runs of equal keys
  * collapsed per wavefront.  Records are int4 {x,y,z,rank}, rank = camera_id<<24 |
  * launch rank, binned by owning shard (owner = hash / ceil(numBuckets/num_shards)):
- * bin s = d_bins[s*capacity*4 ...], record 0 = {count,0,0,0}, records 1..count the
+ * bin s = d_bins[s*bin_stride*4 ...], record 0 = {count,0,0,0}, records 1..count the
  * keys (count > capacity-1 = overflow).  d_packet (nullable) receives the camera
  * packet: pose, inverse pose, camera-z plane (VH_PACKET_HEADER_FLOATS + W*H floats). */
 int vh_generate_keys(vh_context *ctx, const vh_float4 *d_verts, uint32_t camera_id,
-                     int32_t num_shards, int32_t *d_bins, int32_t capacity, float *d_packet);
-/* Insert the keys of num_bins received bins (same layout, contiguous) into this
- * shard under the current lock epoch (call vh_reset_mutexes first). */
-int vh_insert_bins(vh_context *ctx, const int32_t *d_bins, int32_t num_bins, int32_t capacity);
+                     int32_t num_shards, int32_t *d_bins, int32_t capacity, int32_t bin_stride,
+                     float *d_packet);
+/* Insert the keys of num_bins received bins (same layout) into this shard under the
+ * current lock epoch (call vh_reset_mutexes first).  bin_stride / packet_stride: distance
+ * between consecutive bins (in records) / packets (in floats); 0 = dense.  Strides let
+ * several frames per camera travel in one collective (bins[src][frame], packets[cam][frame]). */
+int vh_insert_bins(vh_context *ctx, const int32_t *d_bins, int32_t num_bins, int32_t capacity,
+                   int32_t bin_stride);
 /* flatten + TSDF update of this shard for num_cams camera packets (contiguous,
  * camera order): one walk over the shard's entries for all cameras, then one
  * pass per visible block applying the cameras that see it in order. */
-int vh_integrate_packets(vh_context *ctx, int32_t num_cams, const float *d_packets);
+int vh_integrate_packets(vh_context *ctx, int32_t num_cams, const float *d_packets,
+                         size_t packet_stride);
 
 /* ------------------------------------------------------------------ */
 /* drop-in names (VoxelUtils.h:5-13); process-global default context    */

@@ -23,20 +23,22 @@ def cameras(world, step):
     return out
 
 
-@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("world,batch", [(1, 1), (2, 1), (4, 1), (2, 2), (4, 3)])
 @pytest.mark.parametrize("sem", [0, 1])
-def test_hip_shards_equal_one_oracle_table(oracle, vh, torch_cuda, world, sem):
+def test_hip_shards_equal_one_oracle_table(oracle, vh, torch_cuda, world, batch, sem):
     torch = torch_cuda
     plan = vdist.ShardPlan(KW["numBuckets"], world)
-    shards = [vdist.HipShard(vh.default_params(**KW), W, H, sem, plan, r, W * H // 4) for r in range(world)]
+    shards = [vdist.HipShard(vh.default_params(**KW), W, H, sem, plan, r, W * H // 4, batch=batch)
+              for r in range(world)]
     full = oracle.OracleTable(oracle.default_params(**KW), W, H, sem)
-    for step in range(3):
-        cams = cameras(world, step)
-        d_verts = [torch.from_numpy(c[1]).cuda() for c in cams]
-        vdist.loopback_step(shards, [c[0] for c in cams], d_verts)
+    for step in range(0, 3, batch):
+        frames = [cameras(world, step + b) for b in range(batch)]                 # frames[b][r]
+        vdist.loopback_step(shards, [[frames[b][r][0] for b in range(batch)] for r in range(world)],
+                            [[torch.from_numpy(frames[b][r][1]).cuda() for b in range(batch)] for r in range(world)])
         for sh in shards:
             sh.table.synchronize()
-        vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+        for cams in frames:
+            vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
     total = 0
     for r, sh in enumerate(shards):
         lo, hi = plan.bucket_range(r)
@@ -68,7 +70,7 @@ def test_key_bin_overflow_is_reported(vh, torch_cuda):
     plan = vdist.ShardPlan(KW["numBuckets"], 1)
     sh = vdist.HipShard(vh.default_params(**KW), W, H, 1, plan, 0, 16)      # 15 keys per bin
     pose, verts = cameras(1, 0)[0]
-    vdist.loopback_step([sh], [pose], [torch.from_numpy(verts).cuda()])
+    vdist.loopback_step([sh], [[pose]], [[torch.from_numpy(verts).cuda()]])
     sh.table.synchronize()
     c = sh.table.counters()
     assert c["bin_overflow"] == 1

@@ -13,7 +13,7 @@ from voxelhashing_demo_amd import dist as vdist
 from voxelhashing_demo_amd import synth
 
 W, H = 160, 120
-KW = dict(numBuckets=1 << 12, numVoxelBlocks=2048)
+KW = dict(numBuckets=1 << 12, numVoxelBlocks=8192)   # enough blocks: heap exhaustion is not under test
 
 
 def camera_inputs(world, step):
@@ -49,17 +49,22 @@ def test_shard_plan():
         vdist.ShardPlan(2, 4)
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("world,batch", [(1, 1), (2, 1), (3, 1), (2, 2)])
 @pytest.mark.parametrize("sem", [0, 1])
-def test_loopback_shards_equal_one_table(oracle, world, sem):
+def test_loopback_shards_equal_one_table(oracle, world, batch, sem):
+    """batch > 1: several frames per camera travel in one exchange and are applied in order;
+    the result is the same as one multi-camera frame per exchange."""
     plan = vdist.ShardPlan(KW["numBuckets"], world)
-    shards = [vdist.OracleShard(oracle, oracle.default_params(**KW), W, H, sem, plan, r, W * H + 1) for r in range(world)]
+    shards = [vdist.OracleShard(oracle, oracle.default_params(**KW), W, H, sem, plan, r, W * H + 1, batch=batch)
+              for r in range(world)]
     full = oracle.OracleTable(oracle.default_params(**KW), W, H, sem)
     total = 0
-    for step in range(3):
-        cams = camera_inputs(world, step)
-        vdist.loopback_step(shards, [c[0] for c in cams], [c[1] for c in cams])
-        vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+    for step in range(0, 4, batch):
+        frames = [camera_inputs(world, step + b) for b in range(batch)]          # frames[b][r]
+        vdist.loopback_step(shards, [[frames[b][r][0] for b in range(batch)] for r in range(world)],
+                            [[frames[b][r][1] for b in range(batch)] for r in range(world)])
+        for cams in frames:
+            vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
     for r, sh in enumerate(shards):
         lo, hi = plan.bucket_range(r)
         total += check_shard_against_full(sh.table, full, lo, hi, KW.get("bucketSize", 5))
@@ -85,7 +90,7 @@ def _free_port():
     return port
 
 
-def _gloo_worker(rank, world, port, sem, q):
+def _gloo_worker(rank, world, port, sem, q, batch=2):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         import torch.distributed as dist
@@ -93,13 +98,14 @@ def _gloo_worker(rank, world, port, sem, q):
         import oracle as O
         dist.init_process_group("gloo", rank=rank, world_size=world)
         plan = vdist.ShardPlan(KW["numBuckets"], world)
-        shard = vdist.OracleShard(O, O.default_params(**KW), W, H, sem, plan, rank, W * H + 1)
+        shard = vdist.OracleShard(O, O.default_params(**KW), W, H, sem, plan, rank, W * H + 1, batch=batch)
         full = O.OracleTable(O.default_params(**KW), W, H, sem)
         transport = vdist.TorchDistTransport()
-        for step in range(3):
-            cams = camera_inputs(world, step)
-            vdist.sharded_step(shard, transport, *cams[rank])
-            vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+        for step in range(0, 4, batch):
+            frames = [camera_inputs(world, step + b) for b in range(batch)]
+            vdist.sharded_step(shard, transport, [f[rank][0] for f in frames], [f[rank][1] for f in frames])
+            for cams in frames:
+                vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
         lo, hi = plan.bucket_range(rank)
         n = check_shard_against_full(shard.table, full, lo, hi, 5)
         dist.barrier()

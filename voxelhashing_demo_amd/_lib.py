@@ -101,9 +101,9 @@ SIGNATURES = {
     "vh_set_profiling": (C.c_int, [_vp, C.c_int]),
     "vh_get_kernel_times": (C.c_int, [_vp, C.POINTER(KernelTimes), C.c_int]),
     "vh_create_shard": (C.c_int, [C.POINTER(Config), _u32, _u32, C.POINTER(_vp)]),
-    "vh_generate_keys": (C.c_int, [_vp, _vp, _u32, _i32, _vp, _i32, _vp]),
-    "vh_insert_bins": (C.c_int, [_vp, _vp, _i32, _i32]),
-    "vh_integrate_packets": (C.c_int, [_vp, _i32, _vp]),
+    "vh_generate_keys": (C.c_int, [_vp, _vp, _u32, _i32, _vp, _i32, _i32, _vp]),
+    "vh_insert_bins": (C.c_int, [_vp, _vp, _i32, _i32, _i32]),
+    "vh_integrate_packets": (C.c_int, [_vp, _i32, _vp, C.c_size_t]),
     "updateConstantHashTableParams": (None, [C.POINTER(HashTableParams)]),
     "deviceAllocate": (None, [C.POINTER(HashTableParams)]),
     "deviceFree": (None, []),

@@ -65,6 +65,7 @@ struct vh_context {
     uint64_t profiledFrames = 0;
     vh_kernel_times times{};
     int integrateGrid = 2048;
+    bool compactArmed = false;     // alloc_commit has zeroed the compact counter and no flatten ran since
     int flattenVariant = 1;        // 0: non-temporal ptr loads, 1: plain loads (measured 7 % faster, C2)
 };
 
@@ -392,11 +393,12 @@ static int launch(vh_context *c, int phase, K kernel, dim3 grid, dim3 block, Arg
 static int launch_alloc(vh_context *c, const vh_float4 *verts)
 {
     const int npix = c->fp.width * c->fp.height;
-    int rc = launch(c, kPhaseClaim, alloc_claim_kernel<false>, dim3(grid_for(npix, 256)), dim3(256), c->fp, c->dp,
-                    reinterpret_cast<const float4 *>(verts), (int32_t)1, (int4 *)nullptr, (int32_t)0,
-                    (float *)nullptr, 0u);
+    int rc = launch(c, kPhaseClaim, alloc_claim_kernel, dim3(grid_for(npix, 256)), dim3(256), c->fp, c->dp,
+                    reinterpret_cast<const float4 *>(verts));
     if (rc != VH_OK) return rc;
-    return launch(c, kPhaseCommit, alloc_commit_kernel, dim3(32), dim3(256), c->fp, c->dp);
+    rc = launch(c, kPhaseCommit, alloc_commit_kernel, dim3(32), dim3(256), c->fp, c->dp);
+    c->compactArmed = (rc == VH_OK);
+    return rc;
 }
 
 static int launch_flatten(vh_context *c)
@@ -431,7 +433,9 @@ extern "C" int vh_flatten(vh_context *c, int32_t *occupied_out)
 {
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     DeviceGuard guard(c->device);
-    VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));   // :760
+    if (!c->compactArmed)
+        VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));   // :760
+    c->compactArmed = false;
     int rc = launch_flatten(c);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
@@ -465,6 +469,7 @@ extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4
     if (rc != VH_OK) return rc;
     // alloc_commit re-arms the compact counter, so no memset node is needed here
     if ((rc = launch_alloc(c, verts)) != VH_OK) return rc;
+    c->compactArmed = false;
     if ((rc = launch_flatten(c)) != VH_OK) return rc;
     if ((rc = launch_integrate(c, verts)) != VH_OK) return rc;
     if (c->profiling) c->profiledFrames += 1;
@@ -494,44 +499,54 @@ extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, floa
 // sharding
 // ---------------------------------------------------------------------------
 extern "C" int vh_generate_keys(vh_context *c, const vh_float4 *verts, uint32_t camera_id, int32_t num_shards,
-                                int32_t *d_bins, int32_t capacity, float *d_packet)
+                                int32_t *d_bins, int32_t capacity, int32_t bin_stride, float *d_packet)
 {
-    if (!c || !verts || !d_bins || num_shards <= 0 || capacity < 2 || camera_id >= VH_MAX_CAMERAS)
+    if (bin_stride == 0) bin_stride = capacity;
+    if (!c || !verts || !d_bins || num_shards <= 0 || capacity < 2 || bin_stride < capacity ||
+        camera_id >= VH_MAX_CAMERAS || num_shards > VH_MAX_CAMERAS)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     DeviceGuard guard(c->device);
     const int npix = c->fp.width * c->fp.height;
-    // zero the header record of every bin
-    VH_HIP(hipMemset2DAsync(d_bins, sizeof(int4) * (size_t)capacity, 0, sizeof(int4), (size_t)num_shards, c->stream));
-    if (d_packet) write_packet_header_kernel<<<1, 32, 0, c->stream>>>(c->fp, d_packet);
-    alloc_claim_kernel<true><<<grid_for(npix, 256), 256, 0, c->stream>>>(
-        c->fp, c->dp, reinterpret_cast<const float4 *>(verts), num_shards, reinterpret_cast<int4 *>(d_bins), capacity,
-        d_packet ? d_packet + kPacketHeader : nullptr, camera_id << 24);
+    // zero the header record of every bin, write the packet header
+    prepare_generate_kernel<<<1, 64, 0, c->stream>>>(c->fp, d_packet, reinterpret_cast<int4 *>(d_bins), num_shards,
+                                                     bin_stride);
+    generate_keys_kernel<<<grid_for(npix, kGenThreads), kGenThreads, 0, c->stream>>>(
+        c->fp, reinterpret_cast<const float4 *>(verts), num_shards, reinterpret_cast<int4 *>(d_bins), capacity,
+        bin_stride, d_packet ? d_packet + kPacketHeader : nullptr, camera_id << 24);
     VH_HIP(hipGetLastError());
     return VH_OK;
 }
 
-extern "C" int vh_insert_bins(vh_context *c, const int32_t *d_bins, int32_t num_bins, int32_t capacity)
+extern "C" int vh_insert_bins(vh_context *c, const int32_t *d_bins, int32_t num_bins, int32_t capacity,
+                              int32_t bin_stride)
 {
-    if (!c || !d_bins || num_bins <= 0 || capacity < 2) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    if (bin_stride == 0) bin_stride = capacity;
+    if (!c || !d_bins || num_bins <= 0 || capacity < 2 || bin_stride < capacity)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     if (c->fp.epoch == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
     DeviceGuard guard(c->device);
     int gx = grid_for((size_t)capacity, 256 * 4);
     if (gx < 1) gx = 1;
     int rc = launch(c, kPhaseClaim, claim_bins_kernel, dim3(gx, num_bins), dim3(256), c->fp, c->dp,
-                    reinterpret_cast<const int4 *>(d_bins), capacity);
+                    reinterpret_cast<const int4 *>(d_bins), capacity, bin_stride);
     if (rc == VH_OK) rc = launch(c, kPhaseCommit, alloc_commit_kernel, dim3(32), dim3(256), c->fp, c->dp);
     if (rc != VH_OK) return rc;
+    c->compactArmed = true;
     VH_HIP(hipGetLastError());
     return VH_OK;
 }
 
-extern "C" int vh_integrate_packets(vh_context *c, int32_t num_cams, const float *d_packets)
+extern "C" int vh_integrate_packets(vh_context *c, int32_t num_cams, const float *d_packets, size_t packet_stride)
 {
-    if (!c || !d_packets || num_cams <= 0 || num_cams > VH_MAX_CAMERAS)
+    const size_t dense = c ? (size_t)kPacketHeader + (size_t)c->fp.width * c->fp.height : 0;
+    if (packet_stride == 0) packet_stride = dense;
+    if (!c || !d_packets || num_cams <= 0 || num_cams > VH_MAX_CAMERAS || packet_stride < dense)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     DeviceGuard guard(c->device);
-    const size_t stride = (size_t)kPacketHeader + (size_t)c->fp.width * c->fp.height;
-    VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));
+    const size_t stride = packet_stride;
+    if (!c->compactArmed)
+        VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));
+    c->compactArmed = false;
     int rc = launch(c, kPhaseFlatten, flatten_multi_kernel,
                     dim3(grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane)), dim3(kFlattenThreads), c->fp,
                     c->dp, (uint32_t)c->numEntries, num_cams, d_packets, stride);

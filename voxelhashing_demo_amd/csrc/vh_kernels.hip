@@ -56,52 +56,82 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
 // keys to their first lane before touching the table: ~300 k pixels become a
 // few thousand bucket probes.  Within an image row the launch rank grows with
 // x, so the first lane of a run carries the run's lowest rank.
-//
-// kEmit: instead of probing, bin the surviving keys by owning shard (multi-GPU
-// key exchange, DESIGN.md "sharding").
-template <bool kEmit>
-__global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, const DevPtrs dp,
-                                                          const float4 *__restrict__ verts, int32_t numShards,
-                                                          int4 *__restrict__ outBins, int32_t outCapacity,
-                                                          float *__restrict__ outDepth, uint32_t rankBase)
+struct PixelKey {
+    int kx, ky, kz, px, py;
+    bool leader;       // first lane of a run of equal in-frustum keys in this wave
+};
+
+__device__ __forceinline__ PixelKey pixel_key(const FrameParams &fp, const float4 *__restrict__ verts, int idx,
+                                              float *__restrict__ outDepth)
 {
-    const int npix = fp.width * fp.height;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    PixelKey k{0, 0, 0, 0, 0, false};
     bool want = false;
-    int kx = 0, ky = 0, kz = 0, px = 0, py = 0;
-    if (idx < npix) {
+    if (idx < fp.width * fp.height) {
         const float4 v = verts[idx];
-        if constexpr (kEmit) {
-            if (outDepth) outDepth[idx] = v.z;       // camera-z plane of the camera packet
-        }
-        py = idx / fp.width;
-        px = idx - py * fp.width;
+        if (outDepth) outDepth[idx] = v.z;                               // camera-z plane of a camera packet
+        k.py = idx / fp.width;
+        k.px = idx - k.py * fp.width;
         if (v.z != 0.0f) {                                               // VoxelUtils.cu:621
             const float4 g = mat4_mul(fp.T, v.x, v.y, v.z, v.w);         // :622, w as stored
             const int3_ b = world2block(g.x, g.y, g.z, fp.voxelSize);    // :636
-            kx = b.x; ky = b.y; kz = b.z;
-            want = block_in_frustum(fp, kx, ky, kz);                     // :673
+            k.kx = b.x; k.ky = b.y; k.kz = b.z;
+            want = block_in_frustum(fp, k.kx, k.ky, k.kz);               // :673
         }
     }
     // run-length dedup across the wave
     const int lane = threadIdx.x & (kWave - 1);
-    const int pkx = __shfl_up(kx, 1), pky = __shfl_up(ky, 1), pkz = __shfl_up(kz, 1);
-    const int ppy = __shfl_up(py, 1);
+    const int pkx = __shfl_up(k.kx, 1), pky = __shfl_up(k.ky, 1), pkz = __shfl_up(k.kz, 1);
+    const int ppy = __shfl_up(k.py, 1);
     const int pwant = __shfl_up((int)want, 1);
-    const bool leader = want && (lane == 0 || !pwant || ppy != py || pkx != kx || pky != ky || pkz != kz);
-    if (!leader) return;
+    k.leader = want && (lane == 0 || !pwant || ppy != k.py || pkx != k.kx || pky != k.ky || pkz != k.kz);
+    return k;
+}
 
-    const uint32_t h = hash_block(kx, ky, kz, fp.numBuckets);
-    const uint32_t rank = rankBase + launch_rank(px, py, fp.width);
-    if constexpr (kEmit) {
+__global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, const DevPtrs dp,
+                                                          const float4 *__restrict__ verts)
+{
+    const PixelKey k = pixel_key(fp, verts, blockIdx.x * 256 + threadIdx.x, nullptr);
+    if (!k.leader) return;
+    const uint32_t h = hash_block(k.kx, k.ky, k.kz, fp.numBuckets);
+    if (h < fp.bucketLo || h >= fp.bucketHi) return;                     // not this shard's bucket
+    probe_and_claim(fp, dp, k.kx, k.ky, k.kz, h, launch_rank(k.px, k.py, fp.width));
+}
+
+// Key generation for the multi-GPU exchange: the same per-pixel
+// work, but the surviving keys are binned by owning shard instead of probed.  Slots in
+// a bin come from one global counter per bin; to keep that word off the critical path
+// (one address sustains only ~90 returning atomics per microsecond) a 1024-lane
+// workgroup first counts its keys per owner in LDS and then takes one global
+// atomicAdd per owner it actually has keys for.
+constexpr int kGenThreads = 1024;
+
+__global__ __launch_bounds__(kGenThreads) void generate_keys_kernel(const FrameParams fp,
+                                                                    const float4 *__restrict__ verts,
+                                                                    int32_t numShards, int4 *__restrict__ outBins,
+                                                                    int32_t outCapacity, int32_t outBinStride,
+                                                                    float *__restrict__ outDepth, uint32_t rankBase)
+{
+    __shared__ int ldsCount[VH_MAX_CAMERAS];
+    __shared__ int ldsBase[VH_MAX_CAMERAS];
+    if (threadIdx.x < VH_MAX_CAMERAS) ldsCount[threadIdx.x] = 0;
+    __syncthreads();
+    const PixelKey k = pixel_key(fp, verts, blockIdx.x * kGenThreads + threadIdx.x, outDepth);
+    uint32_t owner = 0;
+    int local = 0;
+    if (k.leader) {
         const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
-        const uint32_t owner = h / perShard;
-        int4 *bin = outBins + (size_t)owner * outCapacity;        // record 0 = {count,0,0,0}
-        const int slot = atomicAdd(&bin[0].x, 1) + 1;
-        if (slot < outCapacity) bin[slot] = make_int4(kx, ky, kz, (int)rank);
-    } else {
-        if (h < fp.bucketLo || h >= fp.bucketHi) return;                 // not this shard's bucket
-        probe_and_claim(fp, dp, kx, ky, kz, h, rank);
+        owner = hash_block(k.kx, k.ky, k.kz, fp.numBuckets) / perShard;
+        local = atomicAdd(&ldsCount[owner], 1);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < numShards && ldsCount[threadIdx.x] > 0)
+        ldsBase[threadIdx.x] = atomicAdd(&outBins[(size_t)threadIdx.x * outBinStride].x, ldsCount[threadIdx.x]);
+    __syncthreads();
+    if (k.leader) {
+        int4 *bin = outBins + (size_t)owner * outBinStride;               // record 0 = {count,0,0,0}
+        const int slot = ldsBase[owner] + local + 1;
+        if (slot < outCapacity)
+            bin[slot] = make_int4(k.kx, k.ky, k.kz, (int)(rankBase + launch_rank(k.px, k.py, fp.width)));
     }
 }
 
@@ -280,9 +310,10 @@ __global__ __launch_bounds__(256) void integrate_kernel(const FrameParams fp, co
 // record 0 = {count,0,0,0}, records 1..count = {x,y,z,rank}.  One lock epoch for all
 // bins; rank = camera<<24 | launch rank, so cameras are served in order.
 __global__ __launch_bounds__(256) void claim_bins_kernel(const FrameParams fp, const DevPtrs dp,
-                                                         const int4 *__restrict__ bins, int32_t capacity)
+                                                         const int4 *__restrict__ bins, int32_t capacity,
+                                                         int32_t binStride)
 {
-    const int4 *bin = bins + (size_t)blockIdx.y * capacity;
+    const int4 *bin = bins + (size_t)blockIdx.y * binStride;
     int n = bin[0].x;
     if (n > capacity - 1) {
         if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(dp.counters + kBinOverflow, 1);
@@ -373,12 +404,18 @@ __global__ __launch_bounds__(256) void integrate_multi_kernel(const FrameParams 
     }
 }
 
-// camera packet header: pose and inverse (the z plane is written by alloc_claim_kernel<true>)
-__global__ void write_packet_header_kernel(const FrameParams fp, float *packet)
+// Runs right before generate_keys_kernel: zeroes the header record of every bin and
+// writes the camera packet header (pose, inverse); the z plane is written by
+// generate_keys_kernel itself.
+__global__ void prepare_generate_kernel(const FrameParams fp, float *packet, int4 *bins, int32_t numShards,
+                                        int32_t binStride)
 {
     const int i = threadIdx.x;
-    if (i < 16) packet[i] = fp.T[i];
-    else if (i < 32) packet[i] = fp.Tinv[i - 16];
+    if (packet) {
+        if (i < 16) packet[i] = fp.T[i];
+        else if (i < 32) packet[i] = fp.Tinv[i - 16];
+    }
+    if (i >= 32 && i - 32 < numShards) bins[(size_t)(i - 32) * binStride] = make_int4(0, 0, 0, 0);
 }
 
 // ---------------------------------------------------------------------------

@@ -85,93 +85,112 @@ class LoopbackExchange:
         self.packets = [None] * world
 
     def post(self, rank: int, bins, packet):
-        self.bins[rank], self.packets[rank] = bins, packet
+        self.bins[rank], self.packets[rank] = bins.clone(), packet.clone()
 
-    def fetch(self, rank: int):
+    def fetch(self, rank: int, bins_recv, packets_out):
         import torch
-        recv = torch.stack([self.bins[src][rank] for src in range(self.world)])      # all-to-all
-        packets = torch.stack(self.packets)                                            # all-gather
-        return recv.contiguous(), packets.contiguous()
+        bins_recv.copy_(torch.stack([self.bins[src][rank] for src in range(self.world)]))     # all-to-all
+        packets_out.copy_(torch.stack(self.packets))                                           # all-gather
 
 
 # ----------------------------------------------------------------------------
 # backends
 # ----------------------------------------------------------------------------
+# Buffers carry `batch` frames per camera so that one all-to-all and one all-gather move
+# several multi-camera frames (fewer, larger collectives: their latency and the host cost of
+# issuing them are paid once per batch).  The frames of a batch are still applied one
+# multi-camera frame after the other, in order, so results do not depend on the batch size.
+#   bins_send[dst, b], bins_recv[src, b] : [capacity, 4] int32 key bins
+#   packet[b], packets[cam, b]           : [32 + W*H] float32 camera packets
 class HipShard:
     """This rank's shard on its GPU (libvoxelhash_hip.so through the C-ABI)."""
 
     def __init__(self, params, width, height, semantics, plan: ShardPlan, rank: int, capacity: int,
-                 device=None, stream=None):
+                 batch: int = 1, device=None, stream=None):
         import torch
 
         from .hashtable import SDFHashtable
-        self.torch = torch
-        self.plan, self.rank, self.capacity = plan, rank, capacity
+        self.plan, self.rank, self.capacity, self.batch = plan, rank, capacity, batch
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.table = SDFHashtable(params, width, height, semantics, device=self.device.index,
                                   bucket_range=plan.bucket_range(rank), stream=stream)
-        self.packet_floats = 32 + width * height
-        R = plan.world
-        self.bins_send = torch.zeros((R, capacity, 4), dtype=torch.int32, device=self.device)
-        self.bins_recv = torch.zeros((R, capacity, 4), dtype=torch.int32, device=self.device)
-        self.packet = torch.zeros(self.packet_floats, dtype=torch.float32, device=self.device)
-        self.packets = torch.zeros((R, self.packet_floats), dtype=torch.float32, device=self.device)
+        self.packet_floats = P = 32 + width * height
+        R, B = plan.world, batch
+        self.bins_send = torch.zeros((R, B, capacity, 4), dtype=torch.int32, device=self.device)
+        self.bins_recv = torch.zeros((R, B, capacity, 4), dtype=torch.int32, device=self.device)
+        self.packet = torch.zeros((B, P), dtype=torch.float32, device=self.device)
+        self.packets = torch.zeros((R, B, P), dtype=torch.float32, device=self.device)
+        self._send_b = [self.bins_send[0, b].data_ptr() for b in range(B)]
+        self._recv_b = [self.bins_recv[0, b].data_ptr() for b in range(B)]
+        self._packet_b = [self.packet[b].data_ptr() for b in range(B)]
+        self._packets_b = [self.packets[0, b].data_ptr() for b in range(B)]
 
-    def generate(self, pose, verts):
+    def generate(self, b: int, pose, verts):
         self.table.set_pose(pose)
-        self.table.generate_keys(verts, self.rank, self.plan.world, self.bins_send, self.capacity, self.packet)
-        return self.bins_send, self.packet
+        self.table.generate_keys(verts, self.rank, self.plan.world, self._send_b[b], self.capacity,
+                                 self._packet_b[b], bin_stride=self.batch * self.capacity)
 
-    def apply(self, bins_recv, packets):
+    def apply(self, b: int):
         self.table.reset_mutexes()
-        self.table.insert_bins(bins_recv, bins_recv.shape[0], self.capacity)
-        self.table.integrate_packets(packets.shape[0], packets)
+        self.table.insert_bins(self._recv_b[b], self.plan.world, self.capacity, bin_stride=self.batch * self.capacity)
+        self.table.integrate_packets(self.plan.world, self._packets_b[b], packet_stride=self.batch * self.packet_floats)
 
 
 class OracleShard:
-    """The same interface on the CPU oracle (tests only; numpy in, CPU tensors out)."""
+    """The same interface on the CPU oracle (tests only; the buffers are CPU tensors)."""
 
-    def __init__(self, oracle_module, params, width, height, semantics, plan: ShardPlan, rank: int, capacity: int):
+    def __init__(self, oracle_module, params, width, height, semantics, plan: ShardPlan, rank: int, capacity: int,
+                 batch: int = 1):
         import torch
-        self.torch = torch
-        self.plan, self.rank, self.capacity = plan, rank, capacity
+        self.plan, self.rank, self.capacity, self.batch = plan, rank, capacity, batch
         self.table = oracle_module.OracleTable(params, width, height, semantics, bucket_range=plan.bucket_range(rank))
-        self.packet_floats = 32 + width * height
-        R = plan.world
-        self.bins_recv = torch.zeros((R, capacity, 4), dtype=torch.int32)
-        self.packets = torch.zeros((R, self.packet_floats), dtype=torch.float32)
+        self.packet_floats = P = 32 + width * height
+        R, B = plan.world, batch
+        self.bins_send = torch.zeros((R, B, capacity, 4), dtype=torch.int32)
+        self.bins_recv = torch.zeros((R, B, capacity, 4), dtype=torch.int32)
+        self.packet = torch.zeros((B, P), dtype=torch.float32)
+        self.packets = torch.zeros((R, B, P), dtype=torch.float32)
 
-    def generate(self, pose, verts):
+    def generate(self, b: int, pose, verts):
+        import torch
         self.table.set_pose(pose)
         bins, packet = self.table.generate_keys(np.asarray(verts), self.rank, self.plan.world, self.capacity)
-        return self.torch.from_numpy(bins), self.torch.from_numpy(packet)
+        self.bins_send[:, b] = torch.from_numpy(bins)
+        self.packet[b] = torch.from_numpy(packet)
 
-    def apply(self, bins_recv, packets):
+    def apply(self, b: int):
         self.table.reset_mutexes()
-        self.table.insert_bins(bins_recv.numpy())
-        self.table.integrate_packets(packets.numpy())
+        self.table.insert_bins(self.bins_recv[:, b].contiguous().numpy())
+        self.table.integrate_packets(self.packets[:, b].contiguous().numpy())
 
 
 # ----------------------------------------------------------------------------
 # the step
 # ----------------------------------------------------------------------------
-def sharded_step(shard, transport: TorchDistTransport, pose, verts):
-    """One multi-camera frame from this rank's point of view."""
-    bins, packet = shard.generate(pose, verts)
-    recv = transport.all_to_all_bins(bins, shard.bins_recv)
-    packets = transport.all_gather_packets(packet, shard.packets)
-    shard.apply(recv, packets)
+def sharded_step(shard, transport: TorchDistTransport, poses, verts_list):
+    """`batch` multi-camera frames from this rank's point of view: poses[b], verts_list[b] are this
+    rank's camera for frame b of the batch."""
+    assert len(poses) == shard.batch == len(verts_list)
+    for b in range(shard.batch):
+        shard.generate(b, poses[b], verts_list[b])
+    transport.all_to_all_bins(shard.bins_send, shard.bins_recv)
+    transport.all_gather_packets(shard.packet.view(-1), shard.packets.view(shard.plan.world, -1))
+    for b in range(shard.batch):
+        shard.apply(b)
 
 
 def loopback_step(shards, poses, verts_list):
-    """The same step with every rank played in this process (no collective library)."""
+    """The same step with every rank played in this process (no collective library):
+    poses[r][b], verts_list[r][b]."""
     ex = LoopbackExchange(len(shards))
     for r, sh in enumerate(shards):
-        bins, packet = sh.generate(poses[r], verts_list[r])
-        ex.post(r, bins.clone(), packet.clone())
+        for b in range(sh.batch):
+            sh.generate(b, poses[r][b], verts_list[r][b])
+        ex.post(r, sh.bins_send, sh.packet)
     for r, sh in enumerate(shards):
-        recv, packets = ex.fetch(r)
-        sh.apply(recv, packets)
+        ex.fetch(r, sh.bins_recv, sh.packets)
+        for b in range(sh.batch):
+            sh.apply(b)
 
 
 def reference_multi_camera_frame(table, poses, verts_list):
@@ -209,7 +228,9 @@ def bench_sharded(args, wl, rank, world, local_rank):
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.Stream(device=dev)
     plan = ShardPlan(wl["buckets"], world)
-    capacity = 4096
+    # one record per 8 pixels of this camera's image, split over the owners (2x the ~1 per 16
+    # pixels a wave-deduplicated room frame produces); overflow is counted and reported
+    capacity = max(1024, -(-Wd * Ht // (8 * world)))
     poses = synth.camera_loop(wl["frames"], phase=camera_phase(rank, world))[:nframes]
     prims = synth.room_primitives()
     verts = torch.empty((nframes, Ht, Wd, 4), dtype=torch.float32, device=dev)
@@ -218,12 +239,13 @@ def bench_sharded(args, wl, rank, world, local_rank):
     torch.cuda.synchronize()
     params = default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
     transport = TorchDistTransport()
+    batch = max(1, args.batch)
     with torch.cuda.stream(stream):
-        shard = HipShard(params, Wd, Ht, SEM_PINHOLE, plan, rank, capacity, device=dev, stream=stream)
+        shard = HipShard(params, Wd, Ht, SEM_PINHOLE, plan, rank, capacity, batch=batch, device=dev, stream=stream)
 
         def step(i):
-            k = i % nframes
-            sharded_step(shard, transport, poses[k], verts[k])
+            ks = [(i * batch + b) % nframes for b in range(batch)]
+            sharded_step(shard, transport, [poses[k] for k in ks], [verts[k] for k in ks])
 
         for i in range(args.warmup):
             step(i)
@@ -244,7 +266,7 @@ def bench_sharded(args, wl, rank, world, local_rank):
     stats = torch.tensor([c["occupied"], c["allocated_total"], c["bin_overflow"]], dtype=torch.int64, device=dev)
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     if rank == 0:
-        frames = args.steps * world
+        frames = args.steps * world * batch
         out = dict(
             metric="frames/s TSDF-integrated, 640x480" if (Wd, Ht) == (640, 480) else f"frames/s TSDF-integrated, {Wd}x{Ht}",
             value=round(frames / elapsed, 1), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -253,7 +275,8 @@ def bench_sharded(args, wl, rank, world, local_rank):
             config=dict(workload=f"C4-style: {world} virtual {Wd}x{Ht} cameras (one per GPU) into one scene, "
                                  f"2^{int(math.log2(wl['buckets']))} buckets sharded by bucket range over {world} GPUs, "
                                  "RCCL all-to-all of block keys + all-gather of depth packets per step, PINHOLE",
-                        frames_per_step=world, resident_frames=nframes, key_bin_capacity=capacity,
+                        frames_per_step=world * batch, frames_per_camera_per_exchange=batch,
+                        resident_frames=nframes, key_bin_capacity=capacity,
                         occupied_blocks_all_ranks=int(stats[0]), allocated_blocks_all_ranks=int(stats[1]),
                         key_bin_overflows=int(stats[2])),
             roofline=None, cpu_baseline=None)

@@ -126,16 +126,19 @@ class SDFHashtable:
         L.check(self._lib.vh_integrate_depth_map(self._h, _dev_ptr(verts)), "vh_integrate_depth_map")
 
     # ---- sharding ----
-    def generate_keys(self, verts, camera_id: int, num_shards: int, bins_out, capacity: int, packet_out=None):
-        """Key bins [num_shards, capacity, 4] int32 (+ the camera packet) for the pose set with set_pose()."""
+    def generate_keys(self, verts, camera_id: int, num_shards: int, bins_out, capacity: int, packet_out=None,
+                      bin_stride: int = 0):
+        """Key bins (capacity records each, `bin_stride` records apart) + the camera packet for the
+        pose set with set_pose().  bins_out / packet_out: device tensors or raw addresses."""
         L.check(self._lib.vh_generate_keys(self._h, _dev_ptr(verts), camera_id, num_shards, _dev_ptr(bins_out),
-                                           capacity, _dev_ptr(packet_out)), "vh_generate_keys")
+                                           capacity, bin_stride, _dev_ptr(packet_out)), "vh_generate_keys")
 
-    def insert_bins(self, bins, num_bins: int, capacity: int):
-        L.check(self._lib.vh_insert_bins(self._h, _dev_ptr(bins), num_bins, capacity), "vh_insert_bins")
+    def insert_bins(self, bins, num_bins: int, capacity: int, bin_stride: int = 0):
+        L.check(self._lib.vh_insert_bins(self._h, _dev_ptr(bins), num_bins, capacity, bin_stride), "vh_insert_bins")
 
-    def integrate_packets(self, num_cams: int, packets):
-        L.check(self._lib.vh_integrate_packets(self._h, num_cams, _dev_ptr(packets)), "vh_integrate_packets")
+    def integrate_packets(self, num_cams: int, packets, packet_stride: int = 0):
+        L.check(self._lib.vh_integrate_packets(self._h, num_cams, _dev_ptr(packets), packet_stride),
+                "vh_integrate_packets")
 
     # ---- queries ----
     def synchronize(self):
