@@ -130,23 +130,34 @@ def main():
     table.set_profiling(False)
     occ = table.counters()["occupied"]
     n_entries = table.num_entries
-    flatten_us = 1e3 * kt["flatten_ms"] / max(1, kt["launches"])
-    # algorithmic bytes of one flatten launch: one pass over the VoxelEntry
-    # array + the compact entries written
-    flatten_bytes = 20 * n_entries + 20 * occ
-    achieved = flatten_bytes / (flatten_us * 1e-6) / 1e9
+    fused = kt["frame_scan_claim_ms"] > 0
+    if fused:
+        # dominant kernel of the fused frame: per-pixel claim phase || walk over the VoxelEntry
+        # array.  Algorithmic bytes of one launch (SURVEY.md 8(d) terms): the vertex map read once
+        # by the claim half (16*W*H), one pass over the table (20*N), the compact entries written
+        # (20*occ) and one 100-byte bucket probe per distinct block key (keys ~ occ).
+        kname = "frame_scan_claim_kernel"
+        dom_us = 1e3 * kt["frame_scan_claim_ms"] / max(1, kt["launches"])
+        dom_bytes = 16 * Wd * Ht + 20 * n_entries + 20 * occ + 100 * occ
+    else:
+        # algorithmic bytes of one flatten launch: one pass over the VoxelEntry array + the
+        # compact entries written
+        kname = "flatten_kernel"
+        dom_us = 1e3 * kt["flatten_ms"] / max(1, kt["launches"])
+        dom_bytes = 20 * n_entries + 20 * occ
+    achieved = dom_bytes / (dom_us * 1e-6) / 1e9
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc_file)).get(args.workload, {}).get("flatten_kernel_hbm_bytes_per_launch")
+            traffic = json.load(open(pmc_file)).get(args.workload, {}).get(kname + "_hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = dict(bound="hbm", kernel="flatten_kernel", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                     unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    bytes_per_launch=flatten_bytes, us_per_launch=round(flatten_us, 2))
+                    bytes_per_launch=dom_bytes, us_per_launch=round(dom_us, 2))
     kernels_us = {k[:-3] + "_us": round(1e3 * v / max(1, kt["launches"]), 2)
-                  for k, v in kt.items() if k.endswith("_ms") and k != "raycast_ms"}
+                  for k, v in kt.items() if k.endswith("_ms") and k != "raycast_ms" and v > 0}
     # algorithmic bytes of the whole frame (SURVEY.md 8(d) B_frame; no mutex memset in this build)
     keys = occ   # distinct in-frustum block keys of a frame ~ occupied blocks (not counted on the device)
     b_frame = 16 * Wd * Ht + 4 * Wd * Ht + 20 * n_entries + 20 * occ + occ * (20 + 4096 + 4096) + 100 * keys

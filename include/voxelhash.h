@@ -133,6 +133,8 @@ typedef struct vh_kernel_times {
     double   integrate_ms;
     double   raycast_ms;
     uint64_t raycast_launches;
+    double   frame_scan_claim_ms;        /* fused vh_integrate, launch 1: claim || table walk */
+    double   frame_commit_integrate_ms;  /* fused vh_integrate, launch 2: commit + TSDF update */
 } vh_kernel_times;
 
 typedef struct vh_context vh_context;
@@ -198,7 +200,8 @@ int vh_download(vh_context *ctx, int which, void *host_dst, size_t bytes);  /* s
  * point: block x,y,z, hash, blockInFrustum, project() x,y, float->int of .w */
 int vh_debug_eval(vh_context *ctx, const vh_float4 *d_points, int32_t n, int32_t *d_out);
 
-/* tuning knobs for A/B measurements ("flatten_variant", "integrate_grid"); results never change */
+/* tuning knobs for A/B measurements ("fused_frame", "flatten_variant", "integrate_grid",
+ * "commit_blocks"); results never change */
 int vh_set_option(vh_context *ctx, const char *name, int value);
 int vh_set_profiling(vh_context *ctx, int enabled);
 int vh_get_kernel_times(vh_context *ctx, vh_kernel_times *out, int reset);  /* synchronises */

@@ -17,11 +17,23 @@ TOL = 1e-4            # north_star: "TSDF within 1e-4 of reference"
 I4 = np.eye(4, dtype=np.float32)
 
 
+_FUSED = {"on": 1}
+
+
+@pytest.fixture(autouse=True, params=["fused", "four-kernel"])
+def frame_variant(request):
+    """Every test runs twice: vh_integrate as the fused two-launch frame (default) and as the
+    four step kernels (alloc claim / commit / flatten / integrate)."""
+    _FUSED["on"] = 1 if request.param == "fused" else 0
+    yield request.param
+
+
 def _pair(oracle, vh, sem, W=640, H=480, **over):
     kw = dict(numBuckets=1 << 17, numVoxelBlocks=4096)
     kw.update(over)
     ot = oracle.OracleTable(oracle.default_params(**kw), W, H, sem)
     gt = vh.SDFHashtable(vh.default_params(**kw), W, H, sem)
+    gt.set_option("fused_frame", _FUSED["on"])
     return ot, gt
 
 

@@ -57,7 +57,8 @@ class Counters(C.Structure):
 class KernelTimes(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("alloc_claim_ms", C.c_double), ("alloc_commit_ms", C.c_double),
                 ("flatten_ms", C.c_double), ("integrate_ms", C.c_double), ("raycast_ms", C.c_double),
-                ("raycast_launches", C.c_uint64)]
+                ("raycast_launches", C.c_uint64), ("frame_scan_claim_ms", C.c_double),
+                ("frame_commit_integrate_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -44,7 +44,10 @@ static int fail(int code, const char *what, hipError_t e = hipSuccess)
 // the pair carries the begin/end timestamps of that kernel alone, the same
 // quantity rocprofv3 --kernel-trace reports, without the inter-kernel gaps a
 // hipEventRecord pair would add.
-enum Phase : int { kPhaseClaim = 0, kPhaseCommit, kPhaseFlatten, kPhaseIntegrate, kPhaseRaycast, kNumPhases };
+enum Phase : int {
+    kPhaseClaim = 0, kPhaseCommit, kPhaseFlatten, kPhaseIntegrate, kPhaseRaycast,
+    kPhaseFrameScanClaim, kPhaseFrameCommitIntegrate, kNumPhases
+};
 
 struct TimedLaunch {
     int phase;
@@ -65,6 +68,9 @@ struct vh_context {
     uint64_t profiledFrames = 0;
     vh_kernel_times times{};
     int integrateGrid = 2048;
+    int fusedFrame = 1;            // vh_integrate as two launches (0: the four step kernels)
+    int commitBlocks = 128;        // workgroups serving candidates in the fused second launch
+    int fusedParity = 0;           // which of the two per-frame counter sets the next fused frame uses
     bool compactArmed = false;     // alloc_commit has zeroed the compact counter and no flatten ran since
     int flattenVariant = 1;        // 0: non-temporal ptr loads, 1: plain loads (measured 7 % faster, C2)
 };
@@ -467,11 +473,28 @@ extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4
     int rc = vh_set_pose(c, pose);
     if (rc == VH_OK) rc = vh_reset_mutexes(c);
     if (rc != VH_OK) return rc;
-    // alloc_commit re-arms the compact counter, so no memset node is needed here
-    if ((rc = launch_alloc(c, verts)) != VH_OK) return rc;
-    c->compactArmed = false;
-    if ((rc = launch_flatten(c)) != VH_OK) return rc;
-    if ((rc = launch_integrate(c, verts)) != VH_OK) return rc;
+    if (c->fusedFrame) {
+        // two launches: {claim || table walk}, then {commit + integrate}; see vh_kernels.hip
+        const uint32_t claimBlocks = (uint32_t)grid_for((size_t)c->fp.width * c->fp.height, 256);
+        const uint32_t scanBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
+        rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel, dim3(claimBlocks + scanBlocks), dim3(256), c->fp,
+                    c->dp, reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
+                    c->fusedParity);
+        if (rc != VH_OK) return rc;
+        const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
+        rc = launch(c, kPhaseFrameCommitIntegrate, frame_commit_integrate_kernel,
+                    dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp,
+                    reinterpret_cast<const float4 *>(verts), commitBlocks, c->fusedParity);
+        if (rc != VH_OK) return rc;
+        c->fusedParity ^= 1;       // this frame cleared the other counter set for the next one
+        c->compactArmed = false;
+    } else {
+        // alloc_commit re-arms the compact counter, so no memset node is needed here
+        if ((rc = launch_alloc(c, verts)) != VH_OK) return rc;
+        c->compactArmed = false;
+        if ((rc = launch_flatten(c)) != VH_OK) return rc;
+        if ((rc = launch_integrate(c, verts)) != VH_OK) return rc;
+    }
     if (c->profiling) c->profiledFrames += 1;
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -632,6 +655,8 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (!c || !name) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     if (std::strcmp(name, "flatten_variant") == 0) { c->flattenVariant = value; return VH_OK; }
     if (std::strcmp(name, "integrate_grid") == 0 && value > 0) { c->integrateGrid = value; return VH_OK; }
+    if (std::strcmp(name, "fused_frame") == 0) { c->fusedFrame = value; return VH_OK; }
+    if (std::strcmp(name, "commit_blocks") == 0 && value > 0) { c->commitBlocks = value; return VH_OK; }
     return fail(VH_ERR_INVALID_ARGUMENT, "unknown option");
 }
 
@@ -656,6 +681,8 @@ extern "C" int vh_get_kernel_times(vh_context *c, vh_kernel_times *out, int rese
             case kPhaseFlatten: c->times.flatten_ms += ms; break;
             case kPhaseIntegrate: c->times.integrate_ms += ms; break;
             case kPhaseRaycast: c->times.raycast_ms += ms; c->times.raycast_launches += 1; break;
+            case kPhaseFrameScanClaim: c->times.frame_scan_claim_ms += ms; break;
+            case kPhaseFrameCommitIntegrate: c->times.frame_commit_integrate_ms += ms; break;
             default: break;
         }
     }

@@ -29,7 +29,13 @@ enum Counter : int {
     kLastCandidates = 5,
     kCommitTicket = 6,
     kBinOverflow = 7,      // a received key bin carried more keys than its capacity
-    kNumCounters = 8
+    // fused frame: per-frame counters, double-buffered by epoch parity so that no workgroup
+    // has to wait for all others before they can be re-armed (frame f's second launch
+    // clears the set frame f+1 will use)
+    kScanCount = 8,        // [2] entries found by the table walk
+    kNewCount = 10,        // [2] entries inserted (and appended) by the commit phase
+    kFusedCand = 12,       // [2] contenders recorded by the claim phase
+    kNumCounters = 16
 };
 
 // Everything a kernel needs about the frame, passed by value in the kernel

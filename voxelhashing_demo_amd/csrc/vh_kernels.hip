@@ -29,7 +29,7 @@ namespace vh {
 // first free slot, nothing is ever deleted), so "present anywhere" equals the
 // reference's in-order scan.
 __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz,
-                                                uint32_t h, uint32_t rank)
+                                                uint32_t h, uint32_t rank, int candCounter = kCandCount)
 {
     const VoxelEntry *bucket = dp.table + (size_t)(h - fp.bucketLo) * fp.bucketSize;
     bool has_free = false;
@@ -43,7 +43,7 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
     }
     if (!has_free) return;               // bucket full: the key is dropped (no overflow list)
     atomicMax(dp.claim + (h - fp.bucketLo), claim_word(fp.epoch, rank));
-    const uint32_t slot = (uint32_t)atomicAdd(dp.counters + kCandCount, 1);
+    const uint32_t slot = (uint32_t)atomicAdd(dp.counters + candCounter, 1);
     if (slot < dp.candCapacity) dp.candidates[slot] = make_int4(kx, ky, kz, (int)rank);
 }
 
@@ -143,33 +143,40 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_kernel(const FrameP
 // reference grid would have let through the atomicExch (VoxelUtils.cu:444-445).
 // It takes the first free slot and pops the heap (top-down, :328-334).  An empty
 // heap refuses the insertion instead of reading heap[-1].
+// Returns true (and the new entry) if candidate k held its bucket's claim and was inserted.
+__device__ __forceinline__ bool commit_candidate(const FrameParams &fp, const DevPtrs &dp, const int4 k,
+                                                 VoxelEntry &e)
+{
+    const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
+    const uint32_t local = h - fp.bucketLo;
+    if (dp.claim[local] != claim_word(fp.epoch, (uint32_t)k.w)) return false;   // lost the bucket this frame
+    dp.claim[local] = consumed_word(fp.epoch);                                   // locked until the next epoch
+    VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
+    for (uint32_t s = 0; s < fp.bucketSize; ++s) {
+        if (bucket[s].ptr != VH_FREE_BLOCK) continue;
+        const int addr = atomicSub(dp.counters + kHeapCounter, 1);
+        if (addr < 0) {                                   // heap empty: undo, refuse
+            atomicAdd(dp.counters + kHeapCounter, 1);
+            atomicAdd(dp.counters + kHeapExhausted, 1);
+            return false;
+        }
+        e.pos[0] = k.x; e.pos[1] = k.y; e.pos[2] = k.z;
+        e.ptr = (int)(dp.heap[addr] * (uint32_t)kBlockVoxels);
+        e.offset = 0;
+        bucket[s] = e;
+        atomicAdd(dp.counters + kAllocatedTotal, 1);
+        return true;
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(256) void alloc_commit_kernel(const FrameParams fp, const DevPtrs dp)
 {
     int n = dp.counters[kCandCount];
     if ((uint32_t)n > dp.candCapacity) n = (int)dp.candCapacity;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int4 k = dp.candidates[i];
-        const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
-        const uint32_t local = h - fp.bucketLo;
-        if (dp.claim[local] != claim_word(fp.epoch, (uint32_t)k.w)) continue;   // lost the bucket this frame
-        dp.claim[local] = consumed_word(fp.epoch);                               // locked until the next epoch
-        VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
-        for (uint32_t s = 0; s < fp.bucketSize; ++s) {
-            if (bucket[s].ptr != VH_FREE_BLOCK) continue;
-            const int addr = atomicSub(dp.counters + kHeapCounter, 1);
-            if (addr < 0) {                                   // heap empty: undo, refuse
-                atomicAdd(dp.counters + kHeapCounter, 1);
-                atomicAdd(dp.counters + kHeapExhausted, 1);
-                break;
-            }
-            VoxelEntry e;
-            e.pos[0] = k.x; e.pos[1] = k.y; e.pos[2] = k.z;
-            e.ptr = (int)(dp.heap[addr] * (uint32_t)kBlockVoxels);
-            e.offset = 0;
-            bucket[s] = e;
-            atomicAdd(dp.counters + kAllocatedTotal, 1);
-            break;
-        }
+        VoxelEntry e;
+        (void)commit_candidate(fp, dp, dp.candidates[i], e);
     }
     // the last workgroup to finish re-arms the per-frame counters
     __syncthreads();
@@ -200,10 +207,10 @@ constexpr int kFlattenThreads = 256;
 constexpr int kEntriesPerLane = 8;
 
 template <bool kNonTemporal>
-__global__ __launch_bounds__(kFlattenThreads) void flatten_kernel(const FrameParams fp, const DevPtrs dp,
-                                                                  uint32_t numEntries)
+__device__ __forceinline__ void flatten_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
+                                             uint32_t tileIndex, int counter)
 {
-    const uint32_t tile = blockIdx.x * (kFlattenThreads * kEntriesPerLane);
+    const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
     const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
     int32_t ptrs[kEntriesPerLane];
 #pragma unroll
@@ -232,13 +239,20 @@ __global__ __launch_bounds__(kFlattenThreads) void flatten_kernel(const FramePar
         if (mask == 0ull) continue;
         int base = 0;
         const int leaderLane = __ffsll((long long)mask) - 1;
-        if (lane == leaderLane) base = atomicAdd(dp.counters + kCompactCount, __popcll(mask));
+        if (lane == leaderLane) base = atomicAdd(dp.counters + counter, __popcll(mask));
         base = __shfl(base, leaderLane);
         if (hit) {
             const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
             dp.compact[base + prefix] = ent;
         }
     }
+}
+
+template <bool kNonTemporal>
+__global__ __launch_bounds__(kFlattenThreads) void flatten_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                  uint32_t numEntries)
+{
+    flatten_tile<kNonTemporal>(fp, dp, numEntries, blockIdx.x, kCompactCount);
 }
 
 // ---------------------------------------------------------------------------
@@ -282,24 +296,99 @@ __device__ __forceinline__ bool tsdf_update(const FrameParams &fp, const float *
     return true;
 }
 
+// the 256 lanes of a workgroup update the 8^3 block of entry e from the float4 vertex map
+__device__ __forceinline__ void integrate_block(const FrameParams &fp, const DevPtrs &dp, const VoxelEntry &e,
+                                                const float4 *__restrict__ verts)
+{
+    const int lin = 2 * (int)threadIdx.x;        // linearizeVoxelPos: z*64 + y*8 + x  (:311-317)
+    const int tx = lin & 7, ty = (lin >> 3) & 7, tz = lin >> 6;
+    const int bx = (int)((uint32_t)e.pos[0] * 8u) + tx;     // block2Voxel + threadIdx (:793-796)
+    const int by = (int)((uint32_t)e.pos[1] * 8u) + ty;
+    const int bz = (int)((uint32_t)e.pos[2] * 8u) + tz;
+    float4 *cell = reinterpret_cast<float4 *>(dp.blocks + (size_t)e.ptr + lin);
+    float4 v = *cell;                            // {sdf0, w0, sdf1, w1}
+    const float *depthBase = reinterpret_cast<const float *>(verts) + 2;   // &verts[0].z
+    const bool u0 = tsdf_update(fp, fp.Tinv, depthBase, 4, bx, by, bz, v.x, v.y);
+    const bool u1 = tsdf_update(fp, fp.Tinv, depthBase, 4, bx + 1, by, bz, v.z, v.w);
+    if (u0 || u1) *cell = v;
+}
+
 __global__ __launch_bounds__(256) void integrate_kernel(const FrameParams fp, const DevPtrs dp,
                                                         const float4 *__restrict__ verts)
 {
     const int count = dp.counters[kCompactCount];
-    const int t = threadIdx.x;
-    const int lin = 2 * t;                       // linearizeVoxelPos: z*64 + y*8 + x  (:311-317)
-    const int tx = lin & 7, ty = (lin >> 3) & 7, tz = lin >> 6;
-    for (int b = blockIdx.x; b < count; b += gridDim.x) {
-        const VoxelEntry e = dp.compact[b];
-        const int bx = (int)((uint32_t)e.pos[0] * 8u) + tx;     // block2Voxel + threadIdx (:793-796)
-        const int by = (int)((uint32_t)e.pos[1] * 8u) + ty;
-        const int bz = (int)((uint32_t)e.pos[2] * 8u) + tz;
-        float4 *cell = reinterpret_cast<float4 *>(dp.blocks + (size_t)e.ptr + lin);
-        float4 v = *cell;                        // {sdf0, w0, sdf1, w1}
-        const float *depthBase = reinterpret_cast<const float *>(verts) + 2;   // &verts[0].z
-        const bool u0 = tsdf_update(fp, fp.Tinv, depthBase, 4, bx, by, bz, v.x, v.y);
-        const bool u1 = tsdf_update(fp, fp.Tinv, depthBase, 4, bx + 1, by, bz, v.z, v.w);
-        if (u0 || u1) *cell = v;
+    for (int b = blockIdx.x; b < count; b += gridDim.x) integrate_block(fp, dp, dp.compact[b], verts);
+}
+
+// ---------------------------------------------------------------------------
+// the fused frame: SDF_Hashtable::integrate in two launches
+// ---------------------------------------------------------------------------
+// Launch 1 runs the per-pixel claim phase and the table walk side by side: both only
+// READ the hash table (claims go to the claim words, hits to the compact list), so the
+// latency-bound pixel work hides under the bandwidth-bound walk.  The walk therefore
+// sees the table as it was at the start of the frame; the entries this frame inserts
+// are appended to the compact list by launch 2 -- they pass the frustum test by
+// construction (allocBlocks tested the same key against the same pose, :673 / :732).
+__global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams fp, const DevPtrs dp,
+                                                               const float4 *__restrict__ verts,
+                                                               uint32_t numEntries, uint32_t claimBlocks,
+                                                               int parity)
+{
+    if (blockIdx.x < claimBlocks) {
+        const PixelKey k = pixel_key(fp, verts, blockIdx.x * 256 + threadIdx.x, nullptr);
+        if (!k.leader) return;
+        const uint32_t h = hash_block(k.kx, k.ky, k.kz, fp.numBuckets);
+        if (h < fp.bucketLo || h >= fp.bucketHi) return;
+        probe_and_claim(fp, dp, k.kx, k.ky, k.kz, h, launch_rank(k.px, k.py, fp.width), kFusedCand + parity);
+    } else {
+        flatten_tile<false>(fp, dp, numEntries, blockIdx.x - claimBlocks, kScanCount + parity);
+    }
+}
+
+// Launch 2: the first commitBlocks workgroups serve the candidates (one candidate per
+// workgroup pass: lane 0 inserts, then all 256 lanes integrate the new block and it is
+// appended to the compact list); the others stride over the entries the walk found.
+// Only the commit workgroups take a ticket (a word that every workgroup of a large grid
+// increments costs tens of microseconds): the last of them publishes the occupied count
+// and clears the counter set of the other parity for the next frame.
+__global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                     const float4 *__restrict__ verts,
+                                                                     uint32_t commitBlocks, int parity)
+{
+    const int scanCount = dp.counters[kScanCount + parity];
+    if (blockIdx.x >= commitBlocks) {
+        for (int b = blockIdx.x - commitBlocks; b < scanCount; b += gridDim.x - commitBlocks)
+            integrate_block(fp, dp, dp.compact[b], verts);
+        return;
+    }
+    __shared__ VoxelEntry newEntry;
+    __shared__ int inserted;
+    int n = dp.counters[kFusedCand + parity];
+    if ((uint32_t)n > dp.candCapacity) n = (int)dp.candCapacity;
+    for (int i = blockIdx.x; i < n; i += commitBlocks) {
+        if (threadIdx.x == 0) {
+            VoxelEntry e;
+            inserted = commit_candidate(fp, dp, dp.candidates[i], e) ? 1 : 0;
+            if (inserted) {
+                newEntry = e;
+                dp.compact[scanCount + atomicAdd(dp.counters + kNewCount + parity, 1)] = e;
+            }
+        }
+        __syncthreads();
+        if (inserted) integrate_block(fp, dp, newEntry, verts);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(dp.counters + kCommitTicket, 1);
+        if (ticket == (int)commitBlocks - 1) {
+            dp.counters[kCompactCount] = scanCount + atomicAdd(dp.counters + kNewCount + parity, 0);
+            dp.counters[kLastCandidates] = n;
+            dp.counters[kScanCount + (parity ^ 1)] = 0;
+            dp.counters[kNewCount + (parity ^ 1)] = 0;
+            dp.counters[kFusedCand + (parity ^ 1)] = 0;
+            dp.counters[kCommitTicket] = 0;
+        }
     }
 }
 
