@@ -13,8 +13,10 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("alloc_claim_kernel", "alloc_commit_kernel", "flatten_kernel", "integrate_kernel", "raycast_kernel",
-        "claim_keys_kernel", "reset_table_kernel", "reset_heap_kernel")
+OURS = ("frame_scan_claim_kernel", "frame_commit_integrate_kernel", "alloc_claim_kernel", "alloc_commit_kernel",
+        "flatten_multi_kernel", "flatten_kernel", "integrate_multi_kernel", "integrate_kernel", "raycast_kernel",
+        "generate_keys_kernel", "prepare_generate_kernel", "claim_bins_kernel", "reset_table_kernel",
+        "reset_heap_kernel", "debug_eval_kernel")
 
 
 def short(name):
