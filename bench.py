@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--profile-steps", type=int, default=200)
     ap.add_argument("--batch", type=int, default=8,
                     help="sharded path: frames per camera carried by one all-to-all / all-gather")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="sharded path: do not overlap key generation + RCCL with the table work")
     ap.add_argument("--sharded", action="store_true",
                     help="force the bucket-range-sharded path (torch.distributed) even with one rank")
     return ap.parse_args()

@@ -75,3 +75,48 @@ def test_key_bin_overflow_is_reported(vh, torch_cuda):
     c = sh.table.counters()
     assert c["bin_overflow"] == 1
     assert 0 < c["allocated_total"] <= 15
+
+
+def test_pipelined_steps_equal_sequential_over_nccl(oracle, vh, torch_cuda):
+    """RCCL transport with one rank: the two-stream pipeline (generate + collectives of step i+1
+    under the table work of step i) leaves exactly the table the plain step sequence leaves,
+    and both equal the oracle."""
+    import os
+
+    import torch.distributed as dist
+    torch = torch_cuda
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        plan = vdist.ShardPlan(KW["numBuckets"], 1)
+        transport = vdist.TorchDistTransport()
+        batch, steps = 2, 5
+        frames = [[cameras(1, s * batch + b)[0] for b in range(batch)] for s in range(steps)]
+        d_frames = [[(p, torch.from_numpy(v).cuda()) for p, v in fs] for fs in frames]
+        tables = []
+        for pipelined in (False, True):
+            table_stream, front = torch.cuda.Stream(), torch.cuda.Stream()
+            sh = vdist.HipShard(vh.default_params(**KW), W, H, 1, plan, 0, W * H // 4, batch=batch,
+                                stream=table_stream, sets=2)
+            if pipelined:
+                pipe = vdist.ShardedPipeline(sh, transport, table_stream, front)
+                for fs in d_frames:
+                    pipe.feed([f[0] for f in fs], [f[1] for f in fs])
+                pipe.flush()
+            else:
+                with torch.cuda.stream(table_stream):
+                    for fs in d_frames:
+                        vdist.sharded_step(sh, transport, [f[0] for f in fs], [f[1] for f in fs])
+                sh.table.synchronize()
+            torch.cuda.synchronize()
+            tables.append(sh)
+        full = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+        for fs in frames:
+            for pose, verts in fs:
+                full.integrate(pose, verts)          # one camera: the multi-camera frame is integrate()
+        for sh in tables:
+            assert check_shard_against_full(sh.table, full, 0, KW["numBuckets"], 5) > 100
+            sh.table.close()
+    finally:
+        dist.destroy_process_group()

@@ -72,7 +72,7 @@ struct vh_context {
     int commitBlocks = 128;        // workgroups serving candidates in the fused second launch
     int fusedParity = 0;           // which of the two per-frame counter sets the next fused frame uses
     bool compactArmed = false;     // alloc_commit has zeroed the compact counter and no flatten ran since
-    int flattenVariant = 1;        // 0: non-temporal ptr loads, 1: plain loads (measured 7 % faster, C2)
+    int flattenVariant = 3;        // WalkKind (A/B in one process, C2: 3 = 16.7 us, 1 = 17.8, 2 = 18.9, 0 = +7 %)
 };
 
 struct DeviceGuard {
@@ -269,7 +269,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
         }                                                                  \
     } while (0)
     VH_ALLOC(dp.heap, sizeof(uint32_t) * (size_t)p.numVoxelBlocks);
-    VH_ALLOC(dp.table, sizeof(VoxelEntry) * c->numEntries);
+    VH_ALLOC(dp.table, sizeof(VoxelEntry) * c->numEntries + 16);   // the wide walk reads whole 16-byte chunks
     VH_ALLOC(dp.compact, sizeof(VoxelEntry) * c->numEntries);
     VH_ALLOC(dp.claim, sizeof(unsigned long long) * (size_t)c->ownedBuckets);
     VH_ALLOC(dp.blocks, sizeof(Voxel) * (size_t)p.numVoxelBlocks * kBlockVoxels);
@@ -407,13 +407,27 @@ static int launch_alloc(vh_context *c, const vh_float4 *verts)
     return rc;
 }
 
+// workgroups of the table walk: 2048 entries each (strided) or 2048 16-byte chunks each (wide)
+static uint32_t walk_blocks(const vh_context *c)
+{
+    if (c->flattenVariant == kWalkWide)
+        return (uint32_t)grid_for(((size_t)c->numEntries * 20 + 15) / 16, kFlattenThreads * kChunksPerLane);
+    return (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
+}
+
 static int launch_flatten(vh_context *c)
 {
-    const dim3 grid(grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane));
-    if (c->flattenVariant == 1)
-        return launch(c, kPhaseFlatten, flatten_kernel<false>, grid, dim3(kFlattenThreads), c->fp, c->dp,
+    const dim3 grid(walk_blocks(c));
+    if (c->flattenVariant == kWalkWide)
+        return launch(c, kPhaseFlatten, flatten_kernel<kWalkWide>, grid, dim3(kFlattenThreads), c->fp, c->dp,
                       (uint32_t)c->numEntries);
-    return launch(c, kPhaseFlatten, flatten_kernel<true>, grid, dim3(kFlattenThreads), c->fp, c->dp,
+    if (c->flattenVariant == kWalkStrided)
+        return launch(c, kPhaseFlatten, flatten_kernel<kWalkStrided>, grid, dim3(kFlattenThreads), c->fp, c->dp,
+                      (uint32_t)c->numEntries);
+    if (c->flattenVariant == kWalkStridedNT)
+        return launch(c, kPhaseFlatten, flatten_kernel<kWalkStridedNT>, grid, dim3(kFlattenThreads), c->fp, c->dp,
+                      (uint32_t)c->numEntries);
+    return launch(c, kPhaseFlatten, flatten_kernel<kWalkStridedBallot>, grid, dim3(kFlattenThreads), c->fp, c->dp,
                   (uint32_t)c->numEntries);
 }
 
@@ -476,10 +490,21 @@ extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4
     if (c->fusedFrame) {
         // two launches: {claim || table walk}, then {commit + integrate}; see vh_kernels.hip
         const uint32_t claimBlocks = (uint32_t)grid_for((size_t)c->fp.width * c->fp.height, 256);
-        const uint32_t scanBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
-        rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel, dim3(claimBlocks + scanBlocks), dim3(256), c->fp,
-                    c->dp, reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
-                    c->fusedParity);
+        const uint32_t scanBlocks = walk_blocks(c);
+        if (c->flattenVariant == kWalkWide)
+            rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kWalkWide>, dim3(claimBlocks + scanBlocks),
+                        dim3(256), c->fp, c->dp, reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries,
+                        claimBlocks, c->fusedParity);
+        else if (c->flattenVariant == kWalkStridedBallot)
+            rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kWalkStridedBallot>,
+                        dim3(claimBlocks + scanBlocks), dim3(256), c->fp, c->dp,
+                        reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
+                        c->fusedParity);
+        else
+            rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kWalkStrided>,
+                        dim3(claimBlocks + scanBlocks), dim3(256), c->fp, c->dp,
+                        reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
+                        c->fusedParity);
         if (rc != VH_OK) return rc;
         const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
         rc = launch(c, kPhaseFrameCommitIntegrate, frame_commit_integrate_kernel,

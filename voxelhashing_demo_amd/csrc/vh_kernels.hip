@@ -196,19 +196,50 @@ __global__ __launch_bounds__(256) void alloc_commit_kernel(const FrameParams fp,
 // flattenIntoBuffer
 // ---------------------------------------------------------------------------
 // Only `ptr` decides whether an entry is live, and all but a few thousand of
-// the millions of entries are free, so every lane reads just the ptr dword of
-// its entries (stride 20 B: a wave instruction covers 1280 contiguous bytes,
-// every fetched line is fully consumed across the kEntriesPerLane loads).  The
-// rare live entries are re-read in full, frustum-tested and appended with one
-// atomic per wave (ballot + mbcnt prefix).  The reference also clears the whole
-// compact table first (VoxelUtils.cu:757-758, its own TODO calls it redundant);
-// that pass is dropped.
+// the millions of entries are free.  Two ways to stream the ptr dwords:
+//   kWalkStrided  every lane reads just the ptr dword of its entries (stride 20 B: a
+//                 wave instruction covers 1280 contiguous bytes, every fetched line
+//                 is consumed across the loads in flight);
+//   kWalkWide     every lane reads 16-byte chunks, a wave instruction 1 KiB, the
+//                 best-coalesced shape there is.  20-byte records repeat every 5
+//                 chunks (80 B = 4 entries), so chunk c holds the ptr of entry
+//                 (4c + d - 3) / 5 in dword d = 3,-,0,1,2 for c mod 5 = 0..4 and no
+//                 staging through LDS is needed to find it.
+// The rare live entries are re-read in full and frustum-tested; slots in the compact
+// list are taken with one atomic per wave (wave scan of the per-lane hit counts).  The
+// reference also clears the whole compact table first (VoxelUtils.cu:757-758, its own
+// TODO calls it redundant); that pass is dropped.
 constexpr int kFlattenThreads = 256;
 constexpr int kEntriesPerLane = 8;
+constexpr int kChunksPerLane = 8;
+enum WalkKind : int { kWalkStridedNT = 0, kWalkStrided = 1, kWalkWide = 2, kWalkStridedBallot = 3 };
 
-template <bool kNonTemporal>
-__device__ __forceinline__ void flatten_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
-                                             uint32_t tileIndex, int counter)
+// First compact slot for this lane's `myCount` hits (one atomicAdd per wave that has any).
+__device__ __forceinline__ int reserve_compact_slots(const DevPtrs &dp, int counter, int myCount)
+{
+    if (__ballot(myCount != 0) == 0ull) return -1;
+    const int lane = threadIdx.x & (kWave - 1);
+    int incl = myCount;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int n = __shfl_up(incl, d);
+        if (lane >= d) incl += n;
+    }
+    int base = 0;
+    if (lane == kWave - 1) base = atomicAdd(dp.counters + counter, incl);
+    base = __shfl(base, kWave - 1);
+    return base + incl - myCount;
+}
+
+__device__ __forceinline__ bool entry_visible(const FrameParams &fp, const DevPtrs &dp, uint32_t e)
+{
+    const VoxelEntry ent = dp.table[e];
+    return block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);        // VoxelUtils.cu:732
+}
+
+// strided walk with one ballot + atomic per unrolled entry slot (hits are rare on small scenes)
+__device__ __forceinline__ void flatten_tile_ballot(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
+                                                    uint32_t tileIndex, int counter)
 {
     const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
     const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
@@ -216,23 +247,19 @@ __device__ __forceinline__ void flatten_tile(const FrameParams &fp, const DevPtr
 #pragma unroll
     for (int j = 0; j < kEntriesPerLane; ++j) {
         const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
-        const int32_t *w = words + (size_t)e * kEntryDwords + 3;
-        if (e >= numEntries) ptrs[j] = VH_FREE_BLOCK;
-        else ptrs[j] = kNonTemporal ? __builtin_nontemporal_load(w) : *w;
+        ptrs[j] = (e < numEntries) ? words[(size_t)e * kEntryDwords + 3] : VH_FREE_BLOCK;
     }
     bool any = false;
 #pragma unroll
     for (int j = 0; j < kEntriesPerLane; ++j) any |= (ptrs[j] != VH_FREE_BLOCK);
     if (__ballot(any) == 0ull) return;
-
     const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll
     for (int j = 0; j < kEntriesPerLane; ++j) {
         bool hit = false;
         VoxelEntry ent;
         if (ptrs[j] != VH_FREE_BLOCK) {
-            const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
-            ent = dp.table[e];
+            ent = dp.table[tile + j * kFlattenThreads + threadIdx.x];
             hit = block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);   // VoxelUtils.cu:732
         }
         const unsigned long long mask = __ballot(hit);
@@ -241,18 +268,71 @@ __device__ __forceinline__ void flatten_tile(const FrameParams &fp, const DevPtr
         const int leaderLane = __ffsll((long long)mask) - 1;
         if (lane == leaderLane) base = atomicAdd(dp.counters + counter, __popcll(mask));
         base = __shfl(base, leaderLane);
-        if (hit) {
-            const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
-            dp.compact[base + prefix] = ent;
-        }
+        if (hit) dp.compact[base + __popcll(mask & ((1ull << lane) - 1ull))] = ent;
     }
 }
 
-template <bool kNonTemporal>
+template <int kKind>
+__device__ __forceinline__ void flatten_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
+                                             uint32_t tileIndex, int counter)
+{
+    if constexpr (kKind == kWalkStridedBallot) {
+        flatten_tile_ballot(fp, dp, numEntries, tileIndex, counter);
+        return;
+    }
+    uint32_t ent[kEntriesPerLane];          // entry index of each candidate, or ~0u
+    uint32_t hits = 0;                      // bit j: entry j is live and in the frustum
+    if constexpr (kKind == kWalkWide) {
+        static_assert(kChunksPerLane == kEntriesPerLane, "one candidate entry per chunk");
+        const uint32_t numChunks = (uint32_t)(((uint64_t)numEntries * 20u + 15u) / 16u);
+        const uint32_t base = tileIndex * (kFlattenThreads * kChunksPerLane);
+        const uint4 *chunks = reinterpret_cast<const uint4 *>(dp.table);
+        uint4 v[kChunksPerLane];
+#pragma unroll
+        for (int j = 0; j < kChunksPerLane; ++j) {
+            const uint32_t c = base + j * kFlattenThreads + threadIdx.x;
+            v[j] = (c < numChunks) ? chunks[c] : make_uint4(~0u, ~0u, ~0u, ~0u);
+        }
+#pragma unroll
+        for (int j = 0; j < kChunksPerLane; ++j) {
+            const uint32_t c = base + j * kFlattenThreads + threadIdx.x;
+            const uint32_t m = c % 5u;
+            const uint32_t d = (m == 0u) ? 3u : m - 2u;                 // m == 1: no ptr in this chunk
+            const uint32_t word = (d == 0u) ? v[j].x : (d == 1u) ? v[j].y : (d == 2u) ? v[j].z : v[j].w;
+            const uint32_t e = (4u * c + d - 3u) / 5u;
+            const bool live = (m != 1u) && (word != (uint32_t)VH_FREE_BLOCK) && (e < numEntries);
+            ent[j] = live ? e : ~0u;
+        }
+    } else {
+        const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
+        const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
+        int32_t ptrs[kEntriesPerLane];
+#pragma unroll
+        for (int j = 0; j < kEntriesPerLane; ++j) {
+            const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
+            const int32_t *w = words + (size_t)e * kEntryDwords + 3;
+            if (e >= numEntries) ptrs[j] = VH_FREE_BLOCK;
+            else ptrs[j] = (kKind == kWalkStridedNT) ? __builtin_nontemporal_load(w) : *w;
+        }
+#pragma unroll
+        for (int j = 0; j < kEntriesPerLane; ++j)
+            ent[j] = (ptrs[j] != VH_FREE_BLOCK) ? tile + j * kFlattenThreads + threadIdx.x : ~0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j)
+        if (ent[j] != ~0u && entry_visible(fp, dp, ent[j])) hits |= 1u << j;
+    int slot = reserve_compact_slots(dp, counter, __popc(hits));
+    if (slot < 0) return;
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j)
+        if ((hits >> j) & 1u) dp.compact[slot++] = dp.table[ent[j]];
+}
+
+template <int kKind>
 __global__ __launch_bounds__(kFlattenThreads) void flatten_kernel(const FrameParams fp, const DevPtrs dp,
                                                                   uint32_t numEntries)
 {
-    flatten_tile<kNonTemporal>(fp, dp, numEntries, blockIdx.x, kCompactCount);
+    flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x, kCompactCount);
 }
 
 // ---------------------------------------------------------------------------
@@ -329,19 +409,27 @@ __global__ __launch_bounds__(256) void integrate_kernel(const FrameParams fp, co
 // sees the table as it was at the start of the frame; the entries this frame inserts
 // are appended to the compact list by launch 2 -- they pass the frustum test by
 // construction (allocBlocks tested the same key against the same pose, :673 / :732).
+template <int kKind>
 __global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams fp, const DevPtrs dp,
                                                                const float4 *__restrict__ verts,
                                                                uint32_t numEntries, uint32_t claimBlocks,
                                                                int parity)
 {
-    if (blockIdx.x < claimBlocks) {
-        const PixelKey k = pixel_key(fp, verts, blockIdx.x * 256 + threadIdx.x, nullptr);
+    // The two roles are interleaved over the grid in proportion (block b is a claim block when
+    // floor((b+1)*claim/total) steps): workgroups are dispatched roughly in index order, and
+    // with all claim blocks in front a large image would fill the chip with latency-bound
+    // pixel work before the first byte of the table is streamed.
+    const uint32_t total = gridDim.x;
+    const uint32_t claimBefore = (uint32_t)(((uint64_t)blockIdx.x * claimBlocks) / total);
+    const uint32_t claimAfter = (uint32_t)(((uint64_t)(blockIdx.x + 1u) * claimBlocks) / total);
+    if (claimAfter != claimBefore) {
+        const PixelKey k = pixel_key(fp, verts, claimBefore * 256 + threadIdx.x, nullptr);
         if (!k.leader) return;
         const uint32_t h = hash_block(k.kx, k.ky, k.kz, fp.numBuckets);
         if (h < fp.bucketLo || h >= fp.bucketHi) return;
         probe_and_claim(fp, dp, k.kx, k.ky, k.kz, h, launch_rank(k.px, k.py, fp.width), kFusedCand + parity);
     } else {
-        flatten_tile<false>(fp, dp, numEntries, blockIdx.x - claimBlocks, kScanCount + parity);
+        flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x - claimBefore, kScanCount + parity);
     }
 }
 
@@ -432,35 +520,27 @@ __global__ __launch_bounds__(kFlattenThreads) void flatten_multi_kernel(const Fr
         const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
         ptrs[j] = (e < numEntries) ? words[(size_t)e * kEntryDwords + 3] : VH_FREE_BLOCK;
     }
-    bool any = false;
-#pragma unroll
-    for (int j = 0; j < kEntriesPerLane; ++j) any |= (ptrs[j] != VH_FREE_BLOCK);
-    if (__ballot(any) == 0ull) return;
-
-    const int lane = threadIdx.x & (kWave - 1);
+    uint32_t seen[kEntriesPerLane];         // cameras whose frustum holds entry j
+    int myCount = 0;
 #pragma unroll
     for (int j = 0; j < kEntriesPerLane; ++j) {
-        uint32_t seen = 0;
-        VoxelEntry ent;
-        if (ptrs[j] != VH_FREE_BLOCK) {
-            const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
-            ent = dp.table[e];
-            for (int c = 0; c < numCams; ++c) {
-                const float *pk = packets + packetStride * c;
-                if (block_in_frustum(fp, pk, pk + 16, ent.pos[0], ent.pos[1], ent.pos[2])) seen |= 1u << c;
-            }
+        seen[j] = 0;
+        if (ptrs[j] == VH_FREE_BLOCK) continue;
+        const VoxelEntry ent = dp.table[tile + j * kFlattenThreads + threadIdx.x];
+        for (int c = 0; c < numCams; ++c) {
+            const float *pk = packets + packetStride * c;
+            if (block_in_frustum(fp, pk, pk + 16, ent.pos[0], ent.pos[1], ent.pos[2])) seen[j] |= 1u << c;
         }
-        const unsigned long long mask = __ballot(seen != 0u);
-        if (mask == 0ull) continue;
-        int base = 0;
-        const int leaderLane = __ffsll((long long)mask) - 1;
-        if (lane == leaderLane) base = atomicAdd(dp.counters + kCompactCount, __popcll(mask));
-        base = __shfl(base, leaderLane);
-        if (seen != 0u) {
-            const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-            dp.compact[slot] = ent;
-            dp.compactMask[slot] = seen;
-        }
+        myCount += seen[j] != 0u;
+    }
+    int slot = reserve_compact_slots(dp, kCompactCount, myCount);
+    if (slot < 0) return;
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) {
+        if (seen[j] == 0u) continue;
+        dp.compact[slot] = dp.table[tile + j * kFlattenThreads + threadIdx.x];
+        dp.compactMask[slot] = seen[j];
+        ++slot;
     }
 }
 

@@ -106,7 +106,7 @@ class HipShard:
     """This rank's shard on its GPU (libvoxelhash_hip.so through the C-ABI)."""
 
     def __init__(self, params, width, height, semantics, plan: ShardPlan, rank: int, capacity: int,
-                 batch: int = 1, device=None, stream=None):
+                 batch: int = 1, device=None, stream=None, sets: int = 1):
         import torch
 
         from .hashtable import SDFHashtable
@@ -116,24 +116,37 @@ class HipShard:
                                   bucket_range=plan.bucket_range(rank), stream=stream)
         self.packet_floats = P = 32 + width * height
         R, B = plan.world, batch
-        self.bins_send = torch.zeros((R, B, capacity, 4), dtype=torch.int32, device=self.device)
-        self.bins_recv = torch.zeros((R, B, capacity, 4), dtype=torch.int32, device=self.device)
-        self.packet = torch.zeros((B, P), dtype=torch.float32, device=self.device)
-        self.packets = torch.zeros((R, B, P), dtype=torch.float32, device=self.device)
-        self._send_b = [self.bins_send[0, b].data_ptr() for b in range(B)]
-        self._recv_b = [self.bins_recv[0, b].data_ptr() for b in range(B)]
-        self._packet_b = [self.packet[b].data_ptr() for b in range(B)]
-        self._packets_b = [self.packets[0, b].data_ptr() for b in range(B)]
+        # `sets` independent buffer sets: the pipelined step fills one while the other is consumed
+        self.sets = []
+        for _ in range(max(1, sets)):
+            s = dict(bins_send=torch.zeros((R, B, capacity, 4), dtype=torch.int32, device=self.device),
+                     bins_recv=torch.zeros((R, B, capacity, 4), dtype=torch.int32, device=self.device),
+                     packet=torch.zeros((B, P), dtype=torch.float32, device=self.device),
+                     packets=torch.zeros((R, B, P), dtype=torch.float32, device=self.device))
+            s["send_b"] = [s["bins_send"][0, b].data_ptr() for b in range(B)]
+            s["recv_b"] = [s["bins_recv"][0, b].data_ptr() for b in range(B)]
+            s["packet_b"] = [s["packet"][b].data_ptr() for b in range(B)]
+            s["packets_b"] = [s["packets"][0, b].data_ptr() for b in range(B)]
+            self.sets.append(s)
+        self.use_set(0)
+
+    def use_set(self, i: int):
+        s = self.sets[i]
+        self.bins_send, self.bins_recv, self.packet, self.packets = (
+            s["bins_send"], s["bins_recv"], s["packet"], s["packets"])
+        self._cur = s
 
     def generate(self, b: int, pose, verts):
         self.table.set_pose(pose)
-        self.table.generate_keys(verts, self.rank, self.plan.world, self._send_b[b], self.capacity,
-                                 self._packet_b[b], bin_stride=self.batch * self.capacity)
+        self.table.generate_keys(verts, self.rank, self.plan.world, self._cur["send_b"][b], self.capacity,
+                                 self._cur["packet_b"][b], bin_stride=self.batch * self.capacity)
 
     def apply(self, b: int):
         self.table.reset_mutexes()
-        self.table.insert_bins(self._recv_b[b], self.plan.world, self.capacity, bin_stride=self.batch * self.capacity)
-        self.table.integrate_packets(self.plan.world, self._packets_b[b], packet_stride=self.batch * self.packet_floats)
+        self.table.insert_bins(self._cur["recv_b"][b], self.plan.world, self.capacity,
+                               bin_stride=self.batch * self.capacity)
+        self.table.integrate_packets(self.plan.world, self._cur["packets_b"][b],
+                                     packet_stride=self.batch * self.packet_floats)
 
 
 class OracleShard:
@@ -177,6 +190,69 @@ def sharded_step(shard, transport: TorchDistTransport, poses, verts_list):
     transport.all_gather_packets(shard.packet.view(-1), shard.packets.view(shard.plan.world, -1))
     for b in range(shard.batch):
         shard.apply(b)
+
+
+class ShardedPipeline:
+    """The same steps, software-pipelined over two HIP streams: while the table stream applies
+    step i (insert / walk / TSDF update), the front stream generates the keys and packets of
+    step i+1 and runs its all-to-all and all-gather, so a step costs max(apply, generate + RCCL)
+    instead of their sum.  Two buffer sets alternate; events order the hand-offs:
+
+        front: [wait applied(i-1)] generate(i+1) -> all_to_all -> all_gather -> [record ready(i+1)]
+        table: [wait ready(i)] apply(i) -> [record applied(i)]
+
+    Operations on the table are issued in exactly the order of `sharded_step`, so results are the
+    same.  `shard` needs sets=2."""
+
+    def __init__(self, shard: HipShard, transport: TorchDistTransport, table_stream, front_stream):
+        import torch
+        assert len(shard.sets) >= 2
+        self.torch, self.shard, self.transport = torch, shard, transport
+        self.table_stream, self.front_stream = table_stream, front_stream
+        self.ready = [torch.cuda.Event() for _ in range(2)]      # exchange of set s has landed
+        self.applied = [torch.cuda.Event() for _ in range(2)]    # set s has been consumed
+        self.count = 0           # steps fed
+        self.pending = None      # set index whose exchange is in flight / landed but not applied
+
+    def _front(self, s, poses, verts_list):
+        torch, sh = self.torch, self.shard
+        with torch.cuda.stream(self.front_stream):
+            if self.count >= 2:
+                self.front_stream.wait_event(self.applied[s])    # set s was last used by step count-2
+            sh.table.set_stream(self.front_stream)
+            sh.use_set(s)
+            for b in range(sh.batch):
+                sh.generate(b, poses[b], verts_list[b])
+            self.transport.all_to_all_bins(sh.bins_send, sh.bins_recv)
+            self.transport.all_gather_packets(sh.packet.view(-1), sh.packets.view(sh.plan.world, -1))
+            self.ready[s].record(self.front_stream)
+
+    def _apply(self, s):
+        torch, sh = self.torch, self.shard
+        with torch.cuda.stream(self.table_stream):
+            self.table_stream.wait_event(self.ready[s])
+            sh.table.set_stream(self.table_stream)
+            sh.use_set(s)
+            for b in range(sh.batch):
+                sh.apply(b)
+            self.applied[s].record(self.table_stream)
+
+    def feed(self, poses, verts_list):
+        """Submit one step (batch frames of this rank's camera); applies the previous one."""
+        s = self.count & 1
+        self._front(s, poses, verts_list)
+        if self.pending is not None:
+            self._apply(self.pending)
+        self.pending = s
+        self.count += 1
+
+    def flush(self):
+        if self.pending is not None:
+            self._apply(self.pending)
+            self.pending = None
+        self.shard.table.set_stream(self.table_stream)
+        self.table_stream.synchronize()
+        self.front_stream.synchronize()
 
 
 def loopback_step(shards, poses, verts_list):
@@ -240,23 +316,35 @@ def bench_sharded(args, wl, rank, world, local_rank):
     params = default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
     transport = TorchDistTransport()
     batch = max(1, args.batch)
+    pipelined = not getattr(args, "no_pipeline", False)
+    front = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        shard = HipShard(params, Wd, Ht, SEM_PINHOLE, plan, rank, capacity, batch=batch, device=dev, stream=stream)
+        shard = HipShard(params, Wd, Ht, SEM_PINHOLE, plan, rank, capacity, batch=batch, device=dev, stream=stream,
+                         sets=2 if pipelined else 1)
+        pipe = ShardedPipeline(shard, transport, stream, front) if pipelined else None
 
         def step(i):
             ks = [(i * batch + b) % nframes for b in range(batch)]
-            sharded_step(shard, transport, [poses[k] for k in ks], [verts[k] for k in ks])
+            if pipe:
+                pipe.feed([poses[k] for k in ks], [verts[k] for k in ks])
+            else:
+                sharded_step(shard, transport, [poses[k] for k in ks], [verts[k] for k in ks])
+
+        def drain():
+            if pipe:
+                pipe.flush()
+            shard.table.synchronize()
+            torch.cuda.synchronize()
 
         for i in range(args.warmup):
             step(i)
-        torch.cuda.synchronize()
+        drain()
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i)
-        shard.table.synchronize()
-        torch.cuda.synchronize()
+        drain()                      # every fed step has been applied when the clock stops
         dist.barrier()
         elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -276,7 +364,7 @@ def bench_sharded(args, wl, rank, world, local_rank):
                                  f"2^{int(math.log2(wl['buckets']))} buckets sharded by bucket range over {world} GPUs, "
                                  "RCCL all-to-all of block keys + all-gather of depth packets per step, PINHOLE",
                         frames_per_step=world * batch, frames_per_camera_per_exchange=batch,
-                        resident_frames=nframes, key_bin_capacity=capacity,
+                        resident_frames=nframes, key_bin_capacity=capacity, pipelined=pipelined,
                         occupied_blocks_all_ranks=int(stats[0]), allocated_blocks_all_ranks=int(stats[1]),
                         key_bin_overflows=int(stats[2])),
             roofline=None, cpu_baseline=None)
