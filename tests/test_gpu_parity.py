@@ -287,3 +287,25 @@ def test_drop_in_names(oracle, vh, torch_cuda):
     finally:
         gt._h = None
         L.deviceFree()
+
+
+def test_raycast_room_scene_moving_camera(oracle, vh, torch_cuda):
+    """Raycast of the fused room (thousands of blocks, rays crossing long stretches of empty
+    space, so the empty-block skip and the bucket bitmap are exercised) from poses on and off the
+    integration path: bit-equal to the oracle, which evaluates every sample."""
+    torch = torch_cuda
+    ot, gt = _pair(oracle, vh, 1, numVoxelBlocks=1 << 14)
+    poses = synth.camera_loop(500)
+    prims = synth.room_primitives()
+    frames = [(poses[i], synth.render_room_verts(poses[i], prims=prims).numpy()) for i in (0, 3, 6, 30)]
+    _run(ot, gt, torch, frames)
+    d_depth = torch.empty((480, 640), dtype=torch.float32, device="cuda")
+    for pose in (poses[3], poses[15], synth.yaw_pose(200.0, (0.3, 0.1, -0.4))):
+        gt.raycast(pose, d_depth, 0.1, 5.0)
+        gt.synchronize()
+        g = d_depth.cpu().numpy()
+        o = ot.raycast(pose, 0.1, 5.0)
+        assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+    gt.raycast(poses[3], d_depth, 0.1, 5.0)
+    gt.synchronize()
+    assert (d_depth.cpu().numpy() > 0).mean() > 0.3

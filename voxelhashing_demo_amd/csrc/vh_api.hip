@@ -203,6 +203,7 @@ static int free_buffers(vh_context *c)
     if (c->dp.counters) (void)hipFree(c->dp.counters);
     if (c->dp.candidates) (void)hipFree(c->dp.candidates);
     if (c->dp.compactMask) (void)hipFree(c->dp.compactMask);
+    if (c->dp.bucketBits) (void)hipFree(c->dp.bucketBits);
     c->dp = DevPtrs{};
     return VH_OK;
 }
@@ -276,6 +277,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     VH_ALLOC(dp.counters, sizeof(int32_t) * kNumCounters);
     VH_ALLOC(dp.candidates, sizeof(int4) * npix);
     VH_ALLOC(dp.compactMask, sizeof(uint32_t) * c->numEntries);
+    VH_ALLOC(dp.bucketBits, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32));
 #undef VH_ALLOC
 
     // deviceAllocate, VoxelUtils.cu:183-208 (+ the compact table and the zeroed
@@ -286,6 +288,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     reset_table_kernel<<<g, 256, 0, s>>>(dp.compact, c->numEntries);
     reset_heap_kernel<<<g, 256, 0, s>>>(dp.heap, p.numVoxelBlocks);
     hipError_t e = hipMemsetAsync(dp.claim, 0, sizeof(unsigned long long) * (size_t)c->ownedBuckets, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dp.bucketBits, 0, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32), s);
     if (e == hipSuccess) e = hipMemsetAsync(dp.blocks, 0, sizeof(Voxel) * (size_t)p.numVoxelBlocks * kBlockVoxels, s);
     int32_t h_counters[kNumCounters] = {0};
     h_counters[kHeapCounter] = (int32_t)p.numVoxelBlocks - 1;               // :207

@@ -68,6 +68,7 @@ struct DevPtrs {
     int4 *candidates;         // {x,y,z,rank} of this frame's contenders
     uint32_t candCapacity;
     uint32_t *compactMask;    // multi-camera frames: cameras that see compact entry i
+    uint32_t *bucketBits;     // one bit per owned bucket: holds at least one entry
 };
 
 // camera packet of the sharded path: 16 floats pose, 16 floats inverse, W*H camera-z plane
@@ -89,6 +90,9 @@ __device__ __forceinline__ int f2i_rz(float x)
 __device__ __forceinline__ uint32_t hash_block(int x, int y, int z, uint32_t numBuckets)
 {
     const uint32_t h = ((uint32_t)x * 73856093u) ^ ((uint32_t)y * 19349669u) ^ ((uint32_t)z * 83492791u);
+    // a 32-bit remainder by a run-time value is ~25 instructions on CDNA; every BASELINE
+    // config uses a power-of-two bucket count, where it is one AND (wave-uniform branch)
+    if ((numBuckets & (numBuckets - 1u)) == 0u) return h & (numBuckets - 1u);
     return h % numBuckets;
 }
 

@@ -164,6 +164,7 @@ __device__ __forceinline__ bool commit_candidate(const FrameParams &fp, const De
         e.ptr = (int)(dp.heap[addr] * (uint32_t)kBlockVoxels);
         e.offset = 0;
         bucket[s] = e;
+        atomicOr(dp.bucketBits + (local >> 5), 1u << (local & 31u));
         atomicAdd(dp.counters + kAllocatedTotal, 1);
         return true;
     }
@@ -595,7 +596,12 @@ __device__ __forceinline__ int lookup_block(const FrameParams &fp, const DevPtrs
 {
     const uint32_t h = hash_block(kx, ky, kz, fp.numBuckets);
     if (h < fp.bucketLo || h >= fp.bucketHi) return VH_FREE_BLOCK;
-    const VoxelEntry *bucket = dp.table + (size_t)(h - fp.bucketLo) * fp.bucketSize;
+    const uint32_t local = h - fp.bucketLo;
+    // One bit per bucket ("holds at least one entry", set by the commit phase): a few hundred
+    // KB that stay in L2, while the table itself is >100 MB.  Nearly every block a ray crosses
+    // is empty space and is answered here without touching the table.
+    if (!((dp.bucketBits[local >> 5] >> (local & 31u)) & 1u)) return VH_FREE_BLOCK;
+    const VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
     for (uint32_t i = 0; i < fp.bucketSize; ++i) {
         const VoxelEntry e = bucket[i];
         if (e.ptr == VH_FREE_BLOCK) return VH_FREE_BLOCK;      // prefix property
@@ -609,6 +615,8 @@ __device__ __forceinline__ int lookup_block(const FrameParams &fp, const DevPtrs
 // consecutive valid samples with sdf_prev > 0 >= sdf_cur, linear interpolation.
 // 16x16-pixel tiles: a wave is a 16x4 patch of neighbouring rays, which walk
 // the same blocks and keep the bucket / voxel lines hot in L2.
+constexpr float kSkipMargin = 0.01f;     // voxels; see the empty-block skip below
+
 __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, const DevPtrs dp, float fx, float fy,
                                                       float cx, float cy, float tMin, int nSteps,
                                                       float *__restrict__ depthOut)
@@ -619,6 +627,11 @@ __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, cons
     const float dx = ((float)u - cx) / fx;
     const float dy = ((float)v - cy) / fy;
     const float dt = fp.voxelSize;
+    const float invDt = __builtin_amdgcn_rcpf(dt) * (1.0f - 1.0e-6f);   // never over-estimates a step count
+    // world-space ray per unit of camera depth (only used to bound empty-block skips)
+    const float dirX = fp.T[0] * dx + fp.T[1] * dy + fp.T[2];
+    const float dirY = fp.T[4] * dx + fp.T[5] * dy + fp.T[6];
+    const float dirZ = fp.T[8] * dx + fp.T[9] * dy + fp.T[10];
     bool prevValid = false, haveKey = false;
     float prevSdf = 0.0f, prevT = 0.0f, hit = 0.0f;
     int ckx = 0, cky = 0, ckz = 0, cptr = VH_FREE_BLOCK;
@@ -634,7 +647,29 @@ __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, cons
             cptr = lookup_block(fp, dp, kx, ky, kz);
             haveKey = true;
         }
-        if (cptr == VH_FREE_BLOCK) { prevValid = false; continue; }
+        if (cptr == VH_FREE_BLOCK) {
+            // Empty block: every further sample inside it is invalid too, so jump to the last
+            // sample that is CERTAINLY still inside (block shrunk by kSkipMargin voxels per side:
+            // 1e-2 voxel = 2e-4 m at 2 cm voxels, against ~1e-6 m of fp32 difference between this
+            // linear ray model and the sample positions above).  Skipping only such samples
+            // leaves the result unchanged.
+            prevValid = false;
+            float tExit = 3.0e38f;
+            const float rayD[3] = {dirX, dirY, dirZ}, rayO[3] = {fp.T[3], fp.T[7], fp.T[11]};
+            const int key[3] = {kx, ky, kz};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                // the block spans voxel centres 8k .. 8k+7, i.e. world [(8k-0.5)vs, (8k+7.5)vs)
+                const float lo = ((float)(key[a] * 8) - 0.5f + kSkipMargin) * fp.voxelSize;
+                const float hi = ((float)(key[a] * 8) + 7.5f - kSkipMargin) * fp.voxelSize;
+                // approximate reciprocals (1 ulp) are fine here: the margin absorbs them
+                if (rayD[a] > 0.0f) tExit = __builtin_fminf(tExit, (hi - rayO[a]) * __builtin_amdgcn_rcpf(rayD[a]));
+                else if (rayD[a] < 0.0f) tExit = __builtin_fminf(tExit, (lo - rayO[a]) * __builtin_amdgcn_rcpf(rayD[a]));
+            }
+            const float steps = (tExit - tMin) * invDt;     // last sample index at or before tExit
+            if (steps > (float)i && steps < 2.0e9f) i = min((int)steps, nSteps - 1);
+            continue;
+        }
         const int lx = (int)((uint32_t)vx - (uint32_t)kx * 8u);
         const int ly = (int)((uint32_t)vy - (uint32_t)ky * 8u);
         const int lz = (int)((uint32_t)vz - (uint32_t)kz * 8u);
