@@ -241,6 +241,24 @@ int vh_insert_bins(vh_context *ctx, const int32_t *d_bins, int32_t num_bins, int
  * pass per visible block applying the cameras that see it in order. */
 int vh_integrate_packets(vh_context *ctx, int32_t num_cams, const float *d_packets,
                          size_t packet_stride);
+/* Batched forms (one host call, fewest launches) for `batch` frames per camera and exchange.
+ * Layouts: bin of shard/source s, frame b at d_bins[(s*bin_stride + b*frame_stride)*4];
+ * packet of camera c, frame b at d_packets[c*packet_stride + b*packet_frame_stride].
+ * A stride of 0 means dense (frame_stride = capacity, bin_stride = batch*frame_stride,
+ * packet_frame_stride = 32 + W*H, packet_stride = batch*packet_frame_stride).
+ * vh_generate_keys_batch: poses = batch*16 host floats, d_verts = host array of `batch`
+ * device pointers; the packets written are this camera's (d_packets[b*packet_frame_stride]).
+ * vh_apply_frames_batch: for b = 0..batch-1: new lock epoch, insert the num_bins bins of
+ * frame b, walk + TSDF update for the num_cams packets of frame b -- two launches per frame
+ * ({claim || walk}, {commit + integrate}); equals vh_reset_mutexes + vh_insert_bins +
+ * vh_integrate_packets per frame. */
+int vh_generate_keys_batch(vh_context *ctx, int32_t batch, const float *poses,
+                           const vh_float4 *const *d_verts, uint32_t camera_id, int32_t num_shards,
+                           int32_t *d_bins, int32_t capacity, int32_t bin_stride, int32_t frame_stride,
+                           float *d_packets, size_t packet_frame_stride);
+int vh_apply_frames_batch(vh_context *ctx, int32_t batch, const int32_t *d_bins, int32_t num_bins,
+                          int32_t capacity, int32_t bin_stride, int32_t frame_stride, int32_t num_cams,
+                          const float *d_packets, size_t packet_stride, size_t packet_frame_stride);
 
 /* ------------------------------------------------------------------ */
 /* drop-in names (VoxelUtils.h:5-13); process-global default context    */

@@ -25,10 +25,14 @@ def cameras(world, step):
 
 @pytest.mark.parametrize("world,batch", [(1, 1), (2, 1), (4, 1), (2, 2), (4, 3)])
 @pytest.mark.parametrize("sem", [0, 1])
-def test_hip_shards_equal_one_oracle_table(oracle, vh, torch_cuda, world, batch, sem):
+@pytest.mark.parametrize("calls", ["batched", "stepwise"])
+def test_hip_shards_equal_one_oracle_table(oracle, vh, torch_cuda, world, batch, sem, calls):
+    """batched: vh_generate_keys_batch + vh_apply_frames_batch (fused two-launch multi-camera
+    frames); stepwise: vh_generate_keys / vh_insert_bins / vh_integrate_packets per frame."""
     torch = torch_cuda
     plan = vdist.ShardPlan(KW["numBuckets"], world)
-    shards = [vdist.HipShard(vh.default_params(**KW), W, H, sem, plan, r, W * H // 4, batch=batch)
+    shards = [vdist.HipShard(vh.default_params(**KW), W, H, sem, plan, r, W * H // 4, batch=batch,
+                             batched_calls=(calls == "batched"))
               for r in range(world)]
     full = oracle.OracleTable(oracle.default_params(**KW), W, H, sem)
     for step in range(0, 3, batch):

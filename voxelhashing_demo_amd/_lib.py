@@ -105,6 +105,9 @@ SIGNATURES = {
     "vh_generate_keys": (C.c_int, [_vp, _vp, _u32, _i32, _vp, _i32, _i32, _vp]),
     "vh_insert_bins": (C.c_int, [_vp, _vp, _i32, _i32, _i32]),
     "vh_integrate_packets": (C.c_int, [_vp, _i32, _vp, C.c_size_t]),
+    "vh_generate_keys_batch": (C.c_int, [_vp, _i32, _fp, C.POINTER(_vp), _u32, _i32, _vp, _i32, _i32, _i32, _vp,
+                                         C.c_size_t]),
+    "vh_apply_frames_batch": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, C.c_size_t, C.c_size_t]),
     "updateConstantHashTableParams": (None, [C.POINTER(HashTableParams)]),
     "deviceAllocate": (None, [C.POINTER(HashTableParams)]),
     "deviceFree": (None, []),

@@ -558,12 +558,88 @@ extern "C" int vh_generate_keys(vh_context *c, const vh_float4 *verts, uint32_t 
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     DeviceGuard guard(c->device);
     const int npix = c->fp.width * c->fp.height;
-    // zero the header record of every bin, write the packet header
-    prepare_generate_kernel<<<1, 64, 0, c->stream>>>(c->fp, d_packet, reinterpret_cast<int4 *>(d_bins), num_shards,
-                                                     bin_stride);
+    prepare_bins_kernel<<<1, 64, 0, c->stream>>>(reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, 1, 0);
     generate_keys_kernel<<<grid_for(npix, kGenThreads), kGenThreads, 0, c->stream>>>(
         c->fp, reinterpret_cast<const float4 *>(verts), num_shards, reinterpret_cast<int4 *>(d_bins), capacity,
         bin_stride, d_packet ? d_packet + kPacketHeader : nullptr, camera_id << 24);
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// `batch` frames of one camera in one call: one launch zeroes all bin headers, then one
+// generate_keys_kernel per frame (each with its own pose in the kernel arguments).
+extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float *poses,
+                                      const vh_float4 *const *d_verts, uint32_t camera_id, int32_t num_shards,
+                                      int32_t *d_bins, int32_t capacity, int32_t bin_stride, int32_t frame_stride,
+                                      float *d_packets, size_t packet_frame_stride)
+{
+    if (!c || !poses || !d_verts || !d_bins || batch <= 0 || num_shards <= 0 || num_shards > VH_MAX_CAMERAS ||
+        capacity < 2 || camera_id >= VH_MAX_CAMERAS)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    if (frame_stride == 0) frame_stride = capacity;
+    if (bin_stride == 0) bin_stride = batch * frame_stride;
+    const size_t dense = (size_t)kPacketHeader + (size_t)c->fp.width * c->fp.height;
+    if (packet_frame_stride == 0) packet_frame_stride = dense;
+    if (frame_stride < capacity || bin_stride < batch * frame_stride || (d_packets && packet_frame_stride < dense))
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
+    DeviceGuard guard(c->device);
+    const int npix = c->fp.width * c->fp.height;
+    prepare_bins_kernel<<<grid_for((size_t)num_shards * batch, 256), 256, 0, c->stream>>>(
+        reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, batch, frame_stride);
+    for (int b = 0; b < batch; ++b) {
+        int rc = vh_set_pose(c, poses + 16 * b);
+        if (rc != VH_OK) return rc;
+        if (!d_verts[b]) return fail(VH_ERR_INVALID_ARGUMENT, "null vertex map");
+        float *packet = d_packets ? d_packets + packet_frame_stride * b : nullptr;
+        generate_keys_kernel<<<grid_for(npix, kGenThreads), kGenThreads, 0, c->stream>>>(
+            c->fp, reinterpret_cast<const float4 *>(d_verts[b]), num_shards,
+            reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b, capacity, bin_stride,
+            packet ? packet + kPacketHeader : nullptr, camera_id << 24);
+    }
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// `batch` multi-camera frames applied one after the other, each as the fused pair of launches
+// (new lock epoch; {claim bins || walk}; {commit + integrate}).
+extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t *d_bins, int32_t num_bins,
+                                     int32_t capacity, int32_t bin_stride, int32_t frame_stride, int32_t num_cams,
+                                     const float *d_packets, size_t packet_stride, size_t packet_frame_stride)
+{
+    if (!c || !d_bins || !d_packets || batch <= 0 || num_bins <= 0 || capacity < 2 || num_cams <= 0 ||
+        num_cams > VH_MAX_CAMERAS)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    const size_t dense = (size_t)kPacketHeader + (size_t)c->fp.width * c->fp.height;
+    if (frame_stride == 0) frame_stride = capacity;
+    if (bin_stride == 0) bin_stride = batch * frame_stride;
+    if (packet_frame_stride == 0) packet_frame_stride = dense;
+    if (packet_stride == 0) packet_stride = (size_t)batch * packet_frame_stride;
+    if (frame_stride < capacity || bin_stride < batch * frame_stride || packet_frame_stride < dense ||
+        packet_stride < (size_t)batch * packet_frame_stride)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
+    DeviceGuard guard(c->device);
+    uint32_t parts = (uint32_t)grid_for((size_t)capacity, 256 * 4);
+    if (parts < 1) parts = 1;
+    const uint32_t scanBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
+    const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
+    for (int b = 0; b < batch; ++b) {
+        int rc = vh_reset_mutexes(c);
+        if (rc != VH_OK) return rc;
+        const int4 *bins = reinterpret_cast<const int4 *>(d_bins) + (size_t)frame_stride * b;
+        const float *packets = d_packets + packet_frame_stride * b;
+        rc = launch(c, kPhaseFrameScanClaim, frame_multi_scan_claim_kernel,
+                    dim3((uint32_t)num_bins * parts + scanBlocks), dim3(256), c->fp, c->dp, bins, capacity, bin_stride,
+                    (uint32_t)num_bins, parts, (uint32_t)c->numEntries, num_cams, packets, packet_stride,
+                    c->fusedParity);
+        if (rc == VH_OK)
+            rc = launch(c, kPhaseFrameCommitIntegrate, frame_multi_commit_integrate_kernel,
+                        dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, num_cams, packets,
+                        packet_stride, commitBlocks, c->fusedParity);
+        if (rc != VH_OK) return rc;
+        c->fusedParity ^= 1;
+        c->compactArmed = false;
+        if (c->profiling) c->profiledFrames += 1;
+    }
     VH_HIP(hipGetLastError());
     return VH_OK;
 }

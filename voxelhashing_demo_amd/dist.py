@@ -106,11 +106,12 @@ class HipShard:
     """This rank's shard on its GPU (libvoxelhash_hip.so through the C-ABI)."""
 
     def __init__(self, params, width, height, semantics, plan: ShardPlan, rank: int, capacity: int,
-                 batch: int = 1, device=None, stream=None, sets: int = 1):
+                 batch: int = 1, device=None, stream=None, sets: int = 1, batched_calls: bool = True):
         import torch
 
         from .hashtable import SDFHashtable
         self.plan, self.rank, self.capacity, self.batch = plan, rank, capacity, batch
+        self.batched_calls = batched_calls     # False: per-frame step calls (4 + 2 launches per frame)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.table = SDFHashtable(params, width, height, semantics, device=self.device.index,
                                   bucket_range=plan.bucket_range(rank), stream=stream)
@@ -148,6 +149,26 @@ class HipShard:
         self.table.integrate_packets(self.plan.world, self._cur["packets_b"][b],
                                      packet_stride=self.batch * self.packet_floats)
 
+    # whole batch in one C call each (fewest launches: 1 + batch, and 2 per multi-camera frame)
+    def generate_all(self, poses, verts_list):
+        import ctypes as C
+        if not self.batched_calls:
+            for b in range(self.batch):
+                self.generate(b, poses[b], verts_list[b])
+            return
+        p16 = np.ascontiguousarray(np.asarray(poses, np.float32).reshape(self.batch, 16))
+        ptrs = (C.c_void_p * self.batch)(*[v.data_ptr() for v in verts_list])
+        self.table.generate_keys_batch(p16, ptrs, self.rank, self.plan.world, self.bins_send, self.capacity,
+                                       self.packet, self.batch)
+
+    def apply_all(self):
+        if not self.batched_calls:
+            for b in range(self.batch):
+                self.apply(b)
+            return
+        self.table.apply_frames_batch(self.bins_recv, self.plan.world, self.capacity, self.plan.world, self.packets,
+                                      self.batch)
+
 
 class OracleShard:
     """The same interface on the CPU oracle (tests only; the buffers are CPU tensors)."""
@@ -176,6 +197,14 @@ class OracleShard:
         self.table.insert_bins(self.bins_recv[:, b].contiguous().numpy())
         self.table.integrate_packets(self.packets[:, b].contiguous().numpy())
 
+    def generate_all(self, poses, verts_list):
+        for b in range(self.batch):
+            self.generate(b, poses[b], verts_list[b])
+
+    def apply_all(self):
+        for b in range(self.batch):
+            self.apply(b)
+
 
 # ----------------------------------------------------------------------------
 # the step
@@ -184,12 +213,10 @@ def sharded_step(shard, transport: TorchDistTransport, poses, verts_list):
     """`batch` multi-camera frames from this rank's point of view: poses[b], verts_list[b] are this
     rank's camera for frame b of the batch."""
     assert len(poses) == shard.batch == len(verts_list)
-    for b in range(shard.batch):
-        shard.generate(b, poses[b], verts_list[b])
+    shard.generate_all(poses, verts_list)
     transport.all_to_all_bins(shard.bins_send, shard.bins_recv)
     transport.all_gather_packets(shard.packet.view(-1), shard.packets.view(shard.plan.world, -1))
-    for b in range(shard.batch):
-        shard.apply(b)
+    shard.apply_all()
 
 
 class ShardedPipeline:
@@ -221,8 +248,7 @@ class ShardedPipeline:
                 self.front_stream.wait_event(self.applied[s])    # set s was last used by step count-2
             sh.table.set_stream(self.front_stream)
             sh.use_set(s)
-            for b in range(sh.batch):
-                sh.generate(b, poses[b], verts_list[b])
+            sh.generate_all(poses, verts_list)
             self.transport.all_to_all_bins(sh.bins_send, sh.bins_recv)
             self.transport.all_gather_packets(sh.packet.view(-1), sh.packets.view(sh.plan.world, -1))
             self.ready[s].record(self.front_stream)
@@ -233,8 +259,7 @@ class ShardedPipeline:
             self.table_stream.wait_event(self.ready[s])
             sh.table.set_stream(self.table_stream)
             sh.use_set(s)
-            for b in range(sh.batch):
-                sh.apply(b)
+            sh.apply_all()
             self.applied[s].record(self.table_stream)
 
     def feed(self, poses, verts_list):
@@ -260,13 +285,11 @@ def loopback_step(shards, poses, verts_list):
     poses[r][b], verts_list[r][b]."""
     ex = LoopbackExchange(len(shards))
     for r, sh in enumerate(shards):
-        for b in range(sh.batch):
-            sh.generate(b, poses[r][b], verts_list[r][b])
+        sh.generate_all(poses[r], verts_list[r])
         ex.post(r, sh.bins_send, sh.packet)
     for r, sh in enumerate(shards):
         ex.fetch(r, sh.bins_recv, sh.packets)
-        for b in range(sh.batch):
-            sh.apply(b)
+        sh.apply_all()
 
 
 def reference_multi_camera_frame(table, poses, verts_list):

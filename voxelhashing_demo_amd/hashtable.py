@@ -140,6 +140,21 @@ class SDFHashtable:
         L.check(self._lib.vh_integrate_packets(self._h, num_cams, _dev_ptr(packets), packet_stride),
                 "vh_integrate_packets")
 
+    def generate_keys_batch(self, poses16, vert_ptrs, camera_id: int, num_shards: int, bins_out, capacity: int,
+                            packets_out, batch: int):
+        """`batch` frames of this camera in one call.  poses16: float32 [batch, 16] (contiguous numpy),
+        vert_ptrs: ctypes array of `batch` device addresses; bins_out [num_shards, batch, capacity, 4],
+        packets_out [batch, 32 + W*H] (dense layouts)."""
+        L.check(self._lib.vh_generate_keys_batch(
+            self._h, batch, poses16.ctypes.data_as(C.POINTER(C.c_float)), vert_ptrs, camera_id, num_shards,
+            _dev_ptr(bins_out), capacity, 0, 0, _dev_ptr(packets_out), 0), "vh_generate_keys_batch")
+
+    def apply_frames_batch(self, bins, num_bins: int, capacity: int, num_cams: int, packets, batch: int):
+        """Apply `batch` multi-camera frames: bins [num_bins, batch, capacity, 4], packets
+        [num_cams, batch, 32 + W*H] (dense layouts)."""
+        L.check(self._lib.vh_apply_frames_batch(self._h, batch, _dev_ptr(bins), num_bins, capacity, 0, 0, num_cams,
+                                                _dev_ptr(packets), 0, 0), "vh_apply_frames_batch")
+
     # ---- queries ----
     def synchronize(self):
         L.check(self._lib.vh_synchronize(self._h), "vh_synchronize")
