@@ -1,0 +1,51 @@
+// Drives the C++ SDF_Hashtable facade the way Application.cpp:33-35,82-85 drives the
+// reference class: default-constructed table, identity pose, integrate() of one vertex
+// map (twice), then the raycast that stands in for SDFRenderer::render().
+//   facade_demo <verts.bin: 640*480 float4>     prints "occupied=<n> allocated=<n> hits=<n>"
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "SDF_Hashtable.h"
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return 2;
+    const size_t n = 640 * 480;
+    std::vector<vh_float4> h_verts(n);
+    FILE *f = std::fopen(argv[1], "rb");
+    if (!f || std::fread(h_verts.data(), sizeof(vh_float4), n, f) != n) return 3;
+    std::fclose(f);
+    vh_float4 *d_verts = nullptr;
+    float *d_depth = nullptr;
+    if (hipMalloc((void **)&d_verts, n * sizeof(vh_float4)) != hipSuccess) return 4;
+    if (hipMalloc((void **)&d_depth, n * sizeof(float)) != hipSuccess) return 4;
+    hipMemcpy(d_verts, h_verts.data(), n * sizeof(vh_float4), hipMemcpyHostToDevice);
+
+    SDF_Hashtable table;                         // common.h defaults, REFERENCE semantics
+    float4x4 pose;
+    pose.setIdentity();                          // Application.cpp:82-83
+    table.integrate(pose, d_verts, (const vh_float4 *)nullptr);
+    table.integrate(pose, d_verts, (const vh_float4 *)nullptr);
+    const int occupied = table.occupiedBlockCount();
+
+    const HashTableParams &p = table.params();
+    std::vector<VoxelEntry> entries((size_t)p.numBuckets * p.bucketSize);
+    if (vh_download(table.context(), VH_BUF_HASH_TABLE, entries.data(), entries.size() * sizeof(VoxelEntry)) != VH_OK)
+        return 5;
+    int allocated = 0;
+    for (const VoxelEntry &e : entries) allocated += e.ptr != VH_FREE_BLOCK;
+
+    table.raycast(pose, d_depth);
+    std::vector<float> depth(n);
+    vh_synchronize(table.context());
+    hipMemcpy(depth.data(), d_depth, n * sizeof(float), hipMemcpyDeviceToHost);
+    int hits = 0;
+    for (float z : depth) hits += z > 0.0f;
+    std::printf("occupied=%d allocated=%d hits=%d\n", occupied, allocated, hits);
+    hipFree(d_verts);
+    hipFree(d_depth);
+    return 0;
+}
