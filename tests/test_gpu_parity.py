@@ -17,14 +17,16 @@ TOL = 1e-4            # north_star: "TSDF within 1e-4 of reference"
 I4 = np.eye(4, dtype=np.float32)
 
 
-_FUSED = {"on": 1}
+_FUSED = {"on": 1, "walk": 3}
 
 
-@pytest.fixture(autouse=True, params=["fused", "four-kernel"])
+@pytest.fixture(autouse=True, params=["fused", "four-kernel", "fused-indexed-walk", "four-kernel-wide-walk"])
 def frame_variant(request):
-    """Every test runs twice: vh_integrate as the fused two-launch frame (default) and as the
-    four step kernels (alloc claim / commit / flatten / integrate)."""
-    _FUSED["on"] = 1 if request.param == "fused" else 0
+    """Every test runs in each variant of vh_integrate: the fused two-launch frame (default), the
+    four step kernels (alloc claim / commit / flatten / integrate), the opt-in walk over the
+    bucket-occupancy bitmap, and the 16-byte-chunk table walk."""
+    _FUSED["on"] = 0 if request.param.startswith("four-kernel") else 1
+    _FUSED["walk"] = 4 if "indexed" in request.param else 2 if "wide" in request.param else 3
     yield request.param
 
 
@@ -34,6 +36,7 @@ def _pair(oracle, vh, sem, W=640, H=480, **over):
     ot = oracle.OracleTable(oracle.default_params(**kw), W, H, sem)
     gt = vh.SDFHashtable(vh.default_params(**kw), W, H, sem)
     gt.set_option("fused_frame", _FUSED["on"])
+    gt.set_option("flatten_variant", _FUSED["walk"])
     return ot, gt
 
 

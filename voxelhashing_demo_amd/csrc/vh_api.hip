@@ -415,12 +415,17 @@ static uint32_t walk_blocks(const vh_context *c)
 {
     if (c->flattenVariant == kWalkWide)
         return (uint32_t)grid_for(((size_t)c->numEntries * 20 + 15) / 16, kFlattenThreads * kChunksPerLane);
+    if (c->flattenVariant == kWalkIndexed)       // one lane per 32-bucket word of the occupancy bitmap
+        return (uint32_t)grid_for(((size_t)c->ownedBuckets + 31) / 32, kFlattenThreads);
     return (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
 }
 
 static int launch_flatten(vh_context *c)
 {
     const dim3 grid(walk_blocks(c));
+    if (c->flattenVariant == kWalkIndexed)
+        return launch(c, kPhaseFlatten, flatten_kernel<kWalkIndexed>, grid, dim3(kFlattenThreads), c->fp, c->dp,
+                      (uint32_t)c->numEntries);
     if (c->flattenVariant == kWalkWide)
         return launch(c, kPhaseFlatten, flatten_kernel<kWalkWide>, grid, dim3(kFlattenThreads), c->fp, c->dp,
                       (uint32_t)c->numEntries);
@@ -494,7 +499,12 @@ extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4
         // two launches: {claim || table walk}, then {commit + integrate}; see vh_kernels.hip
         const uint32_t claimBlocks = (uint32_t)grid_for((size_t)c->fp.width * c->fp.height, 256);
         const uint32_t scanBlocks = walk_blocks(c);
-        if (c->flattenVariant == kWalkWide)
+        if (c->flattenVariant == kWalkIndexed)
+            rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kWalkIndexed>,
+                        dim3(claimBlocks + scanBlocks), dim3(256), c->fp, c->dp,
+                        reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
+                        c->fusedParity);
+        else if (c->flattenVariant == kWalkWide)
             rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kWalkWide>, dim3(claimBlocks + scanBlocks),
                         dim3(256), c->fp, c->dp, reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries,
                         claimBlocks, c->fusedParity);

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void alloc_commit_kernel(const FrameParams fp,
 constexpr int kFlattenThreads = 256;
 constexpr int kEntriesPerLane = 8;
 constexpr int kChunksPerLane = 8;
-enum WalkKind : int { kWalkStridedNT = 0, kWalkStrided = 1, kWalkWide = 2, kWalkStridedBallot = 3 };
+enum WalkKind : int { kWalkStridedNT = 0, kWalkStrided = 1, kWalkWide = 2, kWalkStridedBallot = 3, kWalkIndexed = 4 };
 
 // First compact slot for this lane's `myCount` hits (one atomicAdd per wave that has any).
 __device__ __forceinline__ int reserve_compact_slots(const DevPtrs &dp, int counter, int myCount)
@@ -275,12 +275,53 @@ __device__ __forceinline__ void flatten_tile_ballot(const FrameParams &fp, const
     }
 }
 
+// NOT the reference algorithm (opt-in, "walk_index"): instead of visiting every VoxelEntry,
+// walk the bucket-occupancy bitmap (1 bit per bucket, maintained by the commit phase) and read
+// only the buckets that hold entries.  One lane per 32-bucket word; the compact SET is the
+// same, the bytes moved are numBuckets/8 + 100 per non-empty bucket instead of 20*N.
+__device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
+                                                   int counter)
+{
+    const uint32_t owned = fp.bucketHi - fp.bucketLo;
+    const uint32_t numWords = (owned + 31u) / 32u;
+    const uint32_t w = tileIndex * kFlattenThreads + threadIdx.x;
+    uint32_t bits = (w < numWords) ? dp.bucketBits[w] : 0u;
+    const int lane = threadIdx.x & (kWave - 1);
+    while (__ballot(bits != 0u) != 0ull) {
+        const bool have = bits != 0u;
+        const uint32_t bucket = w * 32u + (have ? (uint32_t)__ffs((int)bits) - 1u : 0u);
+        if (have) bits &= bits - 1u;
+        bool more = have;                   // entries form a prefix of the bucket
+        for (uint32_t s = 0; s < fp.bucketSize; ++s) {
+            VoxelEntry ent;
+            bool hit = false;
+            if (more) {
+                ent = dp.table[(size_t)bucket * fp.bucketSize + s];
+                more = ent.ptr != VH_FREE_BLOCK;
+                hit = more && block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);
+            }
+            const unsigned long long mask = __ballot(hit);
+            if (__ballot(more) == 0ull && mask == 0ull) break;
+            if (mask == 0ull) continue;
+            int base = 0;
+            const int leaderLane = __ffsll((long long)mask) - 1;
+            if (lane == leaderLane) base = atomicAdd(dp.counters + counter, __popcll(mask));
+            base = __shfl(base, leaderLane);
+            if (hit) dp.compact[base + __popcll(mask & ((1ull << lane) - 1ull))] = ent;
+        }
+    }
+}
+
 template <int kKind>
 __device__ __forceinline__ void flatten_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
                                              uint32_t tileIndex, int counter)
 {
     if constexpr (kKind == kWalkStridedBallot) {
         flatten_tile_ballot(fp, dp, numEntries, tileIndex, counter);
+        return;
+    }
+    if constexpr (kKind == kWalkIndexed) {
+        flatten_index_tile(fp, dp, tileIndex, counter);
         return;
     }
     uint32_t ent[kEntriesPerLane];          // entry index of each candidate, or ~0u
