@@ -68,6 +68,7 @@ struct vh_context {
     uint64_t profiledFrames = 0;
     vh_kernel_times times{};
     int integrateGrid = 2048;
+    int raycastBatch = 1;          // in-block samples whose voxels a ray fetches together (1, 2 or 4)
     int fusedFrame = 1;            // vh_integrate as two launches (0: the four step kernels)
     int commitBlocks = 128;        // workgroups serving candidates in the fused second launch
     int fusedParity = 0;           // which of the two per-frame counter sets the next fused frame uses
@@ -549,8 +550,16 @@ extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, floa
     int nsteps = (q >= 2147483648.0f) ? 0x7fffffff : (int)q;
     nsteps += 1;
     dim3 grid((fp.width + 15) / 16, (fp.height + 15) / 16);
-    int rc = launch(c, kPhaseRaycast, raycast_kernel, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx, c->rc_cy,
-                    t_min, nsteps, d_depth_out);
+    int rc;
+    if (c->raycastBatch >= 4)
+        rc = launch(c, kPhaseRaycast, raycast_kernel<4>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
+                    c->rc_cy, t_min, nsteps, d_depth_out);
+    else if (c->raycastBatch >= 2)
+        rc = launch(c, kPhaseRaycast, raycast_kernel<2>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
+                    c->rc_cy, t_min, nsteps, d_depth_out);
+    else
+        rc = launch(c, kPhaseRaycast, raycast_kernel<1>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
+                    c->rc_cy, t_min, nsteps, d_depth_out);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -770,6 +779,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (std::strcmp(name, "flatten_variant") == 0) { c->flattenVariant = value; return VH_OK; }
     if (std::strcmp(name, "integrate_grid") == 0 && value > 0) { c->integrateGrid = value; return VH_OK; }
     if (std::strcmp(name, "fused_frame") == 0) { c->fusedFrame = value; return VH_OK; }
+    if (std::strcmp(name, "raycast_batch") == 0 && value > 0) { c->raycastBatch = value; return VH_OK; }
     if (std::strcmp(name, "commit_blocks") == 0 && value > 0) { c->commitBlocks = value; return VH_OK; }
     return fail(VH_ERR_INVALID_ARGUMENT, "unknown option");
 }

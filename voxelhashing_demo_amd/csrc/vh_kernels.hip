@@ -757,7 +757,9 @@ __device__ __forceinline__ int lookup_block(const FrameParams &fp, const DevPtrs
 // 16x16-pixel tiles: a wave is a 16x4 patch of neighbouring rays, which walk
 // the same blocks and keep the bucket / voxel lines hot in L2.
 constexpr float kSkipMargin = 0.01f;     // voxels; see the empty-block skip below
+// kRayBatch (template): in-block samples whose voxels are fetched together
 
+template <int kRayBatch>
 __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, const DevPtrs dp, float fx, float fy,
                                                       float cx, float cy, float tMin, int nSteps,
                                                       float *__restrict__ depthOut)
@@ -773,7 +775,7 @@ __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, cons
     const float dirX = fp.T[0] * dx + fp.T[1] * dy + fp.T[2];
     const float dirY = fp.T[4] * dx + fp.T[5] * dy + fp.T[6];
     const float dirZ = fp.T[8] * dx + fp.T[9] * dy + fp.T[10];
-    bool prevValid = false, haveKey = false;
+    bool prevValid = false, haveKey = false, found = false;
     float prevSdf = 0.0f, prevT = 0.0f, hit = 0.0f;
     int ckx = 0, cky = 0, ckz = 0, cptr = VH_FREE_BLOCK;
     for (int i = 0; i < nSteps; ++i) {
@@ -811,16 +813,44 @@ __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, cons
             if (steps > (float)i && steps < 2.0e9f) i = min((int)steps, nSteps - 1);
             continue;
         }
-        const int lx = (int)((uint32_t)vx - (uint32_t)kx * 8u);
-        const int ly = (int)((uint32_t)vy - (uint32_t)ky * 8u);
-        const int lz = (int)((uint32_t)vz - (uint32_t)kz * 8u);
-        const Voxel s = dp.blocks[(size_t)cptr + (size_t)(lz * 64 + ly * 8 + lx)];
-        if (!(s.weight > 0.0f)) { prevValid = false; continue; }
-        if (prevValid && prevSdf > 0.0f && s.sdf <= 0.0f) {
-            hit = prevT + (dt * prevSdf) / (prevSdf - s.sdf);
-            break;
+        // Present block: the voxel of sample i and of the next kRayBatch-1 samples that still
+        // fall into this block are fetched together (their addresses do not depend on each
+        // other, only the hit test is sequential), so a ray pays one memory latency per batch
+        // instead of one per sample.  Samples are then classified strictly in order.
+        float bt[kRayBatch];
+        Voxel bs[kRayBatch];
+        bool inBlock[kRayBatch];
+#pragma unroll
+        for (int j = 0; j < kRayBatch; ++j) {
+            bt[j] = tMin + (float)(i + j) * dt;
+            const float4 pj = mat4_mul(fp.T, dx * bt[j], dy * bt[j], bt[j], 1.0f);
+            const int jx = world2voxel1(pj.x, fp.voxelSize);
+            const int jy = world2voxel1(pj.y, fp.voxelSize);
+            const int jz = world2voxel1(pj.z, fp.voxelSize);
+            inBlock[j] = (i + j < nSteps) && voxel2block1(jx) == kx && voxel2block1(jy) == ky &&
+                         voxel2block1(jz) == kz;
+            const int lx = (int)((uint32_t)jx - (uint32_t)kx * 8u);
+            const int ly = (int)((uint32_t)jy - (uint32_t)ky * 8u);
+            const int lz = (int)((uint32_t)jz - (uint32_t)kz * 8u);
+            bs[j] = inBlock[j] ? dp.blocks[(size_t)cptr + (size_t)(lz * 64 + ly * 8 + lx)] : Voxel{0.0f, 0.0f};
         }
-        prevValid = true; prevSdf = s.sdf; prevT = tt;
+        bool done = false;
+        int used = 0;
+#pragma unroll
+        for (int j = 0; j < kRayBatch; ++j) {
+            if (done || !inBlock[j]) { done = true; continue; }   // first sample outside: back to the general path
+            used = j + 1;
+            if (!(bs[j].weight > 0.0f)) { prevValid = false; continue; }
+            if (prevValid && prevSdf > 0.0f && bs[j].sdf <= 0.0f) {
+                hit = prevT + (dt * prevSdf) / (prevSdf - bs[j].sdf);
+                found = true;
+                done = true;
+                continue;
+            }
+            prevValid = true; prevSdf = bs[j].sdf; prevT = bt[j];
+        }
+        if (found) break;
+        i += used - 1;            // sample i itself is always in the block, so used >= 1
     }
     depthOut[(size_t)v * fp.width + u] = hit;
 }
