@@ -22,6 +22,7 @@
 #ifndef VOXELHASH_H
 #define VOXELHASH_H
 
+#include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -259,6 +260,22 @@ int vh_generate_keys_batch(vh_context *ctx, int32_t batch, const float *poses,
 int vh_apply_frames_batch(vh_context *ctx, int32_t batch, const int32_t *d_bins, int32_t num_bins,
                           int32_t capacity, int32_t bin_stride, int32_t frame_stride, int32_t num_cams,
                           const float *d_packets, size_t packet_stride, size_t packet_frame_stride);
+
+/* ------------------------------------------------------------------ */
+/* depth pre-processing                        */
+/* ------------------------------------------------------------------ */
+/* preProcess (CameraTrackingUtils.cu:115-120) = calculateVertexPositions (:50-73) +
+ * calculateNormals (:75-113) as one kernel: uint16 depth (5000 units = 1 m, 0 = invalid)
+ * -> float4 vertex map (K_inv*(x,y,1)*depth, w = 1; invalid -> (0,0,0,1)) and float4
+ * normal map (central-difference cross product, normalised; 0 on the border or next to an
+ * invalid pixel).  k_inv: the 3x3 the reference uploads with SetCameraIntrinsic, read
+ * row-major.  The outputs are what vh_integrate takes as d_verts / d_normals. */
+int vh_preprocess(const uint16_t *d_depth, const float k_inv[9], int32_t width, int32_t height,
+                  vh_float4 *d_positions, vh_float4 *d_normals, void *hip_stream);
+/* the reference's own names (CameraTrackingUtils.cu:218-222, 115-120): 640x480, default
+ * stream, synchronous */
+bool SetCameraIntrinsic(const float *intrinsic, const float *invIntrinsic);
+void preProcess(vh_float4 *positions, vh_float4 *normals, const uint16_t *depth);
 
 /* ------------------------------------------------------------------ */
 /* drop-in names (VoxelUtils.h:5-13); process-global default context    */

@@ -124,6 +124,7 @@ def lib():
         L.vho_write_packet.argtypes = [C.c_void_p, fp, fp]
         L.vho_integrate_packets.argtypes = [C.c_void_p, C.c_int, fp]
         L.vho_integrate_packets.restype = C.c_int
+        L.vho_preprocess.argtypes = [C.POINTER(C.c_uint16), fp, C.c_int, C.c_int, fp, fp]
         _lib = L
     return _lib
 
@@ -190,6 +191,18 @@ def project(m, p):
 
 def launch_rank(x: int, y: int, width: int) -> int:
     return int(lib().vho_launch_rank(x, y, width))
+
+
+def preprocess(depth_u16, k_inv):
+    """(positions, normals) float32 [H, W, 4] from a uint16 depth image (preProcess,
+    CameraTrackingUtils.cu:115-120)."""
+    d = np.ascontiguousarray(depth_u16, np.uint16)
+    H, W = d.shape
+    k = np.ascontiguousarray(np.asarray(k_inv, np.float32).reshape(9))
+    pos = np.empty((H, W, 4), np.float32)
+    nrm = np.empty((H, W, 4), np.float32)
+    lib().vho_preprocess(d.ctypes.data_as(C.POINTER(C.c_uint16)), _fptr(k), W, H, _fptr(pos), _fptr(nrm))
+    return pos, nrm
 
 
 class OracleTable:

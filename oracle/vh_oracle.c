@@ -668,6 +668,55 @@ uint32_t vho_bucket_lo(const vho_table *t) { return t->bucket_lo; }
 uint32_t vho_bucket_hi(const vho_table *t) { return t->bucket_hi; }
 
 /* ------------------------------------------------------------------ */
+/* depth pre-processing: the step that makes   */
+/* the vertex / normal maps integrate() consumes                        */
+/* ------------------------------------------------------------------ */
+
+/* calculateVertexPositions, CameraTrackingUtils.cu:50-73: depth = d / 5000.0f (TUM
+ * convention), point = (K_inv * (x, y, 1)) * depth, w = 1; an invalid depth of 0
+ * gives (0,0,0,1).  k_inv is the 3x3 the reference uploads with SetCameraIntrinsic
+ * (:218-222), read row-major by float3x3::operator*. */
+static void vertex_from_depth(const uint16_t *depth, const float k_inv[9], int W, int x, int y, float out[3])
+{
+    const float d = (float)depth[(size_t)y * W + x] / 5000.0f;
+    const float c[3] = { (float)x, (float)y, 1.0f };
+    float p[3];
+    mat3_mul_vec3(k_inv, c, p);
+    out[0] = p[0] * d; out[1] = p[1] * d; out[2] = p[2] * d;
+}
+
+/* preProcess, CameraTrackingUtils.cu:115-120 = calculateVertexPositions (:50-73) +
+ * calculateNormals (:75-113): central differences, cross product, normalised with a
+ * true divide; zero where a neighbour is missing (.x == 0) or on the image border. */
+void vho_preprocess(const uint16_t *depth, const float k_inv[9], int W, int H,
+                    float *positions /* W*H*4 */, float *normals /* W*H*4 */)
+{
+    for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+        float *v = positions + 4 * ((size_t)y * W + x);
+        vertex_from_depth(depth, k_inv, W, x, y, v);
+        v[3] = 1.0f;
+    }
+    for (int y = 0; y < H; ++y)
+    for (int x = 0; x < W; ++x) {
+        float *n = normals + 4 * ((size_t)y * W + x);
+        n[0] = n[1] = n[2] = n[3] = 0.0f;
+        if (!(x > 0 && x < W - 1 && y > 0 && y < H - 1)) continue;                   /* :95 */
+        const float *CC = positions + 4 * ((size_t)y * W + x);
+        const float *PC = positions + 4 * ((size_t)(y + 1) * W + x);
+        const float *CP = positions + 4 * ((size_t)y * W + x + 1);
+        const float *MC = positions + 4 * ((size_t)(y - 1) * W + x);
+        const float *CM = positions + 4 * ((size_t)y * W + x - 1);
+        if (!(CC[0] != 0 && PC[0] != 0 && CP[0] != 0 && MC[0] != 0 && CM[0] != 0)) continue;   /* :102 */
+        const float a[3] = { PC[0] - MC[0], PC[1] - MC[1], PC[2] - MC[2] };
+        const float b[3] = { CP[0] - CM[0], CP[1] - CM[1], CP[2] - CM[2] };
+        const float c[3] = { a[1]*b[2] - a[2]*b[1], a[2]*b[0] - a[0]*b[2], a[0]*b[1] - a[1]*b[0] };   /* cross */
+        const float l = sqrtf(c[0]*c[0] + c[1]*c[1] + c[2]*c[2]);                       /* length */
+        if (l > 0.0f) { n[0] = c[0] / l; n[1] = c[1] / l; n[2] = c[2] / l; n[3] = 0.0f; }   /* :108-110 */
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* accessors                                                           */
 /* ------------------------------------------------------------------ */
 const vho_params *vho_get_params(const vho_table *t) { return &t->p; }

@@ -108,6 +108,10 @@ int  vho_integrate_packets(vho_table *t, int num_cams, const float *packets);
 uint32_t vho_bucket_lo(const vho_table *t);
 uint32_t vho_bucket_hi(const vho_table *t);
 
+/* ---- depth pre-processing (CameraTrackingUtils.cu:50-120) ---- */
+void vho_preprocess(const uint16_t *depth, const float k_inv[9], int width, int height,
+                    float *positions, float *normals);
+
 /* ---- accessors ---- */
 const vho_params *vho_get_params(const vho_table *t);
 vho_entry        *vho_hash_table(vho_table *t);      /* numBuckets*bucketSize entries */

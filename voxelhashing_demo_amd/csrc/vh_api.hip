@@ -832,6 +832,44 @@ extern "C" int vh_debug_eval(vh_context *c, const vh_float4 *d_points, int32_t n
 }
 
 // ---------------------------------------------------------------------------
+// depth pre-processing (CameraTrackingUtils.cu:115-120, 218-222)
+// ---------------------------------------------------------------------------
+extern "C" int vh_preprocess(const uint16_t *d_depth, const float k_inv[9], int32_t width, int32_t height,
+                             vh_float4 *d_positions, vh_float4 *d_normals, void *hip_stream)
+{
+    if (!d_depth || !k_inv || !d_positions || !d_normals || width <= 0 || height <= 0 ||
+        (uint64_t)width * height > (1u << 24))
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    Mat3 k;
+    std::memcpy(k.m, k_inv, sizeof k.m);
+    preprocess_kernel<<<grid_for((size_t)width * height, 256), 256, 0, (hipStream_t)hip_stream>>>(
+        d_depth, k, width, height, reinterpret_cast<float4 *>(d_positions), reinterpret_cast<float4 *>(d_normals));
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+static float g_k_inv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+
+extern "C" bool SetCameraIntrinsic(const float *intrinsic, const float *invIntrinsic)
+{
+    (void)intrinsic;     // K itself only feeds the ICP kernels (out of scope)
+    if (!invIntrinsic) return false;
+    std::memcpy(g_k_inv, invIntrinsic, sizeof g_k_inv);
+    return true;
+}
+
+extern "C" void preProcess(vh_float4 *positions, vh_float4 *normals, const uint16_t *depth)
+{
+    // 640x480 and the default stream, like the reference (CameraTrackingUtils.cu:28-36,115-120)
+    int rc = vh_preprocess(depth, g_k_inv, 640, 480, positions, normals, nullptr);
+    if (rc == VH_OK && hipDeviceSynchronize() != hipSuccess) rc = VH_ERR_HIP;
+    if (rc != VH_OK) {
+        std::fprintf(stderr, "voxelhash: preProcess failed: %s (%s)\n", vh_error_string(rc), vh_last_error());
+        std::exit(EXIT_FAILURE);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // drop-in names (VoxelUtils.h:5-13) on a process-global context
 // ---------------------------------------------------------------------------
 static vh_context *g_default = nullptr;

@@ -856,6 +856,52 @@ __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, cons
 }
 
 // ---------------------------------------------------------------------------
+// depth pre-processing (preProcess, CameraTrackingUtils.cu:115-120)
+// ---------------------------------------------------------------------------
+// calculateVertexPositions (:50-73) and calculateNormals (:75-113) as ONE kernel: the
+// reference writes the vertex map, synchronises, and reads it back five times per pixel for
+// the normals; here the four neighbour vertices are recomputed from the 2-byte depth (same
+// arithmetic, same bits), so the pass reads 2 B and writes 32 B per pixel.
+struct Mat3 { float m[9]; };
+
+__device__ __forceinline__ float3 vertex_from_depth(const uint16_t *__restrict__ depth, const Mat3 &kinv, int W,
+                                                    int x, int y)
+{
+    const float d = (float)depth[(size_t)y * W + x] / 5000.0f;          // :64, 5000 units = 1 m
+    const float fx = (float)x, fy = (float)y;
+    const float px = kinv.m[0] * fx + kinv.m[1] * fy + kinv.m[2] * 1.0f; // K_inv * (x, y, 1)  :71
+    const float py = kinv.m[3] * fx + kinv.m[4] * fy + kinv.m[5] * 1.0f;
+    const float pz = kinv.m[6] * fx + kinv.m[7] * fy + kinv.m[8] * 1.0f;
+    return make_float3(px * d, py * d, pz * d);
+}
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint16_t *__restrict__ depth, const Mat3 kinv, int W,
+                                                         int H, float4 *__restrict__ positions,
+                                                         float4 *__restrict__ normals)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= W * H) return;
+    const int y = idx / W, x = idx - y * W;
+    const float3 cc = vertex_from_depth(depth, kinv, W, x, y);
+    positions[idx] = make_float4(cc.x, cc.y, cc.z, 1.0f);                                    // :73
+    float4 n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                                          // :90
+    if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {                                          // :92
+        const float3 pc = vertex_from_depth(depth, kinv, W, x, y + 1);
+        const float3 cp = vertex_from_depth(depth, kinv, W, x + 1, y);
+        const float3 mc = vertex_from_depth(depth, kinv, W, x, y - 1);
+        const float3 cm = vertex_from_depth(depth, kinv, W, x - 1, y);
+        if (cc.x != 0.0f && pc.x != 0.0f && cp.x != 0.0f && mc.x != 0.0f && cm.x != 0.0f) { // :100
+            const float ax = pc.x - mc.x, ay = pc.y - mc.y, az = pc.z - mc.z;
+            const float bx = cp.x - cm.x, by = cp.y - cm.y, bz = cp.z - cm.z;
+            const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;   // cross
+            const float l = __builtin_sqrtf(nx * nx + ny * ny + nz * nz);                          // length
+            if (l > 0.0f) n = make_float4(nx / l, ny / l, nz / l, 0.0f);                     // :105-109
+        }
+    }
+    normals[idx] = n;
+}
+
+// ---------------------------------------------------------------------------
 // set-up kernels (deviceAllocate, VoxelUtils.cu:151-166)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void reset_table_kernel(VoxelEntry *table, size_t n)

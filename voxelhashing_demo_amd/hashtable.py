@@ -43,6 +43,17 @@ def _pose16(pose):
     return a, a.ctypes.data_as(C.POINTER(C.c_float))
 
 
+def preprocess(depth_u16, k_inv, positions, normals, stream=None):
+    """preProcess (CameraTrackingUtils.cu:115-120) on the GPU: uint16 depth [H, W] -> float4 vertex
+    and normal maps [H, W, 4] (device tensors, written in place)."""
+    H, W = depth_u16.shape
+    k = np.ascontiguousarray(np.asarray(k_inv, np.float32).reshape(9))
+    handle = 0 if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+    L.check(L.load().vh_preprocess(_dev_ptr(depth_u16), k.ctypes.data_as(C.POINTER(C.c_float)), W, H,
+                                   _dev_ptr(positions), _dev_ptr(normals), C.c_void_p(handle)), "vh_preprocess")
+    return positions, normals
+
+
 class SDFHashtable:
     """One voxel-hash table on one GPU.
 
