@@ -262,6 +262,20 @@ int vh_apply_frames_batch(vh_context *ctx, int32_t batch, const int32_t *d_bins,
                           const float *d_packets, size_t packet_stride, size_t packet_frame_stride);
 
 /* ------------------------------------------------------------------ */
+/* model dump / checkpoint                     */
+/* ------------------------------------------------------------------ */
+/* Text dump in the format of SDFRenderer::printSDFdata (SDFRenderer.cpp:71-110, written to
+ * SDF_dump.txt by the reference): occupied count, then per compact entry pos / ptr / offset
+ * and 512 sdf values at 4 decimals.  Like the original, entry i is followed by voxels
+ * [512*i, 512*i+512) of the volume, not by the block its ptr names.  Synchronises. */
+int vh_dump_sdf_text(vh_context *ctx, const char *path);
+/* Binary snapshot of the model (hash table, heap, counters, the 4 KiB block of every
+ * allocated entry) and its restore into a context created with the same configuration;
+ * fusing can continue after vh_load_snapshot as if never interrupted.  Both synchronise. */
+int vh_save_snapshot(vh_context *ctx, const char *path);
+int vh_load_snapshot(vh_context *ctx, const char *path);
+
+/* ------------------------------------------------------------------ */
 /* depth pre-processing                        */
 /* ------------------------------------------------------------------ */
 /* preProcess (CameraTrackingUtils.cu:115-120) = calculateVertexPositions (:50-73) +

@@ -108,6 +108,9 @@ SIGNATURES = {
     "vh_generate_keys_batch": (C.c_int, [_vp, _i32, _fp, C.POINTER(_vp), _u32, _i32, _vp, _i32, _i32, _i32, _vp,
                                          C.c_size_t]),
     "vh_apply_frames_batch": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, C.c_size_t, C.c_size_t]),
+    "vh_dump_sdf_text": (C.c_int, [_vp, C.c_char_p]),
+    "vh_save_snapshot": (C.c_int, [_vp, C.c_char_p]),
+    "vh_load_snapshot": (C.c_int, [_vp, C.c_char_p]),
     "vh_preprocess": (C.c_int, [_vp, _fp, _i32, _i32, _vp, _vp, _vp]),
     "SetCameraIntrinsic": (C.c_bool, [_fp, _fp]),
     "preProcess": (None, [_vp, _vp, _vp]),

@@ -166,6 +166,17 @@ class SDFHashtable:
         L.check(self._lib.vh_apply_frames_batch(self._h, batch, _dev_ptr(bins), num_bins, capacity, 0, 0, num_cams,
                                                 _dev_ptr(packets), 0, 0), "vh_apply_frames_batch")
 
+    # ---- model dump / checkpoint ----
+    def dump_sdf_text(self, path: str):
+        """SDF_dump.txt in the format of SDFRenderer::printSDFdata (SDFRenderer.cpp:71-110)."""
+        L.check(self._lib.vh_dump_sdf_text(self._h, str(path).encode()), "vh_dump_sdf_text")
+
+    def save_snapshot(self, path: str):
+        L.check(self._lib.vh_save_snapshot(self._h, str(path).encode()), "vh_save_snapshot")
+
+    def load_snapshot(self, path: str):
+        L.check(self._lib.vh_load_snapshot(self._h, str(path).encode()), "vh_load_snapshot")
+
     # ---- queries ----
     def synchronize(self):
         L.check(self._lib.vh_synchronize(self._h), "vh_synchronize")
