@@ -370,6 +370,13 @@ def bench_sharded(args, wl, rank, world, local_rank):
         drain()                      # every fed step has been applied when the clock stops
         dist.barrier()
         elapsed = time.perf_counter() - t0
+        # per-dispatch HIP-event timing of the table kernels (separate, untimed pass)
+        shard.table.set_profiling(True)
+        for i in range(3):
+            step(args.warmup + args.steps + i)
+        drain()
+        kt = shard.table.kernel_times(reset=True)
+        shard.table.set_profiling(False)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -378,6 +385,16 @@ def bench_sharded(args, wl, rank, world, local_rank):
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     if rank == 0:
         frames = args.steps * world * batch
+        launches = max(1, kt["launches"])
+        walk_us = 1e3 * kt["frame_scan_claim_ms"] / launches
+        # rank 0's dominant table launch: one pass over its shard of the VoxelEntry array for all
+        # cameras (20 B per owned entry) + the compact entries written
+        walk_bytes = 20 * shard.table.num_entries + 24 * c["occupied"]
+        achieved = walk_bytes / (walk_us * 1e-6) / 1e9 if walk_us > 0 else 0.0
+        roofline = dict(bound="hbm", kernel="frame_multi_scan_claim_kernel (rank 0)", achieved=round(achieved, 1),
+                        peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4), traffic=None,
+                        bytes_per_launch=walk_bytes, us_per_launch=round(walk_us, 2),
+                        commit_integrate_us=round(1e3 * kt["frame_commit_integrate_ms"] / launches, 2))
         out = dict(
             metric="frames/s TSDF-integrated, 640x480" if (Wd, Ht) == (640, 480) else f"frames/s TSDF-integrated, {Wd}x{Ht}",
             value=round(frames / elapsed, 1), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -390,7 +407,7 @@ def bench_sharded(args, wl, rank, world, local_rank):
                         resident_frames=nframes, key_bin_capacity=capacity, pipelined=pipelined,
                         occupied_blocks_all_ranks=int(stats[0]), allocated_blocks_all_ranks=int(stats[1]),
                         key_bin_overflows=int(stats[2])),
-            roofline=None, cpu_baseline=None)
+            roofline=roofline, cpu_baseline=None)
         print(json.dumps(out))
     shard.table.close()
     dist.destroy_process_group()
