@@ -20,14 +20,18 @@ I4 = np.eye(4, dtype=np.float32)
 _FUSED = {"on": 1, "walk": 3}
 
 
-@pytest.fixture(autouse=True, params=["fused", "four-kernel", "fused-indexed-walk", "four-kernel-wide-walk"])
+@pytest.fixture(autouse=True, params=["fused-mask", "fused-ballot-walk", "four-kernel", "fused-indexed-walk",
+                                      "four-kernel-wide-walk", "fused-persistent-walk"])
 def frame_variant(request):
-    """Every test runs in each variant of vh_integrate: the fused two-launch frame (default), the
-    four step kernels (alloc claim / commit / flatten / integrate), the opt-in walk over the
-    bucket-occupancy bitmap, and the 16-byte-chunk table walk."""
-    _FUSED["on"] = 0 if request.param.startswith("four-kernel") else 1
-    _FUSED["walk"] = 4 if "indexed" in request.param else 2 if "wide" in request.param else 3
-    yield request.param
+    """Every test runs in each variant of vh_integrate: the fused two-launch frame in its mask
+    form (default) and with the in-walk compaction, the four step kernels (alloc claim / commit /
+    flatten / integrate), the opt-in walk over the bucket-occupancy bitmap, the 16-byte-chunk
+    walk and the persistent prefetching walk."""
+    p = request.param
+    _FUSED["on"] = 0 if p.startswith("four-kernel") else 1
+    _FUSED["walk"] = (4 if "indexed" in p else 2 if "wide" in p else 5 if "persistent" in p
+                      else 6 if "mask" in p else 3)
+    yield p
 
 
 def _pair(oracle, vh, sem, W=640, H=480, **over):

@@ -13,7 +13,7 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("frame_scan_claim_kernel", "frame_commit_integrate_kernel", "alloc_claim_kernel", "alloc_commit_kernel",
+OURS = ("frame_mask_claim_kernel", "frame_commit_consume_kernel", "frame_scan_claim_kernel", "frame_commit_integrate_kernel", "frame_multi_scan_claim_kernel", "frame_multi_commit_integrate_kernel", "preprocess_kernel", "alloc_claim_kernel", "alloc_commit_kernel",
         "flatten_multi_kernel", "flatten_kernel", "integrate_multi_kernel", "integrate_kernel", "raycast_kernel",
         "generate_keys_kernel", "prepare_generate_kernel", "claim_bins_kernel", "reset_table_kernel",
         "reset_heap_kernel", "debug_eval_kernel")

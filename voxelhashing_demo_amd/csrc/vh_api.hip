@@ -69,12 +69,18 @@ struct vh_context {
     uint64_t profiledFrames = 0;
     vh_kernel_times times{};
     int integrateGrid = 2048;
+    int persistentBlocks = 2048;   // workgroups of the persistent walk (flatten_variant 5)
     int raycastBatch = 1;          // in-block samples whose voxels a ray fetches together (1, 2 or 4)
     int fusedFrame = 1;            // vh_integrate as two launches (0: the four step kernels)
     int commitBlocks = 128;        // workgroups serving candidates in the fused second launch
     int fusedParity = 0;           // which of the two per-frame counter sets the next fused frame uses
     bool compactArmed = false;     // alloc_commit has zeroed the compact counter and no flatten ran since
-    int flattenVariant = 3;        // WalkKind (A/B in one process, C2: 3 = 16.7 us, 1 = 17.8, 2 = 18.9, 0 = +7 %)
+    // WalkKind.  Same-process A/B of the fused frame (launch 1 + launch 2, us): C2  3: 17.2 + 5.1,
+    // 6 (mask form): 16.8 + 13.6, 1: 17.8, 2: 18.9, 5: 17.7, 4 (index, not the reference walk): 6.4 + 5.3;
+    // C3  3: 88 + 22, 6: 74 + 51, 4: 43 + 19.  The mask form makes launch 1 a pure stream but launch 2
+    // then serialises mask -> entry -> atomic -> block update inside each workgroup.
+    int flattenVariant = 3;
+    int occupiedCounter = kCompactCount;   // which device counter holds the occupied count of the last frame
 };
 
 struct DeviceGuard {
@@ -206,6 +212,7 @@ static int free_buffers(vh_context *c)
     if (c->dp.candidates) (void)hipFree(c->dp.candidates);
     if (c->dp.compactMask) (void)hipFree(c->dp.compactMask);
     if (c->dp.bucketBits) (void)hipFree(c->dp.bucketBits);
+    if (c->dp.allocMask) (void)hipFree(c->dp.allocMask);
     c->dp = DevPtrs{};
     return VH_OK;
 }
@@ -280,6 +287,9 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     VH_ALLOC(dp.candidates, sizeof(int4) * npix);
     VH_ALLOC(dp.compactMask, sizeof(uint32_t) * c->numEntries);
     VH_ALLOC(dp.bucketBits, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32));
+    // 32 mask words per 2048-entry tile, padded to whole 256-word chunks
+    VH_ALLOC(dp.allocMask, sizeof(unsigned long long) *
+                               (((c->numEntries + kMaskChunkEntries - 1) / kMaskChunkEntries) * kMaskChunkWords));
 #undef VH_ALLOC
 
     // deviceAllocate, VoxelUtils.cu:183-208 (+ the compact table and the zeroed
@@ -419,6 +429,9 @@ static uint32_t walk_blocks(const vh_context *c)
         return (uint32_t)grid_for(((size_t)c->numEntries * 20 + 15) / 16, kFlattenThreads * kChunksPerLane);
     if (c->flattenVariant == kWalkIndexed)       // one lane per 32-bucket word of the occupancy bitmap
         return (uint32_t)grid_for(((size_t)c->ownedBuckets + 31) / 32, kFlattenThreads);
+    if (c->flattenVariant == kWalkPersistent)    // resident workgroups striding over the tiles
+        return std::min<uint32_t>((uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane),
+                                  (uint32_t)c->persistentBlocks);
     return (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
 }
 
@@ -427,6 +440,9 @@ static int launch_flatten(vh_context *c)
     const dim3 grid(walk_blocks(c));
     if (c->flattenVariant == kWalkIndexed)
         return launch(c, kPhaseFlatten, flatten_kernel<kWalkIndexed>, grid, dim3(kFlattenThreads), c->fp, c->dp,
+                      (uint32_t)c->numEntries);
+    if (c->flattenVariant == kWalkPersistent)
+        return launch(c, kPhaseFlatten, flatten_kernel<kWalkPersistent>, grid, dim3(kFlattenThreads), c->fp, c->dp,
                       (uint32_t)c->numEntries);
     if (c->flattenVariant == kWalkWide)
         return launch(c, kPhaseFlatten, flatten_kernel<kWalkWide>, grid, dim3(kFlattenThreads), c->fp, c->dp,
@@ -466,6 +482,7 @@ extern "C" int vh_flatten(vh_context *c, int32_t *occupied_out)
     if (!c->compactArmed)
         VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));   // :760
     c->compactArmed = false;
+    c->occupiedCounter = kCompactCount;
     int rc = launch_flatten(c);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
@@ -497,12 +514,36 @@ extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4
     int rc = vh_set_pose(c, pose);
     if (rc == VH_OK) rc = vh_reset_mutexes(c);
     if (rc != VH_OK) return rc;
-    if (c->fusedFrame) {
+    if (c->fusedFrame && c->flattenVariant == kWalkMask) {
+        // mask form: {claim || pure-stream walk that stores allocation masks}, then
+        // {commit || consume the masks: frustum test, compaction, TSDF update}
+        const uint32_t claimBlocks = (uint32_t)grid_for((size_t)c->fp.width * c->fp.height, 256);
+        const uint32_t tiles = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
+        rc = launch(c, kPhaseFrameScanClaim, frame_mask_claim_kernel, dim3(claimBlocks + tiles), dim3(256), c->fp,
+                    c->dp, reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
+                    c->fusedParity);
+        if (rc != VH_OK) return rc;
+        const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
+        const uint32_t chunks = (uint32_t)grid_for(c->numEntries, kMaskChunkEntries);
+        rc = launch(c, kPhaseFrameCommitIntegrate, frame_commit_consume_kernel, dim3(commitBlocks + chunks), dim3(256),
+                    c->fp, c->dp, reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, commitBlocks,
+                    c->fusedParity);
+        if (rc != VH_OK) return rc;
+        c->occupiedCounter = kScanCount + c->fusedParity;   // this frame's slot counter = occupied count
+        c->fusedParity ^= 1;
+        c->compactArmed = false;
+    } else if (c->fusedFrame) {
         // two launches: {claim || table walk}, then {commit + integrate}; see vh_kernels.hip
+        c->occupiedCounter = kCompactCount;
         const uint32_t claimBlocks = (uint32_t)grid_for((size_t)c->fp.width * c->fp.height, 256);
         const uint32_t scanBlocks = walk_blocks(c);
         if (c->flattenVariant == kWalkIndexed)
             rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kWalkIndexed>,
+                        dim3(claimBlocks + scanBlocks), dim3(256), c->fp, c->dp,
+                        reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
+                        c->fusedParity);
+        else if (c->flattenVariant == kWalkPersistent)
+            rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kWalkPersistent>,
                         dim3(claimBlocks + scanBlocks), dim3(256), c->fp, c->dp,
                         reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
                         c->fusedParity);
@@ -530,6 +571,7 @@ extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4
         c->compactArmed = false;
     } else {
         // alloc_commit re-arms the compact counter, so no memset node is needed here
+        c->occupiedCounter = kCompactCount;
         if ((rc = launch_alloc(c, verts)) != VH_OK) return rc;
         c->compactArmed = false;
         if ((rc = launch_flatten(c)) != VH_OK) return rc;
@@ -658,6 +700,7 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
         if (rc != VH_OK) return rc;
         c->fusedParity ^= 1;
         c->compactArmed = false;
+        c->occupiedCounter = kCompactCount;
         if (c->profiling) c->profiledFrames += 1;
     }
     VH_HIP(hipGetLastError());
@@ -694,6 +737,7 @@ extern "C" int vh_integrate_packets(vh_context *c, int32_t num_cams, const float
     if (!c->compactArmed)
         VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));
     c->compactArmed = false;
+    c->occupiedCounter = kCompactCount;
     int rc = launch(c, kPhaseFlatten, flatten_multi_kernel,
                     dim3(grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane)), dim3(kFlattenThreads), c->fp,
                     c->dp, (uint32_t)c->numEntries, num_cams, d_packets, stride);
@@ -724,14 +768,14 @@ extern "C" int vh_get_counters(vh_context *c, vh_counters *out)
     int32_t h[kNumCounters];
     VH_HIP(hipMemcpyAsync(h, c->dp.counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     VH_HIP(hipStreamSynchronize(c->stream));
-    out->occupied = h[kCompactCount];
+    out->occupied = h[c->occupiedCounter];
     out->heap_counter = h[kHeapCounter];
     out->allocated_total = (uint32_t)h[kAllocatedTotal];
     out->heap_exhausted = (uint32_t)h[kHeapExhausted];
     out->candidates = (uint32_t)h[kLastCandidates];
     out->epoch = c->fp.epoch;
     out->bin_overflow = (uint32_t)h[kBinOverflow];
-    c->params.numOccupiedBlocks = (uint32_t)h[kCompactCount];
+    c->params.numOccupiedBlocks = (uint32_t)h[c->occupiedCounter];
     return VH_OK;
 }
 
@@ -912,6 +956,7 @@ extern "C" int vh_load_snapshot(vh_context *c, const char *path)
     c->fp.epoch = 0;                 // the claim words were cleared: any epoch >= 1 is fresh
     c->fusedParity = 0;
     c->compactArmed = false;
+    c->occupiedCounter = kCompactCount;
     return VH_OK;
 }
 
@@ -922,6 +967,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (std::strcmp(name, "integrate_grid") == 0 && value > 0) { c->integrateGrid = value; return VH_OK; }
     if (std::strcmp(name, "fused_frame") == 0) { c->fusedFrame = value; return VH_OK; }
     if (std::strcmp(name, "raycast_batch") == 0 && value > 0) { c->raycastBatch = value; return VH_OK; }
+    if (std::strcmp(name, "persistent_blocks") == 0 && value > 0) { c->persistentBlocks = value; return VH_OK; }
     if (std::strcmp(name, "commit_blocks") == 0 && value > 0) { c->commitBlocks = value; return VH_OK; }
     return fail(VH_ERR_INVALID_ARGUMENT, "unknown option");
 }

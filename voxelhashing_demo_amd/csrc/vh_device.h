@@ -69,6 +69,7 @@ struct DevPtrs {
     uint32_t candCapacity;
     uint32_t *compactMask;    // multi-camera frames: cameras that see compact entry i
     uint32_t *bucketBits;     // one bit per owned bucket: holds at least one entry
+    unsigned long long *allocMask;   // fused frame: one bit per entry "allocated", rewritten by every walk
 };
 
 // camera packet of the sharded path: 16 floats pose, 16 floats inverse, W*H camera-z plane

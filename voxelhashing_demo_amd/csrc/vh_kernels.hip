@@ -215,7 +215,10 @@ __global__ __launch_bounds__(256) void alloc_commit_kernel(const FrameParams fp,
 constexpr int kFlattenThreads = 256;
 constexpr int kEntriesPerLane = 8;
 constexpr int kChunksPerLane = 8;
-enum WalkKind : int { kWalkStridedNT = 0, kWalkStrided = 1, kWalkWide = 2, kWalkStridedBallot = 3, kWalkIndexed = 4 };
+enum WalkKind : int {
+    kWalkStridedNT = 0, kWalkStrided = 1, kWalkWide = 2, kWalkStridedBallot = 3, kWalkIndexed = 4, kWalkPersistent = 5,
+    kWalkMask = 6      // fused frame only: launch 1 stores allocation masks, launch 2 consumes them
+};
 
 // First compact slot for this lane's `myCount` hits (one atomicAdd per wave that has any).
 __device__ __forceinline__ int reserve_compact_slots(const DevPtrs &dp, int counter, int myCount)
@@ -241,17 +244,22 @@ __device__ __forceinline__ bool entry_visible(const FrameParams &fp, const DevPt
 }
 
 // strided walk with one ballot + atomic per unrolled entry slot (hits are rare on small scenes)
-__device__ __forceinline__ void flatten_tile_ballot(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
-                                                    uint32_t tileIndex, int counter)
+__device__ __forceinline__ void walk_load_tile(const DevPtrs &dp, uint32_t numEntries, uint32_t tileIndex,
+                                               int32_t (&ptrs)[kEntriesPerLane])
 {
     const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
     const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
-    int32_t ptrs[kEntriesPerLane];
 #pragma unroll
     for (int j = 0; j < kEntriesPerLane; ++j) {
         const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
         ptrs[j] = (e < numEntries) ? words[(size_t)e * kEntryDwords + 3] : VH_FREE_BLOCK;
     }
+}
+
+__device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
+                                                  const int32_t (&ptrs)[kEntriesPerLane], int counter)
+{
+    const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
     bool any = false;
 #pragma unroll
     for (int j = 0; j < kEntriesPerLane; ++j) any |= (ptrs[j] != VH_FREE_BLOCK);
@@ -272,6 +280,39 @@ __device__ __forceinline__ void flatten_tile_ballot(const FrameParams &fp, const
         if (lane == leaderLane) base = atomicAdd(dp.counters + counter, __popcll(mask));
         base = __shfl(base, leaderLane);
         if (hit) dp.compact[base + __popcll(mask & ((1ull << lane) - 1ull))] = ent;
+    }
+}
+
+__device__ __forceinline__ void flatten_tile_ballot(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
+                                                    uint32_t tileIndex, int counter)
+{
+    int32_t ptrs[kEntriesPerLane];
+    walk_load_tile(dp, numEntries, tileIndex, ptrs);
+    walk_process_tile(fp, dp, tileIndex, ptrs, counter);
+}
+
+// Persistent form of the same walk for tables far larger than the Infinity Cache: a workgroup
+// strides over tiles and issues the ptr loads of its NEXT tile before it works through the live
+// entries of the current one (re-read, frustum test, returning atomic, store: microseconds of
+// latency during which the one-shot form has no streaming loads in flight).
+__device__ __forceinline__ void flatten_tiles_persistent(const FrameParams &fp, const DevPtrs &dp,
+                                                         uint32_t numEntries, uint32_t firstTile, uint32_t stride,
+                                                         int counter)
+{
+    const uint32_t numTiles = (numEntries + kFlattenThreads * kEntriesPerLane - 1) / (kFlattenThreads * kEntriesPerLane);
+    uint32_t t = firstTile;
+    if (t >= numTiles) return;
+    int32_t cur[kEntriesPerLane], nxt[kEntriesPerLane];
+    walk_load_tile(dp, numEntries, t, cur);
+    for (;;) {
+        const uint32_t n = t + stride;
+        const bool more = n < numTiles;
+        if (more) walk_load_tile(dp, numEntries, n, nxt);
+        walk_process_tile(fp, dp, t, cur, counter);
+        if (!more) break;
+#pragma unroll
+        for (int j = 0; j < kEntriesPerLane; ++j) cur[j] = nxt[j];
+        t = n;
     }
 }
 
@@ -312,12 +353,17 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
     }
 }
 
+// tileIndex: index of this workgroup among the `walkBlocks` workgroups doing the walk
 template <int kKind>
 __device__ __forceinline__ void flatten_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
-                                             uint32_t tileIndex, int counter)
+                                             uint32_t tileIndex, int counter, uint32_t walkBlocks)
 {
     if constexpr (kKind == kWalkStridedBallot) {
         flatten_tile_ballot(fp, dp, numEntries, tileIndex, counter);
+        return;
+    }
+    if constexpr (kKind == kWalkPersistent) {
+        flatten_tiles_persistent(fp, dp, numEntries, tileIndex, walkBlocks, counter);
         return;
     }
     if constexpr (kKind == kWalkIndexed) {
@@ -376,7 +422,7 @@ template <int kKind>
 __global__ __launch_bounds__(kFlattenThreads) void flatten_kernel(const FrameParams fp, const DevPtrs dp,
                                                                   uint32_t numEntries)
 {
-    flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x, kCompactCount);
+    flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x, kCompactCount, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -473,7 +519,114 @@ __global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams
         if (h < fp.bucketLo || h >= fp.bucketHi) return;
         probe_and_claim(fp, dp, k.kx, k.ky, k.kz, h, launch_rank(k.px, k.py, fp.width), kFusedCand + parity);
     } else {
-        flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x - claimBefore, kScanCount + parity);
+        flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x - claimBefore, kScanCount + parity, total - claimBlocks);
+    }
+}
+
+// ---- the mask form of the fused frame (default) --------------------------------------------
+// With tens of thousands of allocated entries the walk above stops being a pure stream: every
+// wave that meets a live entry re-reads it, tests it and takes a returning atomic, holding its
+// slot for microseconds with no streaming load in flight (C3: 97 us against 68 us for the same
+// walk over an empty table).  So launch 1 only records WHERE the live entries are -- one 64-bit
+// ballot per wave instruction, stored fire-and-forget (8 bytes per 64 entries) -- and everything
+// with latency in it (re-read, frustum test, compaction, TSDF update) moves to launch 2, where it
+// overlaps with the block updates.
+constexpr int kMaskChunkWords = 256;                   // mask words per consumer workgroup
+constexpr int kMaskChunkEntries = kMaskChunkWords * 64;
+
+__device__ __forceinline__ void walk_mask_tile(const DevPtrs &dp, uint32_t numEntries, uint32_t tileIndex)
+{
+    int32_t ptrs[kEntriesPerLane];
+    walk_load_tile(dp, numEntries, tileIndex, ptrs);
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    // entry = tile*2048 + j*256 + wave*64 + lane  =>  word = entry / 64 = tile*32 + j*4 + wave
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) {
+        const unsigned long long m = __ballot(ptrs[j] != VH_FREE_BLOCK);
+        if (lane == 0) dp.allocMask[(size_t)tileIndex * 32 + j * 4 + wave] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void frame_mask_claim_kernel(const FrameParams fp, const DevPtrs dp,
+                                                               const float4 *__restrict__ verts,
+                                                               uint32_t numEntries, uint32_t claimBlocks, int parity)
+{
+    const uint32_t total = gridDim.x;
+    const uint32_t claimBefore = (uint32_t)(((uint64_t)blockIdx.x * claimBlocks) / total);
+    const uint32_t claimAfter = (uint32_t)(((uint64_t)(blockIdx.x + 1u) * claimBlocks) / total);
+    if (claimAfter != claimBefore) {
+        const PixelKey k = pixel_key(fp, verts, claimBefore * 256 + threadIdx.x, nullptr);
+        if (!k.leader) return;
+        const uint32_t h = hash_block(k.kx, k.ky, k.kz, fp.numBuckets);
+        if (h < fp.bucketLo || h >= fp.bucketHi) return;
+        probe_and_claim(fp, dp, k.kx, k.ky, k.kz, h, launch_rank(k.px, k.py, fp.width), kFusedCand + parity);
+    } else {
+        walk_mask_tile(dp, numEntries, blockIdx.x - claimBefore);
+    }
+}
+
+// Launch 2 of the mask form.  Workgroups [0, commitBlocks): candidates, as below.  The others
+// take one chunk of 256 mask words (16384 entries) each: every lane walks the set bits of its
+// word (re-read, frustum test), visible entries are gathered in LDS, ONE atomicAdd reserves
+// their compact slots, then the workgroup updates their blocks one after the other.  The
+// occupied count is the slot counter of this frame's parity set (read by vh_get_counters).
+__global__ __launch_bounds__(256) void frame_commit_consume_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                   const float4 *__restrict__ verts,
+                                                                   uint32_t numEntries, uint32_t commitBlocks,
+                                                                   int parity)
+{
+    __shared__ unsigned short vis[kMaskChunkEntries];
+    __shared__ int nVis, slotBase;
+    __shared__ VoxelEntry newEntry;
+    __shared__ int inserted;
+    if (blockIdx.x >= commitBlocks) {
+        const uint32_t chunk = blockIdx.x - commitBlocks;
+        const uint32_t numWords = (numEntries + 63u) / 64u;
+        const uint32_t w = chunk * kMaskChunkWords + threadIdx.x;
+        if (threadIdx.x == 0) nVis = 0;
+        __syncthreads();
+        unsigned long long m = (w < numWords) ? dp.allocMask[w] : 0ull;
+        while (m != 0ull) {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const uint32_t e = w * 64u + (uint32_t)bit;
+            if (entry_visible(fp, dp, e)) vis[atomicAdd(&nVis, 1)] = (unsigned short)(threadIdx.x * 64 + bit);
+        }
+        __syncthreads();
+        const int n = nVis;
+        if (n == 0) return;
+        if (threadIdx.x == 0) slotBase = atomicAdd(dp.counters + kScanCount + parity, n);
+        __syncthreads();
+        const uint32_t first = chunk * kMaskChunkEntries;
+        for (int i = threadIdx.x; i < n; i += 256) dp.compact[slotBase + i] = dp.table[first + vis[i]];
+        for (int i = 0; i < n; ++i) integrate_block(fp, dp, dp.table[first + vis[i]], verts);
+        return;
+    }
+    int n = dp.counters[kFusedCand + parity];
+    if ((uint32_t)n > dp.candCapacity) n = (int)dp.candCapacity;
+    for (int i = blockIdx.x; i < n; i += commitBlocks) {
+        if (threadIdx.x == 0) {
+            VoxelEntry e;
+            inserted = commit_candidate(fp, dp, dp.candidates[i], e) ? 1 : 0;
+            if (inserted) {
+                newEntry = e;
+                dp.compact[atomicAdd(dp.counters + kScanCount + parity, 1)] = e;
+            }
+        }
+        __syncthreads();
+        if (inserted) integrate_block(fp, dp, newEntry, verts);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(dp.counters + kCommitTicket, 1);
+        if (ticket == (int)commitBlocks - 1) {
+            dp.counters[kLastCandidates] = n;
+            dp.counters[kScanCount + (parity ^ 1)] = 0;
+            dp.counters[kNewCount + (parity ^ 1)] = 0;
+            dp.counters[kFusedCand + (parity ^ 1)] = 0;
+            dp.counters[kCommitTicket] = 0;
+        }
     }
 }
 
