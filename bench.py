@@ -154,7 +154,9 @@ def main():
     pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc_file)).get(args.workload, {}).get(kname + "_hbm_bytes_per_launch")
+            pmc = json.load(open(pmc_file)).get(args.workload, {})
+            # template argument 3 = the default ballot walk (WalkKind in vh_kernels.hip)
+            traffic = pmc.get(kname + "<3>_hbm_bytes_per_launch", pmc.get(kname + "_hbm_bytes_per_launch"))
         except Exception:
             traffic = None
     roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS,

@@ -20,8 +20,14 @@ OURS = ("frame_mask_claim_kernel", "frame_commit_consume_kernel", "frame_scan_cl
 
 
 def short(name):
+    """Kernel name without namespace / arguments, template arguments kept
+    (frame_scan_claim_kernel<3> = ballot walk, <4> = occupancy-index walk, ...)."""
     for k in OURS:
-        if k in name:
+        i = name.find(k)
+        if i >= 0:
+            rest = name[i + len(k):]
+            if rest.startswith("<"):
+                return k + rest[:rest.find(">") + 1]
             return k
     return None
 
