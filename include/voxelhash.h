@@ -168,6 +168,13 @@ int vh_set_stream(vh_context *ctx, void *hip_stream);   /* NULL = default stream
 int vh_set_projection(vh_context *ctx, const float m[9]);            /* row-major 3x3 */
 int vh_set_raycast_intrinsics(vh_context *ctx, float fx, float fy, float cx, float cy);
 
+/* Opt-in truncation-band allocation (the reference has it commented
+ * out, VoxelUtils.cu:632-703): with band > 0 every valid pixel demands the blocks of
+ * 2*ceil(band/step)+1 points on its viewing ray at camera depths z + (k-half)*step, step =
+ * 4 voxels; the middle sample is the surface point itself.  0 (default) = the reference's
+ * surface-block-only allocation.  One insertion per bucket per frame still holds. */
+int vh_set_alloc_band(vh_context *ctx, float band_metres);
+
 /* SDF_Hashtable.cpp:15-21: stores the pose and its cofactor inverse
  * (cuda_SimpleMatrixUtil.h:944-1069, same summation order, fp32, on the host) */
 int vh_set_pose(vh_context *ctx, const float pose[16]);
@@ -223,8 +230,8 @@ int vh_create_shard(const vh_config *cfg, uint32_t bucket_lo, uint32_t bucket_hi
                     vh_context **out);
 /* Key generation half of allocBlocks for the pose set with vh_set_pose: per valid
  * pixel the block key of the surface point, frustum-tested, runs of equal keys
- * collapsed per wavefront.  Records are int4 {x,y,z,rank}, rank = camera_id<<24 |
- * launch rank, binned by owning shard (owner = hash / ceil(numBuckets/num_shards)):
+ * collapsed per wavefront.  Records are int4 {x,y,z,rank}, rank = camera_id<<27 |
+ * launch rank<<6 | band sample, binned by owning shard (owner = hash / ceil(numBuckets/num_shards)):
  * bin s = d_bins[s*bin_stride*4 ...], record 0 = {count,0,0,0}, records 1..count the
  * keys (count > capacity-1 = overflow).  d_packet (nullable) receives the camera
  * packet: pose, inverse pose, camera-z plane (VH_PACKET_HEADER_FLOATS + W*H floats). */

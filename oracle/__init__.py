@@ -83,6 +83,7 @@ def lib():
         L.vho_destroy.argtypes = [C.c_void_p]
         L.vho_set_projection.argtypes = [C.c_void_p, fp]
         L.vho_set_raycast_intrinsics.argtypes = [C.c_void_p] + [C.c_float] * 4
+        L.vho_set_alloc_band.argtypes = [C.c_void_p, C.c_float]
         L.vho_set_pose.argtypes = [C.c_void_p, fp]
         L.vho_reset_mutexes.argtypes = [C.c_void_p]
         L.vho_alloc_blocks.argtypes = [C.c_void_p, fp]
@@ -274,6 +275,9 @@ class OracleTable:
 
     def set_raycast_intrinsics(self, fx, fy, cx, cy):
         lib().vho_set_raycast_intrinsics(self._h, fx, fy, cx, cy)
+
+    def set_alloc_band(self, band_metres: float):
+        lib().vho_set_alloc_band(self._h, float(band_metres))
 
     def integrate(self, pose, verts) -> int:
         pose = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))

@@ -24,6 +24,7 @@ struct vho_table {
     float proj[9];                 /* "kinectProjectionMatrix", VoxelUtils.cu:24 */
     float rc_fx, rc_fy, rc_cx, rc_cy;
     uint32_t bucket_lo, bucket_hi;  /* this table owns buckets [lo, hi) of the logical table */
+    float alloc_band;               /* 0: surface block only (reference); > 0: truncation-band allocation */
 
     uint32_t  *heap;               /* PtrContainer, VoxelDataStructures.h:54-63 */
     vho_entry *table;
@@ -377,11 +378,47 @@ static void insert_entry(vho_table *t, const int32_t key[3])
     if (saw_free) t->stats.lock_losses++; else t->stats.bucket_full++;
 }
 
+/* Truncation-band allocation (opt-in extension; the reference has the
+ * idea commented out, VoxelUtils.cu:632-703).  With alloc_band = 0 a pixel demands the block of
+ * its surface point only (the live reference behaviour).  With alloc_band = b > 0 it demands the
+ * blocks of 2*ceil(b/step)+1 points on its viewing ray at camera depths z + (k - half)*step,
+ * step = half a block edge; the middle sample is the surface point itself, bit for bit. */
+#define VHO_MAX_BAND_SAMPLES 64
+
+void vho_set_alloc_band(vho_table *t, float band) { t->alloc_band = band > 0.0f ? band : 0.0f; }
+
+static int band_samples(const vho_table *t, float *step_out)
+{
+    const float step = 4.0f * t->p.voxelSize;
+    *step_out = step;
+    if (!(t->alloc_band > 0.0f)) return 1;
+    int half = (int)ceilf(t->alloc_band / step);
+    if (half > (VHO_MAX_BAND_SAMPLES - 1) / 2) half = (VHO_MAX_BAND_SAMPLES - 1) / 2;
+    return 2 * half + 1;
+}
+
+/* block key of sample k of the pixel with camera-space vertex v; 0 if there is none */
+static int band_key(const vho_table *t, const float *v, int k, int nS, float step, int32_t key[3])
+{
+    const int half = (nS - 1) / 2;
+    const float s = v[2] + ((float)k - (float)half) * step;
+    if (!(s > 0.0f)) return 0;
+    const float scale = s / v[2];
+    const float p[4] = { v[0] * scale, v[1] * scale, s, v[3] };
+    const float *src = (k == half) ? v : p;                           /* the surface sample is v itself */
+    float g[4];
+    vho_mat4_mul_vec4(t->p.global_transform, src, g);                 /* :622, w as stored */
+    vho_world2block(g, t->p.voxelSize, t->p.voxelBlockSize, key);     /* :636 */
+    return 1;
+}
+
 /* allocBlocksKernel, VoxelUtils.cu:606-705, visited in launch order */
 void vho_alloc_blocks(vho_table *t, const float *verts)
 {
     const int W = t->width, H = t->height;
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+    float step;
+    const int nS = band_samples(t, &step);
     for (int by = 0; by < tilesY; ++by)
     for (int bx = 0; bx < tilesX; ++bx)
     for (int ty = 0; ty < 16; ++ty)
@@ -391,13 +428,14 @@ void vho_alloc_blocks(vho_table *t, const float *verts)
         const float *v = verts + 4 * ((size_t)y * W + x);
         if (v[2] == 0.0f) continue;                                   /* :621 */
         t->stats.pixels_valid++;
-        float g[4];
-        vho_mat4_mul_vec4(t->p.global_transform, v, g);               /* :622, w as stored */
-        int32_t key[3];
-        vho_world2block(g, t->p.voxelSize, t->p.voxelBlockSize, key); /* :636 */
-        if (!vho_block_in_frustum(t, key)) continue;                  /* :673 */
-        t->stats.pixels_in_frustum++;
-        insert_entry(t, key);
+        int counted = 0;
+        for (int k = 0; k < nS; ++k) {
+            int32_t key[3];
+            if (!band_key(t, v, k, nS, step, key)) continue;
+            if (!vho_block_in_frustum(t, key)) continue;              /* :673 */
+            if (!counted) { t->stats.pixels_in_frustum++; counted = 1; }
+            insert_entry(t, key);
+        }
     }
 }
 
@@ -575,6 +613,9 @@ int vho_generate_keys(vho_table *t, const float *verts, uint32_t camera_id, int 
     const uint32_t per = (t->p.numBuckets + (uint32_t)num_shards - 1u) / (uint32_t)num_shards;
     int worst = 0;
     for (int s = 0; s < num_shards; ++s) memset(bins + (size_t)4 * s * capacity, 0, 4 * sizeof(int32_t));
+    float step;
+    const int nS = band_samples(t, &step);
+    for (int k = 0; k < nS; ++k)
     for (int y = 0; y < H; ++y) {
         int have_prev = 0;
         int32_t prev[3] = {0, 0, 0};
@@ -582,12 +623,7 @@ int vho_generate_keys(vho_table *t, const float *verts, uint32_t camera_id, int 
             const float *v = verts + 4 * ((size_t)y * W + x);
             int32_t key[3];
             int want = 0;
-            if (v[2] != 0.0f) {
-                float g[4];
-                vho_mat4_mul_vec4(t->p.global_transform, v, g);
-                vho_world2block(g, t->p.voxelSize, t->p.voxelBlockSize, key);
-                want = vho_block_in_frustum(t, key);
-            }
+            if (v[2] != 0.0f && band_key(t, v, k, nS, step, key)) want = vho_block_in_frustum(t, key);
             if (!want) { have_prev = 0; continue; }
             if (have_prev && key[0] == prev[0] && key[1] == prev[1] && key[2] == prev[2]) continue;
             have_prev = 1; prev[0] = key[0]; prev[1] = key[1]; prev[2] = key[2];
@@ -598,7 +634,8 @@ int vho_generate_keys(vho_table *t, const float *verts, uint32_t camera_id, int 
             if (slot < capacity) {
                 int32_t *r = bin + 4 * slot;
                 r[0] = key[0]; r[1] = key[1]; r[2] = key[2];
-                r[3] = (int32_t)((camera_id << 24) | vho_launch_rank(x, y, W));
+                /* camera, then launch order, then sample index decide who wins a bucket */
+                r[3] = (int32_t)((camera_id << 27) | (vho_launch_rank(x, y, W) << 6) | (uint32_t)k);
             }
         }
     }

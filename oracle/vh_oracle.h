@@ -82,6 +82,8 @@ vho_table *vho_create(const vho_params *p, int width, int height, int semantics)
 void       vho_destroy(vho_table *t);
 void       vho_set_projection(vho_table *t, const float m[9]);  /* row-major 3x3 */
 void       vho_set_raycast_intrinsics(vho_table *t, float fx, float fy, float cx, float cy);
+/* opt-in truncation-band allocation; 0 = surface block only */
+void       vho_set_alloc_band(vho_table *t, float band_metres);
 
 /* ---- per-frame steps (SDF_Hashtable.cpp:11-40) ---- */
 void vho_set_pose(vho_table *t, const float pose[16]);          /* + cofactor inverse */

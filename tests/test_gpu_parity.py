@@ -23,10 +23,10 @@ _FUSED = {"on": 1, "walk": 3}
 @pytest.fixture(autouse=True, params=["fused-mask", "fused-ballot-walk", "four-kernel", "fused-indexed-walk",
                                       "four-kernel-wide-walk", "fused-persistent-walk"])
 def frame_variant(request):
-    """Every test runs in each variant of vh_integrate: the fused two-launch frame in its mask
-    form (default) and with the in-walk compaction, the four step kernels (alloc claim / commit /
-    flatten / integrate), the opt-in walk over the bucket-occupancy bitmap, the 16-byte-chunk
-    walk and the persistent prefetching walk."""
+    """Every test runs in each variant of vh_integrate: the fused two-launch frame with the
+    in-walk compaction (the default) and in its mask form, the four step kernels (alloc claim /
+    commit / flatten / integrate), the opt-in walk over the bucket-occupancy bitmap, the
+    16-byte-chunk walk and the persistent prefetching walk."""
     p = request.param
     _FUSED["on"] = 0 if p.startswith("four-kernel") else 1
     _FUSED["walk"] = (4 if "indexed" in p else 2 if "wide" in p else 5 if "persistent" in p
@@ -316,3 +316,28 @@ def test_raycast_room_scene_moving_camera(oracle, vh, torch_cuda):
     gt.raycast(poses[3], d_depth, 0.1, 5.0)
     gt.synchronize()
     assert (d_depth.cpu().numpy() > 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("sem,band", [(0, 0.1), (1, 0.1), (1, 0.33)])
+def test_truncation_band_allocation(oracle, vh, torch_cuda, sem, band):
+    """Opt-in extension: blocks along the viewing ray within +-band of the
+    surface are demanded too.  Same winner rule (launch order, then sample index); bit-equal."""
+    ot, gt = _pair(oracle, vh, sem, numVoxelBlocks=1 << 14)
+    ot.set_alloc_band(band)
+    gt.set_alloc_band(band)
+    pose = synth.yaw_pose(5.0, (0.1, 0.0, 0.05))
+    verts = synth.sphere_inside_scene()
+    poses = synth.camera_loop(500)
+    prims = synth.room_primitives()
+    frames = [(pose, verts), (pose, verts), (I4, verts)]
+    if sem == 1:
+        frames += [(poses[i], synth.render_room_verts(poses[i], prims=prims).numpy()) for i in (0, 1, 2)]
+    _run(ot, gt, torch_cuda, frames)
+    _compare(ot, gt)
+    surface_only = oracle.OracleTable(oracle.default_params(numBuckets=1 << 17, numVoxelBlocks=1 << 14), 640, 480, sem)
+    for p, v in frames:
+        surface_only.integrate(p, v)
+    assert entries_as_set(surface_only.allocated()) <= entries_as_set(gt.allocated()) or sem == 0
+    assert len(gt.allocated()) > 1.3 * len(surface_only.allocated())
+    with pytest.raises(vh.VoxelHashError):
+        gt.set_alloc_band(10.0)          # more than 31 half-block steps

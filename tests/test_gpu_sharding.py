@@ -124,3 +124,28 @@ def test_pipelined_steps_equal_sequential_over_nccl(oracle, vh, torch_cuda):
             sh.table.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_sharded_band_allocation(oracle, vh, torch_cuda):
+    """Band allocation through the key exchange: ranks carry camera | launch rank | sample."""
+    torch = torch_cuda
+    world, batch, band = 2, 2, 0.15
+    plan = vdist.ShardPlan(KW["numBuckets"], world)
+    kw = dict(numBuckets=KW["numBuckets"], numVoxelBlocks=1 << 14)
+    shards = [vdist.HipShard(vh.default_params(**kw), W, H, 1, plan, r, W * H, batch=batch) for r in range(world)]
+    full = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    full.set_alloc_band(band)
+    for sh in shards:
+        sh.table.set_alloc_band(band)
+    for step in range(0, 4, batch):
+        frames = [cameras(world, step + b) for b in range(batch)]
+        vdist.loopback_step(shards, [[frames[b][r][0] for b in range(batch)] for r in range(world)],
+                            [[torch.from_numpy(frames[b][r][1]).cuda() for b in range(batch)] for r in range(world)])
+        for cams in frames:
+            vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+    total = 0
+    for r, sh in enumerate(shards):
+        sh.table.synchronize()
+        total += check_shard_against_full(sh.table, full, *plan.bucket_range(r), 5)
+        assert sh.table.counters()["bin_overflow"] == 0
+    assert total == len(full.allocated()) > 500

@@ -123,3 +123,23 @@ def test_sphere_scenes_pinhole(oracle):
     assert r["counts"] == [157, 179] and r["touched"] == 88018
     assert r["range"][0] == pytest.approx(-0.1928, abs=5e-5)
     assert r["range"][1] == pytest.approx(0.1905, abs=5e-5)
+
+
+def test_band_allocation_extends_the_surface_allocation(oracle):
+    """alloc_band = 0 is the reference behaviour (all anchors above run with it); a positive band
+    only adds blocks along the viewing rays."""
+    verts = synth.sphere_inside_scene()
+    tabs = {}
+    for band in (0.0, 0.2):
+        t = oracle.OracleTable(oracle.default_params(numBuckets=NB, numVoxelBlocks=1 << 14), 640, 480, oracle.SEM_PINHOLE)
+        t.set_alloc_band(band)
+        for _ in range(6):
+            t.integrate(I4, verts)
+        tabs[band] = {tuple(e["pos"]) for e in t.allocated()}
+        t.close()
+    assert len(tabs[0.0]) == 179                       # BASELINE.md anchor, unchanged
+    assert tabs[0.0] < tabs[0.2] and len(tabs[0.2]) > 2 * len(tabs[0.0])
+    # every extra block lies within the band of the R = 2 m sphere (block diagonal of slack)
+    for pos in tabs[0.2]:
+        centre = (np.array(pos, np.float64) * 8 + 3.5) * 0.02
+        assert abs(np.linalg.norm(centre) - 2.0) < 0.2 + 0.3

@@ -85,6 +85,7 @@ SIGNATURES = {
     "vh_set_stream": (C.c_int, [_vp, _vp]),
     "vh_set_projection": (C.c_int, [_vp, _fp]),
     "vh_set_raycast_intrinsics": (C.c_int, [_vp, _f, _f, _f, _f]),
+    "vh_set_alloc_band": (C.c_int, [_vp, _f]),
     "vh_set_pose": (C.c_int, [_vp, _fp]),
     "vh_reset_mutexes": (C.c_int, [_vp]),
     "vh_alloc_blocks": (C.c_int, [_vp, _vp, _vp]),

@@ -225,8 +225,9 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     if (p.voxelBlockSize != 8) return fail(VH_ERR_INVALID_ARGUMENT, "voxelBlockSize must be 8");
     if (p.numBuckets == 0 || p.bucketSize == 0 || p.numVoxelBlocks == 0 || !(p.voxelSize > 0.0f))
         return fail(VH_ERR_INVALID_ARGUMENT, "numBuckets, bucketSize, numVoxelBlocks and voxelSize must be positive");
-    if (cfg->width <= 0 || cfg->height <= 0 || (uint64_t)cfg->width * cfg->height > (1u << 24))
-        return fail(VH_ERR_INVALID_ARGUMENT, "bad image size");
+    if (cfg->width <= 0 || cfg->height <= 0 ||
+        (uint64_t)((cfg->width + 15) / 16) * ((cfg->height + 15) / 16) * 256 > (1u << 21))
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad image size (at most 2^21 pixels in 16x16 tiles)");
     if (cfg->semantics != VH_SEM_REFERENCE && cfg->semantics != VH_SEM_PINHOLE)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad semantics");
     if (lo >= hi || hi > p.numBuckets) return fail(VH_ERR_INVALID_ARGUMENT, "bad bucket range");
@@ -260,6 +261,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     fp.bucketHi = hi;
     fp.numVoxelBlocks = p.numVoxelBlocks;
     fp.epoch = 0;
+    fp.allocBand = 0.0f;
     default_projection(c);
 
     c->ownedBuckets = hi - lo;
@@ -362,6 +364,15 @@ extern "C" int vh_set_raycast_intrinsics(vh_context *c, float fx, float fy, floa
 {
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     c->rc_fx = fx; c->rc_fy = fy; c->rc_cx = cx; c->rc_cy = cy;
+    return VH_OK;
+}
+
+extern "C" int vh_set_alloc_band(vh_context *c, float band_metres)
+{
+    if (!c || !(band_metres >= 0.0f)) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    if (band_metres / (4.0f * c->fp.voxelSize) > (float)((kMaxBandSamples - 1) / 2))
+        return fail(VH_ERR_INVALID_ARGUMENT, "band wider than 31 half-block steps");
+    c->fp.allocBand = band_metres;
     return VH_OK;
 }
 
@@ -623,7 +634,7 @@ extern "C" int vh_generate_keys(vh_context *c, const vh_float4 *verts, uint32_t 
     prepare_bins_kernel<<<1, 64, 0, c->stream>>>(reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, 1, 0);
     generate_keys_kernel<<<grid_for(npix, kGenThreads), kGenThreads, 0, c->stream>>>(
         c->fp, reinterpret_cast<const float4 *>(verts), num_shards, reinterpret_cast<int4 *>(d_bins), capacity,
-        bin_stride, d_packet ? d_packet + kPacketHeader : nullptr, camera_id << 24);
+        bin_stride, d_packet ? d_packet + kPacketHeader : nullptr, camera_id << kRankCameraShift);
     VH_HIP(hipGetLastError());
     return VH_OK;
 }
@@ -656,7 +667,7 @@ extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float 
         generate_keys_kernel<<<grid_for(npix, kGenThreads), kGenThreads, 0, c->stream>>>(
             c->fp, reinterpret_cast<const float4 *>(d_verts[b]), num_shards,
             reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b, capacity, bin_stride,
-            packet ? packet + kPacketHeader : nullptr, camera_id << 24);
+            packet ? packet + kPacketHeader : nullptr, camera_id << kRankCameraShift);
     }
     VH_HIP(hipGetLastError());
     return VH_OK;

@@ -56,6 +56,7 @@ struct FrameParams {
     uint32_t bucketHi;
     uint32_t numVoxelBlocks;
     uint32_t epoch;       // bucket-lock epoch of this frame (>= 1)
+    float allocBand;      // 0: a pixel demands its surface block only (reference); > 0: +- band along the ray
 };
 
 struct DevPtrs {
@@ -166,6 +167,10 @@ __device__ __forceinline__ bool block_in_frustum(const FrameParams &fp, int bx, 
 {
     return block_in_frustum(fp, fp.T, fp.Tinv, bx, by, bz);
 }
+
+// Contender ranks are 32 bits: camera (5) | launch rank of the pixel (21) | band sample (6).
+constexpr int kMaxBandSamples = 64;
+constexpr uint32_t kRankSampleBits = 6, kRankCameraShift = 27;
 
 // Position of pixel (x,y) in the launch order of the reference's grid of 16x16
 // tiles (VoxelUtils.cu:610-611,710-712).  The lowest rank contending for a

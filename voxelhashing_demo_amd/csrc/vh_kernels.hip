@@ -56,45 +56,105 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
 // keys to their first lane before touching the table: ~300 k pixels become a
 // few thousand bucket probes.  Within an image row the launch rank grows with
 // x, so the first lane of a run carries the run's lowest rank.
-struct PixelKey {
-    int kx, ky, kz, px, py;
-    bool leader;       // first lane of a run of equal in-frustum keys in this wave
+// Truncation-band allocation (opt-in; commented out in the reference,
+// VoxelUtils.cu:632-703): with fp.allocBand = b > 0 a pixel demands the blocks of
+// 2*ceil(b/step)+1 points on its viewing ray at camera depths z + (k - half)*step, step = half
+// a block edge; the middle sample is the surface point itself.  b = 0: that sample only.
+struct PixelVertex {
+    float4 v;
+    int px, py;
+    bool valid;
 };
 
-__device__ __forceinline__ PixelKey pixel_key(const FrameParams &fp, const float4 *__restrict__ verts, int idx,
-                                              float *__restrict__ outDepth)
+__device__ __forceinline__ int band_samples(const FrameParams &fp, float &step)
 {
-    PixelKey k{0, 0, 0, 0, 0, false};
-    bool want = false;
+    step = 4.0f * fp.voxelSize;
+    if (!(fp.allocBand > 0.0f)) return 1;
+    int half = (int)__builtin_ceilf(fp.allocBand / step);
+    half = min(half, (kMaxBandSamples - 1) / 2);
+    return 2 * half + 1;
+}
+
+__device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const float4 *__restrict__ verts, int idx,
+                                                  float *__restrict__ outDepth)
+{
+    PixelVertex p{make_float4(0.f, 0.f, 0.f, 0.f), 0, 0, false};
     if (idx < fp.width * fp.height) {
-        const float4 v = verts[idx];
-        if (outDepth) outDepth[idx] = v.z;                               // camera-z plane of a camera packet
-        k.py = idx / fp.width;
-        k.px = idx - k.py * fp.width;
-        if (v.z != 0.0f) {                                               // VoxelUtils.cu:621
-            const float4 g = mat4_mul(fp.T, v.x, v.y, v.z, v.w);         // :622, w as stored
+        p.v = verts[idx];
+        if (outDepth) outDepth[idx] = p.v.z;                             // camera-z plane of a camera packet
+        p.py = idx / fp.width;
+        p.px = idx - p.py * fp.width;
+        p.valid = p.v.z != 0.0f;                                         // VoxelUtils.cu:621
+    }
+    return p;
+}
+
+struct SampleKey {
+    int kx, ky, kz;
+    bool leader;       // this lane must probe / emit the key (first of a run of equal in-frustum keys)
+};
+
+// Key of band sample k of this lane's pixel, de-duplicated against the lane's own previous
+// sample and against the previous lane's sample k (runs of equal keys along an image row
+// collapse to their first lane; within a row the launch rank grows with x and, within a pixel,
+// with k, so whoever survives carries the lowest rank of its run).
+__device__ __forceinline__ SampleKey sample_key(const FrameParams &fp, const PixelVertex &p, int k, int nS, float step,
+                                                int &ownX, int &ownY, int &ownZ, bool &ownHave)
+{
+    SampleKey r{0, 0, 0, false};
+    bool want = false;
+    if (p.valid) {
+        const int half = (nS - 1) / 2;
+        const float s = p.v.z + ((float)k - (float)half) * step;
+        if (s > 0.0f) {
+            const float scale = s / p.v.z;
+            const bool surface = (k == half);                            // the vertex itself, bit for bit
+            const float x = surface ? p.v.x : p.v.x * scale, y = surface ? p.v.y : p.v.y * scale;
+            const float z = surface ? p.v.z : s;
+            const float4 g = mat4_mul(fp.T, x, y, z, p.v.w);             // :622, w as stored
             const int3_ b = world2block(g.x, g.y, g.z, fp.voxelSize);    // :636
-            k.kx = b.x; k.ky = b.y; k.kz = b.z;
-            want = block_in_frustum(fp, k.kx, k.ky, k.kz);               // :673
+            r.kx = b.x; r.ky = b.y; r.kz = b.z;
+            want = block_in_frustum(fp, r.kx, r.ky, r.kz);               // :673
         }
     }
-    // run-length dedup across the wave
+    const bool dupOwn = want && ownHave && ownX == r.kx && ownY == r.ky && ownZ == r.kz;
+    if (want) { ownX = r.kx; ownY = r.ky; ownZ = r.kz; ownHave = true; }
     const int lane = threadIdx.x & (kWave - 1);
-    const int pkx = __shfl_up(k.kx, 1), pky = __shfl_up(k.ky, 1), pkz = __shfl_up(k.kz, 1);
-    const int ppy = __shfl_up(k.py, 1);
+    const int pkx = __shfl_up(r.kx, 1), pky = __shfl_up(r.ky, 1), pkz = __shfl_up(r.kz, 1);
+    const int ppy = __shfl_up(p.py, 1);
     const int pwant = __shfl_up((int)want, 1);
-    k.leader = want && (lane == 0 || !pwant || ppy != k.py || pkx != k.kx || pky != k.ky || pkz != k.kz);
-    return k;
+    r.leader = want && !dupOwn &&
+               (lane == 0 || !pwant || ppy != p.py || pkx != r.kx || pky != r.ky || pkz != r.kz);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t sample_rank(const FrameParams &fp, const PixelVertex &p, int k)
+{
+    return (launch_rank(p.px, p.py, fp.width) << kRankSampleBits) | (uint32_t)k;
+}
+
+// the claim phase for one lane = one pixel (shared by alloc_claim_kernel and the fused frame)
+__device__ __forceinline__ void claim_pixel(const FrameParams &fp, const DevPtrs &dp,
+                                            const float4 *__restrict__ verts, int idx, int candCounter)
+{
+    const PixelVertex p = load_pixel(fp, verts, idx, nullptr);
+    float step;
+    const int nS = band_samples(fp, step);
+    int ox = 0, oy = 0, oz = 0;
+    bool oh = false;
+    for (int k = 0; k < nS; ++k) {
+        const SampleKey s = sample_key(fp, p, k, nS, step, ox, oy, oz, oh);
+        if (!s.leader) continue;
+        const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
+        if (h < fp.bucketLo || h >= fp.bucketHi) continue;              // not this shard's bucket
+        probe_and_claim(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(fp, p, k), candCounter);
+    }
 }
 
 __global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, const DevPtrs dp,
                                                           const float4 *__restrict__ verts)
 {
-    const PixelKey k = pixel_key(fp, verts, blockIdx.x * 256 + threadIdx.x, nullptr);
-    if (!k.leader) return;
-    const uint32_t h = hash_block(k.kx, k.ky, k.kz, fp.numBuckets);
-    if (h < fp.bucketLo || h >= fp.bucketHi) return;                     // not this shard's bucket
-    probe_and_claim(fp, dp, k.kx, k.ky, k.kz, h, launch_rank(k.px, k.py, fp.width));
+    claim_pixel(fp, dp, verts, blockIdx.x * 256 + threadIdx.x, kCandCount);
 }
 
 // Key generation for the multi-GPU exchange: the same per-pixel
@@ -113,27 +173,34 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_kernel(const FrameP
 {
     __shared__ int ldsCount[VH_MAX_CAMERAS];
     __shared__ int ldsBase[VH_MAX_CAMERAS];
-    if (threadIdx.x < VH_MAX_CAMERAS) ldsCount[threadIdx.x] = 0;
-    __syncthreads();
     if (outDepth && blockIdx.x == 0 && threadIdx.x < kPacketHeader)      // packet header: pose, inverse
         outDepth[(int)threadIdx.x - kPacketHeader] = threadIdx.x < 16 ? fp.T[threadIdx.x] : fp.Tinv[threadIdx.x - 16];
-    const PixelKey k = pixel_key(fp, verts, blockIdx.x * kGenThreads + threadIdx.x, outDepth);
-    uint32_t owner = 0;
-    int local = 0;
-    if (k.leader) {
-        const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
-        owner = hash_block(k.kx, k.ky, k.kz, fp.numBuckets) / perShard;
-        local = atomicAdd(&ldsCount[owner], 1);
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < numShards && ldsCount[threadIdx.x] > 0)
-        ldsBase[threadIdx.x] = atomicAdd(&outBins[(size_t)threadIdx.x * outBinStride].x, ldsCount[threadIdx.x]);
-    __syncthreads();
-    if (k.leader) {
-        int4 *bin = outBins + (size_t)owner * outBinStride;               // record 0 = {count,0,0,0}
-        const int slot = ldsBase[owner] + local + 1;
-        if (slot < outCapacity)
-            bin[slot] = make_int4(k.kx, k.ky, k.kz, (int)(rankBase + launch_rank(k.px, k.py, fp.width)));
+    const PixelVertex p = load_pixel(fp, verts, blockIdx.x * kGenThreads + threadIdx.x, outDepth);
+    float step;
+    const int nS = band_samples(fp, step);
+    const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
+    int ox = 0, oy = 0, oz = 0;
+    bool oh = false;
+    for (int k = 0; k < nS; ++k) {
+        if (threadIdx.x < VH_MAX_CAMERAS) ldsCount[threadIdx.x] = 0;
+        __syncthreads();
+        const SampleKey s = sample_key(fp, p, k, nS, step, ox, oy, oz, oh);
+        uint32_t owner = 0;
+        int local = 0;
+        if (s.leader) {
+            owner = hash_block(s.kx, s.ky, s.kz, fp.numBuckets) / perShard;
+            local = atomicAdd(&ldsCount[owner], 1);
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < numShards && ldsCount[threadIdx.x] > 0)
+            ldsBase[threadIdx.x] = atomicAdd(&outBins[(size_t)threadIdx.x * outBinStride].x, ldsCount[threadIdx.x]);
+        __syncthreads();
+        if (s.leader) {
+            int4 *bin = outBins + (size_t)owner * outBinStride;           // record 0 = {count,0,0,0}
+            const int slot = ldsBase[owner] + local + 1;
+            if (slot < outCapacity) bin[slot] = make_int4(s.kx, s.ky, s.kz, (int)(rankBase + sample_rank(fp, p, k)));
+        }
+        __syncthreads();
     }
 }
 
@@ -513,11 +580,7 @@ __global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams
     const uint32_t claimBefore = (uint32_t)(((uint64_t)blockIdx.x * claimBlocks) / total);
     const uint32_t claimAfter = (uint32_t)(((uint64_t)(blockIdx.x + 1u) * claimBlocks) / total);
     if (claimAfter != claimBefore) {
-        const PixelKey k = pixel_key(fp, verts, claimBefore * 256 + threadIdx.x, nullptr);
-        if (!k.leader) return;
-        const uint32_t h = hash_block(k.kx, k.ky, k.kz, fp.numBuckets);
-        if (h < fp.bucketLo || h >= fp.bucketHi) return;
-        probe_and_claim(fp, dp, k.kx, k.ky, k.kz, h, launch_rank(k.px, k.py, fp.width), kFusedCand + parity);
+        claim_pixel(fp, dp, verts, claimBefore * 256 + threadIdx.x, kFusedCand + parity);
     } else {
         flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x - claimBefore, kScanCount + parity, total - claimBlocks);
     }
@@ -555,11 +618,7 @@ __global__ __launch_bounds__(256) void frame_mask_claim_kernel(const FrameParams
     const uint32_t claimBefore = (uint32_t)(((uint64_t)blockIdx.x * claimBlocks) / total);
     const uint32_t claimAfter = (uint32_t)(((uint64_t)(blockIdx.x + 1u) * claimBlocks) / total);
     if (claimAfter != claimBefore) {
-        const PixelKey k = pixel_key(fp, verts, claimBefore * 256 + threadIdx.x, nullptr);
-        if (!k.leader) return;
-        const uint32_t h = hash_block(k.kx, k.ky, k.kz, fp.numBuckets);
-        if (h < fp.bucketLo || h >= fp.bucketHi) return;
-        probe_and_claim(fp, dp, k.kx, k.ky, k.kz, h, launch_rank(k.px, k.py, fp.width), kFusedCand + parity);
+        claim_pixel(fp, dp, verts, claimBefore * 256 + threadIdx.x, kFusedCand + parity);
     } else {
         walk_mask_tile(dp, numEntries, blockIdx.x - claimBefore);
     }

@@ -100,6 +100,10 @@ class SDFHashtable:
         a = np.ascontiguousarray(np.asarray(m, np.float32).reshape(9))
         L.check(self._lib.vh_set_projection(self._h, a.ctypes.data_as(C.POINTER(C.c_float))), "vh_set_projection")
 
+    def set_alloc_band(self, band_metres: float):
+        """Opt-in truncation-band allocation; 0 = the reference's surface-block-only allocation."""
+        L.check(self._lib.vh_set_alloc_band(self._h, float(band_metres)), "vh_set_alloc_band")
+
     def set_raycast_intrinsics(self, fx, fy, cx, cy):
         L.check(self._lib.vh_set_raycast_intrinsics(self._h, fx, fy, cx, cy), "vh_set_raycast_intrinsics")
 
