@@ -402,7 +402,7 @@ static int band_key(const vho_table *t, const float *v, int k, int nS, float ste
 {
     const int half = (nS - 1) / 2;
     const float s = v[2] + ((float)k - (float)half) * step;
-    if (!(s > 0.0f)) return 0;
+    if (k != half && !(s > 0.0f)) return 0;      /* the surface sample is never filtered (:621 only tests z != 0) */
     const float scale = s / v[2];
     const float p[4] = { v[0] * scale, v[1] * scale, s, v[3] };
     const float *src = (k == half) ? v : p;                           /* the surface sample is v itself */

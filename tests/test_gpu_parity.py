@@ -341,3 +341,14 @@ def test_truncation_band_allocation(oracle, vh, torch_cuda, sem, band):
     assert len(gt.allocated()) > 1.3 * len(surface_only.allocated())
     with pytest.raises(vh.VoxelHashError):
         gt.set_alloc_band(10.0)          # more than 31 half-block steps
+
+
+def test_negative_depth_vertices_are_processed_like_the_reference(oracle, vh, torch_cuda):
+    """allocBlocksKernel only skips z == 0 (VoxelUtils.cu:621): vertices with a negative z are
+    allocated for too (they just never pass the depth <= 0 test of the TSDF update)."""
+    ot, gt = _pair(oracle, vh, 0)
+    verts = synth.sphere_inside_scene().copy()
+    verts[100:200, 100:300, :3] *= -1.0
+    _run(ot, gt, torch_cuda, [(I4, verts), (I4, verts)])
+    _compare(ot, gt)
+    assert ot.last_stats["pixels_valid"] == 640 * 480

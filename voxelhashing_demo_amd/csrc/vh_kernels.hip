@@ -106,11 +106,12 @@ __device__ __forceinline__ SampleKey sample_key(const FrameParams &fp, const Pix
     if (p.valid) {
         const int half = (nS - 1) / 2;
         const float s = p.v.z + ((float)k - (float)half) * step;
-        if (s > 0.0f) {
-            const float scale = s / p.v.z;
-            const bool surface = (k == half);                            // the vertex itself, bit for bit
-            const float x = surface ? p.v.x : p.v.x * scale, y = surface ? p.v.y : p.v.y * scale;
-            const float z = surface ? p.v.z : s;
+        if (k == half || s > 0.0f) {                                     // the surface sample is never filtered (:621 only tests z != 0)
+            float x = p.v.x, y = p.v.y, z = p.v.z;                       // k == half: the vertex itself, bit for bit
+            if (k != half) {                                             // wave-uniform; no divide on the reference path
+                const float scale = s / p.v.z;
+                x = p.v.x * scale; y = p.v.y * scale; z = s;
+            }
             const float4 g = mat4_mul(fp.T, x, y, z, p.v.w);             // :622, w as stored
             const int3_ b = world2block(g.x, g.y, g.z, fp.voxelSize);    // :636
             r.kx = b.x; r.ky = b.y; r.kz = b.z;
