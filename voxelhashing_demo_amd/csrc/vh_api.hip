@@ -70,6 +70,7 @@ struct vh_context {
     vh_kernel_times times{};
     int integrateGrid = 2048;
     int persistentBlocks = 2048;   // workgroups of the persistent walk (flatten_variant 5)
+    int raycastFastDiv = 0;        // divide-free voxel index with exact fallback in the raycast
     int raycastBatch = 1;          // in-block samples whose voxels a ray fetches together (1, 2 or 4)
     int fusedFrame = 1;            // vh_integrate as two launches (0: the four step kernels)
     int commitBlocks = 128;        // workgroups serving candidates in the fused second launch
@@ -213,6 +214,7 @@ static int free_buffers(vh_context *c)
     if (c->dp.compactMask) (void)hipFree(c->dp.compactMask);
     if (c->dp.bucketBits) (void)hipFree(c->dp.bucketBits);
     if (c->dp.allocMask) (void)hipFree(c->dp.allocMask);
+    if (c->dp.macroBits) (void)hipFree(c->dp.macroBits);
     c->dp = DevPtrs{};
     return VH_OK;
 }
@@ -289,6 +291,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     VH_ALLOC(dp.candidates, sizeof(int4) * npix);
     VH_ALLOC(dp.compactMask, sizeof(uint32_t) * c->numEntries);
     VH_ALLOC(dp.bucketBits, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32));
+    VH_ALLOC(dp.macroBits, kMacroBits / 8);
     // 32 mask words per 2048-entry tile, padded to whole 256-word chunks
     VH_ALLOC(dp.allocMask, sizeof(unsigned long long) *
                                (((c->numEntries + kMaskChunkEntries - 1) / kMaskChunkEntries) * kMaskChunkWords));
@@ -303,6 +306,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     reset_heap_kernel<<<g, 256, 0, s>>>(dp.heap, p.numVoxelBlocks);
     hipError_t e = hipMemsetAsync(dp.claim, 0, sizeof(unsigned long long) * (size_t)c->ownedBuckets, s);
     if (e == hipSuccess) e = hipMemsetAsync(dp.bucketBits, 0, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32), s);
+    if (e == hipSuccess) e = hipMemsetAsync(dp.macroBits, 0, kMacroBits / 8, s);
     if (e == hipSuccess) e = hipMemsetAsync(dp.blocks, 0, sizeof(Voxel) * (size_t)p.numVoxelBlocks * kBlockVoxels, s);
     int32_t h_counters[kNumCounters] = {0};
     h_counters[kHeapCounter] = (int32_t)p.numVoxelBlocks - 1;               // :207
@@ -606,13 +610,16 @@ extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, floa
     dim3 grid((fp.width + 15) / 16, (fp.height + 15) / 16);
     int rc;
     if (c->raycastBatch >= 4)
-        rc = launch(c, kPhaseRaycast, raycast_kernel<4>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
+        rc = launch(c, kPhaseRaycast, raycast_kernel<4, false>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
                     c->rc_cy, t_min, nsteps, d_depth_out);
     else if (c->raycastBatch >= 2)
-        rc = launch(c, kPhaseRaycast, raycast_kernel<2>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
+        rc = launch(c, kPhaseRaycast, raycast_kernel<2, false>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
+                    c->rc_cy, t_min, nsteps, d_depth_out);
+    else if (c->raycastFastDiv)
+        rc = launch(c, kPhaseRaycast, raycast_kernel<1, true>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
                     c->rc_cy, t_min, nsteps, d_depth_out);
     else
-        rc = launch(c, kPhaseRaycast, raycast_kernel<1>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
+        rc = launch(c, kPhaseRaycast, raycast_kernel<1, false>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
                     c->rc_cy, t_min, nsteps, d_depth_out);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
@@ -935,7 +942,7 @@ extern "C" int vh_load_snapshot(vh_context *c, const char *path)
     DeviceGuard guard(c->device);
     hipError_t e = hipStreamSynchronize(c->stream);
     const size_t words = ((size_t)c->ownedBuckets + 31) / 32;
-    std::vector<uint32_t> bits(words, 0u);
+    std::vector<uint32_t> bits(words, 0u), macro(kMacroBits / 32, 0u);
     std::vector<Voxel> block(kBlockVoxels);
     if (ok && e == hipSuccess)
         e = hipMemset(c->dp.blocks, 0, sizeof(Voxel) * (size_t)c->params.numVoxelBlocks * kBlockVoxels);
@@ -943,6 +950,9 @@ extern "C" int vh_load_snapshot(vh_context *c, const char *path)
         if (table[i].ptr == VH_FREE_BLOCK) continue;
         const size_t bucket = i / c->params.bucketSize;
         bits[bucket >> 5] |= 1u << (bucket & 31);
+        const uint32_t hm = ((((uint32_t)(table[i].pos[0] >> 2)) * 73856093u) ^ (((uint32_t)(table[i].pos[1] >> 2)) * 19349669u) ^
+                             (((uint32_t)(table[i].pos[2] >> 2)) * 83492791u)) & (kMacroBits - 1u);
+        macro[hm >> 5] |= 1u << (hm & 31);
         ok = std::fread(block.data(), sizeof(Voxel), kBlockVoxels, f) == (size_t)kBlockVoxels &&
              (uint64_t)table[i].ptr + kBlockVoxels <= (uint64_t)c->params.numVoxelBlocks * kBlockVoxels;
         if (ok) e = hipMemcpy(c->dp.blocks + table[i].ptr, block.data(), sizeof(Voxel) * kBlockVoxels, hipMemcpyHostToDevice);
@@ -956,6 +966,7 @@ extern "C" int vh_load_snapshot(vh_context *c, const char *path)
     if (e == hipSuccess) e = hipMemcpy(c->dp.table, table.data(), sizeof(VoxelEntry) * table.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->dp.heap, heap.data(), sizeof(uint32_t) * heap.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(c->dp.bucketBits, bits.data(), sizeof(uint32_t) * words, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->dp.macroBits, macro.data(), kMacroBits / 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemset(c->dp.claim, 0, sizeof(unsigned long long) * (size_t)c->ownedBuckets);
     if (e == hipSuccess) e = hipMemcpy(c->dp.counters, counters, sizeof counters, hipMemcpyHostToDevice);
     if (e != hipSuccess) return fail(VH_ERR_HIP, "snapshot upload", e);
@@ -978,6 +989,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (std::strcmp(name, "integrate_grid") == 0 && value > 0) { c->integrateGrid = value; return VH_OK; }
     if (std::strcmp(name, "fused_frame") == 0) { c->fusedFrame = value; return VH_OK; }
     if (std::strcmp(name, "raycast_batch") == 0 && value > 0) { c->raycastBatch = value; return VH_OK; }
+    if (std::strcmp(name, "raycast_fast_div") == 0) { c->raycastFastDiv = value; return VH_OK; }
     if (std::strcmp(name, "persistent_blocks") == 0 && value > 0) { c->persistentBlocks = value; return VH_OK; }
     if (std::strcmp(name, "commit_blocks") == 0 && value > 0) { c->commitBlocks = value; return VH_OK; }
     return fail(VH_ERR_INVALID_ARGUMENT, "unknown option");

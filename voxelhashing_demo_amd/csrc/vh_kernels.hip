@@ -213,6 +213,15 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_kernel(const FrameP
 // reference grid would have let through the atomicExch (VoxelUtils.cu:444-445).
 // It takes the first free slot and pops the heap (top-down, :328-334).  An empty
 // heap refuses the insertion instead of reading heap[-1].
+// Raycast accelerator: "macro cells" of 4x4x4 blocks, one bit per hashed macro coordinate
+// (collisions only make the ray skip less).  Set when a block inside the cell is inserted.
+constexpr uint32_t kMacroBits = 1u << 20;      // 128 KB bitmap
+
+__device__ __forceinline__ uint32_t macro_hash(int mx, int my, int mz)
+{
+    return (((uint32_t)mx * 73856093u) ^ ((uint32_t)my * 19349669u) ^ ((uint32_t)mz * 83492791u)) & (kMacroBits - 1u);
+}
+
 // Returns true (and the new entry) if candidate k held its bucket's claim and was inserted.
 __device__ __forceinline__ bool commit_candidate(const FrameParams &fp, const DevPtrs &dp, const int4 k,
                                                  VoxelEntry &e)
@@ -235,6 +244,8 @@ __device__ __forceinline__ bool commit_candidate(const FrameParams &fp, const De
         e.offset = 0;
         bucket[s] = e;
         atomicOr(dp.bucketBits + (local >> 5), 1u << (local & 31u));
+        const uint32_t hm = macro_hash(k.x >> 2, k.y >> 2, k.z >> 2);
+        atomicOr(dp.macroBits + (hm >> 5), 1u << (hm & 31u));
         atomicAdd(dp.counters + kAllocatedTotal, 1);
         return true;
     }
@@ -972,7 +983,7 @@ __device__ __forceinline__ int lookup_block(const FrameParams &fp, const DevPtrs
 constexpr float kSkipMargin = 0.01f;     // voxels; see the empty-block skip below
 // kRayBatch (template): in-block samples whose voxels are fetched together
 
-template <int kRayBatch>
+template <int kRayBatch, bool kFastDiv>
 __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, const DevPtrs dp, float fx, float fy,
                                                       float cx, float cy, float tMin, int nSteps,
                                                       float *__restrict__ depthOut)
@@ -984,43 +995,58 @@ __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, cons
     const float dy = ((float)v - cy) / fy;
     const float dt = fp.voxelSize;
     const float invDt = __builtin_amdgcn_rcpf(dt) * (1.0f - 1.0e-6f);   // never over-estimates a step count
+    const float rcpVoxel = 1.0f / fp.voxelSize;                          // correctly rounded (world2voxel1_fast)
     // world-space ray per unit of camera depth (only used to bound empty-block skips)
     const float dirX = fp.T[0] * dx + fp.T[1] * dy + fp.T[2];
     const float dirY = fp.T[4] * dx + fp.T[5] * dy + fp.T[6];
     const float dirZ = fp.T[8] * dx + fp.T[9] * dy + fp.T[10];
-    bool prevValid = false, haveKey = false, found = false;
+    const float rayD[3] = {dirX, dirY, dirZ}, rayO[3] = {fp.T[3], fp.T[7], fp.T[11]};
+    float invD[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) invD[a] = (rayD[a] != 0.0f) ? __builtin_amdgcn_rcpf(rayD[a]) : 0.0f;
+    bool prevValid = false, haveKey = false, found = false, haveMacro = false, macroEmpty = false;
     float prevSdf = 0.0f, prevT = 0.0f, hit = 0.0f;
     int ckx = 0, cky = 0, ckz = 0, cptr = VH_FREE_BLOCK;
+    int cmx = 0, cmy = 0, cmz = 0;
     for (int i = 0; i < nSteps; ++i) {
         const float tt = tMin + (float)i * dt;
         const float4 pw = mat4_mul(fp.T, dx * tt, dy * tt, tt, 1.0f);
-        const int vx = world2voxel1(pw.x, fp.voxelSize);
-        const int vy = world2voxel1(pw.y, fp.voxelSize);
-        const int vz = world2voxel1(pw.z, fp.voxelSize);
+        const int vx = kFastDiv ? world2voxel1_fast(pw.x, fp.voxelSize, rcpVoxel) : world2voxel1(pw.x, fp.voxelSize);
+        const int vy = kFastDiv ? world2voxel1_fast(pw.y, fp.voxelSize, rcpVoxel) : world2voxel1(pw.y, fp.voxelSize);
+        const int vz = kFastDiv ? world2voxel1_fast(pw.z, fp.voxelSize, rcpVoxel) : world2voxel1(pw.z, fp.voxelSize);
         const int kx = voxel2block1(vx), ky = voxel2block1(vy), kz = voxel2block1(vz);
         if (!haveKey || kx != ckx || ky != cky || kz != ckz) {
             ckx = kx; cky = ky; ckz = kz;
-            cptr = lookup_block(fp, dp, kx, ky, kz);
             haveKey = true;
+            const int mx = kx >> 2, my = ky >> 2, mz = kz >> 2;          // macro cell of 4x4x4 blocks
+            if (!haveMacro || mx != cmx || my != cmy || mz != cmz) {
+                cmx = mx; cmy = my; cmz = mz;
+                haveMacro = true;
+                const uint32_t hm = macro_hash(mx, my, mz);
+                macroEmpty = !((dp.macroBits[hm >> 5] >> (hm & 31u)) & 1u);
+            }
+            cptr = macroEmpty ? VH_FREE_BLOCK : lookup_block(fp, dp, kx, ky, kz);
         }
         if (cptr == VH_FREE_BLOCK) {
             // Empty block: every further sample inside it is invalid too, so jump to the last
-            // sample that is CERTAINLY still inside (block shrunk by kSkipMargin voxels per side:
+            // sample that is CERTAINLY still inside (cell shrunk by kSkipMargin voxels per side:
             // 1e-2 voxel = 2e-4 m at 2 cm voxels, against ~1e-6 m of fp32 difference between this
             // linear ray model and the sample positions above).  Skipping only such samples
             // leaves the result unchanged.
             prevValid = false;
             float tExit = 3.0e38f;
-            const float rayD[3] = {dirX, dirY, dirZ}, rayO[3] = {fp.T[3], fp.T[7], fp.T[11]};
-            const int key[3] = {kx, ky, kz};
+            // an empty macro cell (no block in 4x4x4) is skipped whole: 32 voxels per side
+            const int cell[3] = {macroEmpty ? cmx * 32 : kx * 8, macroEmpty ? cmy * 32 : ky * 8,
+                                 macroEmpty ? cmz * 32 : kz * 8};
+            const float span = macroEmpty ? 31.5f : 7.5f;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                // the block spans voxel centres 8k .. 8k+7, i.e. world [(8k-0.5)vs, (8k+7.5)vs)
-                const float lo = ((float)(key[a] * 8) - 0.5f + kSkipMargin) * fp.voxelSize;
-                const float hi = ((float)(key[a] * 8) + 7.5f - kSkipMargin) * fp.voxelSize;
+                // the cell spans voxel centres c .. c+span-0.5, i.e. world [(c-0.5)vs, (c+span)vs)
+                const float lo = ((float)cell[a] - 0.5f + kSkipMargin) * fp.voxelSize;
+                const float hi = ((float)cell[a] + span - kSkipMargin) * fp.voxelSize;
                 // approximate reciprocals (1 ulp) are fine here: the margin absorbs them
-                if (rayD[a] > 0.0f) tExit = __builtin_fminf(tExit, (hi - rayO[a]) * __builtin_amdgcn_rcpf(rayD[a]));
-                else if (rayD[a] < 0.0f) tExit = __builtin_fminf(tExit, (lo - rayO[a]) * __builtin_amdgcn_rcpf(rayD[a]));
+                if (rayD[a] > 0.0f) tExit = __builtin_fminf(tExit, (hi - rayO[a]) * invD[a]);
+                else if (rayD[a] < 0.0f) tExit = __builtin_fminf(tExit, (lo - rayO[a]) * invD[a]);
             }
             const float steps = (tExit - tMin) * invDt;     // last sample index at or before tExit
             if (steps > (float)i && steps < 2.0e9f) i = min((int)steps, nSteps - 1);
@@ -1037,9 +1063,9 @@ __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, cons
         for (int j = 0; j < kRayBatch; ++j) {
             bt[j] = tMin + (float)(i + j) * dt;
             const float4 pj = mat4_mul(fp.T, dx * bt[j], dy * bt[j], bt[j], 1.0f);
-            const int jx = world2voxel1(pj.x, fp.voxelSize);
-            const int jy = world2voxel1(pj.y, fp.voxelSize);
-            const int jz = world2voxel1(pj.z, fp.voxelSize);
+            const int jx = kFastDiv ? world2voxel1_fast(pj.x, fp.voxelSize, rcpVoxel) : world2voxel1(pj.x, fp.voxelSize);
+            const int jy = kFastDiv ? world2voxel1_fast(pj.y, fp.voxelSize, rcpVoxel) : world2voxel1(pj.y, fp.voxelSize);
+            const int jz = kFastDiv ? world2voxel1_fast(pj.z, fp.voxelSize, rcpVoxel) : world2voxel1(pj.z, fp.voxelSize);
             inBlock[j] = (i + j < nSteps) && voxel2block1(jx) == kx && voxel2block1(jy) == ky &&
                          voxel2block1(jz) == kz;
             const int lx = (int)((uint32_t)jx - (uint32_t)kx * 8u);
