@@ -1,0 +1,262 @@
+// vh_alloc.hip -- allocBlocks: per-pixel block keys, wave-level run dedup, bucket probe + epoch-stamped claim (phase 1),
+// commit of the winners (phase 2), key generation for the multi-GPU exchange.
+// Part of libvoxelhash_hip.so (gfx950); included by vh_kernels.hip after vh_device.h.
+#pragma once
+
+namespace vh {
+
+// ---------------------------------------------------------------------------
+// bucket probe shared by the claim kernels
+// ---------------------------------------------------------------------------
+// Reads the bucket of `key` the way insertVoxelEntry scans it (VoxelUtils.cu:436-456):
+// present -> nothing to do; otherwise, if a free slot exists, stake a claim.
+// Allocated entries always form a prefix of the bucket (insertions take the
+// first free slot, nothing is ever deleted), so "present anywhere" equals the
+// reference's in-order scan.
+__device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz,
+                                                uint32_t h, uint32_t rank, int candCounter = kCandCount)
+{
+    const VoxelEntry *bucket = dp.table + (size_t)(h - fp.bucketLo) * fp.bucketSize;
+    bool has_free = false;
+    for (uint32_t i = 0; i < fp.bucketSize; ++i) {
+        const VoxelEntry e = bucket[i];
+        if (e.ptr == VH_FREE_BLOCK) {
+            has_free = true;
+            break;                       // prefix property: nothing allocated behind a free slot
+        }
+        if (e.pos[0] == kx && e.pos[1] == ky && e.pos[2] == kz) return;   // already allocated
+    }
+    if (!has_free) return;               // bucket full: the key is dropped (no overflow list)
+    atomicMax(dp.claim + (h - fp.bucketLo), claim_word(fp.epoch, rank));
+    const uint32_t slot = (uint32_t)atomicAdd(dp.counters + candCounter, 1);
+    if (slot < dp.candCapacity) dp.candidates[slot] = make_int4(kx, ky, kz, (int)rank);
+}
+
+// ---------------------------------------------------------------------------
+// allocBlocks, phase 1
+// ---------------------------------------------------------------------------
+// One lane per pixel, row-major, so the float4 vertex map is read with 16-byte
+// coalesced loads (1 KiB per wave instruction).  Neighbouring pixels almost
+// always fall into the same 8^3 block, so each wave collapses runs of equal
+// keys to their first lane before touching the table: ~300 k pixels become a
+// few thousand bucket probes.  Within an image row the launch rank grows with
+// x, so the first lane of a run carries the run's lowest rank.
+// Truncation-band allocation (opt-in; commented out in the reference,
+// VoxelUtils.cu:632-703): with fp.allocBand = b > 0 a pixel demands the blocks of
+// 2*ceil(b/step)+1 points on its viewing ray at camera depths z + (k - half)*step, step = half
+// a block edge; the middle sample is the surface point itself.  b = 0: that sample only.
+struct PixelVertex {
+    float4 v;
+    int px, py;
+    bool valid;
+};
+
+__device__ __forceinline__ int band_samples(const FrameParams &fp, float &step)
+{
+    step = 4.0f * fp.voxelSize;
+    if (!(fp.allocBand > 0.0f)) return 1;
+    int half = (int)__builtin_ceilf(fp.allocBand / step);
+    half = min(half, (kMaxBandSamples - 1) / 2);
+    return 2 * half + 1;
+}
+
+__device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const float4 *__restrict__ verts, int idx,
+                                                  float *__restrict__ outDepth)
+{
+    PixelVertex p{make_float4(0.f, 0.f, 0.f, 0.f), 0, 0, false};
+    if (idx < fp.width * fp.height) {
+        p.v = verts[idx];
+        if (outDepth) outDepth[idx] = p.v.z;                             // camera-z plane of a camera packet
+        p.py = idx / fp.width;
+        p.px = idx - p.py * fp.width;
+        p.valid = p.v.z != 0.0f;                                         // VoxelUtils.cu:621
+    }
+    return p;
+}
+
+struct SampleKey {
+    int kx, ky, kz;
+    bool leader;       // this lane must probe / emit the key (first of a run of equal in-frustum keys)
+};
+
+// Key of band sample k of this lane's pixel, de-duplicated against the lane's own previous
+// sample and against the previous lane's sample k (runs of equal keys along an image row
+// collapse to their first lane; within a row the launch rank grows with x and, within a pixel,
+// with k, so whoever survives carries the lowest rank of its run).
+__device__ __forceinline__ SampleKey sample_key(const FrameParams &fp, const PixelVertex &p, int k, int nS, float step,
+                                                int &ownX, int &ownY, int &ownZ, bool &ownHave)
+{
+    SampleKey r{0, 0, 0, false};
+    bool want = false;
+    if (p.valid) {
+        const int half = (nS - 1) / 2;
+        const float s = p.v.z + ((float)k - (float)half) * step;
+        if (k == half || s > 0.0f) {                                     // the surface sample is never filtered (:621 only tests z != 0)
+            float x = p.v.x, y = p.v.y, z = p.v.z;                       // k == half: the vertex itself, bit for bit
+            if (k != half) {                                             // wave-uniform; no divide on the reference path
+                const float scale = s / p.v.z;
+                x = p.v.x * scale; y = p.v.y * scale; z = s;
+            }
+            const float4 g = mat4_mul(fp.T, x, y, z, p.v.w);             // :622, w as stored
+            const int3_ b = world2block(g.x, g.y, g.z, fp.voxelSize);    // :636
+            r.kx = b.x; r.ky = b.y; r.kz = b.z;
+            want = block_in_frustum(fp, r.kx, r.ky, r.kz);               // :673
+        }
+    }
+    const bool dupOwn = want && ownHave && ownX == r.kx && ownY == r.ky && ownZ == r.kz;
+    if (want) { ownX = r.kx; ownY = r.ky; ownZ = r.kz; ownHave = true; }
+    const int lane = threadIdx.x & (kWave - 1);
+    const int pkx = __shfl_up(r.kx, 1), pky = __shfl_up(r.ky, 1), pkz = __shfl_up(r.kz, 1);
+    const int ppy = __shfl_up(p.py, 1);
+    const int pwant = __shfl_up((int)want, 1);
+    r.leader = want && !dupOwn &&
+               (lane == 0 || !pwant || ppy != p.py || pkx != r.kx || pky != r.ky || pkz != r.kz);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t sample_rank(const FrameParams &fp, const PixelVertex &p, int k)
+{
+    return (launch_rank(p.px, p.py, fp.width) << kRankSampleBits) | (uint32_t)k;
+}
+
+// the claim phase for one lane = one pixel (shared by alloc_claim_kernel and the fused frame)
+__device__ __forceinline__ void claim_pixel(const FrameParams &fp, const DevPtrs &dp,
+                                            const float4 *__restrict__ verts, int idx, int candCounter)
+{
+    const PixelVertex p = load_pixel(fp, verts, idx, nullptr);
+    float step;
+    const int nS = band_samples(fp, step);
+    int ox = 0, oy = 0, oz = 0;
+    bool oh = false;
+    for (int k = 0; k < nS; ++k) {
+        const SampleKey s = sample_key(fp, p, k, nS, step, ox, oy, oz, oh);
+        if (!s.leader) continue;
+        const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
+        if (h < fp.bucketLo || h >= fp.bucketHi) continue;              // not this shard's bucket
+        probe_and_claim(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(fp, p, k), candCounter);
+    }
+}
+
+__global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, const DevPtrs dp,
+                                                          const float4 *__restrict__ verts)
+{
+    claim_pixel(fp, dp, verts, blockIdx.x * 256 + threadIdx.x, kCandCount);
+}
+
+// Key generation for the multi-GPU exchange: the same per-pixel
+// work, but the surviving keys are binned by owning shard instead of probed.  Slots in
+// a bin come from one global counter per bin; to keep that word off the critical path
+// (one address sustains only ~90 returning atomics per microsecond) a 1024-lane
+// workgroup first counts its keys per owner in LDS and then takes one global
+// atomicAdd per owner it actually has keys for.
+constexpr int kGenThreads = 1024;
+
+__global__ __launch_bounds__(kGenThreads) void generate_keys_kernel(const FrameParams fp,
+                                                                    const float4 *__restrict__ verts,
+                                                                    int32_t numShards, int4 *__restrict__ outBins,
+                                                                    int32_t outCapacity, int32_t outBinStride,
+                                                                    float *__restrict__ outDepth, uint32_t rankBase)
+{
+    __shared__ int ldsCount[VH_MAX_CAMERAS];
+    __shared__ int ldsBase[VH_MAX_CAMERAS];
+    if (outDepth && blockIdx.x == 0 && threadIdx.x < kPacketHeader)      // packet header: pose, inverse
+        outDepth[(int)threadIdx.x - kPacketHeader] = threadIdx.x < 16 ? fp.T[threadIdx.x] : fp.Tinv[threadIdx.x - 16];
+    const PixelVertex p = load_pixel(fp, verts, blockIdx.x * kGenThreads + threadIdx.x, outDepth);
+    float step;
+    const int nS = band_samples(fp, step);
+    const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
+    int ox = 0, oy = 0, oz = 0;
+    bool oh = false;
+    for (int k = 0; k < nS; ++k) {
+        if (threadIdx.x < VH_MAX_CAMERAS) ldsCount[threadIdx.x] = 0;
+        __syncthreads();
+        const SampleKey s = sample_key(fp, p, k, nS, step, ox, oy, oz, oh);
+        uint32_t owner = 0;
+        int local = 0;
+        if (s.leader) {
+            owner = hash_block(s.kx, s.ky, s.kz, fp.numBuckets) / perShard;
+            local = atomicAdd(&ldsCount[owner], 1);
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < numShards && ldsCount[threadIdx.x] > 0)
+            ldsBase[threadIdx.x] = atomicAdd(&outBins[(size_t)threadIdx.x * outBinStride].x, ldsCount[threadIdx.x]);
+        __syncthreads();
+        if (s.leader) {
+            int4 *bin = outBins + (size_t)owner * outBinStride;           // record 0 = {count,0,0,0}
+            const int slot = ldsBase[owner] + local + 1;
+            if (slot < outCapacity) bin[slot] = make_int4(s.kx, s.ky, s.kz, (int)(rankBase + sample_rank(fp, p, k)));
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// allocBlocks, phase 2
+// ---------------------------------------------------------------------------
+// Exactly one contender per bucket finds its own word in the claim array: the
+// one with the lowest launch rank, i.e. the thread a sequential run of the
+// reference grid would have let through the atomicExch (VoxelUtils.cu:444-445).
+// It takes the first free slot and pops the heap (top-down, :328-334).  An empty
+// heap refuses the insertion instead of reading heap[-1].
+// Raycast accelerator: "macro cells" of 4x4x4 blocks, one bit per hashed macro coordinate
+// (collisions only make the ray skip less).  Set when a block inside the cell is inserted.
+constexpr uint32_t kMacroBits = 1u << 20;      // 128 KB bitmap
+
+__device__ __forceinline__ uint32_t macro_hash(int mx, int my, int mz)
+{
+    return (((uint32_t)mx * 73856093u) ^ ((uint32_t)my * 19349669u) ^ ((uint32_t)mz * 83492791u)) & (kMacroBits - 1u);
+}
+
+// Returns true (and the new entry) if candidate k held its bucket's claim and was inserted.
+__device__ __forceinline__ bool commit_candidate(const FrameParams &fp, const DevPtrs &dp, const int4 k,
+                                                 VoxelEntry &e)
+{
+    const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
+    const uint32_t local = h - fp.bucketLo;
+    if (dp.claim[local] != claim_word(fp.epoch, (uint32_t)k.w)) return false;   // lost the bucket this frame
+    dp.claim[local] = consumed_word(fp.epoch);                                   // locked until the next epoch
+    VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
+    for (uint32_t s = 0; s < fp.bucketSize; ++s) {
+        if (bucket[s].ptr != VH_FREE_BLOCK) continue;
+        const int addr = atomicSub(dp.counters + kHeapCounter, 1);
+        if (addr < 0) {                                   // heap empty: undo, refuse
+            atomicAdd(dp.counters + kHeapCounter, 1);
+            atomicAdd(dp.counters + kHeapExhausted, 1);
+            return false;
+        }
+        e.pos[0] = k.x; e.pos[1] = k.y; e.pos[2] = k.z;
+        e.ptr = (int)(dp.heap[addr] * (uint32_t)kBlockVoxels);
+        e.offset = 0;
+        bucket[s] = e;
+        atomicOr(dp.bucketBits + (local >> 5), 1u << (local & 31u));
+        const uint32_t hm = macro_hash(k.x >> 2, k.y >> 2, k.z >> 2);
+        atomicOr(dp.macroBits + (hm >> 5), 1u << (hm & 31u));
+        atomicAdd(dp.counters + kAllocatedTotal, 1);
+        return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void alloc_commit_kernel(const FrameParams fp, const DevPtrs dp)
+{
+    int n = dp.counters[kCandCount];
+    if ((uint32_t)n > dp.candCapacity) n = (int)dp.candCapacity;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        VoxelEntry e;
+        (void)commit_candidate(fp, dp, dp.candidates[i], e);
+    }
+    // the last workgroup to finish re-arms the per-frame counters
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(dp.counters + kCommitTicket, 1);
+        if (ticket == (int)gridDim.x - 1) {
+            dp.counters[kLastCandidates] = dp.counters[kCandCount];
+            dp.counters[kCandCount] = 0;
+            dp.counters[kCompactCount] = 0;
+            dp.counters[kCommitTicket] = 0;
+        }
+    }
+}
+
+}  // namespace vh

@@ -1,0 +1,72 @@
+// vh_integrate.hip -- integrateDepthMap: 8^3-block TSDF update.
+// Part of libvoxelhash_hip.so (gfx950); included by vh_kernels.hip after vh_device.h.
+#pragma once
+
+namespace vh {
+
+// ---------------------------------------------------------------------------
+// integrateDepthMap
+// ---------------------------------------------------------------------------
+// A workgroup of 256 lanes owns one 8^3 block per pass: lane t updates voxels
+// 2t and 2t+1 (neighbours in x), so the block moves as 16-byte-per-lane
+// coalesced loads and stores (4 KiB in, 4 KiB out) instead of the reference's
+// 8-byte accesses.  The occupied count never leaves the device: the grid is a
+// fixed size and strides over the compact list.
+// depth(x,y) = depthBase[stride*(y*W+x)]: stride 4 from &verts[0].z (float4 vertex map),
+// stride 1 for the camera-z plane of a camera packet.
+__device__ __forceinline__ bool tsdf_update(const FrameParams &fp, const float *Tinv,
+                                            const float *__restrict__ depthBase, int stride, int vx, int vy, int vz,
+                                            float &sdfOut, float &wOut)
+{
+    float cx, cy, cz;
+    if (fp.semantics == VH_SEM_REFERENCE) {
+        // VoxelUtils.cu:797-800: inverse pose on the voxel INDEX, truncate, then metres
+        const float4 r = mat4_mul(Tinv, (float)vx, (float)vy, (float)vz, 1.0f);
+        cx = (float)f2i_rz(r.x) * fp.voxelSize;
+        cy = (float)f2i_rz(r.y) * fp.voxelSize;
+        cz = (float)f2i_rz(r.z) * fp.voxelSize;
+    } else {
+        const float4 r = mat4_mul(Tinv, (float)vx * fp.voxelSize, (float)vy * fp.voxelSize,
+                                  (float)vz * fp.voxelSize, 1.0f);
+        cx = r.x; cy = r.y; cz = r.z;
+    }
+    int sx, sy;
+    project(fp.proj, cx, cy, cz, sx, sy);                                        // :801
+    if (sx < 0 || sx >= fp.width || sy < 0 || sy >= fp.height) return false;     // :803
+    const float depth = depthBase[(size_t)stride * ((size_t)sy * fp.width + sx)];   // :805
+    if (depth <= 0.0f) return false;                                             // :806
+    float sdf = depth - cz;                                                      // :813
+    if (!(sdf > -fp.truncation)) return false;                                   // :818
+    sdf = (sdf >= 0.0f) ? __builtin_fminf(fp.truncation, sdf) : __builtin_fmaxf(-fp.truncation, sdf);
+    // combineVoxel, :779-787, current sample {sdf, 0.1f} (:829)
+    const float ow = wOut, os = sdfOut;
+    sdfOut = ((os * ow) + (sdf * 0.1f)) / (ow + 0.1f);
+    wOut = __builtin_fminf(fp.weightMax, ow + 0.1f);
+    return true;
+}
+
+// the 256 lanes of a workgroup update the 8^3 block of entry e from the float4 vertex map
+__device__ __forceinline__ void integrate_block(const FrameParams &fp, const DevPtrs &dp, const VoxelEntry &e,
+                                                const float4 *__restrict__ verts)
+{
+    const int lin = 2 * (int)threadIdx.x;        // linearizeVoxelPos: z*64 + y*8 + x  (:311-317)
+    const int tx = lin & 7, ty = (lin >> 3) & 7, tz = lin >> 6;
+    const int bx = (int)((uint32_t)e.pos[0] * 8u) + tx;     // block2Voxel + threadIdx (:793-796)
+    const int by = (int)((uint32_t)e.pos[1] * 8u) + ty;
+    const int bz = (int)((uint32_t)e.pos[2] * 8u) + tz;
+    float4 *cell = reinterpret_cast<float4 *>(dp.blocks + (size_t)e.ptr + lin);
+    float4 v = *cell;                            // {sdf0, w0, sdf1, w1}
+    const float *depthBase = reinterpret_cast<const float *>(verts) + 2;   // &verts[0].z
+    const bool u0 = tsdf_update(fp, fp.Tinv, depthBase, 4, bx, by, bz, v.x, v.y);
+    const bool u1 = tsdf_update(fp, fp.Tinv, depthBase, 4, bx + 1, by, bz, v.z, v.w);
+    if (u0 || u1) *cell = v;
+}
+
+__global__ __launch_bounds__(256) void integrate_kernel(const FrameParams fp, const DevPtrs dp,
+                                                        const float4 *__restrict__ verts)
+{
+    const int count = dp.counters[kCompactCount];
+    for (int b = blockIdx.x; b < count; b += gridDim.x) integrate_block(fp, dp, dp.compact[b], verts);
+}
+
+}  // namespace vh

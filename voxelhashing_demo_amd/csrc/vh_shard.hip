@@ -1,0 +1,212 @@
+// vh_shard.hip -- the multi-camera frame on a bucket-range shard (multi-GPU).
+// Part of libvoxelhash_hip.so (gfx950); included by vh_kernels.hip after vh_device.h.
+#pragma once
+
+namespace vh {
+
+// ---------------------------------------------------------------------------
+// multi-camera frame on a bucket-range shard
+// ---------------------------------------------------------------------------
+// phase 1 for key bins that arrived from the other ranks: bin b = bins[b*binStride..],
+// record 0 = {count,0,0,0}, records 1..count = {x,y,z,rank}.  One lock epoch for all
+// bins; rank = camera<<24 | launch rank, so cameras are served in order.
+// (binIndex, part, parts): this workgroup handles every parts-th 256-record slice of the bin.
+__device__ __forceinline__ void claim_bin_slice(const FrameParams &fp, const DevPtrs &dp,
+                                                const int4 *__restrict__ bins, int32_t capacity, int32_t binStride,
+                                                uint32_t binIndex, uint32_t part, uint32_t parts, int candCounter)
+{
+    const int4 *bin = bins + (size_t)binIndex * binStride;
+    int n = bin[0].x;
+    if (n > capacity - 1) {
+        if (part == 0 && threadIdx.x == 0) atomicAdd(dp.counters + kBinOverflow, 1);
+        n = capacity - 1;
+    }
+    for (int i = (int)part * 256 + (int)threadIdx.x; i < n; i += (int)parts * 256) {
+        const int4 k = bin[1 + i];
+        const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
+        if (h < fp.bucketLo || h >= fp.bucketHi) continue;
+        probe_and_claim(fp, dp, k.x, k.y, k.z, h, (uint32_t)k.w, candCounter);
+    }
+}
+
+__global__ __launch_bounds__(256) void claim_bins_kernel(const FrameParams fp, const DevPtrs dp,
+                                                         const int4 *__restrict__ bins, int32_t capacity,
+                                                         int32_t binStride)
+{
+    claim_bin_slice(fp, dp, bins, capacity, binStride, blockIdx.y, blockIdx.x, gridDim.x, kCandCount);
+}
+
+// cameras (bit c) whose frustum holds the block
+__device__ __forceinline__ uint32_t camera_mask(const FrameParams &fp, const int *pos, int32_t numCams,
+                                                const float *__restrict__ packets, size_t packetStride)
+{
+    uint32_t seen = 0;
+    for (int c = 0; c < numCams; ++c) {
+        const float *pk = packets + packetStride * c;
+        if (block_in_frustum(fp, pk, pk + 16, pos[0], pos[1], pos[2])) seen |= 1u << c;
+    }
+    return seen;
+}
+
+// One walk over the shard's entries for ALL cameras of the step: a live entry is
+// tested against every camera's frustum and appended once, with the mask of the
+// cameras that see it.
+__device__ __forceinline__ void flatten_multi_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
+                                                   uint32_t tileIndex, int32_t numCams,
+                                                   const float *__restrict__ packets, size_t packetStride,
+                                                   int counter)
+{
+    const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
+    const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
+    int32_t ptrs[kEntriesPerLane];
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) {
+        const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
+        ptrs[j] = (e < numEntries) ? words[(size_t)e * kEntryDwords + 3] : VH_FREE_BLOCK;
+    }
+    uint32_t seen[kEntriesPerLane];         // cameras whose frustum holds entry j
+    int myCount = 0;
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) {
+        seen[j] = 0;
+        if (ptrs[j] == VH_FREE_BLOCK) continue;
+        const VoxelEntry ent = dp.table[tile + j * kFlattenThreads + threadIdx.x];
+        seen[j] = camera_mask(fp, ent.pos, numCams, packets, packetStride);
+        myCount += seen[j] != 0u;
+    }
+    int slot = reserve_compact_slots(dp, counter, myCount);
+    if (slot < 0) return;
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) {
+        if (seen[j] == 0u) continue;
+        dp.compact[slot] = dp.table[tile + j * kFlattenThreads + threadIdx.x];
+        dp.compactMask[slot] = seen[j];
+        ++slot;
+    }
+}
+
+__global__ __launch_bounds__(kFlattenThreads) void flatten_multi_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                        uint32_t numEntries, int32_t numCams,
+                                                                        const float *__restrict__ packets,
+                                                                        size_t packetStride)
+{
+    flatten_multi_tile(fp, dp, numEntries, blockIdx.x, numCams, packets, packetStride, kCompactCount);
+}
+
+// One 8^3 block per workgroup pass, the voxels stay in registers while the cameras
+// that see the block are applied in camera order (the running average is order
+// dependent): 4 KiB in, 4 KiB out per block whatever the number of cameras.
+__device__ __forceinline__ void integrate_block_multi(const FrameParams &fp, const DevPtrs &dp, const VoxelEntry &e,
+                                                      uint32_t seen, int32_t numCams,
+                                                      const float *__restrict__ packets, size_t packetStride)
+{
+    const int lin = 2 * (int)threadIdx.x;
+    const int tx = lin & 7, ty = (lin >> 3) & 7, tz = lin >> 6;
+    const int bx = (int)((uint32_t)e.pos[0] * 8u) + tx;
+    const int by = (int)((uint32_t)e.pos[1] * 8u) + ty;
+    const int bz = (int)((uint32_t)e.pos[2] * 8u) + tz;
+    float4 *cell = reinterpret_cast<float4 *>(dp.blocks + (size_t)e.ptr + lin);
+    float4 v = *cell;
+    bool dirty = false;
+    for (int c = 0; c < numCams; ++c) {
+        if (!((seen >> c) & 1u)) continue;
+        const float *pk = packets + packetStride * c;
+        dirty |= tsdf_update(fp, pk + 16, pk + kPacketHeader, 1, bx, by, bz, v.x, v.y);
+        dirty |= tsdf_update(fp, pk + 16, pk + kPacketHeader, 1, bx + 1, by, bz, v.z, v.w);
+    }
+    if (dirty) *cell = v;
+}
+
+__global__ __launch_bounds__(256) void integrate_multi_kernel(const FrameParams fp, const DevPtrs dp,
+                                                              int32_t numCams, const float *__restrict__ packets,
+                                                              size_t packetStride)
+{
+    const int count = dp.counters[kCompactCount];
+    for (int b = blockIdx.x; b < count; b += gridDim.x)
+        integrate_block_multi(fp, dp, dp.compact[b], dp.compactMask[b], numCams, packets, packetStride);
+}
+
+// The multi-camera frame in two launches, built like the single-camera fused frame:
+// launch 1 = {claim the received key bins || walk the shard for all cameras} (both only read
+// the table), launch 2 = {commit: insert, camera mask, append, integrate the new block ||
+// integrate the blocks the walk found}.
+__global__ __launch_bounds__(256) void frame_multi_scan_claim_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                     const int4 *__restrict__ bins, int32_t capacity,
+                                                                     int32_t binStride, uint32_t numBins,
+                                                                     uint32_t partsPerBin, uint32_t numEntries,
+                                                                     int32_t numCams,
+                                                                     const float *__restrict__ packets,
+                                                                     size_t packetStride, int parity)
+{
+    const uint32_t claimBlocks = numBins * partsPerBin, total = gridDim.x;
+    const uint32_t claimBefore = (uint32_t)(((uint64_t)blockIdx.x * claimBlocks) / total);
+    const uint32_t claimAfter = (uint32_t)(((uint64_t)(blockIdx.x + 1u) * claimBlocks) / total);
+    if (claimAfter != claimBefore)
+        claim_bin_slice(fp, dp, bins, capacity, binStride, claimBefore / partsPerBin, claimBefore % partsPerBin,
+                        partsPerBin, kFusedCand + parity);
+    else
+        flatten_multi_tile(fp, dp, numEntries, blockIdx.x - claimBefore, numCams, packets, packetStride,
+                           kScanCount + parity);
+}
+
+__global__ __launch_bounds__(256) void frame_multi_commit_integrate_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                           int32_t numCams,
+                                                                           const float *__restrict__ packets,
+                                                                           size_t packetStride,
+                                                                           uint32_t commitBlocks, int parity)
+{
+    const int scanCount = dp.counters[kScanCount + parity];
+    if (blockIdx.x >= commitBlocks) {
+        for (int b = blockIdx.x - commitBlocks; b < scanCount; b += gridDim.x - commitBlocks)
+            integrate_block_multi(fp, dp, dp.compact[b], dp.compactMask[b], numCams, packets, packetStride);
+        return;
+    }
+    __shared__ VoxelEntry newEntry;
+    __shared__ uint32_t newMask;
+    __shared__ int inserted;
+    int n = dp.counters[kFusedCand + parity];
+    if ((uint32_t)n > dp.candCapacity) n = (int)dp.candCapacity;
+    for (int i = blockIdx.x; i < n; i += commitBlocks) {
+        if (threadIdx.x == 0) {
+            VoxelEntry e;
+            inserted = commit_candidate(fp, dp, dp.candidates[i], e) ? 1 : 0;
+            if (inserted) {
+                const uint32_t seen = camera_mask(fp, e.pos, numCams, packets, packetStride);
+                newEntry = e;
+                newMask = seen;
+                if (seen != 0u) {       // what the walk would have appended had it seen the entry
+                    const int slot = scanCount + atomicAdd(dp.counters + kNewCount + parity, 1);
+                    dp.compact[slot] = e;
+                    dp.compactMask[slot] = seen;
+                }
+            }
+        }
+        __syncthreads();
+        if (inserted && newMask != 0u) integrate_block_multi(fp, dp, newEntry, newMask, numCams, packets, packetStride);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(dp.counters + kCommitTicket, 1);
+        if (ticket == (int)commitBlocks - 1) {
+            dp.counters[kCompactCount] = scanCount + atomicAdd(dp.counters + kNewCount + parity, 0);
+            dp.counters[kLastCandidates] = n;
+            dp.counters[kScanCount + (parity ^ 1)] = 0;
+            dp.counters[kNewCount + (parity ^ 1)] = 0;
+            dp.counters[kFusedCand + (parity ^ 1)] = 0;
+            dp.counters[kCommitTicket] = 0;
+        }
+    }
+}
+
+// Zeroes the header record of the bins of `batch` frames x numShards shards before
+// generate_keys_kernel fills them (bin of shard s, frame b at bins[s*binStride + b*frameStride]).
+__global__ void prepare_bins_kernel(int4 *bins, int32_t numShards, int32_t binStride, int32_t batch,
+                                    int32_t frameStride)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < numShards * batch)
+        bins[(size_t)(i / batch) * binStride + (size_t)(i % batch) * frameStride] = make_int4(0, 0, 0, 0);
+}
+
+}  // namespace vh
