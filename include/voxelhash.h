@@ -136,6 +136,8 @@ typedef struct vh_kernel_times {
     uint64_t raycast_launches;
     double   frame_scan_claim_ms;        /* fused vh_integrate, launch 1: claim || table walk */
     double   frame_commit_integrate_ms;  /* fused vh_integrate, launch 2: commit + TSDF update */
+    double   view_export_ms;             /* vh_export_views: select walk + record packing */
+    double   view_import_ms;             /* vh_import_view: clear + insert */
 } vh_kernel_times;
 
 typedef struct vh_context vh_context;
@@ -267,6 +269,38 @@ int vh_generate_keys_batch(vh_context *ctx, int32_t batch, const float *poses,
 int vh_apply_frames_batch(vh_context *ctx, int32_t batch, const int32_t *d_bins, int32_t num_bins,
                           int32_t capacity, int32_t bin_stride, int32_t frame_stride, int32_t num_cams,
                           const float *d_packets, size_t packet_stride, size_t packet_frame_stride);
+
+/* ------------------------------------------------------------------ */
+/* raycast over shards ("replicate the compact table +   */
+/* visible blocks"; DESIGN.md section 6 "raycast")                      */
+/* ------------------------------------------------------------------ */
+/* A ray samples blocks of every shard, so the rank that renders a view first gathers the
+ * blocks the view can touch: each shard exports them as records, the records travel
+ * (all-to-all with per-destination counts), the renderer imports them into a private view
+ * table and calls vh_raycast on it.  The selection is a conservative superset of the blocks
+ * the rays of the view sample, so the result equals vh_raycast on the unsharded table bit
+ * for bit. */
+typedef struct vh_view_record {
+    int32_t  pos[3];
+    int32_t  reserved;
+    Voxel    voxels[512];
+} vh_view_record;                /* 4112 bytes */
+
+/* One walk over this table (shard) for n_views views (poses: n_views*16 host floats,
+ * camera->world; the pyramid is that of the raycast intrinsics, t_min..t_max): the allocated
+ * entries view v can touch are written to d_records, view 0's records first, then view 1's
+ * ... without gaps; d_counts[v] (device) receives the number view v selected.  At most
+ * `capacity` records are written per view (a count above capacity reports the loss).
+ * d_records must hold n_views*capacity records, 16-byte aligned.  n_views <= VH_MAX_CAMERAS. */
+int vh_export_views(vh_context *ctx, const float *poses, int32_t n_views, float t_min, float t_max,
+                    vh_view_record *d_records, int32_t capacity, int32_t *d_counts);
+/* `view`: an unsharded context of the same numBuckets / bucketSize that never integrated a
+ * frame (numVoxelBlocks may be 1).  Its table is emptied and then holds exactly the `count`
+ * records; the voxels stay in d_records, which must stay valid and unchanged until the next
+ * import.  vh_raycast(view, ...) then renders them.  Records that find their bucket full
+ * are dropped and counted in vh_counters.bin_overflow (never happens for records exported
+ * from one logical table of the same geometry). */
+int vh_import_view(vh_context *view, const vh_view_record *d_records, int32_t count);
 
 /* ------------------------------------------------------------------ */
 /* model dump / checkpoint                     */

@@ -126,6 +126,10 @@ def lib():
         L.vho_integrate_packets.argtypes = [C.c_void_p, C.c_int, fp]
         L.vho_integrate_packets.restype = C.c_int
         L.vho_preprocess.argtypes = [C.POINTER(C.c_uint16), fp, C.c_int, C.c_int, fp, fp]
+        L.vho_export_view.argtypes = [C.c_void_p, fp, C.c_float, C.c_float, C.c_void_p, C.c_int]
+        L.vho_export_view.restype = C.c_int
+        L.vho_import_view.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.vho_import_view.restype = C.c_int
         _lib = L
     return _lib
 
@@ -293,6 +297,22 @@ class OracleTable:
         out = np.zeros((self.height, self.width), np.float32)
         lib().vho_raycast(self._h, _fptr(pose), t_min, t_max, _fptr(out))
         return out
+
+    # ---- raycast over shards: view records are uint8 [count, 4112] = {pos[3], 0, 512 voxels} ----
+    VIEW_RECORD_BYTES = 4112
+
+    def export_view(self, pose, capacity: int, t_min: float = 0.1, t_max: float = 5.0):
+        """(records[min(count, capacity)], count): this table's allocated blocks the view can touch."""
+        pose = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
+        rec = np.zeros((max(1, capacity), self.VIEW_RECORD_BYTES), np.uint8)
+        n = int(lib().vho_export_view(self._h, _fptr(pose), t_min, t_max, rec.ctypes.data, capacity))
+        return rec[:min(n, capacity)], n
+
+    def import_view(self, records) -> int:
+        """Make this (otherwise unused, unsharded) table hold exactly `records`; returns the drops."""
+        self._view_records = np.ascontiguousarray(records, np.uint8)      # the voxels stay in here
+        n = self._view_records.size // self.VIEW_RECORD_BYTES
+        return int(lib().vho_import_view(self._h, self._view_records.ctypes.data, n))
 
     def block_in_frustum(self, block) -> bool:
         a = (C.c_int32 * 3)(*[int(c) for c in block])

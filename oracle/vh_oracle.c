@@ -31,6 +31,7 @@ struct vho_table {
     vho_entry *compact;
     int32_t   *mutex;
     vho_voxel *blocks;
+    const vho_voxel *view_blocks;  /* vho_import_view: voxels live in the caller's records */
     int32_t    heap_counter;
     int32_t    compact_counter;
 
@@ -583,7 +584,8 @@ void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max, f
             const int32_t lx = wrap_sub(vox[0], wrap_mul(key[0], 8));
             const int32_t ly = wrap_sub(vox[1], wrap_mul(key[1], 8));
             const int32_t lz = wrap_sub(vox[2], wrap_mul(key[2], 8));
-            const vho_voxel s = t->blocks[(size_t)t->table[cidx].ptr + (size_t)(lz * 64 + ly * 8 + lx)];
+            const vho_voxel *vol = t->view_blocks ? t->view_blocks : t->blocks;
+            const vho_voxel s = vol[(size_t)t->table[cidx].ptr + (size_t)(lz * 64 + ly * 8 + lx)];
             if (!(s.weight > 0.0f)) { prev_valid = 0; continue; }
             if (prev_valid && prev_sdf > 0.0f && s.sdf <= 0.0f) {
                 hit = prev_t + (dt * prev_sdf) / (prev_sdf - s.sdf);
@@ -593,6 +595,100 @@ void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max, f
         }
         depth_out[(size_t)v * W + u] = hit;
     }
+}
+
+/* ------------------------------------------------------------------ */
+/* raycast over shards: replicate the blocks a view can touch           */
+/* (build extension, DESIGN.md section 6 "raycast")     */
+/* ------------------------------------------------------------------ */
+
+/* Conservative "can a ray of this view sample the block" test.  A ray sample lies in
+ * the pyramid {t_min <= z <= t_max, pixel 0..W-1 x 0..H-1} of the view; the voxels of
+ * block k span a cube of half-diagonal 4*sqrt(3) = 6.93 voxels around its centre
+ * (8k+3.5)*voxelSize.  The block is kept when its centre is within 7 voxels of every
+ * bounding plane of that pyramid: a superset of the blocks the rays touch, so a table
+ * that holds exactly these blocks raycasts like the whole table.  The view's frustum
+ * constants are prepared once on the host in this order (HIP side: vh_api.hip
+ * make_view_frustum, same operations, -ffp-contract=off). */
+void vho_view_frustum(const vho_table *t, const float pose[16], float t_min, float t_max, float f[22])
+{
+    float inv[16];
+    vho_invert4x4(pose, inv);
+    memcpy(f, inv, 12 * sizeof(float));
+    const float r = 7.0f * t->p.voxelSize;
+    const float a0 = (0.0f - t->rc_cx) / t->rc_fx, a1 = ((float)(t->width - 1) - t->rc_cx) / t->rc_fx;
+    const float b0 = (0.0f - t->rc_cy) / t->rc_fy, b1 = ((float)(t->height - 1) - t->rc_cy) / t->rc_fy;
+    const float a[4] = { a0, a1, b0, b1 };
+    for (int i = 0; i < 4; ++i) {
+        f[12 + i] = a[i];
+        f[16 + i] = -(r * sqrtf(1.0f + a[i] * a[i]));
+    }
+    f[20] = t_min - r;
+    f[21] = t_max + r;
+}
+
+int vho_view_holds_block(const vho_table *t, const float f[22], const int32_t key[3])
+{
+    float c[4], pc[3];
+    for (int a = 0; a < 3; ++a) c[a] = ((float)wrap_mul(key[a], 8) + 3.5f) * t->p.voxelSize;
+    for (int r = 0; r < 3; ++r)
+        pc[r] = f[4 * r + 0] * c[0] + f[4 * r + 1] * c[1] + f[4 * r + 2] * c[2] + f[4 * r + 3];
+    if (!(pc[2] >= f[20] && pc[2] <= f[21])) return 0;
+    if (!(pc[0] - f[12] * pc[2] >= f[16])) return 0;      /* left   */
+    if (!(f[13] * pc[2] - pc[0] >= f[17])) return 0;      /* right  */
+    if (!(pc[1] - f[14] * pc[2] >= f[18])) return 0;      /* top    */
+    if (!(f[15] * pc[2] - pc[1] >= f[19])) return 0;      /* bottom */
+    return 1;
+}
+
+/* Every allocated entry of this table (shard) the view can touch, as records
+ * {pos[3], 0, 512 voxels} (4112 bytes each), table order.  Returns the number of such
+ * entries; only the first `capacity` are written. */
+int vho_export_view(const vho_table *t, const float pose[16], float t_min, float t_max,
+                    uint8_t *records, int capacity)
+{
+    float f[22];
+    vho_view_frustum(t, pose, t_min, t_max, f);
+    const size_t n = (size_t)(t->bucket_hi - t->bucket_lo) * t->p.bucketSize;
+    int count = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const vho_entry *e = &t->table[i];
+        if (e->ptr == VHO_FREE_BLOCK || !vho_view_holds_block(t, f, e->pos)) continue;
+        if (count < capacity) {
+            uint8_t *rec = records + (size_t)VHO_VIEW_RECORD_BYTES * count;
+            const int32_t head[4] = { e->pos[0], e->pos[1], e->pos[2], 0 };
+            memcpy(rec, head, 16);
+            memcpy(rec + 16, t->blocks + e->ptr, 512 * sizeof(vho_voxel));
+        }
+        ++count;
+    }
+    return count;
+}
+
+/* Replace the contents of `view` (an unsharded table of the same numBuckets / bucketSize,
+ * used for nothing else) by `count` records gathered from the shards.  The voxels stay in
+ * `records`, which must outlive the raycasts.  Returns the number of records that found no
+ * free slot in their bucket (0 when the records come from one logical table of the same
+ * geometry: a bucket of the view then holds a subset of the same logical bucket). */
+int vho_import_view(vho_table *view, const uint8_t *records, int count)
+{
+    const uint32_t bs = view->p.bucketSize;
+    reset_entries(view->table, (size_t)view->p.numBuckets * bs);
+    view->view_blocks = (const vho_voxel *)records;
+    int dropped = 0;
+    for (int i = 0; i < count; ++i) {
+        int32_t head[4];
+        memcpy(head, records + (size_t)VHO_VIEW_RECORD_BYTES * i, 16);
+        const uint32_t h = vho_hash(head[0], head[1], head[2], view->p.numBuckets);
+        uint32_t s = 0;
+        while (s < bs && view->table[(size_t)h * bs + s].ptr != VHO_FREE_BLOCK) ++s;
+        if (s == bs) { ++dropped; continue; }
+        vho_entry *e = &view->table[(size_t)h * bs + s];
+        e->pos[0] = head[0]; e->pos[1] = head[1]; e->pos[2] = head[2];
+        e->ptr = i * (VHO_VIEW_RECORD_BYTES / 8) + 2;       /* in voxels from the start of records */
+        e->offset = 0;
+    }
+    return dropped;
 }
 
 /* ------------------------------------------------------------------ */

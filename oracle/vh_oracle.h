@@ -99,6 +99,15 @@ int  vho_integrate(vho_table *t, const float pose[16], const float *verts,
 void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max,
                  float *depth_out /* W*H */);
 
+/* ---- raycast over shards (build extension): the blocks a view can
+ * touch are gathered from the shards into a view table that raycasts like the whole ---- */
+#define VHO_VIEW_RECORD_BYTES 4112     /* {int32 pos[3], 0, 512 x {sdf, weight}} */
+void vho_view_frustum(const vho_table *t, const float pose[16], float t_min, float t_max, float f[22]);
+int  vho_view_holds_block(const vho_table *t, const float f[22], const int32_t key[3]);
+int  vho_export_view(const vho_table *t, const float pose[16], float t_min, float t_max,
+                     uint8_t *records, int capacity);
+int  vho_import_view(vho_table *view, const uint8_t *records, int count);
+
 /* ---- bucket-range sharding (build extension for multi-GPU) ---- */
 vho_table *vho_create_shard(const vho_params *p, int width, int height, int semantics,
                             uint32_t bucket_lo, uint32_t bucket_hi);

@@ -1,0 +1,169 @@
+"""Raycast over bucket-range shards on the GPU (vh_export_views / vh_import_view / vh_raycast):
+R shard contexts and R view contexts on one device with the in-process exchange, and the RCCL
+transport with one rank.  The depth images must equal the ORACLE's raycast of ONE unsharded
+table bit for bit."""
+import numpy as np
+import pytest
+
+from voxelhashing_demo_amd import dist as vdist
+from voxelhashing_demo_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+W, H = 320, 240
+KW = dict(numBuckets=1 << 14, numVoxelBlocks=4096)
+
+
+def cameras(world, step):
+    prims = synth.room_primitives()
+    out = []
+    for r in range(world):
+        pose = synth.camera_loop(60, phase=vdist.camera_phase(r, world))[(5 * step) % 60]
+        out.append((pose, synth.render_room_verts(pose, W, H, prims).numpy()))
+    return out
+
+
+def build(oracle, vh, torch, world, sem, steps=3):
+    plan = vdist.ShardPlan(KW["numBuckets"], world)
+    shards = [vdist.HipShard(vh.default_params(**KW), W, H, sem, plan, r, W * H // 4) for r in range(world)]
+    full = oracle.OracleTable(oracle.default_params(**KW), W, H, sem)
+    for step in range(steps):
+        cams = cameras(world, step)
+        vdist.loopback_step(shards, [[c[0]] for c in cams], [[torch.from_numpy(c[1]).cuda()] for c in cams])
+        vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+    for sh in shards:
+        sh.table.synchronize()
+    return plan, shards, full
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+@pytest.mark.parametrize("sem", [0, 1])
+def test_sharded_raycast_equals_oracle_raycast_of_one_table(oracle, vh, torch_cuda, world, sem):
+    torch = torch_cuda
+    plan, shards, full = build(oracle, vh, torch, world, sem)
+    views = [vdist.HipViewTable(vh.default_params(**KW), W, H, sem, world, 2048) for _ in range(world)]
+    hits = 0
+    for round_ in range(2):                      # the second round re-imports into used view tables
+        poses = [c[0] for c in cameras(world, 2 - round_)]
+        depths = vdist.loopback_raycast(shards, views, poses, capacity=2048)
+        for r in range(world):
+            ref = full.raycast(poses[r])
+            assert np.array_equal(depths[r].view(np.uint32), ref.view(np.uint32)), (round_, r)
+            hits += int((ref > 0).sum())
+        for v in views:
+            assert v.table.counters()["bin_overflow"] == 0
+    if sem == 1:
+        assert hits > 10000 * world
+    for x in shards + views:
+        x.table.close()
+
+
+def test_export_equals_oracle_export(oracle, vh, torch_cuda):
+    """Same selected set, same voxel bytes (the order inside a view is free)."""
+    torch = torch_cuda
+    world = 2
+    plan, shards, full = build(oracle, vh, torch, world, 1)
+    oshards = []
+    for r in range(world):
+        lo, hi = plan.bucket_range(r)
+        o = oracle.OracleTable(oracle.default_params(**KW), W, H, 1, bucket_range=(lo, hi))
+        oshards.append(o)
+    poses = [c[0] for c in cameras(3, 1)]        # three views, two shards
+    for r, sh in enumerate(shards):
+        records, counts = sh.export_views(poses, 2048)
+        torch.cuda.synchronize()
+        counts = counts.cpu().numpy()
+        rec = records.cpu().numpy()
+        first = 0
+        for v, pose in enumerate(poses):
+            got = rec[first:first + counts[v]]
+            first += counts[v]
+            got_map = {tuple(g[:12].view(np.int32)): g[16:].tobytes() for g in got}
+            assert len(got_map) == counts[v]
+            # oracle selection over the same shard content (downloaded from the GPU shard)
+            table = sh.table.hash_table()
+            blocks = sh.table.sdf_blocks()
+            want = {}
+            import ctypes as C
+            f = np.zeros(22, np.float32)
+            L = oracle.lib()
+            L.vho_view_frustum.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float)]
+            L.vho_view_holds_block.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+            L.vho_view_holds_block.restype = C.c_int
+            p16 = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
+            L.vho_view_frustum(oshards[r]._h, p16.ctypes.data_as(C.POINTER(C.c_float)), 0.1, 5.0,
+                               f.ctypes.data_as(C.POINTER(C.c_float)))
+            for e in table[table["ptr"] != -1]:
+                key = np.ascontiguousarray(e["pos"], np.int32)
+                if L.vho_view_holds_block(oshards[r]._h, f.ctypes.data_as(C.POINTER(C.c_float)),
+                                          key.ctypes.data_as(C.POINTER(C.c_int32))):
+                    want[tuple(key)] = blocks[int(e["ptr"]):int(e["ptr"]) + 512].tobytes()
+            assert got_map == want
+            assert len(want) > 20
+
+
+def test_capacity_overflow_is_reported_and_bounded(oracle, vh, torch_cuda):
+    torch = torch_cuda
+    plan, shards, full = build(oracle, vh, torch, 1, 1, steps=2)
+    poses = [cameras(1, 1)[0][0]]
+    records, counts = shards[0].export_views(poses, 7)
+    torch.cuda.synchronize()
+    assert int(counts[0]) > 7
+    keys = records[:7, :12].cpu().numpy().view(np.int32)
+    allocated = {tuple(k) for k in full.allocated()["pos"].tolist()}
+    assert all(tuple(k) in allocated for k in keys.tolist())
+
+
+def test_more_views_than_one_launch_takes(oracle, vh, torch_cuda):
+    """20 views: the select walk runs twice (16 views per launch)."""
+    torch = torch_cuda
+    plan, shards, full = build(oracle, vh, torch, 1, 1, steps=2)
+    poses = [synth.camera_loop(60)[3 * i] for i in range(20)]
+    view = vdist.HipViewTable(vh.default_params(**KW), W, H, 1, 1, 4096)
+    records, counts = shards[0].export_views(poses, 4096)
+    torch.cuda.synchronize()
+    counts = counts.cpu().tolist()
+    first = 0
+    for v in (0, 15, 16, 19):
+        first = sum(counts[:v])
+        view.recv[:counts[v]].copy_(records[first:first + counts[v]])
+        depth = view.render(counts[v], poses[v]).cpu().numpy()
+        assert np.array_equal(depth, full.raycast(poses[v])), v
+
+
+def test_empty_import_and_argument_checks(oracle, vh, torch_cuda):
+    torch = torch_cuda
+    view = vdist.HipViewTable(vh.default_params(**KW), W, H, 1, 1, 16)
+    depth = view.render(0, synth.camera_loop(60)[0]).cpu().numpy()
+    assert not depth.any()
+    used = vh.SDFHashtable(vh.default_params(**KW), W, H, 1)
+    pose, verts = cameras(1, 0)[0]
+    used.integrate(pose, torch.from_numpy(verts).cuda())
+    with pytest.raises(RuntimeError):
+        used.import_view(view.recv, 0)           # a table that integrated frames is not a view table
+    plan = vdist.ShardPlan(KW["numBuckets"], 2)
+    shard = vh.SDFHashtable(vh.default_params(**KW), W, H, 1, bucket_range=plan.bucket_range(1))
+    with pytest.raises(RuntimeError):
+        shard.import_view(view.recv, 0)          # nor is a shard
+
+
+def test_sharded_raycast_over_nccl(oracle, vh, torch_cuda):
+    import os
+
+    import torch.distributed as dist
+    torch = torch_cuda
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29543")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        plan, shards, full = build(oracle, vh, torch, 1, 1)
+        view = vdist.HipViewTable(vh.default_params(**KW), W, H, 1, 1, 4096)
+        transport = vdist.TorchDistTransport()
+        for step in (2, 0):
+            pose = cameras(1, step)[0][0]
+            depth, lost = vdist.sharded_raycast(shards[0], view, transport, pose, 4096)
+            torch.cuda.synchronize()
+            ref = full.raycast(pose)
+            assert lost == 0 and np.array_equal(depth.cpu().numpy(), ref) and (ref > 0).sum() > 10000
+    finally:
+        dist.destroy_process_group()

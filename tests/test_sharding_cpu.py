@@ -108,6 +108,12 @@ def _gloo_worker(rank, world, port, sem, q, batch=2):
                 vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
         lo, hi = plan.bucket_range(rank)
         n = check_shard_against_full(shard.table, full, lo, hi, 5)
+        # raycast over the shards: this rank's own view, blocks gathered from both ranks
+        view = vdist.OracleViewTable(O, O.default_params(**KW), W, H, sem, world, 2048)
+        pose = frames[-1][rank][0]
+        depth, lost = vdist.sharded_raycast(shard, view, transport, pose, 2048)
+        ref = full.raycast(pose)
+        assert lost == 0 and np.array_equal(depth.numpy(), ref) and (ref > 0).sum() > 1000
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok", n, len(full.allocated())))

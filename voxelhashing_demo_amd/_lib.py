@@ -58,7 +58,8 @@ class KernelTimes(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("alloc_claim_ms", C.c_double), ("alloc_commit_ms", C.c_double),
                 ("flatten_ms", C.c_double), ("integrate_ms", C.c_double), ("raycast_ms", C.c_double),
                 ("raycast_launches", C.c_uint64), ("frame_scan_claim_ms", C.c_double),
-                ("frame_commit_integrate_ms", C.c_double)]
+                ("frame_commit_integrate_ms", C.c_double), ("view_export_ms", C.c_double),
+                ("view_import_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -93,6 +94,8 @@ SIGNATURES = {
     "vh_integrate_depth_map": (C.c_int, [_vp, _vp]),
     "vh_integrate": (C.c_int, [_vp, _fp, _vp, _vp]),
     "vh_raycast": (C.c_int, [_vp, _fp, _f, _f, _vp]),
+    "vh_export_views": (C.c_int, [_vp, _fp, C.c_int32, _f, _f, _vp, C.c_int32, _vp]),
+    "vh_import_view": (C.c_int, [_vp, _vp, C.c_int32]),
     "vh_synchronize": (C.c_int, [_vp]),
     "vh_get_counters": (C.c_int, [_vp, C.POINTER(Counters)]),
     "vh_get_params": (C.c_int, [_vp, C.POINTER(HashTableParams)]),

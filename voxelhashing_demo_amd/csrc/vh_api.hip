@@ -47,7 +47,7 @@ static int fail(int code, const char *what, hipError_t e = hipSuccess)
 // hipEventRecord pair would add.
 enum Phase : int {
     kPhaseClaim = 0, kPhaseCommit, kPhaseFlatten, kPhaseIntegrate, kPhaseRaycast,
-    kPhaseFrameScanClaim, kPhaseFrameCommitIntegrate, kNumPhases
+    kPhaseFrameScanClaim, kPhaseFrameCommitIntegrate, kPhaseViewExport, kPhaseViewImport, kNumPhases
 };
 
 struct TimedLaunch {
@@ -82,6 +82,11 @@ struct vh_context {
     // then serialises mask -> entry -> atomic -> block update inside each workgroup.
     int flattenVariant = 3;
     int occupiedCounter = kCompactCount;   // which device counter holds the occupied count of the last frame
+    // raycast over shards
+    int32_t *viewLists = nullptr;          // export: selected entry indices, [views][capacity]
+    size_t viewListsSize = 0;              // in int32
+    const Voxel *viewBlocks = nullptr;     // import: the record buffer the view table's ptrs address
+    int32_t viewCount = 0;                 // records of the last import (their buckets are listed in compactMask)
 };
 
 struct DeviceGuard {
@@ -215,6 +220,9 @@ static int free_buffers(vh_context *c)
     if (c->dp.bucketBits) (void)hipFree(c->dp.bucketBits);
     if (c->dp.allocMask) (void)hipFree(c->dp.allocMask);
     if (c->dp.macroBits) (void)hipFree(c->dp.macroBits);
+    if (c->viewLists) (void)hipFree(c->viewLists);
+    c->viewLists = nullptr;
+    c->viewListsSize = 0;
     c->dp = DevPtrs{};
     return VH_OK;
 }
@@ -608,20 +616,108 @@ extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, floa
     int nsteps = (q >= 2147483648.0f) ? 0x7fffffff : (int)q;
     nsteps += 1;
     dim3 grid((fp.width + 15) / 16, (fp.height + 15) / 16);
+    DevPtrs dp = c->dp;
+    if (c->viewBlocks) dp.blocks = const_cast<Voxel *>(c->viewBlocks);     // view table: voxels live in the records
     int rc;
     if (c->raycastBatch >= 4)
-        rc = launch(c, kPhaseRaycast, raycast_kernel<4, false>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
+        rc = launch(c, kPhaseRaycast, raycast_kernel<4, false>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy, c->rc_cx,
                     c->rc_cy, t_min, nsteps, d_depth_out);
     else if (c->raycastBatch >= 2)
-        rc = launch(c, kPhaseRaycast, raycast_kernel<2, false>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
+        rc = launch(c, kPhaseRaycast, raycast_kernel<2, false>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy, c->rc_cx,
                     c->rc_cy, t_min, nsteps, d_depth_out);
     else if (c->raycastFastDiv)
-        rc = launch(c, kPhaseRaycast, raycast_kernel<1, true>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
+        rc = launch(c, kPhaseRaycast, raycast_kernel<1, true>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy, c->rc_cx,
                     c->rc_cy, t_min, nsteps, d_depth_out);
     else
-        rc = launch(c, kPhaseRaycast, raycast_kernel<1, false>, grid, dim3(256), fp, c->dp, c->rc_fx, c->rc_fy, c->rc_cx,
+        rc = launch(c, kPhaseRaycast, raycast_kernel<1, false>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy, c->rc_cx,
                     c->rc_cy, t_min, nsteps, d_depth_out);
     if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// raycast over shards: export of the blocks a view can touch, import into a view table
+// ---------------------------------------------------------------------------
+// oracle: vho_view_frustum (same operations in the same order)
+static void make_view_frustum(const vh_context *c, const float pose[16], float t_min, float t_max, float f[22])
+{
+    float inv[16];
+    invert4x4(pose, inv);
+    std::memcpy(f, inv, 12 * sizeof(float));
+    const float r = 7.0f * c->fp.voxelSize;
+    const float a[4] = {(0.0f - c->rc_cx) / c->rc_fx, ((float)(c->fp.width - 1) - c->rc_cx) / c->rc_fx,
+                        (0.0f - c->rc_cy) / c->rc_fy, ((float)(c->fp.height - 1) - c->rc_cy) / c->rc_fy};
+    for (int i = 0; i < 4; ++i) {
+        f[12 + i] = a[i];
+        f[16 + i] = -(r * sqrtf(1.0f + a[i] * a[i]));
+    }
+    f[20] = t_min - r;
+    f[21] = t_max + r;
+}
+
+extern "C" int vh_export_views(vh_context *c, const float *poses, int32_t n_views, float t_min, float t_max,
+                               vh_view_record *d_records, int32_t capacity, int32_t *d_counts)
+{
+    if (!c || !poses || !d_records || !d_counts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_views < 1 || n_views > VH_MAX_CAMERAS) return fail(VH_ERR_INVALID_ARGUMENT, "1..VH_MAX_CAMERAS views");
+    if (capacity < 1) return fail(VH_ERR_INVALID_ARGUMENT, "capacity must be positive");
+    if (!(t_max > t_min)) return fail(VH_ERR_INVALID_ARGUMENT, "t_max must exceed t_min");
+    if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table has no voxels of its own to export");
+    DeviceGuard guard(c->device);
+    const size_t need = (size_t)n_views * (size_t)capacity;
+    if (c->viewListsSize < need) {                         // first call (or a larger one): synchronises
+        VH_HIP(hipStreamSynchronize(c->stream));
+        if (c->viewLists) (void)hipFree(c->viewLists);
+        c->viewLists = nullptr;
+        c->viewListsSize = 0;
+        VH_HIP(hipMalloc((void **)&c->viewLists, need * sizeof(int32_t)));
+        c->viewListsSize = need;
+    }
+    VH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)n_views, c->stream));
+    const uint32_t tiles = (uint32_t)((c->numEntries + kFlattenThreads * kEntriesPerLane - 1) /
+                                      (kFlattenThreads * kEntriesPerLane));
+    for (int32_t base = 0; base < n_views; base += kMaxViewsPerLaunch) {
+        const int32_t n = std::min<int32_t>(kMaxViewsPerLaunch, n_views - base);
+        ViewSet vs;
+        std::memset(&vs, 0, sizeof vs);
+        for (int32_t v = 0; v < n; ++v) make_view_frustum(c, poses + 16 * (size_t)(base + v), t_min, t_max, vs.v[v].f);
+        const int rc = launch(c, kPhaseViewExport, view_select_kernel, dim3(tiles), dim3(kFlattenThreads), c->fp, c->dp,
+                              (uint32_t)c->numEntries, vs, n, c->viewLists + (size_t)base * capacity, capacity,
+                              d_counts + base);
+        if (rc != VH_OK) return rc;
+    }
+    const int rc = launch(c, kPhaseViewExport, view_pack_kernel, dim3((unsigned)std::min<int32_t>(capacity, 2048), n_views),
+                          dim3(256), c->dp, (const int32_t *)c->viewLists, (const int32_t *)d_counts, capacity,
+                          reinterpret_cast<uint8_t *>(d_records));
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_import_view(vh_context *c, const vh_view_record *d_records, int32_t count)
+{
+    if (!c || (!d_records && count > 0)) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (count < 0 || (size_t)count > c->numEntries || (uint64_t)count * kViewRecordVoxels + 514ull > 0x7fffffffull)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad record count");
+    if (c->fp.bucketLo != 0 || c->fp.bucketHi != c->fp.numBuckets)
+        return fail(VH_ERR_INVALID_ARGUMENT, "a view table is unsharded");
+    if (c->fp.epoch != 0) return fail(VH_ERR_INVALID_ARGUMENT, "this context has integrated frames: use a dedicated view context");
+    DeviceGuard guard(c->device);
+    if (c->viewCount > 0) {
+        const int rc = launch(c, kPhaseViewImport, view_clear_kernel, dim3((unsigned)grid_for((size_t)c->viewCount, 256)),
+                              dim3(256), c->fp, c->dp, c->viewCount);
+        if (rc != VH_OK) return rc;
+    }
+    VH_HIP(hipMemsetAsync(c->dp.bucketBits, 0, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32), c->stream));
+    VH_HIP(hipMemsetAsync(c->dp.macroBits, 0, kMacroBits / 8, c->stream));
+    c->viewBlocks = reinterpret_cast<const Voxel *>(d_records);
+    c->viewCount = count;
+    if (count > 0) {
+        const int rc = launch(c, kPhaseViewImport, view_import_kernel, dim3((unsigned)grid_for((size_t)count, 256)),
+                              dim3(256), c->fp, c->dp, reinterpret_cast<const uint8_t *>(d_records), count);
+        if (rc != VH_OK) return rc;
+    }
     VH_HIP(hipGetLastError());
     return VH_OK;
 }
@@ -1018,6 +1114,8 @@ extern "C" int vh_get_kernel_times(vh_context *c, vh_kernel_times *out, int rese
             case kPhaseRaycast: c->times.raycast_ms += ms; c->times.raycast_launches += 1; break;
             case kPhaseFrameScanClaim: c->times.frame_scan_claim_ms += ms; break;
             case kPhaseFrameCommitIntegrate: c->times.frame_commit_integrate_ms += ms; break;
+            case kPhaseViewExport: c->times.view_export_ms += ms; break;
+            case kPhaseViewImport: c->times.view_import_ms += ms; break;
             default: break;
         }
     }

@@ -14,6 +14,7 @@
 //   vh_shard.hip       the multi-camera frame on a bucket-range shard
 //   vh_raycast.hip     per-pixel march through the hash (stand-in for SDFRenderer::render,
 //                      SDFRenderer.cpp:210-255)
+//   vh_view.hip       raycast over shards: export of the blocks a view can touch, view table import
 //   vh_preprocess.hip  depth -> vertex / normal maps (preProcess, CameraTrackingUtils.cu:50-120),
 //                      table set-up kernels (VoxelUtils.cu:151-166), device-side test hook
 //
@@ -27,4 +28,5 @@
 #include "vh_frame.hip"
 #include "vh_shard.hip"
 #include "vh_raycast.hip"
+#include "vh_view.hip"
 #include "vh_preprocess.hip"

@@ -1,0 +1,141 @@
+// vh_view.hip -- raycast over bucket-range shards: every shard hands the blocks a view can
+// touch to the rank that renders the view, which raycasts a private "view table" holding
+// exactly those blocks (SURVEY.md 8(e) "replicate the compact table + visible blocks").
+// Part of libvoxelhash_hip.so (gfx950); included by vh_kernels.hip after vh_device.h.
+#pragma once
+
+namespace vh {
+
+constexpr int kMaxViewsPerLaunch = 16;
+constexpr int kViewRecordBytes = 4112;                 // {int32 pos[3], 0, 512 x {sdf, weight}}
+constexpr int kViewRecordVoxels = kViewRecordBytes / 8;
+
+// Prepared on the host (vh_api.hip make_view_frustum; oracle: vho_view_frustum):
+// f[0..11] rows 0..2 of world->camera, f[12..15] plane slopes (left, right, top, bottom),
+// f[16..19] their thresholds -(r*sqrt(1+a^2)), f[20] zLo, f[21] zHi.
+struct ViewFrustum { float f[22]; };
+struct ViewSet { ViewFrustum v[kMaxViewsPerLaunch]; };
+
+// Conservative test "a ray of the view can sample a voxel of block pos": block centre within
+// 7 voxels (> the 6.93-voxel half diagonal) of every bounding plane of the view pyramid.
+// Same operations in the same order as the oracle's vho_view_holds_block.
+__device__ __forceinline__ bool view_holds_block(const FrameParams &fp, const float *__restrict__ f, const int *pos)
+{
+    float c[3], pc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = ((float)(int)((uint32_t)pos[a] * 8u) + 3.5f) * fp.voxelSize;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pc[r] = f[4 * r + 0] * c[0] + f[4 * r + 1] * c[1] + f[4 * r + 2] * c[2] + f[4 * r + 3];
+    if (!(pc[2] >= f[20] && pc[2] <= f[21])) return false;
+    if (!(pc[0] - f[12] * pc[2] >= f[16])) return false;
+    if (!(f[13] * pc[2] - pc[0] >= f[17])) return false;
+    if (!(pc[1] - f[14] * pc[2] >= f[18])) return false;
+    if (!(f[15] * pc[2] - pc[1] >= f[19])) return false;
+    return true;
+}
+
+// One walk over the shard's entries for up to 16 views (the same strided ptr-dword stream as
+// the flatten walk): a live entry is tested against every view and its index appended to the
+// list of each view that holds it (one atomic per wave and view that has hits).
+__global__ __launch_bounds__(kFlattenThreads) void view_select_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                      uint32_t numEntries, const ViewSet vs,
+                                                                      int32_t numViews, int32_t *__restrict__ lists,
+                                                                      int32_t capacity, int32_t *__restrict__ counts)
+{
+    const uint32_t tile = blockIdx.x * (kFlattenThreads * kEntriesPerLane);
+    const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
+    int32_t ptrs[kEntriesPerLane];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) {
+        const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
+        ptrs[j] = (e < numEntries) ? words[(size_t)e * kEntryDwords + 3] : VH_FREE_BLOCK;
+        any |= ptrs[j] != VH_FREE_BLOCK;
+    }
+    if (__ballot(any) == 0ull) return;
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int j = 0; j < kEntriesPerLane; ++j) {
+        const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
+        uint32_t seen = 0;
+        if (ptrs[j] != VH_FREE_BLOCK) {
+            const VoxelEntry ent = dp.table[e];
+            for (int v = 0; v < numViews; ++v)
+                if (view_holds_block(fp, vs.v[v].f, ent.pos)) seen |= 1u << v;
+        }
+        if (__ballot(seen != 0u) == 0ull) continue;
+        for (int v = 0; v < numViews; ++v) {
+            const bool hit = (seen >> v) & 1u;
+            const unsigned long long mask = __ballot(hit);
+            if (mask == 0ull) continue;
+            int base = 0;
+            const int leaderLane = __ffsll((long long)mask) - 1;
+            if (lane == leaderLane) base = atomicAdd(counts + v, __popcll(mask));
+            base = __shfl(base, leaderLane);
+            const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+            if (hit && slot < capacity) lists[(size_t)v * capacity + slot] = (int32_t)e;
+        }
+    }
+}
+
+// Records of view v follow those of views 0..v-1 without gaps (the caller sends them with
+// per-destination counts); blockIdx.y = view, workgroups stride over its selected entries and
+// copy key + 4 KiB of voxels, 16 bytes per lane.
+__global__ __launch_bounds__(256) void view_pack_kernel(const DevPtrs dp, const int32_t *__restrict__ lists,
+                                                        const int32_t *__restrict__ counts, int32_t capacity,
+                                                        uint8_t *__restrict__ records)
+{
+    const int v = blockIdx.y;
+    size_t first = 0;
+    for (int u = 0; u < v; ++u) first += (size_t)min(counts[u], capacity);
+    const int n = min(counts[v], capacity);
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        const VoxelEntry e = dp.table[lists[(size_t)v * capacity + b]];
+        uint8_t *rec = records + (first + (size_t)b) * kViewRecordBytes;
+        if (threadIdx.x == 0) *reinterpret_cast<int4 *>(rec) = make_int4(e.pos[0], e.pos[1], e.pos[2], 0);
+        reinterpret_cast<float4 *>(rec + 16)[threadIdx.x] =
+            reinterpret_cast<const float4 *>(dp.blocks + (size_t)e.ptr)[threadIdx.x];
+    }
+}
+
+// View table: the buckets the previous import touched (list in compactMask) go back to empty.
+__global__ __launch_bounds__(256) void view_clear_kernel(const FrameParams fp, const DevPtrs dp, int32_t prevCount)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= prevCount) return;
+    const uint32_t h = dp.compactMask[i];
+    VoxelEntry free_;
+    free_.pos[0] = free_.pos[1] = free_.pos[2] = VH_POS_SENTINEL;
+    free_.ptr = VH_FREE_BLOCK;
+    free_.offset = 0;
+    for (uint32_t s = 0; s < fp.bucketSize; ++s) dp.table[(size_t)h * fp.bucketSize + s] = free_;
+    dp.claim[h] = 0ull;
+}
+
+// Record i becomes an entry of its bucket (slots are handed out by a per-bucket fill count kept
+// in the otherwise unused claim word, so the entries of a bucket form a prefix, which
+// lookup_block relies on); ptr addresses the voxels inside the record buffer itself.
+__global__ __launch_bounds__(256) void view_import_kernel(const FrameParams fp, const DevPtrs dp,
+                                                          const uint8_t *__restrict__ records, int32_t count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const int4 k = *reinterpret_cast<const int4 *>(records + (size_t)i * kViewRecordBytes);
+    const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
+    dp.compactMask[i] = h;
+    const uint32_t slot = atomicAdd(reinterpret_cast<unsigned int *>(dp.claim + h), 1u);
+    if (slot >= fp.bucketSize) {
+        atomicAdd(dp.counters + kBinOverflow, 1);
+        return;
+    }
+    VoxelEntry e;
+    e.pos[0] = k.x; e.pos[1] = k.y; e.pos[2] = k.z;
+    e.ptr = i * kViewRecordVoxels + 2;
+    e.offset = 0;
+    dp.table[(size_t)h * fp.bucketSize + slot] = e;
+    atomicOr(dp.bucketBits + (h >> 5), 1u << (h & 31u));
+    const uint32_t hm = macro_hash(k.x >> 2, k.y >> 2, k.z >> 2);
+    atomicOr(dp.macroBits + (hm >> 5), 1u << (hm & 31u));
+}
+
+}  // namespace vh

@@ -118,6 +118,20 @@ class SDFHashtable:
         L.check(self._lib.vh_raycast(self._h, pp, t_min, t_max, _dev_ptr(out)), "vh_raycast")
         return out
 
+    # ---- raycast over shards (DESIGN.md section 6 "raycast") ----
+    VIEW_RECORD_BYTES = 4112
+
+    def export_views(self, poses, records, capacity: int, counts, t_min: float = 0.1, t_max: float = 5.0):
+        """poses: [n][16] host; records: device uint8 [n*capacity, 4112]; counts: device int32 [n]."""
+        p = np.ascontiguousarray(np.asarray(poses, np.float32).reshape(-1, 16))
+        L.check(self._lib.vh_export_views(self._h, p.ctypes.data_as(C.POINTER(C.c_float)), p.shape[0], t_min, t_max,
+                                          _dev_ptr(records), capacity, _dev_ptr(counts)), "vh_export_views")
+
+    def import_view(self, records, count: int):
+        """Make this dedicated, unsharded context hold exactly records[:count] (voxels stay in `records`)."""
+        self._view_records = records            # keep the buffer alive while the table points into it
+        L.check(self._lib.vh_import_view(self._h, _dev_ptr(records), int(count)), "vh_import_view")
+
     # ---- step-level entry points (VoxelUtils.h:5-13) ----
     def set_pose(self, pose):
         _, pp = _pose16(pose)
