@@ -130,6 +130,9 @@ def lib():
         L.vho_export_view.restype = C.c_int
         L.vho_import_view.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.vho_import_view.restype = C.c_int
+        L.vho_view_frustum.argtypes = [C.c_void_p, fp, C.c_float, C.c_float, fp]
+        L.vho_view_holds_block.argtypes = [C.c_void_p, fp, ip]
+        L.vho_view_holds_block.restype = C.c_int
         _lib = L
     return _lib
 
@@ -307,6 +310,16 @@ class OracleTable:
         rec = np.zeros((max(1, capacity), self.VIEW_RECORD_BYTES), np.uint8)
         n = int(lib().vho_export_view(self._h, _fptr(pose), t_min, t_max, rec.ctypes.data, capacity))
         return rec[:min(n, capacity)], n
+
+    def view_frustum(self, pose, t_min: float = 0.1, t_max: float = 5.0) -> np.ndarray:
+        pose = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
+        f = np.zeros(22, np.float32)
+        lib().vho_view_frustum(self._h, _fptr(pose), t_min, t_max, _fptr(f))
+        return f
+
+    def view_holds_block(self, frustum, block) -> bool:
+        a = (C.c_int32 * 3)(*[int(c) for c in block])
+        return bool(lib().vho_view_holds_block(self._h, _fptr(frustum), a))
 
     def import_view(self, records) -> int:
         """Make this (otherwise unused, unsharded) table hold exactly `records`; returns the drops."""

@@ -78,26 +78,16 @@ def test_export_equals_oracle_export(oracle, vh, torch_cuda):
         for v, pose in enumerate(poses):
             got = rec[first:first + counts[v]]
             first += counts[v]
-            got_map = {tuple(g[:12].view(np.int32)): g[16:].tobytes() for g in got}
+            got_map = {tuple(int(c) for c in g[:12].view(np.int32)): g[16:].tobytes() for g in got}
             assert len(got_map) == counts[v]
             # oracle selection over the same shard content (downloaded from the GPU shard)
             table = sh.table.hash_table()
             blocks = sh.table.sdf_blocks()
             want = {}
-            import ctypes as C
-            f = np.zeros(22, np.float32)
-            L = oracle.lib()
-            L.vho_view_frustum.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_float, C.POINTER(C.c_float)]
-            L.vho_view_holds_block.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
-            L.vho_view_holds_block.restype = C.c_int
-            p16 = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
-            L.vho_view_frustum(oshards[r]._h, p16.ctypes.data_as(C.POINTER(C.c_float)), 0.1, 5.0,
-                               f.ctypes.data_as(C.POINTER(C.c_float)))
+            f = oshards[r].view_frustum(pose)
             for e in table[table["ptr"] != -1]:
-                key = np.ascontiguousarray(e["pos"], np.int32)
-                if L.vho_view_holds_block(oshards[r]._h, f.ctypes.data_as(C.POINTER(C.c_float)),
-                                          key.ctypes.data_as(C.POINTER(C.c_int32))):
-                    want[tuple(key)] = blocks[int(e["ptr"]):int(e["ptr"]) + 512].tobytes()
+                if oshards[r].view_holds_block(f, e["pos"]):
+                    want[tuple(int(c) for c in e["pos"])] = blocks[int(e["ptr"]):int(e["ptr"]) + 512].tobytes()
             assert got_map == want
             assert len(want) > 20
 

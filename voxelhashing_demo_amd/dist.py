@@ -89,21 +89,25 @@ class TorchDistTransport:
         self.all_gather_packets(mine, out)
         return out.cpu().numpy()
 
-    def exchange_view_records(self, send, send_counts, recv):
-        """send: [sum(send_counts), 4112] uint8, records for view (= rank) 0 first; returns what each
-        source sent here, their records land in `recv` in source order.  The counts are exchanged
-        first (one small all-to-all) because the payload all-to-all needs them on the host."""
+    def exchange_view_records(self, send, counts, capacity, recv):
+        """send: packed records [*, 4112] uint8, view (= rank) 0's first; counts: [world] int32 selected
+        per view, on the same device (more than `capacity` means the excess was not written).  The
+        clipped counts are exchanged first (one small all-to-all; the payload all-to-all needs them on
+        the host: the only synchronisation of the round).  Records land in `recv` in source order.
+        Returns (recv_counts, lost)."""
         import torch
-        sc = torch.tensor(send_counts, dtype=torch.int64, device=self._device())
+        sc = torch.clamp(counts, max=capacity).to(torch.int64)
         rc = torch.empty_like(sc)
         self.dist.all_to_all_single(rc, sc, group=self.group)
-        recv_counts = [int(x) for x in rc.cpu().tolist()]
+        host = torch.stack([counts.to(torch.int64), sc, rc]).cpu()
+        send_counts, recv_counts = host[1].tolist(), host[2].tolist()
+        lost = int((host[0] - host[1]).sum())
         n_in, n_out = sum(send_counts), sum(recv_counts)
         if n_out > recv.shape[0]:
             raise RuntimeError(f"view receive buffer holds {recv.shape[0]} records, {n_out} arrive")
         self.dist.all_to_all_single(recv[:n_out], send[:n_in], output_split_sizes=recv_counts,
-                                    input_split_sizes=list(send_counts), group=self.group)
-        return recv_counts
+                                    input_split_sizes=send_counts, group=self.group)
+        return recv_counts, lost
 
 
 class LoopbackExchange:
@@ -326,9 +330,8 @@ def sharded_raycast(shard, view, transport: TorchDistTransport, pose, capacity: 
     the image may miss surfaces (raise the capacity)."""
     poses = transport.all_gather_poses(pose)
     records, counts = shard.export_views(poses, capacity, t_min, t_max)
-    sent, lost = _clip_counts(counts, capacity)
-    recv_counts = transport.exchange_view_records(records, sent, view.recv)
-    return view.render(sum(recv_counts), pose, t_min, t_max), sum(lost)
+    recv_counts, lost = transport.exchange_view_records(records, counts, capacity, view.recv)
+    return view.render(sum(recv_counts), pose, t_min, t_max), lost
 
 
 def loopback_raycast(shards, views, poses, capacity: int, t_min: float = 0.1, t_max: float = 5.0):
@@ -531,9 +534,33 @@ def bench_sharded(args, wl, rank, world, local_rank):
         drain()
         kt = shard.table.kernel_times(reset=True)
         shard.table.set_profiling(False)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+
+        # raycast over the shards: every rank renders its own camera's view of the whole table
+        view_cap = 8192
+        view = HipViewTable(params, Wd, Ht, SEM_PINHOLE, world, view_cap, device=dev, stream=stream)
+        rc_iters, lost_total = 20, 0
+        for i in range(2):
+            sharded_raycast(shard, view, transport, poses[i], view_cap)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(rc_iters):
+            _, lost = sharded_raycast(shard, view, transport, poses[(7 * i) % nframes], view_cap)
+            lost_total += lost
+        torch.cuda.synchronize()
+        dist.barrier()
+        rc_elapsed = time.perf_counter() - t1
+        shard.table.set_profiling(True)
+        view.table.set_profiling(True)
+        for i in range(3):
+            sharded_raycast(shard, view, transport, poses[(7 * i) % nframes], view_cap)
+        torch.cuda.synchronize()
+        kte, ktv = shard.table.kernel_times(reset=True), view.table.kernel_times(reset=True)
+        shard.table.set_profiling(False)
+        view.table.set_profiling(False)
+    t = torch.tensor([elapsed, rc_elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, rc_elapsed = float(t[0].item()), float(t[1].item())
     c = shard.table.counters()
     stats = torch.tensor([c["occupied"], c["allocated_total"], c["bin_overflow"]], dtype=torch.int64, device=dev)
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
@@ -561,7 +588,17 @@ def bench_sharded(args, wl, rank, world, local_rank):
                         resident_frames=nframes, key_bin_capacity=capacity, pipelined=pipelined,
                         occupied_blocks_all_ranks=int(stats[0]), allocated_blocks_all_ranks=int(stats[1]),
                         key_bin_overflows=int(stats[2])),
-            roofline=roofline, cpu_baseline=None)
+            roofline=roofline, cpu_baseline=None,
+            sharded_raycast=dict(
+                mpix_per_s=round(world * rc_iters * Wd * Ht / rc_elapsed / 1e6, 1), views_per_round=world,
+                ms_per_round=round(1e3 * rc_elapsed / rc_iters, 4), lost_records=lost_total,
+                record_capacity_per_shard_and_view=view_cap,
+                rank0_export_us=round(1e3 * kte["view_export_ms"] / 3, 2),
+                rank0_import_us=round(1e3 * ktv["view_import_ms"] / 3, 2),
+                rank0_raycast_us=round(1e3 * ktv["raycast_ms"] / max(1, ktv["raycast_launches"]), 2),
+                note="every rank renders its own camera's view of the whole table: one walk of its shard for "
+                     "all views, all-to-all of {key, 512 voxels} records, import into a view table, raycast; "
+                     "bit-equal to a raycast of the unsharded table"))
         print(json.dumps(out))
     shard.table.close()
     dist.destroy_process_group()
