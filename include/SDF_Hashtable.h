@@ -52,6 +52,10 @@ public:
     void unmapCUDApointers() {}
 
     int occupiedBlockCount();                          /* synchronises */
+    /* README.md:15 lists deletion as a feature; the reference's deleteVoxelEntry
+     * (VoxelUtils.cu:544-604) is never called.  Frees every block the last frame saw that holds
+     * nothing within sdfThreshold of a surface (vh_garbage_collect). */
+    void garbageCollect(float sdfThreshold);
     void setStream(void *hipStream);
     vh_context *context() { return ctx_; }
     const HashTableParams &params() const { return h_hashtableParams; }

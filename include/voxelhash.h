@@ -122,6 +122,8 @@ typedef struct vh_counters {
     uint32_t candidates;        /* contenders recorded by the last allocBlocks */
     uint32_t epoch;             /* bucket-lock epoch (= frames since creation) */
     uint32_t bin_overflow;      /* received key bins that exceeded their capacity (keys lost) */
+    uint32_t freed_total;       /* blocks returned to the heap since creation (deletion / GC) */
+    uint32_t last_freed;        /* ... by the last vh_delete_blocks / vh_garbage_collect */
 } vh_counters;
 
 /* per-kernel device time, accumulated while profiling is on (HIP events on
@@ -138,6 +140,8 @@ typedef struct vh_kernel_times {
     double   frame_commit_integrate_ms;  /* fused vh_integrate, launch 2: commit + TSDF update */
     double   view_export_ms;             /* vh_export_views: select walk + record packing */
     double   view_import_ms;             /* vh_import_view: clear + insert */
+    double   gc_ms;                      /* vh_delete_blocks / vh_garbage_collect, all launches */
+    uint64_t gc_calls;
 } vh_kernel_times;
 
 typedef struct vh_context vh_context;
@@ -301,6 +305,26 @@ int vh_export_views(vh_context *ctx, const float *poses, int32_t n_views, float 
  * are dropped and counted in vh_counters.bin_overflow (never happens for records exported
  * from one logical table of the same geometry). */
 int vh_import_view(vh_context *view, const vh_view_record *d_records, int32_t count);
+
+/* ------------------------------------------------------------------ */
+/* block deletion / garbage collection         */
+/* ------------------------------------------------------------------ */
+/* The reference lists deletion as a feature (README.md:15) but deleteVoxelEntry
+ * (VoxelUtils.cu:544-604) is never called and frees the block of the first FREE slot it
+ * meets.  Built as the paper does it (Niessner et al. 2013, 4.4), asynchronous on the context's
+ * stream, in its own lock epoch:
+ *   vh_delete_blocks: for each key {x,y,z,_} (device, n records of 4 int32) present in this
+ *     table (shard): the 512 voxels are zeroed, ptr/512 goes back on the heap
+ *     (removeSingleBlockInHeap, :336-341), the entry is removed and the later entries of its
+ *     bucket move down in order (a bucket's entries stay a prefix of its slots, which
+ *     insertVoxelEntry :421-456 and every lookup rely on).  Absent keys are skipped.
+ *   vh_garbage_collect: the same for every entry of the compact list (the blocks the last frame
+ *     saw) whose voxels have max weight == 0, or min |sdf| over the voxels with weight > 0
+ *     >= sdf_threshold.
+ * Both leave the compact list empty (occupied = 0 until the next frame); vh_counters.last_freed
+ * / freed_total report what was freed. */
+int vh_delete_blocks(vh_context *ctx, const int32_t *d_keys, int32_t n);
+int vh_garbage_collect(vh_context *ctx, float sdf_threshold);
 
 /* ------------------------------------------------------------------ */
 /* model dump / checkpoint                     */

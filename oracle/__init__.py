@@ -95,7 +95,7 @@ def lib():
         L.vho_raycast.argtypes = [C.c_void_p, fp, C.c_float, C.c_float, fp]
         L.vho_get_params.restype = C.POINTER(Params)
         L.vho_get_params.argtypes = [C.c_void_p]
-        for name in ("vho_hash_table", "vho_compact_table", "vho_sdf_blocks"):
+        for name in ("vho_hash_table", "vho_compact_table", "vho_sdf_blocks", "vho_heap"):
             getattr(L, name).restype = C.c_void_p
             getattr(L, name).argtypes = [C.c_void_p]
         L.vho_compact_count.argtypes = [C.c_void_p]
@@ -126,6 +126,10 @@ def lib():
         L.vho_integrate_packets.argtypes = [C.c_void_p, C.c_int, fp]
         L.vho_integrate_packets.restype = C.c_int
         L.vho_preprocess.argtypes = [C.POINTER(C.c_uint16), fp, C.c_int, C.c_int, fp, fp]
+        L.vho_delete_blocks.argtypes = [C.c_void_p, ip, C.c_int]
+        L.vho_delete_blocks.restype = C.c_int
+        L.vho_garbage_collect.argtypes = [C.c_void_p, C.c_float]
+        L.vho_garbage_collect.restype = C.c_int
         L.vho_export_view.argtypes = [C.c_void_p, fp, C.c_float, C.c_float, C.c_void_p, C.c_int]
         L.vho_export_view.restype = C.c_int
         L.vho_import_view.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -301,6 +305,16 @@ class OracleTable:
         lib().vho_raycast(self._h, _fptr(pose), t_min, t_max, _fptr(out))
         return out
 
+    # ---- deletion / garbage collection ----
+    def delete_blocks(self, keys) -> int:
+        k = np.zeros((len(keys), 4), np.int32)
+        if len(keys):
+            k[:, :3] = np.asarray(keys, np.int32).reshape(-1, 3)
+        return int(lib().vho_delete_blocks(self._h, k.ctypes.data_as(C.POINTER(C.c_int32)), len(keys)))
+
+    def garbage_collect(self, sdf_threshold: float) -> int:
+        return int(lib().vho_garbage_collect(self._h, float(sdf_threshold)))
+
     # ---- raycast over shards: view records are uint8 [count, 4112] = {pos[3], 0, 512 voxels} ----
     VIEW_RECORD_BYTES = 4112
 
@@ -355,6 +369,14 @@ class OracleTable:
 
     def heap_counter(self) -> int:
         return int(lib().vho_heap_counter(self._h))
+
+    def heap(self) -> np.ndarray:
+        n = self.params.numVoxelBlocks
+        buf = (C.c_char * (n * 4)).from_address(lib().vho_heap(self._h))
+        return np.frombuffer(buf, dtype=np.uint32, count=n)
+
+    def compact_count(self) -> int:
+        return int(lib().vho_compact_count(self._h))
 
     def allocated(self) -> np.ndarray:
         t = self.hash_table()

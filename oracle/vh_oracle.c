@@ -598,6 +598,83 @@ void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max, f
 }
 
 /* ------------------------------------------------------------------ */
+/* block deletion / garbage collection (build extension, SURVEY.md      */
+/* 8(f) next #4; DESIGN.md "deletion")                                  */
+/* ------------------------------------------------------------------ */
+/* The reference's deleteVoxelEntry (VoxelUtils.cu:544-604) is unreachable and frees the
+ * block of the first FREE slot it meets; its heap push is removeSingleBlockInHeap
+ * (:336-341).  Built "done correctly" as the paper the demo follows does it (Niessner et
+ * al. 2013, section 4.4 "garbage collection"):
+ *   - delete(key): find the entry of `key` in its bucket; zero its 512 voxels (blocks are
+ *     handed out zeroed); push ptr/512 on the heap (:339-340); remove the
+ *     entry and close the gap by moving the later entries of the bucket down in order, so
+ *     a bucket's entries stay a prefix of its slots (insertVoxelEntry :421-456 stops at the
+ *     first free slot; with a hole before an entry it would insert a duplicate);
+ *   - collect(threshold): every entry of the compact list (the blocks the last flatten saw)
+ *     whose voxels have max weight == 0, or min |sdf| over the voxels with weight > 0
+ *     >= threshold, is deleted.  The compact list is empty afterwards. */
+#define VHO_INF_F (__builtin_inff())
+
+static void free_entry_at(vho_table *t, uint32_t local_bucket, uint32_t slot)
+{
+    const uint32_t bs = t->p.bucketSize;
+    vho_entry *bucket = t->table + (size_t)local_bucket * bs;
+    const int32_t ptr = bucket[slot].ptr;
+    memset(t->blocks + ptr, 0, 512 * sizeof(vho_voxel));
+    t->heap[++t->heap_counter] = (uint32_t)(ptr / 512);              /* :338-340 */
+    uint32_t s = slot;
+    for (; s + 1 < bs && bucket[s + 1].ptr != VHO_FREE_BLOCK; ++s) bucket[s] = bucket[s + 1];
+    reset_entries(bucket + s, 1);
+}
+
+/* keys: n x {x,y,z,ignored}.  Returns the number of blocks freed (absent keys are skipped). */
+int vho_delete_blocks(vho_table *t, const int32_t *keys, int n)
+{
+    const uint32_t bs = t->p.bucketSize;
+    int freed = 0;
+    for (int i = 0; i < n; ++i) {
+        const int32_t *k = keys + 4 * (size_t)i;
+        const uint32_t hg = vho_hash(k[0], k[1], k[2], t->p.numBuckets);
+        if (hg < t->bucket_lo || hg >= t->bucket_hi) continue;
+        const uint32_t h = hg - t->bucket_lo;
+        for (uint32_t sl = 0; sl < bs; ++sl) {
+            const vho_entry *e = &t->table[(size_t)h * bs + sl];
+            if (e->ptr == VHO_FREE_BLOCK) break;
+            if (e->pos[0] == k[0] && e->pos[1] == k[1] && e->pos[2] == k[2]) {
+                free_entry_at(t, h, sl);
+                ++freed;
+                break;
+            }
+        }
+    }
+    t->compact_counter = 0;
+    return freed;
+}
+
+int vho_garbage_collect(vho_table *t, float sdf_threshold)
+{
+    const int n = t->compact_counter;
+    int32_t *keys = (int32_t *)malloc((size_t)(n > 0 ? n : 1) * 4 * sizeof(int32_t));
+    int m = 0;
+    for (int b = 0; b < n; ++b) {
+        const vho_entry *e = &t->compact[b];
+        float min_abs = VHO_INF_F, max_w = 0.0f;
+        for (int v = 0; v < 512; ++v) {
+            const vho_voxel x = t->blocks[e->ptr + v];
+            if (x.weight > 0.0f) min_abs = fminf(min_abs, fabsf(x.sdf));
+            max_w = fmaxf(max_w, x.weight);
+        }
+        if (max_w == 0.0f || min_abs >= sdf_threshold) {
+            keys[4 * m + 0] = e->pos[0]; keys[4 * m + 1] = e->pos[1]; keys[4 * m + 2] = e->pos[2]; keys[4 * m + 3] = 0;
+            ++m;
+        }
+    }
+    const int freed = vho_delete_blocks(t, keys, m);
+    free(keys);
+    return freed;
+}
+
+/* ------------------------------------------------------------------ */
 /* raycast over shards: replicate the blocks a view can touch           */
 /* (build extension, DESIGN.md section 6 "raycast")     */
 /* ------------------------------------------------------------------ */
@@ -856,6 +933,7 @@ const vho_params *vho_get_params(const vho_table *t) { return &t->p; }
 vho_entry *vho_hash_table(vho_table *t) { return t->table; }
 vho_entry *vho_compact_table(vho_table *t) { return t->compact; }
 int vho_compact_count(const vho_table *t) { return t->compact_counter; }
+const uint32_t *vho_heap(const vho_table *t) { return t->heap; }
 vho_voxel *vho_sdf_blocks(vho_table *t) { return t->blocks; }
 int vho_heap_counter(const vho_table *t) { return t->heap_counter; }
 const vho_frame_stats *vho_last_stats(const vho_table *t) { return &t->stats; }

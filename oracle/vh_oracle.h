@@ -99,6 +99,10 @@ int  vho_integrate(vho_table *t, const float pose[16], const float *verts,
 void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max,
                  float *depth_out /* W*H */);
 
+/* ---- block deletion / garbage collection (build extension) ---- */
+int vho_delete_blocks(vho_table *t, const int32_t *keys /* n x {x,y,z,_} */, int n);
+int vho_garbage_collect(vho_table *t, float sdf_threshold);
+
 /* ---- raycast over shards (build extension): the blocks a view can
  * touch are gathered from the shards into a view table that raycasts like the whole ---- */
 #define VHO_VIEW_RECORD_BYTES 4112     /* {int32 pos[3], 0, 512 x {sdf, weight}} */
@@ -128,6 +132,7 @@ const vho_params *vho_get_params(const vho_table *t);
 vho_entry        *vho_hash_table(vho_table *t);      /* numBuckets*bucketSize entries */
 vho_entry        *vho_compact_table(vho_table *t);   /* first vho_compact_count valid */
 int               vho_compact_count(const vho_table *t);
+const uint32_t   *vho_heap(const vho_table *t);      /* numVoxelBlocks ids, [0, heap_counter] free */
 vho_voxel        *vho_sdf_blocks(vho_table *t);      /* numVoxelBlocks*512 voxels */
 int               vho_heap_counter(const vho_table *t);
 const vho_frame_stats *vho_last_stats(const vho_table *t);

@@ -51,6 +51,11 @@ void SDF_Hashtable::raycast(const float4x4 &pose, float *d_depth_out, float zNea
     check(vh_raycast(ctx_, pose.entries, zNear, zFar, d_depth_out), "raycast");
 }
 
+void SDF_Hashtable::garbageCollect(float sdfThreshold)
+{
+    check(vh_garbage_collect(ctx_, sdfThreshold), "garbageCollect");
+}
+
 int SDF_Hashtable::occupiedBlockCount()
 {
     vh_counters c;

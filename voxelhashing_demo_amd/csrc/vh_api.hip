@@ -47,7 +47,7 @@ static int fail(int code, const char *what, hipError_t e = hipSuccess)
 // hipEventRecord pair would add.
 enum Phase : int {
     kPhaseClaim = 0, kPhaseCommit, kPhaseFlatten, kPhaseIntegrate, kPhaseRaycast,
-    kPhaseFrameScanClaim, kPhaseFrameCommitIntegrate, kPhaseViewExport, kPhaseViewImport, kNumPhases
+    kPhaseFrameScanClaim, kPhaseFrameCommitIntegrate, kPhaseViewExport, kPhaseViewImport, kPhaseGc, kNumPhases
 };
 
 struct TimedLaunch {
@@ -637,6 +637,49 @@ extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, floa
 }
 
 // ---------------------------------------------------------------------------
+// block deletion / garbage collection
+// ---------------------------------------------------------------------------
+static int sweep_and_release(vh_context *c)
+{
+    int rc = launch(c, kPhaseGc, gc_sweep_kernel, dim3(256), dim3(256), c->fp, c->dp);
+    if (rc != VH_OK) return rc;
+    rc = launch(c, kPhaseGc, gc_release_kernel, dim3(1024), dim3(256), c->dp);
+    if (rc != VH_OK) return rc;
+    rc = launch(c, kPhaseGc, gc_finish_kernel, dim3(1), dim3(1), c->dp, c->occupiedCounter);
+    if (rc != VH_OK) return rc;
+    if (c->profiling) c->times.gc_calls += 1;
+    c->params.numOccupiedBlocks = 0;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_delete_blocks(vh_context *c, const int32_t *d_keys, int32_t n)
+{
+    if (!c || (!d_keys && n > 0) || n < 0) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table owns no blocks");
+    DeviceGuard guard(c->device);
+    c->fp.epoch += 1;                       // the sweep list is built under a fresh lock epoch
+    if (n > 0) {
+        const int rc = launch(c, kPhaseGc, gc_mark_keys_kernel, dim3((unsigned)grid_for((size_t)n, 256)), dim3(256), c->fp,
+                              c->dp, reinterpret_cast<const int4 *>(d_keys), n);
+        if (rc != VH_OK) return rc;
+    }
+    return sweep_and_release(c);
+}
+
+extern "C" int vh_garbage_collect(vh_context *c, float sdf_threshold)
+{
+    if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table owns no blocks");
+    DeviceGuard guard(c->device);
+    c->fp.epoch += 1;
+    const int rc = launch(c, kPhaseGc, gc_identify_kernel, dim3(2048), dim3(256), c->fp, c->dp, c->occupiedCounter,
+                          sdf_threshold);
+    if (rc != VH_OK) return rc;
+    return sweep_and_release(c);
+}
+
+// ---------------------------------------------------------------------------
 // raycast over shards: export of the blocks a view can touch, import into a view table
 // ---------------------------------------------------------------------------
 // oracle: vho_view_frustum (same operations in the same order)
@@ -889,6 +932,8 @@ extern "C" int vh_get_counters(vh_context *c, vh_counters *out)
     out->candidates = (uint32_t)h[kLastCandidates];
     out->epoch = c->fp.epoch;
     out->bin_overflow = (uint32_t)h[kBinOverflow];
+    out->freed_total = (uint32_t)h[kFreedTotal];
+    out->last_freed = (uint32_t)h[kLastFreed];
     c->params.numOccupiedBlocks = (uint32_t)h[c->occupiedCounter];
     return VH_OK;
 }
@@ -1116,6 +1161,7 @@ extern "C" int vh_get_kernel_times(vh_context *c, vh_kernel_times *out, int rese
             case kPhaseFrameCommitIntegrate: c->times.frame_commit_integrate_ms += ms; break;
             case kPhaseViewExport: c->times.view_export_ms += ms; break;
             case kPhaseViewImport: c->times.view_import_ms += ms; break;
+            case kPhaseGc: c->times.gc_ms += ms; break;
             default: break;
         }
     }

@@ -35,7 +35,12 @@ enum Counter : int {
     kScanCount = 8,        // [2] entries found by the table walk
     kNewCount = 10,        // [2] entries inserted (and appended) by the commit phase
     kFusedCand = 12,       // [2] contenders recorded by the claim phase
-    kNumCounters = 16
+    // deletion / garbage collection (vh_gc.hip)
+    kGcBuckets = 14,       // buckets on the sweep list of the running collection
+    kGcFreed = 15,         // blocks on its freed list
+    kFreedTotal = 16,      // blocks returned to the heap since creation
+    kLastFreed = 17,       // ... by the last vh_delete_blocks / vh_garbage_collect
+    kNumCounters = 24
 };
 
 // Everything a kernel needs about the frame, passed by value in the kernel

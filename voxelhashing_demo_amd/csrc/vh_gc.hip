@@ -1,0 +1,135 @@
+// vh_gc.hip -- block deletion and garbage collection.
+// The reference's deleteVoxelEntry (VoxelUtils.cu:544-604) is unreachable and frees the block
+// of the first FREE slot it meets; removeSingleBlockInHeap (:336-341) is its heap push.  Built
+// as the paper the demo follows does it (Niessner et al. 2013, 4.4): identify the blocks of the
+// compact list that hold nothing near a surface, remove their entries, zero their voxels and
+// push them back on the heap.  Oracle: vho_delete_blocks / vho_garbage_collect.
+// Part of libvoxelhash_hip.so (gfx950); included by vh_kernels.hip after vh_device.h.
+#pragma once
+
+namespace vh {
+
+constexpr int kDeleteMark = 0x0044454c;      // VoxelEntry::offset of an entry due for deletion ("DEL")
+
+// Marks the entry of `key` and puts its bucket on the sweep list (once: the first marker of a
+// bucket in this epoch swaps the consumed word into the bucket's claim word).
+__device__ __forceinline__ void mark_for_deletion(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz)
+{
+    const uint32_t h = hash_block(kx, ky, kz, fp.numBuckets);
+    if (h < fp.bucketLo || h >= fp.bucketHi) return;
+    const uint32_t local = h - fp.bucketLo;
+    VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
+    for (uint32_t s = 0; s < fp.bucketSize; ++s) {
+        const VoxelEntry e = bucket[s];
+        if (e.ptr == VH_FREE_BLOCK) return;                     // entries form a prefix
+        if (e.pos[0] != kx || e.pos[1] != ky || e.pos[2] != kz) continue;
+        bucket[s].offset = kDeleteMark;                         // idempotent: a key listed twice is freed once
+        const unsigned long long tag = consumed_word(fp.epoch);
+        if (atomicExch(dp.claim + local, tag) != tag)
+            dp.compactMask[atomicAdd(dp.counters + kGcBuckets, 1)] = local;
+        return;
+    }
+}
+
+// deleteVoxelEntry for a list of keys {x,y,z,_}
+__global__ __launch_bounds__(256) void gc_mark_keys_kernel(const FrameParams fp, const DevPtrs dp,
+                                                           const int4 *__restrict__ keys, int32_t n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 k = keys[i];
+    mark_for_deletion(fp, dp, k.x, k.y, k.z);
+}
+
+// One compact entry per workgroup pass: max weight and min |sdf| over the observed voxels of
+// its block (16 bytes per lane, wave reduction, then across the four waves through LDS);
+// min/max are order independent, so the decision has the oracle's bits.
+__global__ __launch_bounds__(256) void gc_identify_kernel(const FrameParams fp, const DevPtrs dp, int countIndex,
+                                                          float threshold)
+{
+    __shared__ float sMin[4], sMax[4];
+    const int count = dp.counters[countIndex];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    for (int b = blockIdx.x; b < count; b += gridDim.x) {
+        const VoxelEntry e = dp.compact[b];
+        const float4 v = *reinterpret_cast<const float4 *>(dp.blocks + (size_t)e.ptr + 2 * threadIdx.x);
+        float mn = __builtin_inff(), mx = __builtin_fmaxf(v.y, v.w);
+        if (v.y > 0.0f) mn = __builtin_fminf(mn, __builtin_fabsf(v.x));
+        if (v.w > 0.0f) mn = __builtin_fminf(mn, __builtin_fabsf(v.z));
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            mn = __builtin_fminf(mn, __shfl_xor(mn, d));
+            mx = __builtin_fmaxf(mx, __shfl_xor(mx, d));
+        }
+        if (lane == 0) { sMin[wave] = mn; sMax[wave] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float m = __builtin_fminf(__builtin_fminf(sMin[0], sMin[1]), __builtin_fminf(sMin[2], sMin[3]));
+            const float w = __builtin_fmaxf(__builtin_fmaxf(sMax[0], sMax[1]), __builtin_fmaxf(sMax[2], sMax[3]));
+            if (w == 0.0f || m >= threshold) mark_for_deletion(fp, dp, e.pos[0], e.pos[1], e.pos[2]);
+        }
+        __syncthreads();
+    }
+}
+
+// One lane per listed bucket: marked entries leave (their ptr goes to the freed list, which
+// reuses the memory of the now stale compact list), the others move down in order so that the
+// bucket's entries stay a prefix of its slots; the vacated tail becomes free slots.
+__global__ __launch_bounds__(256) void gc_sweep_kernel(const FrameParams fp, const DevPtrs dp)
+{
+    const int n = dp.counters[kGcBuckets];
+    int32_t *freed = reinterpret_cast<int32_t *>(dp.compact);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t local = dp.compactMask[i];
+        VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
+        uint32_t w = 0, s = 0;
+        for (; s < fp.bucketSize; ++s) {
+            const VoxelEntry e = bucket[s];
+            if (e.ptr == VH_FREE_BLOCK) break;
+            if (e.offset == kDeleteMark) {
+                freed[atomicAdd(dp.counters + kGcFreed, 1)] = e.ptr;
+                continue;
+            }
+            if (w != s) bucket[w] = e;
+            ++w;
+        }
+        VoxelEntry none;
+        none.pos[0] = none.pos[1] = none.pos[2] = VH_POS_SENTINEL;
+        none.ptr = VH_FREE_BLOCK;
+        none.offset = 0;
+        for (uint32_t k = w; k < s; ++k) bucket[k] = none;
+        if (w == 0) atomicAnd(dp.bucketBits + (local >> 5), ~(1u << (local & 31u)));
+        // (the macro-cell bitmap is hashed and shared: a stale bit only makes a ray skip less)
+    }
+}
+
+// One freed block per workgroup pass: zero the 4 KiB (blocks are handed out zeroed) and push
+// the block id back on the heap (removeSingleBlockInHeap, VoxelUtils.cu:336-341).
+__global__ __launch_bounds__(256) void gc_release_kernel(const DevPtrs dp)
+{
+    const int n = dp.counters[kGcFreed];
+    const int32_t *freed = reinterpret_cast<const int32_t *>(dp.compact);
+    for (int b = blockIdx.x; b < n; b += gridDim.x) {
+        const int32_t ptr = freed[b];
+        reinterpret_cast<float4 *>(dp.blocks + (size_t)ptr)[threadIdx.x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (threadIdx.x == 0) {
+            const int addr = atomicAdd(dp.counters + kHeapCounter, 1);
+            dp.heap[addr + 1] = (uint32_t)ptr / (uint32_t)kBlockVoxels;
+        }
+    }
+}
+
+// Closes a collection: totals, and the per-call counters and the (now stale) compact count go
+// back to zero.
+__global__ void gc_finish_kernel(const DevPtrs dp, int countIndex)
+{
+    const int n = dp.counters[kGcFreed];
+    dp.counters[kFreedTotal] += n;
+    dp.counters[kLastFreed] = n;
+    dp.counters[kGcFreed] = 0;
+    dp.counters[kGcBuckets] = 0;
+    dp.counters[countIndex] = 0;
+    dp.counters[kCompactCount] = 0;
+}
+
+}  // namespace vh

@@ -14,7 +14,8 @@
 //   vh_shard.hip       the multi-camera frame on a bucket-range shard
 //   vh_raycast.hip     per-pixel march through the hash (stand-in for SDFRenderer::render,
 //                      SDFRenderer.cpp:210-255)
-//   vh_view.hip       raycast over shards: export of the blocks a view can touch, view table import
+//   vh_view.hip        raycast over shards: export of the blocks a view can touch, view table import
+//   vh_gc.hip          block deletion / garbage collection (deleteVoxelEntry :544-604 done correctly)
 //   vh_preprocess.hip  depth -> vertex / normal maps (preProcess, CameraTrackingUtils.cu:50-120),
 //                      table set-up kernels (VoxelUtils.cu:151-166), device-side test hook
 //
@@ -29,4 +30,5 @@
 #include "vh_shard.hip"
 #include "vh_raycast.hip"
 #include "vh_view.hip"
+#include "vh_gc.hip"
 #include "vh_preprocess.hip"

@@ -118,6 +118,15 @@ class SDFHashtable:
         L.check(self._lib.vh_raycast(self._h, pp, t_min, t_max, _dev_ptr(out)), "vh_raycast")
         return out
 
+    # ---- deletion / garbage collection ----
+    def delete_blocks(self, keys, n: int = None):
+        """keys: device int32 [n, 4] = {x, y, z, _}."""
+        n = int(keys.shape[0]) if n is None else int(n)
+        L.check(self._lib.vh_delete_blocks(self._h, _dev_ptr(keys), n), "vh_delete_blocks")
+
+    def garbage_collect(self, sdf_threshold: float):
+        L.check(self._lib.vh_garbage_collect(self._h, float(sdf_threshold)), "vh_garbage_collect")
+
     # ---- raycast over shards (DESIGN.md section 6 "raycast") ----
     VIEW_RECORD_BYTES = 4112
 
