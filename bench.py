@@ -53,6 +53,8 @@ def parse_args():
                     help="sharded path: frames per camera carried by one all-to-all / all-gather")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sharded path: do not overlap key generation + RCCL with the table work")
+    ap.add_argument("--sharded-raycast", action="store_true",
+                    help="sharded path: also time the raycast over the shards (always on with one rank)")
     ap.add_argument("--sharded", action="store_true",
                     help="force the bucket-range-sharded path (torch.distributed) even with one rank")
     return ap.parse_args()
@@ -201,6 +203,49 @@ def main():
     ray_s = time.perf_counter() - t1
     raycast_mpix = args.raycast_steps * Wd * Ht / ray_s / 1e6 if args.raycast_steps else None
 
+    # ---- kernel time of the raycast and of the next-row entry points (all timed regions are over) ----
+    table.set_profiling(True)
+    for i in range(5):
+        lib.vh_raycast(h, pose_ptrs[(7 * i) % nframes], 0.1, 5.0, dptr)
+    kt_r = table.kernel_times(reset=True)
+    raycast_us = 1e3 * kt_r["raycast_ms"] / max(1, kt_r["raycast_launches"])
+    # SURVEY.md 8(d) raycast work unit: every visible block and the output touched once
+    ray_bytes = (4096 + 20) * occ + 4 * Wd * Ht
+    raycast = dict(mpix_per_s=round(raycast_mpix, 1) if raycast_mpix else None, kernel_us=round(raycast_us, 2),
+                   kernel_mpix_per_s=round(Wd * Ht / raycast_us, 1) if raycast_us > 0 else None,
+                   algorithmic_bytes=ray_bytes,
+                   achieved_gbs=round(ray_bytes / (raycast_us * 1e-6) / 1e9, 1) if raycast_us > 0 else None,
+                   bound="valu issue (5.6k VALU instructions per wave against 66 memory reads, DESIGN.md 4.1): "
+                         "the byte rate is far below HBM by construction")
+    # depth pre-processing (next #1): uint16 depth -> vertex + normal maps, one fused kernel
+    depth_u16 = (verts[0, :, :, 2] * 5000.0).clamp(0, 65535).to(torch.uint16)
+    pos_out, nrm_out = torch.empty_like(verts[0]), torch.empty_like(verts[0])
+    k_inv = np.linalg.inv(synth.K_matrix(Wd, Ht).astype(np.float64)).astype(np.float32)
+    with torch.cuda.stream(stream):
+        for i in range(3):
+            V.preprocess(depth_u16, k_inv, pos_out, nrm_out, stream=stream)
+        stream.synchronize()
+        t3 = time.perf_counter()
+        for i in range(50):
+            V.preprocess(depth_u16, k_inv, pos_out, nrm_out, stream=stream)
+        stream.synchronize()
+        pre_us = 1e6 * (time.perf_counter() - t3) / 50
+    pre_bytes = (2 + 16 + 16) * Wd * Ht
+    # garbage collection (next #4) over the blocks the last frame saw; threshold 0 frees them all
+    step(0)
+    table.garbage_collect(0.0)
+    kt_g = table.kernel_times(reset=True)
+    gc_counters = table.counters()
+    table.set_profiling(False)
+    next_rows = dict(
+        preprocess=dict(us_per_frame=round(pre_us, 2), algorithmic_bytes=pre_bytes,
+                        achieved_gbs=round(pre_bytes / (pre_us * 1e-6) / 1e9, 1),
+                        note="vh_preprocess, back-to-back calls timed on the host (launch gaps included)"),
+        garbage_collect=dict(us_per_call=round(1e3 * kt_g["gc_ms"] / max(1, kt_g["gc_calls"]), 2),
+                             blocks_freed=gc_counters["last_freed"],
+                             note="vh_garbage_collect(0): identify + sweep + release + finish, "
+                                  "every block of the last frame freed (8 KiB of voxel traffic each)"))
+
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
     cpu = None
     if not args.no_cpu_baseline:
@@ -231,6 +276,7 @@ def main():
                     keys_last_frame=keys),
         roofline=roofline, cpu_baseline=cpu,
         raycast_mpix_per_s=round(raycast_mpix, 1) if raycast_mpix else None,
+        raycast=raycast, next_rows=next_rows,
         occupancy_index_variant=index_variant,
         kernels=kernels_us,
         frame_algorithmic_bytes=b_frame, frame_algorithmic_gbs=round(frame_gbs, 1),

@@ -5,4 +5,4 @@ include/voxelhash.h) plus the host-side mirrors of the reference's
 SDF_Hashtable class: C++ (include/SDF_Hashtable.h) and Python (hashtable.py).
 """
 from ._lib import (SEM_PINHOLE, SEM_REFERENCE, HashTableParams, VoxelHashError, load)  # noqa: F401
-from .hashtable import ENTRY_DTYPE, VOXEL_DTYPE, SDFHashtable, default_params  # noqa: F401
+from .hashtable import ENTRY_DTYPE, VOXEL_DTYPE, SDFHashtable, default_params, preprocess  # noqa: F401
