@@ -231,6 +231,20 @@ def main():
         stream.synchronize()
         pre_us = 1e6 * (time.perf_counter() - t3) / 50
     pre_bytes = (2 + 16 + 16) * Wd * Ht
+    # camera tracking (next #4): one fused ICP round (pairing + Jacobian + 27 sums) and a raycast target
+    from voxelhashing_demo_amd import tracking
+    Kf = synth.K_matrix(Wd, Ht)
+    trk = tracking.CameraTracking(Wd, Ht, Kf, stream=stream, flags=3)
+    tgt_p, tgt_n = torch.empty_like(verts[0]), torch.empty_like(verts[0])
+    with torch.cuda.stream(stream):
+        lib.vh_raycast(h, pose_ptrs[0], 0.1, 5.0, dptr)
+        tracking.depth_to_maps(depth, k_inv, tgt_p, tgt_n, stream=stream)
+        trk.build_system(verts[1], tgt_p, tgt_n, np.eye(4))
+        t4 = time.perf_counter()
+        for i in range(20):
+            icp_sys = trk.build_system(verts[1], tgt_p, tgt_n, np.eye(4))
+        icp_us = 1e6 * (time.perf_counter() - t4) / 20
+    icp_bytes = 48 * Wd * Ht
     # garbage collection (next #4) over the blocks the last frame saw; threshold 0 frees them all
     step(0)
     table.garbage_collect(0.0)
@@ -238,6 +252,9 @@ def main():
     gc_counters = table.counters()
     table.set_profiling(False)
     next_rows = dict(
+        icp_round=dict(us_per_round=round(icp_us, 2), pairs=icp_sys[3], algorithmic_bytes=icp_bytes,
+                       note="vh_icp_build_system against a raycast target, host-timed and synchronous "
+                            "(each round returns its 27 sums to the host for the 6x6 solve)"),
         preprocess=dict(us_per_frame=round(pre_us, 2), algorithmic_bytes=pre_bytes,
                         achieved_gbs=round(pre_bytes / (pre_us * 1e-6) / 1e9, 1),
                         note="vh_preprocess, back-to-back calls timed on the host (launch gaps included)"),

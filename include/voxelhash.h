@@ -92,7 +92,8 @@ enum {
     VH_ERR_NO_DEVICE = 2,        /* no usable HIP device */
     VH_ERR_OUT_OF_MEMORY = 3,
     VH_ERR_HIP = 4,              /* any other HIP runtime failure; see vh_last_error() */
-    VH_ERR_NOT_INITIALISED = 5   /* drop-in call before deviceAllocate() */
+    VH_ERR_NOT_INITIALISED = 5,  /* drop-in call before deviceAllocate() */
+    VH_ERR_SINGULAR = 6          /* vh_icp_solve: J^T J is not positive definite */
 };
 
 /* projection / transform semantics */
@@ -355,6 +356,65 @@ int vh_preprocess(const uint16_t *d_depth, const float k_inv[9], int32_t width, 
  * stream, synchronous */
 bool SetCameraIntrinsic(const float *intrinsic, const float *invIntrinsic);
 void preProcess(vh_float4 *positions, vh_float4 *normals, const uint16_t *depth);
+
+/* ------------------------------------------------------------------ */
+/* camera tracking: frame-to-frame point-to-plane ICP                  */
+/* (second half)                               */
+/* ------------------------------------------------------------------ */
+/* The reference's tracker (CameraTracking::Align, CameraTracking.cpp:27-69; never called,
+ * Application.cpp:75) aligns the vertex map of one frame (input) to the vertex + normal maps of
+ * another (target): per round FindCorrespondences (CameraTrackingUtils.cu:131-185) projects every
+ * input point, moved by the current estimate, into the target image and keeps the pair when the
+ * point-to-plane distance d = dot(q - t, n) is below the threshold; CalculateJacAndResKernel
+ * (Solver.cu:40-54) writes the 6 x N Jacobian [n, t x n]; cublasSgemv / cublasSsyrk reduce it to
+ * J^T r and J^T J (Solver.cpp:81-90); the host solves and composes in SE3 (Solver.cpp:104-106,
+ * SE3.cpp).  Here one fused pass per round produces the 27 sums directly.  With the target maps
+ * taken from vh_raycast + vh_depth_to_maps this is the frame-to-model tracking of KinectFusion. */
+#define VH_ICP_ABS_DISTANCE 1   /* keep |d| < threshold (the reference keeps the signed d < threshold, :170) */
+#define VH_ICP_NEED_TARGET  2   /* skip pixels whose target has no depth or no normal (the reference pairs them) */
+
+typedef struct vh_icp vh_icp;    /* workspace for one image size on one device */
+typedef struct vh_icp_system {
+    double   JTJ[36];            /* row-major, symmetric; parameter order (v, w) = translation, rotation */
+    double   JTr[6];
+    double   error;              /* sum of d over the kept pairs (computeCorrespondences' return value) */
+    uint32_t count;              /* kept pairs */
+} vh_icp_system;
+
+int vh_icp_create(int32_t width, int32_t height, int32_t device /* -1: current */, vh_icp **out);
+int vh_icp_destroy(vh_icp *icp);
+int vh_icp_set_stream(vh_icp *icp, void *hip_stream);
+/* One round's linear system for the estimate `delta` (row-major 4x4 mapping input points into the
+ * target's camera frame); K = row-major intrinsics.  Device maps are width*height float4.  fp32
+ * sums in a fixed order (reproducible); synchronises to return the system. */
+int vh_icp_build_system(vh_icp *icp, const vh_float4 *d_input, const vh_float4 *d_target,
+                        const vh_float4 *d_target_normals, const float delta[16], const float K[9],
+                        float dist_thres, int32_t flags, vh_icp_system *out);
+/* The same, and also the three maps computeCorrespondences fills (zero where no pair is kept). */
+int vh_icp_correspondences(vh_icp *icp, const vh_float4 *d_input, const vh_float4 *d_target,
+                           const vh_float4 *d_target_normals, const float delta[16], const float K[9],
+                           float dist_thres, int32_t flags, vh_float4 *d_corres, vh_float4 *d_corres_normals,
+                           float *d_residuals, vh_icp_system *out);
+/* Host only.  update = -(JTJ^-1 JTr) by Cholesky, estimate = log(exp(update) exp(estimate)) with
+ * twists (v, w) as in SE3.cpp:4-22.  VH_ERR_SINGULAR leaves the estimate untouched. */
+int  vh_icp_solve(const vh_icp_system *sys, double estimate[6]);
+void vh_se3_exp(const double twist[6], double T[16]);
+void vh_se3_log(const double T[16], double twist[6]);
+/* Up to max_iters rounds (the reference: 20) from the start value in `delta`, which receives the
+ * result; stops early when the summed residual is exactly 0 (:52) or the system is singular. */
+int vh_icp_align(vh_icp *icp, const vh_float4 *d_input, const vh_float4 *d_target,
+                 const vh_float4 *d_target_normals, const float K[9], float dist_thres, int32_t max_iters,
+                 int32_t flags, float delta[16], vh_icp_system *last, int32_t *iterations);
+/* float depth image in metres (0 = nothing, e.g. vh_raycast's output) -> vertex + normal maps with
+ * the arithmetic of preProcess; asynchronous on hip_stream. */
+int vh_depth_to_maps(const float *d_depth, const float k_inv[9], int32_t width, int32_t height,
+                     vh_float4 *d_positions, vh_float4 *d_normals, void *hip_stream);
+/* the reference's own name (CameraTrackingUtils.cu:187-215; float4x4 by value there, a pointer to
+ * its 16 row-major floats here): intrinsics from SetCameraIntrinsic, threshold 0.08 (common.h:12),
+ * synchronous, returns the summed residual */
+float computeCorrespondences(const vh_float4 *d_input, const vh_float4 *d_target,
+                             const vh_float4 *d_targetNormals, vh_float4 *corres, vh_float4 *corresNormals,
+                             float *residual, const float *deltaTransform, int width, int height);
 
 /* ------------------------------------------------------------------ */
 /* drop-in names (VoxelUtils.h:5-13); process-global default context    */

@@ -59,10 +59,9 @@ class FrameStats(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (seconds)."""
-    src = os.path.join(_HERE, "vh_oracle.c")
+    srcs = [os.path.join(_HERE, n) for n in ("vh_oracle.c", "vh_icp_oracle.c", "vh_oracle.h")]
     if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src),
-                                              os.path.getmtime(os.path.join(_HERE, "vh_oracle.h"))):
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
     return _LIB_PATH
 
@@ -126,6 +125,20 @@ def lib():
         L.vho_integrate_packets.argtypes = [C.c_void_p, C.c_int, fp]
         L.vho_integrate_packets.restype = C.c_int
         L.vho_preprocess.argtypes = [C.POINTER(C.c_uint16), fp, C.c_int, C.c_int, fp, fp]
+        dp = C.POINTER(C.c_double)
+        L.vho_depth_to_maps.argtypes = [fp, fp, C.c_int, C.c_int, fp, fp]
+        L.vho_icp_build_system.argtypes = [fp, fp, fp, fp, fp, C.c_float, C.c_int, C.c_int, C.c_int, dp, dp, dp,
+                                           C.POINTER(C.c_uint32)]
+        L.vho_icp_correspondences.argtypes = [fp, fp, fp, fp, fp, C.c_float, C.c_int, C.c_int, C.c_int, fp, fp, fp,
+                                              C.POINTER(C.c_uint32)]
+        L.vho_icp_correspondences.restype = C.c_double
+        L.vho_se3_exp.argtypes = [dp, dp]
+        L.vho_se3_log.argtypes = [dp, dp]
+        L.vho_icp_solve.argtypes = [dp, dp, dp]
+        L.vho_icp_solve.restype = C.c_int
+        L.vho_icp_align.argtypes = [fp, fp, fp, fp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, fp, dp,
+                                    C.POINTER(C.c_uint32)]
+        L.vho_icp_align.restype = C.c_int
         L.vho_delete_blocks.argtypes = [C.c_void_p, ip, C.c_int]
         L.vho_delete_blocks.restype = C.c_int
         L.vho_garbage_collect.argtypes = [C.c_void_p, C.c_float]
@@ -385,3 +398,78 @@ class OracleTable:
     def block_voxels(self, entry) -> np.ndarray:
         ptr = int(entry["ptr"])
         return self.sdf_blocks()[ptr:ptr + 512]
+
+
+# ---- frame-to-frame ICP (vh_icp_oracle.c) ----
+ICP_ABS_DISTANCE, ICP_NEED_TARGET = 1, 2
+
+
+def _f32(a, n=None):
+    a = np.ascontiguousarray(np.asarray(a, np.float32))
+    assert n is None or a.size == n
+    return a
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def depth_to_maps(depth, k_inv):
+    """float depth [H, W] in metres -> (positions [H, W, 4], normals [H, W, 4])."""
+    depth = _f32(depth)
+    H, W = depth.shape
+    k = _f32(k_inv, 9)
+    pos, nrm = np.zeros((H, W, 4), np.float32), np.zeros((H, W, 4), np.float32)
+    lib().vho_depth_to_maps(_fptr(depth), _fptr(k), W, H, _fptr(pos), _fptr(nrm))
+    return pos, nrm
+
+
+def icp_build_system(inp, target, normals, delta, K, dist_thres, flags=0):
+    inp, target, normals = _f32(inp), _f32(target), _f32(normals)
+    H, W = inp.shape[:2]
+    JTJ, JTr, err, cnt = np.zeros(36), np.zeros(6), C.c_double(), C.c_uint32()
+    lib().vho_icp_build_system(_fptr(inp), _fptr(target), _fptr(normals), _fptr(_f32(delta, 16)), _fptr(_f32(K, 9)),
+                               dist_thres, W, H, flags, _dptr(JTJ), _dptr(JTr), C.byref(err), C.byref(cnt))
+    return JTJ.reshape(6, 6), JTr, err.value, cnt.value
+
+
+def icp_correspondences(inp, target, normals, delta, K, dist_thres, flags=0):
+    """-> (corres [H,W,4], corres_normals [H,W,4], residuals [H,W], error, count)"""
+    inp, target, normals = _f32(inp), _f32(target), _f32(normals)
+    H, W = inp.shape[:2]
+    c, cn, r = np.empty((H, W, 4), np.float32), np.empty((H, W, 4), np.float32), np.empty((H, W), np.float32)
+    cnt = C.c_uint32()
+    err = lib().vho_icp_correspondences(_fptr(inp), _fptr(target), _fptr(normals), _fptr(_f32(delta, 16)),
+                                        _fptr(_f32(K, 9)), dist_thres, W, H, flags, _fptr(c), _fptr(cn), _fptr(r),
+                                        C.byref(cnt))
+    return c, cn, r, float(err), cnt.value
+
+
+def se3_exp(twist):
+    t, T = np.ascontiguousarray(twist, np.float64), np.zeros(16)
+    lib().vho_se3_exp(_dptr(t), _dptr(T))
+    return T.reshape(4, 4)
+
+
+def se3_log(T):
+    T, t = np.ascontiguousarray(np.asarray(T, np.float64).reshape(16)), np.zeros(6)
+    lib().vho_se3_log(_dptr(T), _dptr(t))
+    return t
+
+
+def icp_solve(JTJ, JTr, estimate):
+    est = np.ascontiguousarray(estimate, np.float64).copy()
+    ok = lib().vho_icp_solve(_dptr(np.ascontiguousarray(JTJ, np.float64).reshape(36)),
+                             _dptr(np.ascontiguousarray(JTr, np.float64)), _dptr(est))
+    return bool(ok), est
+
+
+def icp_align(inp, target, normals, K, dist_thres=0.08, max_iters=20, flags=0, delta=None):
+    """-> (delta [4,4] float32, iterations, last error, last count)."""
+    inp, target, normals = _f32(inp), _f32(target), _f32(normals)
+    H, W = inp.shape[:2]
+    d = _f32(np.eye(4) if delta is None else delta, 16).reshape(16).copy()
+    err, cnt = C.c_double(), C.c_uint32()
+    it = lib().vho_icp_align(_fptr(inp), _fptr(target), _fptr(normals), _fptr(_f32(K, 9)), dist_thres, W, H,
+                             max_iters, flags, _fptr(d), C.byref(err), C.byref(cnt))
+    return d.reshape(4, 4), int(it), err.value, cnt.value

@@ -137,6 +137,23 @@ vho_voxel        *vho_sdf_blocks(vho_table *t);      /* numVoxelBlocks*512 voxel
 int               vho_heap_counter(const vho_table *t);
 const vho_frame_stats *vho_last_stats(const vho_table *t);
 
+/* ---- frame-to-frame point-to-plane ICP (second half; vh_icp_oracle.c) ---- */
+#define VHO_ICP_ABS_DISTANCE 1   /* |d| < threshold instead of the reference's signed d < threshold */
+#define VHO_ICP_NEED_TARGET  2   /* skip pixels whose target has no depth / no normal */
+void vho_depth_to_maps(const float *depth, const float k_inv[9], int W, int H, float *positions, float *normals);
+void vho_icp_build_system(const float *input, const float *target, const float *target_normals,
+                          const float delta[16], const float K[9], float dist_thres, int W, int H, int flags,
+                          double JTJ[36], double JTr[6], double *error, uint32_t *count);
+double vho_icp_correspondences(const float *input, const float *target, const float *target_normals,
+                               const float delta[16], const float K[9], float dist_thres, int W, int H, int flags,
+                               float *corres, float *corres_normals, float *residuals, uint32_t *count);
+void vho_se3_exp(const double twist[6], double T[16]);
+void vho_se3_log(const double T[16], double twist[6]);
+int  vho_icp_solve(const double JTJ[36], const double JTr[6], double estimate[6]);
+int  vho_icp_align(const float *input, const float *target, const float *target_normals, const float K[9],
+                   float dist_thres, int W, int H, int max_iters, int flags, float delta[16], double *final_error,
+                   uint32_t *final_count);
+
 /* ---- scalar helpers, exported for known-answer tests ---- */
 int32_t  vho_float2int_rz(float x);                               /* GPU cvt semantics */
 uint32_t vho_hash(int32_t x, int32_t y, int32_t z, uint32_t numBuckets);

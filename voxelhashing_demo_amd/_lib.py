@@ -65,6 +65,10 @@ class KernelTimes(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class IcpSystem(C.Structure):
+    _fields_ = [("JTJ", C.c_double * 36), ("JTr", C.c_double * 6), ("error", C.c_double), ("count", C.c_uint32)]
+
+
 class PtrContainer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "d_heap", "d_hashTable", "d_compactifiedHashTable", "d_hashTableBucketMutex", "d_SDFBlocks",
@@ -94,6 +98,19 @@ SIGNATURES = {
     "vh_integrate_depth_map": (C.c_int, [_vp, _vp]),
     "vh_integrate": (C.c_int, [_vp, _fp, _vp, _vp]),
     "vh_raycast": (C.c_int, [_vp, _fp, _f, _f, _vp]),
+    "vh_icp_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "vh_icp_destroy": (C.c_int, [_vp]),
+    "vh_icp_set_stream": (C.c_int, [_vp, _vp]),
+    "vh_icp_build_system": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _fp, _f, C.c_int32, C.POINTER(IcpSystem)]),
+    "vh_icp_correspondences": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _fp, _f, C.c_int32, _vp, _vp, _vp,
+                                         C.POINTER(IcpSystem)]),
+    "vh_icp_solve": (C.c_int, [C.POINTER(IcpSystem), C.POINTER(C.c_double)]),
+    "vh_se3_exp": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vh_se3_log": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "vh_icp_align": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _f, C.c_int32, C.c_int32, _fp, C.POINTER(IcpSystem),
+                               C.POINTER(C.c_int32)]),
+    "vh_depth_to_maps": (C.c_int, [_vp, _fp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
+    "computeCorrespondences": (C.c_float, [_vp, _vp, _vp, _vp, _vp, _vp, _fp, C.c_int, C.c_int]),
     "vh_delete_blocks": (C.c_int, [_vp, _vp, C.c_int32]),
     "vh_garbage_collect": (C.c_int, [_vp, _f]),
     "vh_export_views": (C.c_int, [_vp, _fp, C.c_int32, _f, _f, _vp, C.c_int32, _vp]),

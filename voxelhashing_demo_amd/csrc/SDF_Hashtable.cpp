@@ -2,6 +2,7 @@
 // of the reference.  Errors follow the reference convention (checkCudaErrors,
 // helper_cuda.h:966-977): message on stderr, then exit(EXIT_FAILURE).
 #include "SDF_Hashtable.h"
+#include "CameraTracking.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -65,3 +66,35 @@ int SDF_Hashtable::occupiedBlockCount()
 }
 
 void SDF_Hashtable::setStream(void *s) { check(vh_set_stream(ctx_, s), "set_stream"); }
+
+// ---------------------------------------------------------------------------
+// CameraTracking (CameraTracking.cpp:27-69,118-145)
+// ---------------------------------------------------------------------------
+CameraTracking::CameraTracking(int w, int h) : icp_(nullptr), width(w), height(h)
+{
+    deltaTransform.setIdentity();
+    // common.h:7-10 scaled with the resolution
+    const float sx = (float)w / 640.0f, sy = (float)h / 480.0f;
+    const float K[9] = {517.3f * sx, 0, 318.6f * sx, 0, 516.5f * sy, 255.3f * sy, 0, 0, 1};
+    setIntrinsic(K);
+    check(vh_icp_create(w, h, -1, &icp_), "CameraTracking");
+}
+
+CameraTracking::~CameraTracking() { vh_icp_destroy(icp_); }
+
+void CameraTracking::setIntrinsic(const float K[9])
+{
+    for (int i = 0; i < 9; ++i) K_[i] = K[i];
+}
+
+void CameraTracking::setStream(void *hipStream) { check(vh_icp_set_stream(icp_, hipStream), "setStream"); }
+
+void CameraTracking::Align(vh_float4 *d_input, vh_float4 *, vh_float4 *d_target, vh_float4 *d_targetNormals,
+                           const uint16_t *, const uint16_t *)
+{
+    vh_icp_system last;
+    int rounds = 0;
+    check(vh_icp_align(icp_, d_input, d_target, d_targetNormals, K_, distThres_, maxIters, flags_,
+                       deltaTransform.entries, &last, &rounds), "Align");
+    globalCorrespondenceError = (float)last.error;
+}

@@ -178,6 +178,7 @@ extern "C" const char *vh_error_string(int code)
         case VH_ERR_OUT_OF_MEMORY: return "out of device memory";
         case VH_ERR_HIP: return "HIP runtime error";
         case VH_ERR_NOT_INITIALISED: return "deviceAllocate() has not been called";
+        case VH_ERR_SINGULAR: return "singular linear system";
         default: return "unknown error";
     }
 }
@@ -1204,11 +1205,12 @@ extern "C" int vh_preprocess(const uint16_t *d_depth, const float k_inv[9], int3
 }
 
 static float g_k_inv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+static float g_k[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 
 extern "C" bool SetCameraIntrinsic(const float *intrinsic, const float *invIntrinsic)
 {
-    (void)intrinsic;     // K itself only feeds the ICP kernels (out of scope)
     if (!invIntrinsic) return false;
+    if (intrinsic) std::memcpy(g_k, intrinsic, sizeof g_k);          // K feeds computeCorrespondences
     std::memcpy(g_k_inv, invIntrinsic, sizeof g_k_inv);
     return true;
 }
@@ -1318,3 +1320,5 @@ extern "C" void integrateDepthMap(const HashTableParams *params, const vh_float4
     if (rc == VH_OK) rc = vh_synchronize(g_default);               // :850
     if (rc != VH_OK) die("integrateDepthMap", rc);
 }
+
+#include "vh_api_icp.hip"

@@ -18,6 +18,8 @@
 //   vh_gc.hip          block deletion / garbage collection (deleteVoxelEntry :544-604 done correctly)
 //   vh_preprocess.hip  depth -> vertex / normal maps (preProcess, CameraTrackingUtils.cu:50-120),
 //                      table set-up kernels (VoxelUtils.cu:151-166), device-side test hook
+//   vh_icp.hip         frame-to-frame point-to-plane ICP: correspondences + Jacobian + J^T J / J^T r in one
+//                      pass (CameraTrackingUtils.cu:131-185, Solver.cu:19-54, Solver.cpp:81-90)
 //
 // All of it is integer / fp32 scalar work bound by HBM traffic, latency or VALU issue; there is
 // no contraction to hand to MFMA.  Built with -ffp-contract=off (see vh_device.h).
@@ -32,3 +34,4 @@
 #include "vh_view.hip"
 #include "vh_gc.hip"
 #include "vh_preprocess.hip"
+#include "vh_icp.hip"
