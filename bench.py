@@ -244,6 +244,11 @@ def main():
         for i in range(20):
             icp_sys = trk.build_system(verts[1], tgt_p, tgt_n, np.eye(4))
         icp_us = 1e6 * (time.perf_counter() - t4) / 20
+        trk.Align(verts[1], tgt_p, tgt_n)
+        t5 = time.perf_counter()
+        for i in range(5):
+            trk.Align(verts[1], tgt_p, tgt_n)
+        align_us = 1e6 * (time.perf_counter() - t5) / 5
     icp_bytes = 48 * Wd * Ht
     # garbage collection (next #4) over the blocks the last frame saw; threshold 0 frees them all
     step(0)
@@ -254,7 +259,10 @@ def main():
     next_rows = dict(
         icp_round=dict(us_per_round=round(icp_us, 2), pairs=icp_sys[3], algorithmic_bytes=icp_bytes,
                        note="vh_icp_build_system against a raycast target, host-timed and synchronous "
-                            "(each round returns its 27 sums to the host for the 6x6 solve)"),
+                            "(the step API returns each round's 27 sums to the host)"),
+        icp_align=dict(us_per_align=round(align_us, 1), rounds=trk.iterations, us_per_round=round(align_us / max(1, trk.iterations), 2),
+                       note="vh_icp_align: all rounds queued at once, 6x6 solve + SE3 update on the device, "
+                            "one copy and one synchronisation at the end"),
         preprocess=dict(us_per_frame=round(pre_us, 2), algorithmic_bytes=pre_bytes,
                         achieved_gbs=round(pre_bytes / (pre_us * 1e-6) / 1e9, 1),
                         note="vh_preprocess, back-to-back calls timed on the host (launch gaps included)"),

@@ -8,8 +8,8 @@ struct vh_icp {
     int width = 0, height = 0;
     hipStream_t stream = nullptr;
     float *partials = nullptr;     // [blocks][32]
-    float *sums = nullptr;         // [32] device
-    float *hostSums = nullptr;     // [32] pinned
+    IcpState *state = nullptr;     // device-resident Align state
+    IcpState *hostState = nullptr; // pinned copy
     int blocks = 0;
 };
 
@@ -29,13 +29,14 @@ extern "C" int vh_icp_create(int32_t width, int32_t height, int32_t device, vh_i
     p->device = dev;
     p->width = width;
     p->height = height;
-    p->blocks = grid_for((size_t)width * height, 256);
+    p->blocks = std::min(grid_for((size_t)width * height, kIcpThreads), 256);   // one workgroup per compute unit
+    if (const char *e = std::getenv("VH_ICP_BLOCKS")) p->blocks = std::max(1, std::min(p->blocks, std::atoi(e)));   // tuning knob
     hipError_t e = hipMalloc((void **)&p->partials, sizeof(float) * kIcpStride * (size_t)p->blocks);
-    if (e == hipSuccess) e = hipMalloc((void **)&p->sums, sizeof(float) * kIcpStride);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&p->hostSums, sizeof(float) * kIcpStride, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->state, sizeof(IcpState));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&p->hostState, sizeof(IcpState), hipHostMallocDefault);
     if (e != hipSuccess) {
         if (p->partials) (void)hipFree(p->partials);
-        if (p->sums) (void)hipFree(p->sums);
+        if (p->state) (void)hipFree(p->state);
         delete p;
         return fail(e == hipErrorOutOfMemory ? VH_ERR_OUT_OF_MEMORY : VH_ERR_HIP, "icp workspace", e);
     }
@@ -49,8 +50,8 @@ extern "C" int vh_icp_destroy(vh_icp *p)
     DeviceGuard guard(p->device);
     (void)hipStreamSynchronize(p->stream);
     (void)hipFree(p->partials);
-    (void)hipFree(p->sums);
-    (void)hipHostFree(p->hostSums);
+    (void)hipFree(p->state);
+    (void)hipHostFree(p->hostState);
     delete p;
     return VH_OK;
 }
@@ -60,6 +61,19 @@ extern "C" int vh_icp_set_stream(vh_icp *p, void *stream)
     if (!p) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     p->stream = (hipStream_t)stream;
     return VH_OK;
+}
+
+static void system_from_sums(const float *sums, vh_icp_system *out)
+{
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) {
+            out->JTJ[6 * a + b] = out->JTJ[6 * b + a] = (double)sums[k];
+            ++k;
+        }
+    for (int a = 0; a < 6; ++a) out->JTr[a] = (double)sums[21 + a];
+    out->error = (double)sums[27];
+    out->count = (uint32_t)sums[28];
 }
 
 static int icp_launch(vh_icp *p, const vh_float4 *d_input, const vh_float4 *d_target, const vh_float4 *d_normals,
@@ -73,23 +87,22 @@ static int icp_launch(vh_icp *p, const vh_float4 *d_input, const vh_float4 *d_ta
     ip.width = p->width;
     ip.height = p->height;
     ip.flags = flags;
-    icp_accumulate_kernel<<<p->blocks, 256, 0, p->stream>>>(
-        ip, reinterpret_cast<const float4 *>(d_input), reinterpret_cast<const float4 *>(d_target),
-        reinterpret_cast<const float4 *>(d_normals), p->partials, reinterpret_cast<float4 *>(d_corres),
-        reinterpret_cast<float4 *>(d_corres_normals), d_residuals);
-    icp_finalize_kernel<<<1, 256, 0, p->stream>>>(p->partials, p->blocks, p->sums);
+    VH_HIP(hipMemsetAsync(p->state, 0, sizeof(IcpState), p->stream));
+    if (d_corres)
+        icp_round_kernel<true><<<p->blocks, kIcpThreads, 0, p->stream>>>(
+            ip, reinterpret_cast<const float4 *>(d_input), reinterpret_cast<const float4 *>(d_target),
+            reinterpret_cast<const float4 *>(d_normals), p->partials, reinterpret_cast<float4 *>(d_corres),
+            reinterpret_cast<float4 *>(d_corres_normals), d_residuals, p->state, 0, 0);
+    else
+        icp_round_kernel<false><<<p->blocks, kIcpThreads, 0, p->stream>>>(
+            ip, reinterpret_cast<const float4 *>(d_input), reinterpret_cast<const float4 *>(d_target),
+            reinterpret_cast<const float4 *>(d_normals), p->partials, (float4 *)nullptr, (float4 *)nullptr,
+            (float *)nullptr, p->state, 0, 0);
     VH_HIP(hipGetLastError());
-    VH_HIP(hipMemcpyAsync(p->hostSums, p->sums, sizeof(float) * kIcpStride, hipMemcpyDeviceToHost, p->stream));
+    IcpState &hs = *p->hostState;
+    VH_HIP(hipMemcpyAsync(&hs, p->state, sizeof hs, hipMemcpyDeviceToHost, p->stream));
     VH_HIP(hipStreamSynchronize(p->stream));
-    int k = 0;
-    for (int a = 0; a < 6; ++a)
-        for (int b = a; b < 6; ++b) {
-            out->JTJ[6 * a + b] = out->JTJ[6 * b + a] = (double)p->hostSums[k];
-            ++k;
-        }
-    for (int a = 0; a < 6; ++a) out->JTr[a] = (double)p->hostSums[21 + a];
-    out->error = (double)p->hostSums[27];
-    out->count = (uint32_t)p->hostSums[28];
+    system_from_sums(hs.sums, out);
     return VH_OK;
 }
 
@@ -116,125 +129,54 @@ extern "C" int vh_icp_correspondences(vh_icp *p, const vh_float4 *d_input, const
                       d_residuals, out);
 }
 
-// ---- SE3 (SE3.cpp:4-22): twist = (v, w), M = [[0,-w2,w1,v0],[w2,0,-w0,v1],[-w1,w0,0,v2],0]; the
-// reference evaluates M.exp() / T.log() with Eigen's generic matrix functions, these are the
-// closed forms of the same maps ----
-static void skew_terms(const double w[3], double Kx[9], double K2[9])
-{
-    const double k[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
-    std::memcpy(Kx, k, sizeof k);
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) K2[3 * i + j] = k[3 * i] * k[j] + k[3 * i + 1] * k[3 + j] + k[3 * i + 2] * k[6 + j];
-}
+// SE3 maps and the 6x6 solve: one implementation for host and device (vh_icp.hip)
+extern "C" void vh_se3_exp(const double twist[6], double T[16]) { se3_exp_d(twist, T); }
+extern "C" void vh_se3_log(const double T[16], double twist[6]) { se3_log_d(T, twist); }
 
-extern "C" void vh_se3_exp(const double twist[6], double T[16])
-{
-    const double *v = twist, *w = twist + 3;
-    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = std::sqrt(th2);
-    double A, B, Cc;
-    if (th < 1e-5) { A = 1.0 - th2 / 6.0; B = 0.5 - th2 / 24.0; Cc = 1.0 / 6.0 - th2 / 120.0; }
-    else { A = std::sin(th) / th; B = (1.0 - std::cos(th)) / th2; Cc = (th - std::sin(th)) / (th2 * th); }
-    double Kx[9], K2[9];
-    skew_terms(w, Kx, K2);
-    std::memset(T, 0, 16 * sizeof(double));
-    for (int i = 0; i < 3; ++i) {
-        double t = 0.0;
-        for (int j = 0; j < 3; ++j) {
-            const double I = (i == j) ? 1.0 : 0.0;
-            T[4 * i + j] = I + A * Kx[3 * i + j] + B * K2[3 * i + j];
-            t += (I + B * Kx[3 * i + j] + Cc * K2[3 * i + j]) * v[j];
-        }
-        T[4 * i + 3] = t;
-    }
-    T[15] = 1.0;
-}
-
-extern "C" void vh_se3_log(const double T[16], double twist[6])
-{
-    double c = 0.5 * (T[0] + T[5] + T[10] - 1.0);
-    c = std::min(1.0, std::max(-1.0, c));
-    const double th = std::acos(c), th2 = th * th;
-    const double r[3] = {T[9] - T[6], T[2] - T[8], T[4] - T[1]};
-    const double f = (th < 1e-5) ? 0.5 + th2 / 12.0 : th / (2.0 * std::sin(th));
-    const double w[3] = {f * r[0], f * r[1], f * r[2]};
-    const double D = (th < 1e-5) ? 1.0 / 12.0 + th2 / 720.0
-                                 : (1.0 - th * std::sin(th) / (2.0 * (1.0 - std::cos(th)))) / th2;
-    double Kx[9], K2[9];
-    skew_terms(w, Kx, K2);
-    for (int i = 0; i < 3; ++i) {
-        double s = 0.0;
-        for (int j = 0; j < 3; ++j) s += (((i == j) ? 1.0 : 0.0) - 0.5 * Kx[3 * i + j] + D * K2[3 * i + j]) * T[4 * j + 3];
-        twist[i] = s;
-    }
-    twist[3] = w[0]; twist[4] = w[1]; twist[5] = w[2];
-}
-
-// update = -(JTJ^-1 JTr); estimate = log(exp(update) exp(estimate))   (Solver.cpp:104-106)
 extern "C" int vh_icp_solve(const vh_icp_system *sys, double estimate[6])
 {
     if (!sys || !estimate) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
-    double L[36] = {0}, y[6], x[6];
-    for (int i = 0; i < 6; ++i)
-        for (int j = 0; j <= i; ++j) {
-            double s = sys->JTJ[6 * i + j];
-            for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
-            if (i == j) {
-                if (!(s > 0.0)) return fail(VH_ERR_SINGULAR, "J^T J is not positive definite");
-                L[6 * i + i] = std::sqrt(s);
-            } else {
-                L[6 * i + j] = s / L[6 * j + j];
-            }
-        }
-    for (int i = 0; i < 6; ++i) {
-        double s = -sys->JTr[i];
-        for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
-        y[i] = s / L[6 * i + i];
-    }
-    for (int i = 5; i >= 0; --i) {
-        double s = y[i];
-        for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
-        x[i] = s / L[6 * i + i];
-    }
-    double A[16], B[16], M[16];
-    vh_se3_exp(x, A);
-    vh_se3_exp(estimate, B);
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < 4; ++k) s += A[4 * i + k] * B[4 * k + j];
-            M[4 * i + j] = s;
-        }
-    vh_se3_log(M, estimate);
+    if (!icp_solve_d(sys->JTJ, sys->JTr, estimate)) return fail(VH_ERR_SINGULAR, "J^T J is not positive definite");
     return VH_OK;
 }
 
-// CameraTracking::Align, CameraTracking.cpp:27-69
+// CameraTracking::Align, CameraTracking.cpp:27-69.  All rounds are queued at once: round i's
+// finalize pass solves the system on the device and leaves the new estimate where round i+1 reads
+// it; rounds after a stop condition fall through.  One copy and one synchronisation at the end.
 extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4 *d_target,
                             const vh_float4 *d_target_normals, const float K[9], float dist_thres, int32_t max_iters,
                             int32_t flags, float delta[16], vh_icp_system *last, int32_t *iterations)
 {
-    if (!p || !d_input || !d_target || !d_target_normals || !K || !delta)
-        return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (!p || !d_input || !d_target || !d_target_normals || !K || !delta || max_iters < 0)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     DeviceGuard guard(p->device);
-    double T[16], est[6];
+    IcpState &hs = *p->hostState;
+    std::memset(&hs, 0, sizeof hs);
+    double T[16];
     for (int i = 0; i < 16; ++i) T[i] = (double)delta[i];
-    vh_se3_log(T, est);
-    vh_icp_system sys{};
-    int it = 0;
-    for (; it < max_iters; ++it) {
-        float d32[16];
-        vh_se3_exp(est, T);
-        for (int i = 0; i < 16; ++i) d32[i] = (float)T[i];
-        const int rc = icp_launch(p, d_input, d_target, d_target_normals, d32, K, dist_thres, flags, nullptr, nullptr,
-                                  nullptr, &sys);
-        if (rc != VH_OK) return rc;
-        if (sys.error == 0.0) break;                                 // :52
-        if (vh_icp_solve(&sys, est) != VH_OK) break;
-    }
-    vh_se3_exp(est, T);
-    for (int i = 0; i < 16; ++i) delta[i] = (float)T[i];
-    if (last) *last = sys;
-    if (iterations) *iterations = it;
+    se3_log_d(T, hs.est);
+    se3_exp_d(hs.est, T);
+    for (int i = 0; i < 16; ++i) hs.delta[i] = (float)T[i];
+    VH_HIP(hipMemcpyAsync(p->state, &hs, sizeof hs, hipMemcpyHostToDevice, p->stream));
+    IcpParams ip;
+    std::memset(ip.delta, 0, sizeof ip.delta);
+    std::memcpy(ip.K, K, sizeof ip.K);
+    ip.distThres = dist_thres;
+    ip.width = p->width;
+    ip.height = p->height;
+    ip.flags = flags;
+    for (int it = 0; it < max_iters; ++it)
+        icp_round_kernel<false><<<p->blocks, kIcpThreads, 0, p->stream>>>(
+            ip, reinterpret_cast<const float4 *>(d_input), reinterpret_cast<const float4 *>(d_target),
+            reinterpret_cast<const float4 *>(d_target_normals), p->partials, (float4 *)nullptr, (float4 *)nullptr,
+            (float *)nullptr, p->state, 1, 1);
+    VH_HIP(hipGetLastError());
+    VH_HIP(hipMemcpyAsync(&hs, p->state, sizeof hs, hipMemcpyDeviceToHost, p->stream));
+    VH_HIP(hipStreamSynchronize(p->stream));
+    std::memcpy(delta, hs.delta, 16 * sizeof(float));
+    if (last) system_from_sums(hs.sums, last);
+    // rounds that solved = systems built, minus the one that hit a stop condition (the oracle's count)
+    if (iterations) *iterations = hs.rounds - (hs.done ? 1 : 0);
     return VH_OK;
 }
 

@@ -12,6 +12,7 @@ namespace vh {
 
 constexpr int kIcpTerms = 29;        // 21 (upper triangle of J^T J) + 6 (J^T r) + sum d + count
 constexpr int kIcpStride = 32;       // floats per partial record
+constexpr int kIcpThreads = 256;     // lanes per workgroup (1024-lane workgroups measured slower: 20 vs 17 us per round)
 constexpr int kIcpAbsDistance = 1;   // VH_ICP_ABS_DISTANCE
 constexpr int kIcpNeedTarget = 2;    // VH_ICP_NEED_TARGET
 
@@ -21,6 +22,136 @@ struct IcpParams {
     float distThres;
     int32_t width, height, flags;
 };
+
+// Device-resident state of a whole Align (vh_icp_align): the rounds chain on the stream without
+// returning to the host; the solve of round i runs in the last workgroup of that round's launch.
+struct IcpState {
+    double est[6];       // twist (v, w) of the running estimate
+    float delta[16];     // exp(est), row-major, what the next round's pairing uses
+    float sums[kIcpStride];   // the 29 sums of the last executed round
+    int32_t rounds;      // rounds executed (systems built)
+    int32_t done;        // 1: stop (summed residual exactly 0, CameraTracking.cpp:52, or singular system)
+    int32_t singular;
+    int32_t ticket;      // workgroups of the running round that have stored their partial record
+};
+
+// ---- SE3 (SE3.cpp:4-22): twist = (v, w), M = [[0,-w2,w1,v0],[w2,0,-w0,v1],[-w1,w0,0,v2],0]; the
+// reference evaluates M.exp() / T.log() with Eigen's generic matrix functions, these are the closed
+// forms of the same maps.  Shared by the host entry points and the device-side solve. ----
+// Every loop below has a constant trip count and is unrolled, so that on the device the small
+// matrices live in registers (left as loops they are indexed dynamically and go to scratch memory:
+// the single-lane solve then cost 40 us per round instead of a few).
+#define VH_UNROLL _Pragma("unroll")
+__host__ __device__ inline void skew_terms(const double w[3], double Kx[9], double K2[9])
+{
+    Kx[0] = 0; Kx[1] = -w[2]; Kx[2] = w[1];
+    Kx[3] = w[2]; Kx[4] = 0; Kx[5] = -w[0];
+    Kx[6] = -w[1]; Kx[7] = w[0]; Kx[8] = 0;
+    VH_UNROLL
+    for (int i = 0; i < 3; ++i)
+        VH_UNROLL
+        for (int j = 0; j < 3; ++j)
+            K2[3 * i + j] = Kx[3 * i] * Kx[j] + Kx[3 * i + 1] * Kx[3 + j] + Kx[3 * i + 2] * Kx[6 + j];
+}
+
+__host__ __device__ inline void se3_exp_d(const double twist[6], double T[16])
+{
+    const double *v = twist, *w = twist + 3;
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+    double A, B, Cc;                       // sin(t)/t, (1-cos t)/t^2, (t-sin t)/t^3
+    if (th < 1e-5) { A = 1.0 - th2 / 6.0; B = 0.5 - th2 / 24.0; Cc = 1.0 / 6.0 - th2 / 120.0; }
+    else { A = sin(th) / th; B = (1.0 - cos(th)) / th2; Cc = (th - sin(th)) / (th2 * th); }
+    double Kx[9], K2[9];
+    skew_terms(w, Kx, K2);
+    VH_UNROLL
+    for (int i = 0; i < 16; ++i) T[i] = 0.0;
+    VH_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        double t = 0.0;
+        VH_UNROLL
+        for (int j = 0; j < 3; ++j) {
+            const double I = (i == j) ? 1.0 : 0.0;
+            T[4 * i + j] = I + A * Kx[3 * i + j] + B * K2[3 * i + j];
+            t += (I + B * Kx[3 * i + j] + Cc * K2[3 * i + j]) * v[j];
+        }
+        T[4 * i + 3] = t;
+    }
+    T[15] = 1.0;
+}
+
+__host__ __device__ inline void se3_log_d(const double T[16], double twist[6])
+{
+    double c = 0.5 * (T[0] + T[5] + T[10] - 1.0);
+    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+    const double th = acos(c), th2 = th * th;
+    const double r[3] = {T[9] - T[6], T[2] - T[8], T[4] - T[1]};            // (R - R^T) vee
+    const double f = (th < 1e-5) ? 0.5 + th2 / 12.0 : th / (2.0 * sin(th));
+    const double w[3] = {f * r[0], f * r[1], f * r[2]};
+    const double D = (th < 1e-5) ? 1.0 / 12.0 + th2 / 720.0 : (1.0 - th * sin(th) / (2.0 * (1.0 - cos(th)))) / th2;
+    double Kx[9], K2[9];
+    skew_terms(w, Kx, K2);
+    VH_UNROLL
+    for (int i = 0; i < 3; ++i) {
+        double s = 0.0;
+        VH_UNROLL
+        for (int j = 0; j < 3; ++j) s += (((i == j) ? 1.0 : 0.0) - 0.5 * Kx[3 * i + j] + D * K2[3 * i + j]) * T[4 * j + 3];
+        twist[i] = s;
+    }
+    twist[3] = w[0]; twist[4] = w[1]; twist[5] = w[2];
+}
+
+// update = -(JTJ^-1 JTr) by Cholesky; estimate = log(exp(update) exp(estimate))  (Solver.cpp:104-106).
+// false (estimate untouched) when JTJ is not positive definite.
+__host__ __device__ inline bool icp_solve_d(const double JTJ[36], const double JTr[6], double estimate[6])
+{
+    double L[36], y[6], x[6];
+    VH_UNROLL
+    for (int i = 0; i < 36; ++i) L[i] = 0.0;
+    VH_UNROLL
+    for (int i = 0; i < 6; ++i)
+        VH_UNROLL
+        for (int j = 0; j <= i; ++j) {
+            double s = JTJ[6 * i + j];
+            VH_UNROLL
+            for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
+            if (i == j) {
+                if (!(s > 0.0)) return false;
+                L[6 * i + i] = sqrt(s);
+            } else {
+                L[6 * i + j] = s / L[6 * j + j];
+            }
+        }
+    VH_UNROLL
+    for (int i = 0; i < 6; ++i) {
+        double s = -JTr[i];
+        VH_UNROLL
+        for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
+        y[i] = s / L[6 * i + i];
+    }
+    VH_UNROLL
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+        VH_UNROLL
+        for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
+        x[i] = s / L[6 * i + i];
+    }
+    double A[16], B[16], M[16];
+    se3_exp_d(x, A);
+    se3_exp_d(estimate, B);
+    VH_UNROLL
+    for (int i = 0; i < 4; ++i)
+        VH_UNROLL
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+            VH_UNROLL
+            for (int k = 0; k < 4; ++k) s += A[4 * i + k] * B[4 * k + j];
+            M[4 * i + j] = s;
+        }
+    se3_log_d(M, estimate);
+    return true;
+}
+
+#undef VH_UNROLL
 
 // double -> int as cvt.rzi.s32.f64 (the reference's make_int2(double, double), :129): truncate,
 // saturate, NaN -> 0; v_cvt_i32_f64 has the same contract.
@@ -59,24 +190,58 @@ __device__ __forceinline__ bool icp_correspondence(const IcpParams &ip, const fl
     return (ip.flags & kIcpAbsDistance) ? (__builtin_fabsf(d) < ip.distThres) : (d < ip.distThres);   // :170
 }
 
-// One pixel per lane; the 29 terms are reduced across the wave with shuffles, across the four
-// waves through LDS, and each workgroup stores one partial record.  The order of the additions
-// is fixed by the launch geometry, so the sums are reproducible run to run.
-// corres / corresNormals / residuals: nullptr, or the maps computeCorrespondences fills.
-__global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams ip, const float4 *__restrict__ input,
-                                                             const float4 *__restrict__ target,
-                                                             const float4 *__restrict__ normals,
-                                                             float *__restrict__ partials,
-                                                             float4 *__restrict__ corres,
-                                                             float4 *__restrict__ corresNormals,
-                                                             float *__restrict__ residuals)
+// Sum over the 64 lanes of a wave, result in lane 63: an inclusive scan in DPP steps (row_shr 1, 2,
+// 4, 8 inside each row of 16 lanes, then row_bcast:15 and row_bcast:31 carry the row totals on), six
+// VALU instructions and no LDS traffic per term; __shfl_xor goes through ds_bpermute and made the 29
+// reductions a visible part of the round.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ float dpp_take(float v)
 {
-    __shared__ float sm[4][kIcpStride];
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, kRowMask, 0xf, false));
+}
+
+__device__ __forceinline__ float wave_sum_lane63(float v)
+{
+    v += dpp_take<0x111, 0xf>(v);
+    v += dpp_take<0x112, 0xf>(v);
+    v += dpp_take<0x114, 0xf>(v);
+    v += dpp_take<0x118, 0xf>(v);
+    v += dpp_take<0x142, 0xa>(v);
+    v += dpp_take<0x143, 0xc>(v);
+    return v;
+}
+
+// One launch per round.  256-lane workgroups (one per compute unit) stride over the pixels and keep the 29 terms in
+// registers; each wave reduces them with DPP adds, the four waves combine through LDS and the
+// workgroup stores one partial record.  The last workgroup to finish (ticket) adds the records in a
+// fixed order -- so the sums are reproducible run to run -- and, when `solve` is set, lane 0 solves
+// the 6x6 system in double and advances the estimate in the device-resident state, so the next
+// round starts without the host (the reference returns to the host three times per round,
+// Solver.cpp:83,89 and CameraTrackingUtils.cu:212).
+//   useState: take the estimate from state->delta (Align) instead of ip.delta (step API)
+//   corres / corresNormals / residuals: nullptr, or the maps computeCorrespondences fills
+template <bool kWriteMaps>
+__global__ __launch_bounds__(kIcpThreads) void icp_round_kernel(IcpParams ip, const float4 *__restrict__ input,
+                                                        const float4 *__restrict__ target,
+                                                        const float4 *__restrict__ normals,
+                                                        float *__restrict__ partials, float4 *__restrict__ corres,
+                                                        float4 *__restrict__ corresNormals,
+                                                        float *__restrict__ residuals, IcpState *__restrict__ state,
+                                                        int useState, int solve)
+{
+    __shared__ float sm[kIcpThreads / kWave][kIcpStride];
+    __shared__ float total[kIcpStride];
+    __shared__ int isLast;
+    if (useState) {
+        if (state->done) return;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) ip.delta[i] = state->delta[i];
+    }
     float acc[kIcpTerms];
 #pragma unroll
     for (int k = 0; k < kIcpTerms; ++k) acc[k] = 0.0f;
-    if (idx < ip.width * ip.height) {
+    const int npix = ip.width * ip.height;
+    for (int idx = blockIdx.x * kIcpThreads + threadIdx.x; idx < npix; idx += gridDim.x * kIcpThreads) {
         float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n = t;
         float d = 0.0f;
         const bool kept = icp_correspondence(ip, input, target, normals, idx, t, n, d);
@@ -87,13 +252,13 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams ip,
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
-                for (int b = a; b < 6; ++b) acc[k++] = J[a] * J[b];
+                for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) acc[21 + a] = J[a] * d;
-            acc[27] = d;
-            acc[28] = 1.0f;
+            for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * d;
+            acc[27] += d;
+            acc[28] += 1.0f;
         }
-        if (corres) {                 // the reference clears the maps first (:198-200), then writes the kept ones
+        if constexpr (kWriteMaps) {   // the reference clears the maps first (:198-200), then writes the kept ones
             const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             corres[idx] = kept ? t : zero;
             corresNormals[idx] = kept ? n : zero;
@@ -103,33 +268,72 @@ __global__ __launch_bounds__(256) void icp_accumulate_kernel(const IcpParams ip,
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kIcpTerms; ++k) {
-        float v = acc[k];
-#pragma unroll
-        for (int s = 1; s < kWave; s <<= 1) v += __shfl_xor(v, s);
-        if (lane == 0) sm[wave][k] = v;
+        const float v = wave_sum_lane63(acc[k]);
+        if (lane == kWave - 1) sm[wave][k] = v;
     }
     __syncthreads();
-    if (threadIdx.x < kIcpStride)
-        partials[(size_t)blockIdx.x * kIcpStride + threadIdx.x] =
-            (threadIdx.x < kIcpTerms) ? ((sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x])) : 0.0f;
-}
+    // the record is stored, released and ticketed by wave 0 alone: an agent-scope release writes the
+    // L2 of this XCD back, and executed by all 256 lanes of 512 workgroups it cost 40 us per round
+    if (wave == 0) {
+        if (threadIdx.x < kIcpStride) {
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kIcpThreads / kWave; ++w) v += sm[w][threadIdx.x];
+            partials[(size_t)blockIdx.x * kIcpStride + threadIdx.x] = (threadIdx.x < kIcpTerms) ? v : 0.0f;
+        }
+        __threadfence();
+        if (threadIdx.x == 0) isLast = atomicAdd(&state->ticket, 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!isLast) return;
 
-// One workgroup adds the partial records: lane (part, k) sums every 8th record, then the 8 parts.
-__global__ __launch_bounds__(256) void icp_finalize_kernel(const float *__restrict__ partials, int32_t numBlocks,
-                                                           float *__restrict__ out)
-{
-    __shared__ float sm[8][kIcpStride];
+    // last workgroup: lane (part, k) of the first 256 adds every 8th record, then the 8 parts.  The
+    // records are read 16 at a time into registers so that the loads are in flight together (one
+    // dependent load after the other cost 40 us here); they were written by other compute units
+    // before their ticket, and this workgroup's L1 has never held them.
     const int k = threadIdx.x & (kIcpStride - 1), part = threadIdx.x >> 5;
-    float s = 0.0f;
-    for (int b = part; b < numBlocks; b += 8) s += partials[(size_t)b * kIcpStride + k];
-    sm[part][k] = s;
+    const int numRecords = (int)gridDim.x;
+    if (threadIdx.x < 256) {
+        float s = 0.0f;
+        for (int b0 = part; b0 < numRecords; b0 += 8 * 16) {
+            float r[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int b = b0 + 8 * u;
+                r[u] = (b < numRecords) ? partials[(size_t)b * kIcpStride + k] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += r[u];
+        }
+        sm[part][k] = s;
+    }
     __syncthreads();
     if (threadIdx.x < kIcpStride) {
         float v = 0.0f;
 #pragma unroll
         for (int p = 0; p < 8; ++p) v += sm[p][threadIdx.x];
-        out[threadIdx.x] = v;
+        total[threadIdx.x] = v;
+        state->sums[threadIdx.x] = v;
     }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    state->ticket = 0;
+    state->rounds += 1;
+    if (!solve) return;
+    if (total[27] == 0.0f) { state->done = 1; return; }                 // CameraTracking.cpp:52
+    double JTJ[36], JTr[6], est[6];
+    int t = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) {
+            JTJ[6 * a + b] = JTJ[6 * b + a] = (double)total[t];
+            ++t;
+        }
+    for (int a = 0; a < 6; ++a) { JTr[a] = (double)total[21 + a]; est[a] = state->est[a]; }
+    if (!icp_solve_d(JTJ, JTr, est)) { state->done = 1; state->singular = 1; return; }
+    double T[16];
+    se3_exp_d(est, T);
+    for (int a = 0; a < 6; ++a) state->est[a] = est[a];
+    for (int i = 0; i < 16; ++i) state->delta[i] = (float)T[i];
 }
 
 // float depth image in metres -> vertex + normal maps: preProcess (CameraTrackingUtils.cu:50-113)
