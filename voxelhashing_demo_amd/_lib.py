@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvoxelhash_hip.so")
+LIB_PATH = os.environ.get("VOXELHASH_LIB") or os.path.join(_HERE, "lib", "libvoxelhash_hip.so")   # override: tuning builds
 FACADE_PATH = os.path.join(_HERE, "lib", "libsdf_hashtable.so")
 
 VH_OK = 0

@@ -53,7 +53,7 @@ __device__ __forceinline__ void walk_mask_tile(const DevPtrs &dp, uint32_t numEn
 #pragma unroll
     for (int j = 0; j < kEntriesPerLane; ++j) {
         const unsigned long long m = __ballot(ptrs[j] != VH_FREE_BLOCK);
-        if (lane == 0) dp.allocMask[(size_t)tileIndex * 32 + j * 4 + wave] = m;
+        if (lane == 0) dp.allocMask[(size_t)tileIndex * (kEntriesPerLane * 4) + j * 4 + wave] = m;
     }
 }
 

@@ -22,8 +22,11 @@ namespace vh {
 // reference also clears the whole compact table first (VoxelUtils.cu:757-758, its own
 // TODO calls it redundant); that pass is dropped.
 constexpr int kFlattenThreads = 256;
-constexpr int kEntriesPerLane = 8;
-constexpr int kChunksPerLane = 8;
+#ifndef VH_ENTRIES_PER_LANE
+#define VH_ENTRIES_PER_LANE 8
+#endif
+constexpr int kEntriesPerLane = VH_ENTRIES_PER_LANE;   // tuning knob (make EXTRA=-DVH_ENTRIES_PER_LANE=n)
+constexpr int kChunksPerLane = kEntriesPerLane;
 enum WalkKind : int {
     kWalkStridedNT = 0, kWalkStrided = 1, kWalkWide = 2, kWalkStridedBallot = 3, kWalkIndexed = 4, kWalkPersistent = 5,
     kWalkMask = 6      // fused frame only: launch 1 stores allocation masks, launch 2 consumes them
