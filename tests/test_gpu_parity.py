@@ -352,3 +352,23 @@ def test_negative_depth_vertices_are_processed_like_the_reference(oracle, vh, to
     _run(ot, gt, torch_cuda, [(I4, verts), (I4, verts)])
     _compare(ot, gt)
     assert ot.last_stats["pixels_valid"] == 640 * 480
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_hostile_vertex_values(oracle, vh, torch_cuda, sem):
+    """NaN, +-inf, denormals, huge magnitudes (block indices beyond the int range), negative and tiny
+    depths and w != 1 sprinkled over a frame, with a pose that is not rigid: the GPU follows the oracle
+    through every saturating conversion and wrapping product (SURVEY.md H2, H5, T2 sentinel)."""
+    ot, gt = _pair(oracle, vh, sem, numBuckets=1 << 12, numVoxelBlocks=8192)
+    verts = synth.sphere_inside_scene()
+    rng = np.random.RandomState(11)
+    H, W = verts.shape[:2]
+    specials = np.array([np.nan, np.inf, -np.inf, 1e-42, -1e-42, 3e38, -3e38, 1e9, -1e9, 4.3e7, -4.3e7, 1e-7, -0.0,
+                         2147483.6, -2147483.6], np.float32)
+    for comp in range(4):
+        ys, xs = rng.randint(0, H, 600), rng.randint(0, W, 600)
+        verts[ys, xs, comp] = specials[rng.randint(0, len(specials), 600)]
+    pose = np.array([[1.1, 0.05, 0, 0.1], [0, 0.9, 0.1, -0.05], [0.02, 0, 1.0, 0.2], [0, 0, 0, 1]], np.float32)
+    _run(ot, gt, torch_cuda, [(I4, verts), (pose, verts), (I4, verts)])
+    assert gt.counters()["heap_exhausted"] == 0
+    _compare(ot, gt)

@@ -11,7 +11,7 @@ namespace vh {
 // Reads the bucket of `key` the way insertVoxelEntry scans it (VoxelUtils.cu:436-456):
 // present -> nothing to do; otherwise, if a free slot exists, stake a claim.
 // Allocated entries always form a prefix of the bucket (insertions take the
-// first free slot, nothing is ever deleted), so "present anywhere" equals the
+// first free slot, deletion closes the gap: vh_gc.hip), so "present anywhere" equals the
 // reference's in-order scan.
 __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz,
                                                 uint32_t h, uint32_t rank, int candCounter = kCandCount)
