@@ -111,21 +111,6 @@ __device__ __forceinline__ int world2voxel1(float p, float voxelSize)
     return f2i_rz(q + __builtin_copysignf(0.5f, q));
 }
 
-// The same voxel index without the divide, for instruction-bound callers (the raycast spends a
-// quarter of its VALU work in three IEEE divides per sample).  q' = p * fl(1/voxelSize) is within
-// 3 ulp of the exact quotient, so round(q') equals round(q) whenever q' + 0.5 is not within
-// ~5 ulp of an integer; only then (about one sample in 10^4) the exact divide is redone.
-__device__ __forceinline__ int world2voxel1_fast(float p, float voxelSize, float rcpVoxelSize)
-{
-    const float q = p * rcpVoxelSize;
-    const float s = q + __builtin_copysignf(0.5f, q);
-    const float a = __builtin_fabsf(s);
-    const float f = a - __builtin_floorf(a);
-    const float eps = a * 4.0e-7f + 1.0e-6f;
-    if (f > eps && f < 1.0f - eps && a < 1.0e6f) return f2i_rz(s);
-    return world2voxel1(p, voxelSize);
-}
-
 // voxel2Block, VoxelUtils.cu:266-278: floor division by 8
 __device__ __forceinline__ int voxel2block1(int v)
 {

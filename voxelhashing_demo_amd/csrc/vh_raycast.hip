@@ -31,10 +31,19 @@ __device__ __forceinline__ int lookup_block(const FrameParams &fp, const DevPtrs
 // consecutive valid samples with sdf_prev > 0 >= sdf_cur, linear interpolation.
 // 16x16-pixel tiles: a wave is a 16x4 patch of neighbouring rays, which walk
 // the same blocks and keep the bucket / voxel lines hot in L2.
-constexpr float kSkipMargin = 0.01f;     // voxels; see the empty-block skip below
-// kRayBatch (template): in-block samples whose voxels are fetched together
+//
+// Empty space.  A sample in an absent block (or in a macro cell of 4x4x4 blocks that holds no
+// block) is invalid whatever its voxel index, so whole runs of such samples are skipped -- but
+// only samples that are CERTAINLY in the empty cell: the linear ray model o + d*t used for the
+// bounds differs from the sample positions T*(dx*t, dy*t, t) by ~1e-6 m, and the cell is shrunk by
+// kSkipMargin voxels per side (1e-2 voxel = 2e-4 m at 2 cm voxels) when it is intersected.  The
+// ray jumps to the last sample certainly inside; the next sample is evaluated exactly, like the
+// oracle evaluates every sample, and tells which cell comes next.
+// Measured and dropped: adopting the neighbouring cell after a clear single-face
+// exit without evaluating that sample (bit-equal, but the lanes of a wave then sit in different
+// code paths: 47 -> 64 us), fetching a ray's next in-block voxels together, a divide-free voxel index.
+constexpr float kSkipMargin = 0.01f;     // voxels
 
-template <int kRayBatch, bool kFastDiv>
 __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, const DevPtrs dp, float fx, float fy,
                                                       float cx, float cy, float tMin, int nSteps,
                                                       float *__restrict__ depthOut)
@@ -46,25 +55,23 @@ __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, cons
     const float dy = ((float)v - cy) / fy;
     const float dt = fp.voxelSize;
     const float invDt = __builtin_amdgcn_rcpf(dt) * (1.0f - 1.0e-6f);   // never over-estimates a step count
-    const float rcpVoxel = 1.0f / fp.voxelSize;                          // correctly rounded (world2voxel1_fast)
-    // world-space ray per unit of camera depth (only used to bound empty-block skips)
-    const float dirX = fp.T[0] * dx + fp.T[1] * dy + fp.T[2];
-    const float dirY = fp.T[4] * dx + fp.T[5] * dy + fp.T[6];
-    const float dirZ = fp.T[8] * dx + fp.T[9] * dy + fp.T[10];
-    const float rayD[3] = {dirX, dirY, dirZ}, rayO[3] = {fp.T[3], fp.T[7], fp.T[11]};
+    // world-space ray per unit of camera depth (only used to bound empty-cell skips)
+    const float rayD[3] = {fp.T[0] * dx + fp.T[1] * dy + fp.T[2], fp.T[4] * dx + fp.T[5] * dy + fp.T[6],
+                           fp.T[8] * dx + fp.T[9] * dy + fp.T[10]};
+    const float rayO[3] = {fp.T[3], fp.T[7], fp.T[11]};
     float invD[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) invD[a] = (rayD[a] != 0.0f) ? __builtin_amdgcn_rcpf(rayD[a]) : 0.0f;
-    bool prevValid = false, haveKey = false, found = false, haveMacro = false, macroEmpty = false;
+    bool prevValid = false, haveKey = false, haveMacro = false, macroEmpty = false;
     float prevSdf = 0.0f, prevT = 0.0f, hit = 0.0f;
     int ckx = 0, cky = 0, ckz = 0, cptr = VH_FREE_BLOCK;
     int cmx = 0, cmy = 0, cmz = 0;
     for (int i = 0; i < nSteps; ++i) {
         const float tt = tMin + (float)i * dt;
         const float4 pw = mat4_mul(fp.T, dx * tt, dy * tt, tt, 1.0f);
-        const int vx = kFastDiv ? world2voxel1_fast(pw.x, fp.voxelSize, rcpVoxel) : world2voxel1(pw.x, fp.voxelSize);
-        const int vy = kFastDiv ? world2voxel1_fast(pw.y, fp.voxelSize, rcpVoxel) : world2voxel1(pw.y, fp.voxelSize);
-        const int vz = kFastDiv ? world2voxel1_fast(pw.z, fp.voxelSize, rcpVoxel) : world2voxel1(pw.z, fp.voxelSize);
+        const int vx = world2voxel1(pw.x, fp.voxelSize);
+        const int vy = world2voxel1(pw.y, fp.voxelSize);
+        const int vz = world2voxel1(pw.z, fp.voxelSize);
         const int kx = voxel2block1(vx), ky = voxel2block1(vy), kz = voxel2block1(vz);
         if (!haveKey || kx != ckx || ky != cky || kz != ckz) {
             ckx = kx; cky = ky; ckz = kz;
@@ -79,11 +86,6 @@ __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, cons
             cptr = macroEmpty ? VH_FREE_BLOCK : lookup_block(fp, dp, kx, ky, kz);
         }
         if (cptr == VH_FREE_BLOCK) {
-            // Empty block: every further sample inside it is invalid too, so jump to the last
-            // sample that is CERTAINLY still inside (cell shrunk by kSkipMargin voxels per side:
-            // 1e-2 voxel = 2e-4 m at 2 cm voxels, against ~1e-6 m of fp32 difference between this
-            // linear ray model and the sample positions above).  Skipping only such samples
-            // leaves the result unchanged.
             prevValid = false;
             float tExit = 3.0e38f;
             // an empty macro cell (no block in 4x4x4) is skipped whole: 32 voxels per side
@@ -103,44 +105,17 @@ __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, cons
             if (steps > (float)i && steps < 2.0e9f) i = min((int)steps, nSteps - 1);
             continue;
         }
-        // Present block: the voxel of sample i and of the next kRayBatch-1 samples that still
-        // fall into this block are fetched together (their addresses do not depend on each
-        // other, only the hit test is sequential), so a ray pays one memory latency per batch
-        // instead of one per sample.  Samples are then classified strictly in order.
-        float bt[kRayBatch];
-        Voxel bs[kRayBatch];
-        bool inBlock[kRayBatch];
-#pragma unroll
-        for (int j = 0; j < kRayBatch; ++j) {
-            bt[j] = tMin + (float)(i + j) * dt;
-            const float4 pj = mat4_mul(fp.T, dx * bt[j], dy * bt[j], bt[j], 1.0f);
-            const int jx = kFastDiv ? world2voxel1_fast(pj.x, fp.voxelSize, rcpVoxel) : world2voxel1(pj.x, fp.voxelSize);
-            const int jy = kFastDiv ? world2voxel1_fast(pj.y, fp.voxelSize, rcpVoxel) : world2voxel1(pj.y, fp.voxelSize);
-            const int jz = kFastDiv ? world2voxel1_fast(pj.z, fp.voxelSize, rcpVoxel) : world2voxel1(pj.z, fp.voxelSize);
-            inBlock[j] = (i + j < nSteps) && voxel2block1(jx) == kx && voxel2block1(jy) == ky &&
-                         voxel2block1(jz) == kz;
-            const int lx = (int)((uint32_t)jx - (uint32_t)kx * 8u);
-            const int ly = (int)((uint32_t)jy - (uint32_t)ky * 8u);
-            const int lz = (int)((uint32_t)jz - (uint32_t)kz * 8u);
-            bs[j] = inBlock[j] ? dp.blocks[(size_t)cptr + (size_t)(lz * 64 + ly * 8 + lx)] : Voxel{0.0f, 0.0f};
+        // present block: classify the sample from its voxel
+        const int lx = (int)((uint32_t)vx - (uint32_t)kx * 8u);
+        const int ly = (int)((uint32_t)vy - (uint32_t)ky * 8u);
+        const int lz = (int)((uint32_t)vz - (uint32_t)kz * 8u);
+        const Voxel s = dp.blocks[(size_t)cptr + (size_t)(lz * 64 + ly * 8 + lx)];
+        if (!(s.weight > 0.0f)) { prevValid = false; continue; }
+        if (prevValid && prevSdf > 0.0f && s.sdf <= 0.0f) {
+            hit = prevT + (dt * prevSdf) / (prevSdf - s.sdf);
+            break;
         }
-        bool done = false;
-        int used = 0;
-#pragma unroll
-        for (int j = 0; j < kRayBatch; ++j) {
-            if (done || !inBlock[j]) { done = true; continue; }   // first sample outside: back to the general path
-            used = j + 1;
-            if (!(bs[j].weight > 0.0f)) { prevValid = false; continue; }
-            if (prevValid && prevSdf > 0.0f && bs[j].sdf <= 0.0f) {
-                hit = prevT + (dt * prevSdf) / (prevSdf - bs[j].sdf);
-                found = true;
-                done = true;
-                continue;
-            }
-            prevValid = true; prevSdf = bs[j].sdf; prevT = bt[j];
-        }
-        if (found) break;
-        i += used - 1;            // sample i itself is always in the block, so used >= 1
+        prevValid = true; prevSdf = s.sdf; prevT = tt;
     }
     depthOut[(size_t)v * fp.width + u] = hit;
 }
