@@ -70,6 +70,7 @@ struct vh_context {
     vh_kernel_times times{};
     int integrateGrid = 2048;
     int persistentBlocks = 2048;   // workgroups of the persistent walk (flatten_variant 5)
+    int raycastPatch = 1;          // pixels of a raycast wave: 1 = 8x8 square, 0 = 16x4 rows
     int fusedFrame = 1;            // vh_integrate as two launches (0: the four step kernels)
     int commitBlocks = 128;        // workgroups serving candidates in the fused second launch
     int fusedParity = 0;           // which of the two per-frame counter sets the next fused frame uses
@@ -617,8 +618,11 @@ extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, floa
     dim3 grid((fp.width + 15) / 16, (fp.height + 15) / 16);
     DevPtrs dp = c->dp;
     if (c->viewBlocks) dp.blocks = const_cast<Voxel *>(c->viewBlocks);     // view table: voxels live in the records
-    const int rc = launch(c, kPhaseRaycast, raycast_kernel, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy, c->rc_cx,
-                          c->rc_cy, t_min, nsteps, d_depth_out);
+    const int rc = c->raycastPatch
+                       ? launch(c, kPhaseRaycast, raycast_kernel<1>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy,
+                                c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out)
+                       : launch(c, kPhaseRaycast, raycast_kernel<0>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy,
+                                c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -1117,6 +1121,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (std::strcmp(name, "flatten_variant") == 0) { c->flattenVariant = value; return VH_OK; }
     if (std::strcmp(name, "integrate_grid") == 0 && value > 0) { c->integrateGrid = value; return VH_OK; }
     if (std::strcmp(name, "fused_frame") == 0) { c->fusedFrame = value; return VH_OK; }
+    if (std::strcmp(name, "raycast_patch") == 0) { c->raycastPatch = value; return VH_OK; }
     if (std::strcmp(name, "persistent_blocks") == 0 && value > 0) { c->persistentBlocks = value; return VH_OK; }
     if (std::strcmp(name, "commit_blocks") == 0 && value > 0) { c->commitBlocks = value; return VH_OK; }
     return fail(VH_ERR_INVALID_ARGUMENT, "unknown option");

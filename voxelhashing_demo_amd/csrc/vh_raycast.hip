@@ -44,12 +44,15 @@ __device__ __forceinline__ int lookup_block(const FrameParams &fp, const DevPtrs
 // code paths: 47 -> 64 us), fetching a ray's next in-block voxels together, a divide-free voxel index.
 constexpr float kSkipMargin = 0.01f;     // voxels
 
+// kPatch: pixels of a wave inside the 16x16 tile: 0 = 16x4 rows, 1 = 8x8 square
+template <int kPatch>
 __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, const DevPtrs dp, float fx, float fy,
                                                       float cx, float cy, float tMin, int nSteps,
                                                       float *__restrict__ depthOut)
 {
-    const int u = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int v = blockIdx.y * 16 + (threadIdx.x >> 4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = blockIdx.x * 16 + (kPatch == 0 ? (int)(threadIdx.x & 15) : (wave & 1) * 8 + (lane & 7));
+    const int v = blockIdx.y * 16 + (kPatch == 0 ? (int)(threadIdx.x >> 4) : (wave >> 1) * 8 + (lane >> 3));
     if (u >= fp.width || v >= fp.height) return;
     const float dx = ((float)u - cx) / fx;
     const float dy = ((float)v - cy) / fy;
