@@ -149,7 +149,10 @@ __global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, 
 // (one address sustains only ~90 returning atomics per microsecond) a 1024-lane
 // workgroup first counts its keys per owner in LDS and then takes one global
 // atomicAdd per owner it actually has keys for.
-constexpr int kGenThreads = 1024;
+#ifndef VH_GEN_THREADS
+#define VH_GEN_THREADS 1024
+#endif
+constexpr int kGenThreads = VH_GEN_THREADS;   // tuning knob (make EXTRA=-DVH_GEN_THREADS=n)
 
 __global__ __launch_bounds__(kGenThreads) void generate_keys_kernel(const FrameParams fp,
                                                                     const float4 *__restrict__ verts,
