@@ -154,17 +154,14 @@ __global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, 
 #endif
 constexpr int kGenThreads = VH_GEN_THREADS;   // tuning knob (make EXTRA=-DVH_GEN_THREADS=n)
 
-__global__ __launch_bounds__(kGenThreads) void generate_keys_kernel(const FrameParams fp,
-                                                                    const float4 *__restrict__ verts,
-                                                                    int32_t numShards, int4 *__restrict__ outBins,
-                                                                    int32_t outCapacity, int32_t outBinStride,
-                                                                    float *__restrict__ outDepth, uint32_t rankBase)
+__device__ __forceinline__ void generate_keys_tile(const FrameParams &fp, const float4 *__restrict__ verts,
+                                                   int32_t numShards, int4 *__restrict__ outBins,
+                                                   int32_t outCapacity, int32_t outBinStride,
+                                                   float *__restrict__ outDepth, uint32_t rankBase, uint32_t tile)
 {
     __shared__ int ldsCount[VH_MAX_CAMERAS];
     __shared__ int ldsBase[VH_MAX_CAMERAS];
-    if (outDepth && blockIdx.x == 0 && threadIdx.x < kPacketHeader)      // packet header: pose, inverse
-        outDepth[(int)threadIdx.x - kPacketHeader] = threadIdx.x < 16 ? fp.T[threadIdx.x] : fp.Tinv[threadIdx.x - 16];
-    const PixelVertex p = load_pixel(fp, verts, blockIdx.x * kGenThreads + threadIdx.x, outDepth);
+    const PixelVertex p = load_pixel(fp, verts, tile * kGenThreads + threadIdx.x, outDepth);
     float step;
     const int nS = band_samples(fp, step);
     const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
@@ -191,6 +188,48 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_kernel(const FrameP
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(kGenThreads) void generate_keys_kernel(const FrameParams fp,
+                                                                    const float4 *__restrict__ verts,
+                                                                    int32_t numShards, int4 *__restrict__ outBins,
+                                                                    int32_t outCapacity, int32_t outBinStride,
+                                                                    float *__restrict__ outDepth, uint32_t rankBase)
+{
+    if (outDepth && blockIdx.x == 0 && threadIdx.x < kPacketHeader)      // packet header: pose, inverse
+        outDepth[(int)threadIdx.x - kPacketHeader] = threadIdx.x < 16 ? fp.T[threadIdx.x] : fp.Tinv[threadIdx.x - 16];
+    generate_keys_tile(fp, verts, numShards, outBins, outCapacity, outBinStride, outDepth, rankBase, blockIdx.x);
+}
+
+// Up to kGenBatch frames of one camera in ONE launch (blockIdx.y = frame): a single frame is 300
+// latency-bound workgroups, which leave most of the chip idle; the frames of an exchange batch run
+// side by side instead of one after the other.  Poses and vertex-map pointers travel in the kernel
+// arguments.
+constexpr int kGenBatch = 8;
+struct GenFrames {
+    float T[kGenBatch][16];
+    float Tinv[kGenBatch][16];
+    const float4 *verts[kGenBatch];
+};
+
+__global__ __launch_bounds__(kGenThreads) void generate_keys_batch_kernel(FrameParams fp, const GenFrames fr,
+                                                                          int32_t numShards,
+                                                                          int4 *__restrict__ outBins,
+                                                                          int32_t outCapacity, int32_t outBinStride,
+                                                                          int32_t frameStride,
+                                                                          float *__restrict__ packets,
+                                                                          size_t packetFrameStride, uint32_t rankBase)
+{
+    const int b = blockIdx.y;
+    float *outDepth = packets ? packets + packetFrameStride * b + kPacketHeader : nullptr;
+    // (the header is written from the argument block: indexing the private copy of fp by lane
+    // would push it to scratch memory)
+    if (outDepth && blockIdx.x == 0 && threadIdx.x < kPacketHeader)
+        outDepth[(int)threadIdx.x - kPacketHeader] = threadIdx.x < 16 ? fr.T[b][threadIdx.x] : fr.Tinv[b][threadIdx.x - 16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { fp.T[i] = fr.T[b][i]; fp.Tinv[i] = fr.Tinv[b][i]; }
+    generate_keys_tile(fp, fr.verts[b], numShards, outBins + (size_t)frameStride * b, outCapacity, outBinStride,
+                       outDepth, rankBase, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------

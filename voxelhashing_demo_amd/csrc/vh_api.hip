@@ -777,8 +777,8 @@ extern "C" int vh_generate_keys(vh_context *c, const vh_float4 *verts, uint32_t 
     return VH_OK;
 }
 
-// `batch` frames of one camera in one call: one launch zeroes all bin headers, then one
-// generate_keys_kernel per frame (each with its own pose in the kernel arguments).
+// `batch` frames of one camera in one call: one launch zeroes all bin headers, then one launch per
+// kGenBatch frames (blockIdx.y = frame, poses and vertex-map pointers in the kernel arguments).
 extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float *poses,
                                       const vh_float4 *const *d_verts, uint32_t camera_id, int32_t num_shards,
                                       int32_t *d_bins, int32_t capacity, int32_t bin_stride, int32_t frame_stride,
@@ -797,15 +797,22 @@ extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float 
     const int npix = c->fp.width * c->fp.height;
     prepare_bins_kernel<<<grid_for((size_t)num_shards * batch, 256), 256, 0, c->stream>>>(
         reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, batch, frame_stride);
-    for (int b = 0; b < batch; ++b) {
-        int rc = vh_set_pose(c, poses + 16 * b);
-        if (rc != VH_OK) return rc;
-        if (!d_verts[b]) return fail(VH_ERR_INVALID_ARGUMENT, "null vertex map");
-        float *packet = d_packets ? d_packets + packet_frame_stride * b : nullptr;
-        generate_keys_kernel<<<grid_for(npix, kGenThreads), kGenThreads, 0, c->stream>>>(
-            c->fp, reinterpret_cast<const float4 *>(d_verts[b]), num_shards,
-            reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b, capacity, bin_stride,
-            packet ? packet + kPacketHeader : nullptr, camera_id << kRankCameraShift);
+    for (int b0 = 0; b0 < batch; b0 += kGenBatch) {
+        const int n = std::min<int>(kGenBatch, batch - b0);
+        GenFrames fr;
+        std::memset(&fr, 0, sizeof fr);
+        for (int j = 0; j < n; ++j) {
+            const int rc = vh_set_pose(c, poses + 16 * (size_t)(b0 + j));        // pose + cofactor inverse
+            if (rc != VH_OK) return rc;
+            if (!d_verts[b0 + j]) return fail(VH_ERR_INVALID_ARGUMENT, "null vertex map");
+            std::memcpy(fr.T[j], c->fp.T, sizeof fr.T[j]);
+            std::memcpy(fr.Tinv[j], c->fp.Tinv, sizeof fr.Tinv[j]);
+            fr.verts[j] = reinterpret_cast<const float4 *>(d_verts[b0 + j]);
+        }
+        generate_keys_batch_kernel<<<dim3((unsigned)grid_for(npix, kGenThreads), (unsigned)n), kGenThreads, 0, c->stream>>>(
+            c->fp, fr, num_shards, reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
+            frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
+            camera_id << kRankCameraShift);
     }
     VH_HIP(hipGetLastError());
     return VH_OK;
