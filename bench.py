@@ -307,8 +307,10 @@ def main():
         frame_algorithmic_bytes=b_frame, frame_algorithmic_gbs=round(frame_gbs, 1),
         frame_frac_of_hbm_peak=round(frame_gbs / HBM_PEAK_GBS, 4),
     )
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    trk.close()            # contexts go while the torch stream they were bound to is still alive
     table.close()
+    torch.cuda.synchronize()
 
 
 if __name__ == "__main__":

@@ -351,7 +351,9 @@ extern "C" int vh_destroy(vh_context *c)
 {
     if (!c) return VH_OK;
     DeviceGuard guard(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    // the whole device, not c->stream: the caller's stream object may already be gone when a
+    // language binding destroys the context late (interpreter exit)
+    (void)hipDeviceSynchronize();
     drop_events(c);
     free_buffers(c);
     delete c;

@@ -48,7 +48,7 @@ extern "C" int vh_icp_destroy(vh_icp *p)
 {
     if (!p) return VH_OK;
     DeviceGuard guard(p->device);
-    (void)hipStreamSynchronize(p->stream);
+    (void)hipDeviceSynchronize();      // not p->stream: the caller's stream object may already be gone
     (void)hipFree(p->partials);
     (void)hipFree(p->state);
     (void)hipHostFree(p->hostState);

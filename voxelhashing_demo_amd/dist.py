@@ -538,7 +538,7 @@ def bench_sharded(args, wl, rank, world, local_rank):
         # raycast over the shards (extra, after the timed region).  With more than one rank it runs
         # only on request: the default multi-GPU run is the integration benchmark alone.
         do_raycast = world == 1 or getattr(args, "sharded_raycast", False)
-        rc_elapsed, rc_iters, lost_total, view_cap, kte, ktv = 0.0, 20, 0, 8192, None, None
+        rc_elapsed, rc_iters, lost_total, view_cap, kte, ktv, view = 0.0, 20, 0, 8192, None, None, None
         if do_raycast:
             view = HipViewTable(params, Wd, Ht, SEM_PINHOLE, world, view_cap, device=dev, stream=stream)
             for i in range(2):
@@ -602,6 +602,13 @@ def bench_sharded(args, wl, rank, world, local_rank):
                 note="every rank renders its own camera's view of the whole table: one walk of its shard for "
                      "all views, all-to-all of {key, 512 voxels} records, import into a view table, raycast; "
                      "bit-equal to a raycast of the unsharded table")
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    # orderly teardown while the streams the contexts were bound to are still alive (a context
+    # destroyed by the garbage collector at interpreter exit synchronises a stream torch may
+    # already have released)
+    if view is not None:
+        view.table.close()
     shard.table.close()
+    torch.cuda.synchronize()
+    dist.barrier()
     dist.destroy_process_group()
