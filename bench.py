@@ -81,7 +81,13 @@ def main():
     if world > 1 or args.sharded:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one node by contract: keep RCCL's bootstrap and the c10d store on the loop-back interface
+        # (the container's hostname may not resolve), and surface a stuck collective in minutes
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        import datetime
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=300))
         from voxelhashing_demo_amd import dist as vdist
         return vdist.bench_sharded(args, WORKLOADS[args.workload], rank, world, local_rank)
 
