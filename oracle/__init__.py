@@ -291,7 +291,10 @@ class OracleTable:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: module globals may already be gone
+            pass
 
     def set_projection(self, m):
         a = np.ascontiguousarray(np.asarray(m, np.float32).reshape(9))
