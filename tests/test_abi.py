@@ -84,3 +84,16 @@ def test_facade_library_links(vh):
     for s in ("SDF_Hashtable::SDF_Hashtable()", "SDF_Hashtable::integrate(float4x4 const&, vh_float4 const*, vh_float4 const*)",
               "SDF_Hashtable::raycast(float4x4 const&, float*, float, float)", "SDF_Hashtable::~SDF_Hashtable()"):
         assert s in syms, s
+
+
+def test_headers_compile_as_c99_and_cxx11(tmp_path):
+    """The boundary is a plain C header (and two C++ facade headers): no torch, no HIP types."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    c = tmp_path / "t.c"
+    c.write_text('#include "voxelhash.h"\nint main(void) { return (int)sizeof(vh_icp_system) + (int)sizeof(vh_view_record); }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(c)], check=True)
+    cpp = tmp_path / "t.cpp"
+    cpp.write_text('#include "voxelhash.h"\n#include "SDF_Hashtable.h"\n#include "CameraTracking.h"\nint main() { return 0; }\n')
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(cpp)],
+                   check=True)
