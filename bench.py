@@ -80,7 +80,11 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1 or args.sharded:
         if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+            import socket
+            with socket.socket() as sk:              # direct (not torchrun) launch with --sharded: any free port
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
         # one node by contract: keep RCCL's bootstrap and the c10d store on the loop-back interface
         # (the container's hostname may not resolve), and surface a stuck collective in minutes
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")

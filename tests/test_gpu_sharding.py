@@ -4,7 +4,7 @@ each shard must equal its slice of ONE unsharded oracle table after the same mul
 import numpy as np
 import pytest
 
-from test_sharding_cpu import check_shard_against_full
+from test_sharding_cpu import _free_port, check_shard_against_full
 from voxelhashing_demo_amd import dist as vdist
 from voxelhashing_demo_amd import synth
 
@@ -90,7 +90,7 @@ def test_pipelined_steps_equal_sequential_over_nccl(oracle, vh, torch_cuda):
     import torch.distributed as dist
     torch = torch_cuda
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ["MASTER_PORT"] = str(_free_port())        # a fixed port may still be held by an earlier run
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         plan = vdist.ShardPlan(KW["numBuckets"], 1)

@@ -5,6 +5,7 @@ table bit for bit."""
 import numpy as np
 import pytest
 
+from test_sharding_cpu import _free_port
 from voxelhashing_demo_amd import dist as vdist
 from voxelhashing_demo_amd import synth
 
@@ -143,7 +144,7 @@ def test_sharded_raycast_over_nccl(oracle, vh, torch_cuda):
     import torch.distributed as dist
     torch = torch_cuda
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29543")
+    os.environ["MASTER_PORT"] = str(_free_port())        # a fixed port may still be held by an earlier run
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         plan, shards, full = build(oracle, vh, torch, 1, 1)
