@@ -274,6 +274,23 @@ int vh_generate_keys_batch(vh_context *ctx, int32_t batch, const float *poses,
 int vh_apply_frames_batch(vh_context *ctx, int32_t batch, const int32_t *d_bins, int32_t num_bins,
                           int32_t capacity, int32_t bin_stride, int32_t frame_stride, int32_t num_cams,
                           const float *d_packets, size_t packet_stride, size_t packet_frame_stride);
+/* Camera packet formats (what vh_integrate_packets / vh_apply_frames_batch read; chosen per context
+ * with vh_set_option(ctx, "packet_format", ...)).  Strides stay in 4-byte units.
+ *   VH_PACKET_F32: 32 floats {pose, inverse pose} + W*H float camera-z plane (written by
+ *                  vh_generate_keys / vh_generate_keys_batch when d_packet(s) is given)
+ *   VH_PACKET_U16: 36 floats {pose, inverse pose, K_inv row 2, depth unit 5000} + the W*H uint16
+ *                  sensor image (W*H even): half the bytes on the wire; the owner recomputes the
+ *                  camera z as preProcess does, (K_inv row 2 . (x,y,1)) * (d / 5000), so the result
+ *                  equals the float path on vertex maps made by vh_preprocess from the same image. */
+#define VH_PACKET_F32 0
+#define VH_PACKET_U16 1
+/* Sensor-depth packets of `batch` frames of this camera (poses: batch*16 host floats; d_depth: host
+ * array of `batch` device pointers to W*H uint16; packet of frame b at d_packets[b*packet_frame_stride],
+ * 0 = dense = 36 + W*H/2).  Keys for the same frames: vh_generate_keys_batch with d_packets = NULL on
+ * the vertex maps vh_preprocess made from these images. */
+int vh_write_packets_u16_batch(vh_context *ctx, int32_t batch, const float *poses,
+                               const uint16_t *const *d_depth, const float k_inv[9], float *d_packets,
+                               size_t packet_frame_stride);
 
 /* ------------------------------------------------------------------ */
 /* raycast over shards ("replicate the compact table +   */

@@ -149,3 +149,45 @@ def test_sharded_band_allocation(oracle, vh, torch_cuda):
         total += check_shard_against_full(sh.table, full, *plan.bucket_range(r), 5)
         assert sh.table.counters()["bin_overflow"] == 0
     assert total == len(full.allocated()) > 500
+
+
+@pytest.mark.parametrize("world,batch", [(2, 1), (4, 2)])
+@pytest.mark.parametrize("sem", [0, 1])
+@pytest.mark.parametrize("calls", ["batched", "stepwise"])
+def test_sensor_depth_packets(oracle, vh, torch_cuda, world, batch, sem, calls):
+    """VH_PACKET_U16: the packets carry the uint16 sensor image (half the bytes of the float camera-z
+    plane) and the owner recomputes z like preProcess.  Vertex maps come from preProcess on the same
+    images; the oracle side keeps float packets.  Shards must equal the one oracle table bit for bit."""
+    torch = torch_cuda
+    K = synth.K_matrix(W, H)
+    kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    plan = vdist.ShardPlan(KW["numBuckets"], world)
+    shards = [vdist.HipShard(vh.default_params(**KW), W, H, sem, plan, r, W * H // 4, batch=batch,
+                             batched_calls=(calls == "batched"), sensor_k_inv=kinv) for r in range(world)]
+    full = oracle.OracleTable(oracle.default_params(**KW), W, H, sem)
+    for step in range(0, 4, batch):
+        frames = []
+        for b in range(batch):
+            cams = []
+            for pose, verts in cameras(world, step + b):
+                d16 = np.round(verts[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16)
+                d16[::9, ::7] = 0                                       # sensor holes
+                v = oracle.preprocess(d16, kinv)[0]
+                cams.append((pose, v, d16))
+            frames.append(cams)
+        vdist.loopback_step(shards, [[frames[b][r][0] for b in range(batch)] for r in range(world)],
+                            [[torch.from_numpy(frames[b][r][1]).cuda() for b in range(batch)] for r in range(world)],
+                            [[torch.from_numpy(frames[b][r][2]).cuda() for b in range(batch)] for r in range(world)])
+        for cams in frames:
+            vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+    total = 0
+    for r, sh in enumerate(shards):
+        sh.table.synchronize()
+        total += check_shard_against_full(sh.table, full, *plan.bucket_range(r), 5)
+        assert sh.table.counters()["bin_overflow"] == 0
+        assert sh.packet_floats == 36 + W * H // 2
+    assert total == len(full.allocated())
+    if sem == 1:
+        assert total > 100
+    for sh in shards:
+        sh.table.close()

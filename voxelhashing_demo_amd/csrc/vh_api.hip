@@ -71,6 +71,7 @@ struct vh_context {
     int integrateGrid = 2048;
     int persistentBlocks = 2048;   // workgroups of the persistent walk (flatten_variant 5)
     int raycastPatch = 1;          // pixels of a raycast wave: 1 = 8x8 square, 0 = 16x4 rows
+    int packetFormat = VH_PACKET_F32;   // what vh_integrate_packets / vh_apply_frames_batch read
     int fusedFrame = 1;            // vh_integrate as two launches (0: the four step kernels)
     int commitBlocks = 128;        // workgroups serving candidates in the fused second launch
     int fusedParity = 0;           // which of the two per-frame counter sets the next fused frame uses
@@ -762,6 +763,13 @@ extern "C" int vh_import_view(vh_context *c, const vh_view_record *d_records, in
 // ---------------------------------------------------------------------------
 // sharding
 // ---------------------------------------------------------------------------
+// 4-byte units of one camera packet in the context's packet format
+static size_t packet_units(const vh_context *c)
+{
+    const size_t npix = (size_t)c->fp.width * c->fp.height;
+    return c->packetFormat == VH_PACKET_U16 ? (size_t)kPacketHeaderU16 + (npix + 1) / 2 : (size_t)kPacketHeader + npix;
+}
+
 extern "C" int vh_generate_keys(vh_context *c, const vh_float4 *verts, uint32_t camera_id, int32_t num_shards,
                                 int32_t *d_bins, int32_t capacity, int32_t bin_stride, float *d_packet)
 {
@@ -820,6 +828,42 @@ extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float 
     return VH_OK;
 }
 
+// Sensor-depth packets (VH_PACKET_U16) of `batch` frames of this camera: pose + inverse + K_inv row 2 +
+// depth unit, then the uint16 image as it is.  The key generation for the same frames is
+// vh_generate_keys_batch with d_packets = NULL.
+extern "C" int vh_write_packets_u16_batch(vh_context *c, int32_t batch, const float *poses,
+                                          const uint16_t *const *d_depth, const float k_inv[9], float *d_packets,
+                                          size_t packet_frame_stride)
+{
+    if (!c || !poses || !d_depth || !k_inv || !d_packets || batch <= 0)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    const size_t npix = (size_t)c->fp.width * c->fp.height;
+    if (npix % 2) return fail(VH_ERR_INVALID_ARGUMENT, "sensor-depth packets need an even number of pixels");
+    const size_t dense = (size_t)kPacketHeaderU16 + npix / 2;
+    if (packet_frame_stride == 0) packet_frame_stride = dense;
+    if (packet_frame_stride < dense) return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
+    DeviceGuard guard(c->device);
+    for (int b0 = 0; b0 < batch; b0 += kGenBatch) {
+        const int n = std::min<int>(kGenBatch, batch - b0);
+        SensorFrames fr;
+        std::memset(&fr, 0, sizeof fr);
+        fr.k6 = k_inv[6]; fr.k7 = k_inv[7]; fr.k8 = k_inv[8];
+        fr.unit = 5000.0f;                                               // CameraTrackingUtils.cu:64
+        for (int j = 0; j < n; ++j) {
+            const int rc = vh_set_pose(c, poses + 16 * (size_t)(b0 + j));
+            if (rc != VH_OK) return rc;
+            if (!d_depth[b0 + j]) return fail(VH_ERR_INVALID_ARGUMENT, "null depth image");
+            std::memcpy(fr.T[j], c->fp.T, sizeof fr.T[j]);
+            std::memcpy(fr.Tinv[j], c->fp.Tinv, sizeof fr.Tinv[j]);
+            fr.depth[j] = d_depth[b0 + j];
+        }
+        write_packets_u16_kernel<<<dim3(64, (unsigned)n), 256, 0, c->stream>>>(
+            fr, (int32_t)npix, d_packets + packet_frame_stride * (size_t)b0, packet_frame_stride);
+    }
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
 // `batch` multi-camera frames applied one after the other, each as the fused pair of launches
 // (new lock epoch; {claim bins || walk}; {commit + integrate}).
 extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t *d_bins, int32_t num_bins,
@@ -829,7 +873,7 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
     if (!c || !d_bins || !d_packets || batch <= 0 || num_bins <= 0 || capacity < 2 || num_cams <= 0 ||
         num_cams > VH_MAX_CAMERAS)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
-    const size_t dense = (size_t)kPacketHeader + (size_t)c->fp.width * c->fp.height;
+    const size_t dense = packet_units(c);
     if (frame_stride == 0) frame_stride = capacity;
     if (bin_stride == 0) bin_stride = batch * frame_stride;
     if (packet_frame_stride == 0) packet_frame_stride = dense;
@@ -852,9 +896,13 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
                     (uint32_t)num_bins, parts, (uint32_t)c->numEntries, num_cams, packets, packet_stride,
                     c->fusedParity);
         if (rc == VH_OK)
-            rc = launch(c, kPhaseFrameCommitIntegrate, frame_multi_commit_integrate_kernel,
-                        dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, num_cams, packets,
-                        packet_stride, commitBlocks, c->fusedParity);
+            rc = c->packetFormat == VH_PACKET_U16
+                     ? launch(c, kPhaseFrameCommitIntegrate, frame_multi_commit_integrate_kernel<true>,
+                              dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, num_cams,
+                              packets, packet_stride, commitBlocks, c->fusedParity)
+                     : launch(c, kPhaseFrameCommitIntegrate, frame_multi_commit_integrate_kernel<false>,
+                              dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, num_cams,
+                              packets, packet_stride, commitBlocks, c->fusedParity);
         if (rc != VH_OK) return rc;
         c->fusedParity ^= 1;
         c->compactArmed = false;
@@ -886,7 +934,7 @@ extern "C" int vh_insert_bins(vh_context *c, const int32_t *d_bins, int32_t num_
 
 extern "C" int vh_integrate_packets(vh_context *c, int32_t num_cams, const float *d_packets, size_t packet_stride)
 {
-    const size_t dense = c ? (size_t)kPacketHeader + (size_t)c->fp.width * c->fp.height : 0;
+    const size_t dense = c ? packet_units(c) : 0;
     if (packet_stride == 0) packet_stride = dense;
     if (!c || !d_packets || num_cams <= 0 || num_cams > VH_MAX_CAMERAS || packet_stride < dense)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
@@ -900,8 +948,11 @@ extern "C" int vh_integrate_packets(vh_context *c, int32_t num_cams, const float
                     dim3(grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane)), dim3(kFlattenThreads), c->fp,
                     c->dp, (uint32_t)c->numEntries, num_cams, d_packets, stride);
     if (rc == VH_OK)
-        rc = launch(c, kPhaseIntegrate, integrate_multi_kernel, dim3(c->integrateGrid), dim3(256), c->fp, c->dp,
-                    num_cams, d_packets, stride);
+        rc = c->packetFormat == VH_PACKET_U16
+                 ? launch(c, kPhaseIntegrate, integrate_multi_kernel<true>, dim3(c->integrateGrid), dim3(256), c->fp, c->dp,
+                          num_cams, d_packets, stride)
+                 : launch(c, kPhaseIntegrate, integrate_multi_kernel<false>, dim3(c->integrateGrid), dim3(256), c->fp,
+                          c->dp, num_cams, d_packets, stride);
     if (rc != VH_OK) return rc;
     if (c->profiling) c->profiledFrames += 1;
     VH_HIP(hipGetLastError());
@@ -1131,6 +1182,10 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (std::strcmp(name, "integrate_grid") == 0 && value > 0) { c->integrateGrid = value; return VH_OK; }
     if (std::strcmp(name, "fused_frame") == 0) { c->fusedFrame = value; return VH_OK; }
     if (std::strcmp(name, "raycast_patch") == 0) { c->raycastPatch = value; return VH_OK; }
+    if (std::strcmp(name, "packet_format") == 0 && (value == VH_PACKET_F32 || value == VH_PACKET_U16)) {
+        c->packetFormat = value;
+        return VH_OK;
+    }
     if (std::strcmp(name, "persistent_blocks") == 0 && value > 0) { c->persistentBlocks = value; return VH_OK; }
     if (std::strcmp(name, "commit_blocks") == 0 && value > 0) { c->commitBlocks = value; return VH_OK; }
     return fail(VH_ERR_INVALID_ARGUMENT, "unknown option");

@@ -81,6 +81,11 @@ struct DevPtrs {
 
 // camera packet of the sharded path: 16 floats pose, 16 floats inverse, W*H camera-z plane
 constexpr int kPacketHeader = 32;
+// sensor-depth packet (VH_PACKET_U16): the same 32 floats, then K_inv row 2 (3 floats) and the depth
+// unit (5000 = 1 m, CameraTrackingUtils.cu:64), then the W*H uint16 depth image itself: half the
+// bytes of the float plane on the wire, and the owner recomputes the camera z with preProcess's
+// arithmetic, bit for bit
+constexpr int kPacketHeaderU16 = 36;
 
 struct int3_ { int x, y, z; };
 

@@ -12,11 +12,34 @@ namespace vh {
 // coalesced loads and stores (4 KiB in, 4 KiB out) instead of the reference's
 // 8-byte accesses.  The occupied count never leaves the device: the grid is a
 // fixed size and strides over the compact list.
-// depth(x,y) = depthBase[stride*(y*W+x)]: stride 4 from &verts[0].z (float4 vertex map),
-// stride 1 for the camera-z plane of a camera packet.
-__device__ __forceinline__ bool tsdf_update(const FrameParams &fp, const float *Tinv,
-                                            const float *__restrict__ depthBase, int stride, int vx, int vy, int vz,
-                                            float &sdfOut, float &wOut)
+// Where the camera z of a pixel comes from:
+//   DepthPlane  depth(x,y) = base[stride*(y*W+x)]: stride 4 from &verts[0].z (float4 vertex map),
+//               stride 1 for the camera-z plane of a float camera packet
+//   DepthSensor the uint16 sensor image of a VH_PACKET_U16 packet: z = (K_inv row 2 . (x,y,1)) * (d / unit),
+//               the operations of calculateVertexPositions (CameraTrackingUtils.cu:63-73) in their order
+struct DepthPlane {
+    const float *__restrict__ base;
+    int stride;
+    __device__ __forceinline__ float at(int sx, int sy, int width) const
+    {
+        return base[(size_t)stride * ((size_t)sy * width + sx)];
+    }
+};
+
+struct DepthSensor {
+    const uint16_t *__restrict__ image;
+    float k6, k7, k8, unit;
+    __device__ __forceinline__ float at(int sx, int sy, int width) const
+    {
+        const float d = (float)image[(size_t)sy * width + sx] / unit;
+        const float pz = k6 * (float)sx + k7 * (float)sy + k8 * 1.0f;
+        return pz * d;
+    }
+};
+
+template <class Depth>
+__device__ __forceinline__ bool tsdf_update(const FrameParams &fp, const float *Tinv, const Depth &src, int vx, int vy,
+                                            int vz, float &sdfOut, float &wOut)
 {
     float cx, cy, cz;
     if (fp.semantics == VH_SEM_REFERENCE) {
@@ -33,7 +56,7 @@ __device__ __forceinline__ bool tsdf_update(const FrameParams &fp, const float *
     int sx, sy;
     project(fp.proj, cx, cy, cz, sx, sy);                                        // :801
     if (sx < 0 || sx >= fp.width || sy < 0 || sy >= fp.height) return false;     // :803
-    const float depth = depthBase[(size_t)stride * ((size_t)sy * fp.width + sx)];   // :805
+    const float depth = src.at(sx, sy, fp.width);                                 // :805
     if (depth <= 0.0f) return false;                                             // :806
     float sdf = depth - cz;                                                      // :813
     if (!(sdf > -fp.truncation)) return false;                                   // :818
@@ -56,9 +79,9 @@ __device__ __forceinline__ void integrate_block(const FrameParams &fp, const Dev
     const int bz = (int)((uint32_t)e.pos[2] * 8u) + tz;
     float4 *cell = reinterpret_cast<float4 *>(dp.blocks + (size_t)e.ptr + lin);
     float4 v = *cell;                            // {sdf0, w0, sdf1, w1}
-    const float *depthBase = reinterpret_cast<const float *>(verts) + 2;   // &verts[0].z
-    const bool u0 = tsdf_update(fp, fp.Tinv, depthBase, 4, bx, by, bz, v.x, v.y);
-    const bool u1 = tsdf_update(fp, fp.Tinv, depthBase, 4, bx + 1, by, bz, v.z, v.w);
+    const DepthPlane src{reinterpret_cast<const float *>(verts) + 2, 4};   // &verts[0].z
+    const bool u0 = tsdf_update(fp, fp.Tinv, src, bx, by, bz, v.x, v.y);
+    const bool u1 = tsdf_update(fp, fp.Tinv, src, bx + 1, by, bz, v.z, v.w);
     if (u0 || u1) *cell = v;
 }
 

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(kFlattenThreads) void flatten_multi_kernel(const Fr
 // One 8^3 block per workgroup pass, the voxels stay in registers while the cameras
 // that see the block are applied in camera order (the running average is order
 // dependent): 4 KiB in, 4 KiB out per block whatever the number of cameras.
+template <bool kSensor>
 __device__ __forceinline__ void integrate_block_multi(const FrameParams &fp, const DevPtrs &dp, const VoxelEntry &e,
                                                       uint32_t seen, int32_t numCams,
                                                       const float *__restrict__ packets, size_t packetStride)
@@ -111,19 +112,27 @@ __device__ __forceinline__ void integrate_block_multi(const FrameParams &fp, con
     for (int c = 0; c < numCams; ++c) {
         if (!((seen >> c) & 1u)) continue;
         const float *pk = packets + packetStride * c;
-        dirty |= tsdf_update(fp, pk + 16, pk + kPacketHeader, 1, bx, by, bz, v.x, v.y);
-        dirty |= tsdf_update(fp, pk + 16, pk + kPacketHeader, 1, bx + 1, by, bz, v.z, v.w);
+        if constexpr (kSensor) {
+            const DepthSensor src{reinterpret_cast<const uint16_t *>(pk + kPacketHeaderU16), pk[32], pk[33], pk[34], pk[35]};
+            dirty |= tsdf_update(fp, pk + 16, src, bx, by, bz, v.x, v.y);
+            dirty |= tsdf_update(fp, pk + 16, src, bx + 1, by, bz, v.z, v.w);
+        } else {
+            const DepthPlane src{pk + kPacketHeader, 1};
+            dirty |= tsdf_update(fp, pk + 16, src, bx, by, bz, v.x, v.y);
+            dirty |= tsdf_update(fp, pk + 16, src, bx + 1, by, bz, v.z, v.w);
+        }
     }
     if (dirty) *cell = v;
 }
 
+template <bool kSensor>
 __global__ __launch_bounds__(256) void integrate_multi_kernel(const FrameParams fp, const DevPtrs dp,
                                                               int32_t numCams, const float *__restrict__ packets,
                                                               size_t packetStride)
 {
     const int count = dp.counters[kCompactCount];
     for (int b = blockIdx.x; b < count; b += gridDim.x)
-        integrate_block_multi(fp, dp, dp.compact[b], dp.compactMask[b], numCams, packets, packetStride);
+        integrate_block_multi<kSensor>(fp, dp, dp.compact[b], dp.compactMask[b], numCams, packets, packetStride);
 }
 
 // The multi-camera frame in two launches, built like the single-camera fused frame:
@@ -149,6 +158,7 @@ __global__ __launch_bounds__(256) void frame_multi_scan_claim_kernel(const Frame
                            kScanCount + parity);
 }
 
+template <bool kSensor>
 __global__ __launch_bounds__(256) void frame_multi_commit_integrate_kernel(const FrameParams fp, const DevPtrs dp,
                                                                            int32_t numCams,
                                                                            const float *__restrict__ packets,
@@ -158,7 +168,7 @@ __global__ __launch_bounds__(256) void frame_multi_commit_integrate_kernel(const
     const int scanCount = dp.counters[kScanCount + parity];
     if (blockIdx.x >= commitBlocks) {
         for (int b = blockIdx.x - commitBlocks; b < scanCount; b += gridDim.x - commitBlocks)
-            integrate_block_multi(fp, dp, dp.compact[b], dp.compactMask[b], numCams, packets, packetStride);
+            integrate_block_multi<kSensor>(fp, dp, dp.compact[b], dp.compactMask[b], numCams, packets, packetStride);
         return;
     }
     __shared__ VoxelEntry newEntry;
@@ -187,7 +197,8 @@ __global__ __launch_bounds__(256) void frame_multi_commit_integrate_kernel(const
             }
         }
         __syncthreads();
-        if (inserted && newMask != 0u) integrate_block_multi(fp, dp, newEntry, newMask, numCams, packets, packetStride);
+        if (inserted && newMask != 0u)
+            integrate_block_multi<kSensor>(fp, dp, newEntry, newMask, numCams, packets, packetStride);
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -202,6 +213,30 @@ __global__ __launch_bounds__(256) void frame_multi_commit_integrate_kernel(const
             dp.counters[kCommitTicket] = 0;
         }
     }
+}
+
+// Sensor-depth packets of up to kGenBatch frames of one camera (blockIdx.y = frame): header
+// {pose, inverse, K_inv row 2, depth unit} and a straight copy of the uint16 image, 4 bytes per lane.
+struct SensorFrames {
+    float T[kGenBatch][16];
+    float Tinv[kGenBatch][16];
+    const uint16_t *depth[kGenBatch];
+    float k6, k7, k8, unit;
+};
+
+__global__ __launch_bounds__(256) void write_packets_u16_kernel(const SensorFrames fr, int32_t numPixels,
+                                                                float *__restrict__ packets, size_t packetFrameStride)
+{
+    const int b = blockIdx.y;
+    float *pk = packets + packetFrameStride * b;
+    if (blockIdx.x == 0 && threadIdx.x < kPacketHeaderU16) {
+        const int t = threadIdx.x;
+        pk[t] = t < 16 ? fr.T[b][t] : t < 32 ? fr.Tinv[b][t - 16] : t == 32 ? fr.k6 : t == 33 ? fr.k7 : t == 34 ? fr.k8 : fr.unit;
+    }
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(fr.depth[b]);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(pk + kPacketHeaderU16);
+    const int words = numPixels / 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < words; i += gridDim.x * 256) dst[i] = src[i];
 }
 
 // Zeroes the header record of the bins of `batch` frames x numShards shards before

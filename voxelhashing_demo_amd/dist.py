@@ -141,16 +141,26 @@ class HipShard:
     """This rank's shard on its GPU (libvoxelhash_hip.so through the C-ABI)."""
 
     def __init__(self, params, width, height, semantics, plan: ShardPlan, rank: int, capacity: int,
-                 batch: int = 1, device=None, stream=None, sets: int = 1, batched_calls: bool = True):
+                 batch: int = 1, device=None, stream=None, sets: int = 1, batched_calls: bool = True,
+                 sensor_k_inv=None):
+        """sensor_k_inv: K^-1 (3x3) of the camera -> packets carry the uint16 sensor image (VH_PACKET_U16,
+        half the bytes of the float camera-z plane); generate_* then also need the depth images."""
         import torch
 
         from .hashtable import SDFHashtable
         self.plan, self.rank, self.capacity, self.batch = plan, rank, capacity, batch
+        self.sensor_k_inv = None if sensor_k_inv is None else np.ascontiguousarray(
+            np.asarray(sensor_k_inv, np.float32).reshape(9))
         self.batched_calls = batched_calls     # False: per-frame step calls (4 + 2 launches per frame)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.table = SDFHashtable(params, width, height, semantics, device=self.device.index,
                                   bucket_range=plan.bucket_range(rank), stream=stream)
-        self.packet_floats = P = 32 + width * height
+        if self.sensor_k_inv is not None:
+            assert (width * height) % 2 == 0
+            self.table.set_option("packet_format", 1)
+            self.packet_floats = P = 36 + width * height // 2
+        else:
+            self.packet_floats = P = 32 + width * height
         R, B = plan.world, batch
         # `sets` independent buffer sets: the pipelined step fills one while the other is consumed
         self.sets = []
@@ -172,10 +182,18 @@ class HipShard:
             s["bins_send"], s["bins_recv"], s["packet"], s["packets"])
         self._cur = s
 
-    def generate(self, b: int, pose, verts):
+    def generate(self, b: int, pose, verts, depth=None):
+        import ctypes as C
         self.table.set_pose(pose)
-        self.table.generate_keys(verts, self.rank, self.plan.world, self._cur["send_b"][b], self.capacity,
-                                 self._cur["packet_b"][b], bin_stride=self.batch * self.capacity)
+        if self.sensor_k_inv is None:
+            self.table.generate_keys(verts, self.rank, self.plan.world, self._cur["send_b"][b], self.capacity,
+                                     self._cur["packet_b"][b], bin_stride=self.batch * self.capacity)
+            return
+        self.table.generate_keys(verts, self.rank, self.plan.world, self._cur["send_b"][b], self.capacity, None,
+                                 bin_stride=self.batch * self.capacity)
+        p16 = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(1, 16))
+        self.table.write_packets_u16_batch(p16, (C.c_void_p * 1)(depth.data_ptr()), self.sensor_k_inv,
+                                           self._cur["packet_b"][b], 1)
 
     def apply(self, b: int):
         self.table.reset_mutexes()
@@ -185,16 +203,22 @@ class HipShard:
                                      packet_stride=self.batch * self.packet_floats)
 
     # whole batch in one C call each (fewest launches: 1 + batch, and 2 per multi-camera frame)
-    def generate_all(self, poses, verts_list):
+    def generate_all(self, poses, verts_list, depth_list=None):
         import ctypes as C
         if not self.batched_calls:
             for b in range(self.batch):
-                self.generate(b, poses[b], verts_list[b])
+                self.generate(b, poses[b], verts_list[b], None if depth_list is None else depth_list[b])
             return
         p16 = np.ascontiguousarray(np.asarray(poses, np.float32).reshape(self.batch, 16))
         ptrs = (C.c_void_p * self.batch)(*[v.data_ptr() for v in verts_list])
-        self.table.generate_keys_batch(p16, ptrs, self.rank, self.plan.world, self.bins_send, self.capacity,
-                                       self.packet, self.batch)
+        if self.sensor_k_inv is None:
+            self.table.generate_keys_batch(p16, ptrs, self.rank, self.plan.world, self.bins_send, self.capacity,
+                                           self.packet, self.batch)
+            return
+        self.table.generate_keys_batch(p16, ptrs, self.rank, self.plan.world, self.bins_send, self.capacity, None,
+                                       self.batch)
+        dptrs = (C.c_void_p * self.batch)(*[d.data_ptr() for d in depth_list])
+        self.table.write_packets_u16_batch(p16, dptrs, self.sensor_k_inv, self.packet, self.batch)
 
     def apply_all(self):
         if not self.batched_calls:
@@ -244,7 +268,7 @@ class OracleShard:
         self.table.insert_bins(self.bins_recv[:, b].contiguous().numpy())
         self.table.integrate_packets(self.packets[:, b].contiguous().numpy())
 
-    def generate_all(self, poses, verts_list):
+    def generate_all(self, poses, verts_list, depth_list=None):     # the oracle always ships float planes
         for b in range(self.batch):
             self.generate(b, poses[b], verts_list[b])
 
@@ -366,11 +390,11 @@ def loopback_raycast(shards, views, poses, capacity: int, t_min: float = 0.1, t_
 # ----------------------------------------------------------------------------
 # the step
 # ----------------------------------------------------------------------------
-def sharded_step(shard, transport: TorchDistTransport, poses, verts_list):
-    """`batch` multi-camera frames from this rank's point of view: poses[b], verts_list[b] are this
-    rank's camera for frame b of the batch."""
+def sharded_step(shard, transport: TorchDistTransport, poses, verts_list, depth_list=None):
+    """`batch` multi-camera frames from this rank's point of view: poses[b], verts_list[b] (and, for
+    sensor-depth packets, depth_list[b]) are this rank's camera for frame b of the batch."""
     assert len(poses) == shard.batch == len(verts_list)
-    shard.generate_all(poses, verts_list)
+    shard.generate_all(poses, verts_list, depth_list)
     transport.all_to_all_bins(shard.bins_send, shard.bins_recv)
     transport.all_gather_packets(shard.packet.view(-1), shard.packets.view(shard.plan.world, -1))
     shard.apply_all()
@@ -398,14 +422,14 @@ class ShardedPipeline:
         self.count = 0           # steps fed
         self.pending = None      # set index whose exchange is in flight / landed but not applied
 
-    def _front(self, s, poses, verts_list):
+    def _front(self, s, poses, verts_list, depth_list=None):
         torch, sh = self.torch, self.shard
         with torch.cuda.stream(self.front_stream):
             if self.count >= 2:
                 self.front_stream.wait_event(self.applied[s])    # set s was last used by step count-2
             sh.table.set_stream(self.front_stream)
             sh.use_set(s)
-            sh.generate_all(poses, verts_list)
+            sh.generate_all(poses, verts_list, depth_list)
             self.transport.all_to_all_bins(sh.bins_send, sh.bins_recv)
             self.transport.all_gather_packets(sh.packet.view(-1), sh.packets.view(sh.plan.world, -1))
             self.ready[s].record(self.front_stream)
@@ -419,10 +443,10 @@ class ShardedPipeline:
             sh.apply_all()
             self.applied[s].record(self.table_stream)
 
-    def feed(self, poses, verts_list):
+    def feed(self, poses, verts_list, depth_list=None):
         """Submit one step (batch frames of this rank's camera); applies the previous one."""
         s = self.count & 1
-        self._front(s, poses, verts_list)
+        self._front(s, poses, verts_list, depth_list)
         if self.pending is not None:
             self._apply(self.pending)
         self.pending = s
@@ -437,12 +461,12 @@ class ShardedPipeline:
         self.front_stream.synchronize()
 
 
-def loopback_step(shards, poses, verts_list):
+def loopback_step(shards, poses, verts_list, depth_list=None):
     """The same step with every rank played in this process (no collective library):
-    poses[r][b], verts_list[r][b]."""
+    poses[r][b], verts_list[r][b] (depth_list[r][b] for sensor-depth packets)."""
     ex = LoopbackExchange(len(shards))
     for r, sh in enumerate(shards):
-        sh.generate_all(poses[r], verts_list[r])
+        sh.generate_all(poses[r], verts_list[r], None if depth_list is None else depth_list[r])
         ex.post(r, sh.bins_send, sh.packet)
     for r, sh in enumerate(shards):
         ex.fetch(r, sh.bins_recv, sh.packets)
@@ -490,8 +514,19 @@ def bench_sharded(args, wl, rank, world, local_rank):
     poses = synth.camera_loop(wl["frames"], phase=camera_phase(rank, world))[:nframes]
     prims = synth.room_primitives()
     verts = torch.empty((nframes, Ht, Wd, 4), dtype=torch.float32, device=dev)
+    # Sensor frames as the demo reads them (uint16 depth, 5000 units = 1 m, Application.cpp:38-42) and
+    # the vertex maps preProcess makes from them: the packets then carry the 2-byte image instead of a
+    # 4-byte camera-z plane (--float-packets: the unquantised float maps and float planes instead).
+    sensor = not getattr(args, "float_packets", False) and (Wd * Ht) % 2 == 0
+    from .hashtable import preprocess
+    k_inv = np.linalg.inv(synth.K_matrix(Wd, Ht).astype(np.float64)).astype(np.float32)
+    depth16 = torch.empty((nframes, Ht, Wd), dtype=torch.uint16, device=dev) if sensor else None
+    scratch_n = torch.empty((Ht, Wd, 4), dtype=torch.float32, device=dev)
     for i in range(nframes):
         verts[i] = synth.render_room_verts(poses[i], Wd, Ht, prims, device=dev)
+        if sensor:
+            depth16[i] = (verts[i, :, :, 2] * 5000.0).round().clamp(0, 65535).to(torch.uint16)
+            preprocess(depth16[i], k_inv, verts[i], scratch_n)
     torch.cuda.synchronize()
     params = default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
     transport = TorchDistTransport()
@@ -500,15 +535,16 @@ def bench_sharded(args, wl, rank, world, local_rank):
     front = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
         shard = HipShard(params, Wd, Ht, SEM_PINHOLE, plan, rank, capacity, batch=batch, device=dev, stream=stream,
-                         sets=2 if pipelined else 1)
+                         sets=2 if pipelined else 1, sensor_k_inv=k_inv if sensor else None)
         pipe = ShardedPipeline(shard, transport, stream, front) if pipelined else None
 
         def step(i):
             ks = [(i * batch + b) % nframes for b in range(batch)]
+            depths = [depth16[k] for k in ks] if sensor else None
             if pipe:
-                pipe.feed([poses[k] for k in ks], [verts[k] for k in ks])
+                pipe.feed([poses[k] for k in ks], [verts[k] for k in ks], depths)
             else:
-                sharded_step(shard, transport, [poses[k] for k in ks], [verts[k] for k in ks])
+                sharded_step(shard, transport, [poses[k] for k in ks], [verts[k] for k in ks], depths)
 
         def drain():
             if pipe:
@@ -516,6 +552,18 @@ def bench_sharded(args, wl, rank, world, local_rank):
             shard.table.synchronize()
             torch.cuda.synchronize()
 
+        # A full collection of the Python garbage collector walks every object torch has created
+        # (~10^6): a 30-50 ms stall inside whatever call triggers it (seen in all_to_all_single), which
+        # is several exchanges long.  Existing objects are moved out of its reach and it stays off
+        # while the clock runs.
+        import gc
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+        # a fixed, untimed run-in before the W warm-up steps
+        for i in range(100):
+            step(i)
+        drain()
         for i in range(args.warmup):
             step(i)
         drain()
@@ -585,9 +633,12 @@ def bench_sharded(args, wl, rank, world, local_rank):
             vs_baseline=None, dtype="f32", data="synthetic",
             config=dict(workload=f"C4-style: {world} virtual {Wd}x{Ht} cameras (one per GPU) into one scene, "
                                  f"2^{int(math.log2(wl['buckets']))} buckets sharded by bucket range over {world} GPUs, "
-                                 "RCCL all-to-all of block keys + all-gather of depth packets per step, PINHOLE",
+                                 "RCCL all-to-all of block keys + all-gather of depth packets per step, PINHOLE; "
+                                 + ("uint16 sensor depth, vertex maps by vh_preprocess, packets carry the uint16 image"
+                                    if sensor else "float vertex maps, packets carry a float camera-z plane"),
                         frames_per_step=world * batch, frames_per_camera_per_exchange=batch,
                         resident_frames=nframes, key_bin_capacity=capacity, pipelined=pipelined,
+                        packet_bytes=4 * shard.packet_floats,
                         occupied_blocks_all_ranks=int(stats[0]), allocated_blocks_all_ranks=int(stats[1]),
                         key_bin_overflows=int(stats[2])),
             roofline=roofline, cpu_baseline=None)
