@@ -508,9 +508,10 @@ def bench_sharded(args, wl, rank, world, local_rank):
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.Stream(device=dev)
     plan = ShardPlan(wl["buckets"], world)
-    # one record per 8 pixels of this camera's image, split over the owners (2x the ~1 per 16
-    # pixels a wave-deduplicated room frame produces); overflow is counted and reported
-    capacity = max(1024, -(-Wd * Ht // (8 * world)))
+    # one record per 16 pixels of this camera's image, split over the owners: a wave-deduplicated room
+    # frame produces ~1 key per 700 pixels, so this is a ~40-fold margin (more with band allocation);
+    # the bins travel at full capacity, overflow is counted and reported
+    capacity = max(2048, -(-Wd * Ht // (16 * world)))
     poses = synth.camera_loop(wl["frames"], phase=camera_phase(rank, world))[:nframes]
     prims = synth.room_primitives()
     verts = torch.empty((nframes, Ht, Wd, 4), dtype=torch.float32, device=dev)
