@@ -27,6 +27,9 @@ __global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams
     const uint32_t claimBefore = (uint32_t)(((uint64_t)blockIdx.x * claimBlocks) / total);
     const uint32_t claimAfter = (uint32_t)(((uint64_t)(blockIdx.x + 1u) * claimBlocks) / total);
     if (claimAfter != claimBefore) {
+        // the latency-bound pixel waves issue first when they are ready, so they are off the compute
+        // unit sooner (17.9 -> 17.6 us; raising the streaming waves instead cost 0.25 us)
+        __builtin_amdgcn_s_setprio(3);
         claim_pixel(fp, dp, verts, claimBefore * 256 + threadIdx.x, kFusedCand + parity);
     } else {
         flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x - claimBefore, kScanCount + parity, total - claimBlocks);
