@@ -152,11 +152,13 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
     DeviceGuard guard(p->device);
     IcpState &hs = *p->hostState;
     std::memset(&hs, 0, sizeof hs);
-    double T[16];
+    // the start value goes through log / exp once, like the reference's estimate (a rigid-body
+    // matrix comes back unchanged up to rounding, anything else is projected onto SE3)
+    double T[16], est[6];
     for (int i = 0; i < 16; ++i) T[i] = (double)delta[i];
-    se3_log_d(T, hs.est);
-    se3_exp_d(hs.est, T);
-    for (int i = 0; i < 16; ++i) hs.delta[i] = (float)T[i];
+    se3_log_d(T, est);
+    se3_exp_d(est, T);
+    for (int i = 0; i < 16; ++i) { hs.T[i] = T[i]; hs.delta[i] = (float)T[i]; }
     VH_HIP(hipMemcpyAsync(p->state, &hs, sizeof hs, hipMemcpyHostToDevice, p->stream));
     IcpParams ip;
     std::memset(ip.delta, 0, sizeof ip.delta);

@@ -26,8 +26,8 @@ struct IcpParams {
 // Device-resident state of a whole Align (vh_icp_align): the rounds chain on the stream without
 // returning to the host; the solve of round i runs in the last workgroup of that round's launch.
 struct IcpState {
-    double est[6];       // twist (v, w) of the running estimate
-    float delta[16];     // exp(est), row-major, what the next round's pairing uses
+    double T[16];        // the running estimate as a matrix, T = exp(estimate) (row-major)
+    float delta[16];     // T in fp32: what the next round's pairing uses
     float sums[kIcpStride];   // the 29 sums of the last executed round
     int32_t rounds;      // rounds executed (systems built)
     int32_t done;        // 1: stop (summed residual exactly 0, CameraTracking.cpp:52, or singular system)
@@ -100,11 +100,10 @@ __host__ __device__ inline void se3_log_d(const double T[16], double twist[6])
     twist[3] = w[0]; twist[4] = w[1]; twist[5] = w[2];
 }
 
-// update = -(JTJ^-1 JTr) by Cholesky; estimate = log(exp(update) exp(estimate))  (Solver.cpp:104-106).
-// false (estimate untouched) when JTJ is not positive definite.
-__host__ __device__ inline bool icp_solve_d(const double JTJ[36], const double JTr[6], double estimate[6])
+// update = -(JTJ^-1 JTr) by Cholesky (Solver.cpp:104-105); false when JTJ is not positive definite.
+__host__ __device__ inline bool icp_update_d(const double JTJ[36], const double JTr[6], double x[6])
 {
-    double L[36], y[6], x[6];
+    double L[36], y[6];
     VH_UNROLL
     for (int i = 0; i < 36; ++i) L[i] = 0.0;
     VH_UNROLL
@@ -135,7 +134,15 @@ __host__ __device__ inline bool icp_solve_d(const double JTJ[36], const double J
         for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
         x[i] = s / L[6 * i + i];
     }
-    double A[16], B[16], M[16];
+    return true;
+}
+
+// estimate = log(exp(update) exp(estimate))  (Solver.cpp:106); false (estimate untouched) when the
+// system is singular.
+__host__ __device__ inline bool icp_solve_d(const double JTJ[36], const double JTr[6], double estimate[6])
+{
+    double x[6], A[16], B[16], M[16];
+    if (!icp_update_d(JTJ, JTr, x)) return false;
     se3_exp_d(x, A);
     se3_exp_d(estimate, B);
     VH_UNROLL
@@ -151,6 +158,27 @@ __host__ __device__ inline bool icp_solve_d(const double JTJ[36], const double J
     return true;
 }
 
+// The same step on the matrix itself, T <- exp(update) T: what exp(log(exp(update) exp(estimate)))
+// evaluates to, without the logarithm and the second exponential (the device-side Align keeps T and
+// takes the logarithm never; the single-lane solve is on the critical path of every round).
+__host__ __device__ inline bool icp_step_matrix_d(const double JTJ[36], const double JTr[6], double T[16])
+{
+    double x[6], A[16], M[16];
+    if (!icp_update_d(JTJ, JTr, x)) return false;
+    se3_exp_d(x, A);
+    VH_UNROLL
+    for (int i = 0; i < 4; ++i)
+        VH_UNROLL
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+            VH_UNROLL
+            for (int k = 0; k < 4; ++k) s += A[4 * i + k] * T[4 * k + j];
+            M[4 * i + j] = s;
+        }
+    VH_UNROLL
+    for (int i = 0; i < 16; ++i) T[i] = M[i];
+    return true;
+}
 #undef VH_UNROLL
 
 // double -> int as cvt.rzi.s32.f64 (the reference's make_int2(double, double), :129): truncate,
@@ -321,19 +349,17 @@ __global__ __launch_bounds__(kIcpThreads) void icp_round_kernel(IcpParams ip, co
     state->rounds += 1;
     if (!solve) return;
     if (total[27] == 0.0f) { state->done = 1; return; }                 // CameraTracking.cpp:52
-    double JTJ[36], JTr[6], est[6];
+    double JTJ[36], JTr[6], T[16];
     int t = 0;
     for (int a = 0; a < 6; ++a)
         for (int b = a; b < 6; ++b) {
             JTJ[6 * a + b] = JTJ[6 * b + a] = (double)total[t];
             ++t;
         }
-    for (int a = 0; a < 6; ++a) { JTr[a] = (double)total[21 + a]; est[a] = state->est[a]; }
-    if (!icp_solve_d(JTJ, JTr, est)) { state->done = 1; state->singular = 1; return; }
-    double T[16];
-    se3_exp_d(est, T);
-    for (int a = 0; a < 6; ++a) state->est[a] = est[a];
-    for (int i = 0; i < 16; ++i) state->delta[i] = (float)T[i];
+    for (int a = 0; a < 6; ++a) JTr[a] = (double)total[21 + a];
+    for (int i = 0; i < 16; ++i) T[i] = state->T[i];
+    if (!icp_step_matrix_d(JTJ, JTr, T)) { state->done = 1; state->singular = 1; return; }
+    for (int i = 0; i < 16; ++i) { state->T[i] = T[i]; state->delta[i] = (float)T[i]; }
 }
 
 // float depth image in metres -> vertex + normal maps: preProcess (CameraTrackingUtils.cu:50-113)
