@@ -29,8 +29,9 @@ extern "C" int vh_icp_create(int32_t width, int32_t height, int32_t device, vh_i
     p->device = dev;
     p->width = width;
     p->height = height;
-    p->blocks = std::min(grid_for((size_t)width * height, kIcpThreads), 256);   // one workgroup per compute unit
-    if (const char *e = std::getenv("VH_ICP_BLOCKS")) p->blocks = std::max(1, std::min(p->blocks, std::atoi(e)));   // tuning knob
+    const int maxBlocks = grid_for((size_t)width * height, kIcpThreads);
+    p->blocks = std::min(maxBlocks, 256);                      // one workgroup per compute unit
+    if (const char *e = std::getenv("VH_ICP_BLOCKS")) p->blocks = std::max(1, std::min(maxBlocks, std::atoi(e)));   // tuning knob
     hipError_t e = hipMalloc((void **)&p->partials, sizeof(float) * kIcpStride * (size_t)p->blocks);
     if (e == hipSuccess) e = hipMalloc((void **)&p->state, sizeof(IcpState));
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->hostState, sizeof(IcpState), hipHostMallocDefault);
