@@ -212,6 +212,41 @@ def main():
                          note="vh_set_option(flatten_variant=4): walk over the bucket-occupancy bitmap "
                               "(numBuckets/8 bytes) + the non-empty buckets instead of the 20*N-byte table walk")
 
+    # ---- the same frames straight from uint16 sensor depth (vh_integrate_depth: preProcess's vertex
+    # computation inside the claim phase, no vertex map in memory), against the two-call form
+    # vh_preprocess + vh_integrate.  Extension of the boundary; reported separately. ----
+    k_inv = np.linalg.inv(synth.K_matrix(Wd, Ht).astype(np.float64)).astype(np.float32)
+    nd = min(nframes, 250)
+    depth16 = torch.empty((nd, Ht, Wd), dtype=torch.uint16, device=dev)
+    for i in range(nd):
+        depth16[i] = (verts[i, :, :, 2] * 5000.0).round().clamp(0, 65535).to(torch.uint16)
+    kin = np.ascontiguousarray(k_inv.reshape(9))
+    kin_p = kin.ctypes.data_as(C.POINTER(C.c_float))
+    d_ptrs = [depth16[i].data_ptr() for i in range(nd)]
+    tmp_v, tmp_n = torch.empty_like(verts[0]), torch.empty_like(verts[0])
+    tv, tn, st = tmp_v.data_ptr(), tmp_n.data_ptr(), C.c_void_p(stream.cuda_stream)
+
+    def fused_depth(i):
+        lib.vh_integrate_depth(h, pose_ptrs[i % nd], d_ptrs[i % nd], kin_p)
+
+    def two_calls(i):
+        lib.vh_preprocess(d_ptrs[i % nd], kin_p, Wd, Ht, tv, tn, st)
+        lib.vh_integrate(h, pose_ptrs[i % nd], tv, None)
+
+    sensor = {}
+    for name, fn in (("vh_integrate_depth", fused_depth), ("vh_preprocess + vh_integrate", two_calls)):
+        for i in range(args.warmup):
+            fn(i)
+        table.synchronize()
+        t3 = time.perf_counter()
+        for i in range(args.steps):
+            fn(args.warmup + i)
+        table.synchronize()
+        sensor[name] = round(args.steps / (time.perf_counter() - t3), 1)
+    sensor_depth = dict(frames_per_s=sensor, unit="frames/s",
+                        note="input: uint16 depth images (2 B/pixel); the fused call computes the vertices inside "
+                             "the claim phase and gathers depth from the image, bit-equal to the two-call form")
+
     # ---- raycast Mpix/s (second half of the metric) ----
     depth = torch.empty((Ht, Wd), dtype=torch.float32, device=dev)
     dptr = depth.data_ptr()
@@ -323,7 +358,7 @@ def main():
                     keys_last_frame=keys),
         roofline=roofline, cpu_baseline=cpu,
         raycast_mpix_per_s=round(raycast_mpix, 1) if raycast_mpix else None,
-        raycast=raycast, next_rows=next_rows,
+        raycast=raycast, next_rows=next_rows, sensor_depth_input=sensor_depth,
         occupancy_index_variant=index_variant,
         kernels=kernels_us,
         frame_algorithmic_bytes=b_frame, frame_algorithmic_gbs=round(frame_gbs, 1),

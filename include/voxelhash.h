@@ -199,6 +199,12 @@ int vh_integrate_depth_map(vh_context *ctx, const vh_float4 *d_verts);
 int vh_integrate(vh_context *ctx, const float pose[16],
                  const vh_float4 *d_verts, const vh_float4 *d_normals);
 
+/* The same frame straight from the uint16 sensor image (5000 units = 1 m, 0 = no measurement):
+ * preProcess's vertex computation (CameraTrackingUtils.cu:63-73) runs inside the claim phase and the
+ * TSDF update reads the image, so no vertex map exists in memory: 2 bytes per pixel in instead of
+ * 16.  Equals vh_preprocess + vh_integrate bit for bit.  k_inv: row-major 3x3. */
+int vh_integrate_depth(vh_context *ctx, const float pose[16], const uint16_t *d_depth, const float k_inv[9]);
+
 /* Stand-in for SDFRenderer::render (SDFRenderer.cpp:210-255): one ray per pixel
  * from `pose`, camera depth of the first +/- zero crossing into d_depth_out
  * (width*height floats, 0 = no hit).  Spec: DESIGN.md "raycast". */

@@ -372,3 +372,27 @@ def test_hostile_vertex_values(oracle, vh, torch_cuda, sem):
     _run(ot, gt, torch_cuda, [(I4, verts), (pose, verts), (I4, verts)])
     assert gt.counters()["heap_exhausted"] == 0
     _compare(ot, gt)
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_integrate_depth_equals_preprocess_plus_integrate(oracle, vh, torch_cuda, sem):
+    """vh_integrate_depth: the frame straight from the uint16 sensor image (vertices computed inside the
+    claim phase, TSDF update reading the image) against oracle preProcess + integrate."""
+    torch = torch_cuda
+    W, H = 320, 240
+    ot, gt = _pair(oracle, vh, sem, W=W, H=H, numBuckets=1 << 14, numVoxelBlocks=8192)
+    K = synth.K_matrix(W, H)
+    kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    prims = synth.room_primitives()
+    poses = synth.camera_loop(60)
+    for i in (0, 3, 6, 9, 3):
+        z = synth.render_room_verts(poses[i], W, H, prims).numpy()[..., 2]
+        d16 = np.round(z * 5000.0).clip(0, 65535).astype(np.uint16)
+        d16[::11, ::5] = 0                                              # sensor holes
+        verts = oracle.preprocess(d16, kinv)[0]
+        ot.integrate(poses[i] if sem == 1 else I4, verts)
+        gt.integrate_depth(poses[i] if sem == 1 else I4, torch.from_numpy(d16).cuda(), kinv)
+    gt.synchronize()
+    if sem == 1:
+        assert len(gt.allocated()) > 300
+    _compare(ot, gt)

@@ -60,18 +60,48 @@ __device__ __forceinline__ int band_samples(const FrameParams &fp, float &step)
     return 2 * half + 1;
 }
 
-__device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const float4 *__restrict__ verts, int idx,
+// Where a pixel's vertex comes from: the float4 vertex map of the reference's interface, or the
+// uint16 sensor image itself (vh_integrate_depth: calculateVertexPositions, CameraTrackingUtils.cu:
+// 63-73, evaluated in place -- 2 bytes per pixel read instead of 16, no vertex map in memory).
+struct VertexMap {
+    const float4 *__restrict__ verts;
+    __device__ __forceinline__ float4 vertex(int idx, int, int) const { return verts[idx]; }
+};
+
+struct SensorImage {
+    const uint16_t *__restrict__ depth;
+    float k[9];              // K_inv, row-major
+    float unit;              // 5000 = 1 m
+    __device__ __forceinline__ float4 vertex(int idx, int px, int py) const
+    {
+        const float d = (float)depth[idx] / unit;                                   // :64
+        const float fx = (float)px, fy = (float)py;
+        const float x = k[0] * fx + k[1] * fy + k[2] * 1.0f;                        // K_inv * (x, y, 1), :71
+        const float y = k[3] * fx + k[4] * fy + k[5] * 1.0f;
+        const float z = k[6] * fx + k[7] * fy + k[8] * 1.0f;
+        return make_float4(x * d, y * d, z * d, 1.0f);                              // :73
+    }
+};
+
+template <class In>
+__device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const In &in, int idx,
                                                   float *__restrict__ outDepth)
 {
     PixelVertex p{make_float4(0.f, 0.f, 0.f, 0.f), 0, 0, false};
     if (idx < fp.width * fp.height) {
-        p.v = verts[idx];
-        if (outDepth) outDepth[idx] = p.v.z;                             // camera-z plane of a camera packet
         p.py = idx / fp.width;
         p.px = idx - p.py * fp.width;
+        p.v = in.vertex(idx, p.px, p.py);
+        if (outDepth) outDepth[idx] = p.v.z;                             // camera-z plane of a camera packet
         p.valid = p.v.z != 0.0f;                                         // VoxelUtils.cu:621
     }
     return p;
+}
+
+__device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const float4 *__restrict__ verts, int idx,
+                                                  float *__restrict__ outDepth)
+{
+    return load_pixel(fp, VertexMap{verts}, idx, outDepth);
 }
 
 struct SampleKey {
@@ -120,10 +150,11 @@ __device__ __forceinline__ uint32_t sample_rank(const FrameParams &fp, const Pix
 }
 
 // the claim phase for one lane = one pixel (shared by alloc_claim_kernel and the fused frame)
-__device__ __forceinline__ void claim_pixel(const FrameParams &fp, const DevPtrs &dp,
-                                            const float4 *__restrict__ verts, int idx, int candCounter)
+template <class In>
+__device__ __forceinline__ void claim_pixel(const FrameParams &fp, const DevPtrs &dp, const In &in, int idx,
+                                            int candCounter)
 {
-    const PixelVertex p = load_pixel(fp, verts, idx, nullptr);
+    const PixelVertex p = load_pixel(fp, in, idx, nullptr);
     float step;
     const int nS = band_samples(fp, step);
     int ox = 0, oy = 0, oz = 0;
@@ -135,6 +166,12 @@ __device__ __forceinline__ void claim_pixel(const FrameParams &fp, const DevPtrs
         if (h < fp.bucketLo || h >= fp.bucketHi) continue;              // not this shard's bucket
         probe_and_claim(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(fp, p, k), candCounter);
     }
+}
+
+__device__ __forceinline__ void claim_pixel(const FrameParams &fp, const DevPtrs &dp,
+                                            const float4 *__restrict__ verts, int idx, int candCounter)
+{
+    claim_pixel(fp, dp, VertexMap{verts}, idx, candCounter);
 }
 
 __global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, const DevPtrs dp,

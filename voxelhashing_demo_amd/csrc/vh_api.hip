@@ -608,6 +608,36 @@ extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4
     return VH_OK;
 }
 
+// The frame straight from the uint16 sensor image: preProcess's vertex computation happens inside
+// the claim half, the TSDF update reads the image.  Equals vh_preprocess + vh_integrate.
+extern "C" int vh_integrate_depth(vh_context *c, const float pose[16], const uint16_t *d_depth, const float k_inv[9])
+{
+    if (!c || !pose || !d_depth || !k_inv) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(c->device);
+    int rc = vh_set_pose(c, pose);
+    if (rc == VH_OK) rc = vh_reset_mutexes(c);
+    if (rc != VH_OK) return rc;
+    SensorImage in;
+    in.depth = d_depth;
+    std::memcpy(in.k, k_inv, sizeof in.k);
+    in.unit = 5000.0f;                                                   // CameraTrackingUtils.cu:64
+    c->occupiedCounter = kCompactCount;
+    const uint32_t claimBlocks = (uint32_t)grid_for((size_t)c->fp.width * c->fp.height, 256);
+    const uint32_t scanBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
+    rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_sensor_kernel, dim3(claimBlocks + scanBlocks), dim3(256), c->fp,
+                c->dp, in, (uint32_t)c->numEntries, claimBlocks, c->fusedParity);
+    if (rc != VH_OK) return rc;
+    const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
+    rc = launch(c, kPhaseFrameCommitIntegrate, frame_commit_integrate_sensor_kernel,
+                dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, in, commitBlocks, c->fusedParity);
+    if (rc != VH_OK) return rc;
+    c->fusedParity ^= 1;
+    c->compactArmed = false;
+    if (c->profiling) c->profiledFrames += 1;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
 extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, float t_max, float *d_depth_out)
 {
     if (!c || !pose || !d_depth_out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");

@@ -36,6 +36,25 @@ __global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams
     }
 }
 
+// The same frame straight from the uint16 sensor image (vh_integrate_depth): the claim half
+// computes each pixel's vertex in place, the TSDF update reads the image (DepthSensor).  Default
+// walk only.
+__global__ __launch_bounds__(256) void frame_scan_claim_sensor_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                      const SensorImage in, uint32_t numEntries,
+                                                                      uint32_t claimBlocks, int parity)
+{
+    const uint32_t total = gridDim.x;
+    const uint32_t claimBefore = (uint32_t)(((uint64_t)blockIdx.x * claimBlocks) / total);
+    const uint32_t claimAfter = (uint32_t)(((uint64_t)(blockIdx.x + 1u) * claimBlocks) / total);
+    if (claimAfter != claimBefore) {
+        __builtin_amdgcn_s_setprio(3);
+        claim_pixel(fp, dp, in, claimBefore * 256 + threadIdx.x, kFusedCand + parity);
+    } else {
+        flatten_tile<kWalkStridedBallot>(fp, dp, numEntries, blockIdx.x - claimBefore, kScanCount + parity,
+                                         total - claimBlocks);
+    }
+}
+
 // ---- the mask form of the fused frame (default) --------------------------------------------
 // With tens of thousands of allocated entries the walk above stops being a pure stream: every
 // wave that meets a live entry re-reads it, tests it and takes a returning atomic, holding its
@@ -150,9 +169,9 @@ __global__ __launch_bounds__(256) void frame_commit_consume_kernel(const FramePa
 // Only the commit workgroups take a ticket (a word that every workgroup of a large grid
 // increments costs tens of microseconds): the last of them publishes the occupied count
 // and clears the counter set of the other parity for the next frame.
-__global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const FrameParams fp, const DevPtrs dp,
-                                                                     const float4 *__restrict__ verts,
-                                                                     uint32_t commitBlocks, int parity)
+template <class Depth>
+__device__ __forceinline__ void frame_commit_integrate(const FrameParams &fp, const DevPtrs &dp, const Depth &verts,
+                                                       uint32_t commitBlocks, int parity)
 {
     const int scanCount = dp.counters[kScanCount + parity];
     if (blockIdx.x >= commitBlocks) {
@@ -194,6 +213,20 @@ __global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const Frame
             dp.counters[kCommitTicket] = 0;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                     const float4 *__restrict__ verts,
+                                                                     uint32_t commitBlocks, int parity)
+{
+    frame_commit_integrate(fp, dp, DepthPlane{reinterpret_cast<const float *>(verts) + 2, 4}, commitBlocks, parity);
+}
+
+__global__ __launch_bounds__(256) void frame_commit_integrate_sensor_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                            const SensorImage in,
+                                                                            uint32_t commitBlocks, int parity)
+{
+    frame_commit_integrate(fp, dp, DepthSensor{in.depth, in.k[6], in.k[7], in.k[8], in.unit}, commitBlocks, parity);
 }
 
 }  // namespace vh

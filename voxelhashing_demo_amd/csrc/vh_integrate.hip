@@ -68,9 +68,11 @@ __device__ __forceinline__ bool tsdf_update(const FrameParams &fp, const float *
     return true;
 }
 
-// the 256 lanes of a workgroup update the 8^3 block of entry e from the float4 vertex map
+// the 256 lanes of a workgroup update the 8^3 block of entry e; the depth comes from the float4
+// vertex map (DepthPlane on &verts[0].z) or straight from the sensor image (DepthSensor)
+template <class Depth>
 __device__ __forceinline__ void integrate_block(const FrameParams &fp, const DevPtrs &dp, const VoxelEntry &e,
-                                                const float4 *__restrict__ verts)
+                                                const Depth &src)
 {
     const int lin = 2 * (int)threadIdx.x;        // linearizeVoxelPos: z*64 + y*8 + x  (:311-317)
     const int tx = lin & 7, ty = (lin >> 3) & 7, tz = lin >> 6;
@@ -79,10 +81,15 @@ __device__ __forceinline__ void integrate_block(const FrameParams &fp, const Dev
     const int bz = (int)((uint32_t)e.pos[2] * 8u) + tz;
     float4 *cell = reinterpret_cast<float4 *>(dp.blocks + (size_t)e.ptr + lin);
     float4 v = *cell;                            // {sdf0, w0, sdf1, w1}
-    const DepthPlane src{reinterpret_cast<const float *>(verts) + 2, 4};   // &verts[0].z
     const bool u0 = tsdf_update(fp, fp.Tinv, src, bx, by, bz, v.x, v.y);
     const bool u1 = tsdf_update(fp, fp.Tinv, src, bx + 1, by, bz, v.z, v.w);
     if (u0 || u1) *cell = v;
+}
+
+__device__ __forceinline__ void integrate_block(const FrameParams &fp, const DevPtrs &dp, const VoxelEntry &e,
+                                                const float4 *__restrict__ verts)
+{
+    integrate_block(fp, dp, e, DepthPlane{reinterpret_cast<const float *>(verts) + 2, 4});   // &verts[0].z
 }
 
 __global__ __launch_bounds__(256) void integrate_kernel(const FrameParams fp, const DevPtrs dp,

@@ -113,6 +113,13 @@ class SDFHashtable:
         _, pp = _pose16(pose)
         L.check(self._lib.vh_integrate(self._h, pp, _dev_ptr(verts), _dev_ptr(normals)), "vh_integrate")
 
+    def integrate_depth(self, pose, depth_u16, k_inv):
+        """The frame straight from the uint16 sensor image [H, W] (== preprocess + integrate)."""
+        _, pp = _pose16(pose)
+        k = np.ascontiguousarray(np.asarray(k_inv, np.float32).reshape(9))
+        L.check(self._lib.vh_integrate_depth(self._h, pp, _dev_ptr(depth_u16), k.ctypes.data_as(C.POINTER(C.c_float))),
+                "vh_integrate_depth")
+
     def raycast(self, pose, out, t_min: float = 0.1, t_max: float = 5.0):
         _, pp = _pose16(pose)
         L.check(self._lib.vh_raycast(self._h, pp, t_min, t_max, _dev_ptr(out)), "vh_raycast")
