@@ -298,6 +298,14 @@ int vh_write_packets_u16_batch(vh_context *ctx, int32_t batch, const float *pose
                                const uint16_t *const *d_depth, const float k_inv[9], float *d_packets,
                                size_t packet_frame_stride);
 
+/* Keys AND sensor-depth packets of `batch` frames of this camera from the uint16 images alone (one
+ * launch per 8 frames: vertices are computed in place, the packet is the header plus the image).
+ * Layouts and strides as in vh_generate_keys_batch; d_packets may be NULL (keys only). */
+int vh_generate_keys_depth_batch(vh_context *ctx, int32_t batch, const float *poses,
+                                 const uint16_t *const *d_depth, const float k_inv[9], uint32_t camera_id,
+                                 int32_t num_shards, int32_t *d_bins, int32_t capacity, int32_t bin_stride,
+                                 int32_t frame_stride, float *d_packets, size_t packet_frame_stride);
+
 /* ------------------------------------------------------------------ */
 /* raycast over shards ("replicate the compact table +   */
 /* visible blocks"; DESIGN.md section 6 "raycast")                      */

@@ -112,6 +112,8 @@ SIGNATURES = {
                                C.POINTER(C.c_int32)]),
     "vh_depth_to_maps": (C.c_int, [_vp, _fp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "computeCorrespondences": (C.c_float, [_vp, _vp, _vp, _vp, _vp, _vp, _fp, C.c_int, C.c_int]),
+    "vh_generate_keys_depth_batch": (C.c_int, [_vp, C.c_int32, _fp, C.POINTER(_vp), _fp, C.c_uint32, C.c_int32, _vp,
+                                               C.c_int32, C.c_int32, C.c_int32, _vp, C.c_size_t]),
     "vh_write_packets_u16_batch": (C.c_int, [_vp, C.c_int32, _fp, C.POINTER(_vp), _fp, _vp, C.c_size_t]),
     "vh_delete_blocks": (C.c_int, [_vp, _vp, C.c_int32]),
     "vh_garbage_collect": (C.c_int, [_vp, _f]),

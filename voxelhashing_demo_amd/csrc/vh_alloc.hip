@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, 
 #endif
 constexpr int kGenThreads = VH_GEN_THREADS;   // tuning knob (make EXTRA=-DVH_GEN_THREADS=n)
 
-__device__ __forceinline__ void generate_keys_tile(const FrameParams &fp, const float4 *__restrict__ verts,
+template <class In>
+__device__ __forceinline__ void generate_keys_tile(const FrameParams &fp, const In &verts,
                                                    int32_t numShards, int4 *__restrict__ outBins,
                                                    int32_t outCapacity, int32_t outBinStride,
                                                    float *__restrict__ outDepth, uint32_t rankBase, uint32_t tile)
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_kernel(const FrameP
 {
     if (outDepth && blockIdx.x == 0 && threadIdx.x < kPacketHeader)      // packet header: pose, inverse
         outDepth[(int)threadIdx.x - kPacketHeader] = threadIdx.x < 16 ? fp.T[threadIdx.x] : fp.Tinv[threadIdx.x - 16];
-    generate_keys_tile(fp, verts, numShards, outBins, outCapacity, outBinStride, outDepth, rankBase, blockIdx.x);
+    generate_keys_tile(fp, VertexMap{verts}, numShards, outBins, outCapacity, outBinStride, outDepth, rankBase,
+                       blockIdx.x);
 }
 
 // Up to kGenBatch frames of one camera in ONE launch (blockIdx.y = frame): a single frame is 300
@@ -265,8 +267,51 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_batch_kernel(FrameP
         outDepth[(int)threadIdx.x - kPacketHeader] = threadIdx.x < 16 ? fr.T[b][threadIdx.x] : fr.Tinv[b][threadIdx.x - 16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { fp.T[i] = fr.T[b][i]; fp.Tinv[i] = fr.Tinv[b][i]; }
-    generate_keys_tile(fp, fr.verts[b], numShards, outBins + (size_t)frameStride * b, outCapacity, outBinStride,
-                       outDepth, rankBase, blockIdx.x);
+    generate_keys_tile(fp, VertexMap{fr.verts[b]}, numShards, outBins + (size_t)frameStride * b, outCapacity,
+                       outBinStride, outDepth, rankBase, blockIdx.x);
+}
+
+// The same from uint16 sensor images: vertices computed in place (SensorImage), and the packet of
+// a frame is written by the same launch -- header {pose, inverse, K_inv row 2, unit} and the image
+// itself (VH_PACKET_U16) -- so a whole exchange batch of one camera is ONE launch.
+struct GenSensorFrames {
+    float T[kGenBatch][16];
+    float Tinv[kGenBatch][16];
+    const uint16_t *depth[kGenBatch];
+    float k[9];
+    float unit;
+};
+
+__global__ __launch_bounds__(kGenThreads) void generate_keys_sensor_batch_kernel(FrameParams fp, const GenSensorFrames fr,
+                                                                                 int32_t numShards,
+                                                                                 int4 *__restrict__ outBins,
+                                                                                 int32_t outCapacity,
+                                                                                 int32_t outBinStride,
+                                                                                 int32_t frameStride,
+                                                                                 float *__restrict__ packets,
+                                                                                 size_t packetFrameStride,
+                                                                                 uint32_t rankBase)
+{
+    const int b = blockIdx.y;
+    SensorImage in;
+    in.depth = fr.depth[b];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) in.k[i] = fr.k[i];
+    in.unit = fr.unit;
+    if (packets) {
+        float *pk = packets + packetFrameStride * b;
+        if (blockIdx.x == 0 && threadIdx.x < kPacketHeaderU16) {
+            const int t = threadIdx.x;
+            pk[t] = t < 16 ? fr.T[b][t] : t < 32 ? fr.Tinv[b][t - 16] : t == 32 ? fr.k[6] : t == 33 ? fr.k[7]
+                                                                                  : t == 34 ? fr.k[8] : fr.unit;
+        }
+        const int idx = blockIdx.x * kGenThreads + threadIdx.x;
+        if (idx < fp.width * fp.height) reinterpret_cast<uint16_t *>(pk + kPacketHeaderU16)[idx] = in.depth[idx];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { fp.T[i] = fr.T[b][i]; fp.Tinv[i] = fr.Tinv[b][i]; }
+    generate_keys_tile(fp, in, numShards, outBins + (size_t)frameStride * b, outCapacity, outBinStride, nullptr,
+                       rankBase, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------

@@ -858,6 +858,51 @@ extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float 
     return VH_OK;
 }
 
+// Keys and sensor-depth packets of `batch` frames of this camera from the uint16 images alone: one
+// launch per kGenBatch frames (no vertex map, no separate packet pass).
+extern "C" int vh_generate_keys_depth_batch(vh_context *c, int32_t batch, const float *poses,
+                                            const uint16_t *const *d_depth, const float k_inv[9], uint32_t camera_id,
+                                            int32_t num_shards, int32_t *d_bins, int32_t capacity, int32_t bin_stride,
+                                            int32_t frame_stride, float *d_packets, size_t packet_frame_stride)
+{
+    if (!c || !poses || !d_depth || !k_inv || !d_bins || batch <= 0 || num_shards <= 0 ||
+        num_shards > VH_MAX_CAMERAS || capacity < 2 || camera_id >= VH_MAX_CAMERAS)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    const size_t npix = (size_t)c->fp.width * c->fp.height;
+    if (d_packets && npix % 2) return fail(VH_ERR_INVALID_ARGUMENT, "sensor-depth packets need an even number of pixels");
+    if (frame_stride == 0) frame_stride = capacity;
+    if (bin_stride == 0) bin_stride = batch * frame_stride;
+    const size_t dense = (size_t)kPacketHeaderU16 + npix / 2;
+    if (packet_frame_stride == 0) packet_frame_stride = dense;
+    if (frame_stride < capacity || bin_stride < batch * frame_stride || (d_packets && packet_frame_stride < dense))
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
+    DeviceGuard guard(c->device);
+    prepare_bins_kernel<<<grid_for((size_t)num_shards * batch, 256), 256, 0, c->stream>>>(
+        reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, batch, frame_stride);
+    for (int b0 = 0; b0 < batch; b0 += kGenBatch) {
+        const int n = std::min<int>(kGenBatch, batch - b0);
+        GenSensorFrames fr;
+        std::memset(&fr, 0, sizeof fr);
+        std::memcpy(fr.k, k_inv, sizeof fr.k);
+        fr.unit = 5000.0f;                                               // CameraTrackingUtils.cu:64
+        for (int j = 0; j < n; ++j) {
+            const int rc = vh_set_pose(c, poses + 16 * (size_t)(b0 + j));
+            if (rc != VH_OK) return rc;
+            if (!d_depth[b0 + j]) return fail(VH_ERR_INVALID_ARGUMENT, "null depth image");
+            std::memcpy(fr.T[j], c->fp.T, sizeof fr.T[j]);
+            std::memcpy(fr.Tinv[j], c->fp.Tinv, sizeof fr.Tinv[j]);
+            fr.depth[j] = d_depth[b0 + j];
+        }
+        generate_keys_sensor_batch_kernel<<<dim3((unsigned)grid_for(npix, kGenThreads), (unsigned)n), kGenThreads, 0,
+                                            c->stream>>>(
+            c->fp, fr, num_shards, reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
+            frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
+            camera_id << kRankCameraShift);
+    }
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
 // Sensor-depth packets (VH_PACKET_U16) of `batch` frames of this camera: pose + inverse + K_inv row 2 +
 // depth unit, then the uint16 image as it is.  The key generation for the same frames is
 // vh_generate_keys_batch with d_packets = NULL.

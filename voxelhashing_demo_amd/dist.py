@@ -210,15 +210,15 @@ class HipShard:
                 self.generate(b, poses[b], verts_list[b], None if depth_list is None else depth_list[b])
             return
         p16 = np.ascontiguousarray(np.asarray(poses, np.float32).reshape(self.batch, 16))
-        ptrs = (C.c_void_p * self.batch)(*[v.data_ptr() for v in verts_list])
         if self.sensor_k_inv is None:
+            ptrs = (C.c_void_p * self.batch)(*[v.data_ptr() for v in verts_list])
             self.table.generate_keys_batch(p16, ptrs, self.rank, self.plan.world, self.bins_send, self.capacity,
                                            self.packet, self.batch)
             return
-        self.table.generate_keys_batch(p16, ptrs, self.rank, self.plan.world, self.bins_send, self.capacity, None,
-                                       self.batch)
+        # keys and packets from the sensor images alone, one launch per 8 frames (verts_list is not read)
         dptrs = (C.c_void_p * self.batch)(*[d.data_ptr() for d in depth_list])
-        self.table.write_packets_u16_batch(p16, dptrs, self.sensor_k_inv, self.packet, self.batch)
+        self.table.generate_keys_depth_batch(p16, dptrs, self.sensor_k_inv, self.rank, self.plan.world, self.bins_send,
+                                             self.capacity, self.packet, self.batch)
 
     def apply_all(self):
         if not self.batched_calls:

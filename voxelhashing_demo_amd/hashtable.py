@@ -194,6 +194,15 @@ class SDFHashtable:
             self._h, batch, poses16.ctypes.data_as(C.POINTER(C.c_float)), vert_ptrs, camera_id, num_shards,
             _dev_ptr(bins_out), capacity, 0, 0, _dev_ptr(packets_out), 0), "vh_generate_keys_batch")
 
+    def generate_keys_depth_batch(self, poses16, depth_ptrs, k_inv, camera_id: int, num_shards: int, bins_out,
+                                  capacity: int, packets_out, batch: int):
+        """Keys + sensor-depth packets of `batch` frames from the uint16 images alone (dense layouts)."""
+        k = np.ascontiguousarray(np.asarray(k_inv, np.float32).reshape(9))
+        L.check(self._lib.vh_generate_keys_depth_batch(
+            self._h, batch, poses16.ctypes.data_as(C.POINTER(C.c_float)), depth_ptrs,
+            k.ctypes.data_as(C.POINTER(C.c_float)), camera_id, num_shards, _dev_ptr(bins_out), capacity, 0, 0,
+            _dev_ptr(packets_out), 0), "vh_generate_keys_depth_batch")
+
     def write_packets_u16_batch(self, poses16, depth_ptrs, k_inv, packets_out, batch: int, packet_frame_stride: int = 0):
         """Sensor-depth packets (VH_PACKET_U16) of `batch` frames: depth_ptrs = ctypes array of device
         addresses of W*H uint16 images; packets_out: device tensor or address, [batch, 36 + W*H/2] floats."""
