@@ -1,0 +1,92 @@
+"""Several contexts in one process: on different streams, and driven from different host threads at the
+same time.  No state may leak between contexts (the only process-global state is the default context of
+the reference's drop-in names)."""
+import threading
+
+import numpy as np
+import pytest
+
+from voxelhashing_demo_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+W, H = 320, 240
+KW = dict(numBuckets=1 << 14, numVoxelBlocks=4096)
+
+
+def sequence(seed, n=12):
+    prims = synth.room_primitives()
+    loop = synth.camera_loop(60, phase=0.7 * seed)
+    return [(loop[(3 * i + seed) % 60], synth.render_room_verts(loop[(3 * i + seed) % 60], W, H, prims).numpy()) for i in range(n)]
+
+
+def oracle_table(oracle, frames, sem):
+    ot = oracle.OracleTable(oracle.default_params(**KW), W, H, sem)
+    for pose, verts in frames:
+        ot.integrate(pose, verts)
+    return ot
+
+
+def same(ot, gt):
+    gt.synchronize()
+    a, b = ot.hash_table(), gt.hash_table()
+    assert np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["ptr"] != -1, b["ptr"] != -1)
+    ov, gv = ot.sdf_blocks(), gt.sdf_blocks()
+    for i in np.nonzero(a["ptr"] != -1)[0]:
+        assert np.array_equal(ov[int(a["ptr"][i]):int(a["ptr"][i]) + 512].view(np.uint32),
+                              gv[int(b["ptr"][i]):int(b["ptr"][i]) + 512].view(np.uint32))
+
+
+def test_interleaved_contexts_on_their_own_streams(oracle, vh, torch_cuda):
+    torch = torch_cuda
+    seqs = [sequence(s) for s in range(3)]
+    streams = [torch.cuda.Stream() for _ in seqs]
+    tables = [vh.SDFHashtable(vh.default_params(**KW), W, H, 1, stream=st) for st in streams]
+    dev = [[torch.from_numpy(v).cuda() for _, v in fr] for fr in seqs]
+    torch.cuda.synchronize()
+    depth = [torch.zeros((H, W), device="cuda") for _ in seqs]
+    for i in range(len(seqs[0])):                      # round robin: the three frames of step i overlap on the GPU
+        for t, fr, d, out in zip(tables, seqs, dev, depth):
+            t.integrate(fr[i][0], d[i])
+            if i % 4 == 3:
+                t.raycast(fr[i][0], out)
+                t.garbage_collect(0.3)
+    for t, fr, out in zip(tables, seqs, depth):
+        ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+        last = None
+        for i, (pose, verts) in enumerate(fr):
+            ot.integrate(pose, verts)
+            if i % 4 == 3:
+                last = ot.raycast(pose)
+                ot.garbage_collect(0.3)
+        same(ot, t)
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), last.view(np.uint32))
+
+
+def test_contexts_driven_from_concurrent_host_threads(oracle, vh, torch_cuda):
+    torch = torch_cuda
+    seqs = [sequence(10 + s, n=30) for s in range(4)]
+    dev = [[torch.from_numpy(v).cuda() for _, v in fr] for fr in seqs]
+    torch.cuda.synchronize()
+    tables, errors = [None] * len(seqs), []
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream()
+            t = vh.SDFHashtable(vh.default_params(**KW), W, H, k % 2, stream=st)
+            for (pose, _), d in zip(seqs[k], dev[k]):
+                t.integrate(pose if k % 2 else np.eye(4, dtype=np.float32), d)
+            t.synchronize()
+            tables[k] = t
+        except Exception as e:          # surfaced in the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(seqs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for k, t in enumerate(tables):
+        frames = [(pose if k % 2 else np.eye(4, dtype=np.float32), v) for pose, v in seqs[k]]
+        same(oracle_table(oracle, frames, k % 2), t)
