@@ -186,11 +186,15 @@ int vh_set_alloc_band(vh_context *ctx, float band_metres);
  * (cuda_SimpleMatrixUtil.h:944-1069, same summation order, fp32, on the host) */
 int vh_set_pose(vh_context *ctx, const float pose[16]);
 
-int vh_reset_mutexes(vh_context *ctx);               /* resetHashTableMutexes: bumps the epoch */
+/* resetHashTableMutexes (VoxelUtils.cu:146-149): bumps the lock epoch instead of clearing 4*numBuckets bytes */
+int vh_reset_mutexes(vh_context *ctx);
+/* allocBlocks (VoxelUtils.cu:708-716, kernel :606-705): W*H float4 each, d_normals unused as in the reference (:631) */
 int vh_alloc_blocks(vh_context *ctx, const vh_float4 *d_verts, const vh_float4 *d_normals);
-/* flattenIntoBuffer: with occupied_out != NULL it synchronises the stream and
- * returns the count like the reference does; with NULL it stays asynchronous */
+/* flattenIntoBuffer (VoxelUtils.cu:751-768, kernel :719-749): with occupied_out != NULL it
+ * synchronises the stream and returns the count like the reference does; with NULL it stays
+ * asynchronous */
 int vh_flatten(vh_context *ctx, int32_t *occupied_out);
+/* integrateDepthMap (VoxelUtils.cu:844-852, kernel :790-842) over the compact list of the last flatten */
 int vh_integrate_depth_map(vh_context *ctx, const vh_float4 *d_verts);
 
 /* SDF_Hashtable::integrate (SDF_Hashtable.cpp:11-40) as one asynchronous call:
@@ -221,8 +225,10 @@ int vh_download(vh_context *ctx, int which, void *host_dst, size_t bytes);  /* s
  * point: block x,y,z, hash, blockInFrustum, project() x,y, float->int of .w */
 int vh_debug_eval(vh_context *ctx, const vh_float4 *d_points, int32_t n, int32_t *d_out);
 
-/* tuning knobs for A/B measurements ("fused_frame", "flatten_variant", "integrate_grid",
- * "commit_blocks"); results never change */
+/* Options.  Tuning knobs for A/B measurements, results never change: "fused_frame" (1: two launches
+ * per frame, 0: the four step kernels), "flatten_variant" (walk kinds, 3 = default, 4 = occupancy
+ * index), "integrate_grid", "commit_blocks", "persistent_blocks", "raycast_patch".  Format switch:
+ * "packet_format" (VH_PACKET_F32 / VH_PACKET_U16, below). */
 int vh_set_option(vh_context *ctx, const char *name, int value);
 int vh_set_profiling(vh_context *ctx, int enabled);
 int vh_get_kernel_times(vh_context *ctx, vh_kernel_times *out, int reset);  /* synchronises */
