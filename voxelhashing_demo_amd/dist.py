@@ -401,35 +401,45 @@ def sharded_step(shard, transport: TorchDistTransport, poses, verts_list, depth_
 
 
 class ShardedPipeline:
-    """The same steps, software-pipelined over two HIP streams: while the table stream applies
-    step i (insert / walk / TSDF update), the front stream generates the keys and packets of
-    step i+1 and runs its all-to-all and all-gather, so a step costs max(apply, generate + RCCL)
-    instead of their sum.  Two buffer sets alternate; events order the hand-offs:
+    """The same steps, software-pipelined over three HIP streams (plus RCCL's own): while the table
+    stream applies exchange i (insert / walk / TSDF update), the collectives of exchange i+1 are in
+    flight and the keys and packets of exchange i+2 are being generated, so an exchange costs
+    max(apply, RCCL, generate) instead of their sum.  Two buffer sets alternate; events order the
+    hand-offs:
 
-        front: [wait applied(i-1)] generate(i+1) -> all_to_all -> all_gather -> [record ready(i+1)]
-        table: [wait ready(i)] apply(i) -> [record applied(i)]
+        gen:   [wait ready(i-2): the send buffers of this set have been sent]  generate(i)  [record generated(i)]
+        front: [wait generated(i), applied(i-2): the receive buffers are free]  all_to_all, all_gather  [record ready(i)]
+        table: [wait ready(i)]  apply(i)  [record applied(i)]
 
-    Operations on the table are issued in exactly the order of `sharded_step`, so results are the
-    same.  `shard` needs sets=2."""
+    (generate only writes a set's send buffers and apply only reads its receive buffers, so exchange
+    i+2 may be generated while exchange i is still being applied.)  Operations on the table are issued
+    in exactly the order of `sharded_step`, so results are the same.  `shard` needs sets=2."""
 
-    def __init__(self, shard: HipShard, transport: TorchDistTransport, table_stream, front_stream):
+    def __init__(self, shard: HipShard, transport: TorchDistTransport, table_stream, front_stream, gen_stream=None):
         import torch
         assert len(shard.sets) >= 2
         self.torch, self.shard, self.transport = torch, shard, transport
         self.table_stream, self.front_stream = table_stream, front_stream
-        self.ready = [torch.cuda.Event() for _ in range(2)]      # exchange of set s has landed
-        self.applied = [torch.cuda.Event() for _ in range(2)]    # set s has been consumed
+        self.gen_stream = gen_stream if gen_stream is not None else torch.cuda.Stream(device=shard.device)
+        self.generated = [torch.cuda.Event() for _ in range(2)]  # send buffers of set s are filled
+        self.ready = [torch.cuda.Event() for _ in range(2)]      # exchange of set s has landed (and was sent)
+        self.applied = [torch.cuda.Event() for _ in range(2)]    # receive buffers of set s have been consumed
         self.count = 0           # steps fed
         self.pending = None      # set index whose exchange is in flight / landed but not applied
 
     def _front(self, s, poses, verts_list, depth_list=None):
         torch, sh = self.torch, self.shard
-        with torch.cuda.stream(self.front_stream):
+        with torch.cuda.stream(self.gen_stream):
             if self.count >= 2:
-                self.front_stream.wait_event(self.applied[s])    # set s was last used by step count-2
-            sh.table.set_stream(self.front_stream)
+                self.gen_stream.wait_event(self.ready[s])        # set s was last sent by exchange count-2
+            sh.table.set_stream(self.gen_stream)
             sh.use_set(s)
             sh.generate_all(poses, verts_list, depth_list)
+            self.generated[s].record(self.gen_stream)
+        with torch.cuda.stream(self.front_stream):
+            self.front_stream.wait_event(self.generated[s])
+            if self.count >= 2:
+                self.front_stream.wait_event(self.applied[s])    # set s was last applied as exchange count-2
             self.transport.all_to_all_bins(sh.bins_send, sh.bins_recv)
             self.transport.all_gather_packets(sh.packet.view(-1), sh.packets.view(sh.plan.world, -1))
             self.ready[s].record(self.front_stream)
@@ -459,6 +469,7 @@ class ShardedPipeline:
         self.shard.table.set_stream(self.table_stream)
         self.table_stream.synchronize()
         self.front_stream.synchronize()
+        self.gen_stream.synchronize()
 
 
 def loopback_step(shards, poses, verts_list, depth_list=None):
