@@ -13,23 +13,24 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("frame_mask_claim_kernel", "frame_commit_consume_kernel", "frame_scan_claim_kernel", "frame_commit_integrate_kernel", "frame_multi_scan_claim_kernel", "frame_multi_commit_integrate_kernel", "preprocess_kernel", "alloc_claim_kernel", "alloc_commit_kernel",
-        "flatten_multi_kernel", "flatten_kernel", "integrate_multi_kernel", "integrate_kernel", "raycast_kernel",
-        "generate_keys_kernel", "prepare_generate_kernel", "claim_bins_kernel", "reset_table_kernel",
-        "reset_heap_kernel", "debug_eval_kernel")
-
-
 def short(name):
-    """Kernel name without namespace / arguments, template arguments kept
-    (frame_scan_claim_kernel<3> = ballot walk, <4> = occupancy-index walk, ...)."""
-    for k in OURS:
-        i = name.find(k)
-        if i >= 0:
-            rest = name[i + len(k):]
-            if rest.startswith("<"):
-                return k + rest[:rest.find(">") + 1]
-            return k
-    return None
+    """Name of one of this repo's kernels (they all live in namespace vh) without namespace and
+    arguments, template arguments kept (frame_scan_claim_kernel<3> = ballot walk, <4> = occupancy-index
+    walk, ...); None for anything else (torch, rocclr copies)."""
+    i = name.find("vh::")
+    if i < 0:
+        return None
+    rest = name[i + 4:]
+    depth, end = 0, len(rest)
+    for j, ch in enumerate(rest):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            end = j
+            break
+    return rest[:end].strip()
 
 
 def find(d, pat):
