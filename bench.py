@@ -334,18 +334,49 @@ def main():
         import oracle as O
         op = O.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
         ot = O.OracleTable(op, Wd, Ht, O.SEM_PINHOLE)
+        # the same frame sequence on the host: a few seconds on one thread, then the rest of the budget
+        # on `threads` threads (OpenMP; identical results, tests/test_oracle_anchors.py)
         budget_s, nmax = 15.0, args.cpu_frames or 10 ** 9
-        done, spent = 0, 0.0
-        while done < nmax and (args.cpu_frames or spent < budget_s) and done < 5000:
-            k = done % nframes
+        done, spent, one_done, one_spent = 0, 0.0, 0, 0.0
+        while one_done < nmax and one_spent < 3.0 and one_done < 5000:
+            k = one_done % nframes
             v = verts[k].cpu().numpy()
             c0 = time.perf_counter()
             ot.integrate(poses[k], v)
+            one_spent += time.perf_counter() - c0
+            one_done += 1
+        # thread count: the fastest of a short calibration (on the pool's 2 x 64-core hosts the rate
+        # peaks at 16 threads -- 245 frames/s -- and falls off beyond; the container's CPU share
+        # is not the 256 logical cores it sees)
+        threads, best = 1, one_done / one_spent
+        cal = []
+        for th in (4, 8, 16, 32, 64):
+            if th > (os.cpu_count() or 1):
+                break
+            c0, n = time.perf_counter(), 0
+            while time.perf_counter() - c0 < 0.4:
+                k = (one_done + n) % nframes
+                ot.integrate_mt(poses[k], verts[k].cpu().numpy(), th)
+                n += 1
+            rate = n / (time.perf_counter() - c0)         # includes the device->host copy: only a ranking
+            cal.append((th, round(rate, 1)))
+            if rate > best:
+                threads, best = th, rate
+        while threads > 1 and done < nmax and (args.cpu_frames or spent < budget_s - one_spent) and done < 20000:
+            k = (one_done + done) % nframes
+            v = verts[k].cpu().numpy()
+            c0 = time.perf_counter()
+            ot.integrate_mt(poses[k], v, threads)
             spent += time.perf_counter() - c0
             done += 1
-        cpu = dict(value=round(done / spent, 3), unit="frames/s", cores=1, kind="port",
-                   sample=f"first {done} frames of the same {args.workload} sequence, oracle/vh_oracle.c "
-                          f"(gcc -O2 -ffp-contract=off), 1 thread of {os.cpu_count()} host cores")
+        if threads == 1:
+            done, spent = one_done, one_spent
+        cpu = dict(value=round(done / spent, 3), unit="frames/s", cores=threads, kind="port",
+                   one_thread_frames_per_s=round(one_done / one_spent, 3),
+                   thread_calibration=cal,
+                   sample=f"{one_done} frames on 1 thread, then {done} frames on {threads} threads (fastest of the "
+                          f"calibration) of the same {args.workload} sequence, oracle/vh_oracle.c "
+                          f"(gcc -O2 -ffp-contract=off -fopenmp), {os.cpu_count()} logical host cores")
         ot.close()
 
     out = dict(

@@ -91,6 +91,8 @@ def lib():
         L.vho_integrate_depth_map.argtypes = [C.c_void_p, fp]
         L.vho_integrate.argtypes = [C.c_void_p, fp, fp, C.POINTER(FrameStats)]
         L.vho_integrate.restype = C.c_int
+        L.vho_integrate_mt.argtypes = [C.c_void_p, fp, fp, C.c_int, C.POINTER(FrameStats)]
+        L.vho_integrate_mt.restype = C.c_int
         L.vho_raycast.argtypes = [C.c_void_p, fp, C.c_float, C.c_float, fp]
         L.vho_get_params.restype = C.POINTER(Params)
         L.vho_get_params.argtypes = [C.c_void_p]
@@ -312,6 +314,15 @@ class OracleTable:
         assert verts.size == self.width * self.height * 4
         st = FrameStats()
         occ = lib().vho_integrate(self._h, _fptr(pose), _fptr(verts), C.byref(st))
+        self.last_stats = st.as_dict()
+        return int(occ)
+
+    def integrate_mt(self, pose, verts, threads: int) -> int:
+        """integrate() on `threads` host threads (identical results)."""
+        pose = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
+        verts = np.ascontiguousarray(verts, np.float32)
+        st = FrameStats()
+        occ = lib().vho_integrate_mt(self._h, _fptr(pose), _fptr(verts), int(threads), C.byref(st))
         self.last_stats = st.as_dict()
         return int(occ)
 

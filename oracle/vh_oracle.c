@@ -526,6 +526,137 @@ int vho_integrate(vho_table *t, const float pose[16], const float *verts, vho_fr
 }
 
 /* ------------------------------------------------------------------ */
+/* the same frame on several host threads (bench.py's cpu_baseline;     */
+/* SURVEY.md 8(d) "all cores via a static split")                       */
+/* ------------------------------------------------------------------ */
+/* Identical results to vho_integrate: the per-pixel key computation (transform, rounding, frustum
+ * test) runs in parallel into a key array, the insertions stay serial in launch order (H8 is a
+ * sequential contract); the table walk is cut into one chunk per thread whose hits are concatenated
+ * in chunk order (= table order); the blocks of the compact list are independent. */
+#include <omp.h>
+
+int vho_integrate_mt(vho_table *t, const float pose[16], const float *verts, int threads, vho_frame_stats *stats)
+{
+    if (threads < 1) threads = 1;
+    memset(&t->stats, 0, sizeof t->stats);
+    vho_set_pose(t, pose);
+    vho_reset_mutexes(t);
+    const int W = t->width, H = t->height;
+    float step;
+    const int nS = band_samples(t, &step);
+    /* ---- allocBlocks: keys in parallel, insertions in launch order ---- */
+    int32_t *keys = (int32_t *)malloc((size_t)W * H * nS * 4 * sizeof(int32_t));   /* {x,y,z,wanted} */
+    if (!keys) return -1;
+    #pragma omp parallel for num_threads(threads) schedule(static)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const float *v = verts + 4 * ((size_t)y * W + x);
+            for (int k = 0; k < nS; ++k) {
+                int32_t *kk = keys + 4 * (((size_t)y * W + x) * nS + k);
+                kk[3] = 0;
+                if (v[2] == 0.0f) continue;
+                if (!band_key(t, v, k, nS, step, kk)) continue;
+                kk[3] = vho_block_in_frustum(t, kk) ? 1 : 0;
+            }
+        }
+    const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+    for (int by = 0; by < tilesY; ++by)
+    for (int bx = 0; bx < tilesX; ++bx)
+    for (int ty = 0; ty < 16; ++ty)
+    for (int tx = 0; tx < 16; ++tx) {
+        const int x = bx * 16 + tx, y = by * 16 + ty;
+        if (x >= W || y >= H) continue;
+        if (verts[4 * ((size_t)y * W + x) + 2] == 0.0f) continue;
+        t->stats.pixels_valid++;
+        int counted = 0;
+        for (int k = 0; k < nS; ++k) {
+            const int32_t *kk = keys + 4 * (((size_t)y * W + x) * nS + k);
+            if (!kk[3]) continue;
+            if (!counted) { t->stats.pixels_in_frustum++; counted = 1; }
+            insert_entry(t, kk);
+        }
+    }
+    free(keys);
+    /* ---- flatten: one chunk per thread, concatenated in chunk order ---- */
+    const size_t n = (size_t)(t->bucket_hi - t->bucket_lo) * t->p.bucketSize;
+    size_t *cnt = (size_t *)calloc((size_t)threads + 1, sizeof(size_t));
+    uint32_t **found = (uint32_t **)calloc((size_t)threads, sizeof(uint32_t *));
+    #pragma omp parallel num_threads(threads)
+    {
+        const int me = omp_get_thread_num(), nt = omp_get_num_threads();
+        const size_t lo = n * (size_t)me / (size_t)nt, hi = n * (size_t)(me + 1) / (size_t)nt;
+        uint32_t *mine = NULL;
+        size_t m = 0, cap = 0;
+        for (size_t i = lo; i < hi; ++i) {
+            const vho_entry *e = &t->table[i];
+            if (e->ptr == VHO_FREE_BLOCK || !vho_block_in_frustum(t, e->pos)) continue;
+            if (m == cap) { cap = cap ? 2 * cap : 256; mine = (uint32_t *)realloc(mine, cap * sizeof(uint32_t)); }
+            mine[m++] = (uint32_t)i;
+        }
+        found[me] = mine;
+        cnt[me + 1] = m;
+    }
+    for (int i = 0; i < threads; ++i) cnt[i + 1] += cnt[i];
+    #pragma omp parallel for num_threads(threads) schedule(static, 1)
+    for (int i = 0; i < threads; ++i)
+        for (size_t j = 0; j < cnt[i + 1] - cnt[i]; ++j) t->compact[cnt[i] + j] = t->table[found[i][j]];
+    const int count = (int)cnt[threads];
+    for (int i = 0; i < threads; ++i) free(found[i]);
+    free(found);
+    free(cnt);
+    t->compact_counter = count;
+    t->p.numOccupiedBlocks = (uint32_t)count;
+    t->stats.occupied = (uint32_t)count;
+    /* ---- integrateDepthMap: blocks are independent ---- */
+    if (count > 0) {
+        const float *depth_base = verts + 2;
+        const float trunc = t->p.truncation;
+        uint32_t updated = 0;
+        #pragma omp parallel for num_threads(threads) schedule(dynamic, 4) reduction(+:updated)
+        for (int b = 0; b < count; ++b) {
+            const vho_entry *e = &t->compact[b];
+            int32_t base[3];
+            for (int k = 0; k < 3; ++k) base[k] = wrap_mul(e->pos[k], t->p.voxelBlockSize);
+            for (int tz = 0; tz < 8; ++tz)
+            for (int ty = 0; ty < 8; ++ty)
+            for (int tx = 0; tx < 8; ++tx) {
+                const int32_t vi[3] = { wrap_add(base[0], tx), wrap_add(base[1], ty), wrap_add(base[2], tz) };
+                float pc[3];
+                if (t->semantics == VHO_SEM_REFERENCE) {
+                    const float vf[4] = { (float)vi[0], (float)vi[1], (float)vi[2], 1.0f };
+                    float r[4];
+                    vho_mat4_mul_vec4(t->p.inv_global_transform, vf, r);
+                    for (int k = 0; k < 3; ++k) pc[k] = (float)vho_float2int_rz(r[k]) * t->p.voxelSize;
+                } else {
+                    const float wv[4] = { (float)vi[0] * t->p.voxelSize, (float)vi[1] * t->p.voxelSize,
+                                          (float)vi[2] * t->p.voxelSize, 1.0f };
+                    float r[4];
+                    vho_mat4_mul_vec4(t->p.inv_global_transform, wv, r);
+                    pc[0] = r[0]; pc[1] = r[1]; pc[2] = r[2];
+                }
+                int32_t s[2];
+                vho_project(t->proj, pc, s);
+                if (s[0] < 0 || s[0] >= W || s[1] < 0 || s[1] >= H) continue;
+                const float depth = depth_base[(size_t)4 * ((size_t)s[1] * W + s[0])];
+                if (depth <= 0) continue;
+                float sdf = depth - pc[2];
+                if (sdf > -trunc) {
+                    sdf = (sdf >= 0) ? fminf(trunc, sdf) : fmaxf(-trunc, sdf);
+                    const vho_voxel cur = { sdf, 0.1f };
+                    vho_voxel *dst = &t->blocks[(size_t)e->ptr + (size_t)(tz * 64 + ty * 8 + tx)];
+                    vho_combine_voxel(dst, &cur, t->p.integrationWeightMax, dst);
+                    updated++;
+                }
+            }
+        }
+        t->stats.voxels_updated = updated;
+    }
+    t->stats.heap_counter = t->heap_counter;
+    if (stats) *stats = t->stats;
+    return count;
+}
+
+/* ------------------------------------------------------------------ */
 /* raycast (build spec; the reference's pass is disabled and broken,    */
 /* SDFRenderer.cpp:215-254, raycastSDF.frag:121-177)                   */
 /* ------------------------------------------------------------------ */

@@ -95,6 +95,10 @@ void vho_integrate_depth_map(vho_table *t, const float *verts);  /* VoxelUtils.c
 int  vho_integrate(vho_table *t, const float pose[16], const float *verts,
                    vho_frame_stats *stats);
 
+/* the same frame on `threads` host threads (OpenMP), identical results; for bench.py's cpu_baseline */
+int  vho_integrate_mt(vho_table *t, const float pose[16], const float *verts, int threads,
+                      vho_frame_stats *stats);
+
 /* ---- raycast (build spec; self-pinned) ---- */
 void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max,
                  float *depth_out /* W*H */);

@@ -143,3 +143,23 @@ def test_band_allocation_extends_the_surface_allocation(oracle):
     for pos in tabs[0.2]:
         centre = (np.array(pos, np.float64) * 8 + 3.5) * 0.02
         assert abs(np.linalg.norm(centre) - 2.0) < 0.2 + 0.3
+
+
+def test_threaded_frame_is_identical(oracle):
+    """vho_integrate_mt (bench.py's multi-thread CPU baseline) leaves the bits of vho_integrate."""
+    import numpy as np
+    from voxelhashing_demo_amd import synth
+    W, H = 160, 120
+    prims = synth.room_primitives()
+    frames = [(p, synth.render_room_verts(p, W, H, prims).numpy()) for p in synth.camera_loop(30)[::5]]
+    for sem, band in ((0, 0.0), (1, 0.0), (1, 0.1)):
+        kw = dict(numBuckets=257, bucketSize=3, numVoxelBlocks=2048)
+        a = oracle.OracleTable(oracle.default_params(**kw), W, H, sem)
+        b = oracle.OracleTable(oracle.default_params(**kw), W, H, sem)
+        a.set_alloc_band(band)
+        b.set_alloc_band(band)
+        for i, (p, v) in enumerate(frames):
+            assert a.integrate(p, v) == b.integrate_mt(p, v, 1 + i % 5)
+            assert a.last_stats == b.last_stats
+        assert np.array_equal(a.hash_table(), b.hash_table()) and np.array_equal(a.compact(), b.compact())
+        assert np.array_equal(a.sdf_blocks().view(np.uint32), b.sdf_blocks().view(np.uint32))
