@@ -215,6 +215,15 @@ int vh_integrate_depth(vh_context *ctx, const float pose[16], const uint16_t *d_
 int vh_raycast(vh_context *ctx, const float pose[16], float t_min, float t_max,
                float *d_depth_out);
 
+/* Block silhouettes: the reference's one working render pass (SDFRenderer::drawToFrontAndBack,
+ * SDFRenderer.cpp:165-208: one cube per entry -- block k covers world [8k, 8k+8]*voxelSize,
+ * Application.cpp:130-132 -- nearest front face per pixel; notes.md:3-16 adds the back faces).  Per
+ * pixel the camera depth at which its ray enters the nearest and leaves the farthest cube of ANY
+ * allocated block, clipped to [t_min, t_max], by an exact ray/box test; 0 = no block.  Two W*H float
+ * images.  Uses the raycast intrinsics. */
+int vh_render_blocks(vh_context *ctx, const float pose[16], float t_min, float t_max, float *d_front,
+                     float *d_back);
+
 int vh_synchronize(vh_context *ctx);
 int vh_get_counters(vh_context *ctx, vh_counters *out);              /* synchronises */
 int vh_get_params(vh_context *ctx, HashTableParams *out);

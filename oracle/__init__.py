@@ -91,6 +91,7 @@ def lib():
         L.vho_integrate_depth_map.argtypes = [C.c_void_p, fp]
         L.vho_integrate.argtypes = [C.c_void_p, fp, fp, C.POINTER(FrameStats)]
         L.vho_integrate.restype = C.c_int
+        L.vho_render_blocks.argtypes = [C.c_void_p, fp, C.c_float, C.c_float, fp, fp]
         L.vho_integrate_mt.argtypes = [C.c_void_p, fp, fp, C.c_int, C.POINTER(FrameStats)]
         L.vho_integrate_mt.restype = C.c_int
         L.vho_raycast.argtypes = [C.c_void_p, fp, C.c_float, C.c_float, fp]
@@ -367,6 +368,13 @@ class OracleTable:
         self._view_records = np.ascontiguousarray(records, np.uint8)      # the voxels stay in here
         n = self._view_records.size // self.VIEW_RECORD_BYTES
         return int(lib().vho_import_view(self._h, self._view_records.ctypes.data, n))
+
+    def render_blocks(self, pose, t_min: float = 0.1, t_max: float = 5.0):
+        """(front, back) [H, W]: camera depth of the nearest front / farthest back face of the allocated blocks' cubes."""
+        pose = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
+        front, back = np.zeros((self.height, self.width), np.float32), np.zeros((self.height, self.width), np.float32)
+        lib().vho_render_blocks(self._h, _fptr(pose), t_min, t_max, _fptr(front), _fptr(back))
+        return front, back
 
     def block_in_frustum(self, block) -> bool:
         a = (C.c_int32 * 3)(*[int(c) for c in block])

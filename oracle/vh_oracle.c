@@ -729,6 +729,86 @@ void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max, f
 }
 
 /* ------------------------------------------------------------------ */
+/* block silhouettes: the reference's one       */
+/* working render pass, SDFRenderer::drawToFrontAndBack                 */
+/* (SDFRenderer.cpp:165-208, depthWrite.*; back layer: notes.md:3-16)   */
+/* ------------------------------------------------------------------ */
+static int ray_box(const float o[3], const float d[3], const float lo[3], const float hi[3], float *t_near, float *t_far)
+{
+    float tn = -3.0e38f, tf = 3.0e38f;
+    for (int a = 0; a < 3; ++a) {
+        if (d[a] == 0.0f) {
+            if (o[a] < lo[a] || o[a] > hi[a]) return 0;
+            continue;
+        }
+        const float t0 = (lo[a] - o[a]) / d[a], t1 = (hi[a] - o[a]) / d[a];
+        tn = fmaxf(tn, fminf(t0, t1));
+        tf = fminf(tf, fmaxf(t0, t1));
+    }
+    *t_near = tn;
+    *t_far = tf;
+    return tn <= tf;
+}
+
+/* Per pixel the camera depth at which its ray (origin = pose translation, direction per unit
+ * camera depth = R*(dx,dy,1) with the raycast intrinsics) enters the nearest and leaves the farthest
+ * cube of any allocated block -- block k is the world box [8k, 8k+8]*voxelSize, the unit cube the
+ * reference scales by 0.16 (Application.cpp:130-132) -- clipped to [t_min, t_max]; 0 = none. */
+void vho_render_blocks(const vho_table *t, const float pose[16], float t_min, float t_max, float *front, float *back)
+{
+    const int W = t->width, H = t->height;
+    float inv[16];
+    vho_invert4x4(pose, inv);
+    for (size_t i = 0; i < (size_t)W * H; ++i) { front[i] = INFINITY; back[i] = 0.0f; }
+    const float o[3] = { pose[3], pose[7], pose[11] };
+    const size_t n = (size_t)(t->bucket_hi - t->bucket_lo) * t->p.bucketSize;
+    for (size_t e = 0; e < n; ++e) {
+        if (t->table[e].ptr == VHO_FREE_BLOCK) continue;
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = (float)wrap_mul(t->table[e].pos[a], 8) * t->p.voxelSize;
+            hi[a] = ((float)wrap_mul(t->table[e].pos[a], 8) + 8.0f) * t->p.voxelSize;
+        }
+        /* a generous screen bounding box keeps this loop short; any superset of the hit pixels gives the same image */
+        float zmin = 3.0e38f, umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
+        for (int c = 0; c < 8; ++c) {
+            const float w[4] = { (c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2], 1.0f };
+            float p[4];
+            vho_mat4_mul_vec4(inv, w, p);
+            if (p[2] < zmin) zmin = p[2];
+            const float z = p[2] > 1.0e-6f ? p[2] : 1.0e-6f;
+            const float u = t->rc_fx * p[0] / z + t->rc_cx, v = t->rc_fy * p[1] / z + t->rc_cy;
+            if (u < umin) umin = u;
+            if (u > umax) umax = u;
+            if (v < vmin) vmin = v;
+            if (v > vmax) vmax = v;
+        }
+        int x0 = 0, x1 = W - 1, y0 = 0, y1 = H - 1;
+        if (zmin > 0.1f) {
+            if (umax < -8.0f || vmax < -8.0f || umin > (float)W + 8.0f || vmin > (float)H + 8.0f) continue;
+            x0 = (int)floorf(umin) - 6; if (x0 < 0) x0 = 0;
+            y0 = (int)floorf(vmin) - 6; if (y0 < 0) y0 = 0;
+            x1 = (int)ceilf(fminf(umax, 1.0e6f)) + 6; if (x1 > W - 1) x1 = W - 1;
+            y1 = (int)ceilf(fminf(vmax, 1.0e6f)) + 6; if (y1 > H - 1) y1 = H - 1;
+        }
+        for (int py = y0; py <= y1; ++py)
+        for (int px = x0; px <= x1; ++px) {
+            const float dx = ((float)px - t->rc_cx) / t->rc_fx, dy = ((float)py - t->rc_cy) / t->rc_fy;
+            const float d[3] = { pose[0] * dx + pose[1] * dy + pose[2], pose[4] * dx + pose[5] * dy + pose[6],
+                                 pose[8] * dx + pose[9] * dy + pose[10] };
+            float tn, tf;
+            if (!ray_box(o, d, lo, hi, &tn, &tf)) continue;
+            if (tf < t_min || tn > t_max) continue;
+            const float f = fmaxf(tn, t_min), k = fminf(tf, t_max);
+            float *pf = front + (size_t)py * W + px, *pb = back + (size_t)py * W + px;
+            if (f < *pf) *pf = f;
+            if (k > *pb) *pb = k;
+        }
+    }
+    for (size_t i = 0; i < (size_t)W * H; ++i) if (front[i] == INFINITY) front[i] = 0.0f;
+}
+
+/* ------------------------------------------------------------------ */
 /* block deletion / garbage collection (build extension, SURVEY.md      */
 /* 8(f) next #4; DESIGN.md "deletion")                                  */
 /* ------------------------------------------------------------------ */

@@ -103,6 +103,9 @@ int  vho_integrate_mt(vho_table *t, const float pose[16], const float *verts, in
 void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max,
                  float *depth_out /* W*H */);
 
+/* ---- block silhouettes (SDFRenderer::drawToFrontAndBack) ---- */
+void vho_render_blocks(const vho_table *t, const float pose[16], float t_min, float t_max, float *front, float *back);
+
 /* ---- block deletion / garbage collection (build extension) ---- */
 int vho_delete_blocks(vho_table *t, const int32_t *keys /* n x {x,y,z,_} */, int n);
 int vho_garbage_collect(vho_table *t, float sdf_threshold);

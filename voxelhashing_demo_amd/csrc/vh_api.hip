@@ -47,7 +47,7 @@ static int fail(int code, const char *what, hipError_t e = hipSuccess)
 // hipEventRecord pair would add.
 enum Phase : int {
     kPhaseClaim = 0, kPhaseCommit, kPhaseFlatten, kPhaseIntegrate, kPhaseRaycast,
-    kPhaseFrameScanClaim, kPhaseFrameCommitIntegrate, kPhaseViewExport, kPhaseViewImport, kPhaseGc, kNumPhases
+    kPhaseFrameScanClaim, kPhaseFrameCommitIntegrate, kPhaseViewExport, kPhaseViewImport, kPhaseGc, kPhaseRaycastBounds, kNumPhases
 };
 
 struct TimedLaunch {
@@ -656,6 +656,44 @@ extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, floa
                                 c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out)
                        : launch(c, kPhaseRaycast, raycast_kernel<0>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy,
                                 c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out);
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// Block silhouettes: SDFRenderer::drawToFrontAndBack, SDFRenderer.cpp:165-208.
+extern "C" int vh_render_blocks(vh_context *c, const float pose[16], float t_min, float t_max, float *d_front,
+                                float *d_back)
+{
+    if (!c || !pose || !d_front || !d_back) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (!(t_max > t_min) || !(t_min >= 0.0f)) return fail(VH_ERR_INVALID_ARGUMENT, "need 0 <= t_min < t_max");
+    DeviceGuard guard(c->device);
+    BlockView bv;
+    float inv[16];
+    invert4x4(pose, inv);
+    std::memcpy(bv.T, pose, sizeof bv.T);
+    std::memcpy(bv.Tinv, inv, sizeof bv.Tinv);
+    bv.fx = c->rc_fx; bv.fy = c->rc_fy; bv.cx = c->rc_cx; bv.cy = c->rc_cy;
+    bv.tMin = t_min;
+    bv.tMax = t_max;
+    const int32_t npix = c->fp.width * c->fp.height;
+    // entry list and its counter live in the candidates buffer (free between frames): 4 ints per pixel
+    int32_t *listCount = reinterpret_cast<int32_t *>(c->dp.candidates);
+    int32_t *list = listCount + 4;
+    const int32_t capacity = (int32_t)std::min<size_t>((size_t)c->dp.candCapacity * 4 - 4, c->numEntries);
+    uint32_t *front = reinterpret_cast<uint32_t *>(d_front), *back = reinterpret_cast<uint32_t *>(d_back);
+    int rc = launch(c, kPhaseRaycastBounds, blocks_init_kernel, dim3((unsigned)grid_for((size_t)npix, 256)), dim3(256), front,
+                    back, npix, listCount);
+    const uint32_t words = (c->ownedBuckets + 31u) / 32u;
+    if (rc == VH_OK)
+        rc = launch(c, kPhaseRaycastBounds, blocks_list_kernel, dim3((unsigned)grid_for(words, 256)), dim3(256), c->fp, c->dp,
+                    list, capacity, listCount);
+    if (rc == VH_OK)
+        rc = launch(c, kPhaseRaycastBounds, blocks_raster_kernel, dim3(2048), dim3(256), c->fp, c->dp, bv,
+                    (const int32_t *)list, capacity, (const int32_t *)listCount, front, back);
+    if (rc == VH_OK)
+        rc = launch(c, kPhaseRaycastBounds, blocks_finish_kernel, dim3((unsigned)grid_for((size_t)npix, 256)), dim3(256), front,
+                    npix);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -1292,6 +1330,7 @@ extern "C" int vh_get_kernel_times(vh_context *c, vh_kernel_times *out, int rese
             case kPhaseViewExport: c->times.view_export_ms += ms; break;
             case kPhaseViewImport: c->times.view_import_ms += ms; break;
             case kPhaseGc: c->times.gc_ms += ms; break;
+            case kPhaseRaycastBounds: c->times.raycast_ms += ms; break;      // vh_render_blocks: counted with the render work
             default: break;
         }
     }

@@ -15,6 +15,8 @@
 //   vh_raycast.hip     per-pixel march through the hash (stand-in for SDFRenderer::render,
 //                      SDFRenderer.cpp:210-255)
 //   vh_view.hip        raycast over shards: export of the blocks a view can touch, view table import
+//   vh_blocks.hip      block silhouettes: per-pixel nearest front / farthest back face of the allocated
+//                      blocks' cubes (SDFRenderer::drawToFrontAndBack, SDFRenderer.cpp:165-208)
 //   vh_gc.hip          block deletion / garbage collection (deleteVoxelEntry :544-604 done correctly)
 //   vh_preprocess.hip  depth -> vertex / normal maps (preProcess, CameraTrackingUtils.cu:50-120),
 //                      table set-up kernels (VoxelUtils.cu:151-166), device-side test hook
@@ -33,5 +35,6 @@
 #include "vh_raycast.hip"
 #include "vh_view.hip"
 #include "vh_gc.hip"
+#include "vh_blocks.hip"
 #include "vh_preprocess.hip"
 #include "vh_icp.hip"

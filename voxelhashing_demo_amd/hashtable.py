@@ -125,6 +125,12 @@ class SDFHashtable:
         L.check(self._lib.vh_raycast(self._h, pp, t_min, t_max, _dev_ptr(out)), "vh_raycast")
         return out
 
+    def render_blocks(self, pose, front, back, t_min: float = 0.1, t_max: float = 5.0):
+        """Block silhouettes (SDFRenderer::drawToFrontAndBack): nearest front / farthest back cube face per pixel."""
+        _, pp = _pose16(pose)
+        L.check(self._lib.vh_render_blocks(self._h, pp, t_min, t_max, _dev_ptr(front), _dev_ptr(back)), "vh_render_blocks")
+        return front, back
+
     # ---- deletion / garbage collection (SURVEY.md 8(f) next #4) ----
     def delete_blocks(self, keys, n: int = None):
         """keys: device int32 [n, 4] = {x, y, z, _}."""
