@@ -313,7 +313,20 @@ def main():
     kt_g = table.kernel_times(reset=True)
     gc_counters = table.counters()
     table.set_profiling(False)
+    # block silhouettes (row R1): front / back cube depth per pixel
+    sil_f, sil_b = torch.empty((Ht, Wd), dtype=torch.float32, device=dev), torch.empty((Ht, Wd), dtype=torch.float32, device=dev)
+    for i in range(3):
+        lib.vh_render_blocks(h, pose_ptrs[0], 0.1, 5.0, sil_f.data_ptr(), sil_b.data_ptr())
+    table.synchronize()
+    t6 = time.perf_counter()
+    for i in range(20):
+        lib.vh_render_blocks(h, pose_ptrs[(7 * i) % nframes], 0.1, 5.0, sil_f.data_ptr(), sil_b.data_ptr())
+    table.synchronize()
+    sil_us = 1e6 * (time.perf_counter() - t6) / 20
     next_rows = dict(
+        block_silhouettes=dict(us_per_call=round(sil_us, 1), covered_pixels=int((sil_f > 0).sum()),
+                               note="vh_render_blocks (SDFRenderer::drawToFrontAndBack): exact ray/box test of every "
+                                    "allocated block's cube, 4 launches, host-timed"),
         icp_round=dict(us_per_round=round(icp_us, 2), pairs=icp_sys[3], algorithmic_bytes=icp_bytes,
                        note="vh_icp_build_system against a raycast target, host-timed and synchronous "
                             "(the step API returns each round's 27 sums to the host)"),

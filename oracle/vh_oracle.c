@@ -770,12 +770,13 @@ void vho_render_blocks(const vho_table *t, const float pose[16], float t_min, fl
             hi[a] = ((float)wrap_mul(t->table[e].pos[a], 8) + 8.0f) * t->p.voxelSize;
         }
         /* a generous screen bounding box keeps this loop short; any superset of the hit pixels gives the same image */
-        float zmin = 3.0e38f, umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
+        float zmin = 3.0e38f, zmax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
         for (int c = 0; c < 8; ++c) {
             const float w[4] = { (c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2], 1.0f };
             float p[4];
             vho_mat4_mul_vec4(inv, w, p);
             if (p[2] < zmin) zmin = p[2];
+            if (p[2] > zmax) zmax = p[2];
             const float z = p[2] > 1.0e-6f ? p[2] : 1.0e-6f;
             const float u = t->rc_fx * p[0] / z + t->rc_cx, v = t->rc_fy * p[1] / z + t->rc_cy;
             if (u < umin) umin = u;
@@ -783,6 +784,7 @@ void vho_render_blocks(const vho_table *t, const float pose[16], float t_min, fl
             if (v < vmin) vmin = v;
             if (v > vmax) vmax = v;
         }
+        if (zmax < t_min - 2.0f * t->p.voxelSize || zmin > t_max + 2.0f * t->p.voxelSize) continue;   /* out of the depth range */
         int x0 = 0, x1 = W - 1, y0 = 0, y1 = H - 1;
         if (zmin > 0.1f) {
             if (umax < -8.0f || vmax < -8.0f || umin > (float)W + 8.0f || vmin > (float)H + 8.0f) continue;

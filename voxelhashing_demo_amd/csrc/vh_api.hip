@@ -689,7 +689,7 @@ extern "C" int vh_render_blocks(vh_context *c, const float pose[16], float t_min
         rc = launch(c, kPhaseRaycastBounds, blocks_list_kernel, dim3((unsigned)grid_for(words, 256)), dim3(256), c->fp, c->dp,
                     list, capacity, listCount);
     if (rc == VH_OK)
-        rc = launch(c, kPhaseRaycastBounds, blocks_raster_kernel, dim3(2048), dim3(256), c->fp, c->dp, bv,
+        rc = launch(c, kPhaseRaycastBounds, blocks_raster_kernel, dim3(1024, 16), dim3(256), c->fp, c->dp, bv,
                     (const int32_t *)list, capacity, (const int32_t *)listCount, front, back);
     if (rc == VH_OK)
         rc = launch(c, kPhaseRaycastBounds, blocks_finish_kernel, dim3((unsigned)grid_for((size_t)npix, 256)), dim3(256), front,

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void blocks_raster_kernel(const FrameParams fp
             lo[a] = (float)(int)((uint32_t)e.pos[a] * 8u) * fp.voxelSize;
             hi[a] = ((float)(int)((uint32_t)e.pos[a] * 8u) + 8.0f) * fp.voxelSize;
         }
-        float zmin = 3.0e38f, umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
+        float zmin = 3.0e38f, zmax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float wx = (c & 1) ? hi[0] : lo[0], wy = (c & 2) ? hi[1] : lo[1], wz = (c & 4) ? hi[2] : lo[2];
@@ -90,11 +90,15 @@ __global__ __launch_bounds__(256) void blocks_raster_kernel(const FrameParams fp
             const float y = bv.Tinv[4] * wx + bv.Tinv[5] * wy + bv.Tinv[6] * wz + bv.Tinv[7];
             const float z = bv.Tinv[8] * wx + bv.Tinv[9] * wy + bv.Tinv[10] * wz + bv.Tinv[11];
             zmin = __builtin_fminf(zmin, z);
+            zmax = __builtin_fmaxf(zmax, z);
             const float iz = 1.0f / __builtin_fmaxf(z, 1.0e-6f);
             const float u = bv.fx * x * iz + bv.cx, v = bv.fy * y * iz + bv.cy;
             umin = __builtin_fminf(umin, u); umax = __builtin_fmaxf(umax, u);
             vmin = __builtin_fminf(vmin, v); vmax = __builtin_fmaxf(vmax, v);
         }
+        // wholly nearer than the first sample depth (e.g. behind the camera) or beyond the last: no pixel
+        // can see it in [tMin, tMax] (camera depth along a ray = z of the point)
+        if (zmax < bv.tMin - fp.voxelSize || zmin > bv.tMax + fp.voxelSize) continue;
         int x0 = 0, x1 = fp.width - 1, y0 = 0, y1 = fp.height - 1;
         if (zmin > 0.05f) {
             if (umax < -2.0f || vmax < -2.0f || umin > (float)fp.width + 1.0f || vmin > (float)fp.height + 1.0f) continue;
@@ -103,6 +107,11 @@ __global__ __launch_bounds__(256) void blocks_raster_kernel(const FrameParams fp
             x1 = min(fp.width - 1, (int)__builtin_ceilf(__builtin_fminf(umax, 1.0e6f)) + 2);
             y1 = min(fp.height - 1, (int)__builtin_ceilf(__builtin_fminf(vmax, 1.0e6f)) + 2);
         }
+        // blockIdx.y cuts the box into horizontal bands (a block next to the camera covers 10^5 pixels)
+        const int bandH = (y1 - y0 + (int)gridDim.y) / (int)gridDim.y;
+        y0 += (int)blockIdx.y * bandH;
+        y1 = min(y1, y0 + bandH - 1);
+        if (y0 > y1) continue;
         const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
         const float o[3] = {bv.T[3], bv.T[7], bv.T[11]};
         for (int i = threadIdx.x; i < bw * bh; i += 256) {
