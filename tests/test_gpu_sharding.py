@@ -81,7 +81,8 @@ def test_key_bin_overflow_is_reported(vh, torch_cuda):
     assert 0 < c["allocated_total"] <= 15
 
 
-def test_pipelined_steps_equal_sequential_over_nccl(oracle, vh, torch_cuda):
+@pytest.mark.parametrize("sensor", [False, True])
+def test_pipelined_steps_equal_sequential_over_nccl(oracle, vh, torch_cuda, sensor):
     """RCCL transport with one rank: the two-stream pipeline (generate + collectives of step i+1
     under the table work of step i) leaves exactly the table the plain step sequence leaves,
     and both equal the oracle."""
@@ -97,21 +98,28 @@ def test_pipelined_steps_equal_sequential_over_nccl(oracle, vh, torch_cuda):
         transport = vdist.TorchDistTransport()
         batch, steps = 2, 5
         frames = [[cameras(1, s * batch + b)[0] for b in range(batch)] for s in range(steps)]
+        kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+        depths = None
+        if sensor:        # sensor-depth packets: quantised depth, vertex maps by preProcess, uint16 images on the wire
+            d16 = [[np.round(v[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for _, v in fs] for fs in frames]
+            frames = [[(p, oracle.preprocess(d, kinv)[0]) for (p, _), d in zip(fs, ds)] for fs, ds in zip(frames, d16)]
+            depths = [[torch.from_numpy(d).cuda() for d in ds] for ds in d16]
         d_frames = [[(p, torch.from_numpy(v).cuda()) for p, v in fs] for fs in frames]
         tables = []
         for pipelined in (False, True):
             table_stream, front = torch.cuda.Stream(), torch.cuda.Stream()
             sh = vdist.HipShard(vh.default_params(**KW), W, H, 1, plan, 0, W * H // 4, batch=batch,
-                                stream=table_stream, sets=2)
+                                stream=table_stream, sets=2, sensor_k_inv=kinv if sensor else None)
             if pipelined:
                 pipe = vdist.ShardedPipeline(sh, transport, table_stream, front)
-                for fs in d_frames:
-                    pipe.feed([f[0] for f in fs], [f[1] for f in fs])
+                for i, fs in enumerate(d_frames):
+                    pipe.feed([f[0] for f in fs], [f[1] for f in fs], depths[i] if sensor else None)
                 pipe.flush()
             else:
                 with torch.cuda.stream(table_stream):
-                    for fs in d_frames:
-                        vdist.sharded_step(sh, transport, [f[0] for f in fs], [f[1] for f in fs])
+                    for i, fs in enumerate(d_frames):
+                        vdist.sharded_step(sh, transport, [f[0] for f in fs], [f[1] for f in fs],
+                                           depths[i] if sensor else None)
                 sh.table.synchronize()
             torch.cuda.synchronize()
             tables.append(sh)
