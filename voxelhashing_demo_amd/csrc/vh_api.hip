@@ -85,6 +85,7 @@ struct vh_context {
     // raycast over shards
     int32_t *viewLists = nullptr;          // export: selected entry indices, [views][capacity]
     size_t viewListsSize = 0;              // in int32
+    int32_t *blockList = nullptr;          // vh_render_blocks: counter (4 ints) + indices of all allocated entries
     const Voxel *viewBlocks = nullptr;     // import: the record buffer the view table's ptrs address
     int32_t viewCount = 0;                 // records of the last import (their buckets are listed in compactMask)
 };
@@ -222,6 +223,8 @@ static int free_buffers(vh_context *c)
     if (c->dp.allocMask) (void)hipFree(c->dp.allocMask);
     if (c->dp.macroBits) (void)hipFree(c->dp.macroBits);
     if (c->viewLists) (void)hipFree(c->viewLists);
+    if (c->blockList) (void)hipFree(c->blockList);
+    c->blockList = nullptr;
     c->viewLists = nullptr;
     c->viewListsSize = 0;
     c->dp = DevPtrs{};
@@ -677,10 +680,14 @@ extern "C" int vh_render_blocks(vh_context *c, const float pose[16], float t_min
     bv.tMin = t_min;
     bv.tMax = t_max;
     const int32_t npix = c->fp.width * c->fp.height;
-    // entry list and its counter live in the candidates buffer (free between frames): 4 ints per pixel
-    int32_t *listCount = reinterpret_cast<int32_t *>(c->dp.candidates);
+    // list of the allocated entries: room for every entry of the table, allocated on first use (synchronises once)
+    if (!c->blockList) {
+        VH_HIP(hipStreamSynchronize(c->stream));
+        VH_HIP(hipMalloc((void **)&c->blockList, sizeof(int32_t) * (c->numEntries + 4)));
+    }
+    int32_t *listCount = c->blockList;
     int32_t *list = listCount + 4;
-    const int32_t capacity = (int32_t)std::min<size_t>((size_t)c->dp.candCapacity * 4 - 4, c->numEntries);
+    const int32_t capacity = (int32_t)c->numEntries;
     uint32_t *front = reinterpret_cast<uint32_t *>(d_front), *back = reinterpret_cast<uint32_t *>(d_back);
     int rc = launch(c, kPhaseRaycastBounds, blocks_init_kernel, dim3((unsigned)grid_for((size_t)npix, 256)), dim3(256), front,
                     back, npix, listCount);
