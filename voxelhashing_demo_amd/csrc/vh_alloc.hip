@@ -69,9 +69,9 @@ struct VertexMap {
     // leaves more of the hash table there for the walk (launch 1: 17.5 -> 17.2 us)
     __device__ __forceinline__ float4 vertex(int idx, int, int) const
     {
-        const float *p = reinterpret_cast<const float *>(verts + idx);
-        return make_float4(__builtin_nontemporal_load(p), __builtin_nontemporal_load(p + 1),
-                           __builtin_nontemporal_load(p + 2), __builtin_nontemporal_load(p + 3));
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(verts + idx));   // one 16-byte load
+        return make_float4(v.x, v.y, v.z, v.w);
     }
 };
 
