@@ -12,6 +12,7 @@ namespace vh {
 
 constexpr int kIcpTerms = 29;        // 21 (upper triangle of J^T J) + 6 (J^T r) + sum d + count
 constexpr int kIcpStride = 32;       // floats per partial record
+constexpr int kIcpUnroll = 4;        // pixels a lane has in flight
 constexpr int kIcpThreads = 256;     // lanes per workgroup (1024-lane workgroups measured slower: 20 vs 17 us per round)
 constexpr int kIcpAbsDistance = 1;   // VH_ICP_ABS_DISTANCE
 constexpr int kIcpNeedTarget = 2;    // VH_ICP_NEED_TARGET
@@ -190,16 +191,14 @@ __device__ __forceinline__ int d2i_rz(double x)
     return r;
 }
 
-// FindCorrespondences for one pixel.  Returns true when a correspondence is kept; t / n are the
-// target point and normal, d the signed point-to-plane distance.
-__device__ __forceinline__ bool icp_correspondence(const IcpParams &ip, const float4 *__restrict__ input,
-                                                   const float4 *__restrict__ target,
-                                                   const float4 *__restrict__ normals, int idx, float4 &t, float4 &n,
-                                                   float &d)
+// FindCorrespondences for one pixel, in two halves so that a lane can have the gathers of several
+// pixels in flight:
+//   icp_project: moved point q and the target pixel it lands on (false: no pairing possible)
+//   icp_pair:    signed point-to-plane distance d against the gathered target point t and normal n,
+//                and whether the pair is kept
+__device__ __forceinline__ bool icp_project(const IcpParams &ip, const float4 p, float q[3], int &ti)
 {
-    const float4 p = input[idx];
     if (p.z == 0.0f) return false;                                             // :148
-    float q[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
         q[r] = ip.delta[4 * r + 0] * p.x + ip.delta[4 * r + 1] * p.y + ip.delta[4 * r + 2] * p.z + ip.delta[4 * r + 3] * 1.0f;
@@ -209,9 +208,12 @@ __device__ __forceinline__ bool icp_correspondence(const IcpParams &ip, const fl
     const int u = d2i_rz((double)(sx / sz) + 0.5);
     const int v = d2i_rz((double)(sy / sz) + 0.5);
     if (!(u > 0 && v > 0 && u < ip.width && v < ip.height)) return false;     // :157 (strict > 0)
-    const size_t ti = (size_t)v * ip.width + u;
-    t = target[ti];
-    n = normals[ti];
+    ti = v * ip.width + u;
+    return true;
+}
+
+__device__ __forceinline__ bool icp_pair(const IcpParams &ip, const float q[3], const float4 t, const float4 n, float &d)
+{
     if ((ip.flags & kIcpNeedTarget) && (t.z == 0.0f || (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f))) return false;
     const float dx = q[0] - t.x, dy = q[1] - t.y, dz = q[2] - t.z;
     d = dx * n.x + dy * n.y + dz * n.z;                                        // :168-169
@@ -269,28 +271,58 @@ __global__ __launch_bounds__(kIcpThreads) void icp_round_kernel(IcpParams ip, co
 #pragma unroll
     for (int k = 0; k < kIcpTerms; ++k) acc[k] = 0.0f;
     const int npix = ip.width * ip.height;
-    for (int idx = blockIdx.x * kIcpThreads + threadIdx.x; idx < npix; idx += gridDim.x * kIcpThreads) {
-        float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n = t;
-        float d = 0.0f;
-        const bool kept = icp_correspondence(ip, input, target, normals, idx, t, n, d);
-        if (kept) {
-            // CalculateJacobians, Solver.cu:27-35: J = [n, target x n]
-            const float J[6] = {n.x, n.y, n.z, t.y * n.z - t.z * n.y, t.z * n.x - t.x * n.z, t.x * n.y - t.y * n.x};
-            int k = 0;
+    // kIcpUnroll pixels per pass: their input points are loaded together, then their target points and
+    // normals are gathered together, then the pairs are accumulated (one memory latency per stage for
+    // the group instead of one per pixel)
+    const int stride = gridDim.x * kIcpThreads;
+    for (int base = blockIdx.x * kIcpThreads + threadIdx.x; base < npix; base += stride * kIcpUnroll) {
+        float4 p[kIcpUnroll], t[kIcpUnroll], n[kIcpUnroll];
+        float q[kIcpUnroll][3];
+        int ti[kIcpUnroll];
+        bool ok[kIcpUnroll];
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * d;
-            acc[27] += d;
-            acc[28] += 1.0f;
+        for (int u = 0; u < kIcpUnroll; ++u) {
+            const int idx = base + u * stride;
+            p[u] = idx < npix ? input[idx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
-        if constexpr (kWriteMaps) {   // the reference clears the maps first (:198-200), then writes the kept ones
-            const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            corres[idx] = kept ? t : zero;
-            corresNormals[idx] = kept ? n : zero;
-            residuals[idx] = kept ? d : 0.0f;
+#pragma unroll
+        for (int u = 0; u < kIcpUnroll; ++u) {
+            ti[u] = 0;
+            ok[u] = (base + u * stride < npix) && icp_project(ip, p[u], q[u], ti[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kIcpUnroll; ++u) {
+            t[u] = target[ti[u]];                  // pixel 0 when there is no pairing: harmless, unused
+            n[u] = normals[ti[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kIcpUnroll; ++u) {
+            const int idx = base + u * stride;
+            float d = 0.0f;
+            const bool kept = ok[u] && icp_pair(ip, q[u], t[u], n[u], d);
+            if (kept) {
+                // CalculateJacobians, Solver.cu:27-35: J = [n, target x n]
+                const float4 tt = t[u], nn = n[u];
+                const float J[6] = {nn.x, nn.y, nn.z, tt.y * nn.z - tt.z * nn.y, tt.z * nn.x - tt.x * nn.z,
+                                    tt.x * nn.y - tt.y * nn.x};
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * d;
+                acc[27] += d;
+                acc[28] += 1.0f;
+            }
+            if constexpr (kWriteMaps) {   // the reference clears the maps first (:198-200), then writes the kept ones
+                if (idx < npix) {
+                    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    corres[idx] = kept ? t[u] : zero;
+                    corresNormals[idx] = kept ? n[u] : zero;
+                    residuals[idx] = kept ? d : 0.0f;
+                }
+            }
         }
     }
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
