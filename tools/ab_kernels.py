@@ -4,7 +4,6 @@
   python tools/ab_kernels.py --option flatten_variant --values 0 1 [--workload C2]
 """
 import argparse
-import ctypes as C
 import os
 import sys
 
