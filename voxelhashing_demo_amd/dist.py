@@ -639,7 +639,7 @@ def bench_sharded(args, wl, rank, world, local_rank):
                         bytes_per_launch=walk_bytes, us_per_launch=round(walk_us, 2),
                         commit_integrate_us=round(1e3 * kt["frame_commit_integrate_ms"] / launches, 2))
         out = dict(
-            metric="frames/s TSDF-integrated, 640x480" if (Wd, Ht) == (640, 480) else f"frames/s TSDF-integrated, {Wd}x{Ht}",
+            metric=args.metric_name,
             value=round(frames / elapsed, 1), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=round(1e3 * elapsed / args.steps, 5), higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f32", data="synthetic",
