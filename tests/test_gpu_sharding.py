@@ -199,3 +199,74 @@ def test_sensor_depth_packets(oracle, vh, torch_cuda, world, batch, sem, calls):
         assert total > 100
     for sh in shards:
         sh.table.close()
+
+
+def _hip_gloo_worker(rank, world, port, q, sensor):
+    """One rank of a two-process run on ONE GPU: real HIP shards, real processes, gloo with host staging
+    for the exchange (RCCL refuses two ranks on one device).  Checks its shard against the oracle."""
+    try:
+        import os
+        import sys
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import torch
+        import torch.distributed as dist
+        import oracle as O
+        import voxelhashing_demo_amd as V
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+        plan = vdist.ShardPlan(KW["numBuckets"], world)
+        batch = 2
+        table_stream, front = torch.cuda.Stream(), torch.cuda.Stream()
+        shard = vdist.HipShard(V.default_params(**KW), W, H, 1, plan, rank, W * H // 4, batch=batch, stream=table_stream,
+                               sets=2, sensor_k_inv=kinv if sensor else None)
+        transport = vdist.TorchDistTransport()
+        pipe = vdist.ShardedPipeline(shard, transport, table_stream, front)
+        full = O.OracleTable(O.default_params(**KW), W, H, 1)
+        for step in range(0, 6, batch):
+            frames = []
+            for b in range(batch):
+                cams = []
+                for pose, verts in cameras(world, step + b):
+                    d16 = None
+                    if sensor:
+                        d16 = np.round(verts[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16)
+                        verts = O.preprocess(d16, kinv)[0]
+                    cams.append((pose, verts, d16))
+                frames.append(cams)
+            pipe.feed([f[rank][0] for f in frames], [torch.from_numpy(f[rank][1]).cuda() for f in frames],
+                      [torch.from_numpy(f[rank][2]).cuda() for f in frames] if sensor else None)
+            for cams in frames:
+                vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+        pipe.flush()
+        n = check_shard_against_full(shard.table, full, *plan.bucket_range(rank), 5)
+        # raycast over the two shards: this rank's last view
+        view = vdist.HipViewTable(V.default_params(**KW), W, H, 1, world, 4096)
+        pose = frames[-1][rank][0]
+        depth, lost = vdist.sharded_raycast(shard, view, transport, pose, 4096)
+        torch.cuda.synchronize()
+        assert lost == 0 and np.array_equal(depth.cpu().numpy().view(np.uint32), full.raycast(pose).view(np.uint32))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok", n, len(full.allocated())))
+    except Exception as e:
+        import traceback
+        q.put((rank, "fail", traceback.format_exc(), str(e)))
+
+
+@pytest.mark.parametrize("sensor", [False, True])
+def test_two_processes_on_one_gpu(oracle, vh, torch_cuda, sensor):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hip_gloo_worker, args=(r, 2, port, q, sensor)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for r in results:
+        assert r[1] == "ok", r[2]
+    assert sum(r[2] for r in results) == results[0][3] > 100

@@ -61,14 +61,28 @@ class TorchDistTransport:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
+    def _staged(self, t):
+        """gloo moves host memory only: device buffers are staged through the host (debugging transport
+        for several processes on ONE GPU, which RCCL refuses; never used with the nccl backend)."""
+        return t.is_cuda and self.dist.get_backend(self.group) != "nccl"
+
     def all_to_all_bins(self, send, recv):
         """send/recv: [world, capacity, 4] int32; bin s of `send` goes to rank s."""
+        if self._staged(send):
+            h_send, h_recv = send.cpu().view(-1), recv.cpu().view(-1)
+            self.dist.all_to_all_single(h_recv, h_send, group=self.group)
+            recv.copy_(h_recv.view(recv.shape))
+            return recv
         self.dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
         return recv
 
     def all_gather_packets(self, packet, out):
         """packet: [P] float32 -> out: [world, P], camera order = rank order."""
-        if packet.is_cuda:
+        if self._staged(packet):
+            h_out = out.cpu()
+            self.dist.all_gather(list(h_out.unbind(0)), packet.cpu(), group=self.group)
+            out.copy_(h_out)
+        elif packet.is_cuda:
             self.dist.all_gather_into_tensor(out.view(-1), packet, group=self.group)
         else:
             self.dist.all_gather(list(out.unbind(0)), packet, group=self.group)
@@ -96,6 +110,9 @@ class TorchDistTransport:
         the host: the only synchronisation of the round).  Records land in `recv` in source order.
         Returns (recv_counts, lost)."""
         import torch
+        staged = self._staged(send)
+        if staged:
+            counts = counts.cpu()
         sc = torch.clamp(counts, max=capacity).to(torch.int64)
         rc = torch.empty_like(sc)
         self.dist.all_to_all_single(rc, sc, group=self.group)
@@ -105,6 +122,12 @@ class TorchDistTransport:
         n_in, n_out = sum(send_counts), sum(recv_counts)
         if n_out > recv.shape[0]:
             raise RuntimeError(f"view receive buffer holds {recv.shape[0]} records, {n_out} arrive")
+        if staged:
+            h_recv = torch.empty((n_out, recv.shape[1]), dtype=recv.dtype)
+            self.dist.all_to_all_single(h_recv, send[:n_in].cpu(), output_split_sizes=recv_counts,
+                                        input_split_sizes=send_counts, group=self.group)
+            recv[:n_out].copy_(h_recv)
+            return recv_counts, lost
         self.dist.all_to_all_single(recv[:n_out], send[:n_in], output_split_sizes=recv_counts,
                                     input_split_sizes=send_counts, group=self.group)
         return recv_counts, lost
