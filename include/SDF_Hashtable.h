@@ -48,6 +48,9 @@ public:
         integrate(deltaT, reinterpret_cast<const vh_float4 *>(d_verts), reinterpret_cast<const vh_float4 *>(d_normals));
     }
     void raycast(const float4x4 &pose, float *d_depth_out, float zNear = 0.1f, float zFar = 5.0f);
+    /* depth plus camera-frame vertex and normal maps of the view (what CameraTracking::Align takes as target) */
+    void raycast(const float4x4 &pose, float *d_depth_out, vh_float4 *d_vertices_out, vh_float4 *d_normals_out,
+                 float zNear = 0.1f, float zFar = 5.0f);
     /* SDFRenderer::drawToFrontAndBack (SDFRenderer.cpp:165-208): nearest front / farthest back face of the
      * allocated blocks' cubes per pixel, as two depth images (vh_render_blocks) */
     void renderBlocks(const float4x4 &pose, float *d_front, float *d_back, float zNear = 0.1f, float zFar = 5.0f);

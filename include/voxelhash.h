@@ -455,6 +455,10 @@ int vh_icp_align(vh_icp *icp, const vh_float4 *d_input, const vh_float4 *d_targe
  * the arithmetic of preProcess; asynchronous on hip_stream. */
 int vh_depth_to_maps(const float *d_depth, const float k_inv[9], int32_t width, int32_t height,
                      vh_float4 *d_positions, vh_float4 *d_normals, void *hip_stream);
+/* vh_raycast, then vertex and normal maps (camera frame) of the same view, with the K^-1 of the
+ * raycast intrinsics: the model as an ICP target (raycast(pose, depth, normals)). */
+int vh_raycast_maps(vh_context *ctx, const float pose[16], float t_min, float t_max, float *d_depth_out,
+                    vh_float4 *d_vertices_out, vh_float4 *d_normals_out);
 /* the reference's own name (CameraTrackingUtils.cu:187-215; float4x4 by value there, a pointer to
  * its 16 row-major floats here): intrinsics from SetCameraIntrinsic, threshold 0.08 (common.h:12),
  * synchronous, returns the summed residual */

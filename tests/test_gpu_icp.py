@@ -180,3 +180,29 @@ def test_frame_to_model_tracking_loop(oracle, vh, torch_cuda):
     moved = np.abs(np.asarray(gt[-1], np.float64).reshape(4, 4)[:3, 3] - np.asarray(gt[0], np.float64).reshape(4, 4)[:3, 3]).max()
     assert moved > 0.1
     assert max(errs) < 0.01, errs          # drift below 1 cm over 14 cm of travel
+
+
+def test_raycast_maps_is_raycast_plus_depth_to_maps(oracle, vh, torch_cuda):
+    torch = torch_cuda
+    prims = synth.room_primitives()
+    poses = synth.camera_loop(60)
+    kw = dict(numBuckets=1 << 14, numVoxelBlocks=8192)
+    ot = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    gt = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
+    for p in poses[:9:3]:
+        v = synth.render_room_verts(p, W, H, prims).numpy()
+        ot.integrate(p, v)
+        gt.integrate(p, torch.from_numpy(v).cuda())
+    depth = torch.empty((H, W), device="cuda")
+    vm, nm = torch.empty((H, W, 4), device="cuda"), torch.empty((H, W, 4), device="cuda")
+    gt.raycast_maps(poses[6], depth, vm, nm)
+    torch.cuda.synchronize()
+    ref = ot.raycast(poses[6])
+    fx, fy, cx, cy = (np.float32(a) for a in synth.intrinsics(W, H))
+    one = np.float32(1.0)
+    kinv = np.array([one / fx, 0, -cx / fx, 0, one / fy, -cy / fy, 0, 0, 1], np.float32)
+    ov, on = oracle.depth_to_maps(ref, kinv)
+    assert np.array_equal(depth.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(vm.cpu().numpy().view(np.uint32), ov.view(np.uint32))
+    assert np.array_equal(nm.cpu().numpy().view(np.uint32), on.view(np.uint32))
+    assert (on[..., :3] != 0).any(axis=-1).sum() > 10000

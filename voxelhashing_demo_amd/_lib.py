@@ -111,6 +111,7 @@ SIGNATURES = {
     "vh_se3_log": (None, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "vh_icp_align": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _f, C.c_int32, C.c_int32, _fp, C.POINTER(IcpSystem),
                                C.POINTER(C.c_int32)]),
+    "vh_raycast_maps": (C.c_int, [_vp, _fp, _f, _f, _vp, _vp, _vp]),
     "vh_depth_to_maps": (C.c_int, [_vp, _fp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "computeCorrespondences": (C.c_float, [_vp, _vp, _vp, _vp, _vp, _vp, _fp, C.c_int, C.c_int]),
     "vh_generate_keys_depth_batch": (C.c_int, [_vp, C.c_int32, _fp, C.POINTER(_vp), _fp, C.c_uint32, C.c_int32, _vp,

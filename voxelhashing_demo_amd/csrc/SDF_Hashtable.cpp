@@ -52,6 +52,12 @@ void SDF_Hashtable::raycast(const float4x4 &pose, float *d_depth_out, float zNea
     check(vh_raycast(ctx_, pose.entries, zNear, zFar, d_depth_out), "raycast");
 }
 
+void SDF_Hashtable::raycast(const float4x4 &pose, float *d_depth_out, vh_float4 *d_vertices_out, vh_float4 *d_normals_out,
+                            float zNear, float zFar)
+{
+    check(vh_raycast_maps(ctx_, pose.entries, zNear, zFar, d_depth_out, d_vertices_out, d_normals_out), "raycast");
+}
+
 void SDF_Hashtable::renderBlocks(const float4x4 &pose, float *d_front, float *d_back, float zNear, float zFar)
 {
     check(vh_render_blocks(ctx_, pose.entries, zNear, zFar, d_front, d_back), "renderBlocks");

@@ -197,6 +197,21 @@ extern "C" int vh_depth_to_maps(const float *d_depth, const float k_inv[9], int3
     return VH_OK;
 }
 
+// vh_raycast followed by vh_depth_to_maps with the K^-1 of the raycast intrinsics: depth, camera-frame
+// vertex map and normal map of the model seen from `pose` (raycast(pose, d_depth_out,
+// d_normal_out)).  The maps are what vh_icp_align takes as its target.
+extern "C" int vh_raycast_maps(vh_context *c, const float pose[16], float t_min, float t_max, float *d_depth_out,
+                               vh_float4 *d_vertices_out, vh_float4 *d_normals_out)
+{
+    if (!c || !d_depth_out || !d_vertices_out || !d_normals_out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    const int rc = vh_raycast(c, pose, t_min, t_max, d_depth_out);
+    if (rc != VH_OK) return rc;
+    const float k_inv[9] = {1.0f / c->rc_fx, 0.0f, -c->rc_cx / c->rc_fx, 0.0f, 1.0f / c->rc_fy, -c->rc_cy / c->rc_fy,
+                            0.0f, 0.0f, 1.0f};
+    DeviceGuard guard(c->device);
+    return vh_depth_to_maps(d_depth_out, k_inv, c->fp.width, c->fp.height, d_vertices_out, d_normals_out, c->stream);
+}
+
 // The reference's own name (CameraTrackingUtils.cu:187-215): 640x480, intrinsics from
 // SetCameraIntrinsic, thresholds of common.h:12-13, synchronous; returns the summed residual.
 // `deltaTransform` is a float4x4 passed by value in the reference; here a pointer to its 16

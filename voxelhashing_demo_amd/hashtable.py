@@ -125,6 +125,13 @@ class SDFHashtable:
         L.check(self._lib.vh_raycast(self._h, pp, t_min, t_max, _dev_ptr(out)), "vh_raycast")
         return out
 
+    def raycast_maps(self, pose, depth, vertices, normals, t_min: float = 0.1, t_max: float = 5.0):
+        """raycast + camera-frame vertex and normal maps of the same view (an ICP target)."""
+        _, pp = _pose16(pose)
+        L.check(self._lib.vh_raycast_maps(self._h, pp, t_min, t_max, _dev_ptr(depth), _dev_ptr(vertices),
+                                          _dev_ptr(normals)), "vh_raycast_maps")
+        return depth, vertices, normals
+
     def render_blocks(self, pose, front, back, t_min: float = 0.1, t_max: float = 5.0):
         """Block silhouettes (SDFRenderer::drawToFrontAndBack): nearest front / farthest back cube face per pixel."""
         _, pp = _pose16(pose)
