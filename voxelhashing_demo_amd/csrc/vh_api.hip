@@ -71,6 +71,7 @@ struct vh_context {
     int integrateGrid = 2048;
     int persistentBlocks = 2048;   // workgroups of the persistent walk (flatten_variant 5)
     int raycastPatch = 1;          // pixels of a raycast wave: 1 = 8x8 square, 0 = 16x4 rows
+    int raycastXcd = 1;            // tiles renumbered so that each XCD (own L2) renders a contiguous part of the image
     int packetFormat = VH_PACKET_F32;   // what vh_integrate_packets / vh_apply_frames_batch read
     int fusedFrame = 1;            // vh_integrate as two launches (0: the four step kernels)
     int commitBlocks = 128;        // workgroups serving candidates in the fused second launch
@@ -656,9 +657,9 @@ extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, floa
     if (c->viewBlocks) dp.blocks = const_cast<Voxel *>(c->viewBlocks);     // view table: voxels live in the records
     const int rc = c->raycastPatch
                        ? launch(c, kPhaseRaycast, raycast_kernel<1>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy,
-                                c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out)
+                                c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out, c->raycastXcd)
                        : launch(c, kPhaseRaycast, raycast_kernel<0>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy,
-                                c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out);
+                                c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out, c->raycastXcd);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -1302,6 +1303,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (std::strcmp(name, "integrate_grid") == 0 && value > 0) { c->integrateGrid = value; return VH_OK; }
     if (std::strcmp(name, "fused_frame") == 0) { c->fusedFrame = value; return VH_OK; }
     if (std::strcmp(name, "raycast_patch") == 0) { c->raycastPatch = value; return VH_OK; }
+    if (std::strcmp(name, "raycast_xcd") == 0) { c->raycastXcd = value; return VH_OK; }
     if (std::strcmp(name, "packet_format") == 0 && (value == VH_PACKET_F32 || value == VH_PACKET_U16)) {
         c->packetFormat = value;
         return VH_OK;

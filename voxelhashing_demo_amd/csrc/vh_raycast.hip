@@ -48,11 +48,23 @@ constexpr float kSkipMargin = 0.01f;     // voxels
 template <int kPatch>
 __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, const DevPtrs dp, float fx, float fy,
                                                       float cx, float cy, float tMin, int nSteps,
-                                                      float *__restrict__ depthOut)
+                                                      float *__restrict__ depthOut, int xcdAware)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int u = blockIdx.x * 16 + (kPatch == 0 ? (int)(threadIdx.x & 15) : (wave & 1) * 8 + (lane & 7));
-    const int v = blockIdx.y * 16 + (kPatch == 0 ? (int)(threadIdx.x >> 4) : (wave >> 1) * 8 + (lane >> 3));
+    // Workgroups are handed to the 8 XCDs round robin (workgroup b runs on XCD b % 8, each with its own
+    // L2).  With xcdAware the tiles are renumbered so that an XCD gets a contiguous run of image tiles:
+    // neighbouring rays, which sample the same blocks, then share an L2.
+    int tx = blockIdx.x, ty = blockIdx.y;
+    if (xcdAware) {
+        const int n = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+        if ((n & 7) == 0) {
+            const int r = (b & 7) * (n >> 3) + (b >> 3);
+            ty = r / (int)gridDim.x;
+            tx = r - ty * (int)gridDim.x;
+        }
+    }
+    const int u = tx * 16 + (kPatch == 0 ? (int)(threadIdx.x & 15) : (wave & 1) * 8 + (lane & 7));
+    const int v = ty * 16 + (kPatch == 0 ? (int)(threadIdx.x >> 4) : (wave >> 1) * 8 + (lane >> 3));
     if (u >= fp.width || v >= fp.height) return;
     const float dx = ((float)u - cx) / fx;
     const float dy = ((float)v - cy) / fy;
