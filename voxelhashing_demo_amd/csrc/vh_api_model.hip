@@ -1,0 +1,329 @@
+// vh_api_model.hip -- C-ABI, the model: deletion / garbage collection, queries, dump and snapshot, options and profiling.
+// Included by vh_api.hip (same translation unit: shares fail(), VH_HIP, DeviceGuard, launch()).
+
+// ---------------------------------------------------------------------------
+// block deletion / garbage collection
+// ---------------------------------------------------------------------------
+static int sweep_and_release(vh_context *c)
+{
+    int rc = launch(c, kPhaseGc, gc_sweep_kernel, dim3(256), dim3(256), c->fp, c->dp);
+    if (rc != VH_OK) return rc;
+    rc = launch(c, kPhaseGc, gc_release_kernel, dim3(1024), dim3(256), c->dp);
+    if (rc != VH_OK) return rc;
+    rc = launch(c, kPhaseGc, gc_finish_kernel, dim3(1), dim3(1), c->dp, c->occupiedCounter);
+    if (rc != VH_OK) return rc;
+    if (c->profiling) c->times.gc_calls += 1;
+    c->params.numOccupiedBlocks = 0;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_delete_blocks(vh_context *c, const int32_t *d_keys, int32_t n)
+{
+    if (!c || (!d_keys && n > 0) || n < 0) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table owns no blocks");
+    DeviceGuard guard(c->device);
+    c->fp.epoch += 1;                       // the sweep list is built under a fresh lock epoch
+    if (n > 0) {
+        const int rc = launch(c, kPhaseGc, gc_mark_keys_kernel, dim3((unsigned)grid_for((size_t)n, 256)), dim3(256), c->fp,
+                              c->dp, reinterpret_cast<const int4 *>(d_keys), n);
+        if (rc != VH_OK) return rc;
+    }
+    return sweep_and_release(c);
+}
+
+extern "C" int vh_garbage_collect(vh_context *c, float sdf_threshold)
+{
+    if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table owns no blocks");
+    DeviceGuard guard(c->device);
+    c->fp.epoch += 1;
+    const int rc = launch(c, kPhaseGc, gc_identify_kernel, dim3(2048), dim3(256), c->fp, c->dp, c->occupiedCounter,
+                          sdf_threshold);
+    if (rc != VH_OK) return rc;
+    return sweep_and_release(c);
+}
+
+// ---------------------------------------------------------------------------
+// queries
+// ---------------------------------------------------------------------------
+extern "C" int vh_synchronize(vh_context *c)
+{
+    if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    DeviceGuard guard(c->device);
+    VH_HIP(hipStreamSynchronize(c->stream));
+    return VH_OK;
+}
+
+extern "C" int vh_get_counters(vh_context *c, vh_counters *out)
+{
+    if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(c->device);
+    int32_t h[kNumCounters];
+    VH_HIP(hipMemcpyAsync(h, c->dp.counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    VH_HIP(hipStreamSynchronize(c->stream));
+    out->occupied = h[c->occupiedCounter];
+    out->heap_counter = h[kHeapCounter];
+    out->allocated_total = (uint32_t)h[kAllocatedTotal];
+    out->heap_exhausted = (uint32_t)h[kHeapExhausted];
+    out->candidates = (uint32_t)h[kLastCandidates];
+    out->epoch = c->fp.epoch;
+    out->bin_overflow = (uint32_t)h[kBinOverflow];
+    out->freed_total = (uint32_t)h[kFreedTotal];
+    out->last_freed = (uint32_t)h[kLastFreed];
+    c->params.numOccupiedBlocks = (uint32_t)h[c->occupiedCounter];
+    return VH_OK;
+}
+
+extern "C" int vh_get_params(vh_context *c, HashTableParams *out)
+{
+    if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    *out = c->params;
+    return VH_OK;
+}
+
+extern "C" int vh_get_device_pointers(vh_context *c, PtrContainer *out)
+{
+    if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    out->d_heap = c->dp.heap;
+    out->d_hashTable = c->dp.table;
+    out->d_compactifiedHashTable = c->dp.compact;
+    out->d_hashTableBucketMutex = reinterpret_cast<uint64_t *>(c->dp.claim);
+    out->d_SDFBlocks = c->dp.blocks;
+    out->d_heapCounter = c->dp.counters + kHeapCounter;
+    out->d_compactifiedHashCounter = c->dp.counters + kCompactCount;
+    return VH_OK;
+}
+
+extern "C" int vh_download(vh_context *c, int which, void *dst, size_t bytes)
+{
+    if (!c || !dst) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    const void *src = nullptr;
+    size_t avail = 0;
+    switch (which) {
+        case VH_BUF_HASH_TABLE: src = c->dp.table; avail = sizeof(VoxelEntry) * c->numEntries; break;
+        case VH_BUF_COMPACT: src = c->dp.compact; avail = sizeof(VoxelEntry) * c->numEntries; break;
+        case VH_BUF_SDF_BLOCKS: src = c->dp.blocks; avail = sizeof(Voxel) * (size_t)c->params.numVoxelBlocks * kBlockVoxels; break;
+        case VH_BUF_HEAP: src = c->dp.heap; avail = sizeof(uint32_t) * (size_t)c->params.numVoxelBlocks; break;
+        default: return fail(VH_ERR_INVALID_ARGUMENT, "unknown buffer id");
+    }
+    if (bytes > avail) return fail(VH_ERR_INVALID_ARGUMENT, "download larger than the buffer");
+    DeviceGuard guard(c->device);
+    VH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    VH_HIP(hipStreamSynchronize(c->stream));
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// model dump / checkpoint
+// ---------------------------------------------------------------------------
+// SDFRenderer::printSDFdata (SDFRenderer.cpp:71-110), the reference's only on-disk artefact:
+// the occupied count, then per compact entry "pos / ptr / offset" and 512 sdf values with 4
+// decimals.  Faithful to a quirk of the original: the 512 values printed for entry i are voxels
+// [512*i, 512*i+512) of the volume (it reads the first count*512 voxels, :85-87), NOT the block
+// the entry's ptr names.
+extern "C" int vh_dump_sdf_text(vh_context *c, const char *path)
+{
+    if (!c || !path) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    vh_counters k;
+    int rc = vh_get_counters(c, &k);
+    if (rc != VH_OK) return rc;
+    const size_t n = (size_t)(k.occupied > 0 ? k.occupied : 0);
+    std::vector<VoxelEntry> entries(n);
+    const size_t nvox = std::min(n * kBlockVoxels, (size_t)c->params.numVoxelBlocks * kBlockVoxels);
+    std::vector<Voxel> vox(n * kBlockVoxels, Voxel{0.0f, 0.0f});
+    if (n) {
+        if ((rc = vh_download(c, VH_BUF_COMPACT, entries.data(), n * sizeof(VoxelEntry))) != VH_OK) return rc;
+        if ((rc = vh_download(c, VH_BUF_SDF_BLOCKS, vox.data(), nvox * sizeof(Voxel))) != VH_OK) return rc;
+    }
+    FILE *f = std::fopen(path, "w");
+    if (!f) return fail(VH_ERR_INVALID_ARGUMENT, "cannot open the dump file");
+    std::fprintf(f, "numOccupiedBlocks from GL :%zu\n", n);                                  // :95
+    std::fprintf(f, "\nSDFs \n\n");                                                           // :100
+    for (size_t i = 0; i < n; ++i) {
+        const VoxelEntry &e = entries[i];
+        std::fprintf(f, "%zu) : pos : (%d, %d, %d) ptr = %d offset = %d\n", i, e.pos[0], e.pos[1], e.pos[2], e.ptr,
+                     e.offset);                                                               // :102-103
+        for (int j = 0; j < kBlockVoxels; ++j) std::fprintf(f, "%.4f\t", vox[i * kBlockVoxels + j].sdf);   // :104-106
+        std::fprintf(f, "\n\n\n");
+    }
+    std::fclose(f);
+    return VH_OK;
+}
+
+// Binary snapshot: header, hash table, heap, then the 4 KiB block of every allocated entry in
+// table order.  Enough to continue fusing after vh_load_snapshot as if never interrupted.
+struct SnapshotHeader {
+    char magic[8];                 // "VHSNAP01"
+    HashTableParams params;
+    int32_t width, height, semantics;
+    uint32_t bucketLo, bucketHi;
+    int32_t heapCounter;
+    uint32_t allocatedTotal, heapExhausted, epoch;
+    uint64_t numEntries, numAllocated;
+    float proj[9];
+};
+
+extern "C" int vh_save_snapshot(vh_context *c, const char *path)
+{
+    if (!c || !path) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    vh_counters k;
+    int rc = vh_get_counters(c, &k);
+    if (rc != VH_OK) return rc;
+    std::vector<VoxelEntry> table(c->numEntries);
+    std::vector<uint32_t> heap(c->params.numVoxelBlocks);
+    if ((rc = vh_download(c, VH_BUF_HASH_TABLE, table.data(), table.size() * sizeof(VoxelEntry))) != VH_OK) return rc;
+    if ((rc = vh_download(c, VH_BUF_HEAP, heap.data(), heap.size() * sizeof(uint32_t))) != VH_OK) return rc;
+    SnapshotHeader h{};
+    std::memcpy(h.magic, "VHSNAP01", 8);
+    h.params = c->params;
+    h.width = c->fp.width; h.height = c->fp.height; h.semantics = c->fp.semantics;
+    h.bucketLo = c->fp.bucketLo; h.bucketHi = c->fp.bucketHi;
+    h.heapCounter = k.heap_counter; h.allocatedTotal = k.allocated_total; h.heapExhausted = k.heap_exhausted;
+    h.epoch = c->fp.epoch;
+    h.numEntries = c->numEntries;
+    std::memcpy(h.proj, c->fp.proj, sizeof h.proj);
+    for (const VoxelEntry &e : table) h.numAllocated += e.ptr != VH_FREE_BLOCK;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(VH_ERR_INVALID_ARGUMENT, "cannot open the snapshot file");
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+    ok = ok && std::fwrite(table.data(), sizeof(VoxelEntry), table.size(), f) == table.size();
+    ok = ok && std::fwrite(heap.data(), sizeof(uint32_t), heap.size(), f) == heap.size();
+    DeviceGuard guard(c->device);
+    std::vector<Voxel> block(kBlockVoxels);
+    for (const VoxelEntry &e : table) {
+        if (e.ptr == VH_FREE_BLOCK || !ok) continue;
+        if (hipMemcpy(block.data(), c->dp.blocks + e.ptr, sizeof(Voxel) * kBlockVoxels, hipMemcpyDeviceToHost) !=
+            hipSuccess) { ok = false; break; }
+        ok = std::fwrite(block.data(), sizeof(Voxel), kBlockVoxels, f) == (size_t)kBlockVoxels;
+    }
+    std::fclose(f);
+    return ok ? VH_OK : fail(VH_ERR_HIP, "snapshot write failed");
+}
+
+extern "C" int vh_load_snapshot(vh_context *c, const char *path)
+{
+    if (!c || !path) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(VH_ERR_INVALID_ARGUMENT, "cannot open the snapshot file");
+    SnapshotHeader h;
+    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "VHSNAP01", 8) == 0;
+    ok = ok && h.numEntries == c->numEntries && h.params.numVoxelBlocks == c->params.numVoxelBlocks &&
+         h.params.numBuckets == c->params.numBuckets && h.params.bucketSize == c->params.bucketSize &&
+         h.bucketLo == c->fp.bucketLo && h.bucketHi == c->fp.bucketHi && h.width == c->fp.width &&
+         h.height == c->fp.height;
+    if (!ok) { std::fclose(f); return fail(VH_ERR_INVALID_ARGUMENT, "snapshot does not match this context"); }
+    std::vector<VoxelEntry> table(c->numEntries);
+    std::vector<uint32_t> heap(c->params.numVoxelBlocks);
+    ok = std::fread(table.data(), sizeof(VoxelEntry), table.size(), f) == table.size() &&
+         std::fread(heap.data(), sizeof(uint32_t), heap.size(), f) == heap.size();
+    DeviceGuard guard(c->device);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    const size_t words = ((size_t)c->ownedBuckets + 31) / 32;
+    std::vector<uint32_t> bits(words, 0u), macro(kMacroBits / 32, 0u);
+    std::vector<Voxel> block(kBlockVoxels);
+    if (ok && e == hipSuccess)
+        e = hipMemset(c->dp.blocks, 0, sizeof(Voxel) * (size_t)c->params.numVoxelBlocks * kBlockVoxels);
+    for (size_t i = 0; ok && e == hipSuccess && i < table.size(); ++i) {
+        if (table[i].ptr == VH_FREE_BLOCK) continue;
+        const size_t bucket = i / c->params.bucketSize;
+        bits[bucket >> 5] |= 1u << (bucket & 31);
+        const uint32_t hm = ((((uint32_t)(table[i].pos[0] >> 2)) * 73856093u) ^ (((uint32_t)(table[i].pos[1] >> 2)) * 19349669u) ^
+                             (((uint32_t)(table[i].pos[2] >> 2)) * 83492791u)) & (kMacroBits - 1u);
+        macro[hm >> 5] |= 1u << (hm & 31);
+        ok = std::fread(block.data(), sizeof(Voxel), kBlockVoxels, f) == (size_t)kBlockVoxels &&
+             (uint64_t)table[i].ptr + kBlockVoxels <= (uint64_t)c->params.numVoxelBlocks * kBlockVoxels;
+        if (ok) e = hipMemcpy(c->dp.blocks + table[i].ptr, block.data(), sizeof(Voxel) * kBlockVoxels, hipMemcpyHostToDevice);
+    }
+    std::fclose(f);
+    if (!ok) return fail(VH_ERR_INVALID_ARGUMENT, "snapshot is truncated or corrupt");
+    int32_t counters[kNumCounters] = {0};
+    counters[kHeapCounter] = h.heapCounter;
+    counters[kAllocatedTotal] = (int32_t)h.allocatedTotal;
+    counters[kHeapExhausted] = (int32_t)h.heapExhausted;
+    if (e == hipSuccess) e = hipMemcpy(c->dp.table, table.data(), sizeof(VoxelEntry) * table.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->dp.heap, heap.data(), sizeof(uint32_t) * heap.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->dp.bucketBits, bits.data(), sizeof(uint32_t) * words, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(c->dp.macroBits, macro.data(), kMacroBits / 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(c->dp.claim, 0, sizeof(unsigned long long) * (size_t)c->ownedBuckets);
+    if (e == hipSuccess) e = hipMemcpy(c->dp.counters, counters, sizeof counters, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return fail(VH_ERR_HIP, "snapshot upload", e);
+    c->params = h.params;
+    std::memcpy(c->fp.T, h.params.global_transform, sizeof c->fp.T);
+    std::memcpy(c->fp.Tinv, h.params.inv_global_transform, sizeof c->fp.Tinv);
+    std::memcpy(c->fp.proj, h.proj, sizeof h.proj);
+    c->fp.semantics = h.semantics;
+    c->fp.epoch = 0;                 // the claim words were cleared: any epoch >= 1 is fresh
+    c->fusedParity = 0;
+    c->compactArmed = false;
+    c->occupiedCounter = kCompactCount;
+    return VH_OK;
+}
+
+extern "C" int vh_set_option(vh_context *c, const char *name, int value)
+{
+    if (!c || !name) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (std::strcmp(name, "flatten_variant") == 0) { c->flattenVariant = value; return VH_OK; }
+    if (std::strcmp(name, "integrate_grid") == 0 && value > 0) { c->integrateGrid = value; return VH_OK; }
+    if (std::strcmp(name, "fused_frame") == 0) { c->fusedFrame = value; return VH_OK; }
+    if (std::strcmp(name, "raycast_patch") == 0) { c->raycastPatch = value; return VH_OK; }
+    if (std::strcmp(name, "raycast_xcd") == 0) { c->raycastXcd = value; return VH_OK; }
+    if (std::strcmp(name, "packet_format") == 0 && (value == VH_PACKET_F32 || value == VH_PACKET_U16)) {
+        c->packetFormat = value;
+        return VH_OK;
+    }
+    if (std::strcmp(name, "persistent_blocks") == 0 && value > 0) { c->persistentBlocks = value; return VH_OK; }
+    if (std::strcmp(name, "commit_blocks") == 0 && value > 0) { c->commitBlocks = value; return VH_OK; }
+    return fail(VH_ERR_INVALID_ARGUMENT, "unknown option");
+}
+
+extern "C" int vh_set_profiling(vh_context *c, int enabled)
+{
+    if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    c->profiling = enabled != 0;
+    return VH_OK;
+}
+
+extern "C" int vh_get_kernel_times(vh_context *c, vh_kernel_times *out, int reset)
+{
+    if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(c->device);
+    VH_HIP(hipStreamSynchronize(c->stream));
+    for (auto &t : c->timed) {
+        float ms = 0;
+        VH_HIP(hipEventElapsedTime(&ms, t.start, t.stop));
+        switch (t.phase) {
+            case kPhaseClaim: c->times.alloc_claim_ms += ms; break;
+            case kPhaseCommit: c->times.alloc_commit_ms += ms; break;
+            case kPhaseFlatten: c->times.flatten_ms += ms; break;
+            case kPhaseIntegrate: c->times.integrate_ms += ms; break;
+            case kPhaseRaycast: c->times.raycast_ms += ms; c->times.raycast_launches += 1; break;
+            case kPhaseFrameScanClaim: c->times.frame_scan_claim_ms += ms; break;
+            case kPhaseFrameCommitIntegrate: c->times.frame_commit_integrate_ms += ms; break;
+            case kPhaseViewExport: c->times.view_export_ms += ms; break;
+            case kPhaseViewImport: c->times.view_import_ms += ms; break;
+            case kPhaseGc: c->times.gc_ms += ms; break;
+            case kPhaseRaycastBounds: c->times.raycast_ms += ms; break;      // vh_render_blocks: counted with the render work
+            default: break;
+        }
+    }
+    c->times.launches += c->profiledFrames;
+    c->profiledFrames = 0;
+    drop_events(c);
+    *out = c->times;
+    if (reset) c->times = vh_kernel_times{};
+    return VH_OK;
+}
+
+// test hook: scalar helpers evaluated on the device (8 int32 per point:
+// block x,y,z, hash, inFrustum, screen x,y, f2i_rz(w))
+extern "C" int vh_debug_eval(vh_context *c, const vh_float4 *d_points, int32_t n, int32_t *d_out)
+{
+    if (!c || !d_points || !d_out || n < 0) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(c->device);
+    if (n == 0) return VH_OK;
+    debug_eval_kernel<<<grid_for((size_t)n, 256), 256, 0, c->stream>>>(c->fp, reinterpret_cast<const float4 *>(d_points), n,
+                                                                       d_out);
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}

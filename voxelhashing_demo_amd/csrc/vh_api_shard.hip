@@ -1,0 +1,332 @@
+// vh_api_shard.hip -- C-ABI, bucket-range shards: view export / import for the raycast over shards, key bins, camera packets, batched frames.
+// Included by vh_api.hip (same translation unit: shares fail(), VH_HIP, DeviceGuard, launch()).
+
+// ---------------------------------------------------------------------------
+// raycast over shards: export of the blocks a view can touch, import into a view table
+// ---------------------------------------------------------------------------
+// oracle: vho_view_frustum (same operations in the same order)
+static void make_view_frustum(const vh_context *c, const float pose[16], float t_min, float t_max, float f[22])
+{
+    float inv[16];
+    invert4x4(pose, inv);
+    std::memcpy(f, inv, 12 * sizeof(float));
+    const float r = 7.0f * c->fp.voxelSize;
+    const float a[4] = {(0.0f - c->rc_cx) / c->rc_fx, ((float)(c->fp.width - 1) - c->rc_cx) / c->rc_fx,
+                        (0.0f - c->rc_cy) / c->rc_fy, ((float)(c->fp.height - 1) - c->rc_cy) / c->rc_fy};
+    for (int i = 0; i < 4; ++i) {
+        f[12 + i] = a[i];
+        f[16 + i] = -(r * sqrtf(1.0f + a[i] * a[i]));
+    }
+    f[20] = t_min - r;
+    f[21] = t_max + r;
+}
+
+extern "C" int vh_export_views(vh_context *c, const float *poses, int32_t n_views, float t_min, float t_max,
+                               vh_view_record *d_records, int32_t capacity, int32_t *d_counts)
+{
+    if (!c || !poses || !d_records || !d_counts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_views < 1 || n_views > VH_MAX_CAMERAS) return fail(VH_ERR_INVALID_ARGUMENT, "1..VH_MAX_CAMERAS views");
+    if (capacity < 1) return fail(VH_ERR_INVALID_ARGUMENT, "capacity must be positive");
+    if (!(t_max > t_min)) return fail(VH_ERR_INVALID_ARGUMENT, "t_max must exceed t_min");
+    if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table has no voxels of its own to export");
+    DeviceGuard guard(c->device);
+    const size_t need = (size_t)n_views * (size_t)capacity;
+    if (c->viewListsSize < need) {                         // first call (or a larger one): synchronises
+        VH_HIP(hipStreamSynchronize(c->stream));
+        if (c->viewLists) (void)hipFree(c->viewLists);
+        c->viewLists = nullptr;
+        c->viewListsSize = 0;
+        VH_HIP(hipMalloc((void **)&c->viewLists, need * sizeof(int32_t)));
+        c->viewListsSize = need;
+    }
+    VH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)n_views, c->stream));
+    const uint32_t tiles = (uint32_t)((c->numEntries + kFlattenThreads * kEntriesPerLane - 1) /
+                                      (kFlattenThreads * kEntriesPerLane));
+    for (int32_t base = 0; base < n_views; base += kMaxViewsPerLaunch) {
+        const int32_t n = std::min<int32_t>(kMaxViewsPerLaunch, n_views - base);
+        ViewSet vs;
+        std::memset(&vs, 0, sizeof vs);
+        for (int32_t v = 0; v < n; ++v) make_view_frustum(c, poses + 16 * (size_t)(base + v), t_min, t_max, vs.v[v].f);
+        const int rc = launch(c, kPhaseViewExport, view_select_kernel, dim3(tiles), dim3(kFlattenThreads), c->fp, c->dp,
+                              (uint32_t)c->numEntries, vs, n, c->viewLists + (size_t)base * capacity, capacity,
+                              d_counts + base);
+        if (rc != VH_OK) return rc;
+    }
+    const int rc = launch(c, kPhaseViewExport, view_pack_kernel, dim3((unsigned)std::min<int32_t>(capacity, 2048), n_views),
+                          dim3(256), c->dp, (const int32_t *)c->viewLists, (const int32_t *)d_counts, capacity,
+                          reinterpret_cast<uint8_t *>(d_records));
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_import_view(vh_context *c, const vh_view_record *d_records, int32_t count)
+{
+    if (!c || (!d_records && count > 0)) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (count < 0 || (size_t)count > c->numEntries || (uint64_t)count * kViewRecordVoxels + 514ull > 0x7fffffffull)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad record count");
+    if (c->fp.bucketLo != 0 || c->fp.bucketHi != c->fp.numBuckets)
+        return fail(VH_ERR_INVALID_ARGUMENT, "a view table is unsharded");
+    if (c->fp.epoch != 0) return fail(VH_ERR_INVALID_ARGUMENT, "this context has integrated frames: use a dedicated view context");
+    DeviceGuard guard(c->device);
+    if (c->viewCount > 0) {
+        const int rc = launch(c, kPhaseViewImport, view_clear_kernel, dim3((unsigned)grid_for((size_t)c->viewCount, 256)),
+                              dim3(256), c->fp, c->dp, c->viewCount);
+        if (rc != VH_OK) return rc;
+    }
+    VH_HIP(hipMemsetAsync(c->dp.bucketBits, 0, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32), c->stream));
+    VH_HIP(hipMemsetAsync(c->dp.macroBits, 0, kMacroBits / 8, c->stream));
+    c->viewBlocks = reinterpret_cast<const Voxel *>(d_records);
+    c->viewCount = count;
+    if (count > 0) {
+        const int rc = launch(c, kPhaseViewImport, view_import_kernel, dim3((unsigned)grid_for((size_t)count, 256)),
+                              dim3(256), c->fp, c->dp, reinterpret_cast<const uint8_t *>(d_records), count);
+        if (rc != VH_OK) return rc;
+    }
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// sharding
+// ---------------------------------------------------------------------------
+// 4-byte units of one camera packet in the context's packet format
+static size_t packet_units(const vh_context *c)
+{
+    const size_t npix = (size_t)c->fp.width * c->fp.height;
+    return c->packetFormat == VH_PACKET_U16 ? (size_t)kPacketHeaderU16 + (npix + 1) / 2 : (size_t)kPacketHeader + npix;
+}
+
+extern "C" int vh_generate_keys(vh_context *c, const vh_float4 *verts, uint32_t camera_id, int32_t num_shards,
+                                int32_t *d_bins, int32_t capacity, int32_t bin_stride, float *d_packet)
+{
+    if (bin_stride == 0) bin_stride = capacity;
+    if (!c || !verts || !d_bins || num_shards <= 0 || capacity < 2 || bin_stride < capacity ||
+        camera_id >= VH_MAX_CAMERAS || num_shards > VH_MAX_CAMERAS)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(c->device);
+    const int npix = c->fp.width * c->fp.height;
+    prepare_bins_kernel<<<1, 64, 0, c->stream>>>(reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, 1, 0);
+    generate_keys_kernel<<<grid_for(npix, kGenThreads), kGenThreads, 0, c->stream>>>(
+        c->fp, reinterpret_cast<const float4 *>(verts), num_shards, reinterpret_cast<int4 *>(d_bins), capacity,
+        bin_stride, d_packet ? d_packet + kPacketHeader : nullptr, camera_id << kRankCameraShift);
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// `batch` frames of one camera in one call: one launch zeroes all bin headers, then one launch per
+// kGenBatch frames (blockIdx.y = frame, poses and vertex-map pointers in the kernel arguments).
+extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float *poses,
+                                      const vh_float4 *const *d_verts, uint32_t camera_id, int32_t num_shards,
+                                      int32_t *d_bins, int32_t capacity, int32_t bin_stride, int32_t frame_stride,
+                                      float *d_packets, size_t packet_frame_stride)
+{
+    if (!c || !poses || !d_verts || !d_bins || batch <= 0 || num_shards <= 0 || num_shards > VH_MAX_CAMERAS ||
+        capacity < 2 || camera_id >= VH_MAX_CAMERAS)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    if (frame_stride == 0) frame_stride = capacity;
+    if (bin_stride == 0) bin_stride = batch * frame_stride;
+    const size_t dense = (size_t)kPacketHeader + (size_t)c->fp.width * c->fp.height;
+    if (packet_frame_stride == 0) packet_frame_stride = dense;
+    if (frame_stride < capacity || bin_stride < batch * frame_stride || (d_packets && packet_frame_stride < dense))
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
+    DeviceGuard guard(c->device);
+    const int npix = c->fp.width * c->fp.height;
+    prepare_bins_kernel<<<grid_for((size_t)num_shards * batch, 256), 256, 0, c->stream>>>(
+        reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, batch, frame_stride);
+    for (int b0 = 0; b0 < batch; b0 += kGenBatch) {
+        const int n = std::min<int>(kGenBatch, batch - b0);
+        GenFrames fr;
+        std::memset(&fr, 0, sizeof fr);
+        for (int j = 0; j < n; ++j) {
+            const int rc = vh_set_pose(c, poses + 16 * (size_t)(b0 + j));        // pose + cofactor inverse
+            if (rc != VH_OK) return rc;
+            if (!d_verts[b0 + j]) return fail(VH_ERR_INVALID_ARGUMENT, "null vertex map");
+            std::memcpy(fr.T[j], c->fp.T, sizeof fr.T[j]);
+            std::memcpy(fr.Tinv[j], c->fp.Tinv, sizeof fr.Tinv[j]);
+            fr.verts[j] = reinterpret_cast<const float4 *>(d_verts[b0 + j]);
+        }
+        generate_keys_batch_kernel<<<dim3((unsigned)grid_for(npix, kGenThreads), (unsigned)n), kGenThreads, 0, c->stream>>>(
+            c->fp, fr, num_shards, reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
+            frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
+            camera_id << kRankCameraShift);
+    }
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// Keys and sensor-depth packets of `batch` frames of this camera from the uint16 images alone: one
+// launch per kGenBatch frames (no vertex map, no separate packet pass).
+extern "C" int vh_generate_keys_depth_batch(vh_context *c, int32_t batch, const float *poses,
+                                            const uint16_t *const *d_depth, const float k_inv[9], uint32_t camera_id,
+                                            int32_t num_shards, int32_t *d_bins, int32_t capacity, int32_t bin_stride,
+                                            int32_t frame_stride, float *d_packets, size_t packet_frame_stride)
+{
+    if (!c || !poses || !d_depth || !k_inv || !d_bins || batch <= 0 || num_shards <= 0 ||
+        num_shards > VH_MAX_CAMERAS || capacity < 2 || camera_id >= VH_MAX_CAMERAS)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    const size_t npix = (size_t)c->fp.width * c->fp.height;
+    if (d_packets && npix % 2) return fail(VH_ERR_INVALID_ARGUMENT, "sensor-depth packets need an even number of pixels");
+    if (frame_stride == 0) frame_stride = capacity;
+    if (bin_stride == 0) bin_stride = batch * frame_stride;
+    const size_t dense = (size_t)kPacketHeaderU16 + npix / 2;
+    if (packet_frame_stride == 0) packet_frame_stride = dense;
+    if (frame_stride < capacity || bin_stride < batch * frame_stride || (d_packets && packet_frame_stride < dense))
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
+    DeviceGuard guard(c->device);
+    prepare_bins_kernel<<<grid_for((size_t)num_shards * batch, 256), 256, 0, c->stream>>>(
+        reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, batch, frame_stride);
+    for (int b0 = 0; b0 < batch; b0 += kGenBatch) {
+        const int n = std::min<int>(kGenBatch, batch - b0);
+        GenSensorFrames fr;
+        std::memset(&fr, 0, sizeof fr);
+        std::memcpy(fr.k, k_inv, sizeof fr.k);
+        fr.unit = 5000.0f;                                               // CameraTrackingUtils.cu:64
+        for (int j = 0; j < n; ++j) {
+            const int rc = vh_set_pose(c, poses + 16 * (size_t)(b0 + j));
+            if (rc != VH_OK) return rc;
+            if (!d_depth[b0 + j]) return fail(VH_ERR_INVALID_ARGUMENT, "null depth image");
+            std::memcpy(fr.T[j], c->fp.T, sizeof fr.T[j]);
+            std::memcpy(fr.Tinv[j], c->fp.Tinv, sizeof fr.Tinv[j]);
+            fr.depth[j] = d_depth[b0 + j];
+        }
+        generate_keys_sensor_batch_kernel<<<dim3((unsigned)grid_for(npix, kGenThreads), (unsigned)n), kGenThreads, 0,
+                                            c->stream>>>(
+            c->fp, fr, num_shards, reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
+            frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
+            camera_id << kRankCameraShift);
+    }
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// Sensor-depth packets (VH_PACKET_U16) of `batch` frames of this camera: pose + inverse + K_inv row 2 +
+// depth unit, then the uint16 image as it is.  The key generation for the same frames is
+// vh_generate_keys_batch with d_packets = NULL.
+extern "C" int vh_write_packets_u16_batch(vh_context *c, int32_t batch, const float *poses,
+                                          const uint16_t *const *d_depth, const float k_inv[9], float *d_packets,
+                                          size_t packet_frame_stride)
+{
+    if (!c || !poses || !d_depth || !k_inv || !d_packets || batch <= 0)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    const size_t npix = (size_t)c->fp.width * c->fp.height;
+    if (npix % 2) return fail(VH_ERR_INVALID_ARGUMENT, "sensor-depth packets need an even number of pixels");
+    const size_t dense = (size_t)kPacketHeaderU16 + npix / 2;
+    if (packet_frame_stride == 0) packet_frame_stride = dense;
+    if (packet_frame_stride < dense) return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
+    DeviceGuard guard(c->device);
+    for (int b0 = 0; b0 < batch; b0 += kGenBatch) {
+        const int n = std::min<int>(kGenBatch, batch - b0);
+        SensorFrames fr;
+        std::memset(&fr, 0, sizeof fr);
+        fr.k6 = k_inv[6]; fr.k7 = k_inv[7]; fr.k8 = k_inv[8];
+        fr.unit = 5000.0f;                                               // CameraTrackingUtils.cu:64
+        for (int j = 0; j < n; ++j) {
+            const int rc = vh_set_pose(c, poses + 16 * (size_t)(b0 + j));
+            if (rc != VH_OK) return rc;
+            if (!d_depth[b0 + j]) return fail(VH_ERR_INVALID_ARGUMENT, "null depth image");
+            std::memcpy(fr.T[j], c->fp.T, sizeof fr.T[j]);
+            std::memcpy(fr.Tinv[j], c->fp.Tinv, sizeof fr.Tinv[j]);
+            fr.depth[j] = d_depth[b0 + j];
+        }
+        write_packets_u16_kernel<<<dim3(64, (unsigned)n), 256, 0, c->stream>>>(
+            fr, (int32_t)npix, d_packets + packet_frame_stride * (size_t)b0, packet_frame_stride);
+    }
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// `batch` multi-camera frames applied one after the other, each as the fused pair of launches
+// (new lock epoch; {claim bins || walk}; {commit + integrate}).
+extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t *d_bins, int32_t num_bins,
+                                     int32_t capacity, int32_t bin_stride, int32_t frame_stride, int32_t num_cams,
+                                     const float *d_packets, size_t packet_stride, size_t packet_frame_stride)
+{
+    if (!c || !d_bins || !d_packets || batch <= 0 || num_bins <= 0 || capacity < 2 || num_cams <= 0 ||
+        num_cams > VH_MAX_CAMERAS)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    const size_t dense = packet_units(c);
+    if (frame_stride == 0) frame_stride = capacity;
+    if (bin_stride == 0) bin_stride = batch * frame_stride;
+    if (packet_frame_stride == 0) packet_frame_stride = dense;
+    if (packet_stride == 0) packet_stride = (size_t)batch * packet_frame_stride;
+    if (frame_stride < capacity || bin_stride < batch * frame_stride || packet_frame_stride < dense ||
+        packet_stride < (size_t)batch * packet_frame_stride)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
+    DeviceGuard guard(c->device);
+    uint32_t parts = (uint32_t)grid_for((size_t)capacity, 256 * 4);
+    if (parts < 1) parts = 1;
+    const uint32_t scanBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
+    const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
+    for (int b = 0; b < batch; ++b) {
+        int rc = vh_reset_mutexes(c);
+        if (rc != VH_OK) return rc;
+        const int4 *bins = reinterpret_cast<const int4 *>(d_bins) + (size_t)frame_stride * b;
+        const float *packets = d_packets + packet_frame_stride * b;
+        rc = launch(c, kPhaseFrameScanClaim, frame_multi_scan_claim_kernel,
+                    dim3((uint32_t)num_bins * parts + scanBlocks), dim3(256), c->fp, c->dp, bins, capacity, bin_stride,
+                    (uint32_t)num_bins, parts, (uint32_t)c->numEntries, num_cams, packets, packet_stride,
+                    c->fusedParity);
+        if (rc == VH_OK)
+            rc = c->packetFormat == VH_PACKET_U16
+                     ? launch(c, kPhaseFrameCommitIntegrate, frame_multi_commit_integrate_kernel<true>,
+                              dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, num_cams,
+                              packets, packet_stride, commitBlocks, c->fusedParity)
+                     : launch(c, kPhaseFrameCommitIntegrate, frame_multi_commit_integrate_kernel<false>,
+                              dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, num_cams,
+                              packets, packet_stride, commitBlocks, c->fusedParity);
+        if (rc != VH_OK) return rc;
+        c->fusedParity ^= 1;
+        c->compactArmed = false;
+        c->occupiedCounter = kCompactCount;
+        if (c->profiling) c->profiledFrames += 1;
+    }
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_insert_bins(vh_context *c, const int32_t *d_bins, int32_t num_bins, int32_t capacity,
+                              int32_t bin_stride)
+{
+    if (bin_stride == 0) bin_stride = capacity;
+    if (!c || !d_bins || num_bins <= 0 || capacity < 2 || bin_stride < capacity)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    if (c->fp.epoch == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
+    DeviceGuard guard(c->device);
+    int gx = grid_for((size_t)capacity, 256 * 4);
+    if (gx < 1) gx = 1;
+    int rc = launch(c, kPhaseClaim, claim_bins_kernel, dim3(gx, num_bins), dim3(256), c->fp, c->dp,
+                    reinterpret_cast<const int4 *>(d_bins), capacity, bin_stride);
+    if (rc == VH_OK) rc = launch(c, kPhaseCommit, alloc_commit_kernel, dim3(32), dim3(256), c->fp, c->dp);
+    if (rc != VH_OK) return rc;
+    c->compactArmed = true;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_integrate_packets(vh_context *c, int32_t num_cams, const float *d_packets, size_t packet_stride)
+{
+    const size_t dense = c ? packet_units(c) : 0;
+    if (packet_stride == 0) packet_stride = dense;
+    if (!c || !d_packets || num_cams <= 0 || num_cams > VH_MAX_CAMERAS || packet_stride < dense)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(c->device);
+    const size_t stride = packet_stride;
+    if (!c->compactArmed)
+        VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));
+    c->compactArmed = false;
+    c->occupiedCounter = kCompactCount;
+    int rc = launch(c, kPhaseFlatten, flatten_multi_kernel,
+                    dim3(grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane)), dim3(kFlattenThreads), c->fp,
+                    c->dp, (uint32_t)c->numEntries, num_cams, d_packets, stride);
+    if (rc == VH_OK)
+        rc = c->packetFormat == VH_PACKET_U16
+                 ? launch(c, kPhaseIntegrate, integrate_multi_kernel<true>, dim3(c->integrateGrid), dim3(256), c->fp, c->dp,
+                          num_cams, d_packets, stride)
+                 : launch(c, kPhaseIntegrate, integrate_multi_kernel<false>, dim3(c->integrateGrid), dim3(256), c->fp,
+                          c->dp, num_cams, d_packets, stride);
+    if (rc != VH_OK) return rc;
+    if (c->profiling) c->profiledFrames += 1;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}

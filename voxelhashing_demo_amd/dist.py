@@ -198,6 +198,9 @@ class HipShard:
             s["packets_b"] = [s["packets"][0, b].data_ptr() for b in range(B)]
             self.sets.append(s)
         self.use_set(0)
+        # the buffers were zero-filled on torch's current stream and will be used from other streams
+        # (torch streams do not order themselves against each other): make them ready for all
+        torch.cuda.synchronize(self.device)
 
     def use_set(self, i: int):
         s = self.sets[i]
@@ -343,6 +346,7 @@ class HipViewTable:
                                   stream=stream)
         self.recv = torch.zeros((world * capacity, VIEW_RECORD_BYTES), dtype=torch.uint8, device=self.device)
         self.depth = torch.zeros((height, width), dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)      # ready for whichever stream uses them
 
     def render(self, count: int, pose, t_min: float = 0.1, t_max: float = 5.0):
         self.table.import_view(self.recv, count)
@@ -375,10 +379,27 @@ def sharded_raycast(shard, view, transport: TorchDistTransport, pose, capacity: 
     """Depth image of this rank's view `pose` through the whole sharded table.  Returns
     (depth, lost): `lost` > 0 means some shard selected more than `capacity` blocks for a view and
     the image may miss surfaces (raise the capacity)."""
+    # Everything of the round is enqueued on torch's CURRENT stream: the buffers are torch tensors and the
+    # collectives run there, so the two contexts must not keep enqueuing on streams of their own (torch
+    # streams do not synchronise with each other implicitly: an export on another stream raced with the
+    # zero-fill and the host read of its counts).  Pending work of the contexts is waited for first.
+    restore = []
+    if hasattr(shard.table, "stream_handle"):
+        import torch
+        cur = torch.cuda.current_stream().cuda_stream
+        for t in (shard.table, view.table):
+            if t.stream_handle != cur:
+                t.synchronize()
+                restore.append((t, t.stream_handle))
+                t.set_stream(cur)
     poses = transport.all_gather_poses(pose)
     records, counts = shard.export_views(poses, capacity, t_min, t_max)
-    recv_counts, lost = transport.exchange_view_records(records, counts, capacity, view.recv)
-    return view.render(sum(recv_counts), pose, t_min, t_max), lost
+    recv_counts, lost = transport.exchange_view_records(records, counts, capacity, view.recv)   # synchronises
+    depth = view.render(sum(recv_counts), pose, t_min, t_max)
+    for t, handle in restore:
+        t.synchronize()                  # its work of this round is done before it goes back to its own stream
+        t.set_stream(handle)
+    return depth, lost
 
 
 def loopback_raycast(shards, views, poses, capacity: int, t_min: float = 0.1, t_max: float = 5.0):

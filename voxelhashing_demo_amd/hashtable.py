@@ -76,6 +76,7 @@ class SDFHashtable:
             L.check(self._lib.vh_create_shard(C.byref(cfg), lo, hi, C.byref(h)), "vh_create_shard")
             self.bucket_range = (lo, hi)
         self._h = h
+        self.stream_handle = 0                  # raw hipStream_t the context enqueues on (0 = default stream)
         if stream is not None:
             self.set_stream(stream)
 
@@ -95,6 +96,7 @@ class SDFHashtable:
         """`stream`: a torch.cuda.Stream, or a raw hipStream_t address."""
         handle = stream if isinstance(stream, int) else stream.cuda_stream
         L.check(self._lib.vh_set_stream(self._h, C.c_void_p(handle)), "vh_set_stream")
+        self.stream_handle = handle
 
     def set_projection(self, m):
         a = np.ascontiguousarray(np.asarray(m, np.float32).reshape(9))
