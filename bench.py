@@ -237,6 +237,7 @@ def main():
     d_ptrs = [depth16[i].data_ptr() for i in range(nd)]
     tmp_v, tmp_n = torch.empty_like(verts[0]), torch.empty_like(verts[0])
     tv, tn, st = tmp_v.data_ptr(), tmp_n.data_ptr(), C.c_void_p(stream.cuda_stream)
+    torch.cuda.synchronize()       # the images were written on torch's default stream, the table reads them on its own
 
     def fused_depth(i):
         lib.vh_integrate_depth(h, pose_ptrs[i % nd], d_ptrs[i % nd], kin_p)
@@ -289,6 +290,7 @@ def main():
     # depth pre-processing (next #1): uint16 depth -> vertex + normal maps, one fused kernel
     depth_u16 = (verts[0, :, :, 2] * 5000.0).clamp(0, 65535).to(torch.uint16)
     pos_out, nrm_out = torch.empty_like(verts[0]), torch.empty_like(verts[0])
+    torch.cuda.synchronize()
     k_inv = np.linalg.inv(synth.K_matrix(Wd, Ht).astype(np.float64)).astype(np.float32)
     with torch.cuda.stream(stream):
         for i in range(3):

@@ -16,6 +16,7 @@ dverts = [synth.render_room_verts(p, W, H, prims, device="cuda") for p in poses]
 h_verts = [v.cpu().pin_memory() for v in dverts]
 h_depth = [(v[..., 2] * 5000).round().clamp(0, 65535).to(torch.uint16).cpu().pin_memory() for v in dverts]
 del dverts
+torch.cuda.synchronize()
 table_stream, copy_stream = torch.cuda.Stream(), torch.cuda.Stream()
 for name, host, fn in (("float4 vertex maps", h_verts, "integrate"), ("uint16 sensor images", h_depth, "integrate_depth")):
     t = V.SDFHashtable(V.default_params(numBuckets=1 << 20, numVoxelBlocks=1 << 18), W, H, V.SEM_PINHOLE, stream=table_stream)

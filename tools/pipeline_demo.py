@@ -20,6 +20,7 @@ kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
 # synthetic sensor frames: depth in 1/5000 m, as the TUM sequences the demo reads (Application.cpp:38-42)
 depth16 = [(synth.render_room_verts(p, W, H, prims, device="cuda")[..., 2] * 5000.0).round().clamp(0, 65535).to(torch.uint16)
            for p in gt]
+torch.cuda.synchronize()           # the sensor frames were made on torch's default stream
 stream = torch.cuda.Stream()
 table = V.SDFHashtable(V.default_params(numBuckets=1 << 20, numVoxelBlocks=1 << 16), W, H, V.SEM_PINHOLE, stream=stream)
 trk = tracking.CameraTracking(W, H, K, stream=stream, flags=tracking.ICP_ABS_DISTANCE | tracking.ICP_NEED_TARGET)
