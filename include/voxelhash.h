@@ -15,7 +15,11 @@
  *
  * Device pointers are `hipMalloc`-class addresses (torch CUDA tensors'
  * data_ptr() qualify).  All device work is enqueued on the context's stream
- * and is asynchronous unless a function says it synchronises.
+ * and is asynchronous unless a function says it synchronises.  The usual
+ * stream contract applies: a buffer handed to a call must be ready ON THAT
+ * STREAM (produced there, or ordered before it with an event / a
+ * synchronisation), and results are ready on that stream; the library adds
+ * no synchronisation between streams.
  *
  * Paths in citations are relative to the reference checkout.
  */
