@@ -14,6 +14,8 @@
 #ifndef SDF_HASHTABLE_H
 #define SDF_HASHTABLE_H
 
+#include <cstdint>
+
 #include "voxelhash.h"
 
 /* row-major 4x4, the only part of cuda_SimpleMatrixUtil.h:800-1100 the path uses */
@@ -47,6 +49,9 @@ public:
         static_assert(sizeof(F4) == sizeof(vh_float4), "vertex map elements must be 16-byte float4");
         integrate(deltaT, reinterpret_cast<const vh_float4 *>(d_verts), reinterpret_cast<const vh_float4 *>(d_normals));
     }
+    /* the same frame straight from the uint16 sensor image (preProcess + integrate in one call, no vertex
+     * map in memory; Application.cpp:73-74,84); kInv: row-major 3x3 */
+    void integrate(const float4x4 &deltaT, const uint16_t *d_depth, const float kInv[9]);
     void raycast(const float4x4 &pose, float *d_depth_out, float zNear = 0.1f, float zFar = 5.0f);
     /* depth plus camera-frame vertex and normal maps of the view (what CameraTracking::Align takes as target) */
     void raycast(const float4x4 &pose, float *d_depth_out, vh_float4 *d_vertices_out, vh_float4 *d_normals_out,

@@ -47,6 +47,11 @@ void SDF_Hashtable::integrate(const float4x4 &viewMat, const vh_float4 *verts, c
     check(vh_integrate(ctx_, viewMat.entries, verts, normals), "integrate");
 }
 
+void SDF_Hashtable::integrate(const float4x4 &viewMat, const uint16_t *d_depth, const float kInv[9])
+{
+    check(vh_integrate_depth(ctx_, viewMat.entries, d_depth, kInv), "integrate");
+}
+
 void SDF_Hashtable::raycast(const float4x4 &pose, float *d_depth_out, float zNear, float zFar)
 {
     check(vh_raycast(ctx_, pose.entries, zNear, zFar, d_depth_out), "raycast");
