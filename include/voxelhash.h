@@ -124,11 +124,13 @@ typedef struct vh_counters {
     int32_t  heap_counter;      /* index of the top free heap slot; -1 = heap empty */
     uint32_t allocated_total;   /* blocks handed out since creation */
     uint32_t heap_exhausted;    /* insertions refused because the heap was empty */
-    uint32_t candidates;        /* contenders recorded by the last allocBlocks */
+    uint32_t candidates;        /* contenders of the last allocBlocks (demanded, even if the list was full) */
     uint32_t epoch;             /* bucket-lock epoch (= frames since creation) */
     uint32_t bin_overflow;      /* received key bins that exceeded their capacity (keys lost) */
     uint32_t freed_total;       /* blocks returned to the heap since creation (deletion / GC) */
     uint32_t last_freed;        /* ... by the last vh_delete_blocks / vh_garbage_collect */
+    uint32_t cand_overflow;     /* contenders dropped since creation because the candidate list of their
+                                   frame was full (their keys retry next frame; see "cand_capacity") */
 } vh_counters;
 
 /* per-kernel device time, accumulated while profiling is on (HIP events on
@@ -147,6 +149,7 @@ typedef struct vh_kernel_times {
     double   view_import_ms;             /* vh_import_view: clear + insert */
     double   gc_ms;                      /* vh_delete_blocks / vh_garbage_collect, all launches */
     uint64_t gc_calls;
+    double   render_blocks_ms;           /* vh_render_blocks, all launches */
 } vh_kernel_times;
 
 typedef struct vh_context vh_context;
@@ -239,9 +242,11 @@ int vh_download(vh_context *ctx, int which, void *host_dst, size_t bytes);  /* s
 int vh_debug_eval(vh_context *ctx, const vh_float4 *d_points, int32_t n, int32_t *d_out);
 
 /* Options.  Tuning knobs for A/B measurements, results never change: "fused_frame" (1: two launches
- * per frame, 0: the four step kernels), "flatten_variant" (walk kinds, 3 = default, 4 = occupancy
- * index), "integrate_grid", "commit_blocks", "persistent_blocks", "raycast_patch".  Format switch:
- * "packet_format" (VH_PACKET_F32 / VH_PACKET_U16, below). */
+ * per frame, 0: the four step kernels), "flatten_variant" (3 = the walk over every VoxelEntry, default;
+ * 4 = occupancy index; 5 = persistent prefetching walk; anything else is rejected), "integrate_grid",
+ * "commit_blocks", "persistent_blocks", "raycast_patch", "raycast_xcd".  They apply to vh_integrate and
+ * vh_integrate_depth alike.  "cand_capacity" shrinks the candidate list (test hook for
+ * vh_counters.cand_overflow).  Format switch: "packet_format" (VH_PACKET_F32 / VH_PACKET_U16, below). */
 int vh_set_option(vh_context *ctx, const char *name, int value);
 int vh_set_profiling(vh_context *ctx, int enabled);
 int vh_get_kernel_times(vh_context *ctx, vh_kernel_times *out, int reset);  /* synchronises */

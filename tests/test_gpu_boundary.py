@@ -1,0 +1,163 @@
+"""Corners of the C-ABI boundary on the GPU: the PtrContainer of the reference (SURVEY.md 8(a)
+row T4, VoxelDataStructures.h:54-63) read back through raw device pointers, the candidate-list
+overflow counter, option validation, and snapshot files that must not damage a live model."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import entries_as_set
+from voxelhashing_demo_amd import synth
+
+pytestmark = pytest.mark.gpu
+I4 = np.eye(4, dtype=np.float32)
+KW = dict(numBuckets=1 << 17, numVoxelBlocks=4096)
+
+
+def _hip_memcpy_d2h(vh, dev_ptr, nbytes):
+    """Raw hipMemcpy (device -> host) through the HIP runtime the library itself is linked to:
+    dlsym on the library's handle searches its dependency tree, so no second runtime is loaded."""
+    from voxelhashing_demo_amd import _lib
+    L = C.CDLL(_lib.LIB_PATH)
+    L.hipMemcpy.restype = C.c_int
+    L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    buf = (C.c_uint8 * nbytes)()
+    assert L.hipMemcpy(buf, C.c_void_p(dev_ptr), nbytes, 2) == 0          # hipMemcpyDeviceToHost
+    return bytes(buf)
+
+
+def test_ptr_container_layout_and_contents(vh, torch_cuda):
+    """T4: 7 raw device pointers, 56 bytes, in the reference's order; each one addresses the
+    buffer its name says (checked against vh_download / vh_get_counters)."""
+    torch = torch_cuda
+    from voxelhashing_demo_amd import _lib
+    assert C.sizeof(_lib.PtrContainer) == 56
+    assert [n for n, _ in _lib.PtrContainer._fields_] == [
+        "d_heap", "d_hashTable", "d_compactifiedHashTable", "d_hashTableBucketMutex", "d_SDFBlocks",
+        "d_heapCounter", "d_compactifiedHashCounter"]                      # VoxelDataStructures.h:55-62
+    gt = vh.SDFHashtable(vh.default_params(**KW), 640, 480, 0)
+    d_verts = torch.from_numpy(synth.sphere_inside_scene()).cuda()
+    gt.integrate(I4, d_verts)
+    gt.integrate(I4, d_verts)
+    gt.synchronize()
+    p = gt.device_pointers()
+    ptrs = [getattr(p, n) for n, _ in _lib.PtrContainer._fields_]
+    assert all(ptrs) and len(set(ptrs)) == 7
+    c = gt.counters()
+    assert struct.unpack("<i", _hip_memcpy_d2h(vh, p.d_heapCounter, 4))[0] == c["heap_counter"] == 4095 - 151
+    assert struct.unpack("<i", _hip_memcpy_d2h(vh, p.d_compactifiedHashCounter, 4))[0] == c["occupied"] == 151
+    table = gt.hash_table()
+    n = 1 << 12
+    raw = np.frombuffer(_hip_memcpy_d2h(vh, p.d_hashTable, 20 * n), dtype=vh.ENTRY_DTYPE)
+    assert np.array_equal(raw, table[:n])
+    first = int(np.nonzero(table["ptr"] != -1)[0][0])
+    one = np.frombuffer(_hip_memcpy_d2h(vh, p.d_hashTable + 20 * first, 20), dtype=vh.ENTRY_DTYPE)[0]
+    assert one == table[first] and one["ptr"] % 512 == 0
+    comp = np.frombuffer(_hip_memcpy_d2h(vh, p.d_compactifiedHashTable, 20 * 151), dtype=vh.ENTRY_DTYPE)
+    assert entries_as_set(comp) == entries_as_set(table[table["ptr"] != -1])
+    heap = np.frombuffer(_hip_memcpy_d2h(vh, p.d_heap, 4 * 4096), dtype="<u4")
+    assert np.array_equal(heap, gt.heap())
+    vox = np.frombuffer(_hip_memcpy_d2h(vh, p.d_SDFBlocks + 8 * int(one["ptr"]), 4096), dtype=vh.VOXEL_DTYPE)
+    assert np.array_equal(vox, gt.sdf_blocks()[int(one["ptr"]):int(one["ptr"]) + 512])
+    # the bucket lock of the reference is an int per bucket; here an 8-byte word per bucket whose
+    # upper half is the lock epoch: a bucket that received an entry in the last frame carries it
+    h = first // 5
+    word = struct.unpack("<Q", _hip_memcpy_d2h(vh, p.d_hashTableBucketMutex + 8 * h, 8))[0]
+    assert 1 <= (word >> 32) <= c["epoch"] == 2
+    gt.close()
+
+
+def test_candidate_overflow_is_counted_and_harmless(oracle, vh, torch_cuda):
+    """A full candidate list drops contenders BEFORE they stake a claim: the loss is counted, the
+    frame stays consistent, and the keys come back in the following frames."""
+    torch = torch_cuda
+    gt = vh.SDFHashtable(vh.default_params(**KW), 640, 480, 1)
+    ot = oracle.OracleTable(oracle.default_params(**KW), 640, 480, 1)
+    verts = synth.sphere_inside_scene()
+    d_verts = torch.from_numpy(verts).cuda()
+    gt.set_option("cand_capacity", 8)
+    gt.integrate(I4, d_verts)
+    c = gt.counters()
+    assert c["cand_overflow"] > 0 and c["candidates"] > 8                 # demanded, not clamped
+    assert 0 < c["allocated_total"] <= 8 and c["occupied"] == c["allocated_total"]
+    prev = -1
+    for _ in range(64):
+        gt.integrate(I4, d_verts)
+        n = gt.counters()["allocated_total"]
+        if n == prev:
+            break
+        prev = n
+    for _ in range(3):
+        ot.integrate(I4, verts)
+    tab = gt.hash_table()
+    alloc = tab[tab["ptr"] != -1]
+    assert entries_as_set(alloc) == entries_as_set(ot.allocated()) and len(alloc) == 179
+    assert len(set(alloc["ptr"].tolist())) == len(alloc)
+    gt.close()
+
+
+def test_options_are_validated(vh, torch_cuda):
+    gt = vh.SDFHashtable(vh.default_params(**KW), 640, 480, 1)
+    for bad in (0, 1, 2, 6, 7, -1):
+        with pytest.raises(vh.VoxelHashError):
+            gt.set_option("flatten_variant", bad)
+    for good in (3, 4, 5):
+        gt.set_option("flatten_variant", good)
+    with pytest.raises(vh.VoxelHashError):
+        gt.set_option("no_such_option", 1)
+    gt.close()
+
+
+def test_bad_snapshots_leave_the_model_untouched(oracle, vh, torch_cuda, tmp_path):
+    """vh_load_snapshot validates the whole file on the host before it changes device state."""
+    torch = torch_cuda
+    kw = dict(numBuckets=1 << 12, numVoxelBlocks=2048)
+    poses = synth.camera_loop(500)
+    prims = synth.room_primitives()
+    frames = [(poses[i], synth.render_room_verts(poses[i], 320, 240, prims).numpy()) for i in (0, 3, 6)]
+    ot = oracle.OracleTable(oracle.default_params(**kw), 320, 240, 1)
+    gt = vh.SDFHashtable(vh.default_params(**kw), 320, 240, 1)
+    for pose, v in frames[:2]:
+        gt.integrate(pose, torch.from_numpy(v).cuda())
+        ot.integrate(pose, v)
+    good = tmp_path / "good.vhsnap"
+    gt.save_snapshot(good)
+    assert not (tmp_path / "good.vhsnap.partial").exists()                # written aside, renamed at the end
+    blob = good.read_bytes()
+    before_tab, before_vol, before_c = gt.hash_table(), gt.sdf_blocks(), gt.counters()
+    n_entries = (1 << 12) * 5
+    table_at = len(blob) - 4096 * len(gt.allocated()) - 4 * 2048 - 20 * n_entries
+    heap_counter_at = 8 + 176 + 3 * 4 + 2 * 4                             # SnapshotHeader: magic, params, size, bucket range
+    assert struct.unpack_from("<i", blob, heap_counter_at)[0] == before_c["heap_counter"]
+    first_live = int(np.nonzero(before_tab["ptr"] != -1)[0][0])
+    cases = {
+        "truncated payload": blob[:-100],
+        "truncated table": blob[:table_at + 1000],
+        "trailing bytes": blob + b"\0" * 8,
+        "bad magic": b"XXSNAP01" + blob[8:],
+        "heap counter out of range": blob[:heap_counter_at] + struct.pack("<i", 1 << 20) + blob[heap_counter_at + 4:],
+        "misaligned ptr": blob[:table_at + 20 * first_live + 12] + struct.pack("<i", 513) + blob[table_at + 20 * first_live + 16:],
+        "ptr out of pool": blob[:table_at + 20 * first_live + 12] + struct.pack("<i", 512 * 4096) + blob[table_at + 20 * first_live + 16:],
+    }
+    for name, data in cases.items():
+        bad = tmp_path / "bad.vhsnap"
+        bad.write_bytes(data)
+        with pytest.raises(vh.VoxelHashError):
+            gt.load_snapshot(bad)
+        assert np.array_equal(gt.hash_table(), before_tab), name
+        assert np.array_equal(gt.sdf_blocks().view(np.uint32), before_vol.view(np.uint32)), name
+        assert gt.counters()["heap_counter"] == before_c["heap_counter"], name
+    # a context with another voxel size refuses the file (the kernels would disagree with the header)
+    other = vh.SDFHashtable(vh.default_params(voxelSize=0.01, **kw), 320, 240, 1)
+    with pytest.raises(vh.VoxelHashError, match="does not match"):
+        other.load_snapshot(good)
+    other.close()
+    # ... and the live model still fuses on exactly like the oracle
+    pose, v = frames[2]
+    gt.integrate(pose, torch.from_numpy(v).cuda())
+    ot.integrate(pose, v)
+    gt.synchronize()
+    from test_gpu_parity import _compare
+    _compare(ot, gt)
+    gt.close()

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import blocks_by_pos
+from oracle_shards import OracleShard, OracleViewTable
 from voxelhashing_demo_amd import dist as vdist
 from voxelhashing_demo_amd import synth
 
@@ -55,7 +56,7 @@ def test_loopback_shards_equal_one_table(oracle, world, batch, sem):
     """batch > 1: several frames per camera travel in one exchange and are applied in order;
     the result is the same as one multi-camera frame per exchange."""
     plan = vdist.ShardPlan(KW["numBuckets"], world)
-    shards = [vdist.OracleShard(oracle, oracle.default_params(**KW), W, H, sem, plan, r, W * H + 1, batch=batch)
+    shards = [OracleShard(oracle, oracle.default_params(**KW), W, H, sem, plan, r, W * H + 1, batch=batch)
               for r in range(world)]
     full = oracle.OracleTable(oracle.default_params(**KW), W, H, sem)
     total = 0
@@ -98,7 +99,7 @@ def _gloo_worker(rank, world, port, sem, q, batch=2):
         import oracle as O
         dist.init_process_group("gloo", rank=rank, world_size=world)
         plan = vdist.ShardPlan(KW["numBuckets"], world)
-        shard = vdist.OracleShard(O, O.default_params(**KW), W, H, sem, plan, rank, W * H + 1, batch=batch)
+        shard = OracleShard(O, O.default_params(**KW), W, H, sem, plan, rank, W * H + 1, batch=batch)
         full = O.OracleTable(O.default_params(**KW), W, H, sem)
         transport = vdist.TorchDistTransport()
         for step in range(0, 4, batch):
@@ -109,7 +110,7 @@ def _gloo_worker(rank, world, port, sem, q, batch=2):
         lo, hi = plan.bucket_range(rank)
         n = check_shard_against_full(shard.table, full, lo, hi, 5)
         # raycast over the shards: this rank's own view, blocks gathered from both ranks
-        view = vdist.OracleViewTable(O, O.default_params(**KW), W, H, sem, world, 2048)
+        view = OracleViewTable(O, O.default_params(**KW), W, H, sem, world, 2048)
         pose = frames[-1][rank][0]
         depth, lost = vdist.sharded_raycast(shard, view, transport, pose, 2048)
         ref = full.raycast(pose)

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle_shards import OracleShard, OracleViewTable
 from voxelhashing_demo_amd import dist as vdist
 from voxelhashing_demo_amd import synth
 
@@ -16,7 +17,7 @@ def build_scene(oracle, world, sem=1, steps=3):
     prims = synth.room_primitives()
     plan = vdist.ShardPlan(KW["numBuckets"], world)
     full = oracle.OracleTable(oracle.default_params(**KW), W, H, sem)
-    shards = [vdist.OracleShard(oracle, oracle.default_params(**KW), W, H, sem, plan, r, W * H + 1)
+    shards = [OracleShard(oracle, oracle.default_params(**KW), W, H, sem, plan, r, W * H + 1)
               for r in range(world)]
     poses = []
     for step in range(steps):
@@ -33,7 +34,7 @@ def build_scene(oracle, world, sem=1, steps=3):
 @pytest.mark.parametrize("world", [1, 3, 4])
 def test_view_table_raycasts_like_the_unsharded_table(oracle, world):
     plan, full, shards, poses = build_scene(oracle, world)
-    views = [vdist.OracleViewTable(oracle, oracle.default_params(**KW), W, H, 1) for _ in range(world)]
+    views = [OracleViewTable(oracle, oracle.default_params(**KW), W, H, 1) for _ in range(world)]
     depths = vdist.loopback_raycast(shards, views, poses, capacity=2048)
     hits = 0
     for r in range(world):
@@ -78,7 +79,7 @@ def test_capacity_overflow_is_reported(oracle):
 
 def test_reference_semantics_tables_raycast_too(oracle):
     plan, full, shards, poses = build_scene(oracle, 2, sem=0)
-    views = [vdist.OracleViewTable(oracle, oracle.default_params(**KW), W, H, 0) for _ in range(2)]
+    views = [OracleViewTable(oracle, oracle.default_params(**KW), W, H, 0) for _ in range(2)]
     depths = vdist.loopback_raycast(shards, views, poses, capacity=2048)
     for r in range(2):
         assert np.array_equal(depths[r], full.raycast(poses[r]))

@@ -48,7 +48,8 @@ class Config(C.Structure):
 class Counters(C.Structure):
     _fields_ = [("occupied", C.c_int32), ("heap_counter", C.c_int32), ("allocated_total", C.c_uint32),
                 ("heap_exhausted", C.c_uint32), ("candidates", C.c_uint32), ("epoch", C.c_uint32),
-                ("bin_overflow", C.c_uint32), ("freed_total", C.c_uint32), ("last_freed", C.c_uint32)]
+                ("bin_overflow", C.c_uint32), ("freed_total", C.c_uint32), ("last_freed", C.c_uint32),
+                ("cand_overflow", C.c_uint32)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -59,7 +60,8 @@ class KernelTimes(C.Structure):
                 ("flatten_ms", C.c_double), ("integrate_ms", C.c_double), ("raycast_ms", C.c_double),
                 ("raycast_launches", C.c_uint64), ("frame_scan_claim_ms", C.c_double),
                 ("frame_commit_integrate_ms", C.c_double), ("view_export_ms", C.c_double),
-                ("view_import_ms", C.c_double), ("gc_ms", C.c_double), ("gc_calls", C.c_uint64)]
+                ("view_import_ms", C.c_double), ("gc_ms", C.c_double), ("gc_calls", C.c_uint64),
+                ("render_blocks_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -27,20 +27,30 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
         if (e.pos[0] == kx && e.pos[1] == ky && e.pos[2] == kz) return;   // already allocated
     }
     if (!has_free) return;               // bucket full: the key is dropped (no overflow list)
-    atomicMax(dp.claim + (h - fp.bucketLo), claim_word(fp.epoch, rank));
+    // The record is reserved BEFORE the claim is staked: a contender that finds the candidate list
+    // full must not hold a bucket's winning word (nobody would commit it).  It is counted instead.
     const uint32_t slot = (uint32_t)atomicAdd(dp.counters + candCounter, 1);
-    if (slot < dp.candCapacity) dp.candidates[slot] = make_int4(kx, ky, kz, (int)rank);
+    if (slot >= dp.candCapacity) {
+        atomicAdd(dp.counters + kCandOverflow, 1);
+        return;
+    }
+    dp.candidates[slot] = make_int4(kx, ky, kz, (int)rank);
+    atomicMax(dp.claim + (h - fp.bucketLo), claim_word(fp.epoch, rank));
 }
 
 // ---------------------------------------------------------------------------
 // allocBlocks, phase 1
 // ---------------------------------------------------------------------------
-// One lane per pixel, row-major, so the float4 vertex map is read with 16-byte
-// coalesced loads (1 KiB per wave instruction).  Neighbouring pixels almost
-// always fall into the same 8^3 block, so each wave collapses runs of equal
-// keys to their first lane before touching the table: ~300 k pixels become a
-// few thousand bucket probes.  Within an image row the launch rank grows with
-// x, so the first lane of a run carries the run's lowest rank.
+// One 256-lane workgroup = one 16x16 block of the reference's launch grid (VoxelUtils.cu:610-611,
+// 710-712), lane t = thread (t & 15, t >> 4) of it, so a lane's index inside its workgroup IS its
+// position in the launch order that decides who wins a bucket: rank = tile*256 + t.
+// A wave is a 16x4 pixel patch (four 256-byte row segments of the float4 vertex map per load
+// instruction).  Neighbouring pixels almost always fall into the same 8^3 block, so each wave
+// collapses equal keys before touching the table: a lane stays silent when the lane to its LEFT or
+// the lane ABOVE it (both earlier in launch order) wants the same key.  By induction the earliest
+// lane of every key in the wave survives, which is all the determinism rule needs; what survives
+// redundantly only costs a probe.  ~300 k pixels become one or two thousand bucket probes (the
+// row-only collapse of round 1 left ~9 k on C2 and ~80 k on C3).
 // Truncation-band allocation (opt-in; commented out in the reference,
 // VoxelUtils.cu:632-703): with fp.allocBand = b > 0 a pixel demands the blocks of
 // 2*ceil(b/step)+1 points on its viewing ray at camera depths z + (k - half)*step, step = half
@@ -48,6 +58,7 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
 struct PixelVertex {
     float4 v;
     int px, py;
+    uint32_t rank;      // launch rank of the pixel = tile*256 + t
     bool valid;
 };
 
@@ -90,14 +101,23 @@ struct SensorImage {
     }
 };
 
+__device__ __forceinline__ uint32_t num_tiles(const FrameParams &fp)
+{
+    return (uint32_t)((fp.width + 15) >> 4) * (uint32_t)((fp.height + 15) >> 4);
+}
+
+// pixel of lane t (0..255) of launch tile `tile`
 template <class In>
-__device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const In &in, int idx,
+__device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const In &in, uint32_t tile, uint32_t t,
                                                   float *__restrict__ outDepth)
 {
-    PixelVertex p{make_float4(0.f, 0.f, 0.f, 0.f), 0, 0, false};
-    if (idx < fp.width * fp.height) {
-        p.py = idx / fp.width;
-        p.px = idx - p.py * fp.width;
+    PixelVertex p{make_float4(0.f, 0.f, 0.f, 0.f), 0, 0, (tile << 8) + t, false};
+    const uint32_t tilesX = (uint32_t)(fp.width + 15) >> 4;
+    const uint32_t by = tile / tilesX, bx = tile - by * tilesX;
+    p.px = (int)(bx * 16u + (t & 15u));
+    p.py = (int)(by * 16u + (t >> 4));
+    if (p.px < fp.width && p.py < fp.height) {          // (a tile index past the grid gives py >= height)
+        const int idx = p.py * fp.width + p.px;
         p.v = in.vertex(idx, p.px, p.py);
         if (outDepth) outDepth[idx] = p.v.z;                             // camera-z plane of a camera packet
         p.valid = p.v.z != 0.0f;                                         // VoxelUtils.cu:621
@@ -105,21 +125,13 @@ __device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const I
     return p;
 }
 
-__device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const float4 *__restrict__ verts, int idx,
-                                                  float *__restrict__ outDepth)
-{
-    return load_pixel(fp, VertexMap{verts}, idx, outDepth);
-}
-
 struct SampleKey {
     int kx, ky, kz;
-    bool leader;       // this lane must probe / emit the key (first of a run of equal in-frustum keys)
+    bool leader;       // this lane must probe / emit the key
 };
 
 // Key of band sample k of this lane's pixel, de-duplicated against the lane's own previous
-// sample and against the previous lane's sample k (runs of equal keys along an image row
-// collapse to their first lane; within a row the launch rank grows with x and, within a pixel,
-// with k, so whoever survives carries the lowest rank of its run).
+// sample and against sample k of the lanes to the left and above (see the header comment).
 __device__ __forceinline__ SampleKey sample_key(const FrameParams &fp, const PixelVertex &p, int k, int nS, float step,
                                                 int &ownX, int &ownY, int &ownZ, bool &ownHave)
 {
@@ -143,25 +155,26 @@ __device__ __forceinline__ SampleKey sample_key(const FrameParams &fp, const Pix
     const bool dupOwn = want && ownHave && ownX == r.kx && ownY == r.ky && ownZ == r.kz;
     if (want) { ownX = r.kx; ownY = r.ky; ownZ = r.kz; ownHave = true; }
     const int lane = threadIdx.x & (kWave - 1);
-    const int pkx = __shfl_up(r.kx, 1), pky = __shfl_up(r.ky, 1), pkz = __shfl_up(r.kz, 1);
-    const int ppy = __shfl_up(p.py, 1);
-    const int pwant = __shfl_up((int)want, 1);
-    r.leader = want && !dupOwn &&
-               (lane == 0 || !pwant || ppy != p.py || pkx != r.kx || pky != r.ky || pkz != r.kz);
+    const unsigned long long wants = __ballot(want);
+    const int lx = __shfl_up(r.kx, 1), ly = __shfl_up(r.ky, 1), lz = __shfl_up(r.kz, 1);
+    const int ux = __shfl_up(r.kx, 16), uy = __shfl_up(r.ky, 16), uz = __shfl_up(r.kz, 16);
+    const bool dupLeft = (lane & 15) != 0 && ((wants >> (lane - 1)) & 1ull) && lx == r.kx && ly == r.ky && lz == r.kz;
+    const bool dupUp = lane >= 16 && ((wants >> (lane - 16)) & 1ull) && ux == r.kx && uy == r.ky && uz == r.kz;
+    r.leader = want && !dupOwn && !dupLeft && !dupUp;
     return r;
 }
 
-__device__ __forceinline__ uint32_t sample_rank(const FrameParams &fp, const PixelVertex &p, int k)
+__device__ __forceinline__ uint32_t sample_rank(const PixelVertex &p, int k)
 {
-    return (launch_rank(p.px, p.py, fp.width) << kRankSampleBits) | (uint32_t)k;
+    return (p.rank << kRankSampleBits) | (uint32_t)k;
 }
 
-// the claim phase for one lane = one pixel (shared by alloc_claim_kernel and the fused frame)
+// the claim phase for one 16x16 launch tile = one 256-lane workgroup (alloc_claim_kernel and the fused frame)
 template <class In>
-__device__ __forceinline__ void claim_pixel(const FrameParams &fp, const DevPtrs &dp, const In &in, int idx,
-                                            int candCounter)
+__device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs &dp, const In &in, uint32_t tile,
+                                           int candCounter)
 {
-    const PixelVertex p = load_pixel(fp, in, idx, nullptr);
+    const PixelVertex p = load_pixel(fp, in, tile, threadIdx.x, nullptr);
     float step;
     const int nS = band_samples(fp, step);
     int ox = 0, oy = 0, oz = 0;
@@ -171,42 +184,37 @@ __device__ __forceinline__ void claim_pixel(const FrameParams &fp, const DevPtrs
         if (!s.leader) continue;
         const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
         if (h < fp.bucketLo || h >= fp.bucketHi) continue;              // not this shard's bucket
-        probe_and_claim(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(fp, p, k), candCounter);
+        probe_and_claim(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, k), candCounter);
     }
 }
 
-__device__ __forceinline__ void claim_pixel(const FrameParams &fp, const DevPtrs &dp,
-                                            const float4 *__restrict__ verts, int idx, int candCounter)
+template <class In>
+__global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, const DevPtrs dp, const In in)
 {
-    claim_pixel(fp, dp, VertexMap{verts}, idx, candCounter);
-}
-
-__global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, const DevPtrs dp,
-                                                          const float4 *__restrict__ verts)
-{
-    claim_pixel(fp, dp, verts, blockIdx.x * 256 + threadIdx.x, kCandCount);
+    claim_tile(fp, dp, in, blockIdx.x, kCandCount);
 }
 
 // Key generation for the multi-GPU exchange: the same per-pixel
 // work, but the surviving keys are binned by owning shard instead of probed.  Slots in
 // a bin come from one global counter per bin; to keep that word off the critical path
 // (one address sustains only ~90 returning atomics per microsecond) a 1024-lane
-// workgroup first counts its keys per owner in LDS and then takes one global
-// atomicAdd per owner it actually has keys for.
+// workgroup (four launch tiles) first counts its keys per owner in LDS and then takes one
+// global atomicAdd per owner it actually has keys for.
 #ifndef VH_GEN_THREADS
 #define VH_GEN_THREADS 1024
 #endif
-constexpr int kGenThreads = VH_GEN_THREADS;   // tuning knob (make EXTRA=-DVH_GEN_THREADS=n)
+constexpr int kGenThreads = VH_GEN_THREADS;   // tuning knob (make EXTRA=-DVH_GEN_THREADS=n); a multiple of 256
+constexpr int kGenTiles = kGenThreads / 256;
 
 template <class In>
 __device__ __forceinline__ void generate_keys_tile(const FrameParams &fp, const In &verts,
                                                    int32_t numShards, int4 *__restrict__ outBins,
                                                    int32_t outCapacity, int32_t outBinStride,
-                                                   float *__restrict__ outDepth, uint32_t rankBase, uint32_t tile)
+                                                   float *__restrict__ outDepth, uint32_t rankBase, uint32_t group)
 {
     __shared__ int ldsCount[VH_MAX_CAMERAS];
     __shared__ int ldsBase[VH_MAX_CAMERAS];
-    const PixelVertex p = load_pixel(fp, verts, tile * kGenThreads + threadIdx.x, outDepth);
+    const PixelVertex p = load_pixel(fp, verts, group * kGenTiles + (threadIdx.x >> 8), threadIdx.x & 255u, outDepth);
     float step;
     const int nS = band_samples(fp, step);
     const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
@@ -229,7 +237,7 @@ __device__ __forceinline__ void generate_keys_tile(const FrameParams &fp, const 
         if (s.leader) {
             int4 *bin = outBins + (size_t)owner * outBinStride;           // record 0 = {count,0,0,0}
             const int slot = ldsBase[owner] + local + 1;
-            if (slot < outCapacity) bin[slot] = make_int4(s.kx, s.ky, s.kz, (int)(rankBase + sample_rank(fp, p, k)));
+            if (slot < outCapacity) bin[slot] = make_int4(s.kx, s.ky, s.kz, (int)(rankBase + sample_rank(p, k)));
         }
         __syncthreads();
     }
@@ -312,6 +320,7 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_sensor_batch_kernel
             pk[t] = t < 16 ? fr.T[b][t] : t < 32 ? fr.Tinv[b][t - 16] : t == 32 ? fr.k[6] : t == 33 ? fr.k[7]
                                                                                   : t == 34 ? fr.k[8] : fr.unit;
         }
+        // straight copy of the image, one pixel per lane (the grid covers ceil(tiles/4)*1024 >= W*H lanes)
         const int idx = blockIdx.x * kGenThreads + threadIdx.x;
         if (idx < fp.width * fp.height) reinterpret_cast<uint16_t *>(pk + kPacketHeaderU16)[idx] = in.depth[idx];
     }

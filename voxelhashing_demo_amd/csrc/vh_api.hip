@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "vh_kernels.hip"
@@ -66,6 +67,7 @@ struct vh_context {
     float rc_fx = 0, rc_fy = 0, rc_cx = 0, rc_cy = 0;
     bool profiling = false;
     std::vector<TimedLaunch> timed;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> eventPool;   // idle event pairs, reused by launch()
     uint64_t profiledFrames = 0;
     vh_kernel_times times{};
     int integrateGrid = 2048;
@@ -77,11 +79,11 @@ struct vh_context {
     int commitBlocks = 128;        // workgroups serving candidates in the fused second launch
     int fusedParity = 0;           // which of the two per-frame counter sets the next fused frame uses
     bool compactArmed = false;     // alloc_commit has zeroed the compact counter and no flatten ran since
-    // WalkKind.  Same-process A/B of the fused frame (launch 1 + launch 2, us): C2  3: 17.2 + 5.1,
-    // 6 (mask form): 16.8 + 13.6, 1: 17.8, 2: 18.9, 5: 17.7, 4 (index, not the reference walk): 6.4 + 5.3;
-    // C3  3: 88 + 22, 6: 74 + 51, 4: 43 + 19.  The mask form makes launch 1 a pure stream but launch 2
-    // then serialises mask -> entry -> atomic -> block update inside each workgroup.
+    // WalkKind: 3 = strided ballot walk (default), 4 = occupancy index (not the reference walk),
+    // 5 = persistent prefetching walk.  Round-1 A/B of the fused frame (launch 1 + launch 2, us):
+    // C2  3: 17.2 + 5.1, 5: 17.7, 4: 6.4 + 5.3; C3  3: 88 + 22, 4: 43 + 19.
     int flattenVariant = 3;
+    uint32_t candAllocated = 0;    // records the candidate buffer holds (dp.candCapacity <= this)
     int occupiedCounter = kCompactCount;   // which device counter holds the occupied count of the last frame
     // raycast over shards
     int32_t *viewLists = nullptr;          // export: selected entry indices, [views][capacity]
@@ -221,7 +223,6 @@ static int free_buffers(vh_context *c)
     if (c->dp.candidates) (void)hipFree(c->dp.candidates);
     if (c->dp.compactMask) (void)hipFree(c->dp.compactMask);
     if (c->dp.bucketBits) (void)hipFree(c->dp.bucketBits);
-    if (c->dp.allocMask) (void)hipFree(c->dp.allocMask);
     if (c->dp.macroBits) (void)hipFree(c->dp.macroBits);
     if (c->viewLists) (void)hipFree(c->viewLists);
     if (c->blockList) (void)hipFree(c->blockList);
@@ -284,7 +285,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     const size_t npix = (size_t)cfg->width * cfg->height;
     DevPtrs &dp = c->dp;
     dp = DevPtrs{};
-    dp.candCapacity = (uint32_t)npix;
+    dp.candCapacity = c->candAllocated = (uint32_t)npix;
 
 #define VH_ALLOC(ptr, bytes)                                               \
     do {                                                                   \
@@ -296,7 +297,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
         }                                                                  \
     } while (0)
     VH_ALLOC(dp.heap, sizeof(uint32_t) * (size_t)p.numVoxelBlocks);
-    VH_ALLOC(dp.table, sizeof(VoxelEntry) * c->numEntries + 16);   // the wide walk reads whole 16-byte chunks
+    VH_ALLOC(dp.table, sizeof(VoxelEntry) * c->numEntries);
     VH_ALLOC(dp.compact, sizeof(VoxelEntry) * c->numEntries);
     VH_ALLOC(dp.claim, sizeof(unsigned long long) * (size_t)c->ownedBuckets);
     VH_ALLOC(dp.blocks, sizeof(Voxel) * (size_t)p.numVoxelBlocks * kBlockVoxels);
@@ -305,9 +306,6 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     VH_ALLOC(dp.compactMask, sizeof(uint32_t) * c->numEntries);
     VH_ALLOC(dp.bucketBits, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32));
     VH_ALLOC(dp.macroBits, kMacroBits / 8);
-    // 32 mask words per 2048-entry tile, padded to whole 256-word chunks
-    VH_ALLOC(dp.allocMask, sizeof(unsigned long long) *
-                               (((c->numEntries + kMaskChunkEntries - 1) / kMaskChunkEntries) * kMaskChunkWords));
 #undef VH_ALLOC
 
     // deviceAllocate, VoxelUtils.cu:183-208 (+ the compact table and the zeroed
@@ -350,6 +348,8 @@ static void drop_events(vh_context *c)
 {
     for (auto &t : c->timed) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     c->timed.clear();
+    for (auto &p : c->eventPool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    c->eventPool.clear();
 }
 
 extern "C" int vh_destroy(vh_context *c)
@@ -402,6 +402,23 @@ extern "C" int vh_set_pose(vh_context *c, const float pose[16])
     invert4x4(pose, c->fp.Tinv);                        // SDF_Hashtable.cpp:15
     std::memcpy(c->params.global_transform, c->fp.T, sizeof c->fp.T);
     std::memcpy(c->params.inv_global_transform, c->fp.Tinv, sizeof c->fp.Tinv);
+    return VH_OK;
+}
+
+// The candidate list holds one record per contender of a lock epoch.  A single-camera frame has at
+// most one per pixel and band sample after the wave-level collapse (W*H records are allocated; more
+// is counted in vh_counters.cand_overflow); a multi-camera frame can bring up to
+// num_bins*(capacity-1) keys, for which the list is grown here (synchronises when it grows).
+static int ensure_candidates(vh_context *c, size_t need)
+{
+    if (need <= c->candAllocated) return VH_OK;
+    if (need > 0x7fffffffull) return fail(VH_ERR_INVALID_ARGUMENT, "candidate list too large");
+    VH_HIP(hipStreamSynchronize(c->stream));
+    int4 *fresh = nullptr;
+    VH_HIP(hipMalloc((void **)&fresh, sizeof(int4) * need));
+    (void)hipFree(c->dp.candidates);
+    c->dp.candidates = fresh;
+    c->dp.candCapacity = c->candAllocated = (uint32_t)need;
     return VH_OK;
 }
 

@@ -21,6 +21,18 @@ extern "C" int vh_reset_mutexes(vh_context *c)
 }
 
 static inline int grid_for(size_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
+// 16x16 launch tiles of the depth image (one claim workgroup each, vh_alloc.hip)
+static inline uint32_t host_num_tiles(const vh_context *c)
+{
+    return (uint32_t)((c->fp.width + 15) / 16) * (uint32_t)((c->fp.height + 15) / 16);
+}
+
+// Profiling: a start/stop event pair per dispatch, taken from a pool that vh_get_kernel_times (and
+// accumulate_times below) refill; a profiled run of any length keeps at most kMaxTimedLaunches
+// pairs alive (at that point the stream is synchronised once and the pending pairs are folded
+// into the totals).
+constexpr size_t kMaxTimedLaunches = 8192;
+static int accumulate_times(vh_context *c);
 
 template <typename K, typename... Args>
 static int launch(vh_context *c, int phase, K kernel, dim3 grid, dim3 block, Args... args)
@@ -29,30 +41,41 @@ static int launch(vh_context *c, int phase, K kernel, dim3 grid, dim3 block, Arg
         hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, args...);
         return VH_OK;
     }
+    if (c->timed.size() >= kMaxTimedLaunches) {
+        const int rc = accumulate_times(c);
+        if (rc != VH_OK) return rc;
+    }
     TimedLaunch t{phase, nullptr, nullptr};
-    VH_HIP(hipEventCreate(&t.start));
-    VH_HIP(hipEventCreate(&t.stop));
+    if (!c->eventPool.empty()) {
+        t.start = c->eventPool.back().first;
+        t.stop = c->eventPool.back().second;
+        c->eventPool.pop_back();
+    } else {
+        VH_HIP(hipEventCreate(&t.start));
+        const hipError_t e = hipEventCreate(&t.stop);
+        if (e != hipSuccess) {
+            (void)hipEventDestroy(t.start);
+            return fail(VH_ERR_HIP, "hipEventCreate", e);
+        }
+    }
     hipExtLaunchKernelGGL(kernel, grid, block, 0, c->stream, t.start, t.stop, 0, args...);
     c->timed.push_back(t);
     return VH_OK;
 }
 
-static int launch_alloc(vh_context *c, const vh_float4 *verts)
+template <class In>
+static int launch_alloc(vh_context *c, const In &in)
 {
-    const int npix = c->fp.width * c->fp.height;
-    int rc = launch(c, kPhaseClaim, alloc_claim_kernel, dim3(grid_for(npix, 256)), dim3(256), c->fp, c->dp,
-                    reinterpret_cast<const float4 *>(verts));
+    int rc = launch(c, kPhaseClaim, alloc_claim_kernel<In>, dim3(host_num_tiles(c)), dim3(256), c->fp, c->dp, in);
     if (rc != VH_OK) return rc;
     rc = launch(c, kPhaseCommit, alloc_commit_kernel, dim3(32), dim3(256), c->fp, c->dp);
     c->compactArmed = (rc == VH_OK);
     return rc;
 }
 
-// workgroups of the table walk: 2048 entries each (strided) or 2048 16-byte chunks each (wide)
+// workgroups of the table walk: 2048 entries each
 static uint32_t walk_blocks(const vh_context *c)
 {
-    if (c->flattenVariant == kWalkWide)
-        return (uint32_t)grid_for(((size_t)c->numEntries * 20 + 15) / 16, kFlattenThreads * kChunksPerLane);
     if (c->flattenVariant == kWalkIndexed)       // one lane per 32-bucket word of the occupancy bitmap
         return (uint32_t)grid_for(((size_t)c->ownedBuckets + 31) / 32, kFlattenThreads);
     if (c->flattenVariant == kWalkPersistent)    // resident workgroups striding over the tiles
@@ -70,23 +93,14 @@ static int launch_flatten(vh_context *c)
     if (c->flattenVariant == kWalkPersistent)
         return launch(c, kPhaseFlatten, flatten_kernel<kWalkPersistent>, grid, dim3(kFlattenThreads), c->fp, c->dp,
                       (uint32_t)c->numEntries);
-    if (c->flattenVariant == kWalkWide)
-        return launch(c, kPhaseFlatten, flatten_kernel<kWalkWide>, grid, dim3(kFlattenThreads), c->fp, c->dp,
-                      (uint32_t)c->numEntries);
-    if (c->flattenVariant == kWalkStrided)
-        return launch(c, kPhaseFlatten, flatten_kernel<kWalkStrided>, grid, dim3(kFlattenThreads), c->fp, c->dp,
-                      (uint32_t)c->numEntries);
-    if (c->flattenVariant == kWalkStridedNT)
-        return launch(c, kPhaseFlatten, flatten_kernel<kWalkStridedNT>, grid, dim3(kFlattenThreads), c->fp, c->dp,
-                      (uint32_t)c->numEntries);
     return launch(c, kPhaseFlatten, flatten_kernel<kWalkStridedBallot>, grid, dim3(kFlattenThreads), c->fp, c->dp,
                   (uint32_t)c->numEntries);
 }
 
-static int launch_integrate(vh_context *c, const vh_float4 *verts)
+template <class Depth>
+static int launch_integrate(vh_context *c, const Depth &depth)
 {
-    return launch(c, kPhaseIntegrate, integrate_kernel, dim3(c->integrateGrid), dim3(256), c->fp, c->dp,
-                  reinterpret_cast<const float4 *>(verts));
+    return launch(c, kPhaseIntegrate, integrate_kernel<Depth>, dim3(c->integrateGrid), dim3(256), c->fp, c->dp, depth);
 }
 
 extern "C" int vh_alloc_blocks(vh_context *c, const vh_float4 *verts, const vh_float4 *normals)
@@ -95,7 +109,7 @@ extern "C" int vh_alloc_blocks(vh_context *c, const vh_float4 *verts, const vh_f
     if (!c || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     if (c->fp.epoch == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
     DeviceGuard guard(c->device);
-    int rc = launch_alloc(c, verts);
+    int rc = launch_alloc(c, VertexMap{reinterpret_cast<const float4 *>(verts)});
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -126,8 +140,52 @@ extern "C" int vh_integrate_depth_map(vh_context *c, const vh_float4 *verts)
 {
     if (!c || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(c->device);
-    int rc = launch_integrate(c, verts);
+    int rc = launch_integrate(c, vertex_depth(reinterpret_cast<const float4 *>(verts)));
     if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// One frame (pose and lock epoch already set): In = where the claim phase reads a pixel's vertex,
+// Depth = where the TSDF update reads a pixel's camera z.  Honours "fused_frame" and "flatten_variant".
+template <int kKind, class In>
+static int launch_scan_claim(vh_context *c, const In &in, uint32_t claimBlocks, uint32_t scanBlocks)
+{
+    return launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kKind, In>, dim3(claimBlocks + scanBlocks),
+                  dim3(256), c->fp, c->dp, in, (uint32_t)c->numEntries, claimBlocks, c->fusedParity);
+}
+
+template <class In, class Depth>
+static int run_frame(vh_context *c, const In &in, const Depth &depth)
+{
+    int rc;
+    c->occupiedCounter = kCompactCount;
+    if (c->fusedFrame) {
+        // two launches: {claim || table walk}, then {commit + integrate}; see vh_frame.hip
+        const uint32_t claimBlocks = host_num_tiles(c);
+        const uint32_t scanBlocks = walk_blocks(c);
+        if (c->flattenVariant == kWalkIndexed)
+            rc = launch_scan_claim<kWalkIndexed>(c, in, claimBlocks, scanBlocks);
+        else if (c->flattenVariant == kWalkPersistent)
+            rc = launch_scan_claim<kWalkPersistent>(c, in, claimBlocks, scanBlocks);
+        else
+            rc = launch_scan_claim<kWalkStridedBallot>(c, in, claimBlocks, scanBlocks);
+        if (rc != VH_OK) return rc;
+        const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
+        rc = launch(c, kPhaseFrameCommitIntegrate, frame_commit_integrate_kernel<Depth>,
+                    dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, depth, commitBlocks,
+                    c->fusedParity);
+        if (rc != VH_OK) return rc;
+        c->fusedParity ^= 1;       // this frame cleared the other counter set for the next one
+        c->compactArmed = false;
+    } else {
+        // alloc_commit re-arms the compact counter, so no memset node is needed here
+        if ((rc = launch_alloc(c, in)) != VH_OK) return rc;
+        c->compactArmed = false;
+        if ((rc = launch_flatten(c)) != VH_OK) return rc;
+        if ((rc = launch_integrate(c, depth)) != VH_OK) return rc;
+    }
+    if (c->profiling) c->profiledFrames += 1;
     VH_HIP(hipGetLastError());
     return VH_OK;
 }
@@ -140,72 +198,8 @@ extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4
     int rc = vh_set_pose(c, pose);
     if (rc == VH_OK) rc = vh_reset_mutexes(c);
     if (rc != VH_OK) return rc;
-    if (c->fusedFrame && c->flattenVariant == kWalkMask) {
-        // mask form: {claim || pure-stream walk that stores allocation masks}, then
-        // {commit || consume the masks: frustum test, compaction, TSDF update}
-        const uint32_t claimBlocks = (uint32_t)grid_for((size_t)c->fp.width * c->fp.height, 256);
-        const uint32_t tiles = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
-        rc = launch(c, kPhaseFrameScanClaim, frame_mask_claim_kernel, dim3(claimBlocks + tiles), dim3(256), c->fp,
-                    c->dp, reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
-                    c->fusedParity);
-        if (rc != VH_OK) return rc;
-        const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
-        const uint32_t chunks = (uint32_t)grid_for(c->numEntries, kMaskChunkEntries);
-        rc = launch(c, kPhaseFrameCommitIntegrate, frame_commit_consume_kernel, dim3(commitBlocks + chunks), dim3(256),
-                    c->fp, c->dp, reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, commitBlocks,
-                    c->fusedParity);
-        if (rc != VH_OK) return rc;
-        c->occupiedCounter = kScanCount + c->fusedParity;   // this frame's slot counter = occupied count
-        c->fusedParity ^= 1;
-        c->compactArmed = false;
-    } else if (c->fusedFrame) {
-        // two launches: {claim || table walk}, then {commit + integrate}; see vh_kernels.hip
-        c->occupiedCounter = kCompactCount;
-        const uint32_t claimBlocks = (uint32_t)grid_for((size_t)c->fp.width * c->fp.height, 256);
-        const uint32_t scanBlocks = walk_blocks(c);
-        if (c->flattenVariant == kWalkIndexed)
-            rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kWalkIndexed>,
-                        dim3(claimBlocks + scanBlocks), dim3(256), c->fp, c->dp,
-                        reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
-                        c->fusedParity);
-        else if (c->flattenVariant == kWalkPersistent)
-            rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kWalkPersistent>,
-                        dim3(claimBlocks + scanBlocks), dim3(256), c->fp, c->dp,
-                        reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
-                        c->fusedParity);
-        else if (c->flattenVariant == kWalkWide)
-            rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kWalkWide>, dim3(claimBlocks + scanBlocks),
-                        dim3(256), c->fp, c->dp, reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries,
-                        claimBlocks, c->fusedParity);
-        else if (c->flattenVariant == kWalkStridedBallot)
-            rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kWalkStridedBallot>,
-                        dim3(claimBlocks + scanBlocks), dim3(256), c->fp, c->dp,
-                        reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
-                        c->fusedParity);
-        else
-            rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kWalkStrided>,
-                        dim3(claimBlocks + scanBlocks), dim3(256), c->fp, c->dp,
-                        reinterpret_cast<const float4 *>(verts), (uint32_t)c->numEntries, claimBlocks,
-                        c->fusedParity);
-        if (rc != VH_OK) return rc;
-        const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
-        rc = launch(c, kPhaseFrameCommitIntegrate, frame_commit_integrate_kernel,
-                    dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp,
-                    reinterpret_cast<const float4 *>(verts), commitBlocks, c->fusedParity);
-        if (rc != VH_OK) return rc;
-        c->fusedParity ^= 1;       // this frame cleared the other counter set for the next one
-        c->compactArmed = false;
-    } else {
-        // alloc_commit re-arms the compact counter, so no memset node is needed here
-        c->occupiedCounter = kCompactCount;
-        if ((rc = launch_alloc(c, verts)) != VH_OK) return rc;
-        c->compactArmed = false;
-        if ((rc = launch_flatten(c)) != VH_OK) return rc;
-        if ((rc = launch_integrate(c, verts)) != VH_OK) return rc;
-    }
-    if (c->profiling) c->profiledFrames += 1;
-    VH_HIP(hipGetLastError());
-    return VH_OK;
+    const float4 *v = reinterpret_cast<const float4 *>(verts);
+    return run_frame(c, VertexMap{v}, vertex_depth(v));
 }
 
 // The frame straight from the uint16 sensor image: preProcess's vertex computation happens inside
@@ -221,21 +215,7 @@ extern "C" int vh_integrate_depth(vh_context *c, const float pose[16], const uin
     in.depth = d_depth;
     std::memcpy(in.k, k_inv, sizeof in.k);
     in.unit = 5000.0f;                                                   // CameraTrackingUtils.cu:64
-    c->occupiedCounter = kCompactCount;
-    const uint32_t claimBlocks = (uint32_t)grid_for((size_t)c->fp.width * c->fp.height, 256);
-    const uint32_t scanBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
-    rc = launch(c, kPhaseFrameScanClaim, frame_scan_claim_sensor_kernel, dim3(claimBlocks + scanBlocks), dim3(256), c->fp,
-                c->dp, in, (uint32_t)c->numEntries, claimBlocks, c->fusedParity);
-    if (rc != VH_OK) return rc;
-    const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
-    rc = launch(c, kPhaseFrameCommitIntegrate, frame_commit_integrate_sensor_kernel,
-                dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, in, commitBlocks, c->fusedParity);
-    if (rc != VH_OK) return rc;
-    c->fusedParity ^= 1;
-    c->compactArmed = false;
-    if (c->profiling) c->profiledFrames += 1;
-    VH_HIP(hipGetLastError());
-    return VH_OK;
+    return run_frame(c, in, DepthSensor{in.depth, in.k[6], in.k[7], in.k[8], in.unit});
 }
 
 extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, float t_max, float *d_depth_out)

@@ -23,7 +23,10 @@ extern "C" int vh_delete_blocks(vh_context *c, const int32_t *d_keys, int32_t n)
     if (!c || (!d_keys && n > 0) || n < 0) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table owns no blocks");
     DeviceGuard guard(c->device);
-    c->fp.epoch += 1;                       // the sweep list is built under a fresh lock epoch
+    {   // the sweep list is built under a fresh lock epoch (with the wrap handling of the frame's epochs)
+        const int rc = vh_reset_mutexes(c);
+        if (rc != VH_OK) return rc;
+    }
     if (n > 0) {
         const int rc = launch(c, kPhaseGc, gc_mark_keys_kernel, dim3((unsigned)grid_for((size_t)n, 256)), dim3(256), c->fp,
                               c->dp, reinterpret_cast<const int4 *>(d_keys), n);
@@ -37,7 +40,10 @@ extern "C" int vh_garbage_collect(vh_context *c, float sdf_threshold)
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table owns no blocks");
     DeviceGuard guard(c->device);
-    c->fp.epoch += 1;
+    {
+        const int rc = vh_reset_mutexes(c);
+        if (rc != VH_OK) return rc;
+    }
     const int rc = launch(c, kPhaseGc, gc_identify_kernel, dim3(2048), dim3(256), c->fp, c->dp, c->occupiedCounter,
                           sdf_threshold);
     if (rc != VH_OK) return rc;
@@ -71,6 +77,7 @@ extern "C" int vh_get_counters(vh_context *c, vh_counters *out)
     out->bin_overflow = (uint32_t)h[kBinOverflow];
     out->freed_total = (uint32_t)h[kFreedTotal];
     out->last_freed = (uint32_t)h[kLastFreed];
+    out->cand_overflow = (uint32_t)h[kCandOverflow];
     c->params.numOccupiedBlocks = (uint32_t)h[c->occupiedCounter];
     return VH_OK;
 }
@@ -184,7 +191,10 @@ extern "C" int vh_save_snapshot(vh_context *c, const char *path)
     h.numEntries = c->numEntries;
     std::memcpy(h.proj, c->fp.proj, sizeof h.proj);
     for (const VoxelEntry &e : table) h.numAllocated += e.ptr != VH_FREE_BLOCK;
-    FILE *f = std::fopen(path, "wb");
+    // written next to the target and renamed over it at the end: a crash mid-save never leaves a
+    // truncated file under the final name
+    const std::string tmp = std::string(path) + ".partial";
+    FILE *f = std::fopen(tmp.c_str(), "wb");
     if (!f) return fail(VH_ERR_INVALID_ARGUMENT, "cannot open the snapshot file");
     bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
     ok = ok && std::fwrite(table.data(), sizeof(VoxelEntry), table.size(), f) == table.size();
@@ -197,73 +207,149 @@ extern "C" int vh_save_snapshot(vh_context *c, const char *path)
             hipSuccess) { ok = false; break; }
         ok = std::fwrite(block.data(), sizeof(Voxel), kBlockVoxels, f) == (size_t)kBlockVoxels;
     }
-    std::fclose(f);
-    return ok ? VH_OK : fail(VH_ERR_HIP, "snapshot write failed");
+    ok = (std::fflush(f) == 0) && ok;
+    ok = (std::fclose(f) == 0) && ok;
+    if (ok) ok = std::rename(tmp.c_str(), path) == 0;
+    if (!ok) {
+        (void)std::remove(tmp.c_str());
+        return fail(VH_ERR_HIP, "snapshot write failed");
+    }
+    return VH_OK;
 }
 
+// Empties the model (table, heap, counters, bitmaps, volume) on the context's stream.
+static hipError_t reset_model(vh_context *c)
+{
+    hipStream_t s = c->stream;
+    const int g = 2048;
+    reset_table_kernel<<<g, 256, 0, s>>>(c->dp.table, c->numEntries);
+    reset_heap_kernel<<<g, 256, 0, s>>>(c->dp.heap, c->params.numVoxelBlocks);
+    hipError_t e = hipMemsetAsync(c->dp.claim, 0, sizeof(unsigned long long) * (size_t)c->ownedBuckets, s);
+    if (e == hipSuccess) e = hipMemsetAsync(c->dp.bucketBits, 0, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32), s);
+    if (e == hipSuccess) e = hipMemsetAsync(c->dp.macroBits, 0, kMacroBits / 8, s);
+    if (e == hipSuccess) e = hipMemsetAsync(c->dp.blocks, 0, sizeof(Voxel) * (size_t)c->params.numVoxelBlocks * kBlockVoxels, s);
+    int32_t counters[kNumCounters] = {0};
+    counters[kHeapCounter] = (int32_t)c->params.numVoxelBlocks - 1;
+    if (e == hipSuccess) e = hipMemcpyAsync(c->dp.counters, counters, sizeof counters, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    c->fp.epoch = 0;
+    c->fusedParity = 0;
+    c->compactArmed = false;
+    c->occupiedCounter = kCompactCount;
+    return e;
+}
+
+// The file is read and validated on the host -- header against this context, every entry, the
+// heap, the pool partition, the file size -- BEFORE the first byte of device state changes: a
+// truncated, corrupt or mismatched file leaves the live model untouched.  Only the voxel payload is
+// streamed afterwards; should reading it fail then (an I/O error after the size check), the model
+// is reset to empty rather than left half-loaded.
 extern "C" int vh_load_snapshot(vh_context *c, const char *path)
 {
     if (!c || !path) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table owns no blocks");
     FILE *f = std::fopen(path, "rb");
     if (!f) return fail(VH_ERR_INVALID_ARGUMENT, "cannot open the snapshot file");
+    struct Closer { FILE *f; ~Closer() { std::fclose(f); } } closer{f};
     SnapshotHeader h;
-    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "VHSNAP01", 8) == 0;
-    ok = ok && h.numEntries == c->numEntries && h.params.numVoxelBlocks == c->params.numVoxelBlocks &&
-         h.params.numBuckets == c->params.numBuckets && h.params.bucketSize == c->params.bucketSize &&
-         h.bucketLo == c->fp.bucketLo && h.bucketHi == c->fp.bucketHi && h.width == c->fp.width &&
-         h.height == c->fp.height;
-    if (!ok) { std::fclose(f); return fail(VH_ERR_INVALID_ARGUMENT, "snapshot does not match this context"); }
+    if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, "VHSNAP01", 8) != 0)
+        return fail(VH_ERR_INVALID_ARGUMENT, "not a snapshot file");
+    const HashTableParams &p = c->params;
+    const bool match = h.numEntries == c->numEntries && h.params.numVoxelBlocks == p.numVoxelBlocks &&
+                       h.params.numBuckets == p.numBuckets && h.params.bucketSize == p.bucketSize &&
+                       h.params.voxelBlockSize == p.voxelBlockSize && h.bucketLo == c->fp.bucketLo &&
+                       h.bucketHi == c->fp.bucketHi && h.width == c->fp.width && h.height == c->fp.height &&
+                       h.semantics == c->fp.semantics &&
+                       std::memcmp(&h.params.voxelSize, &p.voxelSize, sizeof(float)) == 0 &&
+                       std::memcmp(&h.params.truncation, &p.truncation, sizeof(float)) == 0 &&
+                       std::memcmp(&h.params.integrationWeightMax, &p.integrationWeightMax, sizeof(float)) == 0;
+    if (!match) return fail(VH_ERR_INVALID_ARGUMENT, "snapshot does not match this context");
+    const int64_t pool = (int64_t)p.numVoxelBlocks;
+    if (h.heapCounter < -1 || (int64_t)h.heapCounter >= pool)
+        return fail(VH_ERR_INVALID_ARGUMENT, "snapshot is corrupt: heap counter out of range");
     std::vector<VoxelEntry> table(c->numEntries);
-    std::vector<uint32_t> heap(c->params.numVoxelBlocks);
-    ok = std::fread(table.data(), sizeof(VoxelEntry), table.size(), f) == table.size() &&
-         std::fread(heap.data(), sizeof(uint32_t), heap.size(), f) == heap.size();
+    std::vector<uint32_t> heap(p.numVoxelBlocks);
+    if (std::fread(table.data(), sizeof(VoxelEntry), table.size(), f) != table.size() ||
+        std::fread(heap.data(), sizeof(uint32_t), heap.size(), f) != heap.size())
+        return fail(VH_ERR_INVALID_ARGUMENT, "snapshot is truncated");
+    // every block id is either referenced by exactly one entry or on the free part of the heap
+    std::vector<uint8_t> seen(p.numVoxelBlocks, 0);
+    uint64_t allocated = 0;
+    for (const VoxelEntry &e : table) {
+        if (e.ptr == VH_FREE_BLOCK) continue;
+        if (e.ptr < 0 || e.ptr % kBlockVoxels != 0 || (int64_t)(e.ptr / kBlockVoxels) >= pool || seen[e.ptr / kBlockVoxels])
+            return fail(VH_ERR_INVALID_ARGUMENT, "snapshot is corrupt: bad or duplicate block pointer");
+        seen[e.ptr / kBlockVoxels] = 1;
+        ++allocated;
+    }
+    for (int64_t i = 0; i <= (int64_t)h.heapCounter; ++i) {
+        if ((int64_t)heap[i] >= pool || seen[heap[i]])
+            return fail(VH_ERR_INVALID_ARGUMENT, "snapshot is corrupt: free list overlaps the allocated blocks");
+        seen[heap[i]] = 1;
+    }
+    if (allocated != h.numAllocated || (int64_t)allocated + (int64_t)h.heapCounter + 1 != pool)
+        return fail(VH_ERR_INVALID_ARGUMENT, "snapshot is corrupt: blocks and free list do not partition the pool");
+    const long payload_at = std::ftell(f);
+    if (payload_at < 0 || std::fseek(f, 0, SEEK_END) != 0) return fail(VH_ERR_INVALID_ARGUMENT, "snapshot is unreadable");
+    const long file_end = std::ftell(f);
+    if (file_end < 0 || (uint64_t)(file_end - payload_at) != allocated * sizeof(Voxel) * kBlockVoxels)
+        return fail(VH_ERR_INVALID_ARGUMENT, "snapshot is truncated or has trailing bytes");
+    if (std::fseek(f, payload_at, SEEK_SET) != 0) return fail(VH_ERR_INVALID_ARGUMENT, "snapshot is unreadable");
+
+    // ---- from here on the device state changes ----
     DeviceGuard guard(c->device);
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = reset_model(c);
     const size_t words = ((size_t)c->ownedBuckets + 31) / 32;
     std::vector<uint32_t> bits(words, 0u), macro(kMacroBits / 32, 0u);
     std::vector<Voxel> block(kBlockVoxels);
-    if (ok && e == hipSuccess)
-        e = hipMemset(c->dp.blocks, 0, sizeof(Voxel) * (size_t)c->params.numVoxelBlocks * kBlockVoxels);
+    bool ok = true;
     for (size_t i = 0; ok && e == hipSuccess && i < table.size(); ++i) {
         if (table[i].ptr == VH_FREE_BLOCK) continue;
-        const size_t bucket = i / c->params.bucketSize;
+        const size_t bucket = i / p.bucketSize;
         bits[bucket >> 5] |= 1u << (bucket & 31);
         const uint32_t hm = ((((uint32_t)(table[i].pos[0] >> 2)) * 73856093u) ^ (((uint32_t)(table[i].pos[1] >> 2)) * 19349669u) ^
                              (((uint32_t)(table[i].pos[2] >> 2)) * 83492791u)) & (kMacroBits - 1u);
         macro[hm >> 5] |= 1u << (hm & 31);
-        ok = std::fread(block.data(), sizeof(Voxel), kBlockVoxels, f) == (size_t)kBlockVoxels &&
-             (uint64_t)table[i].ptr + kBlockVoxels <= (uint64_t)c->params.numVoxelBlocks * kBlockVoxels;
+        ok = std::fread(block.data(), sizeof(Voxel), kBlockVoxels, f) == (size_t)kBlockVoxels;
         if (ok) e = hipMemcpy(c->dp.blocks + table[i].ptr, block.data(), sizeof(Voxel) * kBlockVoxels, hipMemcpyHostToDevice);
     }
-    std::fclose(f);
-    if (!ok) return fail(VH_ERR_INVALID_ARGUMENT, "snapshot is truncated or corrupt");
     int32_t counters[kNumCounters] = {0};
     counters[kHeapCounter] = h.heapCounter;
     counters[kAllocatedTotal] = (int32_t)h.allocatedTotal;
     counters[kHeapExhausted] = (int32_t)h.heapExhausted;
-    if (e == hipSuccess) e = hipMemcpy(c->dp.table, table.data(), sizeof(VoxelEntry) * table.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(c->dp.heap, heap.data(), sizeof(uint32_t) * heap.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(c->dp.bucketBits, bits.data(), sizeof(uint32_t) * words, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(c->dp.macroBits, macro.data(), kMacroBits / 8, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemset(c->dp.claim, 0, sizeof(unsigned long long) * (size_t)c->ownedBuckets);
-    if (e == hipSuccess) e = hipMemcpy(c->dp.counters, counters, sizeof counters, hipMemcpyHostToDevice);
-    if (e != hipSuccess) return fail(VH_ERR_HIP, "snapshot upload", e);
-    c->params = h.params;
+    if (ok && e == hipSuccess) e = hipMemcpy(c->dp.table, table.data(), sizeof(VoxelEntry) * table.size(), hipMemcpyHostToDevice);
+    if (ok && e == hipSuccess) e = hipMemcpy(c->dp.heap, heap.data(), sizeof(uint32_t) * heap.size(), hipMemcpyHostToDevice);
+    if (ok && e == hipSuccess) e = hipMemcpy(c->dp.bucketBits, bits.data(), sizeof(uint32_t) * words, hipMemcpyHostToDevice);
+    if (ok && e == hipSuccess) e = hipMemcpy(c->dp.macroBits, macro.data(), kMacroBits / 8, hipMemcpyHostToDevice);
+    if (ok && e == hipSuccess) e = hipMemcpy(c->dp.counters, counters, sizeof counters, hipMemcpyHostToDevice);
+    if (!ok || e != hipSuccess) {
+        (void)reset_model(c);                       // never leave a half-loaded model behind
+        return !ok ? fail(VH_ERR_INVALID_ARGUMENT, "snapshot payload could not be read; the model was reset to empty")
+                   : fail(VH_ERR_HIP, "snapshot upload failed; the model was reset to empty", e);
+    }
+    // pose, projection: the snapshot's; geometry and fusion constants were checked equal above
+    std::memcpy(c->params.global_transform, h.params.global_transform, sizeof c->fp.T);
+    std::memcpy(c->params.inv_global_transform, h.params.inv_global_transform, sizeof c->fp.Tinv);
     std::memcpy(c->fp.T, h.params.global_transform, sizeof c->fp.T);
     std::memcpy(c->fp.Tinv, h.params.inv_global_transform, sizeof c->fp.Tinv);
     std::memcpy(c->fp.proj, h.proj, sizeof h.proj);
-    c->fp.semantics = h.semantics;
-    c->fp.epoch = 0;                 // the claim words were cleared: any epoch >= 1 is fresh
-    c->fusedParity = 0;
-    c->compactArmed = false;
-    c->occupiedCounter = kCompactCount;
+    c->params.numOccupiedBlocks = 0;
     return VH_OK;
 }
 
 extern "C" int vh_set_option(vh_context *c, const char *name, int value)
 {
     if (!c || !name) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
-    if (std::strcmp(name, "flatten_variant") == 0) { c->flattenVariant = value; return VH_OK; }
+    if (std::strcmp(name, "flatten_variant") == 0) {
+        if (value != kWalkStridedBallot && value != kWalkIndexed && value != kWalkPersistent)
+            return fail(VH_ERR_INVALID_ARGUMENT, "flatten_variant: 3 (walk), 4 (occupancy index) or 5 (persistent walk)");
+        c->flattenVariant = value;
+        return VH_OK;
+    }
+    if (std::strcmp(name, "cand_capacity") == 0 && value > 0) {     // test hook: a smaller candidate list
+        c->dp.candCapacity = std::min<uint32_t>((uint32_t)value, c->candAllocated);
+        return VH_OK;
+    }
     if (std::strcmp(name, "integrate_grid") == 0 && value > 0) { c->integrateGrid = value; return VH_OK; }
     if (std::strcmp(name, "fused_frame") == 0) { c->fusedFrame = value; return VH_OK; }
     if (std::strcmp(name, "raycast_patch") == 0) { c->raycastPatch = value; return VH_OK; }
@@ -284,10 +370,9 @@ extern "C" int vh_set_profiling(vh_context *c, int enabled)
     return VH_OK;
 }
 
-extern "C" int vh_get_kernel_times(vh_context *c, vh_kernel_times *out, int reset)
+// Folds the pending event pairs into c->times (synchronises the stream) and returns them to the pool.
+static int accumulate_times(vh_context *c)
 {
-    if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
-    DeviceGuard guard(c->device);
     VH_HIP(hipStreamSynchronize(c->stream));
     for (auto &t : c->timed) {
         float ms = 0;
@@ -303,13 +388,23 @@ extern "C" int vh_get_kernel_times(vh_context *c, vh_kernel_times *out, int rese
             case kPhaseViewExport: c->times.view_export_ms += ms; break;
             case kPhaseViewImport: c->times.view_import_ms += ms; break;
             case kPhaseGc: c->times.gc_ms += ms; break;
-            case kPhaseRaycastBounds: c->times.raycast_ms += ms; break;      // vh_render_blocks: counted with the render work
+            case kPhaseRaycastBounds: c->times.render_blocks_ms += ms; break;
             default: break;
         }
+        c->eventPool.emplace_back(t.start, t.stop);
     }
+    c->timed.clear();
     c->times.launches += c->profiledFrames;
     c->profiledFrames = 0;
-    drop_events(c);
+    return VH_OK;
+}
+
+extern "C" int vh_get_kernel_times(vh_context *c, vh_kernel_times *out, int reset)
+{
+    if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(c->device);
+    const int rc = accumulate_times(c);
+    if (rc != VH_OK) return rc;
     *out = c->times;
     if (reset) c->times = vh_kernel_times{};
     return VH_OK;

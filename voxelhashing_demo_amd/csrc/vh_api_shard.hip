@@ -105,9 +105,8 @@ extern "C" int vh_generate_keys(vh_context *c, const vh_float4 *verts, uint32_t 
         camera_id >= VH_MAX_CAMERAS || num_shards > VH_MAX_CAMERAS)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     DeviceGuard guard(c->device);
-    const int npix = c->fp.width * c->fp.height;
     prepare_bins_kernel<<<1, 64, 0, c->stream>>>(reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, 1, 0);
-    generate_keys_kernel<<<grid_for(npix, kGenThreads), kGenThreads, 0, c->stream>>>(
+    generate_keys_kernel<<<grid_for(host_num_tiles(c), kGenTiles), kGenThreads, 0, c->stream>>>(
         c->fp, reinterpret_cast<const float4 *>(verts), num_shards, reinterpret_cast<int4 *>(d_bins), capacity,
         bin_stride, d_packet ? d_packet + kPacketHeader : nullptr, camera_id << kRankCameraShift);
     VH_HIP(hipGetLastError());
@@ -131,7 +130,6 @@ extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float 
     if (frame_stride < capacity || bin_stride < batch * frame_stride || (d_packets && packet_frame_stride < dense))
         return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
     DeviceGuard guard(c->device);
-    const int npix = c->fp.width * c->fp.height;
     prepare_bins_kernel<<<grid_for((size_t)num_shards * batch, 256), 256, 0, c->stream>>>(
         reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, batch, frame_stride);
     for (int b0 = 0; b0 < batch; b0 += kGenBatch) {
@@ -146,7 +144,7 @@ extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float 
             std::memcpy(fr.Tinv[j], c->fp.Tinv, sizeof fr.Tinv[j]);
             fr.verts[j] = reinterpret_cast<const float4 *>(d_verts[b0 + j]);
         }
-        generate_keys_batch_kernel<<<dim3((unsigned)grid_for(npix, kGenThreads), (unsigned)n), kGenThreads, 0, c->stream>>>(
+        generate_keys_batch_kernel<<<dim3((unsigned)grid_for(host_num_tiles(c), kGenTiles), (unsigned)n), kGenThreads, 0, c->stream>>>(
             c->fp, fr, num_shards, reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
             frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
             camera_id << kRankCameraShift);
@@ -190,7 +188,7 @@ extern "C" int vh_generate_keys_depth_batch(vh_context *c, int32_t batch, const 
             std::memcpy(fr.Tinv[j], c->fp.Tinv, sizeof fr.Tinv[j]);
             fr.depth[j] = d_depth[b0 + j];
         }
-        generate_keys_sensor_batch_kernel<<<dim3((unsigned)grid_for(npix, kGenThreads), (unsigned)n), kGenThreads, 0,
+        generate_keys_sensor_batch_kernel<<<dim3((unsigned)grid_for(host_num_tiles(c), kGenTiles), (unsigned)n), kGenThreads, 0,
                                             c->stream>>>(
             c->fp, fr, num_shards, reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
             frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
@@ -254,6 +252,10 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
         packet_stride < (size_t)batch * packet_frame_stride)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
     DeviceGuard guard(c->device);
+    {
+        const int rc = ensure_candidates(c, (size_t)num_bins * (size_t)(capacity - 1));
+        if (rc != VH_OK) return rc;
+    }
     uint32_t parts = (uint32_t)grid_for((size_t)capacity, 256 * 4);
     if (parts < 1) parts = 1;
     const uint32_t scanBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
@@ -293,6 +295,10 @@ extern "C" int vh_insert_bins(vh_context *c, const int32_t *d_bins, int32_t num_
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     if (c->fp.epoch == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
     DeviceGuard guard(c->device);
+    {
+        const int rc = ensure_candidates(c, (size_t)num_bins * (size_t)(capacity - 1));
+        if (rc != VH_OK) return rc;
+    }
     int gx = grid_for((size_t)capacity, 256 * 4);
     if (gx < 1) gx = 1;
     int rc = launch(c, kPhaseClaim, claim_bins_kernel, dim3(gx, num_bins), dim3(256), c->fp, c->dp,

@@ -40,6 +40,7 @@ enum Counter : int {
     kGcFreed = 15,         // blocks on its freed list
     kFreedTotal = 16,      // blocks returned to the heap since creation
     kLastFreed = 17,       // ... by the last vh_delete_blocks / vh_garbage_collect
+    kCandOverflow = 18,    // contenders dropped because the candidate list was full (never cleared)
     kNumCounters = 24
 };
 
@@ -76,7 +77,6 @@ struct DevPtrs {
     uint32_t *compactMask;    // multi-camera frames: cameras that see compact entry i
     uint32_t *bucketBits;     // one bit per owned bucket: holds at least one entry
     uint32_t *macroBits;      // raycast: one bit per hashed 4x4x4-block macro cell that holds a block
-    unsigned long long *allocMask;   // fused frame: one bit per entry "allocated", rewritten by every walk
 };
 
 // camera packet of the sharded path: 16 floats pose, 16 floats inverse, W*H camera-z plane
@@ -180,6 +180,8 @@ __device__ __forceinline__ bool block_in_frustum(const FrameParams &fp, int bx, 
 }
 
 // Contender ranks are 32 bits: camera (5) | launch rank of the pixel (21) | band sample (6).
+// A pixel has at most 63 band samples (k <= 62), so the all-ones rank never occurs and a claim
+// word can never equal consumed_word() of its epoch.
 constexpr int kMaxBandSamples = 64;
 constexpr uint32_t kRankSampleBits = 6, kRankCameraShift = 27;
 

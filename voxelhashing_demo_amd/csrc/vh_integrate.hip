@@ -86,14 +86,14 @@ __device__ __forceinline__ void integrate_block(const FrameParams &fp, const Dev
     if (u0 || u1) *cell = v;
 }
 
-__device__ __forceinline__ void integrate_block(const FrameParams &fp, const DevPtrs &dp, const VoxelEntry &e,
-                                                const float4 *__restrict__ verts)
+// DepthPlane over the .z of a float4 vertex map
+__host__ __device__ __forceinline__ DepthPlane vertex_depth(const float4 *__restrict__ verts)
 {
-    integrate_block(fp, dp, e, DepthPlane{reinterpret_cast<const float *>(verts) + 2, 4});   // &verts[0].z
+    return DepthPlane{reinterpret_cast<const float *>(verts) + 2, 4};   // &verts[0].z
 }
 
-__global__ __launch_bounds__(256) void integrate_kernel(const FrameParams fp, const DevPtrs dp,
-                                                        const float4 *__restrict__ verts)
+template <class Depth>
+__global__ __launch_bounds__(256) void integrate_kernel(const FrameParams fp, const DevPtrs dp, const Depth verts)
 {
     const int count = dp.counters[kCompactCount];
     for (int b = blockIdx.x; b < count; b += gridDim.x) integrate_block(fp, dp, dp.compact[b], verts);

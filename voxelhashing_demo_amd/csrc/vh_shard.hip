@@ -174,8 +174,8 @@ __global__ __launch_bounds__(256) void frame_multi_commit_integrate_kernel(const
     __shared__ VoxelEntry newEntry;
     __shared__ uint32_t newMask;
     __shared__ int inserted;
-    int n = dp.counters[kFusedCand + parity];
-    if ((uint32_t)n > dp.candCapacity) n = (int)dp.candCapacity;
+    const int demanded = dp.counters[kFusedCand + parity];
+    const int n = min(demanded, (int)dp.candCapacity);
     // only the workgroups that have a candidate to serve take part in the ticket (a release fence and
     // a returning atomic on one word per workgroup: 128 of them cost 0.8 us of a steady-state frame
     // that has a few dozen candidates)
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void frame_multi_commit_integrate_kernel(const
         const int ticket = atomicAdd(dp.counters + kCommitTicket, 1);
         if (ticket == workers - 1) {
             dp.counters[kCompactCount] = scanCount + atomicAdd(dp.counters + kNewCount + parity, 0);
-            dp.counters[kLastCandidates] = n;
+            dp.counters[kLastCandidates] = demanded;
             dp.counters[kScanCount + (parity ^ 1)] = 0;
             dp.counters[kNewCount + (parity ^ 1)] = 0;
             dp.counters[kFusedCand + (parity ^ 1)] = 0;

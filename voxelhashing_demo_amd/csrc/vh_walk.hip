@@ -7,30 +7,24 @@ namespace vh {
 // ---------------------------------------------------------------------------
 // flattenIntoBuffer
 // ---------------------------------------------------------------------------
-// Only `ptr` decides whether an entry is live, and all but a few thousand of
-// the millions of entries are free.  Two ways to stream the ptr dwords:
-//   kWalkStrided  every lane reads just the ptr dword of its entries (stride 20 B: a
-//                 wave instruction covers 1280 contiguous bytes, every fetched line
-//                 is consumed across the loads in flight);
-//   kWalkWide     every lane reads 16-byte chunks, a wave instruction 1 KiB, the
-//                 best-coalesced shape there is.  20-byte records repeat every 5
-//                 chunks (80 B = 4 entries), so chunk c holds the ptr of entry
-//                 (4c + d - 3) / 5 in dword d = 3,-,0,1,2 for c mod 5 = 0..4 and no
-//                 staging through LDS is needed to find it.
-// The rare live entries are re-read in full and frustum-tested; slots in the compact
-// list are taken with one atomic per wave (wave scan of the per-lane hit counts).  The
-// reference also clears the whole compact table first (VoxelUtils.cu:757-758, its own
-// TODO calls it redundant); that pass is dropped.
+// Only `ptr` decides whether an entry is live, and all but a few thousand of the millions of
+// entries are free.  Every lane reads just the ptr dword of its entries (stride 20 B: a wave
+// instruction covers 1280 contiguous bytes, every fetched line is consumed across the loads in
+// flight).  The rare live entries are re-read in full and frustum-tested; slots in the compact
+// list are taken with one atomic per wave instruction that has a hit (ballot + popcount).  The
+// reference also clears the whole compact table first (VoxelUtils.cu:757-758, its own TODO calls
+// it redundant); that pass is dropped.
+// Measured and removed in round 2 (profiles/r01_*): non-temporal ptr loads (+7 %),
+// 16-byte-chunk loads with the ptr picked out of the chunk (+10 %), a per-lane hit count with one
+// wave scan (+3 %), and a "mask" form that stored allocation ballots for a second launch to
+// consume (launch 1 -0.4 us, launch 2 +8.5 us).
 constexpr int kFlattenThreads = 256;
 #ifndef VH_ENTRIES_PER_LANE
 #define VH_ENTRIES_PER_LANE 8
 #endif
 constexpr int kEntriesPerLane = VH_ENTRIES_PER_LANE;   // tuning knob (make EXTRA=-DVH_ENTRIES_PER_LANE=n)
-constexpr int kChunksPerLane = kEntriesPerLane;
-enum WalkKind : int {
-    kWalkStridedNT = 0, kWalkStrided = 1, kWalkWide = 2, kWalkStridedBallot = 3, kWalkIndexed = 4, kWalkPersistent = 5,
-    kWalkMask = 6      // fused frame only: launch 1 stores allocation masks, launch 2 consumes them
-};
+// option "flatten_variant" (values kept from round 1)
+enum WalkKind : int { kWalkStridedBallot = 3, kWalkIndexed = 4, kWalkPersistent = 5 };
 
 // First compact slot for this lane's `myCount` hits (one atomicAdd per wave that has any).
 __device__ __forceinline__ int reserve_compact_slots(const DevPtrs &dp, int counter, int myCount)
@@ -47,12 +41,6 @@ __device__ __forceinline__ int reserve_compact_slots(const DevPtrs &dp, int coun
     if (lane == kWave - 1) base = atomicAdd(dp.counters + counter, incl);
     base = __shfl(base, kWave - 1);
     return base + incl - myCount;
-}
-
-__device__ __forceinline__ bool entry_visible(const FrameParams &fp, const DevPtrs &dp, uint32_t e)
-{
-    const VoxelEntry ent = dp.table[e];
-    return block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);        // VoxelUtils.cu:732
 }
 
 // strided walk with one ballot + atomic per unrolled entry slot (hits are rare on small scenes)
@@ -170,64 +158,12 @@ template <int kKind>
 __device__ __forceinline__ void flatten_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
                                              uint32_t tileIndex, int counter, uint32_t walkBlocks)
 {
-    if constexpr (kKind == kWalkStridedBallot) {
-        flatten_tile_ballot(fp, dp, numEntries, tileIndex, counter);
-        return;
-    }
-    if constexpr (kKind == kWalkPersistent) {
+    if constexpr (kKind == kWalkPersistent)
         flatten_tiles_persistent(fp, dp, numEntries, tileIndex, walkBlocks, counter);
-        return;
-    }
-    if constexpr (kKind == kWalkIndexed) {
+    else if constexpr (kKind == kWalkIndexed)
         flatten_index_tile(fp, dp, tileIndex, counter);
-        return;
-    }
-    uint32_t ent[kEntriesPerLane];          // entry index of each candidate, or ~0u
-    uint32_t hits = 0;                      // bit j: entry j is live and in the frustum
-    if constexpr (kKind == kWalkWide) {
-        static_assert(kChunksPerLane == kEntriesPerLane, "one candidate entry per chunk");
-        const uint32_t numChunks = (uint32_t)(((uint64_t)numEntries * 20u + 15u) / 16u);
-        const uint32_t base = tileIndex * (kFlattenThreads * kChunksPerLane);
-        const uint4 *chunks = reinterpret_cast<const uint4 *>(dp.table);
-        uint4 v[kChunksPerLane];
-#pragma unroll
-        for (int j = 0; j < kChunksPerLane; ++j) {
-            const uint32_t c = base + j * kFlattenThreads + threadIdx.x;
-            v[j] = (c < numChunks) ? chunks[c] : make_uint4(~0u, ~0u, ~0u, ~0u);
-        }
-#pragma unroll
-        for (int j = 0; j < kChunksPerLane; ++j) {
-            const uint32_t c = base + j * kFlattenThreads + threadIdx.x;
-            const uint32_t m = c % 5u;
-            const uint32_t d = (m == 0u) ? 3u : m - 2u;                 // m == 1: no ptr in this chunk
-            const uint32_t word = (d == 0u) ? v[j].x : (d == 1u) ? v[j].y : (d == 2u) ? v[j].z : v[j].w;
-            const uint32_t e = (4u * c + d - 3u) / 5u;
-            const bool live = (m != 1u) && (word != (uint32_t)VH_FREE_BLOCK) && (e < numEntries);
-            ent[j] = live ? e : ~0u;
-        }
-    } else {
-        const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
-        const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
-        int32_t ptrs[kEntriesPerLane];
-#pragma unroll
-        for (int j = 0; j < kEntriesPerLane; ++j) {
-            const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
-            const int32_t *w = words + (size_t)e * kEntryDwords + 3;
-            if (e >= numEntries) ptrs[j] = VH_FREE_BLOCK;
-            else ptrs[j] = (kKind == kWalkStridedNT) ? __builtin_nontemporal_load(w) : *w;
-        }
-#pragma unroll
-        for (int j = 0; j < kEntriesPerLane; ++j)
-            ent[j] = (ptrs[j] != VH_FREE_BLOCK) ? tile + j * kFlattenThreads + threadIdx.x : ~0u;
-    }
-#pragma unroll
-    for (int j = 0; j < kEntriesPerLane; ++j)
-        if (ent[j] != ~0u && entry_visible(fp, dp, ent[j])) hits |= 1u << j;
-    int slot = reserve_compact_slots(dp, counter, __popc(hits));
-    if (slot < 0) return;
-#pragma unroll
-    for (int j = 0; j < kEntriesPerLane; ++j)
-        if ((hits >> j) & 1u) dp.compact[slot++] = dp.table[ent[j]];
+    else
+        flatten_tile_ballot(fp, dp, numEntries, tileIndex, counter);
 }
 
 template <int kKind>

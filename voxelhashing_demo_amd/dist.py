@@ -14,8 +14,8 @@ from every camera enters the table together.
        order, then launch order, decides who wins a bucket), one walk over the shard
        for all cameras, TSDF update of every visible block in camera order
 
-The per-rank logic (`sharded_step`) only talks to a *backend* (the HIP shard, or the
-CPU oracle shard in tests) and a *transport* (torch.distributed, or an in-process
+The per-rank logic (`sharded_step`) only talks to a *backend* (the HIP shard; tests plug in a
+CPU oracle shard with the same interface, tests/oracle_shards.py) and a *transport* (torch.distributed, or an in-process
 loop-back that plays all ranks in one process).  torch is transport and buffer owner only.
 """
 from __future__ import annotations
@@ -267,52 +267,6 @@ class HipShard:
         return self._view_send, self._view_counts
 
 
-class OracleShard:
-    """The same interface on the CPU oracle (tests only; the buffers are CPU tensors)."""
-
-    def __init__(self, oracle_module, params, width, height, semantics, plan: ShardPlan, rank: int, capacity: int,
-                 batch: int = 1):
-        import torch
-        self.plan, self.rank, self.capacity, self.batch = plan, rank, capacity, batch
-        self.table = oracle_module.OracleTable(params, width, height, semantics, bucket_range=plan.bucket_range(rank))
-        self.packet_floats = P = 32 + width * height
-        R, B = plan.world, batch
-        self.bins_send = torch.zeros((R, B, capacity, 4), dtype=torch.int32)
-        self.bins_recv = torch.zeros((R, B, capacity, 4), dtype=torch.int32)
-        self.packet = torch.zeros((B, P), dtype=torch.float32)
-        self.packets = torch.zeros((R, B, P), dtype=torch.float32)
-
-    def generate(self, b: int, pose, verts):
-        import torch
-        self.table.set_pose(pose)
-        bins, packet = self.table.generate_keys(np.asarray(verts), self.rank, self.plan.world, self.capacity)
-        self.bins_send[:, b] = torch.from_numpy(bins)
-        self.packet[b] = torch.from_numpy(packet)
-
-    def apply(self, b: int):
-        self.table.reset_mutexes()
-        self.table.insert_bins(self.bins_recv[:, b].contiguous().numpy())
-        self.table.integrate_packets(self.packets[:, b].contiguous().numpy())
-
-    def generate_all(self, poses, verts_list, depth_list=None):     # the oracle always ships float planes
-        for b in range(self.batch):
-            self.generate(b, poses[b], verts_list[b])
-
-    def apply_all(self):
-        for b in range(self.batch):
-            self.apply(b)
-
-    def export_views(self, poses, capacity: int, t_min: float = 0.1, t_max: float = 5.0):
-        import torch
-        recs, counts = [], []
-        for pose in poses:
-            r, n = self.table.export_view(pose, capacity, t_min, t_max)
-            recs.append(r)
-            counts.append(n)
-        packed = np.concatenate(recs) if recs else np.zeros((0, VIEW_RECORD_BYTES), np.uint8)
-        return torch.from_numpy(packed), torch.tensor(counts, dtype=torch.int32)
-
-
 # ----------------------------------------------------------------------------
 # raycast over shards (SURVEY.md 8(e)): a ray samples blocks of every shard, so the rank that
 # renders a view gathers the blocks the view can touch and raycasts a private view table.
@@ -351,21 +305,6 @@ class HipViewTable:
     def render(self, count: int, pose, t_min: float = 0.1, t_max: float = 5.0):
         self.table.import_view(self.recv, count)
         return self.table.raycast(pose, self.depth, t_min, t_max)
-
-
-class OracleViewTable:
-    """The same on the CPU oracle (tests only)."""
-
-    def __init__(self, oracle_module, params, width, height, semantics, world: int = 1, capacity: int = 0):
-        import torch
-        self.table = oracle_module.OracleTable(_view_params(params), width, height, semantics)
-        self.recv = torch.zeros((max(1, world * capacity), VIEW_RECORD_BYTES), dtype=torch.uint8)
-
-    def render(self, count: int, pose, t_min: float = 0.1, t_max: float = 5.0):
-        import torch
-        dropped = self.table.import_view(self.recv[:count].numpy())
-        assert dropped == 0
-        return torch.from_numpy(self.table.raycast(pose, t_min, t_max))
 
 
 def _clip_counts(counts, capacity):
