@@ -1,19 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the voxel-hashing TSDF path on MI355X (BASELINE.json metric).
 
-A step = one 640x480 depth frame taken through SDF_Hashtable::integrate
-(lock epoch -> allocBlocks -> flattenIntoBuffer -> integrateDepthMap) on the
-synthetic room of config C2; vertex maps and poses are resident in HBM before
-the timed region.  One JSON line on stdout (rank 0).
+A step = one depth frame taken through SDF_Hashtable::integrate (lock epoch -> allocBlocks ->
+flattenIntoBuffer -> integrateDepthMap) on the synthetic room of config C2 (640x480); vertex maps
+and poses are resident in HBM before the timed region.  One JSON line on stdout (rank 0).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C5] [--legs a,b,...]
+
+Timing: after a fixed run-in lap and W warm-up steps, windows of EXACTLY K steps are timed, each
+bracketed by a barrier and a device synchronisation on both sides; windows are repeated until at
+least MIN_TIMED_S seconds have been timed and `value` is K / (median window).  Everything else
+in the line (roofline, first lap, C3 sub-record, loaded integrate, raycast, sharded path with one
+rank, CPU baseline) is measured after that, outside the timed windows.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
 import json
+import math
 import os
+import statistics
 import sys
 import time
 
@@ -25,17 +32,29 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MIN_TIMED_S = 0.3            # windows of K steps are repeated until this much has been timed
+L3_BYTES = 256 << 20         # Infinity Cache (MI355X_MICROARCH.md)
 
 WORKLOADS = {
     # BASELINE.json configs[1]
-    "C2": dict(width=640, height=480, frames=500, buckets=1 << 20, blocks=1 << 18, voxel=0.02,
+    "C2": dict(width=640, height=480, frames=500, buckets=1 << 20, blocks=1 << 18, voxel=0.02, loop=500,
                desc="C2: synthetic 6x3x5 m room, 640x480 x 500-pose camera loop, 2^20 buckets x 5, "
                     "2^18 voxel blocks, voxel 0.02 m, PINHOLE semantics"),
-    # BASELINE.json configs[2] (HBM-bound stress); selectable with --workload C3
-    "C3": dict(width=1280, height=960, frames=200, buckets=1 << 22, blocks=1 << 21, voxel=0.005,
-               desc="C3: synthetic room, 1280x960, 2^22 buckets x 5, 2^21 voxel blocks, voxel 0.005 m, "
-                    "PINHOLE semantics (200 distinct frames of the 2000-pose path resident)"),
+    # C2 with truncation-band allocation (+-10 cm along the viewing ray): thousands of blocks updated per frame
+    "C2band": dict(width=640, height=480, frames=500, buckets=1 << 20, blocks=1 << 18, voxel=0.02, loop=500, band=0.1,
+                   desc="C2 with vh_set_alloc_band(0.1): every pixel demands the blocks within +-10 cm of its surface "
+                        "point, launch 2 (commit + integrateDepthMap) under load"),
+    # BASELINE.json configs[2] (HBM-bound stress)
+    "C3": dict(width=1280, height=960, frames=200, buckets=1 << 22, blocks=1 << 21, voxel=0.005, loop=2000,
+               desc="C3: synthetic room, 1280x960, 2^22 buckets x 5 (419 MB of VoxelEntry: beyond the 256 MiB "
+                    "Infinity Cache), 2^21 voxel blocks, voxel 0.005 m, PINHOLE semantics (the first 200 poses of "
+                    "the 2000-pose path resident)"),
+    # BASELINE.json configs[4], per-rank share when launched with --gpus 8 (one stream per GPU)
+    "C5": dict(width=1920, height=1080, frames=64, buckets=1 << 24, blocks=1 << 21, voxel=0.01, loop=500,
+               desc="C5: synthetic room, 1920x1080 streams, 2^24 buckets x 5 in all, 2^21 voxel blocks per rank, "
+                    "voxel 0.01 m, PINHOLE semantics"),
 }
+ALL_LEGS = ("first_lap", "index", "sensor", "raycast", "next", "loaded", "c3", "sharded", "cpu")
 
 
 def parse_args():
@@ -45,6 +64,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--frames", type=int, default=0, help="distinct resident frames (default: workload's)")
+    ap.add_argument("--legs", default="all",
+                    help="comma list of the extra legs to run after the timed windows: " + ",".join(ALL_LEGS) +
+                         " (all / none); the timed windows and the roofline of the dominant kernel always run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU sample (0 = auto, about 15 s)")
     ap.add_argument("--raycast-steps", type=int, default=50)
@@ -59,7 +81,14 @@ def parse_args():
                     help="sharded path: also time the raycast over the shards (always on with one rank)")
     ap.add_argument("--sharded", action="store_true",
                     help="force the bucket-range-sharded path (torch.distributed) even with one rank")
-    return ap.parse_args()
+    a = ap.parse_args()
+    legs = set(ALL_LEGS) if a.legs == "all" else set() if a.legs == "none" else set(a.legs.split(","))
+    if a.no_cpu_baseline:
+        legs.discard("cpu")
+    if a.raycast_steps <= 0:
+        legs.discard("raycast")
+    a.leg_set = legs
+    return a
 
 
 def baseline_metric(width, height):
@@ -69,8 +98,212 @@ def baseline_metric(width, height):
         try:
             return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
-            return "frames/s TSDF-integrated + raycast Mpix/s, 640\u00d7480, 1/2/4/8 MI355X"
+            return "frames/s TSDF-integrated + raycast Mpix/s, 640×480, 1/2/4/8 MI355X"
     return f"frames/s TSDF-integrated + raycast Mpix/s, {width}x{height}"
+
+
+def timed_windows(step, sync, steps, warmup, first=0, min_time=MIN_TIMED_S, max_windows=400):
+    """W untimed warm-up steps, then windows of exactly `steps` steps (sync on both sides) until
+    `min_time` seconds have been timed.  Returns (window times, next step index)."""
+    i = first
+    for _ in range(warmup):
+        step(i)
+        i += 1
+    sync()
+    times = []
+    while not times or (sum(times) < min_time and len(times) < max_windows):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(i)
+            i += 1
+        sync()
+        times.append(time.perf_counter() - t0)
+    return times, i
+
+
+def window_stats(times, steps):
+    med = statistics.median(times)
+    return dict(value=round(steps / med, 1), ms_per_step=round(1e3 * med / steps, 5), windows=len(times),
+                timed_s=round(sum(times), 4), window_min_ms=round(1e3 * min(times), 4),
+                window_max_ms=round(1e3 * max(times), 4))
+
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_latest.json:
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE), or None."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get(workload, {})
+    except Exception:
+        return None
+    for k, v in pmc.items():
+        if k.endswith("_hbm_bytes_per_launch") and k.startswith(kernel):
+            return v
+    return None
+
+
+def render_frames(synth, wl, nframes, dev, torch):
+    poses = synth.camera_loop(wl["loop"])[:nframes]
+    prims = synth.room_primitives()
+    verts = torch.empty((nframes, wl["height"], wl["width"], 4), dtype=torch.float32, device=dev)
+    for i in range(nframes):
+        verts[i] = synth.render_room_verts(poses[i], wl["width"], wl["height"], prims, device=dev)
+    torch.cuda.synchronize()
+    return poses, verts
+
+
+class Integrator:
+    """One table + resident frames; step(i) = vh_integrate of frame i mod nframes."""
+
+    def __init__(self, V, L, wl, poses, verts, local_rank, stream):
+        self.V, self.L, self.wl, self.stream = V, L, wl, stream
+        self.nframes = len(poses)
+        params = V.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
+        self.table = V.SDFHashtable(params, wl["width"], wl["height"], V.SEM_PINHOLE, device=local_rank, stream=stream)
+        if wl.get("band"):
+            self.table.set_alloc_band(wl["band"])
+        self.lib, self.h = self.table._lib, self.table._h
+        self.pose_keep = [np.ascontiguousarray(p.reshape(16)) for p in poses]
+        self.pose_ptrs = [p.ctypes.data_as(C.POINTER(C.c_float)) for p in self.pose_keep]
+        self.vert_ptrs = [verts[i].data_ptr() for i in range(self.nframes)]
+
+    def step(self, i):
+        k = i % self.nframes
+        rc = self.lib.vh_integrate(self.h, self.pose_ptrs[k], self.vert_ptrs[k], None)
+        if rc != 0:
+            self.L.check(rc, "vh_integrate")
+
+    def sync(self):
+        self.table.synchronize()
+
+    def kernel_profile(self, n, first):
+        """Per-dispatch HIP events on the path's own stream (untimed pass)."""
+        self.table.set_profiling(True)
+        for i in range(n):
+            self.step(first + i)
+        kt = self.table.kernel_times(reset=True)
+        self.table.set_profiling(False)
+        return kt
+
+    def dominant_roofline(self, workload, kt, occ):
+        wl = self.wl
+        Wd, Ht, n_entries = wl["width"], wl["height"], self.table.num_entries
+        launches = max(1, kt["launches"])
+        # dominant kernel of the fused frame: per-pixel claim phase || walk over the VoxelEntry array.
+        # Algorithmic bytes of one launch (SURVEY.md 8(d) terms): the vertex map read once by the claim
+        # half (16*W*H), one pass over the table (20*N), the compact entries written (20*occ) and one
+        # 100-byte bucket probe per distinct block key (keys ~ occ).
+        kname = "frame_scan_claim_kernel"
+        us = 1e3 * kt["frame_scan_claim_ms"] / launches
+        nbytes = 16 * Wd * Ht + 20 * n_entries + 20 * occ + 100 * occ
+        achieved = nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        table_bytes = 20 * n_entries
+        resident = table_bytes + 16 * Wd * Ht + 8212 * occ < L3_BYTES
+        # launch 2: per occupied block the 20-byte entry, 4 KiB of voxels read and 4 KiB written, plus the
+        # depth plane the update gathers from (counted once)
+        us2 = 1e3 * kt["frame_commit_integrate_ms"] / launches
+        bytes2 = occ * (20 + 4096 + 4096) + 4 * Wd * Ht
+        ach2 = bytes2 / (us2 * 1e-6) / 1e9 if us2 > 0 else 0.0
+        self.commit_roofline = dict(bound="hbm", kernel="frame_commit_integrate_kernel", achieved=round(ach2, 1),
+                                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach2 / HBM_PEAK_GBS, 4),
+                                    traffic=pmc_traffic(workload, "frame_commit_integrate_kernel"),
+                                    bytes_per_launch=bytes2, us_per_launch=round(us2, 2))
+        return dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(workload, kname),
+                    bytes_per_launch=nbytes, us_per_launch=round(us, 2),
+                    residency=("the %.0f MB table plus the frame's stream fit the 256 MiB Infinity Cache: in steady state "
+                               "the walk is served on-die, so this is a fraction of the HBM PEAK, not measured HBM "
+                               "traffic (FETCH_SIZE counts Infinity-Cache hits); the HBM-resident figure is "
+                               "configs.C3.roofline" % (table_bytes / 1e6)) if resident else
+                              ("the %.0f MB table exceeds the 256 MiB Infinity Cache: streamed from HBM every frame"
+                               % (table_bytes / 1e6)))
+
+    def close(self):
+        self.table.close()
+
+
+def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, want_profile=True, frames=None):
+    """Timed windows + dominant-kernel roofline of one single-GPU workload.  Returns (record, Integrator, poses, verts)."""
+    wl = WORKLOADS[name]
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    nframes = args.frames or wl["frames"]
+    poses, verts = frames if frames is not None else render_frames(synth, wl, nframes, dev, torch)
+    nframes = len(poses)
+    it = Integrator(V, L, wl, poses, verts, local_rank, stream)
+    lap = max(nframes, 500) if name.startswith("C2") else nframes
+    for i in range(lap):           # fixed, untimed run-in (one lap of the resident frames) before the W warm-up steps
+        it.step(i)
+    it.sync()
+    times, nxt = timed_windows(it.step, lambda: (it.sync(), torch.cuda.synchronize()), steps, warmup, first=lap)
+    rec = window_stats(times, steps)
+    counters = it.table.counters()
+    occ = counters["occupied"]
+    rec["occupied_blocks"], rec["allocated_blocks"] = occ, counters["allocated_total"]
+    if want_profile and args.profile_steps > 0:
+        kt = it.kernel_profile(args.profile_steps, nxt)
+        rec["roofline"] = it.dominant_roofline(name, kt, occ)
+        rec["roofline_commit_integrate"] = it.commit_roofline
+        rec["kernels"] = {k[:-3] + "_us": round(1e3 * v / max(1, kt["launches"]), 2)
+                          for k, v in kt.items() if k.endswith("_ms") and v > 0 and k not in ("raycast_ms",)}
+    Wd, Ht, n_entries = wl["width"], wl["height"], it.table.num_entries
+    # algorithmic bytes of the whole frame (SURVEY.md 8(d) B_frame; no mutex memset in this build);
+    # distinct in-frustum block keys of a frame ~ occupied blocks (not counted on the device)
+    b_frame = 16 * Wd * Ht + 4 * Wd * Ht + 20 * n_entries + 20 * occ + occ * (20 + 4096 + 4096) + 100 * occ
+    rec["frame_algorithmic_bytes"] = b_frame
+    rec["frame_algorithmic_gbs"] = round(b_frame * rec["value"] / 1e9, 1)
+    rec["frame_frac_of_hbm_peak"] = round(b_frame * rec["value"] / 1e9 / HBM_PEAK_GBS, 4)
+    return rec, it, poses, verts
+
+
+def cpu_baseline_leg(args, name, poses, verts):
+    """The oracle (kind "port") on this box's host cores over a bounded sample of the same frame
+    sequence: a few seconds on one thread, then the rest of ~15 s on the fastest thread count."""
+    import oracle as O
+    wl = WORKLOADS[name]
+    Wd, Ht, nframes = wl["width"], wl["height"], len(poses)
+    op = O.default_params(numBuckets=wl["buckets"], numVoxelBlocks=min(wl["blocks"], 1 << 18), voxelSize=wl["voxel"])
+    ot = O.OracleTable(op, Wd, Ht, O.SEM_PINHOLE)
+    budget_s, nmax = 15.0, args.cpu_frames or 10 ** 9
+    done, spent, one_done, one_spent = 0, 0.0, 0, 0.0
+    while one_done < nmax and one_spent < 3.0 and one_done < 5000:
+        k = one_done % nframes
+        v = verts[k].cpu().numpy()
+        c0 = time.perf_counter()
+        ot.integrate(poses[k], v)
+        one_spent += time.perf_counter() - c0
+        one_done += 1
+    # thread count: the fastest of a short calibration (on the pool's 2 x 64-core hosts the rate
+    # peaks at 16 threads and falls off beyond; the container's CPU share is not the 256 logical
+    # cores it sees)
+    threads, best, cal = 1, one_done / one_spent, []
+    for th in (4, 8, 16, 32, 64):
+        if th > (os.cpu_count() or 1):
+            break
+        c0, n = time.perf_counter(), 0
+        while time.perf_counter() - c0 < 0.4:
+            k = (one_done + n) % nframes
+            ot.integrate_mt(poses[k], verts[k].cpu().numpy(), th)
+            n += 1
+        rate = n / (time.perf_counter() - c0)         # includes the device->host copy: only a ranking
+        cal.append((th, round(rate, 1)))
+        if rate > best:
+            threads, best = th, rate
+    while threads > 1 and done < nmax and (args.cpu_frames or spent < budget_s - one_spent) and done < 20000:
+        k = (one_done + done) % nframes
+        v = verts[k].cpu().numpy()
+        c0 = time.perf_counter()
+        ot.integrate_mt(poses[k], v, threads)
+        spent += time.perf_counter() - c0
+        done += 1
+    if threads == 1:
+        done, spent = one_done, one_spent
+    ot.close()
+    return dict(value=round(done / spent, 3), unit="frames/s", cores=threads, kind="port",
+                one_thread_frames_per_s=round(one_done / one_spent, 3), thread_calibration=cal,
+                sample=f"{one_done} frames on 1 thread, then {done} frames on {threads} threads (fastest of the "
+                       f"calibration) of the same {name} sequence, oracle/vh_oracle.c "
+                       f"(gcc -O2 -ffp-contract=off -fopenmp), {os.cpu_count()} logical host cores")
 
 
 def main():
@@ -91,207 +324,263 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
+    legs = args.leg_set
     if world > 1 or args.sharded:
-        if "MASTER_ADDR" not in os.environ:
-            import socket
-            with socket.socket() as sk:              # direct (not torchrun) launch with --sharded: any free port
-                sk.bind(("127.0.0.1", 0))
-                port = sk.getsockname()[1]
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
-        # one node by contract: keep RCCL's bootstrap and the c10d store on the loop-back interface
-        # (the container's hostname may not resolve), and surface a stuck collective in minutes
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        import datetime
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
-                                timeout=datetime.timedelta(seconds=300))
         from voxelhashing_demo_amd import dist as vdist
-        args.metric_name = baseline_metric(WORKLOADS[args.workload]["width"], WORKLOADS[args.workload]["height"])
-        return vdist.bench_sharded(args, WORKLOADS[args.workload], rank, world, local_rank)
-
-    wl = WORKLOADS[args.workload]
-    Wd, Ht = wl["width"], wl["height"]
-    nframes = args.frames or wl["frames"]
-    dev = torch.device("cuda", local_rank)
-    stream = torch.cuda.Stream(device=dev)
-
-    # ---- inputs: rendered on the GPU, resident before timing ----
-    poses = synth.camera_loop(wl["frames"])[:nframes]
-    prims = synth.room_primitives()
-    verts = torch.empty((nframes, Ht, Wd, 4), dtype=torch.float32, device=dev)
-    for i in range(nframes):
-        verts[i] = synth.render_room_verts(poses[i], Wd, Ht, prims, device=dev)
-    torch.cuda.synchronize()
-
-    params = V.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
-    table = V.SDFHashtable(params, Wd, Ht, V.SEM_PINHOLE, device=local_rank, stream=stream)
-    lib, h = table._lib, table._h
-    pose_ptrs = [np.ascontiguousarray(p.reshape(16)).ctypes.data_as(C.POINTER(C.c_float)) for p in poses]
-    pose_keep = [np.ascontiguousarray(p.reshape(16)) for p in poses]
-    pose_ptrs = [p.ctypes.data_as(C.POINTER(C.c_float)) for p in pose_keep]
-    vert_ptrs = [verts[i].data_ptr() for i in range(nframes)]
-
-    def step(i):
-        k = i % nframes
-        rc = lib.vh_integrate(h, pose_ptrs[k], vert_ptrs[k], None)
-        if rc != 0:
-            L.check(rc, "vh_integrate")
+        init_dist(dist, torch, local_rank)
+        wl = WORKLOADS[args.workload]
+        args.metric_name = baseline_metric(wl["width"], wl["height"])
+        out = vdist.bench_sharded(args, wl, args.workload, rank, world, local_rank)
+        if rank == 0:
+            if "cpu" in legs:       # the reported CPU baseline: one camera's frames of the same workload, rank 0's host
+                poses, verts = render_frames(synth, wl, min(32, wl["frames"]), torch.device("cuda", local_rank), torch)
+                out["cpu_baseline"] = cpu_baseline_leg(args, args.workload, poses, verts)
+            print(json.dumps(out), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     # A full collection of the Python garbage collector walks every object torch has created (~10^6):
-    # 30-50 ms, i.e. longer than the whole timed region.  Existing objects are moved out of its reach
-    # and it stays off while the clock runs (the loop allocates only small short-lived objects).
+    # 30-50 ms, i.e. longer than a timed window.  Existing objects are moved out of its reach
+    # and it stays off while the clock runs (the loops allocate only small short-lived objects).
     import gc
     gc.collect()
     gc.freeze()
     gc.disable()
-    for i in range(500):           # fixed, untimed run-in (one lap of the loop) before the W warm-up steps
-        step(i)
-    table.synchronize()
-    for i in range(args.warmup):
-        step(i)
-    table.synchronize()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    table.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    fps = args.steps / elapsed
-    counters = table.counters()
 
-    # ---- per-kernel durations: HIP events on the path's own stream ----
-    nprof = args.profile_steps
-    table.set_profiling(True)
-    occ_sum = 0
-    for i in range(nprof):
-        step(args.warmup + args.steps + i)
-    kt = table.kernel_times(reset=True)
-    table.set_profiling(False)
-    occ = table.counters()["occupied"]
-    n_entries = table.num_entries
-    fused = kt["frame_scan_claim_ms"] > 0
-    if fused:
-        # dominant kernel of the fused frame: per-pixel claim phase || walk over the VoxelEntry
-        # array.  Algorithmic bytes of one launch (SURVEY.md 8(d) terms): the vertex map read once
-        # by the claim half (16*W*H), one pass over the table (20*N), the compact entries written
-        # (20*occ) and one 100-byte bucket probe per distinct block key (keys ~ occ).
-        kname = "frame_scan_claim_kernel"
-        dom_us = 1e3 * kt["frame_scan_claim_ms"] / max(1, kt["launches"])
-        dom_bytes = 16 * Wd * Ht + 20 * n_entries + 20 * occ + 100 * occ
-    else:
-        # algorithmic bytes of one flatten launch: one pass over the VoxelEntry array + the
-        # compact entries written
-        kname = "flatten_kernel"
-        dom_us = 1e3 * kt["flatten_ms"] / max(1, kt["launches"])
-        dom_bytes = 20 * n_entries + 20 * occ
-    achieved = dom_bytes / (dom_us * 1e-6) / 1e9
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc_file):
-        try:
-            pmc = json.load(open(pmc_file)).get(args.workload, {})
-            # template argument 3 = the default ballot walk (WalkKind in vh_kernels.hip)
-            traffic = pmc.get(kname + "<3>_hbm_bytes_per_launch", pmc.get(kname + "_hbm_bytes_per_launch"))
-        except Exception:
-            traffic = None
-    roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
-                    unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    bytes_per_launch=dom_bytes, us_per_launch=round(dom_us, 2))
-    kernels_us = {k[:-3] + "_us": round(1e3 * v / max(1, kt["launches"]), 2)
-                  for k, v in kt.items() if k.endswith("_ms") and k != "raycast_ms" and v > 0}
-    # algorithmic bytes of the whole frame (SURVEY.md 8(d) B_frame; no mutex memset in this build)
-    keys = occ   # distinct in-frustum block keys of a frame ~ occupied blocks (not counted on the device)
-    b_frame = 16 * Wd * Ht + 4 * Wd * Ht + 20 * n_entries + 20 * occ + occ * (20 + 4096 + 4096) + 100 * keys
-    frame_gbs = b_frame * fps / 1e9
+    name = args.workload
+    wl = WORKLOADS[name]
+    Wd, Ht = wl["width"], wl["height"]
+    main_rec, it, poses, verts = measure_workload(args, V, L, synth, torch, name, local_rank, args.steps, args.warmup)
+    table, lib, h, nframes = it.table, it.lib, it.h, it.nframes
+    pose_ptrs = it.pose_ptrs
+    dev = torch.device("cuda", local_rank)
+    stream = it.stream
+    occ = main_rec["occupied_blocks"]
+    sync = lambda: (table.synchronize(), torch.cuda.synchronize())        # noqa: E731
+    extra = {}
+
+    # ---- first lap: a FRESH table over the resident frames in order -- the frames in which blocks are
+    # actually inserted (commit phase, heap pops, new-block integration); the steady-state `value`
+    # above only revisits known blocks ----
+    if "first_lap" in legs:
+        fresh = Integrator(V, L, wl, poses, verts, local_rank, stream)
+        fresh.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nframes):
+            fresh.step(i)
+        fresh.sync()
+        lap_s = time.perf_counter() - t0
+        fc = fresh.table.counters()
+        extra["first_lap"] = dict(value=round(nframes / lap_s, 1), unit="frames/s", frames=nframes,
+                                  ms_per_step=round(1e3 * lap_s / nframes, 5), blocks_inserted=fc["allocated_total"],
+                                  note="fresh table, resident frames 0..n-1 once, in order: every block of the model is "
+                                       "inserted inside this window")
+        fresh.close()
 
     # ---- same workload with the opt-in occupancy-index walk (NOT the reference algorithm: the
     # flatten step reads the 1-bit-per-bucket index and only the non-empty buckets instead of
     # every VoxelEntry; reported separately, never as `value`) ----
-    table.set_option("flatten_variant", 4)
-    for i in range(args.warmup):
-        step(i)
-    table.synchronize()
-    t2 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    table.synchronize()
-    idx_elapsed = time.perf_counter() - t2
-    table.set_option("flatten_variant", 3)
-    index_variant = dict(value=round(args.steps / idx_elapsed, 1), unit="frames/s",
-                         ms_per_step=round(1e3 * idx_elapsed / args.steps, 5),
-                         flatten_bytes=wl["buckets"] // 8 + 100 * counters["allocated_total"],
-                         note="vh_set_option(flatten_variant=4): walk over the bucket-occupancy bitmap "
-                              "(numBuckets/8 bytes) + the non-empty buckets instead of the 20*N-byte table walk")
+    if "index" in legs:
+        table.set_option("flatten_variant", 4)
+        t_idx, _ = timed_windows(it.step, sync, args.steps, args.warmup)
+        table.set_option("flatten_variant", 3)
+        extra["occupancy_index_variant"] = dict(
+            window_stats(t_idx, args.steps), unit="frames/s",
+            flatten_bytes=wl["buckets"] // 8 + 100 * main_rec["allocated_blocks"],
+            note="vh_set_option(flatten_variant=4): walk over the bucket-occupancy bitmap (numBuckets/8 bytes) + "
+                 "the non-empty buckets instead of the 20*N-byte table walk")
 
     # ---- the same frames straight from uint16 sensor depth (vh_integrate_depth: preProcess's vertex
     # computation inside the claim phase, no vertex map in memory), against the two-call form
     # vh_preprocess + vh_integrate.  Extension of the boundary; reported separately. ----
     k_inv = np.linalg.inv(synth.K_matrix(Wd, Ht).astype(np.float64)).astype(np.float32)
-    nd = min(nframes, 250)
-    depth16 = torch.empty((nd, Ht, Wd), dtype=torch.uint16, device=dev)
-    for i in range(nd):
-        depth16[i] = (verts[i, :, :, 2] * 5000.0).round().clamp(0, 65535).to(torch.uint16)
     kin = np.ascontiguousarray(k_inv.reshape(9))
     kin_p = kin.ctypes.data_as(C.POINTER(C.c_float))
-    d_ptrs = [depth16[i].data_ptr() for i in range(nd)]
-    tmp_v, tmp_n = torch.empty_like(verts[0]), torch.empty_like(verts[0])
-    tv, tn, st = tmp_v.data_ptr(), tmp_n.data_ptr(), C.c_void_p(stream.cuda_stream)
-    torch.cuda.synchronize()       # the images were written on torch's default stream, the table reads them on its own
+    if "sensor" in legs:
+        nd = min(nframes, 250)
+        depth16 = torch.empty((nd, Ht, Wd), dtype=torch.uint16, device=dev)
+        for i in range(nd):
+            depth16[i] = (verts[i, :, :, 2] * 5000.0).round().clamp(0, 65535).to(torch.uint16)
+        d_ptrs = [depth16[i].data_ptr() for i in range(nd)]
+        tmp_v, tmp_n = torch.empty_like(verts[0]), torch.empty_like(verts[0])
+        tv, tn, st = tmp_v.data_ptr(), tmp_n.data_ptr(), C.c_void_p(stream.cuda_stream)
+        torch.cuda.synchronize()   # the images were written on torch's default stream, the table reads them on its own
 
-    def fused_depth(i):
-        lib.vh_integrate_depth(h, pose_ptrs[i % nd], d_ptrs[i % nd], kin_p)
+        def fused_depth(i):
+            lib.vh_integrate_depth(h, pose_ptrs[i % nd], d_ptrs[i % nd], kin_p)
 
-    def two_calls(i):
-        lib.vh_preprocess(d_ptrs[i % nd], kin_p, Wd, Ht, tv, tn, st)
-        lib.vh_integrate(h, pose_ptrs[i % nd], tv, None)
+        def two_calls(i):
+            lib.vh_preprocess(d_ptrs[i % nd], kin_p, Wd, Ht, tv, tn, st)
+            lib.vh_integrate(h, pose_ptrs[i % nd], tv, None)
 
-    sensor = {}
-    for name, fn in (("vh_integrate_depth", fused_depth), ("vh_preprocess + vh_integrate", two_calls)):
-        for i in range(args.warmup):
-            fn(i)
-        table.synchronize()
-        t3 = time.perf_counter()
-        for i in range(args.steps):
-            fn(args.warmup + i)
-        table.synchronize()
-        sensor[name] = round(args.steps / (time.perf_counter() - t3), 1)
-    sensor_depth = dict(frames_per_s=sensor, unit="frames/s",
-                        note="input: uint16 depth images (2 B/pixel); the fused call computes the vertices inside "
-                             "the claim phase and gathers depth from the image, bit-equal to the two-call form")
+        sensor = {}
+        for label, fn in (("vh_integrate_depth", fused_depth), ("vh_preprocess + vh_integrate", two_calls)):
+            t_s, _ = timed_windows(fn, sync, args.steps, args.warmup)
+            sensor[label] = window_stats(t_s, args.steps)["value"]
+        extra["sensor_depth_input"] = dict(
+            frames_per_s=sensor, unit="frames/s",
+            note="input: uint16 depth images (2 B/pixel); the fused call computes the vertices inside the claim "
+                 "phase and gathers depth from the image, bit-equal to the two-call form")
+        del depth16
 
-    # ---- raycast Mpix/s (second half of the metric) ----
+    # ---- raycast Mpix/s (second half of the metric): end to end and per-dispatch over the SAME poses ----
+    raycast_mpix = None
+    if "raycast" in legs:
+        depth = torch.empty((Ht, Wd), dtype=torch.float32, device=dev)
+        dptr = depth.data_ptr()
+        ray_poses = [(7 * i) % nframes for i in range(args.raycast_steps)]
+        torch.cuda.synchronize()
+        for k in ray_poses[:5]:
+            lib.vh_raycast(h, pose_ptrs[k], 0.1, 5.0, dptr)
+        sync()
+        t1 = time.perf_counter()
+        for k in ray_poses:
+            lib.vh_raycast(h, pose_ptrs[k], 0.1, 5.0, dptr)
+        sync()
+        ray_s = time.perf_counter() - t1
+        raycast_mpix = len(ray_poses) * Wd * Ht / ray_s / 1e6
+        table.set_profiling(True)
+        for k in ray_poses:
+            lib.vh_raycast(h, pose_ptrs[k], 0.1, 5.0, dptr)
+        kt_r = table.kernel_times(reset=True)
+        table.set_profiling(False)
+        raycast_us = 1e3 * kt_r["raycast_ms"] / max(1, kt_r["raycast_launches"])
+        # SURVEY.md 8(d) raycast work unit: every visible block and the output touched once
+        ray_bytes = (4096 + 20) * occ + 4 * Wd * Ht
+        rc = dict(mpix_per_s=round(raycast_mpix, 1), kernel_us=round(raycast_us, 2), poses=len(ray_poses),
+                  kernel_mpix_per_s=round(Wd * Ht / raycast_us, 1) if raycast_us > 0 else None,
+                  algorithmic_bytes=ray_bytes,
+                  achieved_gbs=round(ray_bytes / (raycast_us * 1e-6) / 1e9, 1) if raycast_us > 0 else None,
+                  note="kernel_us is the mean HIP-event duration over the same poses as the end-to-end loop")
+        rc["roofline"] = raycast_roofline(name, raycast_us, Wd, Ht)
+        extra["raycast"] = rc
+
+    # ---- loaded integrate: truncation-band allocation on (every pixel demands the blocks within
+    # +-10 cm of its surface point), so thousands of 8^3 blocks are updated per frame and launch 2
+    # (commit + integrateDepthMap) is measured under load: 20 B entry + 4 KiB read + 4 KiB written per block ----
+    if "loaded" in legs and name == "C2":
+        l_rec, l_it, _, _ = measure_workload(args, V, L, synth, torch, "C2band", local_rank, args.steps, args.warmup,
+                                             frames=(poses, verts))
+        l_rec["unit"], l_rec["workload"] = "frames/s", WORKLOADS["C2band"]["desc"]
+        l_rec["roofline"], l_rec["roofline_scan_claim"] = l_rec.pop("roofline_commit_integrate", None), l_rec.get("roofline")
+        extra["loaded_integrate"] = l_rec
+        l_it.close()
+
+    # ---- next rows ----
+    if "next" in legs:
+        extra["next_rows"] = next_rows_leg(V, synth, torch, it, verts, k_inv, stream, Wd, Ht)
+
+    # ---- C3 sub-record: the table that does NOT fit the Infinity Cache (true HBM streaming) ----
+    if "c3" in legs and name == "C2":
+        it.close()
+        it = None
+        del verts
+        torch.cuda.empty_cache()
+        c3_rec, c3_it, c3_poses, c3_verts = measure_workload(args, V, L, synth, torch, "C3", local_rank,
+                                                              max(50, min(args.steps, 200)), min(args.warmup, 20))
+        c3_rec["workload"] = WORKLOADS["C3"]["desc"]
+        c3_rec["unit"] = "frames/s"
+        extra["configs"] = {"C3": c3_rec}
+        c3_it.close()
+        del c3_verts
+        torch.cuda.empty_cache()
+        poses, verts = render_frames(synth, wl, min(nframes, 64), dev, torch)     # for the CPU sample below
+        nframes = len(poses)
+
+    # ---- the sharded path with ONE rank over RCCL: the code path the N > 1 lines run, so that the
+    # scaling curve's anchor and its points share a code path ----
+    if "sharded" in legs and name == "C2":
+        try:
+            if it is not None:
+                it.close()
+                it = None
+            from voxelhashing_demo_amd import dist as vdist
+            init_dist(dist, torch, local_rank)
+            sargs = argparse.Namespace(**vars(args))
+            sargs.steps, sargs.warmup = max(20, min(args.steps, 200) // max(1, args.batch)), 5
+            sargs.metric_name = baseline_metric(Wd, Ht)
+            extra["sharded_world1"] = vdist.bench_sharded(sargs, wl, name, 0, 1, local_rank)
+            dist.destroy_process_group()
+        except Exception as e:       # the main line must not be lost to a transport problem
+            extra["sharded_world1"] = dict(error=repr(e))
+
+    # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
+    cpu = cpu_baseline_leg(args, name, poses, verts) if "cpu" in legs else None
+
+    out = dict(
+        metric=baseline_metric(Wd, Ht),
+        value=main_rec["value"], unit="frames/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
+        ms_per_step=main_rec["ms_per_step"], higher_is_better=True, scaling="weak",
+        vs_baseline=None, dtype="f32", data="synthetic",
+        metric_note="value = frames/s TSDF-integrated (median window of K steps); the raycast half of the metric "
+                    "is raycast_mpix_per_s",
+        windows=main_rec["windows"], timed_s=main_rec["timed_s"],
+        window_min_ms=main_rec["window_min_ms"], window_max_ms=main_rec["window_max_ms"],
+        config=dict(workload=wl["desc"], resident_frames=it.nframes if it else nframes, semantics="pinhole",
+                    occupied_blocks=occ, allocated_blocks=main_rec["allocated_blocks"], keys_last_frame=occ),
+        roofline=main_rec.get("roofline"), cpu_baseline=cpu,
+        raycast_mpix_per_s=round(raycast_mpix, 1) if raycast_mpix else None,
+        kernels=main_rec.get("kernels"),
+        frame_algorithmic_bytes=main_rec["frame_algorithmic_bytes"],
+        frame_algorithmic_gbs=main_rec["frame_algorithmic_gbs"],
+        frame_frac_of_hbm_peak=main_rec["frame_frac_of_hbm_peak"],
+    )
+    out.update(extra)
+    print(json.dumps(out), flush=True)
+    if it is not None:
+        it.close()
+    torch.cuda.synchronize()
+
+
+def init_dist(dist, torch, local_rank):
+    if "MASTER_ADDR" not in os.environ:
+        import socket
+        with socket.socket() as sk:              # direct (not torchrun) launch: any free port
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    # one node by contract: keep RCCL's bootstrap and the c10d store on the loop-back interface
+    # (the container's hostname may not resolve), and surface a stuck collective in minutes
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    import datetime
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                            timeout=datetime.timedelta(seconds=300))
+
+
+def raycast_roofline(workload, kernel_us, Wd, Ht):
+    """The raycast is bound by VALU issue, not by bytes: instructions per wave come from
+    the committed rocprofv3 --pmc pass (profiles/pmc_latest.json: SQ_INSTS_VALU / SQ_WAVES of
+    raycast_kernel); the chip issues one VALU wave-instruction per SIMD per 2 cycles at most
+    (MI355X_MICROARCH.md: a wave64 VALU op takes 2 cycles on a SIMD-32): 256 CUs x 4 SIMDs x 2.4 GHz / 2."""
+    peak = 256 * 4 * 2.4e9 / 2 / 1e9                      # G wave-instructions / s
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get(workload + "_raycast", {})
+        valu_per_wave = pmc.get("raycast_kernel_valu_per_wave")
+    except Exception:
+        valu_per_wave = None
+    waves = math.ceil(Wd / 16) * math.ceil(Ht / 16) * 4
+    if not valu_per_wave or kernel_us <= 0:
+        return dict(bound="valu-issue", kernel="raycast_kernel", achieved=None, peak=round(peak, 1),
+                    unit="G wave-instr/s", frac=None, traffic=None, note="no VALU count in profiles/pmc_latest.json")
+    achieved = valu_per_wave * waves / (kernel_us * 1e-6) / 1e9
+    return dict(bound="valu-issue", kernel="raycast_kernel", achieved=round(achieved, 1), peak=round(peak, 1),
+                unit="G wave-instr/s", frac=round(achieved / peak, 4), traffic=None, valu_per_wave=valu_per_wave, waves=waves,
+                us_per_launch=round(kernel_us, 2))
+
+
+def next_rows_leg(V, synth, torch, it, verts, k_inv, stream, Wd, Ht):
+    from voxelhashing_demo_amd import tracking
+    table, lib, h, pose_ptrs, nframes = it.table, it.lib, it.h, it.pose_ptrs, it.nframes
+    dev = verts.device
     depth = torch.empty((Ht, Wd), dtype=torch.float32, device=dev)
     dptr = depth.data_ptr()
-    for i in range(5):
-        lib.vh_raycast(h, pose_ptrs[i % nframes], 0.1, 5.0, dptr)
-    table.synchronize()
-    t1 = time.perf_counter()
-    for i in range(args.raycast_steps):
-        lib.vh_raycast(h, pose_ptrs[(7 * i) % nframes], 0.1, 5.0, dptr)
-    table.synchronize()
-    ray_s = time.perf_counter() - t1
-    raycast_mpix = args.raycast_steps * Wd * Ht / ray_s / 1e6 if args.raycast_steps else None
-
-    # ---- kernel time of the raycast and of the next-row entry points (all timed regions are over) ----
-    table.set_profiling(True)
-    for i in range(5):
-        lib.vh_raycast(h, pose_ptrs[(7 * i) % nframes], 0.1, 5.0, dptr)
-    kt_r = table.kernel_times(reset=True)
-    raycast_us = 1e3 * kt_r["raycast_ms"] / max(1, kt_r["raycast_launches"])
-    # SURVEY.md 8(d) raycast work unit: every visible block and the output touched once
-    ray_bytes = (4096 + 20) * occ + 4 * Wd * Ht
-    raycast = dict(mpix_per_s=round(raycast_mpix, 1) if raycast_mpix else None, kernel_us=round(raycast_us, 2),
-                   kernel_mpix_per_s=round(Wd * Ht / raycast_us, 1) if raycast_us > 0 else None,
-                   algorithmic_bytes=ray_bytes,
-                   achieved_gbs=round(ray_bytes / (raycast_us * 1e-6) / 1e9, 1) if raycast_us > 0 else None,
-                   bound="valu issue (5.6k VALU instructions per wave against 66 memory reads, DESIGN.md 4.1): "
-                         "the byte rate is far below HBM by construction")
     # depth pre-processing (next #1): uint16 depth -> vertex + normal maps, one fused kernel
     depth_u16 = (verts[0, :, :, 2] * 5000.0).clamp(0, 65535).to(torch.uint16)
     pos_out, nrm_out = torch.empty_like(verts[0]), torch.empty_like(verts[0])
     torch.cuda.synchronize()
-    k_inv = np.linalg.inv(synth.K_matrix(Wd, Ht).astype(np.float64)).astype(np.float32)
     with torch.cuda.stream(stream):
         for i in range(3):
             V.preprocess(depth_u16, k_inv, pos_out, nrm_out, stream=stream)
@@ -303,7 +592,6 @@ def main():
         pre_us = 1e6 * (time.perf_counter() - t3) / 50
     pre_bytes = (2 + 16 + 16) * Wd * Ht
     # camera tracking (next #4): one fused ICP round (pairing + Jacobian + 27 sums) and a raycast target
-    from voxelhashing_demo_amd import tracking
     Kf = synth.K_matrix(Wd, Ht)
     trk = tracking.CameraTracking(Wd, Ht, Kf, stream=stream, flags=3)
     tgt_p, tgt_n = torch.empty_like(verts[0]), torch.empty_like(verts[0])
@@ -321,14 +609,10 @@ def main():
             trk.Align(verts[1], tgt_p, tgt_n)
         align_us = 1e6 * (time.perf_counter() - t5) / 5
     icp_bytes = 48 * Wd * Ht
-    # garbage collection (next #4) over the blocks the last frame saw; threshold 0 frees them all
-    step(0)
-    table.garbage_collect(0.0)
-    kt_g = table.kernel_times(reset=True)
-    gc_counters = table.counters()
-    table.set_profiling(False)
     # block silhouettes (row R1): front / back cube depth per pixel
-    sil_f, sil_b = torch.empty((Ht, Wd), dtype=torch.float32, device=dev), torch.empty((Ht, Wd), dtype=torch.float32, device=dev)
+    sil_f = torch.empty((Ht, Wd), dtype=torch.float32, device=dev)
+    sil_b = torch.empty((Ht, Wd), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
     for i in range(3):
         lib.vh_render_blocks(h, pose_ptrs[0], 0.1, 5.0, sil_f.data_ptr(), sil_b.data_ptr())
     table.synchronize()
@@ -337,14 +621,26 @@ def main():
         lib.vh_render_blocks(h, pose_ptrs[(7 * i) % nframes], 0.1, 5.0, sil_f.data_ptr(), sil_b.data_ptr())
     table.synchronize()
     sil_us = 1e6 * (time.perf_counter() - t6) / 20
-    next_rows = dict(
-        block_silhouettes=dict(us_per_call=round(sil_us, 1), covered_pixels=int((sil_f > 0).sum()),
+    table.set_profiling(True)
+    for i in range(20):
+        lib.vh_render_blocks(h, pose_ptrs[(7 * i) % nframes], 0.1, 5.0, sil_f.data_ptr(), sil_b.data_ptr())
+    kt_s = table.kernel_times(reset=True)
+    # garbage collection (next #4) over the blocks the last frame saw; threshold 0 frees them all
+    it.step(0)
+    table.garbage_collect(0.0)
+    kt_g = table.kernel_times(reset=True)
+    gc_counters = table.counters()
+    table.set_profiling(False)
+    out = dict(
+        block_silhouettes=dict(us_per_call=round(sil_us, 1), kernels_us=round(1e3 * kt_s["render_blocks_ms"] / 20, 1),
+                               covered_pixels=int((sil_f > 0).sum()),
                                note="vh_render_blocks (SDFRenderer::drawToFrontAndBack): exact ray/box test of every "
-                                    "allocated block's cube, 4 launches, host-timed"),
+                                    "allocated block's cube, host-timed per call and summed kernel time"),
         icp_round=dict(us_per_round=round(icp_us, 2), pairs=icp_sys[3], algorithmic_bytes=icp_bytes,
                        note="vh_icp_build_system against a raycast target, host-timed and synchronous "
                             "(the step API returns each round's 27 sums to the host)"),
-        icp_align=dict(us_per_align=round(align_us, 1), rounds=trk.iterations, us_per_round=round(align_us / max(1, trk.iterations), 2),
+        icp_align=dict(us_per_align=round(align_us, 1), rounds=trk.iterations,
+                       us_per_round=round(align_us / max(1, trk.iterations), 2),
                        note="vh_icp_align: all rounds queued at once, 6x6 solve + SE3 update on the device, "
                             "one copy and one synchronisation at the end"),
         preprocess=dict(us_per_frame=round(pre_us, 2), algorithmic_bytes=pre_bytes,
@@ -354,79 +650,8 @@ def main():
                              blocks_freed=gc_counters["last_freed"],
                              note="vh_garbage_collect(0): identify + sweep + release + finish, "
                                   "every block of the last frame freed (8 KiB of voxel traffic each)"))
-
-    # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
-    cpu = None
-    if not args.no_cpu_baseline:
-        import oracle as O
-        op = O.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
-        ot = O.OracleTable(op, Wd, Ht, O.SEM_PINHOLE)
-        # the same frame sequence on the host: a few seconds on one thread, then the rest of the budget
-        # on `threads` threads (OpenMP; identical results, tests/test_oracle_anchors.py)
-        budget_s, nmax = 15.0, args.cpu_frames or 10 ** 9
-        done, spent, one_done, one_spent = 0, 0.0, 0, 0.0
-        while one_done < nmax and one_spent < 3.0 and one_done < 5000:
-            k = one_done % nframes
-            v = verts[k].cpu().numpy()
-            c0 = time.perf_counter()
-            ot.integrate(poses[k], v)
-            one_spent += time.perf_counter() - c0
-            one_done += 1
-        # thread count: the fastest of a short calibration (on the pool's 2 x 64-core hosts the rate
-        # peaks at 16 threads -- 245 frames/s -- and falls off beyond; the container's CPU share
-        # is not the 256 logical cores it sees)
-        threads, best = 1, one_done / one_spent
-        cal = []
-        for th in (4, 8, 16, 32, 64):
-            if th > (os.cpu_count() or 1):
-                break
-            c0, n = time.perf_counter(), 0
-            while time.perf_counter() - c0 < 0.4:
-                k = (one_done + n) % nframes
-                ot.integrate_mt(poses[k], verts[k].cpu().numpy(), th)
-                n += 1
-            rate = n / (time.perf_counter() - c0)         # includes the device->host copy: only a ranking
-            cal.append((th, round(rate, 1)))
-            if rate > best:
-                threads, best = th, rate
-        while threads > 1 and done < nmax and (args.cpu_frames or spent < budget_s - one_spent) and done < 20000:
-            k = (one_done + done) % nframes
-            v = verts[k].cpu().numpy()
-            c0 = time.perf_counter()
-            ot.integrate_mt(poses[k], v, threads)
-            spent += time.perf_counter() - c0
-            done += 1
-        if threads == 1:
-            done, spent = one_done, one_spent
-        cpu = dict(value=round(done / spent, 3), unit="frames/s", cores=threads, kind="port",
-                   one_thread_frames_per_s=round(one_done / one_spent, 3),
-                   thread_calibration=cal,
-                   sample=f"{one_done} frames on 1 thread, then {done} frames on {threads} threads (fastest of the "
-                          f"calibration) of the same {args.workload} sequence, oracle/vh_oracle.c "
-                          f"(gcc -O2 -ffp-contract=off -fopenmp), {os.cpu_count()} logical host cores")
-        ot.close()
-
-    out = dict(
-        metric=baseline_metric(Wd, Ht),
-        value=round(fps, 1), unit="frames/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
-        ms_per_step=round(1e3 * elapsed / args.steps, 5), higher_is_better=True, scaling="weak",
-        vs_baseline=None, dtype="f32", data="synthetic",
-        metric_note="value = frames/s TSDF-integrated; the raycast half of the metric is raycast_mpix_per_s",
-        config=dict(workload=wl["desc"], resident_frames=nframes, semantics="pinhole",
-                    occupied_blocks=occ, allocated_blocks=counters["allocated_total"],
-                    keys_last_frame=keys),
-        roofline=roofline, cpu_baseline=cpu,
-        raycast_mpix_per_s=round(raycast_mpix, 1) if raycast_mpix else None,
-        raycast=raycast, next_rows=next_rows, sensor_depth_input=sensor_depth,
-        occupancy_index_variant=index_variant,
-        kernels=kernels_us,
-        frame_algorithmic_bytes=b_frame, frame_algorithmic_gbs=round(frame_gbs, 1),
-        frame_frac_of_hbm_peak=round(frame_gbs / HBM_PEAK_GBS, 4),
-    )
-    print(json.dumps(out), flush=True)
-    trk.close()            # contexts go while the torch stream they were bound to is still alive
-    table.close()
-    torch.cuda.synchronize()
+    trk.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -236,6 +236,9 @@ int vh_get_counters(vh_context *ctx, vh_counters *out);              /* synchron
 int vh_get_params(vh_context *ctx, HashTableParams *out);
 int vh_get_device_pointers(vh_context *ctx, PtrContainer *out);
 int vh_download(vh_context *ctx, int which, void *host_dst, size_t bytes);  /* synchronises */
+/* the same for `bytes` bytes starting `offset_bytes` into the buffer (one 4 KiB block of a
+ * multi-gigabyte volume: offset = 8 * entry.ptr) */
+int vh_download_range(vh_context *ctx, int which, size_t offset_bytes, void *host_dst, size_t bytes);
 
 /* test hook: evaluates the device scalar helpers on n points; writes 8 int32 per
  * point: block x,y,z, hash, blockInFrustum, project() x,y, float->int of .w */

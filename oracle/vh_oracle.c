@@ -245,6 +245,8 @@ void vho_default_params(vho_params *p)
 
 static void reset_entries(vho_entry *e, size_t n)   /* resetHashTableKernel, :151-158 */
 {
+    /* (threads only to spread the first touch of multi-gigabyte tables; the values are per-entry constants) */
+#pragma omp parallel for schedule(static) if (n > (1u << 20))
     for (size_t i = 0; i < n; ++i) {
         e[i].offset = 0;
         e[i].ptr = VHO_FREE_BLOCK;
@@ -690,6 +692,8 @@ void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max, f
     const int W = t->width, H = t->height;
     const float dt = t->p.voxelSize;
     const int nsteps = vho_float2int_rz((t_max - t_min) / dt) + 1;
+    /* rays are independent and only read the model: rows are spread over the host's threads */
+#pragma omp parallel for schedule(dynamic, 4)
     for (int v = 0; v < H; ++v)
     for (int u = 0; u < W; ++u) {
         const float dx = ((float)u - t->rc_cx) / t->rc_fx;

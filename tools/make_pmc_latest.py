@@ -7,7 +7,12 @@ gfx950 correction of MI355X_MICROARCH.md section HBM (FETCH_SIZE tallies 128-byt
 20*N = 104 857 600 bytes and WRITE_SIZE reports 104.89 MB; the table walk consumes every
 fetched line, and 2*FETCH_SIZE matches its algorithmic bytes to < 1 %.
 
-  make_pmc_latest.py gpurun_out/r01 C2 [more workloads...]
+  make_pmc_latest.py gpurun_out/r02 C2 C3 [C2band C2sharded ...]
+
+Extras picked up when present in the source directory:
+  pmc_VALU_raycast_C2.json          -> "C2_raycast": VALU instructions per wave of raycast_kernel
+  bench_sharded_world1_<WL>.json    -> "<WL>sharded".algorithmic_bytes_per_launch (the one-rank sharded run's
+                                       roofline.bytes_per_launch, for the ratio bench.py applies at N > 1)
 """
 import json
 import os
@@ -20,8 +25,8 @@ out = json.load(open(out_path)) if os.path.exists(out_path) else {}
 for wl in sys.argv[2:]:
     f = json.load(open(os.path.join(src, f"pmc_FETCH_SIZE_{wl}.json")))
     w = json.load(open(os.path.join(src, f"pmc_WRITE_SIZE_{wl}.json")))
-    d = {"source": f"{src}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --workload {wl} "
-                   "--steps 100 --warmup 10, mean over dispatches after the first 10",
+    d = {"source": f"{src}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, bench.py --legs none --workload "
+                   f"{wl} --steps 100 --warmup 10, mean over dispatches after the first 10",
          "correction": "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B)"}
     for k in sorted(set(f) | set(w)):
         fk = f.get(k, {}).get("FETCH_SIZE", {}).get("mean", 0.0)
@@ -29,6 +34,25 @@ for wl in sys.argv[2:]:
         d[k + "_fetch_size_kb"] = round(fk, 2)
         d[k + "_write_size_kb"] = round(wk, 2)
         d[k + "_hbm_bytes_per_launch"] = int(round(2 * fk * 1024 + wk * 1024))
+    if wl.endswith("sharded"):
+        try:
+            line = json.load(open(os.path.join(src, f"bench_sharded_world1_{wl[:-7]}.json")))
+            d["algorithmic_bytes_per_launch"] = line["roofline"]["bytes_per_launch"]
+            # key without template arguments, as dist.bench_sharded looks it up
+            for k in list(d):
+                if k.startswith("frame_multi_scan_claim_kernel") and k.endswith("_hbm_bytes_per_launch"):
+                    d["frame_multi_scan_claim_kernel_hbm_bytes_per_launch"] = d[k]
+        except Exception as e:
+            d["algorithmic_bytes_per_launch_error"] = repr(e)
     out[wl] = d
+    valu = os.path.join(src, f"pmc_VALU_raycast_{wl}.json")
+    if os.path.exists(valu):
+        v = json.load(open(valu))
+        for k, cs in v.items():
+            if k.startswith("raycast_kernel") and "SQ_INSTS_VALU" in cs and "SQ_WAVES" in cs:
+                out[wl + "_raycast"] = {
+                    "source": f"{src}: rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES, bench.py --legs raycast --workload {wl}",
+                    "raycast_kernel_valu_insts": cs["SQ_INSTS_VALU"]["mean"], "raycast_kernel_waves": cs["SQ_WAVES"]["mean"],
+                    "raycast_kernel_valu_per_wave": round(cs["SQ_INSTS_VALU"]["mean"] / max(1.0, cs["SQ_WAVES"]["mean"]), 1)}
 json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -128,6 +128,7 @@ SIGNATURES = {
     "vh_get_params": (C.c_int, [_vp, C.POINTER(HashTableParams)]),
     "vh_get_device_pointers": (C.c_int, [_vp, C.POINTER(PtrContainer)]),
     "vh_download": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
+    "vh_download_range": (C.c_int, [_vp, C.c_int, C.c_size_t, _vp, C.c_size_t]),
     "vh_debug_eval": (C.c_int, [_vp, _vp, _i32, _vp]),
     "vh_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "vh_set_profiling": (C.c_int, [_vp, C.c_int]),

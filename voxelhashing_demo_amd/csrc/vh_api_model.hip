@@ -102,23 +102,37 @@ extern "C" int vh_get_device_pointers(vh_context *c, PtrContainer *out)
     return VH_OK;
 }
 
-extern "C" int vh_download(vh_context *c, int which, void *dst, size_t bytes)
+static int download_range(vh_context *c, int which, size_t offset, void *dst, size_t bytes)
 {
     if (!c || !dst) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
-    const void *src = nullptr;
+    const char *src = nullptr;
     size_t avail = 0;
     switch (which) {
-        case VH_BUF_HASH_TABLE: src = c->dp.table; avail = sizeof(VoxelEntry) * c->numEntries; break;
-        case VH_BUF_COMPACT: src = c->dp.compact; avail = sizeof(VoxelEntry) * c->numEntries; break;
-        case VH_BUF_SDF_BLOCKS: src = c->dp.blocks; avail = sizeof(Voxel) * (size_t)c->params.numVoxelBlocks * kBlockVoxels; break;
-        case VH_BUF_HEAP: src = c->dp.heap; avail = sizeof(uint32_t) * (size_t)c->params.numVoxelBlocks; break;
+        case VH_BUF_HASH_TABLE: src = (const char *)c->dp.table; avail = sizeof(VoxelEntry) * c->numEntries; break;
+        case VH_BUF_COMPACT: src = (const char *)c->dp.compact; avail = sizeof(VoxelEntry) * c->numEntries; break;
+        case VH_BUF_SDF_BLOCKS:
+            src = (const char *)(c->viewBlocks ? c->viewBlocks : c->dp.blocks);
+            avail = c->viewBlocks ? (size_t)c->viewCount * sizeof(vh_view_record)
+                                  : sizeof(Voxel) * (size_t)c->params.numVoxelBlocks * kBlockVoxels;
+            break;
+        case VH_BUF_HEAP: src = (const char *)c->dp.heap; avail = sizeof(uint32_t) * (size_t)c->params.numVoxelBlocks; break;
         default: return fail(VH_ERR_INVALID_ARGUMENT, "unknown buffer id");
     }
-    if (bytes > avail) return fail(VH_ERR_INVALID_ARGUMENT, "download larger than the buffer");
+    if (offset > avail || bytes > avail - offset) return fail(VH_ERR_INVALID_ARGUMENT, "download past the end of the buffer");
     DeviceGuard guard(c->device);
-    VH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    VH_HIP(hipMemcpyAsync(dst, src + offset, bytes, hipMemcpyDeviceToHost, c->stream));
     VH_HIP(hipStreamSynchronize(c->stream));
     return VH_OK;
+}
+
+extern "C" int vh_download(vh_context *c, int which, void *dst, size_t bytes)
+{
+    return download_range(c, which, 0, dst, bytes);
+}
+
+extern "C" int vh_download_range(vh_context *c, int which, size_t offset_bytes, void *dst, size_t bytes)
+{
+    return download_range(c, which, offset_bytes, dst, bytes);
 }
 
 // ---------------------------------------------------------------------------

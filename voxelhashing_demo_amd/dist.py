@@ -489,8 +489,12 @@ def camera_phase(rank: int, world: int) -> float:
 # ----------------------------------------------------------------------------
 # bench (called by bench.py when WORLD_SIZE > 1)
 # ----------------------------------------------------------------------------
-def bench_sharded(args, wl, rank, world, local_rank):
+def bench_sharded(args, wl, wl_name, rank, world, local_rank):
+    """Timed windows of K exchanges on the bucket-range-sharded path (the process group is the caller's).
+    Returns the result record on rank 0 and None elsewhere."""
     import json
+    import os
+    import statistics
 
     import torch
     import torch.distributed as dist
@@ -506,7 +510,7 @@ def bench_sharded(args, wl, rank, world, local_rank):
     # frame produces ~1 key per 700 pixels, so this is a ~40-fold margin (more with band allocation);
     # the bins travel at full capacity, overflow is counted and reported
     capacity = max(2048, -(-Wd * Ht // (16 * world)))
-    poses = synth.camera_loop(wl["frames"], phase=camera_phase(rank, world))[:nframes]
+    poses = synth.camera_loop(wl.get("loop", wl["frames"]), phase=camera_phase(rank, world))[:nframes]
     prims = synth.room_primitives()
     verts = torch.empty((nframes, Ht, Wd, 4), dtype=torch.float32, device=dev)
     # Sensor frames as the demo reads them (uint16 depth, 5000 units = 1 m, Application.cpp:38-42) and
@@ -562,18 +566,28 @@ def bench_sharded(args, wl, rank, world, local_rank):
         for i in range(args.warmup):
             step(i)
         drain()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        drain()                      # every fed step has been applied when the clock stops
-        dist.barrier()
-        elapsed = time.perf_counter() - t0
+        # windows of exactly K steps, each bracketed by a barrier + synchronisation on both sides, repeated
+        # until ~0.3 s have been timed (every rank takes the same number: the decision is rank 0's)
+        windows, nxt = [], args.warmup
+        while True:
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step(nxt + i)
+            drain()                  # every fed step has been applied when the clock stops
+            dist.barrier()
+            windows.append(time.perf_counter() - t0)
+            nxt += args.steps
+            go = torch.tensor([1 if (sum(windows) < 0.3 and len(windows) < 200) else 0], dtype=torch.int32, device=dev)
+            dist.broadcast(go, 0)
+            if int(go.item()) == 0:
+                break
+        elapsed = statistics.median(windows)
         # per-dispatch HIP-event timing of the table kernels (separate, untimed pass)
         shard.table.set_profiling(True)
         for i in range(3):
-            step(args.warmup + args.steps + i)
+            step(nxt + i)
         drain()
         kt = shard.table.kernel_times(reset=True)
         shard.table.set_profiling(False)
@@ -603,12 +617,17 @@ def bench_sharded(args, wl, rank, world, local_rank):
             kte, ktv = shard.table.kernel_times(reset=True), view.table.kernel_times(reset=True)
             shard.table.set_profiling(False)
             view.table.set_profiling(False)
-    t = torch.tensor([elapsed, rc_elapsed], dtype=torch.float64, device=dev)
+    wt = torch.tensor(windows, dtype=torch.float64, device=dev)
+    dist.all_reduce(wt, op=dist.ReduceOp.MAX)                 # every window: the slowest rank's time
+    windows = [float(x) for x in wt.tolist()]
+    elapsed = statistics.median(windows)
+    t = torch.tensor([rc_elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, rc_elapsed = float(t[0].item()), float(t[1].item())
+    rc_elapsed = float(t[0].item())
     c = shard.table.counters()
     stats = torch.tensor([c["occupied"], c["allocated_total"], c["bin_overflow"]], dtype=torch.int64, device=dev)
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    out = None
     if rank == 0:
         frames = args.steps * world * batch
         launches = max(1, kt["launches"])
@@ -617,8 +636,23 @@ def bench_sharded(args, wl, rank, world, local_rank):
         # cameras (20 B per owned entry) + the compact entries written
         walk_bytes = 20 * shard.table.num_entries + 24 * c["occupied"]
         achieved = walk_bytes / (walk_us * 1e-6) / 1e9 if walk_us > 0 else 0.0
+        # HBM traffic: rocprofv3 --pmc passes are single-process runs, so the counter figure is the one-rank
+        # run's (profiles/pmc_latest.json, "<workload>sharded"): its measured bytes / algorithmic bytes ratio
+        # applied to this rank's launch
+        traffic, traffic_source = None, None
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                                              "pmc_latest.json"))).get(wl_name + "sharded", {})
+            m, a = pmc.get("frame_multi_scan_claim_kernel_hbm_bytes_per_launch"), pmc.get("algorithmic_bytes_per_launch")
+            if m and a:
+                traffic = int(round(walk_bytes * m / a)) if world > 1 else int(m)
+                traffic_source = ("rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of the one-rank run" if world == 1 else
+                                  f"one-rank PMC ratio {m / a:.3f} x this rank's algorithmic bytes")
+        except Exception:
+            pass
         roofline = dict(bound="hbm", kernel="frame_multi_scan_claim_kernel (rank 0)", achieved=round(achieved, 1),
-                        peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4), traffic=None,
+                        peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4), traffic=traffic,
+                        traffic_source=traffic_source,
                         bytes_per_launch=walk_bytes, us_per_launch=round(walk_us, 2),
                         commit_integrate_us=round(1e3 * kt["frame_commit_integrate_ms"] / launches, 2))
         out = dict(
@@ -626,7 +660,8 @@ def bench_sharded(args, wl, rank, world, local_rank):
             value=round(frames / elapsed, 1), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=round(1e3 * elapsed / args.steps, 5), higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f32", data="synthetic",
-            config=dict(workload=f"C4-style: {world} virtual {Wd}x{Ht} cameras (one per GPU) into one scene, "
+            windows=len(windows), timed_s=round(sum(windows), 4),
+            config=dict(workload=f"{'C5' if wl_name == 'C5' else 'C4-style'}: {world} virtual {Wd}x{Ht} cameras (one per GPU) into one scene, "
                                  f"2^{int(math.log2(wl['buckets']))} buckets sharded by bucket range over {world} GPUs, "
                                  "RCCL all-to-all of block keys + all-gather of depth packets per step, PINHOLE; "
                                  + ("uint16 sensor depth, vertex maps by vh_preprocess, packets carry the uint16 image"
@@ -635,7 +670,8 @@ def bench_sharded(args, wl, rank, world, local_rank):
                         resident_frames=nframes, key_bin_capacity=capacity, pipelined=pipelined,
                         packet_bytes=4 * shard.packet_floats,
                         occupied_blocks_all_ranks=int(stats[0]), allocated_blocks_all_ranks=int(stats[1]),
-                        key_bin_overflows=int(stats[2])),
+                        key_bin_overflows=int(stats[2]), voxel_size=wl["voxel"],
+                        voxel_blocks_per_rank=wl["blocks"]),
             roofline=roofline, cpu_baseline=None)
         if do_raycast:
             out["sharded_raycast"] = dict(
@@ -648,7 +684,6 @@ def bench_sharded(args, wl, rank, world, local_rank):
                 note="every rank renders its own camera's view of the whole table: one walk of its shard for "
                      "all views, all-to-all of {key, 512 voxels} records, import into a view table, raycast; "
                      "bit-equal to a raycast of the unsharded table")
-        print(json.dumps(out), flush=True)
     # orderly teardown while the streams the contexts were bound to are still alive (a context
     # destroyed by the garbage collector at interpreter exit synchronises a stream torch may
     # already have released)
@@ -657,4 +692,4 @@ def bench_sharded(args, wl, rank, world, local_rank):
     shard.table.close()
     torch.cuda.synchronize()
     dist.barrier()
-    dist.destroy_process_group()
+    return out if rank == 0 else None

@@ -282,6 +282,13 @@ class SDFHashtable:
     def heap(self) -> np.ndarray:
         return self._download(L.BUF_HEAP, np.dtype("<u4"), self.params.numVoxelBlocks)
 
+    def block_voxels(self, ptr: int) -> np.ndarray:
+        """The 512 voxels of the block at voxel index `ptr` (an entry's ptr), without the rest of the volume."""
+        out = np.empty(512, VOXEL_DTYPE)
+        L.check(self._lib.vh_download_range(self._h, L.BUF_SDF_BLOCKS, 8 * int(ptr), out.ctypes.data_as(C.c_void_p),
+                                            out.nbytes), "vh_download_range")
+        return out
+
     def allocated(self) -> np.ndarray:
         t = self.hash_table()
         return t[t["ptr"] != L.FREE_BLOCK]
