@@ -18,6 +18,8 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libvh_oracle.so")
 SEM_REFERENCE = 0
 SEM_PINHOLE = 1
 FREE_BLOCK = -1
+BAND_RAY, BAND_NORMAL_DDA = 0, 1
+INT_DEPTH_TRUNCATION, INT_WEIGHT_SAMPLE = 1, 2
 POS_SENTINEL = 0x7FFFFFFF
 
 ENTRY_DTYPE = np.dtype([("pos", "<i4", (3,)), ("ptr", "<i4"), ("offset", "<i4")])
@@ -83,6 +85,10 @@ def lib():
         L.vho_set_projection.argtypes = [C.c_void_p, fp]
         L.vho_set_raycast_intrinsics.argtypes = [C.c_void_p] + [C.c_float] * 4
         L.vho_set_alloc_band.argtypes = [C.c_void_p, C.c_float]
+        L.vho_set_band_mode.argtypes = [C.c_void_p, C.c_int]
+        L.vho_set_normals.argtypes = [C.c_void_p, fp]
+        L.vho_set_overflow.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+        L.vho_set_integrate_flags.argtypes = [C.c_void_p, C.c_int]
         L.vho_set_pose.argtypes = [C.c_void_p, fp]
         L.vho_reset_mutexes.argtypes = [C.c_void_p]
         L.vho_alloc_blocks.argtypes = [C.c_void_p, fp]
@@ -306,13 +312,29 @@ class OracleTable:
     def set_raycast_intrinsics(self, fx, fy, cx, cy):
         lib().vho_set_raycast_intrinsics(self._h, fx, fy, cx, cy)
 
-    def set_alloc_band(self, band_metres: float):
+    def set_alloc_band(self, band_metres: float, mode: int = None):
         lib().vho_set_alloc_band(self._h, float(band_metres))
+        if mode is not None:
+            lib().vho_set_band_mode(self._h, int(mode))
 
-    def integrate(self, pose, verts) -> int:
+    def set_normals(self, normals):
+        """Normal map [H, W, 4] (camera frame) of the frames that follow, for BAND_NORMAL_DDA; None = none."""
+        self._normals = None if normals is None else np.ascontiguousarray(normals, np.float32)
+        lib().vho_set_normals(self._h, None if normals is None else _fptr(self._normals))
+
+    def set_overflow(self, enabled: bool, segment_buckets: int = 0):
+        """Overflow linked list on / off; chains wrap inside segments of `segment_buckets` buckets (0: own range)."""
+        lib().vho_set_overflow(self._h, int(bool(enabled)), int(segment_buckets))
+
+    def set_integrate_flags(self, flags: int):
+        lib().vho_set_integrate_flags(self._h, int(flags))
+
+    def integrate(self, pose, verts, normals=None) -> int:
         pose = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
         verts = np.ascontiguousarray(verts, np.float32)
         assert verts.size == self.width * self.height * 4
+        if normals is not None:
+            self.set_normals(normals)
         st = FrameStats()
         occ = lib().vho_integrate(self._h, _fptr(pose), _fptr(verts), C.byref(st))
         self.last_stats = st.as_dict()

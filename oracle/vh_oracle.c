@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define VHO_INF_F (__builtin_inff())
+
 struct vho_table {
     vho_params p;
     int   width, height, semantics;
@@ -25,6 +27,13 @@ struct vho_table {
     float rc_fx, rc_fy, rc_cx, rc_cy;
     uint32_t bucket_lo, bucket_hi;  /* this table owns buckets [lo, hi) of the logical table */
     float alloc_band;               /* 0: surface block only (reference); > 0: truncation-band allocation */
+    int   band_mode;                /* VHO_BAND_RAY / VHO_BAND_NORMAL_DDA */
+    const float *normals;           /* normal map of the running allocBlocks (NORMAL_DDA), camera frame */
+    int   overflow;                 /* overflow linked list on (VoxelUtils.cu:384-411,458-539,578-602 done right) */
+    uint32_t overflow_seg;          /* chains wrap inside segments of this many buckets (0: the owned range) */
+    uint32_t epoch;                 /* lock epochs since creation (vho_reset_mutexes) */
+    uint32_t *slot_epoch;           /* epoch in which a slot received its entry (overflow look-ahead rule) */
+    int   integrate_flags;          /* VHO_INT_DEPTH_TRUNCATION | VHO_INT_WEIGHT_SAMPLE */
 
     uint32_t  *heap;               /* PtrContainer, VoxelDataStructures.h:54-63 */
     vho_entry *table;
@@ -283,8 +292,9 @@ vho_table *vho_create_shard(const vho_params *p, int width, int height, int sema
     t->table   = (vho_entry *)malloc(sizeof(vho_entry) * n);
     t->compact = (vho_entry *)malloc(sizeof(vho_entry) * n);
     t->mutex   = (int32_t *)calloc(hi - lo, sizeof(int32_t));
+    t->slot_epoch = (uint32_t *)calloc(n, sizeof(uint32_t));
     t->blocks  = (vho_voxel *)calloc((size_t)p->numVoxelBlocks * 512, sizeof(vho_voxel));
-    if (!t->heap || !t->table || !t->compact || !t->mutex || !t->blocks) {
+    if (!t->heap || !t->table || !t->compact || !t->mutex || !t->blocks || !t->slot_epoch) {
         vho_destroy(t);
         return NULL;
     }
@@ -307,7 +317,7 @@ vho_table *vho_create_shard(const vho_params *p, int width, int height, int sema
 void vho_destroy(vho_table *t)
 {
     if (!t) return;
-    free(t->heap); free(t->table); free(t->compact); free(t->mutex); free(t->blocks);
+    free(t->heap); free(t->table); free(t->compact); free(t->mutex); free(t->blocks); free(t->slot_epoch);
     free(t);
 }
 
@@ -335,6 +345,7 @@ void vho_set_pose(vho_table *t, const float pose[16])
 void vho_reset_mutexes(vho_table *t)
 {
     memset(t->mutex, 0, sizeof(int32_t) * (t->bucket_hi - t->bucket_lo));
+    t->epoch += 1;
 }
 
 /* allocSingleBlockInHeap, VoxelUtils.cu:328-334, with the exhaustion case
@@ -348,8 +359,11 @@ static int32_t heap_pop(vho_table *t)
 }
 
 /* insertVoxelEntry, live part VoxelUtils.cu:421-456 */
+static void insert_entry_overflow(vho_table *t, const int32_t key[3]);
+
 static void insert_entry(vho_table *t, const int32_t key[3])
 {
+    if (t->overflow) { insert_entry_overflow(t, key); return; }
     const uint32_t bs = t->p.bucketSize, nb = t->p.numBuckets;
     const uint32_t hg = vho_hash(key[0], key[1], key[2], nb);
     if (hg < t->bucket_lo || hg >= t->bucket_hi) return;               /* another shard's bucket */
@@ -379,6 +393,151 @@ static void insert_entry(vho_table *t, const int32_t key[3])
         }
     }
     if (saw_free) t->stats.lock_losses++; else t->stats.bucket_full++;
+}
+
+/* ------------------------------------------------------------------ */
+/* overflow linked list (opt-in)                */
+/* ------------------------------------------------------------------ */
+/* The reference carries the idea as dead, unfinished code (#ifdef LINKED_LIST_ENABLED, never defined:
+ * lookup tail VoxelUtils.cu:384-411, insert tail :458-539, delete tail :578-602, beforeThis() missing).
+ * Its lookup tail is coherent and is restated verbatim; insert and delete are completed the way the
+ * paper the demo follows does it (Niessner et al. 2013, 3.1 / 4.2), keeping what the dead code shows
+ * of the author's intent:
+ *   - a key whose home bucket is full lives in a free slot of a following bucket; the entries of one
+ *     home bucket form a chain that starts in the bucket's LAST slot and is linked through `offset`,
+ *     measured from that last slot, modulo the table (:388-399: i = lastEntryInBucket + curr.offset;
+ *     i %= numBuckets*bucketSize);
+ *   - lookups follow at most attachedLinkedListSize iterations of that loop (:391-392), i.e. the last
+ *     slot plus attachedLinkedListSize-1 chained entries; insertion refuses to grow a chain beyond what
+ *     the loop can reach;
+ *   - the free slot is searched among the 9 slots behind the bucket's last slot (:475-478 looks ahead
+ *     `j < 10`), never in a bucket's last slot (it is that bucket's own chain head);
+ *   - the home bucket is locked first, then the bucket that holds the free slot (:472-482); both stay
+ *     locked for the frame, so "at most one insertion per bucket per frame" holds for both;
+ *   - the new entry goes to the FRONT of the chain (entry.offset = head.offset; head.offset = j): only
+ *     the two locked buckets are written.
+ * A slot that received its entry earlier in the SAME lock epoch counts as free in the look-ahead (its
+ * bucket is locked, so the insertion fails): contenders are then judged against the table as it was
+ * when the epoch began, whatever order cameras are served in -- the rule the GPU's single claim launch
+ * realises.
+ * With the list on, a bucket's entries no longer form a prefix of its slots (deletion leaves holes,
+ * as in the paper), so every scan covers all bucketSize slots. */
+void vho_set_overflow(vho_table *t, int enabled, uint32_t segment_buckets)
+{
+    t->overflow = enabled != 0;
+    t->overflow_seg = segment_buckets;
+}
+
+/* chain arithmetic: entries [base, base+n) of the segment that holds local bucket h */
+static void chain_segment(const vho_table *t, uint32_t h, size_t *base, size_t *n)
+{
+    const uint32_t bs = t->p.bucketSize, owned = t->bucket_hi - t->bucket_lo;
+    if (t->overflow_seg == 0 || t->overflow_seg >= t->p.numBuckets) { *base = 0; *n = (size_t)owned * bs; return; }
+    const uint32_t hg = h + t->bucket_lo;
+    uint32_t lo = (hg / t->overflow_seg) * t->overflow_seg, hi = lo + t->overflow_seg;
+    if (hi > t->p.numBuckets) hi = t->p.numBuckets;
+    if (lo < t->bucket_lo) lo = t->bucket_lo;
+    if (hi > t->bucket_hi) hi = t->bucket_hi;
+    *base = (size_t)(lo - t->bucket_lo) * bs;
+    *n = (size_t)(hi - lo) * bs;
+}
+
+static size_t chain_slot(size_t last, int32_t offset, size_t base, size_t n)
+{
+    return base + (size_t)(((int64_t)(last - base) + (int64_t)offset) % (int64_t)n);
+}
+
+static int key_at(const vho_entry *e, const int32_t key[3])
+{
+    return e->pos[0] == key[0] && e->pos[1] == key[1] && e->pos[2] == key[2] && e->ptr != VHO_FREE_BLOCK;
+}
+
+/* getVoxelEntry4Block with the list (:362-411): entry index or -1; *prev_out = chain predecessor
+ * (entry index) when the key was found behind the bucket's last slot, else -1 */
+static int64_t find_overflow(const vho_table *t, const int32_t key[3], uint32_t h, int64_t *prev_out)
+{
+    const uint32_t bs = t->p.bucketSize, L = t->p.attachedLinkedListSize;
+    const size_t start = (size_t)h * bs, last = start + bs - 1;
+    if (prev_out) *prev_out = -1;
+    for (uint32_t i = 0; i < bs; ++i)
+        if (key_at(&t->table[start + i], key)) return (int64_t)(start + i);            /* :374-381 */
+    size_t base, n;
+    chain_segment(t, h, &base, &n);
+    size_t i = last, prev = last;
+    for (uint32_t iter = 0; iter < L; ++iter) {                                          /* :391-392 */
+        const vho_entry *curr = &t->table[i];
+        if (key_at(curr, key)) { if (prev_out && i != last) *prev_out = (int64_t)prev; return (int64_t)i; }
+        if (curr->offset == 0) break;                                                    /* :396 */
+        prev = i;
+        i = chain_slot(last, curr->offset, base, n);                                     /* :398-399 */
+    }
+    return -1;
+}
+
+static void insert_entry_overflow(vho_table *t, const int32_t key[3])
+{
+    const uint32_t bs = t->p.bucketSize, nb = t->p.numBuckets, L = t->p.attachedLinkedListSize;
+    const uint32_t hg = vho_hash(key[0], key[1], key[2], nb);
+    if (hg < t->bucket_lo || hg >= t->bucket_hi) return;
+    const uint32_t h = hg - t->bucket_lo;
+    const size_t start = (size_t)h * bs, last = start + bs - 1;
+    int64_t first_empty = -1;
+    for (uint32_t i = 0; i < bs; ++i) {
+        const vho_entry *e = &t->table[start + i];
+        if (key_at(e, key)) return;                                                      /* already there */
+        if (first_empty < 0 && e->ptr == VHO_FREE_BLOCK) first_empty = (int64_t)(start + i);
+    }
+    size_t base, n;
+    chain_segment(t, h, &base, &n);
+    /* the lookup loop again: presence, and how long the chain is */
+    uint32_t links = 0;
+    int ended = 0;
+    size_t i = last;
+    for (uint32_t iter = 0; iter < L; ++iter) {
+        const vho_entry *curr = &t->table[i];
+        if (key_at(curr, key)) return;
+        if (curr->offset == 0) { ended = 1; break; }
+        i = chain_slot(last, curr->offset, base, n);
+        ++links;
+    }
+    if (first_empty >= 0) {                                        /* a slot of the home bucket: as without the list */
+        const int32_t prev = t->mutex[h];
+        t->mutex[h] = VHO_LOCKED_BLOCK;
+        if (prev == VHO_LOCKED_BLOCK) { t->stats.lock_losses++; return; }
+        const int32_t blk = heap_pop(t);
+        if (blk < 0) { t->stats.heap_exhausted++; return; }
+        vho_entry *e = &t->table[first_empty];
+        e->pos[0] = key[0]; e->pos[1] = key[1]; e->pos[2] = key[2];
+        e->ptr = blk * 512;                                        /* (a free last slot has offset 0: no chain without a head) */
+        t->slot_epoch[first_empty] = t->epoch;
+        t->stats.inserted++;
+        return;
+    }
+    if (!ended || links + 1 > L - 1 || L < 2) { t->stats.bucket_full++; return; }   /* chain at the reach of the lookup loop */
+    int64_t target = -1;
+    int32_t tj = 0;
+    for (int32_t j = 1; j < 10; ++j) {                                               /* :475-478 */
+        const size_t s = chain_slot(last, j, base, n);
+        if (s % bs == bs - 1) continue;                            /* another bucket's chain head */
+        if (t->table[s].ptr == VHO_FREE_BLOCK || t->slot_epoch[s] == t->epoch) { target = (int64_t)s; tj = j; break; }
+    }
+    if (target < 0) { t->stats.bucket_full++; return; }
+    int32_t prev = t->mutex[h];                                                      /* [1] lock the parent block, :472 */
+    t->mutex[h] = VHO_LOCKED_BLOCK;
+    if (prev == VHO_LOCKED_BLOCK) { t->stats.lock_losses++; return; }
+    const uint32_t hb = (uint32_t)((size_t)target / bs);
+    prev = t->mutex[hb];                                                             /* [3] now lock this new bucket, :482 */
+    t->mutex[hb] = VHO_LOCKED_BLOCK;
+    if (prev == VHO_LOCKED_BLOCK) { t->stats.lock_losses++; return; }
+    const int32_t blk = heap_pop(t);
+    if (blk < 0) { t->stats.heap_exhausted++; return; }
+    vho_entry *e = &t->table[target];
+    e->pos[0] = key[0]; e->pos[1] = key[1]; e->pos[2] = key[2];
+    e->ptr = blk * 512;
+    e->offset = t->table[last].offset;
+    t->table[last].offset = tj;
+    t->slot_epoch[target] = t->epoch;
+    t->stats.inserted++;
 }
 
 /* Truncation-band allocation (opt-in extension; the reference has the
@@ -415,6 +574,80 @@ static int band_key(const vho_table *t, const float *v, int k, int nS, float ste
     return 1;
 }
 
+/* Second band mode, VHO_BAND_NORMAL_DDA: what the reference has commented out in allocBlocksKernel
+ * (VoxelUtils.cu:632-633 the two ray ends p -+ truncation*n, :641-656 step / tMax / tDelta, :678-699 the
+ * walk): every block the segment from p - b*n to p + b*n crosses is demanded, visited by a block DDA
+ * (Amanatides-Woo).  p = the pixel's world point (:622), n = its normal from preProcess's normal map
+ * rotated into the world frame, b = alloc_band.  A pixel without a normal (preProcess writes 0 at
+ * the border and next to invalid depth) demands its surface block only.  Restated so that oracle and
+ * kernel can agree bit for bit: the segment is parametrised over [0,1] (no normalisation, no square
+ * root); block k covers world coordinates [(8k - 0.5) * voxelSize, (8k + 7.5) * voxelSize) on an
+ * axis, which is what world2Block's rounding (:280-287, :266-278) maps to k; ties are broken as in
+ * :683-698 (x only if strictly smallest, then z if smaller than y, else y); the walk ends at the
+ * end block, after 62 steps (rank bits), or when the next crossing lies beyond the segment's end. */
+void vho_set_band_mode(vho_table *t, int mode) { t->band_mode = mode; }
+void vho_set_normals(vho_table *t, const float *normals) { t->normals = normals; }
+
+static int dda_keys(const vho_table *t, const float *v, const float *nrm, int32_t keys[][3])
+{
+    float g[4];
+    vho_mat4_mul_vec4(t->p.global_transform, v, g);                   /* :622, w as stored */
+    vho_world2block(g, t->p.voxelSize, t->p.voxelBlockSize, keys[0]);
+    if (!nrm || (nrm[0] == 0.0f && nrm[1] == 0.0f && nrm[2] == 0.0f) || nrm[0] != nrm[0] || nrm[1] != nrm[1] ||
+        nrm[2] != nrm[2])
+        return 1;
+    const float *T = t->p.global_transform;
+    const float b = t->alloc_band, vs = t->p.voxelSize;
+    float start[3], end[3], dir[3];
+    for (int a = 0; a < 3; ++a) {
+        const float nw = T[4*a+0]*nrm[0] + T[4*a+1]*nrm[1] + T[4*a+2]*nrm[2];
+        start[a] = g[a] - (b * nw);                                   /* :632 */
+        end[a] = g[a] + (b * nw);                                     /* :633 */
+        dir[a] = end[a] - start[a];
+    }
+    int32_t cur[3], last[3];
+    vho_world2block(start, vs, t->p.voxelBlockSize, cur);
+    vho_world2block(end, vs, t->p.voxelBlockSize, last);
+    int32_t step[3];
+    float tmax[3], tdelta[3];
+    for (int a = 0; a < 3; ++a) {
+        step[a] = dir[a] > 0.0f ? 1 : dir[a] < 0.0f ? -1 : 0;
+        if (step[a] == 0) { tmax[a] = VHO_INF_F; tdelta[a] = VHO_INF_F; continue; }   /* :658-668 */
+        const float boundary = ((float)wrap_mul(wrap_add(cur[a], step[a] > 0 ? 1 : 0), 8) - 0.5f) * vs;
+        tmax[a] = (boundary - start[a]) / dir[a];
+        tdelta[a] = (8.0f * vs) / fabsf(dir[a]);
+    }
+    int n = 0;
+    keys[n][0] = cur[0]; keys[n][1] = cur[1]; keys[n][2] = cur[2];
+    ++n;
+    while ((cur[0] != last[0] || cur[1] != last[1] || cur[2] != last[2]) && n < VHO_MAX_BAND_SAMPLES - 1) {
+        int a;
+        if (tmax[0] < tmax[1] && tmax[0] < tmax[2]) a = 0;            /* :683 */
+        else if (tmax[2] < tmax[1]) a = 2;                            /* :688 */
+        else a = 1;                                                   /* :693 */
+        if (!(tmax[a] <= 1.0f)) break;
+        cur[a] = wrap_add(cur[a], step[a]);
+        tmax[a] += tdelta[a];
+        keys[n][0] = cur[0]; keys[n][1] = cur[1]; keys[n][2] = cur[2];
+        ++n;
+    }
+    return n;
+}
+
+/* the block keys pixel (x,y) demands, in rank order; valid[k] = 0 where a ray sample has no key */
+static int pixel_keys(const vho_table *t, const float *verts, int x, int y, int nS, float step, int32_t keys[][3],
+                      uint8_t *valid)
+{
+    const float *v = verts + 4 * ((size_t)y * t->width + x);
+    if (t->band_mode == VHO_BAND_NORMAL_DDA && t->alloc_band > 0.0f) {
+        const int n = dda_keys(t, v, t->normals ? t->normals + 4 * ((size_t)y * t->width + x) : NULL, keys);
+        for (int k = 0; k < n; ++k) valid[k] = 1;
+        return n;
+    }
+    for (int k = 0; k < nS; ++k) valid[k] = (uint8_t)band_key(t, v, k, nS, step, keys[k]);
+    return nS;
+}
+
 /* allocBlocksKernel, VoxelUtils.cu:606-705, visited in launch order */
 void vho_alloc_blocks(vho_table *t, const float *verts)
 {
@@ -432,12 +665,14 @@ void vho_alloc_blocks(vho_table *t, const float *verts)
         if (v[2] == 0.0f) continue;                                   /* :621 */
         t->stats.pixels_valid++;
         int counted = 0;
-        for (int k = 0; k < nS; ++k) {
-            int32_t key[3];
-            if (!band_key(t, v, k, nS, step, key)) continue;
-            if (!vho_block_in_frustum(t, key)) continue;              /* :673 */
+        int32_t keys[VHO_MAX_BAND_SAMPLES][3];
+        uint8_t valid[VHO_MAX_BAND_SAMPLES];
+        const int n = pixel_keys(t, verts, x, y, nS, step, keys, valid);
+        for (int k = 0; k < n; ++k) {
+            if (!valid[k]) continue;
+            if (!vho_block_in_frustum(t, keys[k])) continue;          /* :673 */
             if (!counted) { t->stats.pixels_in_frustum++; counted = 1; }
-            insert_entry(t, key);
+            insert_entry(t, keys[k]);
         }
     }
 }
@@ -468,50 +703,65 @@ void vho_integrate_depth_map(vho_table *t, const float *verts)
     integrate_depth(t, verts + 2, 4);          /* verts[idx].z */
 }
 
-static void integrate_depth(vho_table *t, const float *depth_base, int stride)
+/* one voxel of integrateDepthMapKernel (:793-840); returns 1 if the voxel was written */
+static int integrate_voxel(vho_table *t, const vho_entry *e, const int32_t base[3], int tx, int ty, int tz,
+                           const float *depth_base, int stride)
 {
     const int W = t->width, H = t->height;
-    const float trunc = t->p.truncation;
+    const int32_t vi[3] = { wrap_add(base[0], tx), wrap_add(base[1], ty), wrap_add(base[2], tz) };
+    float pc[3];   /* camera-space point handed to project() */
+    if (t->semantics == VHO_SEM_REFERENCE) {
+        /* :797-800 -- the inverse pose is applied to the voxel INDEX, the
+         * result is truncated back to an int index, then scaled to metres */
+        const float vf[4] = { (float)vi[0], (float)vi[1], (float)vi[2], 1.0f };
+        float r[4];
+        vho_mat4_mul_vec4(t->p.inv_global_transform, vf, r);
+        for (int k = 0; k < 3; ++k)
+            pc[k] = (float)vho_float2int_rz(r[k]) * t->p.voxelSize;
+    } else {
+        const float wv[4] = { (float)vi[0] * t->p.voxelSize, (float)vi[1] * t->p.voxelSize,
+                              (float)vi[2] * t->p.voxelSize, 1.0f };
+        float r[4];
+        vho_mat4_mul_vec4(t->p.inv_global_transform, wv, r);
+        pc[0] = r[0]; pc[1] = r[1]; pc[2] = r[2];
+    }
+    int32_t s[2];
+    vho_project(t->proj, pc, s);                                          /* :801 */
+    if (s[0] < 0 || s[0] >= W || s[1] < 0 || s[1] >= H) return 0;         /* :803 */
+    const float depth = depth_base[(size_t)stride * ((size_t)s[1] * W + s[0])];  /* :805 */
+    if (depth <= 0) return 0;                                             /* :806 */
+    float sdf = depth - pc[2];                                            /* :813 */
+    float trunc = t->p.truncation;                                        /* :815 */
+    if (t->integrate_flags & VHO_INT_DEPTH_TRUNCATION)                    /* the commented half of :815 = getTruncation, :261-264 */
+        trunc = t->p.truncation + (t->p.truncScale * depth);
+    if (!(sdf > -trunc)) return 0;                                        /* :818 */
+    sdf = (sdf >= 0) ? fminf(trunc, sdf) : fmaxf(-trunc, sdf);            /* :819-824 */
+    float weight = 0.1f;                                                  /* :829 */
+    if (t->integrate_flags & VHO_INT_WEIGHT_SAMPLE) {                     /* the commented :827 with :808-811 */
+        const float range_min = 0.5f, range_max = 5.0f;
+        const float zero_one = (depth - range_min) / (range_max - range_min);
+        weight = fmaxf((float)((double)t->p.integrationWeightSample * 1.5 * (1.0 - (double)zero_one)), 1.0f);
+    }
+    const vho_voxel cur = { sdf, weight };
+    vho_voxel *dst = &t->blocks[(size_t)e->ptr + (size_t)(tz * 64 + ty * 8 + tx)];  /* :836 */
+    vho_combine_voxel(dst, &cur, t->p.integrationWeightMax, dst);
+    return 1;
+}
+
+static void integrate_depth(vho_table *t, const float *depth_base, int stride)
+{
     for (int b = 0; b < t->compact_counter; ++b) {
         const vho_entry *e = &t->compact[b];
         int32_t base[3];
         for (int k = 0; k < 3; ++k) base[k] = wrap_mul(e->pos[k], t->p.voxelBlockSize);  /* :793 */
         for (int tz = 0; tz < 8; ++tz)
         for (int ty = 0; ty < 8; ++ty)
-        for (int tx = 0; tx < 8; ++tx) {
-            const int32_t vi[3] = { wrap_add(base[0], tx), wrap_add(base[1], ty), wrap_add(base[2], tz) };
-            float pc[3];   /* camera-space point handed to project() */
-            if (t->semantics == VHO_SEM_REFERENCE) {
-                /* :797-800 -- the inverse pose is applied to the voxel INDEX, the
-                 * result is truncated back to an int index, then scaled to metres */
-                const float vf[4] = { (float)vi[0], (float)vi[1], (float)vi[2], 1.0f };
-                float r[4];
-                vho_mat4_mul_vec4(t->p.inv_global_transform, vf, r);
-                for (int k = 0; k < 3; ++k)
-                    pc[k] = (float)vho_float2int_rz(r[k]) * t->p.voxelSize;
-            } else {
-                const float wv[4] = { (float)vi[0] * t->p.voxelSize, (float)vi[1] * t->p.voxelSize,
-                                      (float)vi[2] * t->p.voxelSize, 1.0f };
-                float r[4];
-                vho_mat4_mul_vec4(t->p.inv_global_transform, wv, r);
-                pc[0] = r[0]; pc[1] = r[1]; pc[2] = r[2];
-            }
-            int32_t s[2];
-            vho_project(t->proj, pc, s);                                          /* :801 */
-            if (s[0] < 0 || s[0] >= W || s[1] < 0 || s[1] >= H) continue;         /* :803 */
-            const float depth = depth_base[(size_t)stride * ((size_t)s[1] * W + s[0])];  /* :805 */
-            if (depth <= 0) continue;                                             /* :806 */
-            float sdf = depth - pc[2];                                            /* :813 */
-            if (sdf > -trunc) {                                                   /* :818 */
-                sdf = (sdf >= 0) ? fminf(trunc, sdf) : fmaxf(-trunc, sdf);        /* :819-824 */
-                const vho_voxel cur = { sdf, 0.1f };                              /* :829 */
-                vho_voxel *dst = &t->blocks[(size_t)e->ptr + (size_t)(tz * 64 + ty * 8 + tx)];  /* :836 */
-                vho_combine_voxel(dst, &cur, t->p.integrationWeightMax, dst);
-                t->stats.voxels_updated++;
-            }
-        }
+        for (int tx = 0; tx < 8; ++tx)
+            t->stats.voxels_updated += (uint32_t)integrate_voxel(t, e, base, tx, ty, tz, depth_base, stride);
     }
 }
+
+void vho_set_integrate_flags(vho_table *t, int flags) { t->integrate_flags = flags; }
 
 /* SDF_Hashtable::integrate, SDF_Hashtable.cpp:11-40 */
 int vho_integrate(vho_table *t, const float pose[16], const float *verts, vho_frame_stats *stats)
@@ -547,18 +797,23 @@ int vho_integrate_mt(vho_table *t, const float pose[16], const float *verts, int
     float step;
     const int nS = band_samples(t, &step);
     /* ---- allocBlocks: keys in parallel, insertions in launch order ---- */
-    int32_t *keys = (int32_t *)malloc((size_t)W * H * nS * 4 * sizeof(int32_t));   /* {x,y,z,wanted} */
+    const int maxK = (t->band_mode == VHO_BAND_NORMAL_DDA && t->alloc_band > 0.0f) ? VHO_MAX_BAND_SAMPLES : nS;
+    int32_t *keys = (int32_t *)malloc((size_t)W * H * maxK * 4 * sizeof(int32_t));   /* {x,y,z,wanted} */
     if (!keys) return -1;
     #pragma omp parallel for num_threads(threads) schedule(static)
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
             const float *v = verts + 4 * ((size_t)y * W + x);
-            for (int k = 0; k < nS; ++k) {
-                int32_t *kk = keys + 4 * (((size_t)y * W + x) * nS + k);
-                kk[3] = 0;
-                if (v[2] == 0.0f) continue;
-                if (!band_key(t, v, k, nS, step, kk)) continue;
-                kk[3] = vho_block_in_frustum(t, kk) ? 1 : 0;
+            int32_t *kk = keys + 4 * (((size_t)y * W + x) * maxK);
+            for (int k = 0; k < maxK; ++k) kk[4 * k + 3] = 0;
+            if (v[2] == 0.0f) continue;
+            int32_t pk[VHO_MAX_BAND_SAMPLES][3];
+            uint8_t valid[VHO_MAX_BAND_SAMPLES];
+            const int n = pixel_keys(t, verts, x, y, nS, step, pk, valid);
+            for (int k = 0; k < n; ++k) {
+                if (!valid[k]) continue;
+                kk[4 * k + 0] = pk[k][0]; kk[4 * k + 1] = pk[k][1]; kk[4 * k + 2] = pk[k][2];
+                kk[4 * k + 3] = vho_block_in_frustum(t, pk[k]) ? 1 : 0;
             }
         }
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
@@ -571,8 +826,8 @@ int vho_integrate_mt(vho_table *t, const float pose[16], const float *verts, int
         if (verts[4 * ((size_t)y * W + x) + 2] == 0.0f) continue;
         t->stats.pixels_valid++;
         int counted = 0;
-        for (int k = 0; k < nS; ++k) {
-            const int32_t *kk = keys + 4 * (((size_t)y * W + x) * nS + k);
+        for (int k = 0; k < maxK; ++k) {
+            const int32_t *kk = keys + 4 * (((size_t)y * W + x) * maxK + k);
             if (!kk[3]) continue;
             if (!counted) { t->stats.pixels_in_frustum++; counted = 1; }
             insert_entry(t, kk);
@@ -612,7 +867,6 @@ int vho_integrate_mt(vho_table *t, const float pose[16], const float *verts, int
     /* ---- integrateDepthMap: blocks are independent ---- */
     if (count > 0) {
         const float *depth_base = verts + 2;
-        const float trunc = t->p.truncation;
         uint32_t updated = 0;
         #pragma omp parallel for num_threads(threads) schedule(dynamic, 4) reduction(+:updated)
         for (int b = 0; b < count; ++b) {
@@ -621,35 +875,8 @@ int vho_integrate_mt(vho_table *t, const float pose[16], const float *verts, int
             for (int k = 0; k < 3; ++k) base[k] = wrap_mul(e->pos[k], t->p.voxelBlockSize);
             for (int tz = 0; tz < 8; ++tz)
             for (int ty = 0; ty < 8; ++ty)
-            for (int tx = 0; tx < 8; ++tx) {
-                const int32_t vi[3] = { wrap_add(base[0], tx), wrap_add(base[1], ty), wrap_add(base[2], tz) };
-                float pc[3];
-                if (t->semantics == VHO_SEM_REFERENCE) {
-                    const float vf[4] = { (float)vi[0], (float)vi[1], (float)vi[2], 1.0f };
-                    float r[4];
-                    vho_mat4_mul_vec4(t->p.inv_global_transform, vf, r);
-                    for (int k = 0; k < 3; ++k) pc[k] = (float)vho_float2int_rz(r[k]) * t->p.voxelSize;
-                } else {
-                    const float wv[4] = { (float)vi[0] * t->p.voxelSize, (float)vi[1] * t->p.voxelSize,
-                                          (float)vi[2] * t->p.voxelSize, 1.0f };
-                    float r[4];
-                    vho_mat4_mul_vec4(t->p.inv_global_transform, wv, r);
-                    pc[0] = r[0]; pc[1] = r[1]; pc[2] = r[2];
-                }
-                int32_t s[2];
-                vho_project(t->proj, pc, s);
-                if (s[0] < 0 || s[0] >= W || s[1] < 0 || s[1] >= H) continue;
-                const float depth = depth_base[(size_t)4 * ((size_t)s[1] * W + s[0])];
-                if (depth <= 0) continue;
-                float sdf = depth - pc[2];
-                if (sdf > -trunc) {
-                    sdf = (sdf >= 0) ? fminf(trunc, sdf) : fmaxf(-trunc, sdf);
-                    const vho_voxel cur = { sdf, 0.1f };
-                    vho_voxel *dst = &t->blocks[(size_t)e->ptr + (size_t)(tz * 64 + ty * 8 + tx)];
-                    vho_combine_voxel(dst, &cur, t->p.integrationWeightMax, dst);
-                    updated++;
-                }
-            }
+            for (int tx = 0; tx < 8; ++tx)
+                updated += (uint32_t)integrate_voxel(t, e, base, tx, ty, tz, depth_base, 4);
         }
         t->stats.voxels_updated = updated;
     }
@@ -671,6 +898,7 @@ static int64_t lookup_block(const vho_table *t, const int32_t key[3])
     const uint32_t hg = vho_hash(key[0], key[1], key[2], t->p.numBuckets);
     if (hg < t->bucket_lo || hg >= t->bucket_hi) return -1;
     const uint32_t h = hg - t->bucket_lo;
+    if (t->overflow) return find_overflow(t, key, h, NULL);
     for (uint32_t i = 0; i < bs; ++i) {
         const vho_entry *e = &t->table[(size_t)h * bs + i];
         if (e->pos[0] == key[0] && e->pos[1] == key[1] && e->pos[2] == key[2]
@@ -830,7 +1058,6 @@ void vho_render_blocks(const vho_table *t, const float pose[16], float t_min, fl
  *   - collect(threshold): every entry of the compact list (the blocks the last flatten saw)
  *     whose voxels have max weight == 0, or min |sdf| over the voxels with weight > 0
  *     >= threshold, is deleted.  The compact list is empty afterwards. */
-#define VHO_INF_F (__builtin_inff())
 
 static void free_entry_at(vho_table *t, uint32_t local_bucket, uint32_t slot)
 {
@@ -844,11 +1071,55 @@ static void free_entry_at(vho_table *t, uint32_t local_bucket, uint32_t slot)
     reset_entries(bucket + s, 1);
 }
 
+/* Deletion with the overflow list on (the reference's tail, VoxelUtils.cu:578-602, needs the
+ * missing beforeThis(); completed as in the paper): no compaction -- a freed slot simply becomes
+ * free -- except that a bucket's last slot, which heads its chain, is refilled with the first
+ * chained entry when it is deleted while the chain is not empty (so "last slot free" always means
+ * "no chain"); a chained entry is unlinked from its predecessor (prev.offset = curr.offset, :594).
+ * The outcome does not depend on the order in which a set of keys is deleted. */
+static void release_block(vho_table *t, int32_t ptr)
+{
+    memset(t->blocks + ptr, 0, 512 * sizeof(vho_voxel));
+    t->heap[++t->heap_counter] = (uint32_t)(ptr / 512);              /* :338-340 */
+}
+
+static int delete_entry_overflow(vho_table *t, const int32_t key[3])
+{
+    const uint32_t bs = t->p.bucketSize;
+    const uint32_t hg = vho_hash(key[0], key[1], key[2], t->p.numBuckets);
+    if (hg < t->bucket_lo || hg >= t->bucket_hi) return 0;
+    const uint32_t h = hg - t->bucket_lo;
+    const size_t last = (size_t)h * bs + bs - 1;
+    int64_t prev;
+    const int64_t at = find_overflow(t, key, h, &prev);
+    if (at < 0) return 0;
+    vho_entry *e = &t->table[at];
+    release_block(t, e->ptr);
+    if ((size_t)at == last && e->offset != 0) {                     /* chain head with followers: pull the first one in */
+        size_t base, n;
+        chain_segment(t, h, &base, &n);
+        vho_entry *nx = &t->table[chain_slot(last, e->offset, base, n)];
+        *e = *nx;                                                    /* pos, ptr and its link to the rest of the chain */
+        reset_entries(nx, 1);
+    } else if (prev >= 0) {                                          /* chained entry */
+        t->table[prev].offset = e->offset;                           /* :594 */
+        reset_entries(e, 1);
+    } else {
+        reset_entries(e, 1);                                         /* a slot of the home bucket (a last slot here has offset 0) */
+    }
+    return 1;
+}
+
 /* keys: n x {x,y,z,ignored}.  Returns the number of blocks freed (absent keys are skipped). */
 int vho_delete_blocks(vho_table *t, const int32_t *keys, int n)
 {
     const uint32_t bs = t->p.bucketSize;
     int freed = 0;
+    if (t->overflow) {
+        for (int i = 0; i < n; ++i) freed += delete_entry_overflow(t, keys + 4 * (size_t)i);
+        t->compact_counter = 0;
+        return freed;
+    }
     for (int i = 0; i < n; ++i) {
         const int32_t *k = keys + 4 * (size_t)i;
         const uint32_t hg = vho_hash(k[0], k[1], k[2], t->p.numBuckets);
@@ -1005,27 +1276,32 @@ int vho_generate_keys(vho_table *t, const float *verts, uint32_t camera_id, int 
     for (int s = 0; s < num_shards; ++s) memset(bins + (size_t)4 * s * capacity, 0, 4 * sizeof(int32_t));
     float step;
     const int nS = band_samples(t, &step);
-    for (int k = 0; k < nS; ++k)
     for (int y = 0; y < H; ++y) {
-        int have_prev = 0;
-        int32_t prev[3] = {0, 0, 0};
+        int have_prev[VHO_MAX_BAND_SAMPLES];
+        int32_t prev[VHO_MAX_BAND_SAMPLES][3];
+        memset(have_prev, 0, sizeof have_prev);
         for (int x = 0; x < W; ++x) {
             const float *v = verts + 4 * ((size_t)y * W + x);
-            int32_t key[3];
-            int want = 0;
-            if (v[2] != 0.0f && band_key(t, v, k, nS, step, key)) want = vho_block_in_frustum(t, key);
-            if (!want) { have_prev = 0; continue; }
-            if (have_prev && key[0] == prev[0] && key[1] == prev[1] && key[2] == prev[2]) continue;
-            have_prev = 1; prev[0] = key[0]; prev[1] = key[1]; prev[2] = key[2];
-            const uint32_t h = vho_hash(key[0], key[1], key[2], t->p.numBuckets);
-            int32_t *bin = bins + (size_t)4 * (h / per) * capacity;
-            const int slot = ++bin[0];
-            if (slot > worst) worst = slot;
-            if (slot < capacity) {
-                int32_t *r = bin + 4 * slot;
-                r[0] = key[0]; r[1] = key[1]; r[2] = key[2];
-                /* camera, then launch order, then sample index decide who wins a bucket */
-                r[3] = (int32_t)((camera_id << 27) | (vho_launch_rank(x, y, W) << 6) | (uint32_t)k);
+            int32_t pk[VHO_MAX_BAND_SAMPLES][3];
+            uint8_t valid[VHO_MAX_BAND_SAMPLES];
+            int n = 0;
+            if (v[2] != 0.0f) n = pixel_keys(t, verts, x, y, nS, step, pk, valid);
+            for (int k = 0; k < VHO_MAX_BAND_SAMPLES; ++k) {
+                const int32_t *key = pk[k];
+                const int want = k < n && valid[k] && vho_block_in_frustum(t, key);
+                if (!want) { have_prev[k] = 0; continue; }
+                if (have_prev[k] && key[0] == prev[k][0] && key[1] == prev[k][1] && key[2] == prev[k][2]) continue;
+                have_prev[k] = 1; prev[k][0] = key[0]; prev[k][1] = key[1]; prev[k][2] = key[2];
+                const uint32_t h = vho_hash(key[0], key[1], key[2], t->p.numBuckets);
+                int32_t *bin = bins + (size_t)4 * (h / per) * capacity;
+                const int slot = ++bin[0];
+                if (slot > worst) worst = slot;
+                if (slot < capacity) {
+                    int32_t *r = bin + 4 * slot;
+                    r[0] = key[0]; r[1] = key[1]; r[2] = key[2];
+                    /* camera, then launch order, then sample index decide who wins a bucket */
+                    r[3] = (int32_t)((camera_id << 27) | (vho_launch_rank(x, y, W) << 6) | (uint32_t)k);
+                }
             }
         }
     }

@@ -84,6 +84,17 @@ void       vho_set_projection(vho_table *t, const float m[9]);  /* row-major 3x3
 void       vho_set_raycast_intrinsics(vho_table *t, float fx, float fy, float cx, float cy);
 /* opt-in truncation-band allocation; 0 = surface block only */
 void       vho_set_alloc_band(vho_table *t, float band_metres);
+#define VHO_BAND_RAY        0   /* samples on the viewing ray, half-block steps (round 1) */
+#define VHO_BAND_NORMAL_DDA 1   /* block DDA from p - b*n to p + b*n (VoxelUtils.cu:632-703, commented out there) */
+void       vho_set_band_mode(vho_table *t, int mode);
+void       vho_set_normals(vho_table *t, const float *normals);   /* W*H float4, camera frame; borrowed; NULL = none */
+/* opt-in overflow linked list (VoxelUtils.cu:384-411, 458-539, 578-602: dead code there); chains wrap
+ * inside segments of `segment_buckets` buckets (0 = the table's own bucket range) */
+void       vho_set_overflow(vho_table *t, int enabled, uint32_t segment_buckets);
+/* opt-in TSDF update variants the reference has commented out */
+#define VHO_INT_DEPTH_TRUNCATION 1   /* truncation + truncScale * depth (VoxelUtils.cu:815, getTruncation :261-264) */
+#define VHO_INT_WEIGHT_SAMPLE    2   /* weight = max(integrationWeightSample * 1.5 * (1 - depth01), 1) (:808-811, :827) */
+void       vho_set_integrate_flags(vho_table *t, int flags);
 
 /* ---- per-frame steps (SDF_Hashtable.cpp:11-40) ---- */
 void vho_set_pose(vho_table *t, const float pose[16]);          /* + cofactor inverse */

@@ -29,7 +29,7 @@ def main():
     wl = WORKLOADS[a.workload]
     Wd, Ht = wl["width"], wl["height"]
     dev = torch.device("cuda", 0)
-    poses = synth.camera_loop(wl["frames"])[:a.frames]
+    poses = synth.camera_loop(wl.get("loop", wl["frames"]))[:a.frames]
     prims = synth.room_primitives()
     verts = [synth.render_room_verts(p, Wd, Ht, prims, device=dev) for p in poses]
     stream = torch.cuda.Stream(device=dev)

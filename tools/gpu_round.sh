@@ -1,0 +1,15 @@
+#!/bin/bash
+# One GPU-box session: the gpu test suite, the default bench line, and the profile passes.
+#   tools/gpu_round.sh r02 [skip-tests]
+set -u
+TAG=${1:-r02}
+OUT=gpurun_out/$TAG; mkdir -p $OUT
+if [ "${2:-}" != "skip-tests" ]; then
+  timeout 1800 python -m pytest tests -m gpu -q --durations=20 -x > $OUT/gputest.log 2>&1
+  echo "pytest exit $?" >> $OUT/gputest.log
+  tail -40 $OUT/gputest.log
+fi
+timeout 900 python bench.py > $OUT/bench_default.log 2>&1; echo "bench exit $?"
+grep '"metric"' $OUT/bench_default.log > $OUT/bench_default.json; tail -c 3000 $OUT/bench_default.log
+timeout 900 bash tools/profile_round.sh $TAG C2 > $OUT/profile_C2.log 2>&1; tail -25 $OUT/profile_C2.log
+timeout 900 bash tools/profile_round.sh $TAG C3 > $OUT/profile_C3.log 2>&1; tail -12 $OUT/profile_C3.log
