@@ -46,7 +46,8 @@ typedef struct Voxel { float sdf; float weight; } Voxel;
 typedef struct VoxelEntry {
     int32_t pos[3];   /* int3 pos: block coordinate */
     int32_t ptr;      /* first voxel index of the block in the volume, -1 = free */
-    int32_t offset;   /* linked-list offset; always 0 (list code is dead) */
+    int32_t offset;   /* overflow chain link, measured from the home bucket's last slot; 0 = none (always 0
+                         unless the option "overflow_list" is on: the list code is dead in the reference) */
 } VoxelEntry;
 
 /* VoxelDataStructures.h:29-52; 176 bytes.  Matrices are row-major float4x4. */
@@ -55,15 +56,15 @@ typedef struct HashTableParams {
     float    inv_global_transform[16];
     uint32_t numBuckets;
     uint32_t bucketSize;
-    uint32_t attachedLinkedListSize;   /* unused (dead list code) */
+    uint32_t attachedLinkedListSize;   /* iterations of the chain lookup loop (option "overflow_list"; dead code in the reference) */
     uint32_t numVoxelBlocks;
     int32_t  voxelBlockSize;           /* must be 8 */
     float    voxelSize;
     uint32_t numOccupiedBlocks;
     float    maxIntegrationDistance;   /* unused by the reference kernels */
-    float    truncScale;               /* unused by the reference kernels */
+    float    truncScale;               /* unused by the reference kernels (option "depth_truncation") */
     float    truncation;
-    uint32_t integrationWeightSample;  /* unused by the reference kernels */
+    uint32_t integrationWeightSample;  /* unused by the reference kernels (option "weight_sample") */
     float    integrationWeightMax;
 } HashTableParams;
 
@@ -188,6 +189,27 @@ int vh_set_raycast_intrinsics(vh_context *ctx, float fx, float fy, float cx, flo
  * 4 voxels; the middle sample is the surface point itself.  0 (default) = the reference's
  * surface-block-only allocation.  One insertion per bucket per frame still holds. */
 int vh_set_alloc_band(vh_context *ctx, float band_metres);
+
+/* Opt-in extensions, all off by default (= the live reference path), chosen with vh_set_option:
+ *   "overflow_list" 1   the bucket overflow list the reference carries as dead code (#ifdef LINKED_LIST_ENABLED,
+ *                       VoxelUtils.cu:384-411 lookup, :458-539 insert, :578-602 delete): a key whose home bucket is
+ *                       full goes to a free slot among the 9 slots behind the bucket (never another bucket's last
+ *                       slot) and is chained from the home bucket's last slot through VoxelEntry::offset, at most
+ *                       params.attachedLinkedListSize - 1 chained entries per bucket; both buckets are locked for
+ *                       the frame; deletion leaves holes instead of compacting.  Must be set before the first
+ *                       frame.  A shard's chains stay inside the shard.  With the list on, vh_alloc_blocks may run
+ *                       once per lock epoch (several cameras per epoch: vh_insert_bins / vh_apply_frames_batch).
+ *   "band_mode"         VH_BAND_RAY (default: vh_set_alloc_band's samples along the viewing ray) or
+ *                       VH_BAND_NORMAL_DDA: every block the segment from p - band*n to p + band*n crosses, by a
+ *                       block DDA (commented out in the reference, VoxelUtils.cu:632-703); n comes from the
+ *                       d_normals argument of vh_alloc_blocks / vh_integrate (preProcess's normal map, camera
+ *                       frame), pixels without a normal demand their surface block only.  Not offered by
+ *                       vh_integrate_depth and the key-generation calls (they carry no normal map).
+ *   "depth_truncation" 1   truncation + truncScale * depth in the TSDF update (VoxelUtils.cu:815, getTruncation)
+ *   "weight_sample" 1      sample weight max(integrationWeightSample * 1.5 * (1 - (depth - 0.5) / 4.5), 1) instead of
+ *                          0.1 (VoxelUtils.cu:808-811, :827) */
+#define VH_BAND_RAY        0
+#define VH_BAND_NORMAL_DDA 1
 
 /* SDF_Hashtable.cpp:15-21: stores the pose and its cofactor inverse
  * (cuda_SimpleMatrixUtil.h:944-1069, same summation order, fp32, on the host) */

@@ -1247,10 +1247,41 @@ int vho_import_view(vho_table *view, const uint8_t *records, int count)
         const uint32_t h = vho_hash(head[0], head[1], head[2], view->p.numBuckets);
         uint32_t s = 0;
         while (s < bs && view->table[(size_t)h * bs + s].ptr != VHO_FREE_BLOCK) ++s;
-        if (s == bs) { ++dropped; continue; }
+        const int32_t ptr = i * (VHO_VIEW_RECORD_BYTES / 8) + 2;   /* in voxels from the start of records */
+        if (s == bs) {
+            /* with the overflow list on, the shards' table holds chains: the record goes behind its full
+             * bucket like an insertion (insert_entry_overflow), without the locks */
+            if (!view->overflow) { ++dropped; continue; }
+            const uint32_t L = view->p.attachedLinkedListSize;
+            const size_t last = (size_t)h * bs + bs - 1;
+            size_t base, n, at = last;
+            chain_segment(view, h, &base, &n);
+            uint32_t links = 0;
+            int ended = 0;
+            for (uint32_t iter = 0; iter < L; ++iter) {
+                if (view->table[at].offset == 0) { ended = 1; break; }
+                at = chain_slot(last, view->table[at].offset, base, n);
+                ++links;
+            }
+            int64_t target = -1;
+            int32_t tj = 0;
+            if (ended && L >= 2 && links + 1 <= L - 1)
+                for (int32_t j = 1; j < 10; ++j) {
+                    const size_t q = chain_slot(last, j, base, n);
+                    if (q % bs == bs - 1) continue;
+                    if (view->table[q].ptr == VHO_FREE_BLOCK) { target = (int64_t)q; tj = j; break; }
+                }
+            if (target < 0) { ++dropped; continue; }
+            vho_entry *e = &view->table[target];
+            e->pos[0] = head[0]; e->pos[1] = head[1]; e->pos[2] = head[2];
+            e->ptr = ptr;
+            e->offset = view->table[last].offset;
+            view->table[last].offset = tj;
+            continue;
+        }
         vho_entry *e = &view->table[(size_t)h * bs + s];
         e->pos[0] = head[0]; e->pos[1] = head[1]; e->pos[2] = head[2];
-        e->ptr = i * (VHO_VIEW_RECORD_BYTES / 8) + 2;       /* in voxels from the start of records */
+        e->ptr = ptr;
         e->offset = 0;
     }
     return dropped;

@@ -1,0 +1,251 @@
+"""The opt-in extensions of SURVEY.md 8(f) next #2 on the GPU, against the oracle: overflow linked
+list (slot-exact including the chain links in VoxelEntry::offset), normal-directed block DDA band,
+depth-dependent truncation and sample weight.  tests/test_overflow_cpu.py pins the oracle's side."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import _compare
+from test_overflow_cpu import _plane_scene, chains_ok
+from voxelhashing_demo_amd import dist as vdist
+from voxelhashing_demo_amd import synth
+
+pytestmark = pytest.mark.gpu
+I4 = np.eye(4, dtype=np.float32)
+VARIANTS = {"fused-ballot-walk": (1, 3), "four-kernel-persistent-walk": (0, 5), "fused-indexed-walk": (1, 4)}
+
+
+def pair(oracle, vh, variant, W=640, H=480, sem=0, overflow=True, **kw):
+    ot = oracle.OracleTable(oracle.default_params(**kw), W, H, sem)
+    gt = vh.SDFHashtable(vh.default_params(**kw), W, H, sem)
+    fused, walk = VARIANTS[variant]
+    gt.set_option("fused_frame", fused)
+    gt.set_option("flatten_variant", walk)
+    if overflow:
+        ot.set_overflow(True)
+        gt.set_option("overflow_list", 1)
+    return ot, gt
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("nb,bs,L", [(48, 5, 6), (64, 4, 4), (96, 2, 8)])
+def test_overflow_list_collision_scene(oracle, vh, torch_cuda, variant, nb, bs, L):
+    """G5's collision scene with the list on: frame by frame the same slots, the same chain links."""
+    torch = torch_cuda
+    ot, gt = pair(oracle, vh, variant, numBuckets=nb, bucketSize=bs, numVoxelBlocks=1024, attachedLinkedListSize=L)
+    verts = synth.sphere_inside_scene()
+    d_verts = torch.from_numpy(verts).cuda()
+    prev = -1
+    for f in range(40):
+        ot.integrate(I4, verts)
+        gt.integrate(I4, d_verts)
+        gt.synchronize()
+        _compare(ot, gt)
+        n = len(gt.allocated())
+        if n == prev:
+            break
+        prev = n
+    assert n == prev and (gt.hash_table()["offset"] != 0).sum() >= 5
+    chains_ok(oracle, ot)
+    if (nb, bs, L) == (48, 5, 6):
+        assert n == 150
+    assert gt.counters()["cand_overflow"] == 0
+
+
+@pytest.mark.parametrize("variant", ["fused-ballot-walk", "four-kernel-persistent-walk"])
+def test_overflow_delete_and_collect(oracle, vh, torch_cuda, variant):
+    """Deleting heads with followers, chained entries and plain slots; then garbage collection; then
+    fusing on -- the table stays equal to the oracle's slot for slot."""
+    torch = torch_cuda
+    ot, gt = pair(oracle, vh, variant, numBuckets=48, bucketSize=5, numVoxelBlocks=1024, attachedLinkedListSize=6)
+    verts = synth.sphere_inside_scene()
+    d_verts = torch.from_numpy(verts).cuda()
+    for _ in range(12):
+        ot.integrate(I4, verts)
+        gt.integrate(I4, d_verts)
+    gt.synchronize()
+    _compare(ot, gt)
+    tab = ot.hash_table()
+    heads = [i for i in range(4, len(tab), 5) if tab[i]["ptr"] != -1 and tab[i]["offset"] != 0]
+    chained = [int(i) for i in np.nonzero(tab["ptr"] != -1)[0]
+               if oracle.hash_block(*[int(c) for c in tab[i]["pos"]], 48) != i // 5]
+    plain = [int(i) for i in np.nonzero(tab["ptr"] != -1)[0] if i % 5 == 2][:5]
+    assert len(heads) >= 3 and len(chained) >= 5
+    doomed = sorted(set(heads[:3] + chained[1::2] + plain))
+    keys = np.zeros((len(doomed) + 1, 4), np.int32)
+    keys[:-1, :3] = tab["pos"][doomed]
+    keys[-1, :3] = (77, 77, 77)                                       # absent
+    freed = ot.delete_blocks([tuple(k[:3]) for k in keys.tolist()])
+    gt.delete_blocks(torch.from_numpy(keys).cuda())
+    gt.synchronize()
+    assert gt.counters()["last_freed"] == freed == len(doomed)
+    _compare(ot, gt)
+    chains_ok(oracle, ot)
+    for _ in range(6):                                                # the keys come back
+        ot.integrate(I4, verts)
+        gt.integrate(I4, d_verts)
+    gt.synchronize()
+    _compare(ot, gt)
+    # collection of everything the last frame saw that holds no surface (threshold 0.05)
+    a = ot.garbage_collect(0.05)
+    gt.garbage_collect(0.05)
+    gt.synchronize()
+    assert gt.counters()["last_freed"] == a > 0
+    _compare(ot, gt)
+    chains_ok(oracle, ot)
+    for _ in range(4):
+        ot.integrate(I4, verts)
+        gt.integrate(I4, d_verts)
+    gt.synchronize()
+    _compare(ot, gt)
+    # pool partition on the GPU side
+    alloc = gt.allocated()
+    heap = gt.heap()[:gt.counters()["heap_counter"] + 1]
+    assert len(set(heap.tolist()) | set((alloc["ptr"] // 512).tolist())) == 1024 and len(heap) + len(alloc) == 1024
+
+
+def test_overflow_raycast_and_snapshot(oracle, vh, torch_cuda, tmp_path):
+    """Lookups follow the chains: the raycast of a table with chains equals the oracle's; a snapshot
+    carries the chains and refuses to load into a context without the list."""
+    torch = torch_cuda
+    W, H = 320, 240
+    kw = dict(numBuckets=512, bucketSize=2, numVoxelBlocks=4096, attachedLinkedListSize=8)
+    ot, gt = pair(oracle, vh, "fused-ballot-walk", W, H, 1, **kw)
+    poses = synth.camera_loop(60)
+    prims = synth.room_primitives()
+    for i in range(0, 24, 3):
+        v = synth.render_room_verts(poses[i], W, H, prims).numpy()
+        ot.integrate(poses[i], v)
+        gt.integrate(poses[i], torch.from_numpy(v).cuda())
+    gt.synchronize()
+    _compare(ot, gt)
+    assert (gt.hash_table()["offset"] != 0).sum() > 20
+    depth = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    gt.raycast(poses[21], depth)
+    gt.synchronize()
+    ref = ot.raycast(poses[21])
+    assert (ref > 0).mean() > 0.5 and np.array_equal(depth.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    snap = tmp_path / "chains.vhsnap"
+    gt.save_snapshot(snap)
+    plain = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
+    with pytest.raises(vh.VoxelHashError, match="overflow"):
+        plain.load_snapshot(snap)
+    plain.close()
+    again = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
+    again.set_option("overflow_list", 1)
+    again.load_snapshot(snap)
+    v = synth.render_room_verts(poses[27], W, H, prims).numpy()
+    ot.integrate(poses[27], v)
+    again.integrate(poses[27], torch.from_numpy(v).cuda())
+    again.synchronize()
+    _compare(ot, again)
+    with pytest.raises(vh.VoxelHashError, match="before the first frame"):
+        again.set_option("overflow_list", 0)
+
+
+@pytest.mark.parametrize("world,calls", [(2, "batched"), (4, "stepwise")])
+def test_overflow_on_shards(oracle, vh, torch_cuda, world, calls):
+    """Bucket-range shards with the list on: chains wrap inside a shard; R HIP shards equal ONE oracle
+    table whose chains wrap inside segments of the shard size; the raycast over the shards (view
+    tables with chains of their own) equals the oracle's raycast of that table."""
+    torch = torch_cuda
+    W, H = 160, 120
+    kw = dict(numBuckets=512, bucketSize=2, numVoxelBlocks=4096, attachedLinkedListSize=8)
+    plan = vdist.ShardPlan(kw["numBuckets"], world)
+    shards = [vdist.HipShard(vh.default_params(**kw), W, H, 1, plan, r, W * H, batched_calls=(calls == "batched"))
+              for r in range(world)]
+    full = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    full.set_overflow(True, plan.per_shard)
+    for sh in shards:
+        sh.table.set_option("overflow_list", 1)
+    prims = synth.room_primitives()
+    poses = None
+    for step in range(6):
+        cams = []
+        for r in range(world):
+            pose = synth.camera_loop(40, phase=vdist.camera_phase(r, world))[(3 * step) % 40]
+            cams.append((pose, synth.render_room_verts(pose, W, H, prims).numpy()))
+        vdist.loopback_step(shards, [[c[0]] for c in cams], [[torch.from_numpy(c[1]).cuda()] for c in cams])
+        vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+        poses = [c[0] for c in cams]
+    ftab, fvol = full.hash_table(), full.sdf_blocks()
+    total = 0
+    for r, sh in enumerate(shards):
+        sh.table.synchronize()
+        lo, hi = plan.bucket_range(r)
+        mine = sh.table.hash_table()
+        want = ftab[lo * 2:hi * 2]
+        assert np.array_equal(mine["pos"], want["pos"]) and np.array_equal(mine["offset"], want["offset"])
+        assert np.array_equal(mine["ptr"] != -1, want["ptr"] != -1)
+        for i in np.nonzero(mine["ptr"] != -1)[0][::3]:
+            assert np.array_equal(sh.table.block_voxels(int(mine["ptr"][i])).view(np.uint32),
+                                  fvol[int(want["ptr"][i]):int(want["ptr"][i]) + 512].view(np.uint32))
+        total += int((mine["ptr"] != -1).sum())
+        assert sh.table.counters()["bin_overflow"] == 0
+    assert total == len(full.allocated()) and (ftab["offset"] != 0).sum() > 10
+    views = [vdist.HipViewTable(vh.default_params(**kw), W, H, 1, world, 4096) for _ in range(world)]
+    for v in views:
+        v.table.set_option("overflow_list", 1)
+    depths = vdist.loopback_raycast(shards, views, poses, capacity=4096)
+    for r in range(world):
+        assert views[r].table.counters()["bin_overflow"] == 0
+        assert np.array_equal(depths[r].view(np.uint32), full.raycast(poses[r]).view(np.uint32)), r
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_normal_dda_band(oracle, vh, torch_cuda, variant):
+    """Band allocation by the block DDA along the normal: a tilted plane with an analytic normal map,
+    then the room with the normal maps preProcess makes, moving camera -- slot-exact."""
+    torch = torch_cuda
+    W, H = 160, 120
+    verts, normals, _ = _plane_scene(W, H)
+    ot, gt = pair(oracle, vh, variant, W, H, 1, overflow=False, numBuckets=1 << 14, numVoxelBlocks=1 << 14)
+    ot.set_alloc_band(0.2, oracle.BAND_NORMAL_DDA)
+    gt.set_alloc_band(0.2)
+    gt.set_option("band_mode", 1)
+    dv, dn = torch.from_numpy(verts).cuda(), torch.from_numpy(normals).cuda()
+    for _ in range(4):
+        ot.integrate(I4, verts, normals)
+        gt.integrate(I4, dv, dn)
+        gt.synchronize()
+        _compare(ot, gt)
+    assert len(gt.allocated()) > 300
+    # room scene: sensor depth -> preProcess maps on the GPU, the same bits handed to the oracle
+    W, H = 320, 240
+    ot, gt = pair(oracle, vh, variant, W, H, 1, overflow=False, numBuckets=1 << 15, numVoxelBlocks=1 << 15)
+    ot.set_alloc_band(0.1, oracle.BAND_NORMAL_DDA)
+    gt.set_alloc_band(0.1)
+    gt.set_option("band_mode", 1)
+    kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+    poses = synth.camera_loop(60)
+    prims = synth.room_primitives()
+    for i in (0, 2, 4, 9):
+        z = synth.render_room_verts(poses[i], W, H, prims)[..., 2]
+        d16 = (z * 5000.0).round().clamp(0, 65535).to(torch.uint16).cuda()
+        dv, dn = torch.empty((H, W, 4), device="cuda"), torch.empty((H, W, 4), device="cuda")
+        vh.preprocess(d16, kinv, dv, dn)
+        torch.cuda.synchronize()
+        ot.integrate(poses[i], dv.cpu().numpy(), dn.cpu().numpy())
+        gt.integrate(poses[i], dv, dn)
+        gt.synchronize()
+        _compare(ot, gt)
+    assert len(gt.allocated()) > 1500
+
+
+def test_tsdf_update_variants(oracle, vh, torch_cuda):
+    """depth_truncation (VoxelUtils.cu:815) and weight_sample (:827): bit-exact voxels."""
+    torch = torch_cuda
+    kw = dict(numBuckets=1 << 14, numVoxelBlocks=4096, truncation=0.04, truncScale=0.02, integrationWeightSample=10)
+    for flags in (1, 2, 3):
+        ot, gt = pair(oracle, vh, "fused-ballot-walk", sem=1, overflow=False, **kw)
+        ot.set_integrate_flags(flags)
+        gt.set_option("depth_truncation", flags & 1)
+        gt.set_option("weight_sample", (flags >> 1) & 1)
+        verts = synth.sphere_inside_scene()
+        d_verts = torch.from_numpy(verts).cuda()
+        for _ in range(3):
+            ot.integrate(I4, verts)
+            gt.integrate(I4, d_verts)
+        gt.synchronize()
+        _compare(ot, gt)
+        w = gt.sdf_blocks()["weight"]
+        assert (w.max() > 25.0) == bool(flags & 2)

@@ -13,9 +13,61 @@ namespace vh {
 // Allocated entries always form a prefix of the bucket (insertions take the
 // first free slot, deletion closes the gap: vh_gc.hip), so "present anywhere" equals the
 // reference's in-order scan.
+// The same with the overflow list on (kFlagOverflow; oracle: insert_entry_overflow).  A bucket's entries
+// no longer form a prefix (deletion leaves holes), so all slots are scanned; the chain behind the
+// bucket's last slot is walked with the reference's lookup loop; a key whose home bucket is full
+// looks for a free slot among the kLookAhead-1 slots behind it (never another bucket's last slot,
+// which heads that bucket's own chain) and then needs BOTH buckets: it stakes its claim on both and
+// commits only if it holds both (the reference locks the parent bucket, then the new one,
+// VoxelUtils.cu:472-482; both stay locked for the frame).
+__device__ __forceinline__ void probe_and_claim_overflow(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz,
+                                                         uint32_t h, uint32_t rank, int candCounter)
+{
+    const uint32_t local = h - fp.bucketLo, bs = fp.bucketSize, n = owned_entries(fp);
+    const uint32_t start = local * bs, last = start + bs - 1u;
+    bool has_free = false;
+    for (uint32_t i = 0; i < bs; ++i) {
+        const VoxelEntry e = dp.table[start + i];
+        if (entry_is(e, kx, ky, kz)) return;
+        has_free |= e.ptr == VH_FREE_BLOCK;
+    }
+    uint32_t links = 0, i = last;
+    bool ended = false;
+    for (uint32_t iter = 0; iter < fp.listSize; ++iter) {
+        const VoxelEntry curr = dp.table[i];
+        if (entry_is(curr, kx, ky, kz)) return;
+        if (curr.offset == 0) { ended = true; break; }
+        i = chain_slot(last, curr.offset, n);
+        ++links;
+    }
+    uint32_t target = ~0u;
+    if (!has_free) {
+        if (!ended || fp.listSize < 2u || links + 1u > fp.listSize - 1u) return;    // chain at the reach of the lookup loop
+        for (int j = 1; j < kLookAhead; ++j) {                                     // :475-478
+            const uint32_t s = chain_slot(last, j, n);
+            if (s % bs == bs - 1u) continue;
+            if (dp.table[s].ptr == VH_FREE_BLOCK) { target = s; break; }
+        }
+        if (target == ~0u) return;
+    }
+    const uint32_t slot = (uint32_t)atomicAdd(dp.counters + candCounter, 1);
+    if (slot >= dp.candCapacity) {
+        atomicAdd(dp.counters + kCandOverflow, 1);
+        return;
+    }
+    dp.candidates[slot] = make_int4(kx, ky, kz, (int)rank);
+    dp.candTarget[slot] = target;
+    atomicMax(dp.claim + local, claim_word(fp.epoch, rank));
+    if (target != ~0u) atomicMax(dp.claim + target / bs, claim_word(fp.epoch, rank));
+}
+
 __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz,
                                                 uint32_t h, uint32_t rank, int candCounter = kCandCount)
 {
+    if (fp.flags & kFlagOverflow) {
+        probe_and_claim_overflow(fp, dp, kx, ky, kz, h, rank, candCounter);
+        return;
+    }
     const VoxelEntry *bucket = dp.table + (size_t)(h - fp.bucketLo) * fp.bucketSize;
     bool has_free = false;
     for (uint32_t i = 0; i < fp.bucketSize; ++i) {
@@ -57,6 +109,7 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
 // a block edge; the middle sample is the surface point itself.  b = 0: that sample only.
 struct PixelVertex {
     float4 v;
+    float4 n;           // normal (kFlagBandDda only)
     int px, py;
     uint32_t rank;      // launch rank of the pixel = tile*256 + t
     bool valid;
@@ -76,6 +129,11 @@ __device__ __forceinline__ int band_samples(const FrameParams &fp, float &step)
 // 63-73, evaluated in place -- 2 bytes per pixel read instead of 16, no vertex map in memory).
 struct VertexMap {
     const float4 *__restrict__ verts;
+    const float4 *__restrict__ normals;      // preProcess's normal map (camera frame), read by the DDA band only; may be null
+    __device__ __forceinline__ float4 normal(int idx) const
+    {
+        return normals ? normals[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // non-temporal: a vertex map is streamed once per frame, and keeping it out of the Infinity Cache
     // leaves more of the hash table there for the walk (launch 1: 17.5 -> 17.2 us)
     __device__ __forceinline__ float4 vertex(int idx, int, int) const
@@ -90,6 +148,7 @@ struct SensorImage {
     const uint16_t *__restrict__ depth;
     float k[9];              // K_inv, row-major
     float unit;              // 5000 = 1 m
+    __device__ __forceinline__ float4 normal(int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }   // no normal map
     __device__ __forceinline__ float4 vertex(int idx, int px, int py) const
     {
         const float d = (float)depth[idx] / unit;                                   // :64
@@ -111,7 +170,7 @@ template <class In>
 __device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const In &in, uint32_t tile, uint32_t t,
                                                   float *__restrict__ outDepth)
 {
-    PixelVertex p{make_float4(0.f, 0.f, 0.f, 0.f), 0, 0, (tile << 8) + t, false};
+    PixelVertex p{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), 0, 0, (tile << 8) + t, false};
     const uint32_t tilesX = (uint32_t)(fp.width + 15) >> 4;
     const uint32_t by = tile / tilesX, bx = tile - by * tilesX;
     p.px = (int)(bx * 16u + (t & 15u));
@@ -119,6 +178,7 @@ __device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const I
     if (p.px < fp.width && p.py < fp.height) {          // (a tile index past the grid gives py >= height)
         const int idx = p.py * fp.width + p.px;
         p.v = in.vertex(idx, p.px, p.py);
+        if ((fp.flags & kFlagBandDda) && fp.allocBand > 0.0f) p.n = in.normal(idx);
         if (outDepth) outDepth[idx] = p.v.z;                             // camera-z plane of a camera packet
         p.valid = p.v.z != 0.0f;                                         // VoxelUtils.cu:621
     }
@@ -130,28 +190,111 @@ struct SampleKey {
     bool leader;       // this lane must probe / emit the key
 };
 
-// Key of band sample k of this lane's pixel, de-duplicated against the lane's own previous
+// The keys one pixel demands, in rank order (sample index k):
+//   ray band (default)   2*half+1 points on the viewing ray, half-block steps, see above
+//   DDA band             kFlagBandDda: every block the segment from p - b*n to p + b*n crosses, by a
+//                        block DDA -- what the reference has commented out in allocBlocksKernel
+//                        (VoxelUtils.cu:632-633 the two ends, :641-668 step / tMax / tDelta, :678-699 the
+//                        walk).  p = the pixel's world point, n = its normal rotated into the world frame.
+//                        The segment is parametrised over [0,1] (no normalisation, no square root); block
+//                        k covers world [(8k - 0.5) * voxelSize, (8k + 7.5) * voxelSize) on an axis, which is
+//                        what world2Block's rounding maps to k; ties as in :683-698; the walk ends at the end
+//                        block, after 62 steps, or when the next crossing lies beyond the segment.  A pixel
+//                        without a normal demands its surface block only.  Oracle: dda_keys.
+struct BandWalk {
+    int nS;             // ray band: number of samples (wave-uniform)
+    float step;
+    bool dda;           // wave-uniform
+    // DDA state of this lane
+    int cur[3], end[3], st[3];
+    float tmax[3], tdelta[3];
+    bool more;          // the walk has not ended
+
+    __device__ __forceinline__ void init(const FrameParams &fp, const PixelVertex &p)
+    {
+        nS = band_samples(fp, step);
+        dda = (fp.flags & kFlagBandDda) && fp.allocBand > 0.0f;
+        more = false;
+        if (!dda || !p.valid) return;
+        const float4 g = mat4_mul(fp.T, p.v.x, p.v.y, p.v.z, p.v.w);                 // :622, w as stored
+        const int3_ sb = world2block(g.x, g.y, g.z, fp.voxelSize);
+        cur[0] = sb.x; cur[1] = sb.y; cur[2] = sb.z;
+        end[0] = sb.x; end[1] = sb.y; end[2] = sb.z;
+        const float nx = p.n.x, ny = p.n.y, nz = p.n.z;
+        if ((nx == 0.0f && ny == 0.0f && nz == 0.0f) || nx != nx || ny != ny || nz != nz) return;   // surface block only
+        const float gw[3] = {g.x, g.y, g.z};
+        float start[3], dir[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float nw = fp.T[4 * a + 0] * nx + fp.T[4 * a + 1] * ny + fp.T[4 * a + 2] * nz;
+            start[a] = gw[a] - (fp.allocBand * nw);                                   // :632
+            const float e = gw[a] + (fp.allocBand * nw);                              // :633
+            dir[a] = e - start[a];
+            cur[a] = voxel2block1(world2voxel1(start[a], fp.voxelSize));
+            end[a] = voxel2block1(world2voxel1(e, fp.voxelSize));
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            st[a] = dir[a] > 0.0f ? 1 : dir[a] < 0.0f ? -1 : 0;
+            if (st[a] == 0) { tmax[a] = __builtin_inff(); tdelta[a] = __builtin_inff(); continue; }   // :658-668
+            const float boundary = ((float)(int)((uint32_t)(cur[a] + (st[a] > 0 ? 1 : 0)) * 8u) - 0.5f) * fp.voxelSize;
+            tmax[a] = (boundary - start[a]) / dir[a];
+            tdelta[a] = (8.0f * fp.voxelSize) / __builtin_fabsf(dir[a]);
+        }
+        more = true;
+    }
+
+    // sample k of this lane's pixel: true if there is one (key in kx,ky,kz).  Must be called for k = 0, 1, 2, ...
+    __device__ __forceinline__ bool key(const FrameParams &fp, const PixelVertex &p, int k, int &kx, int &ky, int &kz)
+    {
+        if (!p.valid) return false;
+        if (dda) {
+            if (k == 0) { kx = cur[0]; ky = cur[1]; kz = cur[2]; return true; }
+            if (!more) return false;
+            if (cur[0] == end[0] && cur[1] == end[1] && cur[2] == end[2]) { more = false; return false; }
+            int a;
+            if (tmax[0] < tmax[1] && tmax[0] < tmax[2]) a = 0;                        // :683
+            else if (tmax[2] < tmax[1]) a = 2;                                        // :688
+            else a = 1;                                                               // :693
+            const float t = a == 0 ? tmax[0] : a == 1 ? tmax[1] : tmax[2];
+            if (!(t <= 1.0f)) { more = false; return false; }
+            if (a == 0) { cur[0] = (int)((uint32_t)cur[0] + (uint32_t)st[0]); tmax[0] += tdelta[0]; }
+            else if (a == 1) { cur[1] = (int)((uint32_t)cur[1] + (uint32_t)st[1]); tmax[1] += tdelta[1]; }
+            else { cur[2] = (int)((uint32_t)cur[2] + (uint32_t)st[2]); tmax[2] += tdelta[2]; }
+            kx = cur[0]; ky = cur[1]; kz = cur[2];
+            return true;
+        }
+        if (k >= nS) return false;
+        const int half = (nS - 1) / 2;
+        const float s = p.v.z + ((float)k - (float)half) * step;
+        if (!(k == half || s > 0.0f)) return false;                      // the surface sample is never filtered (:621 only tests z != 0)
+        float x = p.v.x, y = p.v.y, z = p.v.z;                           // k == half: the vertex itself, bit for bit
+        if (k != half) {                                                 // wave-uniform; no divide on the reference path
+            const float scale = s / p.v.z;
+            x = p.v.x * scale; y = p.v.y * scale; z = s;
+        }
+        const float4 g = mat4_mul(fp.T, x, y, z, p.v.w);                 // :622, w as stored
+        const int3_ b = world2block(g.x, g.y, g.z, fp.voxelSize);        // :636
+        kx = b.x; ky = b.y; kz = b.z;
+        return true;
+    }
+
+    // wave-uniform: is there any lane that may still produce a sample with index >= k?
+    __device__ __forceinline__ bool wave_done(int k) const
+    {
+        if (!dda) return k >= nS;
+        return k >= kMaxBandSamples - 1 || (k > 0 && __ballot(more) == 0ull);
+    }
+};
+
+// Sample k of this lane's pixel, frustum-tested and de-duplicated against the lane's own previous
 // sample and against sample k of the lanes to the left and above (see the header comment).
-__device__ __forceinline__ SampleKey sample_key(const FrameParams &fp, const PixelVertex &p, int k, int nS, float step,
+__device__ __forceinline__ SampleKey sample_key(const FrameParams &fp, const PixelVertex &p, BandWalk &walk, int k,
                                                 int &ownX, int &ownY, int &ownZ, bool &ownHave)
 {
     SampleKey r{0, 0, 0, false};
-    bool want = false;
-    if (p.valid) {
-        const int half = (nS - 1) / 2;
-        const float s = p.v.z + ((float)k - (float)half) * step;
-        if (k == half || s > 0.0f) {                                     // the surface sample is never filtered (:621 only tests z != 0)
-            float x = p.v.x, y = p.v.y, z = p.v.z;                       // k == half: the vertex itself, bit for bit
-            if (k != half) {                                             // wave-uniform; no divide on the reference path
-                const float scale = s / p.v.z;
-                x = p.v.x * scale; y = p.v.y * scale; z = s;
-            }
-            const float4 g = mat4_mul(fp.T, x, y, z, p.v.w);             // :622, w as stored
-            const int3_ b = world2block(g.x, g.y, g.z, fp.voxelSize);    // :636
-            r.kx = b.x; r.ky = b.y; r.kz = b.z;
-            want = block_in_frustum(fp, r.kx, r.ky, r.kz);               // :673
-        }
-    }
+    bool want = walk.key(fp, p, k, r.kx, r.ky, r.kz);
+    if (want) want = block_in_frustum(fp, r.kx, r.ky, r.kz);             // :673
     const bool dupOwn = want && ownHave && ownX == r.kx && ownY == r.ky && ownZ == r.kz;
     if (want) { ownX = r.kx; ownY = r.ky; ownZ = r.kz; ownHave = true; }
     const int lane = threadIdx.x & (kWave - 1);
@@ -175,12 +318,12 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
                                            int candCounter)
 {
     const PixelVertex p = load_pixel(fp, in, tile, threadIdx.x, nullptr);
-    float step;
-    const int nS = band_samples(fp, step);
+    BandWalk walk;
+    walk.init(fp, p);
     int ox = 0, oy = 0, oz = 0;
     bool oh = false;
-    for (int k = 0; k < nS; ++k) {
-        const SampleKey s = sample_key(fp, p, k, nS, step, ox, oy, oz, oh);
+    for (int k = 0; !walk.wave_done(k); ++k) {
+        const SampleKey s = sample_key(fp, p, walk, k, ox, oy, oz, oh);
         if (!s.leader) continue;
         const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
         if (h < fp.bucketLo || h >= fp.bucketHi) continue;              // not this shard's bucket
@@ -215,15 +358,17 @@ __device__ __forceinline__ void generate_keys_tile(const FrameParams &fp, const 
     __shared__ int ldsCount[VH_MAX_CAMERAS];
     __shared__ int ldsBase[VH_MAX_CAMERAS];
     const PixelVertex p = load_pixel(fp, verts, group * kGenTiles + (threadIdx.x >> 8), threadIdx.x & 255u, outDepth);
-    float step;
-    const int nS = band_samples(fp, step);
+    BandWalk walk;
+    walk.init(fp, p);
     const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
     int ox = 0, oy = 0, oz = 0;
     bool oh = false;
-    for (int k = 0; k < nS; ++k) {
+    // (the ray band's sample count is the same for every lane of the workgroup; the DDA band is not
+    // offered on this path: vh_generate_keys* carry no normal map)
+    for (int k = 0; k < walk.nS; ++k) {
         if (threadIdx.x < VH_MAX_CAMERAS) ldsCount[threadIdx.x] = 0;
         __syncthreads();
-        const SampleKey s = sample_key(fp, p, k, nS, step, ox, oy, oz, oh);
+        const SampleKey s = sample_key(fp, p, walk, k, ox, oy, oz, oh);
         uint32_t owner = 0;
         int local = 0;
         if (s.leader) {
@@ -251,7 +396,7 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_kernel(const FrameP
 {
     if (outDepth && blockIdx.x == 0 && threadIdx.x < kPacketHeader)      // packet header: pose, inverse
         outDepth[(int)threadIdx.x - kPacketHeader] = threadIdx.x < 16 ? fp.T[threadIdx.x] : fp.Tinv[threadIdx.x - 16];
-    generate_keys_tile(fp, VertexMap{verts}, numShards, outBins, outCapacity, outBinStride, outDepth, rankBase,
+    generate_keys_tile(fp, VertexMap{verts, nullptr}, numShards, outBins, outCapacity, outBinStride, outDepth, rankBase,
                        blockIdx.x);
 }
 
@@ -282,7 +427,7 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_batch_kernel(FrameP
         outDepth[(int)threadIdx.x - kPacketHeader] = threadIdx.x < 16 ? fr.T[b][threadIdx.x] : fr.Tinv[b][threadIdx.x - 16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { fp.T[i] = fr.T[b][i]; fp.Tinv[i] = fr.Tinv[b][i]; }
-    generate_keys_tile(fp, VertexMap{fr.verts[b]}, numShards, outBins + (size_t)frameStride * b, outCapacity,
+    generate_keys_tile(fp, VertexMap{fr.verts[b], nullptr}, numShards, outBins + (size_t)frameStride * b, outCapacity,
                        outBinStride, outDepth, rankBase, blockIdx.x);
 }
 
@@ -348,13 +493,39 @@ __device__ __forceinline__ uint32_t macro_hash(int mx, int my, int mz)
 }
 
 // Returns true (and the new entry) if candidate k held its bucket's claim and was inserted.
+// `index`: position of the candidate in dp.candidates (its look-ahead target sits beside it)
 __device__ __forceinline__ bool commit_candidate(const FrameParams &fp, const DevPtrs &dp, const int4 k,
-                                                 VoxelEntry &e)
+                                                 VoxelEntry &e, uint32_t index)
 {
     const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
     const uint32_t local = h - fp.bucketLo;
     if (dp.claim[local] != claim_word(fp.epoch, (uint32_t)k.w)) return false;   // lost the bucket this frame
     dp.claim[local] = consumed_word(fp.epoch);                                   // locked until the next epoch
+    const uint32_t target = (fp.flags & kFlagOverflow) ? dp.candTarget[index] : ~0u;
+    if (target != ~0u) {
+        // home bucket full: the entry goes to the free slot found behind it and to the FRONT of the
+        // bucket's chain -- if this contender also holds the bucket of that slot
+        const uint32_t tb = target / fp.bucketSize;
+        if (dp.claim[tb] != claim_word(fp.epoch, (uint32_t)k.w)) return false;  // the home bucket stays locked, as in the reference
+        dp.claim[tb] = consumed_word(fp.epoch);
+        const int addr = atomicSub(dp.counters + kHeapCounter, 1);
+        if (addr < 0) {
+            atomicAdd(dp.counters + kHeapCounter, 1);
+            atomicAdd(dp.counters + kHeapExhausted, 1);
+            return false;
+        }
+        const uint32_t last = local * fp.bucketSize + fp.bucketSize - 1u, n = owned_entries(fp);
+        e.pos[0] = k.x; e.pos[1] = k.y; e.pos[2] = k.z;
+        e.ptr = (int)(dp.heap[addr] * (uint32_t)kBlockVoxels);
+        e.offset = dp.table[last].offset;
+        dp.table[target] = e;
+        dp.table[last].offset = (int)(target >= last ? target - last : target + n - last);
+        atomicOr(dp.bucketBits + (tb >> 5), 1u << (tb & 31u));
+        const uint32_t hm = macro_hash(k.x >> 2, k.y >> 2, k.z >> 2);
+        atomicOr(dp.macroBits + (hm >> 5), 1u << (hm & 31u));
+        atomicAdd(dp.counters + kAllocatedTotal, 1);
+        return true;
+    }
     VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
     for (uint32_t s = 0; s < fp.bucketSize; ++s) {
         if (bucket[s].ptr != VH_FREE_BLOCK) continue;
@@ -383,7 +554,7 @@ __global__ __launch_bounds__(256) void alloc_commit_kernel(const FrameParams fp,
     if ((uint32_t)n > dp.candCapacity) n = (int)dp.candCapacity;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         VoxelEntry e;
-        (void)commit_candidate(fp, dp, dp.candidates[i], e);
+        (void)commit_candidate(fp, dp, dp.candidates[i], e, (uint32_t)i);
     }
     // the last workgroup to finish re-arms the per-frame counters
     __syncthreads();

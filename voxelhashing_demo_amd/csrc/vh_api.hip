@@ -84,6 +84,7 @@ struct vh_context {
     // C2  3: 17.2 + 5.1, 5: 17.7, 4: 6.4 + 5.3; C3  3: 88 + 22, 4: 43 + 19.
     int flattenVariant = 3;
     uint32_t candAllocated = 0;    // records the candidate buffer holds (dp.candCapacity <= this)
+    uint32_t allocEpoch = 0;       // lock epoch of the last allocBlocks (overflow list: one per epoch)
     int occupiedCounter = kCompactCount;   // which device counter holds the occupied count of the last frame
     // raycast over shards
     int32_t *viewLists = nullptr;          // export: selected entry indices, [views][capacity]
@@ -221,6 +222,8 @@ static int free_buffers(vh_context *c)
     if (c->dp.blocks) (void)hipFree(c->dp.blocks);
     if (c->dp.counters) (void)hipFree(c->dp.counters);
     if (c->dp.candidates) (void)hipFree(c->dp.candidates);
+    if (c->dp.candTarget) (void)hipFree(c->dp.candTarget);
+    if (c->dp.gcMarks) (void)hipFree(c->dp.gcMarks);
     if (c->dp.compactMask) (void)hipFree(c->dp.compactMask);
     if (c->dp.bucketBits) (void)hipFree(c->dp.bucketBits);
     if (c->dp.macroBits) (void)hipFree(c->dp.macroBits);
@@ -278,6 +281,10 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     fp.numVoxelBlocks = p.numVoxelBlocks;
     fp.epoch = 0;
     fp.allocBand = 0.0f;
+    fp.flags = 0;
+    fp.listSize = p.attachedLinkedListSize;
+    fp.truncScale = p.truncScale;
+    fp.weightSample = p.integrationWeightSample;
     default_projection(c);
 
     c->ownedBuckets = hi - lo;
@@ -303,6 +310,8 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     VH_ALLOC(dp.blocks, sizeof(Voxel) * (size_t)p.numVoxelBlocks * kBlockVoxels);
     VH_ALLOC(dp.counters, sizeof(int32_t) * kNumCounters);
     VH_ALLOC(dp.candidates, sizeof(int4) * npix);
+    VH_ALLOC(dp.candTarget, sizeof(uint32_t) * npix);
+    VH_ALLOC(dp.gcMarks, sizeof(uint32_t) * ((c->numEntries + 31) / 32));
     VH_ALLOC(dp.compactMask, sizeof(uint32_t) * c->numEntries);
     VH_ALLOC(dp.bucketBits, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32));
     VH_ALLOC(dp.macroBits, kMacroBits / 8);
@@ -318,6 +327,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     hipError_t e = hipMemsetAsync(dp.claim, 0, sizeof(unsigned long long) * (size_t)c->ownedBuckets, s);
     if (e == hipSuccess) e = hipMemsetAsync(dp.bucketBits, 0, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32), s);
     if (e == hipSuccess) e = hipMemsetAsync(dp.macroBits, 0, kMacroBits / 8, s);
+    if (e == hipSuccess) e = hipMemsetAsync(dp.gcMarks, 0, sizeof(uint32_t) * ((c->numEntries + 31) / 32), s);
     if (e == hipSuccess) e = hipMemsetAsync(dp.blocks, 0, sizeof(Voxel) * (size_t)p.numVoxelBlocks * kBlockVoxels, s);
     int32_t h_counters[kNumCounters] = {0};
     h_counters[kHeapCounter] = (int32_t)p.numVoxelBlocks - 1;               // :207
@@ -415,9 +425,16 @@ static int ensure_candidates(vh_context *c, size_t need)
     if (need > 0x7fffffffull) return fail(VH_ERR_INVALID_ARGUMENT, "candidate list too large");
     VH_HIP(hipStreamSynchronize(c->stream));
     int4 *fresh = nullptr;
+    uint32_t *freshTarget = nullptr;
     VH_HIP(hipMalloc((void **)&fresh, sizeof(int4) * need));
+    if (hipMalloc((void **)&freshTarget, sizeof(uint32_t) * need) != hipSuccess) {
+        (void)hipFree(fresh);
+        return fail(VH_ERR_OUT_OF_MEMORY, "hipMalloc candidate targets");
+    }
     (void)hipFree(c->dp.candidates);
+    (void)hipFree(c->dp.candTarget);
     c->dp.candidates = fresh;
+    c->dp.candTarget = freshTarget;
     c->dp.candCapacity = c->candAllocated = (uint32_t)need;
     return VH_OK;
 }

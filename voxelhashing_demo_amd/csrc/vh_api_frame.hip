@@ -105,11 +105,15 @@ static int launch_integrate(vh_context *c, const Depth &depth)
 
 extern "C" int vh_alloc_blocks(vh_context *c, const vh_float4 *verts, const vh_float4 *normals)
 {
-    (void)normals;   // loaded into a dead variable by the reference (VoxelUtils.cu:631)
+    // normals: loaded into a dead variable by the reference (VoxelUtils.cu:631); read only by the DDA band
     if (!c || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     if (c->fp.epoch == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
+    if ((c->fp.flags & kFlagOverflow) && c->allocEpoch == c->fp.epoch)
+        return fail(VH_ERR_INVALID_ARGUMENT, "with the overflow list on, allocBlocks runs once per lock epoch "
+                                             "(several cameras: vh_insert_bins / vh_apply_frames_batch)");
+    c->allocEpoch = c->fp.epoch;
     DeviceGuard guard(c->device);
-    int rc = launch_alloc(c, VertexMap{reinterpret_cast<const float4 *>(verts)});
+    int rc = launch_alloc(c, VertexMap{reinterpret_cast<const float4 *>(verts), reinterpret_cast<const float4 *>(normals)});
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -192,14 +196,14 @@ static int run_frame(vh_context *c, const In &in, const Depth &depth)
 
 extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4 *verts, const vh_float4 *normals)
 {
-    (void)normals;
     if (!c || !pose || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(c->device);
     int rc = vh_set_pose(c, pose);
     if (rc == VH_OK) rc = vh_reset_mutexes(c);
     if (rc != VH_OK) return rc;
+    c->allocEpoch = c->fp.epoch;
     const float4 *v = reinterpret_cast<const float4 *>(verts);
-    return run_frame(c, VertexMap{v}, vertex_depth(v));
+    return run_frame(c, VertexMap{v, reinterpret_cast<const float4 *>(normals)}, vertex_depth(v));
 }
 
 // The frame straight from the uint16 sensor image: preProcess's vertex computation happens inside
@@ -215,6 +219,7 @@ extern "C" int vh_integrate_depth(vh_context *c, const float pose[16], const uin
     in.depth = d_depth;
     std::memcpy(in.k, k_inv, sizeof in.k);
     in.unit = 5000.0f;                                                   // CameraTrackingUtils.cu:64
+    c->allocEpoch = c->fp.epoch;
     return run_frame(c, in, DepthSensor{in.depth, in.k[6], in.k[7], in.k[8], in.unit});
 }
 

@@ -6,7 +6,13 @@
 // ---------------------------------------------------------------------------
 static int sweep_and_release(vh_context *c)
 {
-    int rc = launch(c, kPhaseGc, gc_sweep_kernel, dim3(256), dim3(256), c->fp, c->dp);
+    int rc;
+    if (c->fp.flags & kFlagOverflow) {
+        rc = launch(c, kPhaseGc, gc_sweep_overflow_a_kernel, dim3(256), dim3(256), c->fp, c->dp);
+        if (rc == VH_OK) rc = launch(c, kPhaseGc, gc_sweep_overflow_b_kernel, dim3(256), dim3(256), c->fp, c->dp);
+    } else {
+        rc = launch(c, kPhaseGc, gc_sweep_kernel, dim3(256), dim3(256), c->fp, c->dp);
+    }
     if (rc != VH_OK) return rc;
     rc = launch(c, kPhaseGc, gc_release_kernel, dim3(1024), dim3(256), c->dp);
     if (rc != VH_OK) return rc;
@@ -295,6 +301,10 @@ extern "C" int vh_load_snapshot(vh_context *c, const char *path)
             return fail(VH_ERR_INVALID_ARGUMENT, "snapshot is corrupt: bad or duplicate block pointer");
         seen[e.ptr / kBlockVoxels] = 1;
         ++allocated;
+        if (e.offset != 0 && !(c->fp.flags & kFlagOverflow))
+            return fail(VH_ERR_INVALID_ARGUMENT, "snapshot holds overflow chains: set the option overflow_list before loading it");
+        if (e.offset < 0 || e.offset >= kLookAhead)
+            return fail(VH_ERR_INVALID_ARGUMENT, "snapshot is corrupt: chain offset out of range");
     }
     for (int64_t i = 0; i <= (int64_t)h.heapCounter; ++i) {
         if ((int64_t)heap[i] >= pool || seen[heap[i]])
@@ -358,6 +368,26 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
         if (value != kWalkStridedBallot && value != kWalkIndexed && value != kWalkPersistent)
             return fail(VH_ERR_INVALID_ARGUMENT, "flatten_variant: 3 (walk), 4 (occupancy index) or 5 (persistent walk)");
         c->flattenVariant = value;
+        return VH_OK;
+    }
+    if (std::strcmp(name, "overflow_list") == 0) {
+        // a table is built with the list or without it: the two keep different invariants (holes vs prefix)
+        if (c->fp.epoch != 0 && ((c->fp.flags & kFlagOverflow) != 0u) != (value != 0))
+            return fail(VH_ERR_INVALID_ARGUMENT, "overflow_list must be chosen before the first frame");
+        if (c->fp.listSize < 2 && value) return fail(VH_ERR_INVALID_ARGUMENT, "attachedLinkedListSize must be at least 2");
+        c->fp.flags = value ? (c->fp.flags | kFlagOverflow) : (c->fp.flags & ~kFlagOverflow);
+        return VH_OK;
+    }
+    if (std::strcmp(name, "band_mode") == 0 && (value == VH_BAND_RAY || value == VH_BAND_NORMAL_DDA)) {
+        c->fp.flags = value == VH_BAND_NORMAL_DDA ? (c->fp.flags | kFlagBandDda) : (c->fp.flags & ~kFlagBandDda);
+        return VH_OK;
+    }
+    if (std::strcmp(name, "depth_truncation") == 0) {
+        c->fp.flags = value ? (c->fp.flags | kFlagDepthTruncation) : (c->fp.flags & ~kFlagDepthTruncation);
+        return VH_OK;
+    }
+    if (std::strcmp(name, "weight_sample") == 0) {
+        c->fp.flags = value ? (c->fp.flags | kFlagWeightSample) : (c->fp.flags & ~kFlagWeightSample);
         return VH_OK;
     }
     if (std::strcmp(name, "cand_capacity") == 0 && value > 0) {     // test hook: a smaller candidate list

@@ -68,6 +68,10 @@ extern "C" int vh_import_view(vh_context *c, const vh_view_record *d_records, in
     if (c->fp.bucketLo != 0 || c->fp.bucketHi != c->fp.numBuckets)
         return fail(VH_ERR_INVALID_ARGUMENT, "a view table is unsharded");
     if (c->fp.epoch != 0) return fail(VH_ERR_INVALID_ARGUMENT, "this context has integrated frames: use a dedicated view context");
+    if ((size_t)count > c->candAllocated && (c->fp.flags & kFlagOverflow)) {
+        const int rc = ensure_candidates(c, (size_t)count);
+        if (rc != VH_OK) return rc;
+    }
     DeviceGuard guard(c->device);
     if (c->viewCount > 0) {
         const int rc = launch(c, kPhaseViewImport, view_clear_kernel, dim3((unsigned)grid_for((size_t)c->viewCount, 256)),
@@ -79,8 +83,11 @@ extern "C" int vh_import_view(vh_context *c, const vh_view_record *d_records, in
     c->viewBlocks = reinterpret_cast<const Voxel *>(d_records);
     c->viewCount = count;
     if (count > 0) {
-        const int rc = launch(c, kPhaseViewImport, view_import_kernel, dim3((unsigned)grid_for((size_t)count, 256)),
-                              dim3(256), c->fp, c->dp, reinterpret_cast<const uint8_t *>(d_records), count);
+        int rc = launch(c, kPhaseViewImport, view_import_kernel, dim3((unsigned)grid_for((size_t)count, 256)),
+                        dim3(256), c->fp, c->dp, reinterpret_cast<const uint8_t *>(d_records), count);
+        if (rc == VH_OK && (c->fp.flags & kFlagOverflow))
+            rc = launch(c, kPhaseViewImport, view_import_overflow_kernel, dim3(1), dim3(64), c->fp, c->dp,
+                        reinterpret_cast<const uint8_t *>(d_records));
         if (rc != VH_OK) return rc;
     }
     VH_HIP(hipGetLastError());

@@ -63,7 +63,17 @@ struct FrameParams {
     uint32_t numVoxelBlocks;
     uint32_t epoch;       // bucket-lock epoch of this frame (>= 1)
     float allocBand;      // 0: a pixel demands its surface block only (reference); > 0: +- band along the ray
+    uint32_t flags;       // kFlag*: opt-in extensions (all 0 = the live reference path)
+    uint32_t listSize;    // attachedLinkedListSize: iterations of the chain loop (VoxelUtils.cu:391-392)
+    float truncScale;     // getTruncation, :261-264 (kFlagDepthTruncation)
+    uint32_t weightSample;   // integrationWeightSample, :827 (kFlagWeightSample)
 };
+
+constexpr uint32_t kFlagOverflow = 1u;          // overflow linked list (dead code in the reference, :384-411, :458-539, :578-602)
+constexpr uint32_t kFlagBandDda = 2u;           // band allocation by a block DDA along the normal (:632-703) instead of ray samples
+constexpr uint32_t kFlagDepthTruncation = 4u;   // truncation + truncScale * depth (:815)
+constexpr uint32_t kFlagWeightSample = 8u;      // weight = max(integrationWeightSample * 1.5 * (1 - depth01), 1) (:808-811, :827)
+constexpr int kLookAhead = 10;                  // free-slot search behind a full bucket: j < 10 (:475-478)
 
 struct DevPtrs {
     uint32_t *heap;
@@ -74,6 +84,8 @@ struct DevPtrs {
     int32_t *counters;        // Counter[]
     int4 *candidates;         // {x,y,z,rank} of this frame's contenders
     uint32_t candCapacity;
+    uint32_t *candTarget;     // overflow list: entry index of the free slot a contender found outside its full home bucket (~0u: none)
+    uint32_t *gcMarks;        // one bit per entry: due for deletion by the running vh_delete_blocks / vh_garbage_collect
     uint32_t *compactMask;    // multi-camera frames: cameras that see compact entry i
     uint32_t *bucketBits;     // one bit per owned bucket: holds at least one entry
     uint32_t *macroBits;      // raycast: one bit per hashed 4x4x4-block macro cell that holds a block
@@ -207,6 +219,48 @@ __device__ __forceinline__ unsigned long long claim_word(uint32_t epoch, uint32_
 __device__ __forceinline__ unsigned long long consumed_word(uint32_t epoch)
 {
     return ((unsigned long long)epoch << 32) | 0xffffffffull;
+}
+
+// ---- overflow list (kFlagOverflow) -------------------------------------------------------------
+// The entries of one home bucket that did not fit its slots form a chain that starts in the bucket's
+// LAST slot and is linked through `offset`, measured from that slot, modulo this table's entries
+// (VoxelUtils.cu:388-399; a shard's chains wrap inside the shard).  offset 0 ends the chain.
+__device__ __forceinline__ uint32_t chain_slot(uint32_t last, int32_t offset, uint32_t numEntries)
+{
+    uint32_t s = last + (uint32_t)offset;            // offsets are 1..kLookAhead-1
+    if (s >= numEntries) s -= numEntries;
+    return s;
+}
+
+__device__ __forceinline__ uint32_t owned_entries(const FrameParams &fp)
+{
+    return (fp.bucketHi - fp.bucketLo) * fp.bucketSize;
+}
+
+__device__ __forceinline__ bool entry_is(const VoxelEntry &e, int kx, int ky, int kz)
+{
+    return e.pos[0] == kx && e.pos[1] == ky && e.pos[2] == kz && e.ptr != VH_FREE_BLOCK;
+}
+
+// getVoxelEntry4Block with the list (:362-411): entry index of the key or ~0u; prev = its chain
+// predecessor when it was found behind the bucket's last slot (~0u otherwise)
+__device__ __forceinline__ uint32_t find_entry_overflow(const FrameParams &fp, const VoxelEntry *__restrict__ table,
+                                                        uint32_t numEntries, uint32_t local, int kx, int ky, int kz,
+                                                        uint32_t &prev)
+{
+    const uint32_t start = local * fp.bucketSize, last = start + fp.bucketSize - 1u;
+    prev = ~0u;
+    for (uint32_t i = 0; i < fp.bucketSize; ++i)
+        if (entry_is(table[start + i], kx, ky, kz)) return start + i;                 // :374-381
+    uint32_t i = last, before = last;
+    for (uint32_t iter = 0; iter < fp.listSize; ++iter) {                             // :391-392
+        const VoxelEntry curr = table[i];
+        if (entry_is(curr, kx, ky, kz)) { if (i != last) prev = before; return i; }
+        if (curr.offset == 0) break;                                                  // :396
+        before = i;
+        i = chain_slot(last, curr.offset, numEntries);                                // :398-399
+    }
+    return ~0u;
 }
 
 }  // namespace vh

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const Frame
     for (int i = blockIdx.x; i < n; i += commitBlocks) {
         if (threadIdx.x == 0) {
             VoxelEntry e;
-            inserted = commit_candidate(fp, dp, dp.candidates[i], e) ? 1 : 0;
+            inserted = commit_candidate(fp, dp, dp.candidates[i], e, (uint32_t)i) ? 1 : 0;
             if (inserted) {
                 newEntry = e;
                 dp.compact[scanCount + atomicAdd(dp.counters + kNewCount + parity, 1)] = e;

@@ -9,26 +9,39 @@
 
 namespace vh {
 
-constexpr int kDeleteMark = 0x0044454c;      // VoxelEntry::offset of an entry due for deletion ("DEL")
+// Entries due for deletion are marked in a bitmap (one bit per entry, dp.gcMarks; all zero between
+// calls).  (Round 1 kept the mark in VoxelEntry::offset, which now carries the overflow chain.)
+__device__ __forceinline__ bool gc_marked(const DevPtrs &dp, uint32_t e)
+{
+    return (dp.gcMarks[e >> 5] >> (e & 31u)) & 1u;
+}
+__device__ __forceinline__ void gc_mark(const DevPtrs &dp, uint32_t e) { atomicOr(dp.gcMarks + (e >> 5), 1u << (e & 31u)); }
+__device__ __forceinline__ void gc_unmark(const DevPtrs &dp, uint32_t e) { atomicAnd(dp.gcMarks + (e >> 5), ~(1u << (e & 31u))); }
 
-// Marks the entry of `key` and puts its bucket on the sweep list (once: the first marker of a
+// Marks the entry of `key` and puts its HOME bucket on the sweep list (once: the first marker of a
 // bucket in this epoch swaps the consumed word into the bucket's claim word).
 __device__ __forceinline__ void mark_for_deletion(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz)
 {
     const uint32_t h = hash_block(kx, ky, kz, fp.numBuckets);
     if (h < fp.bucketLo || h >= fp.bucketHi) return;
     const uint32_t local = h - fp.bucketLo;
-    VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
-    for (uint32_t s = 0; s < fp.bucketSize; ++s) {
-        const VoxelEntry e = bucket[s];
-        if (e.ptr == VH_FREE_BLOCK) return;                     // entries form a prefix
-        if (e.pos[0] != kx || e.pos[1] != ky || e.pos[2] != kz) continue;
-        bucket[s].offset = kDeleteMark;                         // idempotent: a key listed twice is freed once
-        const unsigned long long tag = consumed_word(fp.epoch);
-        if (atomicExch(dp.claim + local, tag) != tag)
-            dp.compactMask[atomicAdd(dp.counters + kGcBuckets, 1)] = local;
-        return;
+    uint32_t at = ~0u;
+    if (fp.flags & kFlagOverflow) {
+        uint32_t prev;
+        at = find_entry_overflow(fp, dp.table, owned_entries(fp), local, kx, ky, kz, prev);
+    } else {
+        const VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
+        for (uint32_t s = 0; s < fp.bucketSize; ++s) {
+            const VoxelEntry e = bucket[s];
+            if (e.ptr == VH_FREE_BLOCK) break;                      // entries form a prefix
+            if (e.pos[0] == kx && e.pos[1] == ky && e.pos[2] == kz) { at = local * fp.bucketSize + s; break; }
+        }
     }
+    if (at == ~0u) return;
+    gc_mark(dp, at);                                                // idempotent: a key listed twice is freed once
+    const unsigned long long tag = consumed_word(fp.epoch);
+    if (atomicExch(dp.claim + local, tag) != tag)
+        dp.compactMask[atomicAdd(dp.counters + kGcBuckets, 1)] = local;
 }
 
 // deleteVoxelEntry for a list of keys {x,y,z,_}
@@ -86,7 +99,8 @@ __global__ __launch_bounds__(256) void gc_sweep_kernel(const FrameParams fp, con
         for (; s < fp.bucketSize; ++s) {
             const VoxelEntry e = bucket[s];
             if (e.ptr == VH_FREE_BLOCK) break;
-            if (e.offset == kDeleteMark) {
+            if (gc_marked(dp, local * fp.bucketSize + s)) {
+                gc_unmark(dp, local * fp.bucketSize + s);
                 freed[atomicAdd(dp.counters + kGcFreed, 1)] = e.ptr;
                 continue;
             }
@@ -100,6 +114,93 @@ __global__ __launch_bounds__(256) void gc_sweep_kernel(const FrameParams fp, con
         for (uint32_t k = w; k < s; ++k) bucket[k] = none;
         if (w == 0) atomicAnd(dp.bucketBits + (local >> 5), ~(1u << (local & 31u)));
         // (the macro-cell bitmap is hashed and shared: a stale bit only makes a ray skip less)
+    }
+}
+
+// ---- the same with the overflow list on (oracle: delete_entry_overflow) --------------------------
+// No compaction: a freed slot simply becomes free (Niessner et al. 2013, 4.2) -- except that a
+// bucket's last slot, which heads its chain, is refilled with the first chained entry when it is
+// deleted while the chain is not empty ("last slot free" always means "no chain"), and a chained
+// entry is unlinked from its predecessor (prev.offset = curr.offset, VoxelUtils.cu:594).  The result
+// does not depend on the order in which a set of keys is deleted, so one lane per listed HOME bucket
+// can apply all of its deletions.  Two launches, because chained entries live in OTHER buckets' slots:
+//   A  the marked entries in the home bucket's slots other than the last (told apart from foreign
+//      chained entries by their hash; nobody writes those slots during A)
+//   B  the last slot and the chain behind it (only this lane touches the chain's slots during B)
+// the slot becomes free; the occupancy bit of its bucket is cleared when nothing lives there any more
+// (a stale set bit is harmless: lookups and the index walk then read an empty bucket)
+__device__ __forceinline__ void gc_reset_slot(const FrameParams &fp, const DevPtrs &dp, uint32_t e)
+{
+    VoxelEntry none;
+    none.pos[0] = none.pos[1] = none.pos[2] = VH_POS_SENTINEL;
+    none.ptr = VH_FREE_BLOCK;
+    none.offset = 0;
+    dp.table[e] = none;
+    const uint32_t b = e / fp.bucketSize;
+    bool any = false;
+    for (uint32_t s = 0; s < fp.bucketSize; ++s) any |= dp.table[b * fp.bucketSize + s].ptr != VH_FREE_BLOCK;
+    if (!any) atomicAnd(dp.bucketBits + (b >> 5), ~(1u << (b & 31u)));
+}
+
+__device__ __forceinline__ void gc_free_slot(const FrameParams &fp, const DevPtrs &dp, uint32_t e, int32_t *freed)
+{
+    freed[atomicAdd(dp.counters + kGcFreed, 1)] = dp.table[e].ptr;
+    gc_reset_slot(fp, dp, e);
+}
+
+__global__ __launch_bounds__(256) void gc_sweep_overflow_a_kernel(const FrameParams fp, const DevPtrs dp)
+{
+    const int n = dp.counters[kGcBuckets];
+    int32_t *freed = reinterpret_cast<int32_t *>(dp.compact);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t local = dp.compactMask[i], start = local * fp.bucketSize;
+        for (uint32_t s = 0; s + 1u < fp.bucketSize; ++s) {
+            const uint32_t e = start + s;
+            if (!gc_marked(dp, e)) continue;
+            const VoxelEntry ent = dp.table[e];
+            if (ent.ptr == VH_FREE_BLOCK || hash_block(ent.pos[0], ent.pos[1], ent.pos[2], fp.numBuckets) != local + fp.bucketLo)
+                continue;                                           // a chained entry of another bucket: its home's lane frees it in B
+            gc_unmark(dp, e);
+            gc_free_slot(fp, dp, e, freed);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gc_sweep_overflow_b_kernel(const FrameParams fp, const DevPtrs dp)
+{
+    const int n = dp.counters[kGcBuckets];
+    const uint32_t total = owned_entries(fp);
+    int32_t *freed = reinterpret_cast<int32_t *>(dp.compact);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t local = dp.compactMask[i], last = local * fp.bucketSize + fp.bucketSize - 1u;
+        // the head: while it is marked, free its block and pull the next chained entry in
+        while (dp.table[last].ptr != VH_FREE_BLOCK && gc_marked(dp, last)) {
+            gc_unmark(dp, last);
+            const VoxelEntry head = dp.table[last];
+            if (head.offset == 0) {
+                gc_free_slot(fp, dp, last, freed);
+                break;
+            }
+            freed[atomicAdd(dp.counters + kGcFreed, 1)] = head.ptr;
+            const uint32_t nx = chain_slot(last, head.offset, total);
+            dp.table[last] = dp.table[nx];                          // pos, ptr and its link to the rest of the chain
+            if (gc_marked(dp, nx)) { gc_unmark(dp, nx); gc_mark(dp, last); }
+            gc_reset_slot(fp, dp, nx);
+        }
+        // the chain behind the (surviving) head: unlink the marked entries
+        uint32_t prev = last;
+        for (uint32_t iter = 0; iter < fp.listSize; ++iter) {
+            const int32_t off = dp.table[prev].offset;
+            if (off == 0 || dp.table[prev].ptr == VH_FREE_BLOCK) break;
+            const uint32_t cur = chain_slot(last, off, total);
+            if (gc_marked(dp, cur)) {
+                gc_unmark(dp, cur);
+                dp.table[prev].offset = dp.table[cur].offset;       // :594
+                gc_free_slot(fp, dp, cur, freed);
+            } else {
+                prev = cur;
+            }
+        }
     }
 }
 

@@ -59,12 +59,19 @@ __device__ __forceinline__ bool tsdf_update(const FrameParams &fp, const float *
     const float depth = src.at(sx, sy, fp.width);                                 // :805
     if (depth <= 0.0f) return false;                                             // :806
     float sdf = depth - cz;                                                      // :813
-    if (!(sdf > -fp.truncation)) return false;                                   // :818
-    sdf = (sdf >= 0.0f) ? __builtin_fminf(fp.truncation, sdf) : __builtin_fmaxf(-fp.truncation, sdf);
-    // combineVoxel, :779-787, current sample {sdf, 0.1f} (:829)
+    float trunc = fp.truncation;                                                 // :815
+    if (fp.flags & kFlagDepthTruncation) trunc = fp.truncation + (fp.truncScale * depth);   // its commented half = getTruncation, :261-264
+    if (!(sdf > -trunc)) return false;                                           // :818
+    sdf = (sdf >= 0.0f) ? __builtin_fminf(trunc, sdf) : __builtin_fmaxf(-trunc, sdf);
+    float cw = 0.1f;                                                             // :829
+    if (fp.flags & kFlagWeightSample) {                                          // the commented :827 with :808-811 (double arithmetic there)
+        const float zeroOne = (depth - 0.5f) / (5.0f - 0.5f);
+        cw = __builtin_fmaxf((float)((double)fp.weightSample * 1.5 * (1.0 - (double)zeroOne)), 1.0f);
+    }
+    // combineVoxel, :779-787
     const float ow = wOut, os = sdfOut;
-    sdfOut = ((os * ow) + (sdf * 0.1f)) / (ow + 0.1f);
-    wOut = __builtin_fminf(fp.weightMax, ow + 0.1f);
+    sdfOut = ((os * ow) + (sdf * cw)) / (ow + cw);
+    wOut = __builtin_fminf(fp.weightMax, ow + cw);
     return true;
 }
 

@@ -17,6 +17,12 @@ __device__ __forceinline__ int lookup_block(const FrameParams &fp, const DevPtrs
     // KB that stay in L2, while the table itself is >100 MB.  Nearly every block a ray crosses
     // is empty space and is answered here without touching the table.
     if (!((dp.bucketBits[local >> 5] >> (local & 31u)) & 1u)) return VH_FREE_BLOCK;
+    if (fp.flags & kFlagOverflow) {
+        // (a bucket with a chain has an allocated last slot, so its bit is set; bits are per slot residence)
+        uint32_t prev;
+        const uint32_t at = find_entry_overflow(fp, dp.table, owned_entries(fp), local, kx, ky, kz, prev);
+        return at == ~0u ? VH_FREE_BLOCK : dp.table[at].ptr;
+    }
     const VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
     for (uint32_t i = 0; i < fp.bucketSize; ++i) {
         const VoxelEntry e = bucket[i];

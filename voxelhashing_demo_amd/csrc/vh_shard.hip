@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void frame_multi_commit_integrate_kernel(const
     for (int i = blockIdx.x; i < n; i += commitBlocks) {
         if (threadIdx.x == 0) {
             VoxelEntry e;
-            inserted = commit_candidate(fp, dp, dp.candidates[i], e) ? 1 : 0;
+            inserted = commit_candidate(fp, dp, dp.candidates[i], e, (uint32_t)i) ? 1 : 0;
             if (inserted) {
                 const uint32_t seen = camera_mask(fp, e.pos, numCams, packets, packetStride);
                 newEntry = e;

@@ -125,6 +125,12 @@ __global__ __launch_bounds__(256) void view_import_kernel(const FrameParams fp, 
     dp.compactMask[i] = h;
     const uint32_t slot = atomicAdd(reinterpret_cast<unsigned int *>(dp.claim + h), 1u);
     if (slot >= fp.bucketSize) {
+        // more records than slots in this bucket: with the overflow list on (the shards' table has
+        // chains) the record is placed by view_import_overflow_kernel, otherwise it is lost and counted
+        if (fp.flags & kFlagOverflow) {
+            const uint32_t q = (uint32_t)atomicAdd(dp.counters + kCandCount, 1);
+            if (q < dp.candCapacity) { dp.candTarget[q] = (uint32_t)i; return; }
+        }
         atomicAdd(dp.counters + kBinOverflow, 1);
         return;
     }
@@ -136,6 +142,55 @@ __global__ __launch_bounds__(256) void view_import_kernel(const FrameParams fp, 
     atomicOr(dp.bucketBits + (h >> 5), 1u << (h & 31u));
     const uint32_t hm = macro_hash(k.x >> 2, k.y >> 2, k.z >> 2);
     atomicOr(dp.macroBits + (hm >> 5), 1u << (hm & 31u));
+}
+
+// The records that found their bucket full, one after the other (they are few): each goes to a free
+// slot among the kLookAhead-1 slots behind its home bucket (not a bucket's last slot) and to the front
+// of the home bucket's chain, like an insertion into the shards' table (vh_alloc.hip), without the
+// locks -- nothing else runs on a view table.  Which slot a record gets does not matter: the view
+// table only has to answer lookups.
+__global__ void view_import_overflow_kernel(const FrameParams fp, const DevPtrs dp, const uint8_t *__restrict__ records)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int n = min(dp.counters[kCandCount], (int)dp.candCapacity);
+    const uint32_t total = owned_entries(fp), bs = fp.bucketSize;
+    for (int q = 0; q < n; ++q) {
+        const uint32_t i = dp.candTarget[q];
+        const int4 k = *reinterpret_cast<const int4 *>(records + (size_t)i * kViewRecordBytes);
+        const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
+        const uint32_t last = h * bs + bs - 1u;
+        uint32_t links = 0, at = last;
+        bool ended = false;
+        for (uint32_t iter = 0; iter < fp.listSize; ++iter) {
+            const VoxelEntry curr = dp.table[at];
+            if (curr.offset == 0) { ended = true; break; }
+            at = chain_slot(last, curr.offset, total);
+            ++links;
+        }
+        uint32_t target = ~0u;
+        if (ended && fp.listSize >= 2u && links + 1u <= fp.listSize - 1u)
+            for (int j = 1; j < kLookAhead; ++j) {
+                const uint32_t s = chain_slot(last, j, total);
+                if (s % bs == bs - 1u) continue;
+                if (dp.table[s].ptr == VH_FREE_BLOCK) { target = s; break; }
+            }
+        if (target == ~0u) {
+            atomicAdd(dp.counters + kBinOverflow, 1);
+            continue;
+        }
+        VoxelEntry e;
+        e.pos[0] = k.x; e.pos[1] = k.y; e.pos[2] = k.z;
+        e.ptr = (int)i * kViewRecordVoxels + 2;
+        e.offset = dp.table[last].offset;
+        dp.table[target] = e;
+        dp.table[last].offset = (int)(target >= last ? target - last : target + total - last);
+        const uint32_t tb = target / bs;
+        dp.compactMask[i] = tb;                      // the next import clears this bucket too (the home bucket is listed by its own records)
+        atomicOr(dp.bucketBits + (tb >> 5), 1u << (tb & 31u));
+        const uint32_t hm = macro_hash(k.x >> 2, k.y >> 2, k.z >> 2);
+        atomicOr(dp.macroBits + (hm >> 5), 1u << (hm & 31u));
+    }
+    dp.counters[kCandCount] = 0;
 }
 
 }  // namespace vh

@@ -132,14 +132,16 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
         const bool have = bits != 0u;
         const uint32_t bucket = w * 32u + (have ? (uint32_t)__ffs((int)bits) - 1u : 0u);
         if (have) bits &= bits - 1u;
-        bool more = have;                   // entries form a prefix of the bucket
+        bool more = have;                   // entries form a prefix of the bucket (not with the overflow list: holes)
+        const bool holes = (fp.flags & kFlagOverflow) != 0u;
         for (uint32_t s = 0; s < fp.bucketSize; ++s) {
             VoxelEntry ent;
             bool hit = false;
             if (more) {
                 ent = dp.table[(size_t)bucket * fp.bucketSize + s];
-                more = ent.ptr != VH_FREE_BLOCK;
-                hit = more && block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);
+                const bool live = ent.ptr != VH_FREE_BLOCK;
+                more = live || holes;
+                hit = live && block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);
             }
             const unsigned long long mask = __ballot(hit);
             if (__ballot(more) == 0ull && mask == 0ull) break;
