@@ -123,7 +123,7 @@ def test_overflow_raycast_and_snapshot(oracle, vh, torch_cuda, tmp_path):
     gt.raycast(poses[21], depth)
     gt.synchronize()
     ref = ot.raycast(poses[21])
-    assert (ref > 0).mean() > 0.5 and np.array_equal(depth.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert (ref > 0).mean() > 0.2 and np.array_equal(depth.cpu().numpy().view(np.uint32), ref.view(np.uint32))
     snap = tmp_path / "chains.vhsnap"
     gt.save_snapshot(snap)
     plain = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
@@ -228,7 +228,7 @@ def test_normal_dda_band(oracle, vh, torch_cuda, variant):
         gt.integrate(poses[i], dv, dn)
         gt.synchronize()
         _compare(ot, gt)
-    assert len(gt.allocated()) > 1500
+    assert len(gt.allocated()) > 1000
 
 
 def test_tsdf_update_variants(oracle, vh, torch_cuda):
