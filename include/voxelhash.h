@@ -73,7 +73,8 @@ typedef struct vh_float4 { float x, y, z, w; } vh_float4;
 
 /* VoxelDataStructures.h:54-63 -- raw device pointers of one table.  The bucket
  * lock is an 8-byte epoch-stamped claim word per bucket instead of the
- * reference's memset-per-frame int (see DESIGN.md "bucket lock"). */
+ * reference's memset-per-frame int (see DESIGN.md "bucket lock"): epoch in the
+ * top 10 bits, then the winner's inverted launch rank, slot and record index. */
 typedef struct PtrContainer {
     uint32_t   *d_heap;
     VoxelEntry *d_hashTable;
@@ -151,6 +152,7 @@ typedef struct vh_kernel_times {
     double   gc_ms;                      /* vh_delete_blocks / vh_garbage_collect, all launches */
     uint64_t gc_calls;
     double   render_blocks_ms;           /* vh_render_blocks, all launches */
+    double   frame_pipelined_ms;         /* pipelined frames: the one launch per frame */
 } vh_kernel_times;
 
 typedef struct vh_context vh_context;
@@ -237,6 +239,27 @@ int vh_integrate(vh_context *ctx, const float pose[16],
  * TSDF update reads the image, so no vertex map exists in memory: 2 bytes per pixel in instead of
  * 16.  Equals vh_preprocess + vh_integrate bit for bit.  k_inv: row-major 3x3. */
 int vh_integrate_depth(vh_context *ctx, const float pose[16], const uint16_t *d_depth, const float k_inv[9]);
+
+/* Pipelined frames.  With vh_set_option(ctx, "pipeline", 1) a frame is ONE launch: vh_integrate enqueues
+ * {claim || walk} of its frame together with the {commit + TSDF update} of the PREVIOUS frame, whose
+ * results it leaves pending; the pending half is launched by the next vh_integrate / vh_integrate_depth,
+ * by vh_flush, and by every call that reads or changes the model (counters, download, raycast, collection,
+ * snapshot, step-level calls, vh_set_stream, vh_synchronize ...), so the library's own entry points always
+ * see completed frames.  Code that reads the model through raw device pointers (vh_get_device_pointers)
+ * calls vh_flush first.  The caller's depth / vertex buffer is only read by the launch of its own frame
+ * (the deferred half works from a private copy of the camera-z plane), so buffers may be reused as with
+ * the unpipelined calls.  Results equal the unpipelined frames bit for bit, with one documented
+ * difference: a frame whose new blocks outnumber the free blocks of the heap allocates none of them
+ * (they count as heap_exhausted and retry), where vh_integrate serves as many as there are blocks.
+ * Not combined with "overflow_list", bucketSize > 8 or a flatten_variant other than 3: those frames run
+ * unpipelined.  vh_integrate_batch / vh_integrate_depth_batch: `count` frames (poses: count*16 host
+ * floats; d_verts / d_normals / d_depth: host arrays of `count` device pointers, d_normals may be NULL)
+ * in count + 1 launches -- the pipeline switched on for the call and flushed at its end. */
+int vh_flush(vh_context *ctx);
+int vh_integrate_batch(vh_context *ctx, int32_t count, const float *poses, const vh_float4 *const *d_verts,
+                       const vh_float4 *const *d_normals);
+int vh_integrate_depth_batch(vh_context *ctx, int32_t count, const float *poses, const uint16_t *const *d_depth,
+                             const float k_inv[9]);
 
 /* Stand-in for SDFRenderer::render (SDFRenderer.cpp:210-255): one ray per pixel
  * from `pose`, camera depth of the first +/- zero crossing into d_depth_out

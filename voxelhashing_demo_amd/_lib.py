@@ -61,7 +61,7 @@ class KernelTimes(C.Structure):
                 ("raycast_launches", C.c_uint64), ("frame_scan_claim_ms", C.c_double),
                 ("frame_commit_integrate_ms", C.c_double), ("view_export_ms", C.c_double),
                 ("view_import_ms", C.c_double), ("gc_ms", C.c_double), ("gc_calls", C.c_uint64),
-                ("render_blocks_ms", C.c_double)]
+                ("render_blocks_ms", C.c_double), ("frame_pipelined_ms", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -129,6 +129,9 @@ SIGNATURES = {
     "vh_get_device_pointers": (C.c_int, [_vp, C.POINTER(PtrContainer)]),
     "vh_download": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
     "vh_download_range": (C.c_int, [_vp, C.c_int, C.c_size_t, _vp, C.c_size_t]),
+    "vh_flush": (C.c_int, [_vp]),
+    "vh_integrate_batch": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "vh_integrate_depth_batch": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_void_p), C.POINTER(C.c_float)]),
     "vh_debug_eval": (C.c_int, [_vp, _vp, _i32, _vp]),
     "vh_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "vh_set_profiling": (C.c_int, [_vp, C.c_int]),

@@ -57,28 +57,57 @@ __device__ __forceinline__ void probe_and_claim_overflow(const FrameParams &fp, 
     }
     dp.candidates[slot] = make_int4(kx, ky, kz, (int)rank);
     dp.candTarget[slot] = target;
-    atomicMax(dp.claim + local, claim_word(fp.epoch, rank));
-    if (target != ~0u) atomicMax(dp.claim + target / bs, claim_word(fp.epoch, rank));
+    atomicMax(dp.claim + local, claim_word(fp.epoch, rank, 0u, slot));
+    if (target != ~0u) atomicMax(dp.claim + target / bs, claim_word(fp.epoch, rank, 0u, slot));
 }
 
+// Pipelined frames (vh_frame.hip): the frame whose commit phase runs CONCURRENTLY with this claim
+// phase.  Its claim words and candidate list are final (they were written by the previous launch),
+// so a bucket's pending insertion is known without looking at the slot that is being written: word
+// of the previous epoch = {who: slot -> key, where: f}.  live = false: that frame's insertions are
+// all refused (the heap cannot serve them all, see frame_pipelined_kernel) and the table is as it reads.
+struct Pending {
+    const unsigned long long *__restrict__ claim;     // nullptr: no frame in flight
+    const int4 *__restrict__ cand;
+    uint32_t epoch;
+    bool live;
+    int winnersCounter;                               // of the frame being claimed: counts its distinct buckets
+};
+
 __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz,
-                                                uint32_t h, uint32_t rank, int candCounter = kCandCount)
+                                                uint32_t h, uint32_t rank, int candCounter = kCandCount,
+                                                const Pending *pend = nullptr)
 {
     if (fp.flags & kFlagOverflow) {
         probe_and_claim_overflow(fp, dp, kx, ky, kz, h, rank, candCounter);
         return;
     }
-    const VoxelEntry *bucket = dp.table + (size_t)(h - fp.bucketLo) * fp.bucketSize;
-    bool has_free = false;
+    const uint32_t local = h - fp.bucketLo;
+    const VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
+    // the insertion in flight into this bucket, if any: it takes the bucket's first free slot (pf)
+    uint32_t pf = ~0u;
+    int4 pk = make_int4(0, 0, 0, 0);
+    if (pend && pend->claim && pend->live) {
+        const unsigned long long w = pend->claim[local];
+        if (claim_epoch(w) == pend->epoch) {
+            pf = claim_f(w);
+            pk = pend->cand[claim_slot(w)];
+        }
+    }
+    uint32_t firstFree = ~0u;
     for (uint32_t i = 0; i < fp.bucketSize; ++i) {
+        if (i == pf) {                   // being written right now: never read, it WILL hold pk
+            if (pk.x == kx && pk.y == ky && pk.z == kz) return;
+            continue;
+        }
         const VoxelEntry e = bucket[i];
         if (e.ptr == VH_FREE_BLOCK) {
-            has_free = true;
+            firstFree = i;
             break;                       // prefix property: nothing allocated behind a free slot
         }
         if (e.pos[0] == kx && e.pos[1] == ky && e.pos[2] == kz) return;   // already allocated
     }
-    if (!has_free) return;               // bucket full: the key is dropped (no overflow list)
+    if (firstFree == ~0u) return;        // bucket full: the key is dropped (no overflow list)
     // The record is reserved BEFORE the claim is staked: a contender that finds the candidate list
     // full must not hold a bucket's winning word (nobody would commit it).  It is counted instead.
     const uint32_t slot = (uint32_t)atomicAdd(dp.counters + candCounter, 1);
@@ -87,7 +116,9 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
         return;
     }
     dp.candidates[slot] = make_int4(kx, ky, kz, (int)rank);
-    atomicMax(dp.claim + (h - fp.bucketLo), claim_word(fp.epoch, rank));
+    const unsigned long long before = atomicMax(dp.claim + local, claim_word(fp.epoch, rank, firstFree, slot));
+    // first claim on this bucket in this epoch: one more entry the commit phase will insert
+    if (pend && claim_epoch(before) != fp.epoch) atomicAdd(dp.counters + pend->winnersCounter, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -134,6 +165,7 @@ struct VertexMap {
     {
         return normals ? normals[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    __device__ __forceinline__ uint16_t raw(int) const { return 0; }
     // non-temporal: a vertex map is streamed once per frame, and keeping it out of the Infinity Cache
     // leaves more of the hash table there for the walk (launch 1: 17.5 -> 17.2 us)
     __device__ __forceinline__ float4 vertex(int idx, int, int) const
@@ -149,6 +181,7 @@ struct SensorImage {
     float k[9];              // K_inv, row-major
     float unit;              // 5000 = 1 m
     __device__ __forceinline__ float4 normal(int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }   // no normal map
+    __device__ __forceinline__ uint16_t raw(int idx) const { return depth[idx]; }
     __device__ __forceinline__ float4 vertex(int idx, int px, int py) const
     {
         const float d = (float)depth[idx] / unit;                                   // :64
@@ -166,9 +199,11 @@ __device__ __forceinline__ uint32_t num_tiles(const FrameParams &fp)
 }
 
 // pixel of lane t (0..255) of launch tile `tile`
+// outDepth / outRaw (optional): the pixel's camera z as a float plane (camera packets; the pipelined
+// frame's private copy of what the TSDF update will gather) / the raw uint16 sensor value
 template <class In>
 __device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const In &in, uint32_t tile, uint32_t t,
-                                                  float *__restrict__ outDepth)
+                                                  float *__restrict__ outDepth, uint16_t *__restrict__ outRaw = nullptr)
 {
     PixelVertex p{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), 0, 0, (tile << 8) + t, false};
     const uint32_t tilesX = (uint32_t)(fp.width + 15) >> 4;
@@ -180,6 +215,7 @@ __device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const I
         p.v = in.vertex(idx, p.px, p.py);
         if ((fp.flags & kFlagBandDda) && fp.allocBand > 0.0f) p.n = in.normal(idx);
         if (outDepth) outDepth[idx] = p.v.z;                             // camera-z plane of a camera packet
+        if (outRaw) outRaw[idx] = in.raw(idx);
         p.valid = p.v.z != 0.0f;                                         // VoxelUtils.cu:621
     }
     return p;
@@ -315,9 +351,10 @@ __device__ __forceinline__ uint32_t sample_rank(const PixelVertex &p, int k)
 // the claim phase for one 16x16 launch tile = one 256-lane workgroup (alloc_claim_kernel and the fused frame)
 template <class In>
 __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs &dp, const In &in, uint32_t tile,
-                                           int candCounter)
+                                           int candCounter, const Pending *pend = nullptr,
+                                           float *__restrict__ outDepth = nullptr, uint16_t *__restrict__ outRaw = nullptr)
 {
-    const PixelVertex p = load_pixel(fp, in, tile, threadIdx.x, nullptr);
+    const PixelVertex p = load_pixel(fp, in, tile, threadIdx.x, outDepth, outRaw);
     BandWalk walk;
     walk.init(fp, p);
     int ox = 0, oy = 0, oz = 0;
@@ -327,7 +364,7 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
         if (!s.leader) continue;
         const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
         if (h < fp.bucketLo || h >= fp.bucketHi) continue;              // not this shard's bucket
-        probe_and_claim(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, k), candCounter);
+        probe_and_claim(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, k), candCounter, pend);
     }
 }
 
@@ -494,19 +531,24 @@ __device__ __forceinline__ uint32_t macro_hash(int mx, int my, int mz)
 
 // Returns true (and the new entry) if candidate k held its bucket's claim and was inserted.
 // `index`: position of the candidate in dp.candidates (its look-ahead target sits beside it)
+// consume = false (pipelined frames): the claim words stay as they are -- the claim phase and the
+// walk of the NEXT frame read them while this commit runs; nobody stakes a claim in this epoch any more.
 __device__ __forceinline__ bool commit_candidate(const FrameParams &fp, const DevPtrs &dp, const int4 k,
-                                                 VoxelEntry &e, uint32_t index)
+                                                 VoxelEntry &e, uint32_t index, bool consume = true)
 {
     const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
     const uint32_t local = h - fp.bucketLo;
-    if (dp.claim[local] != claim_word(fp.epoch, (uint32_t)k.w)) return false;   // lost the bucket this frame
-    dp.claim[local] = consumed_word(fp.epoch);                                   // locked until the next epoch
+    const unsigned long long w = dp.claim[local];
+    if (claim_epoch(w) != fp.epoch || claim_slot(w) != index || w == consumed_word(fp.epoch)) return false;   // lost the bucket this frame
+    if (consume) dp.claim[local] = consumed_word(fp.epoch);                      // locked until the next epoch
     const uint32_t target = (fp.flags & kFlagOverflow) ? dp.candTarget[index] : ~0u;
     if (target != ~0u) {
         // home bucket full: the entry goes to the free slot found behind it and to the FRONT of the
         // bucket's chain -- if this contender also holds the bucket of that slot
         const uint32_t tb = target / fp.bucketSize;
-        if (dp.claim[tb] != claim_word(fp.epoch, (uint32_t)k.w)) return false;  // the home bucket stays locked, as in the reference
+        const unsigned long long wt = dp.claim[tb];
+        if (claim_epoch(wt) != fp.epoch || claim_slot(wt) != index || wt == consumed_word(fp.epoch))
+            return false;                                                        // the home bucket stays locked, as in the reference
         dp.claim[tb] = consumed_word(fp.epoch);
         const int addr = atomicSub(dp.counters + kHeapCounter, 1);
         if (addr < 0) {

@@ -48,7 +48,7 @@ static int fail(int code, const char *what, hipError_t e = hipSuccess)
 // hipEventRecord pair would add.
 enum Phase : int {
     kPhaseClaim = 0, kPhaseCommit, kPhaseFlatten, kPhaseIntegrate, kPhaseRaycast,
-    kPhaseFrameScanClaim, kPhaseFrameCommitIntegrate, kPhaseViewExport, kPhaseViewImport, kPhaseGc, kPhaseRaycastBounds, kNumPhases
+    kPhaseFrameScanClaim, kPhaseFrameCommitIntegrate, kPhaseViewExport, kPhaseViewImport, kPhaseGc, kPhaseRaycastBounds, kPhaseFramePipelined, kNumPhases
 };
 
 struct TimedLaunch {
@@ -84,7 +84,21 @@ struct vh_context {
     // C2  3: 17.2 + 5.1, 5: 17.7, 4: 6.4 + 5.3; C3  3: 88 + 22, 4: 43 + 19.
     int flattenVariant = 3;
     uint32_t candAllocated = 0;    // records the candidate buffer holds (dp.candCapacity <= this)
-    uint32_t allocEpoch = 0;       // lock epoch of the last allocBlocks (overflow list: one per epoch)
+    uint32_t allocEpoch = 0;       // lock epoch (epochTotal) of the last allocBlocks (overflow list: one per epoch)
+    uint32_t epochTotal = 0;       // lock epochs since creation (fp.epoch is the 10-bit epoch of the claim words)
+    // pipelined frames (option "pipeline", vh_integrate_batch; vh_frame.hip)
+    int pipeline = 0;
+    bool pipePending = false;      // the commit + TSDF update of the last frame are still to be launched
+    FrameParams pipeFp;            // that frame's parameters
+    int pipeSet = 0;               // counter set its claim / walk filled
+    int pipeParity = 0;            // which of the two buffer sets it used
+    int pipeSensor = 0;            // its private depth copy: 0 = float camera-z plane, 1 = uint16 sensor image
+    float pipeK[4] = {0, 0, 0, 0}; // K_inv row 2 and the depth unit of a sensor frame
+    unsigned long long *claimBuf[2] = {nullptr, nullptr};
+    int4 *candBuf[2] = {nullptr, nullptr};
+    VoxelEntry *compactBuf[2] = {nullptr, nullptr};
+    float *planeBuf[2] = {nullptr, nullptr};
+    uint16_t *rawBuf[2] = {nullptr, nullptr};
     int occupiedCounter = kCompactCount;   // which device counter holds the occupied count of the last frame
     // raycast over shards
     int32_t *viewLists = nullptr;          // export: selected entry indices, [views][capacity]
@@ -213,8 +227,20 @@ static void default_projection(vh_context *c)
     c->rc_fx = fx; c->rc_fy = fy; c->rc_cx = cx; c->rc_cy = cy;
 }
 
+static int flush_pending(vh_context *c);       // vh_api_frame.hip: launches a pipelined frame's deferred half
+
 static int free_buffers(vh_context *c)
 {
+    // the second buffer set of the pipelined frames (set 0 aliases dp.claim / dp.candidates / dp.compact of creation)
+    for (int i = 0; i < 2; ++i) {
+        if (c->claimBuf[i] && c->claimBuf[i] != c->dp.claim) (void)hipFree(c->claimBuf[i]);
+        if (c->candBuf[i] && c->candBuf[i] != c->dp.candidates) (void)hipFree(c->candBuf[i]);
+        if (c->compactBuf[i] && c->compactBuf[i] != c->dp.compact) (void)hipFree(c->compactBuf[i]);
+        if (c->planeBuf[i]) (void)hipFree(c->planeBuf[i]);
+        if (c->rawBuf[i]) (void)hipFree(c->rawBuf[i]);
+        c->claimBuf[i] = nullptr; c->candBuf[i] = nullptr; c->compactBuf[i] = nullptr;
+        c->planeBuf[i] = nullptr; c->rawBuf[i] = nullptr;
+    }
     if (c->dp.heap) (void)hipFree(c->dp.heap);
     if (c->dp.table) (void)hipFree(c->dp.table);
     if (c->dp.compact) (void)hipFree(c->dp.compact);
@@ -292,7 +318,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     const size_t npix = (size_t)cfg->width * cfg->height;
     DevPtrs &dp = c->dp;
     dp = DevPtrs{};
-    dp.candCapacity = c->candAllocated = (uint32_t)npix;
+    dp.candCapacity = c->candAllocated = (uint32_t)std::min<size_t>(npix, kMaxCandidates);
 
 #define VH_ALLOC(ptr, bytes)                                               \
     do {                                                                   \
@@ -378,6 +404,11 @@ extern "C" int vh_destroy(vh_context *c)
 extern "C" int vh_set_stream(vh_context *c, void *stream)
 {
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    if (c->pipePending) {            // the deferred half of the last frame belongs on the stream that frame ran on
+        DeviceGuard guard(c->device);
+        const int rc = flush_pending(c);
+        if (rc != VH_OK) return rc;
+    }
     c->stream = (hipStream_t)stream;
     return VH_OK;
 }
@@ -421,17 +452,30 @@ extern "C" int vh_set_pose(vh_context *c, const float pose[16])
 // num_bins*(capacity-1) keys, for which the list is grown here (synchronises when it grows).
 static int ensure_candidates(vh_context *c, size_t need)
 {
+    if (need > kMaxCandidates) need = kMaxCandidates;        // a claim word names its record with 19 bits; more is counted as overflow
     if (need <= c->candAllocated) return VH_OK;
-    if (need > 0x7fffffffull) return fail(VH_ERR_INVALID_ARGUMENT, "candidate list too large");
+    int rc = flush_pending(c);
+    if (rc != VH_OK) return rc;
     VH_HIP(hipStreamSynchronize(c->stream));
-    int4 *fresh = nullptr;
+    int4 *fresh = nullptr, *fresh2 = nullptr;
     uint32_t *freshTarget = nullptr;
-    VH_HIP(hipMalloc((void **)&fresh, sizeof(int4) * need));
-    if (hipMalloc((void **)&freshTarget, sizeof(uint32_t) * need) != hipSuccess) {
-        (void)hipFree(fresh);
-        return fail(VH_ERR_OUT_OF_MEMORY, "hipMalloc candidate targets");
+    const bool two = c->candBuf[0] != nullptr;               // the pipelined frames' second list
+    hipError_t e = hipMalloc((void **)&fresh, sizeof(int4) * need);
+    if (e == hipSuccess) e = hipMalloc((void **)&freshTarget, sizeof(uint32_t) * need);
+    if (e == hipSuccess && two) e = hipMalloc((void **)&fresh2, sizeof(int4) * need);
+    if (e != hipSuccess) {
+        if (fresh) (void)hipFree(fresh);
+        if (freshTarget) (void)hipFree(freshTarget);
+        return fail(VH_ERR_OUT_OF_MEMORY, "hipMalloc candidate list", e);
     }
-    (void)hipFree(c->dp.candidates);
+    if (two) {
+        (void)hipFree(c->candBuf[0]);
+        (void)hipFree(c->candBuf[1]);
+        c->candBuf[0] = fresh;
+        c->candBuf[1] = fresh2;
+    } else {
+        (void)hipFree(c->dp.candidates);
+    }
     (void)hipFree(c->dp.candTarget);
     c->dp.candidates = fresh;
     c->dp.candTarget = freshTarget;

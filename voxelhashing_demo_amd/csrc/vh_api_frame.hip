@@ -7,16 +7,24 @@
 extern "C" int vh_reset_mutexes(vh_context *c)
 {
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
-    // The reference memsets 4*numBuckets bytes every frame (VoxelUtils.cu:146-149).
-    // Claim words carry the epoch in their upper half, so starting a new epoch
-    // invalidates every lock at once.  After 2^32-1 frames the words are cleared
-    // for real and the epoch restarts.
-    if (c->fp.epoch == 0xffffffffu) {
+    // The reference memsets 4*numBuckets bytes every frame (VoxelUtils.cu:146-149).  Claim words carry
+    // the epoch in their top 10 bits, so starting a new epoch invalidates every lock at once.  After
+    // kMaxClaimEpoch epochs the words are cleared for real and the epoch restarts at 1.
+    if (c->fp.epoch >= kMaxClaimEpoch) {
         DeviceGuard guard(c->device);
-        VH_HIP(hipMemsetAsync(c->dp.claim, 0, sizeof(unsigned long long) * (size_t)c->ownedBuckets, c->stream));
+        const int rc = flush_pending(c);
+        if (rc != VH_OK) return rc;
+        const size_t bytes = sizeof(unsigned long long) * (size_t)c->ownedBuckets;
+        if (c->claimBuf[0]) {
+            VH_HIP(hipMemsetAsync(c->claimBuf[0], 0, bytes, c->stream));
+            VH_HIP(hipMemsetAsync(c->claimBuf[1], 0, bytes, c->stream));
+        } else {
+            VH_HIP(hipMemsetAsync(c->dp.claim, 0, bytes, c->stream));
+        }
         c->fp.epoch = 0;
     }
     c->fp.epoch += 1;
+    c->epochTotal += 1;
     return VH_OK;
 }
 
@@ -107,12 +115,13 @@ extern "C" int vh_alloc_blocks(vh_context *c, const vh_float4 *verts, const vh_f
 {
     // normals: loaded into a dead variable by the reference (VoxelUtils.cu:631); read only by the DDA band
     if (!c || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
-    if (c->fp.epoch == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
-    if ((c->fp.flags & kFlagOverflow) && c->allocEpoch == c->fp.epoch)
+    if (c->epochTotal == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
+    if ((c->fp.flags & kFlagOverflow) && c->allocEpoch == c->epochTotal)
         return fail(VH_ERR_INVALID_ARGUMENT, "with the overflow list on, allocBlocks runs once per lock epoch "
                                              "(several cameras: vh_insert_bins / vh_apply_frames_batch)");
-    c->allocEpoch = c->fp.epoch;
+    c->allocEpoch = c->epochTotal;
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     int rc = launch_alloc(c, VertexMap{reinterpret_cast<const float4 *>(verts), reinterpret_cast<const float4 *>(normals)});
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
@@ -123,6 +132,7 @@ extern "C" int vh_flatten(vh_context *c, int32_t *occupied_out)
 {
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     if (!c->compactArmed)
         VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));   // :760
     c->compactArmed = false;
@@ -144,10 +154,135 @@ extern "C" int vh_integrate_depth_map(vh_context *c, const vh_float4 *verts)
 {
     if (!c || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     int rc = launch_integrate(c, vertex_depth(reinterpret_cast<const float4 *>(verts)));
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// pipelined frames (vh_frame.hip: frame_pipelined_kernel)
+// ---------------------------------------------------------------------------
+// second claim array / candidate list / compact list and the private depth copies, on first use
+static int ensure_pipeline_buffers(vh_context *c)
+{
+    if (c->claimBuf[1]) return VH_OK;
+    const size_t npix = (size_t)c->fp.width * c->fp.height;
+    const size_t claimBytes = sizeof(unsigned long long) * (size_t)c->ownedBuckets;
+    unsigned long long *claim2 = nullptr;
+    int4 *cand2 = nullptr;
+    VoxelEntry *compact2 = nullptr;
+    float *plane[2] = {nullptr, nullptr};
+    uint16_t *raw[2] = {nullptr, nullptr};
+    hipError_t e = hipMalloc((void **)&claim2, claimBytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&cand2, sizeof(int4) * (size_t)c->candAllocated);
+    if (e == hipSuccess) e = hipMalloc((void **)&compact2, sizeof(VoxelEntry) * c->numEntries);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipMalloc((void **)&plane[i], sizeof(float) * npix);
+        if (e == hipSuccess) e = hipMalloc((void **)&raw[i], sizeof(uint16_t) * npix);
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(claim2, 0, claimBytes, c->stream);
+    if (e != hipSuccess) {
+        if (claim2) (void)hipFree(claim2);
+        if (cand2) (void)hipFree(cand2);
+        if (compact2) (void)hipFree(compact2);
+        for (int i = 0; i < 2; ++i) { if (plane[i]) (void)hipFree(plane[i]); if (raw[i]) (void)hipFree(raw[i]); }
+        return fail(e == hipErrorOutOfMemory ? VH_ERR_OUT_OF_MEMORY : VH_ERR_HIP, "pipeline buffers", e);
+    }
+    c->claimBuf[0] = c->dp.claim;          c->claimBuf[1] = claim2;
+    c->candBuf[0] = c->dp.candidates;      c->candBuf[1] = cand2;
+    c->compactBuf[0] = c->dp.compact;      c->compactBuf[1] = compact2;
+    for (int i = 0; i < 2; ++i) { c->planeBuf[i] = plane[i]; c->rawBuf[i] = raw[i]; }
+    c->pipeParity = 0;                     // dp.* currently alias set 0
+    return VH_OK;
+}
+
+static DevPtrs pipe_view(const vh_context *c, int parity)
+{
+    DevPtrs d = c->dp;
+    d.claim = c->claimBuf[parity];
+    d.candidates = c->candBuf[parity];
+    d.compact = c->compactBuf[parity];
+    return d;
+}
+
+// can this context run its frames pipelined right now?
+static bool pipeline_applies(const vh_context *c)
+{
+    return c->pipeline && c->fusedFrame && c->flattenVariant == kWalkStridedBallot && !(c->fp.flags & kFlagOverflow) &&
+           c->fp.bucketSize <= 8u && !c->viewBlocks;
+}
+
+// One launch: {claim || walk} of the new frame (in != nullptr) and {commit + integrate} of the pending one.
+template <class In>
+static int launch_pipelined(vh_context *c, const In *in, int newSensor, const float newK[4])
+{
+    const bool hasNew = in != nullptr, hasOld = c->pipePending;
+    if (!hasNew && !hasOld) return VH_OK;
+    int rc;
+    if (!hasOld) {
+        if ((rc = ensure_pipeline_buffers(c)) != VH_OK) return rc;
+        hipLaunchKernelGGL(pipe_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->dp);
+    }
+    const int oldParity = c->pipeParity, newParity = hasOld ? oldParity ^ 1 : oldParity ^ 1;
+    const int setOld = c->pipeSet, setNew = hasOld ? (setOld + 1) % 3 : 0;
+    PipeArgs a;
+    a.claimBlocks = hasNew ? host_num_tiles(c) : 0u;
+    a.walkBlocks = hasNew ? (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane) : 0u;
+    a.commitBlocks = hasOld ? (uint32_t)c->commitBlocks : 0u;
+    a.integrateBlocks = hasOld ? (uint32_t)c->integrateGrid : 0u;
+    a.numEntries = (uint32_t)c->numEntries;
+    a.setNew = setNew; a.setOld = setOld; a.setClear = (setNew + 1) % 3;
+    a.hasNew = hasNew; a.hasOld = hasOld;
+    a.planeNew = (hasNew && !newSensor) ? c->planeBuf[newParity] : nullptr;
+    a.rawNew = (hasNew && newSensor) ? c->rawBuf[newParity] : nullptr;
+    const DevPtrs dpNew = pipe_view(c, newParity), dpOld = pipe_view(c, oldParity);
+    const dim3 grid(a.commitBlocks + a.integrateBlocks + a.claimBlocks + a.walkBlocks);
+    In inNew{};
+    if (hasNew) inNew = *in;
+    if (hasOld && c->pipeSensor) {
+        const DepthSensor d{c->rawBuf[oldParity], c->pipeK[0], c->pipeK[1], c->pipeK[2], c->pipeK[3]};
+        rc = launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DepthSensor>, grid, dim3(256), c->fp, dpNew, inNew,
+                    c->pipeFp, dpOld, d, a);
+    } else {
+        const DepthPlane d{c->planeBuf[oldParity], 1};
+        rc = launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DepthPlane>, grid, dim3(256), c->fp, dpNew, inNew,
+                    c->pipeFp, dpOld, d, a);
+    }
+    if (rc != VH_OK) return rc;
+    if (hasNew) {
+        c->pipePending = true;
+        c->pipeFp = c->fp;
+        c->pipeSet = setNew;
+        c->pipeParity = newParity;
+        c->pipeSensor = newSensor;
+        if (newK) std::memcpy(c->pipeK, newK, sizeof c->pipeK);
+        c->dp.claim = dpNew.claim;               // the "current" buffers of everything that is not pipelined
+        c->dp.candidates = dpNew.candidates;
+        c->dp.compact = dpNew.compact;
+    } else {
+        c->pipePending = false;
+    }
+    c->occupiedCounter = kCompactCount;
+    c->compactArmed = false;
+    return VH_OK;
+}
+
+static int flush_pending(vh_context *c)
+{
+    if (!c->pipePending) return VH_OK;
+    const int rc = launch_pipelined<VertexMap>(c, nullptr, 0, nullptr);
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_flush(vh_context *c)
+{
+    if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    DeviceGuard guard(c->device);
+    return flush_pending(c);
 }
 
 // One frame (pose and lock epoch already set): In = where the claim phase reads a pixel's vertex,
@@ -159,11 +294,25 @@ static int launch_scan_claim(vh_context *c, const In &in, uint32_t claimBlocks, 
                   dim3(256), c->fp, c->dp, in, (uint32_t)c->numEntries, claimBlocks, c->fusedParity);
 }
 
+static inline int pipe_is_sensor(const VertexMap &) { return 0; }
+static inline int pipe_is_sensor(const SensorImage &) { return 1; }
+struct PipeK { float v[4]; };
+static inline PipeK pipe_k(const VertexMap &) { return PipeK{{0, 0, 0, 0}}; }
+static inline PipeK pipe_k(const SensorImage &s) { return PipeK{{s.k[6], s.k[7], s.k[8], s.unit}}; }
+
 template <class In, class Depth>
 static int run_frame(vh_context *c, const In &in, const Depth &depth)
 {
     int rc;
     c->occupiedCounter = kCompactCount;
+    if (pipeline_applies(c)) {
+        rc = launch_pipelined(c, &in, pipe_is_sensor(in), pipe_k(in).v);
+        if (rc != VH_OK) return rc;
+        if (c->profiling) c->profiledFrames += 1;
+        VH_HIP(hipGetLastError());
+        return VH_OK;
+    }
+    if ((rc = flush_pending(c)) != VH_OK) return rc;
     if (c->fusedFrame) {
         // two launches: {claim || table walk}, then {commit + integrate}; see vh_frame.hip
         const uint32_t claimBlocks = host_num_tiles(c);
@@ -201,7 +350,7 @@ extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4
     int rc = vh_set_pose(c, pose);
     if (rc == VH_OK) rc = vh_reset_mutexes(c);
     if (rc != VH_OK) return rc;
-    c->allocEpoch = c->fp.epoch;
+    c->allocEpoch = c->epochTotal;
     const float4 *v = reinterpret_cast<const float4 *>(verts);
     return run_frame(c, VertexMap{v, reinterpret_cast<const float4 *>(normals)}, vertex_depth(v));
 }
@@ -219,8 +368,42 @@ extern "C" int vh_integrate_depth(vh_context *c, const float pose[16], const uin
     in.depth = d_depth;
     std::memcpy(in.k, k_inv, sizeof in.k);
     in.unit = 5000.0f;                                                   // CameraTrackingUtils.cu:64
-    c->allocEpoch = c->fp.epoch;
+    c->allocEpoch = c->epochTotal;
     return run_frame(c, in, DepthSensor{in.depth, in.k[6], in.k[7], in.k[8], in.unit});
+}
+
+// K frames in K + 1 launches: the pipeline switched on for the call, flushed at its end.
+extern "C" int vh_integrate_batch(vh_context *c, int32_t count, const float *poses, const vh_float4 *const *d_verts,
+                                  const vh_float4 *const *d_normals)
+{
+    if (!c || count < 0 || (count > 0 && (!poses || !d_verts))) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    const int saved = c->pipeline;
+    c->pipeline = 1;
+    int rc = VH_OK;
+    for (int32_t i = 0; i < count && rc == VH_OK; ++i)
+        rc = vh_integrate(c, poses + 16 * (size_t)i, d_verts[i], d_normals ? d_normals[i] : nullptr);
+    c->pipeline = saved;
+    if (!saved) {
+        const int rc2 = vh_flush(c);
+        if (rc == VH_OK) rc = rc2;
+    }
+    return rc;
+}
+
+extern "C" int vh_integrate_depth_batch(vh_context *c, int32_t count, const float *poses, const uint16_t *const *d_depth,
+                                        const float k_inv[9])
+{
+    if (!c || count < 0 || (count > 0 && (!poses || !d_depth || !k_inv))) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    const int saved = c->pipeline;
+    c->pipeline = 1;
+    int rc = VH_OK;
+    for (int32_t i = 0; i < count && rc == VH_OK; ++i) rc = vh_integrate_depth(c, poses + 16 * (size_t)i, d_depth[i], k_inv);
+    c->pipeline = saved;
+    if (!saved) {
+        const int rc2 = vh_flush(c);
+        if (rc == VH_OK) rc = rc2;
+    }
+    return rc;
 }
 
 extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, float t_max, float *d_depth_out)
@@ -228,6 +411,7 @@ extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, floa
     if (!c || !pose || !d_depth_out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     if (!(t_max > t_min)) return fail(VH_ERR_INVALID_ARGUMENT, "t_max must exceed t_min");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     FrameParams fp = c->fp;
     std::memcpy(fp.T, pose, sizeof fp.T);
     const float q = (t_max - t_min) / fp.voxelSize;
@@ -253,6 +437,7 @@ extern "C" int vh_render_blocks(vh_context *c, const float pose[16], float t_min
     if (!c || !pose || !d_front || !d_back) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     if (!(t_max > t_min) || !(t_min >= 0.0f)) return fail(VH_ERR_INVALID_ARGUMENT, "need 0 <= t_min < t_max");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     BlockView bv;
     float inv[16];
     invert4x4(pose, inv);

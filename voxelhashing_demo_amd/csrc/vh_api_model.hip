@@ -29,6 +29,7 @@ extern "C" int vh_delete_blocks(vh_context *c, const int32_t *d_keys, int32_t n)
     if (!c || (!d_keys && n > 0) || n < 0) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table owns no blocks");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     {   // the sweep list is built under a fresh lock epoch (with the wrap handling of the frame's epochs)
         const int rc = vh_reset_mutexes(c);
         if (rc != VH_OK) return rc;
@@ -46,6 +47,7 @@ extern "C" int vh_garbage_collect(vh_context *c, float sdf_threshold)
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table owns no blocks");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     {
         const int rc = vh_reset_mutexes(c);
         if (rc != VH_OK) return rc;
@@ -63,6 +65,7 @@ extern "C" int vh_synchronize(vh_context *c)
 {
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     VH_HIP(hipStreamSynchronize(c->stream));
     return VH_OK;
 }
@@ -71,6 +74,7 @@ extern "C" int vh_get_counters(vh_context *c, vh_counters *out)
 {
     if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     int32_t h[kNumCounters];
     VH_HIP(hipMemcpyAsync(h, c->dp.counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
     VH_HIP(hipStreamSynchronize(c->stream));
@@ -79,7 +83,7 @@ extern "C" int vh_get_counters(vh_context *c, vh_counters *out)
     out->allocated_total = (uint32_t)h[kAllocatedTotal];
     out->heap_exhausted = (uint32_t)h[kHeapExhausted];
     out->candidates = (uint32_t)h[kLastCandidates];
-    out->epoch = c->fp.epoch;
+    out->epoch = c->epochTotal;
     out->bin_overflow = (uint32_t)h[kBinOverflow];
     out->freed_total = (uint32_t)h[kFreedTotal];
     out->last_freed = (uint32_t)h[kLastFreed];
@@ -111,6 +115,7 @@ extern "C" int vh_get_device_pointers(vh_context *c, PtrContainer *out)
 static int download_range(vh_context *c, int which, size_t offset, void *dst, size_t bytes)
 {
     if (!c || !dst) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    { DeviceGuard fguard(c->device); const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     const char *src = nullptr;
     size_t avail = 0;
     switch (which) {
@@ -126,6 +131,7 @@ static int download_range(vh_context *c, int which, size_t offset, void *dst, si
     }
     if (offset > avail || bytes > avail - offset) return fail(VH_ERR_INVALID_ARGUMENT, "download past the end of the buffer");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     VH_HIP(hipMemcpyAsync(dst, src + offset, bytes, hipMemcpyDeviceToHost, c->stream));
     VH_HIP(hipStreamSynchronize(c->stream));
     return VH_OK;
@@ -207,7 +213,7 @@ extern "C" int vh_save_snapshot(vh_context *c, const char *path)
     h.width = c->fp.width; h.height = c->fp.height; h.semantics = c->fp.semantics;
     h.bucketLo = c->fp.bucketLo; h.bucketHi = c->fp.bucketHi;
     h.heapCounter = k.heap_counter; h.allocatedTotal = k.allocated_total; h.heapExhausted = k.heap_exhausted;
-    h.epoch = c->fp.epoch;
+    h.epoch = c->epochTotal;
     h.numEntries = c->numEntries;
     std::memcpy(h.proj, c->fp.proj, sizeof h.proj);
     for (const VoxelEntry &e : table) h.numAllocated += e.ptr != VH_FREE_BLOCK;
@@ -254,8 +260,11 @@ static hipError_t reset_model(vh_context *c)
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     c->fp.epoch = 0;
     c->fusedParity = 0;
+    c->pipePending = false;
     c->compactArmed = false;
     c->occupiedCounter = kCompactCount;
+    if (e == hipSuccess && c->claimBuf[1])
+        e = hipMemset(c->claimBuf[1 - (c->dp.claim == c->claimBuf[1] ? 1 : 0)], 0, sizeof(unsigned long long) * (size_t)c->ownedBuckets);
     return e;
 }
 
@@ -322,6 +331,7 @@ extern "C" int vh_load_snapshot(vh_context *c, const char *path)
 
     // ---- from here on the device state changes ----
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     hipError_t e = reset_model(c);
     const size_t words = ((size_t)c->ownedBuckets + 31) / 32;
     std::vector<uint32_t> bits(words, 0u), macro(kMacroBits / 32, 0u);
@@ -358,11 +368,13 @@ extern "C" int vh_load_snapshot(vh_context *c, const char *path)
     std::memcpy(c->fp.Tinv, h.params.inv_global_transform, sizeof c->fp.Tinv);
     std::memcpy(c->fp.proj, h.proj, sizeof h.proj);
     c->params.numOccupiedBlocks = 0;
+    c->epochTotal = h.epoch;         // (frames have been integrated into this model: build-time options stay locked)
     return VH_OK;
 }
 
 extern "C" int vh_set_option(vh_context *c, const char *name, int value)
 {
+    if (c) { DeviceGuard fguard(c->device); const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     if (!c || !name) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     if (std::strcmp(name, "flatten_variant") == 0) {
         if (value != kWalkStridedBallot && value != kWalkIndexed && value != kWalkPersistent)
@@ -370,9 +382,13 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
         c->flattenVariant = value;
         return VH_OK;
     }
+    if (std::strcmp(name, "pipeline") == 0) {
+        c->pipeline = value != 0;
+        return VH_OK;                // (a pending frame was flushed at the top of this call)
+    }
     if (std::strcmp(name, "overflow_list") == 0) {
         // a table is built with the list or without it: the two keep different invariants (holes vs prefix)
-        if (c->fp.epoch != 0 && ((c->fp.flags & kFlagOverflow) != 0u) != (value != 0))
+        if (c->epochTotal != 0 && ((c->fp.flags & kFlagOverflow) != 0u) != (value != 0))
             return fail(VH_ERR_INVALID_ARGUMENT, "overflow_list must be chosen before the first frame");
         if (c->fp.listSize < 2 && value) return fail(VH_ERR_INVALID_ARGUMENT, "attachedLinkedListSize must be at least 2");
         c->fp.flags = value ? (c->fp.flags | kFlagOverflow) : (c->fp.flags & ~kFlagOverflow);
@@ -433,6 +449,7 @@ static int accumulate_times(vh_context *c)
             case kPhaseViewImport: c->times.view_import_ms += ms; break;
             case kPhaseGc: c->times.gc_ms += ms; break;
             case kPhaseRaycastBounds: c->times.render_blocks_ms += ms; break;
+            case kPhaseFramePipelined: c->times.frame_pipelined_ms += ms; break;
             default: break;
         }
         c->eventPool.emplace_back(t.start, t.stop);

@@ -30,6 +30,7 @@ extern "C" int vh_export_views(vh_context *c, const float *poses, int32_t n_view
     if (!(t_max > t_min)) return fail(VH_ERR_INVALID_ARGUMENT, "t_max must exceed t_min");
     if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table has no voxels of its own to export");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     const size_t need = (size_t)n_views * (size_t)capacity;
     if (c->viewListsSize < need) {                         // first call (or a larger one): synchronises
         VH_HIP(hipStreamSynchronize(c->stream));
@@ -67,12 +68,13 @@ extern "C" int vh_import_view(vh_context *c, const vh_view_record *d_records, in
         return fail(VH_ERR_INVALID_ARGUMENT, "bad record count");
     if (c->fp.bucketLo != 0 || c->fp.bucketHi != c->fp.numBuckets)
         return fail(VH_ERR_INVALID_ARGUMENT, "a view table is unsharded");
-    if (c->fp.epoch != 0) return fail(VH_ERR_INVALID_ARGUMENT, "this context has integrated frames: use a dedicated view context");
+    if (c->epochTotal != 0) return fail(VH_ERR_INVALID_ARGUMENT, "this context has integrated frames: use a dedicated view context");
     if ((size_t)count > c->candAllocated && (c->fp.flags & kFlagOverflow)) {
         const int rc = ensure_candidates(c, (size_t)count);
         if (rc != VH_OK) return rc;
     }
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     if (c->viewCount > 0) {
         const int rc = launch(c, kPhaseViewImport, view_clear_kernel, dim3((unsigned)grid_for((size_t)c->viewCount, 256)),
                               dim3(256), c->fp, c->dp, c->viewCount);
@@ -259,6 +261,7 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
         packet_stride < (size_t)batch * packet_frame_stride)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     {
         const int rc = ensure_candidates(c, (size_t)num_bins * (size_t)(capacity - 1));
         if (rc != VH_OK) return rc;
@@ -300,8 +303,9 @@ extern "C" int vh_insert_bins(vh_context *c, const int32_t *d_bins, int32_t num_
     if (bin_stride == 0) bin_stride = capacity;
     if (!c || !d_bins || num_bins <= 0 || capacity < 2 || bin_stride < capacity)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
-    if (c->fp.epoch == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
+    if (c->epochTotal == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_reset_mutexes must start the frame");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     {
         const int rc = ensure_candidates(c, (size_t)num_bins * (size_t)(capacity - 1));
         if (rc != VH_OK) return rc;
@@ -324,6 +328,7 @@ extern "C" int vh_integrate_packets(vh_context *c, int32_t num_cams, const float
     if (!c || !d_packets || num_cams <= 0 || num_cams > VH_MAX_CAMERAS || packet_stride < dense)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     const size_t stride = packet_stride;
     if (!c->compactArmed)
         VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));

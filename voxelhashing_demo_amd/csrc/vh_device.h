@@ -41,7 +41,15 @@ enum Counter : int {
     kFreedTotal = 16,      // blocks returned to the heap since creation
     kLastFreed = 17,       // ... by the last vh_delete_blocks / vh_garbage_collect
     kCandOverflow = 18,    // contenders dropped because the candidate list was full (never cleared)
-    kNumCounters = 24
+    // pipelined frames (vh_integrate_batch): three rotating sets -- the launch of frame i+1 fills set
+    // (i+1)%3 (claim / walk), consumes set i%3 (commit / integrate of frame i) and clears set (i+2)%3
+    kPipeScan = 20,        // [3]
+    kPipeNew = 23,         // [3]
+    kPipeCand = 26,        // [3]
+    kPipeHeapFree = 29,    // [3] free blocks on the heap when the launch that consumes the set began (written by the
+                           //     last commit workgroup of the launch before, into the set the next launch consumes)
+    kPipeWinners = 32,     // [3] buckets claimed in the frame = entries its commit phase will insert
+    kNumCounters = 36
 };
 
 // Everything a kernel needs about the frame, passed by value in the kernel
@@ -61,7 +69,7 @@ struct FrameParams {
     uint32_t bucketLo;    // this context owns buckets [bucketLo, bucketHi)
     uint32_t bucketHi;
     uint32_t numVoxelBlocks;
-    uint32_t epoch;       // bucket-lock epoch of this frame (>= 1)
+    uint32_t epoch;       // bucket-lock epoch of this frame, 1..kMaxClaimEpoch (the host clears the claim words on wrap)
     float allocBand;      // 0: a pixel demands its surface block only (reference); > 0: +- band along the ray
     uint32_t flags;       // kFlag*: opt-in extensions (all 0 = the live reference path)
     uint32_t listSize;    // attachedLinkedListSize: iterations of the chain loop (VoxelUtils.cu:391-392)
@@ -206,20 +214,34 @@ __device__ __forceinline__ uint32_t launch_rank(int x, int y, int width)
     return ((((uint32_t)y >> 4) * tilesX + ((uint32_t)x >> 4)) << 8) + (((uint32_t)y & 15u) << 4) + ((uint32_t)x & 15u);
 }
 
-// Claim word of a contender: newer epochs beat stale words, and within an epoch the
-// lowest rank gives the largest word.  Once the winner has been served the word is
-// replaced by the epoch's largest value, so the bucket stays locked for the rest of
-// the epoch even if allocBlocks runs again before the next reset (the reference's
-// mutex is never released within a frame, VoxelUtils.cu:444-445).
-__device__ __forceinline__ unsigned long long claim_word(uint32_t epoch, uint32_t rank)
+// Claim word of a contender, 64 bits: [epoch:10 | 0xfffffffe - rank:32 | f:3 | slot:19].
+// Newer epochs beat stale words and, within an epoch, the lowest rank gives the largest word, so
+// atomicMax over the contenders of a bucket leaves the winner's word: the thread a sequential run of
+// the reference grid would have let through the atomicExch (VoxelUtils.cu:444-445).  The word also
+// says WHO won (slot = index of the contender's record in the candidate list, hence its key) and
+// WHERE the entry goes (f = first free slot of the bucket as the contender saw it): the pipelined
+// frame reads both while the insertion itself is still in flight (vh_frame.hip).  Once the winner has
+// been served the word is replaced by the epoch's largest value, so the bucket stays locked for the
+// rest of the epoch even if allocBlocks runs again before the next reset (the reference's mutex is
+// never released within a frame).
+constexpr uint32_t kMaxClaimEpoch = 1023u;
+constexpr uint32_t kClaimSlotBits = 19, kClaimFBits = 3;
+constexpr uint32_t kMaxCandidates = (1u << kClaimSlotBits) - 1u;      // candidate records per lock epoch
+
+__device__ __forceinline__ unsigned long long claim_word(uint32_t epoch, uint32_t rank, uint32_t f, uint32_t slot)
 {
-    return ((unsigned long long)epoch << 32) | (unsigned long long)(0xfffffffeu - rank);
+    return ((unsigned long long)epoch << 54) | ((unsigned long long)(0xfffffffeu - rank) << 22) |
+           ((unsigned long long)(f & 7u) << kClaimSlotBits) | (unsigned long long)slot;
 }
 
 __device__ __forceinline__ unsigned long long consumed_word(uint32_t epoch)
 {
-    return ((unsigned long long)epoch << 32) | 0xffffffffull;
+    return ((unsigned long long)epoch << 54) | 0x3fffffffffffffull;
 }
+
+__device__ __forceinline__ uint32_t claim_epoch(unsigned long long w) { return (uint32_t)(w >> 54); }
+__device__ __forceinline__ uint32_t claim_slot(unsigned long long w) { return (uint32_t)w & kMaxCandidates; }
+__device__ __forceinline__ uint32_t claim_f(unsigned long long w) { return (uint32_t)(w >> kClaimSlotBits) & 7u; }
 
 // ---- overflow list (kFlagOverflow) -------------------------------------------------------------
 // The entries of one home bucket that did not fit its slots form a chain that starts in the bucket's

@@ -92,4 +92,129 @@ __global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const Frame
     }
 }
 
+// ---------------------------------------------------------------------------
+// the pipelined frame: ONE launch per frame (option "pipeline", vh_integrate_batch)
+// ---------------------------------------------------------------------------
+// The two launches of a frame are ordered by data -- commit(i) needs every claim of frame i -- but the
+// second one is a few microseconds of latency (counters -> candidate -> bucket -> heap -> block) that a
+// kernel boundary on each side turns into a quarter of the frame.  Here the launch of frame i+1 also
+// carries the deferred half of frame i:
+//     launch i+1 = { claim(i+1) || walk(i+1) || commit(i) + integrate(i) }
+// so the only ordering left is one kernel boundary per frame.  What makes this exact:
+//   * claim(i+1) must judge every bucket as it will be AFTER commit(i), which runs concurrently.  It
+//     never reads a slot that is being written: frame i's claim words (final, written by the previous
+//     launch) say for every bucket who won it and which slot the entry goes to (claim_word: slot -> key,
+//     f), so the insertion in flight is substituted from there (probe_and_claim, Pending);
+//   * walk(i+1) must list the entries allocated after commit(i) and visible from pose i+1.  An entry
+//     that commit(i) is inserting is skipped by the walk whatever it sees of it (same claim words) and
+//     appended to frame i+1's list by commit(i) itself after the frustum test with pose i+1;
+//   * integrate(i) gathers depth from a private copy of frame i's camera-z plane (float) or sensor
+//     image (uint16) that claim(i) wrote, so the caller's buffer is only read by the launch of its own
+//     frame: no lifetime requirement beyond vh_integrate's;
+//   * claim words, candidate lists and compact lists alternate between two buffers, the per-frame
+//     counters between three sets (filled by frame i+1, consumed by frame i, cleared for frame i+2);
+//   * a frame that would insert more entries than the heap has free blocks is refused as a whole (all its
+//     winners count as heap_exhausted and retry next frame): then claim(i+1) knows -- from two numbers
+//     that are stable while the launch runs -- that nothing is in flight and reads the table as it is.
+//     (vh_integrate without the pipeline serves as many winners as there are blocks.)
+// Roles by workgroup index: [commit][integrate][claim and walk interleaved as in frame_scan_claim_kernel].
+struct PipeArgs {
+    uint32_t claimBlocks, walkBlocks, commitBlocks, integrateBlocks;
+    uint32_t numEntries;
+    int32_t setNew, setOld, setClear;      // counter sets: filled, consumed, cleared by this launch
+    uint32_t hasNew, hasOld;               // first launch of a run: no old frame; flush launch: no new frame
+    float *planeNew;                       // private depth copies written by claim(new) ...
+    uint16_t *rawNew;
+};
+
+template <class In, class Depth>
+__global__ __launch_bounds__(256) void frame_pipelined_kernel(const FrameParams fpNew, const DevPtrs dpNew, const In inNew,
+                                                              const FrameParams fpOld, const DevPtrs dpOld,
+                                                              const Depth depthOld, const PipeArgs a)
+{
+    int32_t *counters = dpNew.counters;
+    // is frame i's commit phase inserting (live) or refusing everything?  Both numbers are stable while
+    // this launch runs: the count of claimed buckets was final when the previous launch ended, the
+    // free-block count was stored by its last commit workgroup (or by pipe_begin_kernel) in a word this
+    // launch does not write.
+    const int demandedOld = a.hasOld ? counters[kPipeCand + a.setOld] : 0;
+    const int candOld = min(demandedOld, (int)dpOld.candCapacity);
+    const bool live = a.hasOld && counters[kPipeHeapFree + a.setOld] >= counters[kPipeWinners + a.setOld];
+    const uint32_t b = blockIdx.x;
+    if (b >= a.commitBlocks + a.integrateBlocks) {
+        // ---- frame i+1: claim || walk ----
+        if (!a.hasNew) return;
+        const Pending pend{a.hasOld ? dpOld.claim : nullptr, dpOld.candidates, fpOld.epoch, live, kPipeWinners + a.setNew};
+        const uint32_t r = b - a.commitBlocks - a.integrateBlocks, total = a.claimBlocks + a.walkBlocks;
+        const uint32_t claimBefore = (uint32_t)(((uint64_t)r * a.claimBlocks) / total);
+        const uint32_t claimAfter = (uint32_t)(((uint64_t)(r + 1u) * a.claimBlocks) / total);
+        if (claimAfter != claimBefore) {
+            __builtin_amdgcn_s_setprio(3);
+            claim_tile(fpNew, dpNew, inNew, claimBefore, kPipeCand + a.setNew, &pend, a.planeNew, a.rawNew);
+        } else {
+            flatten_tile_ballot(fpNew, dpNew, a.numEntries, r - claimBefore, kPipeScan + a.setNew, &pend);
+        }
+        return;
+    }
+    if (!a.hasOld) return;
+    const int scanOld = counters[kPipeScan + a.setOld];
+    if (b >= a.commitBlocks) {
+        // ---- frame i: TSDF update of the blocks its walk (and commit(i-1)) listed ----
+        for (int k = (int)(b - a.commitBlocks); k < scanOld; k += (int)a.integrateBlocks)
+            integrate_block(fpOld, dpOld, dpOld.compact[k], depthOld);
+        return;
+    }
+    // ---- frame i: commit ----
+    __shared__ VoxelEntry newEntry;
+    __shared__ int inserted;
+    const int workers = max(1, min(candOld, (int)a.commitBlocks));
+    if ((int)b >= workers) return;
+    for (int i = (int)b; i < candOld; i += (int)a.commitBlocks) {
+        if (threadIdx.x == 0) {
+            inserted = 0;
+            const int4 k = dpOld.candidates[i];
+            if (live) {
+                VoxelEntry e;
+                inserted = commit_candidate(fpOld, dpOld, k, e, (uint32_t)i, false) ? 1 : 0;
+                if (inserted) {
+                    newEntry = e;
+                    dpOld.compact[scanOld + atomicAdd(counters + kPipeNew + a.setOld, 1)] = e;
+                    // what walk(i+1) would have listed had it seen the entry
+                    if (a.hasNew && block_in_frustum(fpNew, e.pos[0], e.pos[1], e.pos[2]))
+                        dpNew.compact[atomicAdd(counters + kPipeScan + a.setNew, 1)] = e;
+                }
+            } else {
+                const uint32_t local = hash_block(k.x, k.y, k.z, fpOld.numBuckets) - fpOld.bucketLo;
+                const unsigned long long w = dpOld.claim[local];
+                if (claim_epoch(w) == fpOld.epoch && claim_slot(w) == (uint32_t)i) atomicAdd(counters + kHeapExhausted, 1);
+            }
+        }
+        __syncthreads();
+        if (inserted) integrate_block(fpOld, dpOld, newEntry, depthOld);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(counters + kCommitTicket, 1);
+        if (ticket == workers - 1) {
+            counters[kCompactCount] = scanOld + atomicAdd(counters + kPipeNew + a.setOld, 0);
+            counters[kLastCandidates] = demandedOld;
+            counters[kPipeScan + a.setClear] = 0;
+            counters[kPipeNew + a.setClear] = 0;
+            counters[kPipeCand + a.setClear] = 0;
+            counters[kPipeWinners + a.setClear] = 0;
+            counters[kPipeHeapFree + a.setNew] = atomicAdd(counters + kHeapCounter, 0) + 1;   // what the next launch starts with
+            counters[kCommitTicket] = 0;
+        }
+    }
+}
+
+// start of a pipelined run: the three counter sets are empty, the free-block count is current
+__global__ void pipe_begin_kernel(const DevPtrs dp)
+{
+    if (threadIdx.x < 9) dp.counters[kPipeScan + threadIdx.x] = 0;       // kPipeScan, kPipeNew, kPipeCand: 3 x 3 consecutive
+    if (threadIdx.x >= 9 && threadIdx.x < 12) dp.counters[kPipeHeapFree + threadIdx.x - 9] = dp.counters[kHeapCounter] + 1;
+    if (threadIdx.x >= 12 && threadIdx.x < 15) dp.counters[kPipeWinners + threadIdx.x - 12] = 0;
+}
+
 }  // namespace vh

@@ -56,8 +56,12 @@ __device__ __forceinline__ void walk_load_tile(const DevPtrs &dp, uint32_t numEn
     }
 }
 
+// pend (pipelined frames only): the frame whose commit phase runs concurrently.  The entry it is
+// inserting into a bucket (slot f of the bucket's claim word of that epoch) may or may not be visible
+// yet; it is skipped here whatever the walk sees, and appended by that commit phase itself.
 __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
-                                                  const int32_t (&ptrs)[kEntriesPerLane], int counter)
+                                                  const int32_t (&ptrs)[kEntriesPerLane], int counter,
+                                                  const Pending *pend = nullptr)
 {
     const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
     bool any = false;
@@ -70,8 +74,17 @@ __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const D
         bool hit = false;
         VoxelEntry ent;
         if (ptrs[j] != VH_FREE_BLOCK) {
-            ent = dp.table[tile + j * kFlattenThreads + threadIdx.x];
-            hit = block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);   // VoxelUtils.cu:732
+            const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
+            bool inFlight = false;
+            if (pend && pend->claim && pend->live) {
+                const uint32_t b = e / fp.bucketSize;
+                const unsigned long long w = pend->claim[b];
+                inFlight = claim_epoch(w) == pend->epoch && claim_f(w) == e - b * fp.bucketSize;
+            }
+            if (!inFlight) {
+                ent = dp.table[e];
+                hit = block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);   // VoxelUtils.cu:732
+            }
         }
         const unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;
@@ -84,11 +97,11 @@ __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const D
 }
 
 __device__ __forceinline__ void flatten_tile_ballot(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
-                                                    uint32_t tileIndex, int counter)
+                                                    uint32_t tileIndex, int counter, const Pending *pend = nullptr)
 {
     int32_t ptrs[kEntriesPerLane];
     walk_load_tile(dp, numEntries, tileIndex, ptrs);
-    walk_process_tile(fp, dp, tileIndex, ptrs, counter);
+    walk_process_tile(fp, dp, tileIndex, ptrs, counter, pend);
 }
 
 // Persistent form of the same walk for tables far larger than the Infinity Cache: a workgroup

@@ -122,6 +122,27 @@ class SDFHashtable:
         L.check(self._lib.vh_integrate_depth(self._h, pp, _dev_ptr(depth_u16), k.ctypes.data_as(C.POINTER(C.c_float))),
                 "vh_integrate_depth")
 
+    def integrate_batch(self, poses, verts_list, normals_list=None):
+        """len(poses) frames in len(poses) + 1 launches (pipelined frames, flushed at the end); equals
+        integrate() frame by frame."""
+        n = len(poses)
+        p = np.ascontiguousarray(np.asarray(poses, np.float32).reshape(n, 16))
+        v = (C.c_void_p * n)(*[_dev_ptr(t) for t in verts_list])
+        nn = None if normals_list is None else (C.c_void_p * n)(*[_dev_ptr(t) for t in normals_list])
+        L.check(self._lib.vh_integrate_batch(self._h, n, p.ctypes.data_as(C.POINTER(C.c_float)), v, nn), "vh_integrate_batch")
+
+    def integrate_depth_batch(self, poses, depth_list, k_inv):
+        n = len(poses)
+        p = np.ascontiguousarray(np.asarray(poses, np.float32).reshape(n, 16))
+        d = (C.c_void_p * n)(*[_dev_ptr(t) for t in depth_list])
+        k = np.ascontiguousarray(np.asarray(k_inv, np.float32).reshape(9))
+        L.check(self._lib.vh_integrate_depth_batch(self._h, n, p.ctypes.data_as(C.POINTER(C.c_float)), d,
+                                                   k.ctypes.data_as(C.POINTER(C.c_float))), "vh_integrate_depth_batch")
+
+    def flush(self):
+        """Launch the pending half of the last pipelined frame (option "pipeline")."""
+        L.check(self._lib.vh_flush(self._h), "vh_flush")
+
     def raycast(self, pose, out, t_min: float = 0.1, t_max: float = 5.0):
         _, pp = _pose16(pose)
         L.check(self._lib.vh_raycast(self._h, pp, t_min, t_max, _dev_ptr(out)), "vh_raycast")
