@@ -54,7 +54,7 @@ WORKLOADS = {
                desc="C5: synthetic room, 1920x1080 streams, 2^24 buckets x 5 in all, 2^21 voxel blocks per rank, "
                     "voxel 0.01 m, PINHOLE semantics"),
 }
-ALL_LEGS = ("first_lap", "index", "sensor", "raycast", "next", "loaded", "c3", "sharded", "cpu")
+ALL_LEGS = ("two_launch", "first_lap", "index", "sensor", "raycast", "next", "loaded", "c3", "sharded", "cpu")
 
 
 def parse_args():
@@ -155,13 +155,16 @@ def render_frames(synth, wl, nframes, dev, torch):
 class Integrator:
     """One table + resident frames; step(i) = vh_integrate of frame i mod nframes."""
 
-    def __init__(self, V, L, wl, poses, verts, local_rank, stream):
-        self.V, self.L, self.wl, self.stream = V, L, wl, stream
+    def __init__(self, V, L, wl, poses, verts, local_rank, stream, pipeline=True):
+        self.V, self.L, self.wl, self.stream, self.pipeline = V, L, wl, stream, pipeline
         self.nframes = len(poses)
         params = V.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
         self.table = V.SDFHashtable(params, wl["width"], wl["height"], V.SEM_PINHOLE, device=local_rank, stream=stream)
         if wl.get("band"):
             self.table.set_alloc_band(wl["band"])
+        # pipelined frames: one launch per frame (the commit + TSDF update of frame i ride in the launch of
+        # frame i+1); every synchronisation flushes, so a timed window contains all of its frames' work
+        self.table.set_option("pipeline", 1 if pipeline else 0)
         self.lib, self.h = self.table._lib, self.table._h
         self.pose_keep = [np.ascontiguousarray(p.reshape(16)) for p in poses]
         self.pose_ptrs = [p.ctypes.data_as(C.POINTER(C.c_float)) for p in self.pose_keep]
@@ -189,40 +192,50 @@ class Integrator:
         wl = self.wl
         Wd, Ht, n_entries = wl["width"], wl["height"], self.table.num_entries
         launches = max(1, kt["launches"])
-        # dominant kernel of the fused frame: per-pixel claim phase || walk over the VoxelEntry array.
-        # Algorithmic bytes of one launch (SURVEY.md 8(d) terms): the vertex map read once by the claim
-        # half (16*W*H), one pass over the table (20*N), the compact entries written (20*occ) and one
-        # 100-byte bucket probe per distinct block key (keys ~ occ).
-        kname = "frame_scan_claim_kernel"
-        us = 1e3 * kt["frame_scan_claim_ms"] / launches
-        nbytes = 16 * Wd * Ht + 20 * n_entries + 20 * occ + 100 * occ
-        achieved = nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
         table_bytes = 20 * n_entries
         resident = table_bytes + 16 * Wd * Ht + 8212 * occ < L3_BYTES
-        # launch 2: per occupied block the 20-byte entry, 4 KiB of voxels read and 4 KiB written, plus the
-        # depth plane the update gathers from (counted once)
-        us2 = 1e3 * kt["frame_commit_integrate_ms"] / launches
-        bytes2 = occ * (20 + 4096 + 4096) + 4 * Wd * Ht
-        ach2 = bytes2 / (us2 * 1e-6) / 1e9 if us2 > 0 else 0.0
-        self.commit_roofline = dict(bound="hbm", kernel="frame_commit_integrate_kernel", achieved=round(ach2, 1),
-                                    peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach2 / HBM_PEAK_GBS, 4),
-                                    traffic=pmc_traffic(workload, "frame_commit_integrate_kernel"),
-                                    bytes_per_launch=bytes2, us_per_launch=round(us2, 2))
+        residency = (("the %.0f MB table plus the frame's stream fit the 256 MiB Infinity Cache: in steady state the walk "
+                      "is served on-die, so this is a fraction of the HBM PEAK, not measured HBM traffic (FETCH_SIZE counts "
+                      "Infinity-Cache hits); the HBM-resident figure is configs.C3.roofline" % (table_bytes / 1e6))
+                     if resident else
+                     ("the %.0f MB table exceeds the 256 MiB Infinity Cache: streamed from HBM every frame" % (table_bytes / 1e6)))
+        self.commit_roofline = None
+        if kt.get("frame_pipelined_ms", 0) > 0:
+            # the ONE launch of a pipelined frame: {claim || walk} of frame i+1 and {commit + TSDF update} of frame
+            # i.  Its algorithmic bytes are SURVEY.md 8(d)'s B_frame: the vertex map read once (16*W*H), the
+            # depth the update gathers (4*W*H), one pass over the table (20*N), the compact entries written
+            # (20*occ), per visible block its entry and 4 KiB read + 4 KiB written, one 100-byte bucket probe
+            # per distinct block key (keys ~ occ).
+            kname = "frame_pipelined_kernel"
+            us = 1e3 * kt["frame_pipelined_ms"] / launches
+            nbytes = 16 * Wd * Ht + 4 * Wd * Ht + 20 * n_entries + 20 * occ + occ * (20 + 4096 + 4096) + 100 * occ
+        else:
+            # dominant kernel of the two-launch frame: per-pixel claim phase || walk over the VoxelEntry array:
+            # the vertex map read once by the claim half (16*W*H), one pass over the table (20*N), the compact
+            # entries written (20*occ) and one 100-byte bucket probe per distinct block key (keys ~ occ).
+            kname = "frame_scan_claim_kernel"
+            us = 1e3 * kt["frame_scan_claim_ms"] / launches
+            nbytes = 16 * Wd * Ht + 20 * n_entries + 20 * occ + 100 * occ
+            # launch 2: per occupied block the 20-byte entry, 4 KiB of voxels read and 4 KiB written, plus the
+            # depth plane the update gathers from (counted once)
+            us2 = 1e3 * kt["frame_commit_integrate_ms"] / launches
+            bytes2 = occ * (20 + 4096 + 4096) + 4 * Wd * Ht
+            ach2 = bytes2 / (us2 * 1e-6) / 1e9 if us2 > 0 else 0.0
+            self.commit_roofline = dict(bound="hbm", kernel="frame_commit_integrate_kernel", achieved=round(ach2, 1),
+                                        peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach2 / HBM_PEAK_GBS, 4),
+                                        traffic=pmc_traffic(workload, "frame_commit_integrate_kernel"),
+                                        bytes_per_launch=bytes2, us_per_launch=round(us2, 2))
+        achieved = nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
         return dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(workload, kname),
-                    bytes_per_launch=nbytes, us_per_launch=round(us, 2),
-                    residency=("the %.0f MB table plus the frame's stream fit the 256 MiB Infinity Cache: in steady state "
-                               "the walk is served on-die, so this is a fraction of the HBM PEAK, not measured HBM "
-                               "traffic (FETCH_SIZE counts Infinity-Cache hits); the HBM-resident figure is "
-                               "configs.C3.roofline" % (table_bytes / 1e6)) if resident else
-                              ("the %.0f MB table exceeds the 256 MiB Infinity Cache: streamed from HBM every frame"
-                               % (table_bytes / 1e6)))
+                    bytes_per_launch=nbytes, us_per_launch=round(us, 2), residency=residency)
 
     def close(self):
         self.table.close()
 
 
-def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, want_profile=True, frames=None):
+def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, want_profile=True, frames=None,
+                     pipeline=True):
     """Timed windows + dominant-kernel roofline of one single-GPU workload.  Returns (record, Integrator, poses, verts)."""
     wl = WORKLOADS[name]
     dev = torch.device("cuda", local_rank)
@@ -230,7 +243,7 @@ def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, 
     nframes = args.frames or wl["frames"]
     poses, verts = frames if frames is not None else render_frames(synth, wl, nframes, dev, torch)
     nframes = len(poses)
-    it = Integrator(V, L, wl, poses, verts, local_rank, stream)
+    it = Integrator(V, L, wl, poses, verts, local_rank, stream, pipeline=pipeline)
     lap = max(nframes, 500) if name.startswith("C2") else nframes
     for i in range(lap):           # fixed, untimed run-in (one lap of the resident frames) before the W warm-up steps
         it.step(i)
@@ -239,11 +252,12 @@ def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, 
     rec = window_stats(times, steps)
     counters = it.table.counters()
     occ = counters["occupied"]
-    rec["occupied_blocks"], rec["allocated_blocks"] = occ, counters["allocated_total"]
+    rec["occupied_blocks"], rec["allocated_blocks"], rec["resident_frames"] = occ, counters["allocated_total"], nframes
     if want_profile and args.profile_steps > 0:
         kt = it.kernel_profile(args.profile_steps, nxt)
         rec["roofline"] = it.dominant_roofline(name, kt, occ)
-        rec["roofline_commit_integrate"] = it.commit_roofline
+        if it.commit_roofline:
+            rec["roofline_commit_integrate"] = it.commit_roofline
         rec["kernels"] = {k[:-3] + "_us": round(1e3 * v / max(1, kt["launches"]), 2)
                           for k, v in kt.items() if k.endswith("_ms") and v > 0 and k not in ("raycast_ms",)}
     Wd, Ht, n_entries = wl["width"], wl["height"], it.table.num_entries
@@ -360,6 +374,21 @@ def main():
     sync = lambda: (table.synchronize(), torch.cuda.synchronize())        # noqa: E731
     extra = {}
 
+    # ---- the same frames unpipelined: vh_integrate as two launches per frame ({claim || walk}, {commit + TSDF
+    # update}); what round 1 measured, and what a caller gets who reads the model between frames ----
+    if "two_launch" in legs:
+        table.set_option("pipeline", 0)
+        t_2, nxt2 = timed_windows(it.step, sync, args.steps, args.warmup)
+        rec2 = dict(window_stats(t_2, args.steps), unit="frames/s")
+        if args.profile_steps > 0:
+            kt2 = it.kernel_profile(args.profile_steps, nxt2)
+            rec2["roofline_scan_claim"] = it.dominant_roofline(name, kt2, occ)
+            rec2["roofline_commit_integrate"] = it.commit_roofline
+            rec2["kernels"] = {k[:-3] + "_us": round(1e3 * v / max(1, kt2["launches"]), 2)
+                               for k, v in kt2.items() if k.endswith("_ms") and v > 0 and k not in ("raycast_ms",)}
+        extra["two_launch_frame"] = rec2
+        table.set_option("pipeline", 1)
+
     # ---- first lap: a FRESH table over the resident frames in order -- the frames in which blocks are
     # actually inserted (commit phase, heap pops, new-block integration); the steady-state `value`
     # above only revisits known blocks ----
@@ -464,8 +493,14 @@ def main():
         l_rec, l_it, _, _ = measure_workload(args, V, L, synth, torch, "C2band", local_rank, args.steps, args.warmup,
                                              frames=(poses, verts))
         l_rec["unit"], l_rec["workload"] = "frames/s", WORKLOADS["C2band"]["desc"]
-        l_rec["roofline"], l_rec["roofline_scan_claim"] = l_rec.pop("roofline_commit_integrate", None), l_rec.get("roofline")
         extra["loaded_integrate"] = l_rec
+        # launch 2 alone under this load (two-launch frames): the 8^3-block read-modify-write by itself
+        l_it.table.set_option("pipeline", 0)
+        for i in range(20):
+            l_it.step(i)
+        kt_l2 = l_it.kernel_profile(min(200, max(20, args.profile_steps)), 20)
+        l_it.dominant_roofline("C2band", kt_l2, l_it.table.counters()["occupied"])
+        l_rec["roofline_commit_integrate_two_launch"] = l_it.commit_roofline
         l_it.close()
 
     # ---- next rows ----
@@ -514,11 +549,12 @@ def main():
         value=main_rec["value"], unit="frames/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
         ms_per_step=main_rec["ms_per_step"], higher_is_better=True, scaling="weak",
         vs_baseline=None, dtype="f32", data="synthetic",
-        metric_note="value = frames/s TSDF-integrated (median window of K steps); the raycast half of the metric "
+        metric_note="value = frames/s TSDF-integrated (median window of K steps, pipelined frames: one launch per frame, "
+                    "flushed inside the window; two_launch_frame = the same unpipelined); the raycast half of the metric "
                     "is raycast_mpix_per_s",
         windows=main_rec["windows"], timed_s=main_rec["timed_s"],
         window_min_ms=main_rec["window_min_ms"], window_max_ms=main_rec["window_max_ms"],
-        config=dict(workload=wl["desc"], resident_frames=it.nframes if it else nframes, semantics="pinhole",
+        config=dict(workload=wl["desc"], resident_frames=main_rec["resident_frames"], semantics="pinhole", pipelined=True,
                     occupied_blocks=occ, allocated_blocks=main_rec["allocated_blocks"], keys_last_frame=occ),
         roofline=main_rec.get("roofline"), cpu_baseline=cpu,
         raycast_mpix_per_s=round(raycast_mpix, 1) if raycast_mpix else None,

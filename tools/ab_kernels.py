@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--per-round", type=int, default=50)
+    ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--set", nargs="*", default=[], help="name=value options set once")
     a = ap.parse_args()
     import torch
 
@@ -35,9 +37,15 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     t = V.SDFHashtable(V.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"]),
                        Wd, Ht, V.SEM_PINHOLE, stream=stream)
+    if wl.get("band"):
+        t.set_alloc_band(wl["band"])
     for i in range(a.frames):
         t.integrate(poses[i], verts[i])
     t.synchronize()
+    t.set_option("pipeline", a.pipeline)
+    for kv in a.set:
+        k, v = kv.split("=")
+        t.set_option(k, int(v))
     res = {v: [] for v in a.values}
     for r in range(a.rounds):
         for v in a.values:
@@ -52,7 +60,8 @@ def main():
     for v in a.values:
         keys = res[v][0].keys()
         print(f"{a.option}={v}: " + "  ".join(
-            f"{k[:-3]} med {np.median([x[k] for x in res[v]]):.2f} min {np.min([x[k] for x in res[v]]):.2f} us" for k in keys))
+            f"{k[:-3]} med {np.median([x[k] for x in res[v]]):.2f} min {np.min([x[k] for x in res[v]]):.2f} us" for k in keys
+            if np.max([x[k] for x in res[v]]) > 0))
 
 
 if __name__ == "__main__":

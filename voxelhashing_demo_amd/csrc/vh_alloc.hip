@@ -71,12 +71,13 @@ struct Pending {
     const int4 *__restrict__ cand;
     uint32_t epoch;
     bool live;
-    int winnersCounter;                               // of the frame being claimed: counts its distinct buckets
+    int winnersCounter;                               // of the frame being claimed: counts its distinct buckets (-1: not counted)
 };
+__device__ constexpr Pending kNoPending{nullptr, nullptr, 0u, false, -1};
 
 __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz,
                                                 uint32_t h, uint32_t rank, int candCounter = kCandCount,
-                                                const Pending *pend = nullptr)
+                                                const Pending &pend = kNoPending)
 {
     if (fp.flags & kFlagOverflow) {
         probe_and_claim_overflow(fp, dp, kx, ky, kz, h, rank, candCounter);
@@ -87,11 +88,11 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
     // the insertion in flight into this bucket, if any: it takes the bucket's first free slot (pf)
     uint32_t pf = ~0u;
     int4 pk = make_int4(0, 0, 0, 0);
-    if (pend && pend->claim && pend->live) {
-        const unsigned long long w = pend->claim[local];
-        if (claim_epoch(w) == pend->epoch) {
+    if (pend.claim && pend.live) {
+        const unsigned long long w = pend.claim[local];
+        if (claim_epoch(w) == pend.epoch) {
             pf = claim_f(w);
-            pk = pend->cand[claim_slot(w)];
+            pk = pend.cand[claim_slot(w)];
         }
     }
     uint32_t firstFree = ~0u;
@@ -118,7 +119,7 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
     dp.candidates[slot] = make_int4(kx, ky, kz, (int)rank);
     const unsigned long long before = atomicMax(dp.claim + local, claim_word(fp.epoch, rank, firstFree, slot));
     // first claim on this bucket in this epoch: one more entry the commit phase will insert
-    if (pend && claim_epoch(before) != fp.epoch) atomicAdd(dp.counters + pend->winnersCounter, 1);
+    if (pend.winnersCounter >= 0 && claim_epoch(before) != fp.epoch) atomicAdd(dp.counters + pend.winnersCounter, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -351,7 +352,7 @@ __device__ __forceinline__ uint32_t sample_rank(const PixelVertex &p, int k)
 // the claim phase for one 16x16 launch tile = one 256-lane workgroup (alloc_claim_kernel and the fused frame)
 template <class In>
 __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs &dp, const In &in, uint32_t tile,
-                                           int candCounter, const Pending *pend = nullptr,
+                                           int candCounter, const Pending &pend = kNoPending,
                                            float *__restrict__ outDepth = nullptr, uint16_t *__restrict__ outRaw = nullptr)
 {
     const PixelVertex p = load_pixel(fp, in, tile, threadIdx.x, outDepth, outRaw);

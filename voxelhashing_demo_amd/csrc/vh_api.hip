@@ -88,6 +88,7 @@ struct vh_context {
     uint32_t epochTotal = 0;       // lock epochs since creation (fp.epoch is the 10-bit epoch of the claim words)
     // pipelined frames (option "pipeline", vh_integrate_batch; vh_frame.hip)
     int pipeline = 0;
+    int pipeIntegrateGrid = 512;   // workgroups of the deferred TSDF update inside a pipelined launch (4 blocks each per pass)
     bool pipePending = false;      // the commit + TSDF update of the last frame are still to be launched
     FrameParams pipeFp;            // that frame's parameters
     int pipeSet = 0;               // counter set its claim / walk filled

@@ -16,10 +16,13 @@ namespace vh {
 //
 // In: where a pixel's vertex comes from -- VertexMap (the float4 map of the reference's
 // interface) or SensorImage (vh_integrate_depth: the uint16 image, vertices computed in place).
+// planeOut (nullable): the claim half also leaves the camera z of every pixel in a packed float plane
+// for launch 2 to gather from -- 4 bytes per pixel written once here instead of a 16-byte-strided
+// gather from the vertex map there (C3, launch 2: 72 MB of traffic for 40 MB of algorithmic bytes).
 template <int kKind, class In>
 __global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams fp, const DevPtrs dp, const In in,
                                                                uint32_t numEntries, uint32_t claimBlocks,
-                                                               int parity)
+                                                               int parity, float *__restrict__ planeOut)
 {
     // The two roles are interleaved over the grid in proportion (block b is a claim block when
     // floor((b+1)*claim/total) steps): workgroups are dispatched roughly in index order, and
@@ -32,7 +35,7 @@ __global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams
         // the latency-bound pixel waves issue first when they are ready, so they are off the compute
         // unit sooner (17.9 -> 17.6 us; raising the streaming waves instead cost 0.25 us)
         __builtin_amdgcn_s_setprio(3);
-        claim_tile(fp, dp, in, claimBefore, kFusedCand + parity);
+        claim_tile(fp, dp, in, claimBefore, kFusedCand + parity, kNoPending, planeOut);
     } else {
         flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x - claimBefore, kScanCount + parity, total - claimBlocks);
     }
@@ -52,8 +55,7 @@ __global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const Frame
 {
     const int scanCount = dp.counters[kScanCount + parity];
     if (blockIdx.x >= commitBlocks) {
-        for (int b = blockIdx.x - commitBlocks; b < scanCount; b += gridDim.x - commitBlocks)
-            integrate_block(fp, dp, dp.compact[b], verts);
+        integrate_list(fp, dp, dp.compact, scanCount, (int)(blockIdx.x - commitBlocks), (int)(gridDim.x - commitBlocks), verts);
         return;
     }
     __shared__ VoxelEntry newEntry;
@@ -117,7 +119,6 @@ __global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const Frame
 //     winners count as heap_exhausted and retry next frame): then claim(i+1) knows -- from two numbers
 //     that are stable while the launch runs -- that nothing is in flight and reads the table as it is.
 //     (vh_integrate without the pipeline serves as many winners as there are blocks.)
-// Roles by workgroup index: [commit][integrate][claim and walk interleaved as in frame_scan_claim_kernel].
 struct PipeArgs {
     uint32_t claimBlocks, walkBlocks, commitBlocks, integrateBlocks;
     uint32_t numEntries;
@@ -127,10 +128,14 @@ struct PipeArgs {
     uint16_t *rawNew;
 };
 
+#ifndef VH_PIPE_ORDER
+#define VH_PIPE_ORDER 0
+#endif
+
 template <class In, class Depth>
-__global__ __launch_bounds__(256) void frame_pipelined_kernel(const FrameParams fpNew, const DevPtrs dpNew, const In inNew,
-                                                              const FrameParams fpOld, const DevPtrs dpOld,
-                                                              const Depth depthOld, const PipeArgs a)
+__device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const DevPtrs &dpNew, const In &inNew,
+                                                const FrameParams &fpOld, const DevPtrs &dpOld, const Depth &depthOld,
+                                                const PipeArgs &a)
 {
     int32_t *counters = dpNew.counters;
     // is frame i's commit phase inserting (live) or refusing everything?  Both numbers are stable while
@@ -140,36 +145,59 @@ __global__ __launch_bounds__(256) void frame_pipelined_kernel(const FrameParams 
     const int demandedOld = a.hasOld ? counters[kPipeCand + a.setOld] : 0;
     const int candOld = min(demandedOld, (int)dpOld.candCapacity);
     const bool live = a.hasOld && counters[kPipeHeapFree + a.setOld] >= counters[kPipeWinners + a.setOld];
+    // Roles by workgroup index: [commit][integrate][claim and walk interleaved as in frame_scan_claim_kernel]:
+    // frame i's deferred half runs first, at full width, then the table streams.  Measured on C2 / C3
+    // (launch time, us): this order with 512 integrate workgroups 18.8 / 88.9; with 2048 of them (mostly
+    // idle, but dispatched before the first walk tile) 19.7 / 91.9; integrate and claim workgroups
+    // interleaved among the walk tiles (VH_PIPE_ORDER 1) 20.5 / 93.7 -- the latency-bound block updates
+    // then hold the slots the stream needs; claims before the walk (VH_PIPE_ORDER 2) 20.4 / 93.0.
     const uint32_t b = blockIdx.x;
-    if (b >= a.commitBlocks + a.integrateBlocks) {
+    uint32_t role, index;                          // 0 commit, 1 integrate, 2 claim, 3 walk
+#if VH_PIPE_ORDER == 0
+    if (b < a.commitBlocks) { role = 0; index = b; }
+    else if (b < a.commitBlocks + a.integrateBlocks) { role = 1; index = b - a.commitBlocks; }
+    else {
+        const uint32_t r = b - a.commitBlocks - a.integrateBlocks, total = a.claimBlocks + a.walkBlocks;
+        const uint32_t before = (uint32_t)(((uint64_t)r * a.claimBlocks) / total);
+        const uint32_t after = (uint32_t)(((uint64_t)(r + 1u) * a.claimBlocks) / total);
+        if (after != before) { role = 2; index = before; } else { role = 3; index = r - before; }
+    }
+#else
+    if (b < a.commitBlocks) { role = 0; index = b; }
+    else {
+        const uint32_t r = b - a.commitBlocks, lat = a.integrateBlocks + a.claimBlocks, total = lat + a.walkBlocks;
+        const uint32_t before = (uint32_t)(((uint64_t)r * lat) / total);
+        const uint32_t after = (uint32_t)(((uint64_t)(r + 1u) * lat) / total);
+        if (after != before) {
+            if (before < a.integrateBlocks) { role = 1; index = before; } else { role = 2; index = before - a.integrateBlocks; }
+        } else { role = 3; index = r - before; }
+    }
+#endif
+    if (role >= 2u) {
         // ---- frame i+1: claim || walk ----
         if (!a.hasNew) return;
         const Pending pend{a.hasOld ? dpOld.claim : nullptr, dpOld.candidates, fpOld.epoch, live, kPipeWinners + a.setNew};
-        const uint32_t r = b - a.commitBlocks - a.integrateBlocks, total = a.claimBlocks + a.walkBlocks;
-        const uint32_t claimBefore = (uint32_t)(((uint64_t)r * a.claimBlocks) / total);
-        const uint32_t claimAfter = (uint32_t)(((uint64_t)(r + 1u) * a.claimBlocks) / total);
-        if (claimAfter != claimBefore) {
+        if (role == 2u) {
             __builtin_amdgcn_s_setprio(3);
-            claim_tile(fpNew, dpNew, inNew, claimBefore, kPipeCand + a.setNew, &pend, a.planeNew, a.rawNew);
+            claim_tile(fpNew, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
         } else {
-            flatten_tile_ballot(fpNew, dpNew, a.numEntries, r - claimBefore, kPipeScan + a.setNew, &pend);
+            flatten_tile_ballot(fpNew, dpNew, a.numEntries, index, kPipeScan + a.setNew, pend);
         }
         return;
     }
     if (!a.hasOld) return;
     const int scanOld = counters[kPipeScan + a.setOld];
-    if (b >= a.commitBlocks) {
+    if (role == 1u) {
         // ---- frame i: TSDF update of the blocks its walk (and commit(i-1)) listed ----
-        for (int k = (int)(b - a.commitBlocks); k < scanOld; k += (int)a.integrateBlocks)
-            integrate_block(fpOld, dpOld, dpOld.compact[k], depthOld);
+        integrate_list(fpOld, dpOld, dpOld.compact, scanOld, (int)index, (int)a.integrateBlocks, depthOld);
         return;
     }
     // ---- frame i: commit ----
     __shared__ VoxelEntry newEntry;
     __shared__ int inserted;
     const int workers = max(1, min(candOld, (int)a.commitBlocks));
-    if ((int)b >= workers) return;
-    for (int i = (int)b; i < candOld; i += (int)a.commitBlocks) {
+    if ((int)index >= workers) return;
+    for (int i = (int)index; i < candOld; i += (int)a.commitBlocks) {
         if (threadIdx.x == 0) {
             inserted = 0;
             const int4 k = dpOld.candidates[i];
@@ -207,6 +235,14 @@ __global__ __launch_bounds__(256) void frame_pipelined_kernel(const FrameParams 
             counters[kCommitTicket] = 0;
         }
     }
+}
+
+template <class In, class Depth>
+__global__ __launch_bounds__(256) void frame_pipelined_kernel(const FrameParams fpNew, const DevPtrs dpNew, const In inNew,
+                                                              const FrameParams fpOld, const DevPtrs dpOld,
+                                                              const Depth depthOld, const PipeArgs a)
+{
+    frame_pipelined(fpNew, dpNew, inNew, fpOld, dpOld, depthOld, a);
 }
 
 // start of a pipelined run: the three counter sets are empty, the free-block count is current

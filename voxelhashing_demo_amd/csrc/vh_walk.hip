@@ -61,7 +61,7 @@ __device__ __forceinline__ void walk_load_tile(const DevPtrs &dp, uint32_t numEn
 // yet; it is skipped here whatever the walk sees, and appended by that commit phase itself.
 __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
                                                   const int32_t (&ptrs)[kEntriesPerLane], int counter,
-                                                  const Pending *pend = nullptr)
+                                                  const Pending &pend = kNoPending)
 {
     const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
     bool any = false;
@@ -76,10 +76,10 @@ __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const D
         if (ptrs[j] != VH_FREE_BLOCK) {
             const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
             bool inFlight = false;
-            if (pend && pend->claim && pend->live) {
+            if (pend.claim && pend.live) {
                 const uint32_t b = e / fp.bucketSize;
-                const unsigned long long w = pend->claim[b];
-                inFlight = claim_epoch(w) == pend->epoch && claim_f(w) == e - b * fp.bucketSize;
+                const unsigned long long w = pend.claim[b];
+                inFlight = claim_epoch(w) == pend.epoch && claim_f(w) == e - b * fp.bucketSize;
             }
             if (!inFlight) {
                 ent = dp.table[e];
@@ -97,7 +97,7 @@ __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const D
 }
 
 __device__ __forceinline__ void flatten_tile_ballot(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
-                                                    uint32_t tileIndex, int counter, const Pending *pend = nullptr)
+                                                    uint32_t tileIndex, int counter, const Pending &pend = kNoPending)
 {
     int32_t ptrs[kEntriesPerLane];
     walk_load_tile(dp, numEntries, tileIndex, ptrs);
