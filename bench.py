@@ -270,6 +270,22 @@ def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, 
     return rec, it, poses, verts
 
 
+def two_launch_record(args, it, name, occ, steps, warmup, sync):
+    """The same frames unpipelined: vh_integrate as two launches per frame ({claim || walk}, {commit + TSDF
+    update}); what round 1 measured, and what a caller gets who reads the model between frames."""
+    it.table.set_option("pipeline", 0)
+    t_2, nxt2 = timed_windows(it.step, sync, steps, warmup)
+    rec2 = dict(window_stats(t_2, steps), unit="frames/s")
+    if args.profile_steps > 0:
+        kt2 = it.kernel_profile(args.profile_steps, nxt2)
+        rec2["roofline_scan_claim"] = it.dominant_roofline(name, kt2, occ)
+        rec2["roofline_commit_integrate"] = it.commit_roofline
+        rec2["kernels"] = {k[:-3] + "_us": round(1e3 * v / max(1, kt2["launches"]), 2)
+                           for k, v in kt2.items() if k.endswith("_ms") and v > 0 and k not in ("raycast_ms",)}
+    it.table.set_option("pipeline", 1)
+    return rec2
+
+
 def cpu_baseline_leg(args, name, poses, verts):
     """The oracle (kind "port") on this box's host cores over a bounded sample of the same frame
     sequence: a few seconds on one thread, then the rest of ~15 s on the fastest thread count."""
@@ -377,17 +393,7 @@ def main():
     # ---- the same frames unpipelined: vh_integrate as two launches per frame ({claim || walk}, {commit + TSDF
     # update}); what round 1 measured, and what a caller gets who reads the model between frames ----
     if "two_launch" in legs:
-        table.set_option("pipeline", 0)
-        t_2, nxt2 = timed_windows(it.step, sync, args.steps, args.warmup)
-        rec2 = dict(window_stats(t_2, args.steps), unit="frames/s")
-        if args.profile_steps > 0:
-            kt2 = it.kernel_profile(args.profile_steps, nxt2)
-            rec2["roofline_scan_claim"] = it.dominant_roofline(name, kt2, occ)
-            rec2["roofline_commit_integrate"] = it.commit_roofline
-            rec2["kernels"] = {k[:-3] + "_us": round(1e3 * v / max(1, kt2["launches"]), 2)
-                               for k, v in kt2.items() if k.endswith("_ms") and v > 0 and k not in ("raycast_ms",)}
-        extra["two_launch_frame"] = rec2
-        table.set_option("pipeline", 1)
+        extra["two_launch_frame"] = two_launch_record(args, it, name, occ, args.steps, args.warmup, sync)
 
     # ---- first lap: a FRESH table over the resident frames in order -- the frames in which blocks are
     # actually inserted (commit phase, heap pops, new-block integration); the steady-state `value`
@@ -517,6 +523,10 @@ def main():
                                                               max(50, min(args.steps, 200)), min(args.warmup, 20))
         c3_rec["workload"] = WORKLOADS["C3"]["desc"]
         c3_rec["unit"] = "frames/s"
+        if "two_launch" in legs:
+            c3_rec["two_launch_frame"] = two_launch_record(
+                args, c3_it, "C3", c3_rec["occupied_blocks"], max(50, min(args.steps, 200)), min(args.warmup, 20),
+                lambda: (c3_it.sync(), torch.cuda.synchronize()))
         extra["configs"] = {"C3": c3_rec}
         c3_it.close()
         del c3_verts
