@@ -87,6 +87,7 @@ struct vh_context {
     uint32_t allocEpoch = 0;       // lock epoch (epochTotal) of the last allocBlocks (overflow list: one per epoch)
     uint32_t epochTotal = 0;       // lock epochs since creation (fp.epoch is the 10-bit epoch of the claim words)
     // pipelined frames (option "pipeline", vh_integrate_batch; vh_frame.hip)
+    float *fusedPlane = nullptr;   // packed camera-z plane launch 1 of the two-launch frame leaves for launch 2 (large images)
     int pipeline = 0;
     int pipeIntegrateGrid = 512;   // workgroups of the deferred TSDF update inside a pipelined launch (4 blocks each per pass)
     bool pipePending = false;      // the commit + TSDF update of the last frame are still to be launched
@@ -254,6 +255,8 @@ static int free_buffers(vh_context *c)
     if (c->dp.compactMask) (void)hipFree(c->dp.compactMask);
     if (c->dp.bucketBits) (void)hipFree(c->dp.bucketBits);
     if (c->dp.macroBits) (void)hipFree(c->dp.macroBits);
+    if (c->fusedPlane) (void)hipFree(c->fusedPlane);
+    c->fusedPlane = nullptr;
     if (c->viewLists) (void)hipFree(c->viewLists);
     if (c->blockList) (void)hipFree(c->blockList);
     c->blockList = nullptr;

@@ -294,6 +294,17 @@ static int launch_scan_claim(vh_context *c, const In &in, uint32_t claimBlocks, 
                   dim3(256), c->fp, c->dp, in, (uint32_t)c->numEntries, claimBlocks, c->fusedParity, planeOut);
 }
 
+// the packed camera-z plane launch 1 leaves for launch 2 (vertex-map input only)
+static inline float *fused_plane(vh_context *c, const VertexMap &)
+{
+    if (!c->fusedPlane && hipMalloc((void **)&c->fusedPlane, sizeof(float) * (size_t)c->fp.width * c->fp.height) != hipSuccess)
+        c->fusedPlane = nullptr;                  // (out of memory: launch 2 gathers from the vertex map as before)
+    return c->fusedPlane;
+}
+static inline float *fused_plane(vh_context *, const SensorImage &) { return nullptr; }
+static inline DepthPlane plane_depth(const DepthPlane &fromVerts, float *plane) { return plane ? DepthPlane{plane, 1} : fromVerts; }
+static inline DepthSensor plane_depth(const DepthSensor &d, float *) { return d; }
+
 static inline int pipe_is_sensor(const VertexMap &) { return 0; }
 static inline int pipe_is_sensor(const SensorImage &) { return 1; }
 struct PipeK { float v[4]; };
@@ -317,9 +328,11 @@ static int run_frame(vh_context *c, const In &in, const Depth &depth)
         // two launches: {claim || table walk}, then {commit + integrate}; see vh_frame.hip
         const uint32_t claimBlocks = host_num_tiles(c);
         const uint32_t scanBlocks = walk_blocks(c);
-        // (a packed camera-z plane written by launch 1 for launch 2 to gather from, as the pipelined frame
-        // keeps one, was measured here too: C3 launch 1 +1.4 us, launch 2 -2.9 us; C2 +0.7 / -0.1 us: not kept)
-        float *plane = nullptr;
+        // Large images: launch 1 also leaves the camera z of every pixel in a packed float plane and launch 2
+        // gathers from that instead of the 16-byte-strided .z of the vertex map, which drags every line of the
+        // map through launch 2 (C3: 72 MB of counter traffic for 40 MB of algorithmic bytes).  In-process A/B:
+        // C3 (1.2 M pixels) launch 1 +1.4 us, launch 2 -2.9 us; C2 (0.3 M) +0.7 / -0.1 us: hence the size rule.
+        float *plane = (size_t)c->fp.width * c->fp.height >= ((size_t)1 << 20) ? fused_plane(c, in) : nullptr;
         if (c->flattenVariant == kWalkIndexed)
             rc = launch_scan_claim<kWalkIndexed>(c, in, claimBlocks, scanBlocks, plane);
         else if (c->flattenVariant == kWalkPersistent)
@@ -329,8 +342,8 @@ static int run_frame(vh_context *c, const In &in, const Depth &depth)
         if (rc != VH_OK) return rc;
         const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
         rc = launch(c, kPhaseFrameCommitIntegrate, frame_commit_integrate_kernel<Depth>,
-                    dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, depth, commitBlocks,
-                    c->fusedParity);
+                    dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, plane_depth(depth, plane),
+                    commitBlocks, c->fusedParity);
         if (rc != VH_OK) return rc;
         c->fusedParity ^= 1;       // this frame cleared the other counter set for the next one
         c->compactArmed = false;

@@ -49,9 +49,8 @@ __global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams
 // and clears the counter set of the other parity for the next frame.
 // Depth: where the TSDF update reads a pixel's camera z -- DepthPlane on &verts[0].z or DepthSensor.
 template <class Depth>
-__global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const FrameParams fp, const DevPtrs dp,
-                                                                     const Depth verts, uint32_t commitBlocks,
-                                                                     int parity)
+__device__ __forceinline__ void frame_commit_integrate(const FrameParams &fp, const DevPtrs &dp, const Depth &verts,
+                                                       uint32_t commitBlocks, int parity)
 {
     const int scanCount = dp.counters[kScanCount + parity];
     if (blockIdx.x >= commitBlocks) {
@@ -92,6 +91,14 @@ __global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const Frame
             dp.counters[kCommitTicket] = 0;
         }
     }
+}
+
+template <class Depth>
+__global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                     const Depth verts, uint32_t commitBlocks,
+                                                                     int parity)
+{
+    frame_commit_integrate(fp, dp, verts, commitBlocks, parity);
 }
 
 // ---------------------------------------------------------------------------
