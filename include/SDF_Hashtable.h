@@ -67,6 +67,14 @@ public:
      * (VoxelUtils.cu:544-604) is never called.  Frees every block the last frame saw that holds
      * nothing within sdfThreshold of a surface (vh_garbage_collect). */
     void garbageCollect(float sdfThreshold);
+    /* Opt-in extensions (voxelhash.h, vh_set_option): "pipeline" (one launch per frame, the commit and
+     * TSDF update of a frame ride in the launch of the next; flush() launches the pending half),
+     * "overflow_list", "band_mode", "depth_truncation", "weight_sample", ... */
+    void setOption(const char *name, int value);
+    void setAllocBand(float bandMetres);
+    void flush();
+    /* count frames in count + 1 launches (vh_integrate_batch): poses = count * 16 row-major floats */
+    void integrateBatch(int count, const float *poses, const vh_float4 *const *d_verts, const vh_float4 *const *d_normals);
     void setStream(void *hipStream);
     vh_context *context() { return ctx_; }
     const HashTableParams &params() const { return h_hashtableParams; }

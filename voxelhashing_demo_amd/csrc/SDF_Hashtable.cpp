@@ -82,6 +82,14 @@ int SDF_Hashtable::occupiedBlockCount()
 }
 
 void SDF_Hashtable::setStream(void *s) { check(vh_set_stream(ctx_, s), "set_stream"); }
+void SDF_Hashtable::setOption(const char *name, int value) { check(vh_set_option(ctx_, name, value), "set_option"); }
+void SDF_Hashtable::setAllocBand(float bandMetres) { check(vh_set_alloc_band(ctx_, bandMetres), "set_alloc_band"); }
+void SDF_Hashtable::flush() { check(vh_flush(ctx_), "flush"); }
+void SDF_Hashtable::integrateBatch(int count, const float *poses, const vh_float4 *const *d_verts,
+                                   const vh_float4 *const *d_normals)
+{
+    check(vh_integrate_batch(ctx_, count, poses, d_verts, d_normals), "integrate_batch");
+}
 
 // ---------------------------------------------------------------------------
 // CameraTracking (CameraTracking.cpp:27-69,118-145)
