@@ -410,6 +410,21 @@ int vh_export_views(vh_context *ctx, const float *poses, int32_t n_views, float 
  * from one logical table of the same geometry). */
 int vh_import_view(vh_context *view, const vh_view_record *d_records, int32_t count);
 
+/* The same round without any host synchronisation.  vh_export_views_fixed: the view poses are DEVICE
+ * memory (n_views*16 floats, e.g. straight out of an all-gather; n_views <= 16) and view v's records go
+ * to the fixed slot range [v*capacity, (v+1)*capacity) of d_records, so the exchange has equal sizes known
+ * to the host; d_counts[v] = records selected (above capacity: the excess was not written).
+ * The count also travels inside the payload: the spare header word (`reserved`) of the first record of a
+ * view's slot range holds it.  vh_import_views: `num_sources` slot ranges of `capacity` records each,
+ * source s holding min(count_s, capacity) records, count_s = d_counts[s] (device) or, with d_counts =
+ * NULL, that header word; what the sources selected beyond the
+ * capacity is added to vh_counters.bin_overflow of the view context.  Costs bandwidth instead of
+ * latency: the exchange moves num_sources*capacity records whatever the counts are. */
+int vh_export_views_fixed(vh_context *ctx, const float *d_poses, int32_t n_views, float t_min, float t_max,
+                          vh_view_record *d_records, int32_t capacity, int32_t *d_counts);
+int vh_import_views(vh_context *view, const vh_view_record *d_records, int32_t num_sources, int32_t capacity,
+                    const int32_t *d_counts);
+
 /* ------------------------------------------------------------------ */
 /* block deletion / garbage collection         */
 /* ------------------------------------------------------------------ */

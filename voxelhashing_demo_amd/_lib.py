@@ -129,6 +129,8 @@ SIGNATURES = {
     "vh_get_device_pointers": (C.c_int, [_vp, C.POINTER(PtrContainer)]),
     "vh_download": (C.c_int, [_vp, C.c_int, _vp, C.c_size_t]),
     "vh_download_range": (C.c_int, [_vp, C.c_int, C.c_size_t, _vp, C.c_size_t]),
+    "vh_export_views_fixed": (C.c_int, [_vp, _vp, C.c_int32, C.c_float, C.c_float, _vp, C.c_int32, _vp]),
+    "vh_import_views": (C.c_int, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
     "vh_flush": (C.c_int, [_vp]),
     "vh_integrate_batch": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "vh_integrate_depth_batch": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_void_p), C.POINTER(C.c_float)]),

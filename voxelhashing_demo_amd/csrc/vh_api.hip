@@ -103,6 +103,7 @@ struct vh_context {
     uint16_t *rawBuf[2] = {nullptr, nullptr};
     int occupiedCounter = kCompactCount;   // which device counter holds the occupied count of the last frame
     // raycast over shards
+    void *viewSet = nullptr;               // vh_export_views_fixed: the prepared views (ViewSet) in device memory
     int32_t *viewLists = nullptr;          // export: selected entry indices, [views][capacity]
     size_t viewListsSize = 0;              // in int32
     int32_t *blockList = nullptr;          // vh_render_blocks: counter (4 ints) + indices of all allocated entries
@@ -257,6 +258,8 @@ static int free_buffers(vh_context *c)
     if (c->dp.macroBits) (void)hipFree(c->dp.macroBits);
     if (c->fusedPlane) (void)hipFree(c->fusedPlane);
     c->fusedPlane = nullptr;
+    if (c->viewSet) (void)hipFree(c->viewSet);
+    c->viewSet = nullptr;
     if (c->viewLists) (void)hipFree(c->viewLists);
     if (c->blockList) (void)hipFree(c->blockList);
     c->blockList = nullptr;

@@ -55,7 +55,7 @@ extern "C" int vh_export_views(vh_context *c, const float *poses, int32_t n_view
     }
     const int rc = launch(c, kPhaseViewExport, view_pack_kernel, dim3((unsigned)std::min<int32_t>(capacity, 2048), n_views),
                           dim3(256), c->dp, (const int32_t *)c->viewLists, (const int32_t *)d_counts, capacity,
-                          reinterpret_cast<uint8_t *>(d_records));
+                          reinterpret_cast<uint8_t *>(d_records), 0);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -86,12 +86,90 @@ extern "C" int vh_import_view(vh_context *c, const vh_view_record *d_records, in
     c->viewCount = count;
     if (count > 0) {
         int rc = launch(c, kPhaseViewImport, view_import_kernel, dim3((unsigned)grid_for((size_t)count, 256)),
-                        dim3(256), c->fp, c->dp, reinterpret_cast<const uint8_t *>(d_records), count);
+                        dim3(256), c->fp, c->dp, reinterpret_cast<const uint8_t *>(d_records), count,
+                        (const int32_t *)nullptr, 0);
         if (rc == VH_OK && (c->fp.flags & kFlagOverflow))
             rc = launch(c, kPhaseViewImport, view_import_overflow_kernel, dim3(1), dim3(64), c->fp, c->dp,
                         reinterpret_cast<const uint8_t *>(d_records));
         if (rc != VH_OK) return rc;
     }
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+// The same round without a host synchronisation: view poses stay on the device (they arrive by
+// all-gather), every view's records go to a fixed slot range [v * capacity, (v + 1) * capacity) so the
+// exchange has equal, host-known sizes, and the importer reads the counts on the device.
+extern "C" int vh_export_views_fixed(vh_context *c, const float *d_poses, int32_t n_views, float t_min, float t_max,
+                                     vh_view_record *d_records, int32_t capacity, int32_t *d_counts)
+{
+    if (!c || !d_poses || !d_records || !d_counts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_views < 1 || n_views > kMaxViewsPerLaunch) return fail(VH_ERR_INVALID_ARGUMENT, "1..16 views");
+    if (capacity < 1) return fail(VH_ERR_INVALID_ARGUMENT, "capacity must be positive");
+    if (!(t_max > t_min)) return fail(VH_ERR_INVALID_ARGUMENT, "t_max must exceed t_min");
+    if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table has no voxels of its own to export");
+    DeviceGuard guard(c->device);
+    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
+    const size_t need = (size_t)n_views * (size_t)capacity;
+    if (c->viewListsSize < need || !c->viewSet) {            // first call (or a larger one): synchronises
+        VH_HIP(hipStreamSynchronize(c->stream));
+        if (c->viewListsSize < need) {
+            if (c->viewLists) (void)hipFree(c->viewLists);
+            c->viewLists = nullptr;
+            c->viewListsSize = 0;
+            VH_HIP(hipMalloc((void **)&c->viewLists, need * sizeof(int32_t)));
+            c->viewListsSize = need;
+        }
+        if (!c->viewSet) VH_HIP(hipMalloc((void **)&c->viewSet, sizeof(ViewSet)));
+    }
+    VH_HIP(hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)n_views, c->stream));
+    const ViewCamera cam{c->rc_fx, c->rc_fy, c->rc_cx, c->rc_cy, t_min, t_max, c->fp.width, c->fp.height};
+    int rc = launch(c, kPhaseViewExport, view_frustum_kernel, dim3(1), dim3(64), d_poses, n_views, cam, c->fp.voxelSize,
+                    reinterpret_cast<ViewSet *>(c->viewSet));
+    const uint32_t tiles = (uint32_t)((c->numEntries + kFlattenThreads * kEntriesPerLane - 1) /
+                                      (kFlattenThreads * kEntriesPerLane));
+    if (rc == VH_OK)
+        rc = launch(c, kPhaseViewExport, view_select_mem_kernel, dim3(tiles), dim3(kFlattenThreads), c->fp, c->dp,
+                    (uint32_t)c->numEntries, (const ViewSet *)c->viewSet, n_views, c->viewLists, capacity, d_counts);
+    if (rc == VH_OK)
+        rc = launch(c, kPhaseViewExport, view_pack_kernel, dim3((unsigned)std::min<int32_t>(capacity, 2048), n_views),
+                    dim3(256), c->dp, (const int32_t *)c->viewLists, (const int32_t *)d_counts, capacity,
+                    reinterpret_cast<uint8_t *>(d_records), 1);
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_import_views(vh_context *c, const vh_view_record *d_records, int32_t num_sources, int32_t capacity,
+                               const int32_t *d_counts)
+{
+    if (!c || !d_records || num_sources < 1 || capacity < 1) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    const size_t slots = (size_t)num_sources * (size_t)capacity;
+    if (slots > c->numEntries || (uint64_t)slots * kViewRecordVoxels + 514ull > 0x7fffffffull)
+        return fail(VH_ERR_INVALID_ARGUMENT, "too many record slots for this view table");
+    if (c->fp.bucketLo != 0 || c->fp.bucketHi != c->fp.numBuckets)
+        return fail(VH_ERR_INVALID_ARGUMENT, "a view table is unsharded");
+    if (c->epochTotal != 0) return fail(VH_ERR_INVALID_ARGUMENT, "this context has integrated frames: use a dedicated view context");
+    DeviceGuard guard(c->device);
+    if ((c->fp.flags & kFlagOverflow) && slots > c->candAllocated) {
+        const int rc = ensure_candidates(c, slots);
+        if (rc != VH_OK) return rc;
+    }
+    if (c->viewCount > 0) {
+        const int rc = launch(c, kPhaseViewImport, view_clear_kernel, dim3((unsigned)grid_for((size_t)c->viewCount, 256)),
+                              dim3(256), c->fp, c->dp, c->viewCount);
+        if (rc != VH_OK) return rc;
+    }
+    VH_HIP(hipMemsetAsync(c->dp.bucketBits, 0, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32), c->stream));
+    VH_HIP(hipMemsetAsync(c->dp.macroBits, 0, kMacroBits / 8, c->stream));
+    c->viewBlocks = reinterpret_cast<const Voxel *>(d_records);
+    c->viewCount = (int32_t)slots;
+    int rc = launch(c, kPhaseViewImport, view_import_kernel, dim3((unsigned)grid_for(slots, 256)), dim3(256), c->fp, c->dp,
+                    reinterpret_cast<const uint8_t *>(d_records), (int32_t)slots, d_counts, capacity);
+    if (rc == VH_OK && (c->fp.flags & kFlagOverflow))
+        rc = launch(c, kPhaseViewImport, view_import_overflow_kernel, dim3(1), dim3(64), c->fp, c->dp,
+                    reinterpret_cast<const uint8_t *>(d_records));
+    if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
 }

@@ -34,13 +34,73 @@ __device__ __forceinline__ bool view_holds_block(const FrameParams &fp, const fl
     return true;
 }
 
+// The same preparation on the device (vh_export_views_fixed: the view poses arrive by all-gather and
+// never visit the host): rows 0..2 of the cofactor inverse (the 12 of its 16 sums the test needs, same
+// order as the host's invert4x4 / cuda_SimpleMatrixUtil.h:944-1069), slopes, thresholds.  One lane per view.
+struct ViewCamera { float fx, fy, cx, cy, tMin, tMax; int32_t width, height; };
+
+__device__ __forceinline__ void invert4x4_device(const float *e, float *out)
+{
+    // adjugate by cofactors, each the sum of six signed triple products in the reference's order
+    const signed char cof[16][6][4] = {
+        {{+1,5,10,15},{-1,5,11,14},{-1,9,6,15},{+1,9,7,14},{+1,13,6,11},{-1,13,7,10}},
+        {{-1,1,10,15},{+1,1,11,14},{+1,9,2,15},{-1,9,3,14},{-1,13,2,11},{+1,13,3,10}},
+        {{+1,1,6,15},{-1,1,7,14},{-1,5,2,15},{+1,5,3,14},{+1,13,2,7},{-1,13,3,6}},
+        {{-1,1,6,11},{+1,1,7,10},{+1,5,2,11},{-1,5,3,10},{-1,9,2,7},{+1,9,3,6}},
+        {{-1,4,10,15},{+1,4,11,14},{+1,8,6,15},{-1,8,7,14},{-1,12,6,11},{+1,12,7,10}},
+        {{+1,0,10,15},{-1,0,11,14},{-1,8,2,15},{+1,8,3,14},{+1,12,2,11},{-1,12,3,10}},
+        {{-1,0,6,15},{+1,0,7,14},{+1,4,2,15},{-1,4,3,14},{-1,12,2,7},{+1,12,3,6}},
+        {{+1,0,6,11},{-1,0,7,10},{-1,4,2,11},{+1,4,3,10},{+1,8,2,7},{-1,8,3,6}},
+        {{+1,4,9,15},{-1,4,11,13},{-1,8,5,15},{+1,8,7,13},{+1,12,5,11},{-1,12,7,9}},
+        {{-1,0,9,15},{+1,0,11,13},{+1,8,1,15},{-1,8,3,13},{-1,12,1,11},{+1,12,3,9}},
+        {{+1,0,5,15},{-1,0,7,13},{-1,4,1,15},{+1,4,3,13},{+1,12,1,7},{-1,12,3,5}},
+        {{-1,0,5,11},{+1,0,7,9},{+1,4,1,11},{-1,4,3,9},{-1,8,1,7},{+1,8,3,5}},
+        {{-1,4,9,14},{+1,4,10,13},{+1,8,5,14},{-1,8,6,13},{-1,12,5,10},{+1,12,6,9}},
+        {{+1,0,9,14},{-1,0,10,13},{-1,8,1,14},{+1,8,2,13},{+1,12,1,10},{-1,12,2,9}},
+        {{-1,0,5,14},{+1,0,6,13},{+1,4,1,14},{-1,4,2,13},{-1,12,1,6},{+1,12,2,5}},
+        {{+1,0,5,10},{-1,0,6,9},{-1,4,1,10},{+1,4,2,9},{+1,8,1,6},{-1,8,2,5}},
+    };
+    float inv[16];
+    for (int o = 0; o < 16; ++o) {
+        float acc = 0.0f;
+        for (int k = 0; k < 6; ++k) {
+            float t = (e[cof[o][k][1]] * e[cof[o][k][2]]) * e[cof[o][k][3]];
+            if (cof[o][k][0] < 0) t = -t;
+            acc = (k == 0) ? t : acc + t;
+        }
+        inv[o] = acc;
+    }
+    const float det = e[0] * inv[0] + e[1] * inv[4] + e[2] * inv[8] + e[3] * inv[12];
+    const float detr = 1.0f / det;
+    for (int i = 0; i < 16; ++i) out[i] = inv[i] * detr;
+}
+
+__global__ void view_frustum_kernel(const float *__restrict__ poses, int32_t numViews, ViewCamera cam, float voxelSize,
+                                    ViewSet *__restrict__ out)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= numViews) return;
+    float inv[16];
+    invert4x4_device(poses + 16 * (size_t)v, inv);
+    float *f = out->v[v].f;
+    for (int i = 0; i < 12; ++i) f[i] = inv[i];
+    const float r = 7.0f * voxelSize;
+    const float a[4] = {(0.0f - cam.cx) / cam.fx, ((float)(cam.width - 1) - cam.cx) / cam.fx,
+                        (0.0f - cam.cy) / cam.fy, ((float)(cam.height - 1) - cam.cy) / cam.fy};
+    for (int i = 0; i < 4; ++i) {
+        f[12 + i] = a[i];
+        f[16 + i] = -(r * __builtin_sqrtf(1.0f + a[i] * a[i]));
+    }
+    f[20] = cam.tMin - r;
+    f[21] = cam.tMax + r;
+}
+
 // One walk over the shard's entries for up to 16 views (the same strided ptr-dword stream as
 // the flatten walk): a live entry is tested against every view and its index appended to the
 // list of each view that holds it (one atomic per wave and view that has hits).
-__global__ __launch_bounds__(kFlattenThreads) void view_select_kernel(const FrameParams fp, const DevPtrs dp,
-                                                                      uint32_t numEntries, const ViewSet vs,
-                                                                      int32_t numViews, int32_t *__restrict__ lists,
-                                                                      int32_t capacity, int32_t *__restrict__ counts)
+__device__ __forceinline__ void view_select(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
+                                            const ViewSet &vs, int32_t numViews, int32_t *__restrict__ lists,
+                                            int32_t capacity, int32_t *__restrict__ counts)
 {
     const uint32_t tile = blockIdx.x * (kFlattenThreads * kEntriesPerLane);
     const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
@@ -78,21 +138,51 @@ __global__ __launch_bounds__(kFlattenThreads) void view_select_kernel(const Fram
     }
 }
 
+__global__ __launch_bounds__(kFlattenThreads) void view_select_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                      uint32_t numEntries, const ViewSet vs,
+                                                                      int32_t numViews, int32_t *__restrict__ lists,
+                                                                      int32_t capacity, int32_t *__restrict__ counts)
+{
+    view_select(fp, dp, numEntries, vs, numViews, lists, capacity, counts);
+}
+
+// the same with the prepared views in device memory (view_frustum_kernel)
+__global__ __launch_bounds__(kFlattenThreads) void view_select_mem_kernel(const FrameParams fp, const DevPtrs dp,
+                                                                          uint32_t numEntries,
+                                                                          const ViewSet *__restrict__ vs,
+                                                                          int32_t numViews, int32_t *__restrict__ lists,
+                                                                          int32_t capacity, int32_t *__restrict__ counts)
+{
+    __shared__ ViewSet s;
+    for (int i = threadIdx.x; i < (int)(sizeof(ViewSet) / 4); i += blockDim.x)
+        reinterpret_cast<float *>(&s)[i] = reinterpret_cast<const float *>(vs)[i];
+    __syncthreads();
+    view_select(fp, dp, numEntries, s, numViews, lists, capacity, counts);
+}
+
 // Records of view v follow those of views 0..v-1 without gaps (the caller sends them with
 // per-destination counts); blockIdx.y = view, workgroups stride over its selected entries and
 // copy key + 4 KiB of voxels, 16 bytes per lane.
+// fixedSlots: view v's records start at v * capacity instead (fixed-size exchange, no counts on the host).
 __global__ __launch_bounds__(256) void view_pack_kernel(const DevPtrs dp, const int32_t *__restrict__ lists,
                                                         const int32_t *__restrict__ counts, int32_t capacity,
-                                                        uint8_t *__restrict__ records)
+                                                        uint8_t *__restrict__ records, int32_t fixedSlots)
 {
     const int v = blockIdx.y;
     size_t first = 0;
-    for (int u = 0; u < v; ++u) first += (size_t)min(counts[u], capacity);
+    if (fixedSlots) first = (size_t)v * (size_t)capacity;
+    else for (int u = 0; u < v; ++u) first += (size_t)min(counts[u], capacity);
     const int n = min(counts[v], capacity);
+    // fixed slots: the first record's spare header word carries the view's count, so the counts travel
+    // inside the payload (an empty view gets a key-less header there)
+    if (fixedSlots && n == 0 && blockIdx.x == 0 && threadIdx.x == 0)
+        *reinterpret_cast<int4 *>(records + first * kViewRecordBytes) =
+            make_int4(VH_POS_SENTINEL, VH_POS_SENTINEL, VH_POS_SENTINEL, counts[v]);
     for (int b = blockIdx.x; b < n; b += gridDim.x) {
         const VoxelEntry e = dp.table[lists[(size_t)v * capacity + b]];
         uint8_t *rec = records + (first + (size_t)b) * kViewRecordBytes;
-        if (threadIdx.x == 0) *reinterpret_cast<int4 *>(rec) = make_int4(e.pos[0], e.pos[1], e.pos[2], 0);
+        if (threadIdx.x == 0)
+            *reinterpret_cast<int4 *>(rec) = make_int4(e.pos[0], e.pos[1], e.pos[2], (fixedSlots && b == 0) ? counts[v] : 0);
         reinterpret_cast<float4 *>(rec + 16)[threadIdx.x] =
             reinterpret_cast<const float4 *>(dp.blocks + (size_t)e.ptr)[threadIdx.x];
     }
@@ -104,6 +194,7 @@ __global__ __launch_bounds__(256) void view_clear_kernel(const FrameParams fp, c
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= prevCount) return;
     const uint32_t h = dp.compactMask[i];
+    if (h == ~0u) return;                    // an unused slot of a fixed-capacity import
     VoxelEntry free_;
     free_.pos[0] = free_.pos[1] = free_.pos[2] = VH_POS_SENTINEL;
     free_.ptr = VH_FREE_BLOCK;
@@ -115,11 +206,23 @@ __global__ __launch_bounds__(256) void view_clear_kernel(const FrameParams fp, c
 // Record i becomes an entry of its bucket (slots are handed out by a per-bucket fill count kept
 // in the otherwise unused claim word, so the entries of a bucket form a prefix, which
 // lookup_block relies on); ptr addresses the voxels inside the record buffer itself.
+// counts != nullptr (vh_import_views): `count` = numSources * capacity slots, source s's records sit in
+// slots [s * capacity, s * capacity + min(counts[s], capacity)); the other slots are skipped (their
+// compactMask entry says "no bucket") and what a source selected beyond the capacity is counted as lost.
 __global__ __launch_bounds__(256) void view_import_kernel(const FrameParams fp, const DevPtrs dp,
-                                                          const uint8_t *__restrict__ records, int32_t count)
+                                                          const uint8_t *__restrict__ records, int32_t count,
+                                                          const int32_t *__restrict__ counts, int32_t capacity)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
+    if (capacity > 0) {
+        const int src = i / capacity, k = i - src * capacity;
+        // the source's count: from the device array, or from the spare header word of its first record
+        const int have = counts ? counts[src]
+                                : reinterpret_cast<const int4 *>(records + (size_t)src * capacity * kViewRecordBytes)->w;
+        if (k == 0 && have > capacity) atomicAdd(dp.counters + kBinOverflow, have - capacity);
+        if (k >= min(have, capacity)) { dp.compactMask[i] = ~0u; return; }
+    }
     const int4 k = *reinterpret_cast<const int4 *>(records + (size_t)i * kViewRecordBytes);
     const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
     dp.compactMask[i] = h;

@@ -341,6 +341,78 @@ def sharded_raycast(shard, view, transport: TorchDistTransport, pose, capacity: 
     return depth, lost
 
 
+def sharded_raycast_fixed(shard, view, transport: TorchDistTransport, pose, capacity: int,
+                          t_min: float = 0.1, t_max: float = 5.0, state=None):
+    """The same round with NO host synchronisation: the poses are gathered on the device, every shard
+    exports view v's records into the fixed slot range [v*capacity, (v+1)*capacity), the exchange has
+    equal sizes (records: world x capacity x 4112 bytes per rank, counts: world int32), and the view
+    table reads the counts on the device.  Trades bandwidth for latency: the payload does not shrink
+    with the number of blocks a view really touches, so `capacity` should be sized to the scene.
+    Returns (depth, lost) with `lost` a DEVICE tensor (records the shards selected beyond the capacity,
+    summed over this view's sources) that the caller may inspect whenever it synchronises anyway.
+    `state`: dict kept by the caller across rounds (buffers)."""
+    import torch
+    world = transport.world
+    dev = shard.device
+    restore = []
+    cur = torch.cuda.current_stream().cuda_stream
+    for t in (shard.table, view.table):
+        if t.stream_handle != cur:
+            t.synchronize()
+            restore.append((t, t.stream_handle))
+            t.set_stream(cur)
+    st = state if state is not None else {}
+    if st.get("capacity") != capacity or st.get("world") != world:
+        st.update(capacity=capacity, world=world,
+                  pose_all=torch.empty((world, 16), dtype=torch.float32, device=dev),
+                  pose_mine=torch.empty((16,), dtype=torch.float32, device=dev),
+                  pose_host=torch.empty((16,), dtype=torch.float32).pin_memory(),
+                  send=torch.zeros((world * capacity, VIEW_RECORD_BYTES), dtype=torch.uint8, device=dev),
+                  recv=torch.zeros((world * capacity, VIEW_RECORD_BYTES), dtype=torch.uint8, device=dev),
+                  counts=torch.zeros((world,), dtype=torch.int32, device=dev))
+    st["pose_host"].copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))))
+    st["pose_mine"].copy_(st["pose_host"], non_blocking=True)               # pinned -> device, no synchronisation
+    transport.dist.all_gather_into_tensor(st["pose_all"].view(-1), st["pose_mine"], group=transport.group)
+    shard.table.export_views_fixed(st["pose_all"], world, st["send"], capacity, st["counts"], t_min, t_max)
+    # one payload collective: the counts ride in the spare header word of each slot range's first record
+    transport.dist.all_to_all_single(st["recv"].view(-1), st["send"].view(-1), group=transport.group)
+    view.table.import_views(st["recv"], world, capacity, None)
+    depth = view.table.raycast(pose, view.depth, t_min, t_max)
+    heads = st["recv"].view(world, capacity * VIEW_RECORD_BYTES)[:, 12:16].contiguous().view(torch.int32).view(-1)
+    lost = torch.clamp(heads - capacity, min=0).sum()
+    for t, handle in restore:
+        t.synchronize()
+        t.set_stream(handle)
+    return depth, lost
+
+
+def loopback_raycast_fixed(shards, views, poses, capacity: int, t_min: float = 0.1, t_max: float = 5.0):
+    """vh_export_views_fixed / vh_import_views with every rank played in this process."""
+    import torch
+    world = len(shards)
+    dev = shards[0].device
+    d_poses = torch.from_numpy(np.ascontiguousarray(np.asarray(poses, np.float32).reshape(world, 16))).to(dev)
+    sends, counts = [], []
+    for sh in shards:
+        send = torch.zeros((world * capacity, VIEW_RECORD_BYTES), dtype=torch.uint8, device=dev)
+        cnt = torch.zeros((world,), dtype=torch.int32, device=dev)
+        sh.table.export_views_fixed(d_poses, world, send, capacity, cnt, t_min, t_max)
+        sends.append(send.view(world, capacity, VIEW_RECORD_BYTES))
+        counts.append(cnt)
+    out = []
+    for r, view in enumerate(views):
+        recv = torch.stack([sends[src][r] for src in range(world)]).view(world * capacity, VIEW_RECORD_BYTES).contiguous()
+        cin = torch.stack([counts[src][r] for src in range(world)]).contiguous()
+        torch.cuda.synchronize()
+        view.table.import_views(recv, world, capacity, cin if r % 2 == 0 else None)   # counts array / header word
+        view._fixed_recv = recv
+        depth = view.table.raycast(poses[r], view.depth, t_min, t_max)
+        torch.cuda.synchronize()
+        assert int(torch.clamp(cin - capacity, min=0).sum()) == 0, "view capacity exceeded"
+        out.append(depth.cpu().numpy().copy())
+    return out
+
+
 def loopback_raycast(shards, views, poses, capacity: int, t_min: float = 0.1, t_max: float = 5.0):
     """The same with every rank played in this process: view r is rendered from poses[r] by views[r].
     Returns the depth images as numpy arrays."""
@@ -596,6 +668,7 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
         # only on request: the default multi-GPU run is the integration benchmark alone.
         do_raycast = world == 1 or getattr(args, "sharded_raycast", False)
         rc_elapsed, rc_iters, lost_total, view_cap, kte, ktv, view = 0.0, 20, 0, 8192, None, None, None
+        rc_fixed_elapsed, lost_fixed, fixed_cap = 0.0, 0, 2048
         if do_raycast:
             view = HipViewTable(params, Wd, Ht, SEM_PINHOLE, world, view_cap, device=dev, stream=stream)
             for i in range(2):
@@ -609,6 +682,21 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             torch.cuda.synchronize()
             dist.barrier()
             rc_elapsed = time.perf_counter() - t1
+            # the same without host synchronisation (fixed record slots, counts read on the device)
+            fixed_cap, fstate = 2048, {}
+            for i in range(2):
+                sharded_raycast_fixed(shard, view, transport, poses[i], fixed_cap, state=fstate)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t2 = time.perf_counter()
+            lost_dev = None
+            for i in range(rc_iters):
+                _, lost_f = sharded_raycast_fixed(shard, view, transport, poses[(7 * i) % nframes], fixed_cap, state=fstate)
+                lost_dev = lost_f if lost_dev is None else lost_dev + lost_f
+            torch.cuda.synchronize()
+            dist.barrier()
+            rc_fixed_elapsed = time.perf_counter() - t2
+            lost_fixed = int(lost_dev.item())
             shard.table.set_profiling(True)
             view.table.set_profiling(True)
             for i in range(3):
@@ -621,9 +709,9 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     dist.all_reduce(wt, op=dist.ReduceOp.MAX)                 # every window: the slowest rank's time
     windows = [float(x) for x in wt.tolist()]
     elapsed = statistics.median(windows)
-    t = torch.tensor([rc_elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([rc_elapsed, rc_fixed_elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    rc_elapsed = float(t[0].item())
+    rc_elapsed, rc_fixed_elapsed = float(t[0].item()), float(t[1].item())
     c = shard.table.counters()
     stats = torch.tensor([c["occupied"], c["allocated_total"], c["bin_overflow"]], dtype=torch.int64, device=dev)
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
@@ -677,6 +765,12 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             out["sharded_raycast"] = dict(
                 mpix_per_s=round(world * rc_iters * Wd * Ht / rc_elapsed / 1e6, 1), views_per_round=world,
                 ms_per_round=round(1e3 * rc_elapsed / rc_iters, 4), lost_records=lost_total,
+                fixed_slots=dict(ms_per_round=round(1e3 * rc_fixed_elapsed / rc_iters, 4),
+                                 mpix_per_s=round(world * rc_iters * Wd * Ht / rc_fixed_elapsed / 1e6, 1),
+                                 record_capacity_per_shard_and_view=fixed_cap, lost_records=lost_fixed,
+                                 payload_bytes_per_rank=world * fixed_cap * VIEW_RECORD_BYTES,
+                                 note="sharded_raycast_fixed: poses gathered on the device, fixed record slots, "
+                                      "counts read on the device -- no host synchronisation in the round"),
                 record_capacity_per_shard_and_view=view_cap,
                 rank0_export_us=round(1e3 * kte["view_export_ms"] / 3, 2),
                 rank0_import_us=round(1e3 * ktv["view_import_ms"] / 3, 2),

@@ -179,6 +179,18 @@ class SDFHashtable:
         L.check(self._lib.vh_export_views(self._h, p.ctypes.data_as(C.POINTER(C.c_float)), p.shape[0], t_min, t_max,
                                           _dev_ptr(records), capacity, _dev_ptr(counts)), "vh_export_views")
 
+    def export_views_fixed(self, d_poses, n_views: int, records, capacity: int, counts, t_min: float = 0.1,
+                           t_max: float = 5.0):
+        """The same with device poses [n_views, 16] and fixed slots: view v's records at records[v*capacity:]."""
+        L.check(self._lib.vh_export_views_fixed(self._h, _dev_ptr(d_poses), int(n_views), t_min, t_max, _dev_ptr(records),
+                                                capacity, _dev_ptr(counts)), "vh_export_views_fixed")
+
+    def import_views(self, records, num_sources: int, capacity: int, counts):
+        """Fixed-slot import: source s holds min(counts[s], capacity) records at records[s*capacity:] (counts on the device)."""
+        self._view_records = records
+        L.check(self._lib.vh_import_views(self._h, _dev_ptr(records), int(num_sources), int(capacity), _dev_ptr(counts)),
+                "vh_import_views")
+
     def import_view(self, records, count: int):
         """Make this dedicated, unsharded context hold exactly records[:count] (voxels stay in `records`)."""
         self._view_records = records            # keep the buffer alive while the table points into it
