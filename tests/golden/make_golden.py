@@ -67,6 +67,7 @@ def digest_scene(t):
     comp = comp[np.lexsort((comp[:, 2], comp[:, 1], comp[:, 0]))] if len(comp) else comp.reshape(0, 3)
     first = int(tab["ptr"][alloc_idx[order[0]]]) if len(order) else 0
     return dict(pos=pos.astype(np.int32), slots=slots.astype(np.int64), compact=comp.astype(np.int32),
+                offsets=tab["offset"][slots].astype(np.int32),          # chain links (all 0 without the overflow list)
                 sha=np.frombuffer(h.digest(), np.uint8), block0=vol[first:first + 512].copy().view(np.uint32).reshape(-1))
 
 
@@ -81,18 +82,62 @@ SCENES = {
     "inside_pin_pose_f2": (1, synth.yaw_pose(5.0, (0.1, 0.0, 0.05)), "inside", 2, {}),
     "collision_64x2_f4": (1, I4, "inside", 4, dict(numBuckets=64, bucketSize=2, numVoxelBlocks=256)),
     "saturate_f10": (1, I4, "inside", 10, dict(integrationWeightMax=0.55)),
+    # round 2: the opt-in extensions (a 6th element names the options)
+    "overflow_48x5_f8": (0, I4, "inside", 8, dict(numBuckets=48, bucketSize=5, numVoxelBlocks=1024,
+                                                  attachedLinkedListSize=6), dict(overflow=1)),
+    "overflow_96x2_f6": (1, I4, "inside", 6, dict(numBuckets=96, bucketSize=2, numVoxelBlocks=1024,
+                                                  attachedLinkedListSize=8), dict(overflow=1)),
+    "dda_band_pin_f2": (1, synth.yaw_pose(5.0, (0.1, 0.0, 0.05)), "inside", 2, dict(numVoxelBlocks=1 << 14),
+                        dict(dda_band=0.2)),
+    "tsdf_variants_pin_f3": (1, I4, "inside", 3, dict(truncation=0.04, truncScale=0.02, integrationWeightSample=10),
+                             dict(integrate_flags=3)),
 }
 
 
+def sphere_normals(verts):
+    """Analytic normal map of the inside-sphere scene (camera frame): towards the camera, 0 where invalid."""
+    n = np.zeros_like(verts)
+    r = np.linalg.norm(verts[..., :3].astype(np.float64), axis=-1, keepdims=True)
+    ok = r[..., 0] > 0
+    n[..., :3][ok] = (-verts[..., :3].astype(np.float64)[ok] / r[ok]).astype(np.float32)
+    return n
+
+
 def run_scene(name, table_factory):
-    sem, pose, scene, frames, over = SCENES[name]
+    sem, pose, scene, frames, over = SCENES[name][:5]
+    opts = SCENES[name][5] if len(SCENES[name]) > 5 else {}
     kw = dict(numBuckets=NB, numVoxelBlocks=4096)
     kw.update(over)
     verts = synth.sphere_inside_scene() if scene == "inside" else synth.sphere_outside_scene()
     t = table_factory(kw, sem)
+    normals = None
+    if opts:
+        t.apply_options(opts)                    # the two table wrappers translate these to their own calls
+        if "dda_band" in opts:
+            normals = sphere_normals(verts)
     for _ in range(frames):
-        t.integrate_np(pose, verts)
+        t.integrate_np(pose, verts, normals)
     return t
+
+
+def oracle_options(O, t, opts):
+    if opts.get("overflow"):
+        t.set_overflow(True)
+    if "dda_band" in opts:
+        t.set_alloc_band(opts["dda_band"], O.BAND_NORMAL_DDA)
+    if "integrate_flags" in opts:
+        t.set_integrate_flags(opts["integrate_flags"])
+
+
+def hip_options(t, opts):
+    if opts.get("overflow"):
+        t.set_option("overflow_list", 1)
+    if "dda_band" in opts:
+        t.set_alloc_band(opts["dda_band"])
+        t.set_option("band_mode", 1)
+    if "integrate_flags" in opts:
+        t.set_option("depth_truncation", opts["integrate_flags"] & 1)
+        t.set_option("weight_sample", (opts["integrate_flags"] >> 1) & 1)
 
 
 def main():
@@ -100,8 +145,11 @@ def main():
     out = {}
 
     class OT(O.OracleTable):
-        def integrate_np(self, pose, verts):
-            self.integrate(pose, verts)
+        def integrate_np(self, pose, verts, normals=None):
+            self.integrate(pose, verts, normals)
+
+        def apply_options(self, opts):
+            oracle_options(O, self, opts)
 
     for name in SCENES:
         t = run_scene(name, lambda kw, sem: OT(O.default_params(**kw), 640, 480, sem))

@@ -53,8 +53,11 @@ def _check(name, table):
 @pytest.mark.parametrize("name", sorted(G.SCENES))
 def test_oracle_reproduces_scene(oracle, name):
     class OT(oracle.OracleTable):
-        def integrate_np(self, pose, verts):
-            self.integrate(pose, verts)
+        def integrate_np(self, pose, verts, normals=None):
+            self.integrate(pose, verts, normals)
+
+        def apply_options(self, opts):
+            G.oracle_options(oracle, self, opts)
 
     t = G.run_scene(name, lambda kw, sem: OT(oracle.default_params(**kw), 640, 480, sem))
     _check(name, t)
@@ -72,9 +75,12 @@ def test_hip_reproduces_scene(vh, torch_cuda, name):
     torch = torch_cuda
 
     class GT(vh.SDFHashtable):
-        def integrate_np(self, pose, verts):
-            self.integrate(pose, torch.from_numpy(verts).cuda())
+        def integrate_np(self, pose, verts, normals=None):
+            self.integrate(pose, torch.from_numpy(verts).cuda(), None if normals is None else torch.from_numpy(normals).cuda())
             self.synchronize()
+
+        def apply_options(self, opts):
+            G.hip_options(self, opts)
 
     t = G.run_scene(name, lambda kw, sem: GT(vh.default_params(**kw), 640, 480, sem))
     _check(name, t)

@@ -1,5 +1,6 @@
 """Random sequences of API calls on one context against the oracle: frames in both launch forms and
-several walk variants, step-level frames, collections, deletions, raycasts, snapshot round trips.
+several walk variants, pipelined frames and batches, step-level frames, collections, deletions, raycasts,
+snapshot round trips.
 State that survives between calls (lock epoch, counter parity, which counter holds the occupied
 count, the armed compact counter) must never depend on what was called before."""
 import numpy as np
@@ -43,12 +44,20 @@ def test_random_call_sequences(oracle, vh, torch_cuda, tmp_path, seed, sem):
     depth = torch.zeros((H, W), device="cuda")
     log = []
     for step in range(45):
-        op = rng.choice(["frame", "frame", "frame", "steps", "gc", "delete", "raycast", "snapshot", "option", "band"])
+        op = rng.choice(["frame", "frame", "frame", "batch", "steps", "gc", "delete", "raycast", "snapshot", "option",
+                         "pipeline", "band"])
         log.append(op)
         pose, verts = frames[rng.randint(len(frames))]
         if op == "frame":
             ot.integrate(pose, verts)
             gt.integrate(pose, torch.from_numpy(verts).cuda())
+        elif op == "batch":                                             # several frames, one launch each + a flush
+            part = [frames[rng.randint(len(frames))] for _ in range(int(rng.randint(1, 5)))]
+            gt.integrate_batch([p for p, _ in part], [torch.from_numpy(v).cuda() for _, v in part])
+            for p, v in part:
+                ot.integrate(p, v)
+        elif op == "pipeline":                                          # plain frames pipelined from here on (or not)
+            gt.set_option("pipeline", int(rng.randint(2)))
         elif op == "steps":                                             # the reference's four calls, one by one
             d = torch.from_numpy(verts).cuda()
             for t, v in ((ot, verts), (gt, d)):
@@ -84,7 +93,9 @@ def test_random_call_sequences(oracle, vh, torch_cuda, tmp_path, seed, sem):
             b = float(rng.choice([0.0, 0.1]))
             ot.set_alloc_band(b)
             gt.set_alloc_band(b)
-        if op not in ("raycast", "option", "band"):
+        if op == "frame" and rng.randint(2):
+            continue                                                    # (pipelined frames stay in flight across ops)
+        if op not in ("raycast", "option", "band", "pipeline"):
             try:
                 c = same(ot, gt)
             except AssertionError as e:
