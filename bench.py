@@ -102,7 +102,7 @@ def baseline_metric(width, height):
     return f"frames/s TSDF-integrated + raycast Mpix/s, {width}x{height}"
 
 
-def timed_windows(step, sync, steps, warmup, first=0, min_time=MIN_TIMED_S, max_windows=400):
+def timed_windows(step, sync, steps, warmup, first=0, min_time=MIN_TIMED_S, max_windows=4000):
     """W untimed warm-up steps, then windows of exactly `steps` steps (sync on both sides) until
     `min_time` seconds have been timed.  Returns (window times, next step index)."""
     i = first

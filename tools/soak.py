@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""One-off soak: the full 500-frame C2 sequence twice on the GPU (with a raycast every 10 frames and a
+"""One-off soak: the full 500-frame C2 sequence four times on the GPU (two-launch, four-kernel, occupancy-index
+walk, pipelined) (with a raycast every 10 frames and a
 garbage collection every 50) and once on the oracle; all three final tables must agree slot for slot
 and voxel for voxel.  Catches rare schedule-dependent outcomes the short parity tests could miss."""
 import os, sys, time
@@ -20,6 +21,7 @@ def run_gpu(variant):
     t = V.SDFHashtable(V.default_params(**kw), W, H, V.SEM_PINHOLE)
     t.set_option("fused_frame", variant[0])
     t.set_option("flatten_variant", variant[1])
+    t.set_option("pipeline", variant[2] if len(variant) > 2 else 0)   # (the raycasts / collections flush on their own)
     depth = torch.empty((H, W), device="cuda")
     rays = []
     for i, p in enumerate(poses):
@@ -37,6 +39,7 @@ t0 = time.time()
 a, ra = run_gpu((1, 3))
 b, rb = run_gpu((0, 3))
 c, rc = run_gpu((1, 4))
+d, rd = run_gpu((1, 3, 1))
 print("gpu runs", round(time.time() - t0, 1), "s")
 ot = O.OracleTable(O.default_params(**kw), W, H, O.SEM_PINHOLE)
 ro = []
@@ -50,7 +53,7 @@ for i, p in enumerate(poses):
 print("oracle run", round(time.time() - t0, 1), "s")
 ref = ot.hash_table()
 ovol = ot.sdf_blocks()
-for name, t, rays in (("fused", a, ra), ("four-kernel", b, rb), ("fused-indexed", c, rc)):
+for name, t, rays in (("fused", a, ra), ("four-kernel", b, rb), ("fused-indexed", c, rc), ("pipelined", d, rd)):
     tab = t.hash_table()
     assert np.array_equal(tab["pos"], ref["pos"]) and np.array_equal(tab["ptr"] != -1, ref["ptr"] != -1), name
     vol = t.sdf_blocks()

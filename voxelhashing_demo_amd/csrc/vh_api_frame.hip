@@ -235,6 +235,7 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     a.numEntries = (uint32_t)c->numEntries;
     a.setNew = setNew; a.setOld = setOld; a.setClear = (setNew + 1) % 3;
     a.hasNew = hasNew; a.hasOld = hasOld;
+    a.order = (uint32_t)c->pipeOrder;
     a.planeNew = (hasNew && !newSensor) ? c->planeBuf[newParity] : nullptr;
     a.rawNew = (hasNew && newSensor) ? c->rawBuf[newParity] : nullptr;
     const DevPtrs dpNew = pipe_view(c, newParity), dpOld = pipe_view(c, oldParity);

@@ -131,13 +131,10 @@ struct PipeArgs {
     uint32_t numEntries;
     int32_t setNew, setOld, setClear;      // counter sets: filled, consumed, cleared by this launch
     uint32_t hasNew, hasOld;               // first launch of a run: no old frame; flush launch: no new frame
+    uint32_t order;                        // where the deferred half sits in the grid (see the role mapping)
     float *planeNew;                       // private depth copies written by claim(new) ...
     uint16_t *rawNew;
 };
-
-#ifndef VH_PIPE_ORDER
-#define VH_PIPE_ORDER 0
-#endif
 
 template <class In, class Depth>
 __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const DevPtrs &dpNew, const In &inNew,
@@ -152,34 +149,33 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
     const int demandedOld = a.hasOld ? counters[kPipeCand + a.setOld] : 0;
     const int candOld = min(demandedOld, (int)dpOld.candCapacity);
     const bool live = a.hasOld && counters[kPipeHeapFree + a.setOld] >= counters[kPipeWinners + a.setOld];
-    // Roles by workgroup index: [commit][integrate][claim and walk interleaved as in frame_scan_claim_kernel]:
-    // frame i's deferred half runs first, at full width, then the table streams.  Measured on C2 / C3
-    // (launch time, us): this order with 512 integrate workgroups 18.8 / 88.9; with 2048 of them (mostly
-    // idle, but dispatched before the first walk tile) 19.7 / 91.9; integrate and claim workgroups
-    // interleaved among the walk tiles (VH_PIPE_ORDER 1) 20.5 / 93.7 -- the latency-bound block updates
-    // then hold the slots the stream needs; claims before the walk (VH_PIPE_ORDER 2) 20.4 / 93.0.
+    // Roles by workgroup index (a.order 0): [commit][integrate][claim and walk interleaved as in
+    // frame_scan_claim_kernel]: frame i's deferred half runs first, at full width, then the table streams.
+    // In-process A/B on C2 / C3 (launch time, us): this order with 512 integrate workgroups 18.8 / 88.9; with
+    // 2048 of them (mostly idle, but dispatched before the first walk tile) 19.7 / 91.9; integrate and claim
+    // workgroups interleaved among the walk tiles 20.5 / 93.7 (the latency-bound block updates then hold the
+    // slots the stream needs); all claim tiles before the walk 20.4 / 93.0; the deferred half at the END of
+    // the grid, where the walk drains (a.order 3; 4 = commit first, integrate last) 21.5 / 105.9 against
+    // 21.0 / 94.6 for order 0 on that (slower) box.  Option "pipe_order" keeps 0, 3 and 4 selectable.
     const uint32_t b = blockIdx.x;
     uint32_t role, index;                          // 0 commit, 1 integrate, 2 claim, 3 walk
-#if VH_PIPE_ORDER == 0
-    if (b < a.commitBlocks) { role = 0; index = b; }
-    else if (b < a.commitBlocks + a.integrateBlocks) { role = 1; index = b - a.commitBlocks; }
-    else {
-        const uint32_t r = b - a.commitBlocks - a.integrateBlocks, total = a.claimBlocks + a.walkBlocks;
-        const uint32_t before = (uint32_t)(((uint64_t)r * a.claimBlocks) / total);
-        const uint32_t after = (uint32_t)(((uint64_t)(r + 1u) * a.claimBlocks) / total);
-        if (after != before) { role = 2; index = before; } else { role = 3; index = r - before; }
+    {
+        // a.order 0: [commit][integrate][claim/walk]   3: [claim/walk][commit][integrate]   4: [commit][claim/walk][integrate]
+        const uint32_t stream = a.claimBlocks + a.walkBlocks;
+        const uint32_t head = a.order == 0u ? a.commitBlocks + a.integrateBlocks : a.order == 4u ? a.commitBlocks : 0u;
+        if (b < head) {
+            if (b < a.commitBlocks) { role = 0; index = b; } else { role = 1; index = b - a.commitBlocks; }
+        } else if (b < head + stream) {
+            const uint32_t r = b - head;
+            const uint32_t before = (uint32_t)(((uint64_t)r * a.claimBlocks) / stream);
+            const uint32_t after = (uint32_t)(((uint64_t)(r + 1u) * a.claimBlocks) / stream);
+            if (after != before) { role = 2; index = before; } else { role = 3; index = r - before; }
+        } else {
+            const uint32_t r = b - head - stream;      // the tail
+            if (a.order == 3u && r < a.commitBlocks) { role = 0; index = r; }
+            else { role = 1; index = a.order == 3u ? r - a.commitBlocks : r; }
+        }
     }
-#else
-    if (b < a.commitBlocks) { role = 0; index = b; }
-    else {
-        const uint32_t r = b - a.commitBlocks, lat = a.integrateBlocks + a.claimBlocks, total = lat + a.walkBlocks;
-        const uint32_t before = (uint32_t)(((uint64_t)r * lat) / total);
-        const uint32_t after = (uint32_t)(((uint64_t)(r + 1u) * lat) / total);
-        if (after != before) {
-            if (before < a.integrateBlocks) { role = 1; index = before; } else { role = 2; index = before - a.integrateBlocks; }
-        } else { role = 3; index = r - before; }
-    }
-#endif
     if (role >= 2u) {
         // ---- frame i+1: claim || walk ----
         if (!a.hasNew) return;
