@@ -72,7 +72,8 @@ def parse_args():
     ap.add_argument("--raycast-steps", type=int, default=50)
     ap.add_argument("--profile-steps", type=int, default=200)
     ap.add_argument("--batch", type=int, default=8,
-                    help="sharded path: frames per camera carried by one all-to-all / all-gather")
+                    help="frames per step: handed to one vh_integrate_batch (one GPU) / carried per camera by one "
+                         "all-to-all + all-gather (sharded path)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sharded path: do not overlap key generation + RCCL with the table work")
     ap.add_argument("--float-packets", action="store_true",
@@ -122,9 +123,10 @@ def timed_windows(step, sync, steps, warmup, first=0, min_time=MIN_TIMED_S, max_
     return times, i
 
 
-def window_stats(times, steps):
+def window_stats(times, steps, frames_per_step=1):
     med = statistics.median(times)
-    return dict(value=round(steps / med, 1), ms_per_step=round(1e3 * med / steps, 5), windows=len(times),
+    return dict(value=round(steps * frames_per_step / med, 1), ms_per_step=round(1e3 * med / steps, 5),
+                frames_per_step=frames_per_step, windows=len(times),
                 timed_s=round(sum(times), 4), window_min_ms=round(1e3 * min(times), 4),
                 window_max_ms=round(1e3 * max(times), 4))
 
@@ -155,8 +157,8 @@ def render_frames(synth, wl, nframes, dev, torch):
 class Integrator:
     """One table + resident frames; step(i) = vh_integrate of frame i mod nframes."""
 
-    def __init__(self, V, L, wl, poses, verts, local_rank, stream, pipeline=True):
-        self.V, self.L, self.wl, self.stream, self.pipeline = V, L, wl, stream, pipeline
+    def __init__(self, V, L, wl, poses, verts, local_rank, stream, pipeline=True, batch=8):
+        self.V, self.L, self.wl, self.stream, self.pipeline, self.batch = V, L, wl, stream, pipeline, max(1, batch)
         self.nframes = len(poses)
         params = V.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
         self.table = V.SDFHashtable(params, wl["width"], wl["height"], V.SEM_PINHOLE, device=local_rank, stream=stream)
@@ -169,8 +171,25 @@ class Integrator:
         self.pose_keep = [np.ascontiguousarray(p.reshape(16)) for p in poses]
         self.pose_ptrs = [p.ctypes.data_as(C.POINTER(C.c_float)) for p in self.pose_keep]
         self.vert_ptrs = [verts[i].data_ptr() for i in range(self.nframes)]
+        # a step = one batch of `batch` consecutive frames handed to vh_integrate_batch (as the sharded path's
+        # step is one exchange of `batch` frames per camera): argument blocks prepared once per start frame
+        B, n = self.batch, self.nframes
+        self._batch_poses = [np.ascontiguousarray(np.stack([self.pose_keep[(k + j) % n] for j in range(B)])) for k in range(n)]
+        self._batch_pose_ptrs = [a.ctypes.data_as(C.POINTER(C.c_float)) for a in self._batch_poses]
+        self._batch_verts = [(C.c_void_p * B)(*[self.vert_ptrs[(k + j) % n] for j in range(B)]) for k in range(n)]
 
     def step(self, i):
+        k = (i * self.batch) % self.nframes
+        if not self.pipeline:                     # the same frames one vh_integrate (two launches) at a time
+            for j in range(self.batch):
+                self.frame(k + j)
+            return
+        rc = self.lib.vh_integrate_batch(self.h, self.batch, self._batch_pose_ptrs[k], self._batch_verts[k], None)
+        if rc != 0:
+            self.L.check(rc, "vh_integrate_batch")
+
+    def frame(self, i):
+        """one frame (the legs that are not batch-shaped)"""
         k = i % self.nframes
         rc = self.lib.vh_integrate(self.h, self.pose_ptrs[k], self.vert_ptrs[k], None)
         if rc != 0:
@@ -243,13 +262,14 @@ def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, 
     nframes = args.frames or wl["frames"]
     poses, verts = frames if frames is not None else render_frames(synth, wl, nframes, dev, torch)
     nframes = len(poses)
-    it = Integrator(V, L, wl, poses, verts, local_rank, stream, pipeline=pipeline)
-    lap = max(nframes, 500) if name.startswith("C2") else nframes
+    it = Integrator(V, L, wl, poses, verts, local_rank, stream, pipeline=pipeline, batch=args.batch)
+    B = it.batch
+    lap = -(-(max(nframes, 500) if name.startswith("C2") else nframes) // B)
     for i in range(lap):           # fixed, untimed run-in (one lap of the resident frames) before the W warm-up steps
         it.step(i)
     it.sync()
     times, nxt = timed_windows(it.step, lambda: (it.sync(), torch.cuda.synchronize()), steps, warmup, first=lap)
-    rec = window_stats(times, steps)
+    rec = window_stats(times, steps, B)
     counters = it.table.counters()
     occ = counters["occupied"]
     rec["occupied_blocks"], rec["allocated_blocks"], rec["resident_frames"] = occ, counters["allocated_total"], nframes
@@ -265,6 +285,7 @@ def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, 
     # distinct in-frustum block keys of a frame ~ occupied blocks (not counted on the device)
     b_frame = 16 * Wd * Ht + 4 * Wd * Ht + 20 * n_entries + 20 * occ + occ * (20 + 4096 + 4096) + 100 * occ
     rec["frame_algorithmic_bytes"] = b_frame
+    rec["ms_per_frame"] = round(rec["ms_per_step"] / B, 5)
     rec["frame_algorithmic_gbs"] = round(b_frame * rec["value"] / 1e9, 1)
     rec["frame_frac_of_hbm_peak"] = round(b_frame * rec["value"] / 1e9 / HBM_PEAK_GBS, 4)
     return rec, it, poses, verts
@@ -274,8 +295,9 @@ def two_launch_record(args, it, name, occ, steps, warmup, sync):
     """The same frames unpipelined: vh_integrate as two launches per frame ({claim || walk}, {commit + TSDF
     update}); what round 1 measured, and what a caller gets who reads the model between frames."""
     it.table.set_option("pipeline", 0)
+    it.pipeline = False
     t_2, nxt2 = timed_windows(it.step, sync, steps, warmup)
-    rec2 = dict(window_stats(t_2, steps), unit="frames/s")
+    rec2 = dict(window_stats(t_2, steps, it.batch), unit="frames/s")
     if args.profile_steps > 0:
         kt2 = it.kernel_profile(args.profile_steps, nxt2)
         rec2["roofline_scan_claim"] = it.dominant_roofline(name, kt2, occ)
@@ -283,6 +305,7 @@ def two_launch_record(args, it, name, occ, steps, warmup, sync):
         rec2["kernels"] = {k[:-3] + "_us": round(1e3 * v / max(1, kt2["launches"]), 2)
                            for k, v in kt2.items() if k.endswith("_ms") and v > 0 and k not in ("raycast_ms",)}
     it.table.set_option("pipeline", 1)
+    it.pipeline = True
     return rec2
 
 
@@ -404,7 +427,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(nframes):
-            fresh.step(i)
+            fresh.frame(i)
         fresh.sync()
         lap_s = time.perf_counter() - t0
         fc = fresh.table.counters()
@@ -422,7 +445,7 @@ def main():
         t_idx, _ = timed_windows(it.step, sync, args.steps, args.warmup)
         table.set_option("flatten_variant", 3)
         extra["occupancy_index_variant"] = dict(
-            window_stats(t_idx, args.steps), unit="frames/s",
+            window_stats(t_idx, args.steps, it.batch), unit="frames/s",
             flatten_bytes=wl["buckets"] // 8 + 100 * main_rec["allocated_blocks"],
             note="vh_set_option(flatten_variant=4): walk over the bucket-occupancy bitmap (numBuckets/8 bytes) + "
                  "the non-empty buckets instead of the 20*N-byte table walk")
@@ -452,8 +475,8 @@ def main():
 
         sensor = {}
         for label, fn in (("vh_integrate_depth", fused_depth), ("vh_preprocess + vh_integrate", two_calls)):
-            t_s, _ = timed_windows(fn, sync, args.steps, args.warmup)
-            sensor[label] = window_stats(t_s, args.steps)["value"]
+            t_s, _ = timed_windows(fn, sync, args.steps * it.batch, args.warmup)
+            sensor[label] = window_stats(t_s, args.steps * it.batch)["value"]
         extra["sensor_depth_input"] = dict(
             frames_per_s=sensor, unit="frames/s",
             note="input: uint16 depth images (2 B/pixel); the fused call computes the vertices inside the claim "
@@ -502,6 +525,7 @@ def main():
         extra["loaded_integrate"] = l_rec
         # launch 2 alone under this load (two-launch frames): the 8^3-block read-modify-write by itself
         l_it.table.set_option("pipeline", 0)
+        l_it.pipeline = False
         for i in range(20):
             l_it.step(i)
         kt_l2 = l_it.kernel_profile(min(200, max(20, args.profile_steps)), 20)
@@ -559,9 +583,11 @@ def main():
         value=main_rec["value"], unit="frames/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
         ms_per_step=main_rec["ms_per_step"], higher_is_better=True, scaling="weak",
         vs_baseline=None, dtype="f32", data="synthetic",
-        metric_note="value = frames/s TSDF-integrated (median window of K steps, pipelined frames: one launch per frame, "
-                    "flushed inside the window; two_launch_frame = the same unpipelined); the raycast half of the metric "
-                    "is raycast_mpix_per_s",
+        metric_note="value = frames/s TSDF-integrated: a step is one vh_integrate_batch of frames_per_step consecutive "
+                    "resident frames (pipelined: one launch per frame), windows of exactly K steps with a synchronisation "
+                    "(which flushes the last frame) on both sides, median window; two_launch_frame = the same unpipelined; "
+                    "the raycast half of the metric is raycast_mpix_per_s",
+        frames_per_step=main_rec["frames_per_step"], ms_per_frame=main_rec["ms_per_frame"],
         windows=main_rec["windows"], timed_s=main_rec["timed_s"],
         window_min_ms=main_rec["window_min_ms"], window_max_ms=main_rec["window_max_ms"],
         config=dict(workload=wl["desc"], resident_frames=main_rec["resident_frames"], semantics="pinhole", pipelined=True,
@@ -672,7 +698,7 @@ def next_rows_leg(V, synth, torch, it, verts, k_inv, stream, Wd, Ht):
         lib.vh_render_blocks(h, pose_ptrs[(7 * i) % nframes], 0.1, 5.0, sil_f.data_ptr(), sil_b.data_ptr())
     kt_s = table.kernel_times(reset=True)
     # garbage collection (next #4) over the blocks the last frame saw; threshold 0 frees them all
-    it.step(0)
+    it.frame(0)
     table.garbage_collect(0.0)
     kt_g = table.kernel_times(reset=True)
     gc_counters = table.counters()

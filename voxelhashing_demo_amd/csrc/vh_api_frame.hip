@@ -221,12 +221,11 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     const bool hasNew = in != nullptr, hasOld = c->pipePending;
     if (!hasNew && !hasOld) return VH_OK;
     int rc;
-    if (!hasOld) {
-        if ((rc = ensure_pipeline_buffers(c)) != VH_OK) return rc;
-        hipLaunchKernelGGL(pipe_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->dp);
-    }
-    const int oldParity = c->pipeParity, newParity = hasOld ? oldParity ^ 1 : oldParity ^ 1;
-    const int setOld = c->pipeSet, setNew = hasOld ? (setOld + 1) % 3 : 0;
+    if (!hasOld && (rc = ensure_pipeline_buffers(c)) != VH_OK) return rc;
+    // buffers alternate and counter sets rotate from frame to frame, across flushes too (a flush leaves
+    // the two sets it did not consume empty; at creation all three are)
+    const int oldParity = c->pipeParity, newParity = oldParity ^ 1;
+    const int setOld = c->pipeSet, setNew = (setOld + 1) % 3;
     PipeArgs a;
     a.claimBlocks = hasNew ? host_num_tiles(c) : 0u;
     a.walkBlocks = hasNew ? (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane) : 0u;
@@ -263,7 +262,7 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
         c->dp.candidates = dpNew.candidates;
         c->dp.compact = dpNew.compact;
     } else {
-        c->pipePending = false;
+        c->pipePending = false;          // (pipeSet / pipeParity stay: the next run starts on the following set)
     }
     c->occupiedCounter = kCompactCount;
     c->compactArmed = false;

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const Frame
 //     image (uint16) that claim(i) wrote, so the caller's buffer is only read by the launch of its own
 //     frame: no lifetime requirement beyond vh_integrate's;
 //   * claim words, candidate lists and compact lists alternate between two buffers, the per-frame
-//     counters between three sets (filled by frame i+1, consumed by frame i, cleared for frame i+2);
+//     counters between three sets (filled by frame i+1, consumed by frame i, cleared for frame i+2; the
+//     rotation simply continues across flushes, a flush clearing the two sets it does not consume);
 //   * a frame that would insert more entries than the heap has free blocks is refused as a whole (all its
 //     winners count as heap_exhausted and retry next frame): then claim(i+1) knows -- from two numbers
 //     that are stable while the launch runs -- that nothing is in flight and reads the table as it is.
@@ -144,7 +145,7 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
     int32_t *counters = dpNew.counters;
     // is frame i's commit phase inserting (live) or refusing everything?  Both numbers are stable while
     // this launch runs: the count of claimed buckets was final when the previous launch ended, the
-    // free-block count was stored by its last commit workgroup (or by pipe_begin_kernel) in a word this
+    // free-block count was stored by its last commit workgroup (or, in a run's first launch, its first workgroup) in a word this
     // launch does not write.
     const int demandedOld = a.hasOld ? counters[kPipeCand + a.setOld] : 0;
     const int candOld = min(demandedOld, (int)dpOld.candCapacity);
@@ -176,6 +177,9 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
             else { role = 1; index = a.order == 3u ? r - a.commitBlocks : r; }
         }
     }
+    // first launch of a run (no frame in flight): nobody pops the heap during it, so its first workgroup
+    // leaves the free-block count the NEXT launch will test frame i+1's insertions against
+    if (!a.hasOld && b == 0u && threadIdx.x == 0) counters[kPipeHeapFree + a.setNew] = counters[kHeapCounter] + 1;
     if (role >= 2u) {
         // ---- frame i+1: claim || walk ----
         if (!a.hasNew) return;
@@ -234,6 +238,12 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
             counters[kPipeNew + a.setClear] = 0;
             counters[kPipeCand + a.setClear] = 0;
             counters[kPipeWinners + a.setClear] = 0;
+            if (!a.hasNew) {                       // flush launch: the set a new frame would have filled is unused: the next
+                counters[kPipeScan + a.setNew] = 0;    // run starts on it (the host keeps rotating), and finds it empty
+                counters[kPipeNew + a.setNew] = 0;
+                counters[kPipeCand + a.setNew] = 0;
+                counters[kPipeWinners + a.setNew] = 0;
+            }
             counters[kPipeHeapFree + a.setNew] = atomicAdd(counters + kHeapCounter, 0) + 1;   // what the next launch starts with
             counters[kCommitTicket] = 0;
         }
@@ -246,14 +256,6 @@ __global__ __launch_bounds__(256) void frame_pipelined_kernel(const FrameParams 
                                                               const Depth depthOld, const PipeArgs a)
 {
     frame_pipelined(fpNew, dpNew, inNew, fpOld, dpOld, depthOld, a);
-}
-
-// start of a pipelined run: the three counter sets are empty, the free-block count is current
-__global__ void pipe_begin_kernel(const DevPtrs dp)
-{
-    if (threadIdx.x < 9) dp.counters[kPipeScan + threadIdx.x] = 0;       // kPipeScan, kPipeNew, kPipeCand: 3 x 3 consecutive
-    if (threadIdx.x >= 9 && threadIdx.x < 12) dp.counters[kPipeHeapFree + threadIdx.x - 9] = dp.counters[kHeapCounter] + 1;
-    if (threadIdx.x >= 12 && threadIdx.x < 15) dp.counters[kPipeWinners + threadIdx.x - 12] = 0;
 }
 
 }  // namespace vh
