@@ -292,7 +292,8 @@ int vh_debug_eval(vh_context *ctx, const vh_float4 *d_points, int32_t n, int32_t
 /* Options.  Tuning knobs for A/B measurements, results never change: "fused_frame" (1: two launches
  * per frame, 0: the four step kernels), "flatten_variant" (3 = the walk over every VoxelEntry, default;
  * 4 = occupancy index; 5 = persistent prefetching walk; anything else is rejected), "integrate_grid",
- * "commit_blocks", "persistent_blocks", "raycast_patch", "raycast_xcd".  They apply to vh_integrate and
+ * "commit_blocks", "persistent_blocks", "raycast_patch", "raycast_xcd", "walk_nt" (non-temporal loads in
+ * the table walk; on by default when the table exceeds the 256 MiB Infinity Cache).  They apply to vh_integrate and
  * vh_integrate_depth alike.  "cand_capacity" shrinks the candidate list (test hook for
  * vh_counters.cand_overflow).  Format switch: "packet_format" (VH_PACKET_F32 / VH_PACKET_U16, below). */
 int vh_set_option(vh_context *ctx, const char *name, int value);

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--per-round", type=int, default=50)
     ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0, help="frames per vh_integrate_batch call (0: vh_integrate)")
     ap.add_argument("--set", nargs="*", default=[], help="name=value options set once")
     a = ap.parse_args()
     import torch
@@ -51,9 +52,14 @@ def main():
         for v in a.values:
             t.set_option(a.option, v)
             t.set_profiling(True)
-            for i in range(a.per_round):
-                k = (r * a.per_round + i) % a.frames
-                t.integrate(poses[k], verts[k])
+            if a.batch:
+                for i in range(0, a.per_round, a.batch):
+                    ks = [(r * a.per_round + i + j) % a.frames for j in range(a.batch)]
+                    t.integrate_batch([poses[k] for k in ks], [verts[k] for k in ks])
+            else:
+                for i in range(a.per_round):
+                    k = (r * a.per_round + i) % a.frames
+                    t.integrate(poses[k], verts[k])
             kt = t.kernel_times(reset=True)
             t.set_profiling(False)
             res[v].append({k: 1e3 * kt[k] / kt["launches"] for k in kt if k.endswith("_ms") and k != "raycast_ms"})

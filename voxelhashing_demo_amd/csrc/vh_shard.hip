@@ -57,13 +57,8 @@ __device__ __forceinline__ void flatten_multi_tile(const FrameParams &fp, const 
                                                    int counter)
 {
     const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
-    const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
     int32_t ptrs[kEntriesPerLane];
-#pragma unroll
-    for (int j = 0; j < kEntriesPerLane; ++j) {
-        const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
-        ptrs[j] = (e < numEntries) ? words[(size_t)e * kEntryDwords + 3] : VH_FREE_BLOCK;
-    }
+    walk_load_tile(fp, dp, numEntries, tileIndex, ptrs);
     uint32_t seen[kEntriesPerLane];         // cameras whose frustum holds entry j
     int myCount = 0;
 #pragma unroll

@@ -103,15 +103,11 @@ __device__ __forceinline__ void view_select(const FrameParams &fp, const DevPtrs
                                             int32_t capacity, int32_t *__restrict__ counts)
 {
     const uint32_t tile = blockIdx.x * (kFlattenThreads * kEntriesPerLane);
-    const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
     int32_t ptrs[kEntriesPerLane];
+    walk_load_tile(fp, dp, numEntries, blockIdx.x, ptrs);
     bool any = false;
 #pragma unroll
-    for (int j = 0; j < kEntriesPerLane; ++j) {
-        const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
-        ptrs[j] = (e < numEntries) ? words[(size_t)e * kEntryDwords + 3] : VH_FREE_BLOCK;
-        any |= ptrs[j] != VH_FREE_BLOCK;
-    }
+    for (int j = 0; j < kEntriesPerLane; ++j) any |= ptrs[j] != VH_FREE_BLOCK;
     if (__ballot(any) == 0ull) return;
     const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll

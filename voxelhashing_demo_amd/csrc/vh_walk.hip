@@ -14,10 +14,15 @@ namespace vh {
 // list are taken with one atomic per wave instruction that has a hit (ballot + popcount).  The
 // reference also clears the whole compact table first (VoxelUtils.cu:757-758, its own TODO calls
 // it redundant); that pass is dropped.
-// Measured and removed in round 2 (profiles/r01_*): non-temporal ptr loads (+7 %),
-// 16-byte-chunk loads with the ptr picked out of the chunk (+10 %), a per-lane hit count with one
-// wave scan (+3 %), and a "mask" form that stored allocation ballots for a second launch to
-// consume (launch 1 -0.4 us, launch 2 +8.5 us).
+// The ptr loads are non-temporal when the table is larger than the 256 MiB Infinity Cache (kFlagWalkNt,
+// set at creation, option "walk_nt"): C3 launch 1 76.2 -> 70.2 us and launch 2 13.5 -> 11.7 us (the voxel
+// blocks stay cached); on a resident table (C2) they cost 2 %.  tools/micro/membw.hip is the ceiling probe:
+// 419 MB read once at 5.9 TB/s with dwordx4 loads, 6.0 with this access shape, 7.0 with it non-temporal.
+// Measured and removed in round 2: 16-byte-chunk loads with the ptr picked out of the
+// chunk (+10 %), a per-lane hit count with one wave scan (+3 %), a "mask" form that stored allocation
+// ballots for a second launch to consume (launch 1 -0.4 us, launch 2 +8.5 us), and an LDS-DMA form
+// (global_load_lds_dwordx4, 5 KiB chunks per wave, ptr and live entries read back from LDS: C3 75.9 vs
+// 69.5 us with non-temporal loads in both, C2 17.7 vs 17.1 us).
 constexpr int kFlattenThreads = 256;
 #ifndef VH_ENTRIES_PER_LANE
 #define VH_ENTRIES_PER_LANE 8
@@ -44,11 +49,19 @@ __device__ __forceinline__ int reserve_compact_slots(const DevPtrs &dp, int coun
 }
 
 // strided walk with one ballot + atomic per unrolled entry slot (hits are rare on small scenes)
-__device__ __forceinline__ void walk_load_tile(const DevPtrs &dp, uint32_t numEntries, uint32_t tileIndex,
-                                               int32_t (&ptrs)[kEntriesPerLane])
+__device__ __forceinline__ void walk_load_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
+                                               uint32_t tileIndex, int32_t (&ptrs)[kEntriesPerLane])
 {
     const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
     const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
+    if (fp.flags & kFlagWalkNt) {
+#pragma unroll
+        for (int j = 0; j < kEntriesPerLane; ++j) {
+            const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
+            ptrs[j] = (e < numEntries) ? __builtin_nontemporal_load(words + (size_t)e * kEntryDwords + 3) : VH_FREE_BLOCK;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < kEntriesPerLane; ++j) {
         const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
@@ -100,7 +113,7 @@ __device__ __forceinline__ void flatten_tile_ballot(const FrameParams &fp, const
                                                     uint32_t tileIndex, int counter, const Pending &pend = kNoPending)
 {
     int32_t ptrs[kEntriesPerLane];
-    walk_load_tile(dp, numEntries, tileIndex, ptrs);
+    walk_load_tile(fp, dp, numEntries, tileIndex, ptrs);
     walk_process_tile(fp, dp, tileIndex, ptrs, counter, pend);
 }
 
@@ -116,11 +129,11 @@ __device__ __forceinline__ void flatten_tiles_persistent(const FrameParams &fp, 
     uint32_t t = firstTile;
     if (t >= numTiles) return;
     int32_t cur[kEntriesPerLane], nxt[kEntriesPerLane];
-    walk_load_tile(dp, numEntries, t, cur);
+    walk_load_tile(fp, dp, numEntries, t, cur);
     for (;;) {
         const uint32_t n = t + stride;
         const bool more = n < numTiles;
-        if (more) walk_load_tile(dp, numEntries, n, nxt);
+        if (more) walk_load_tile(fp, dp, numEntries, n, nxt);
         walk_process_tile(fp, dp, t, cur, counter);
         if (!more) break;
 #pragma unroll
