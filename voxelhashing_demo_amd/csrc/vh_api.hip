@@ -107,7 +107,8 @@ struct vh_context {
     void *viewSet = nullptr;               // vh_export_views_fixed: the prepared views (ViewSet) in device memory
     int32_t *viewLists = nullptr;          // export: selected entry indices, [views][capacity]
     size_t viewListsSize = 0;              // in int32
-    int32_t *blockList = nullptr;          // vh_render_blocks: counter (4 ints) + indices of all allocated entries
+    int32_t *blockList = nullptr;          // vh_render_blocks: two counter words (4 ints) + the records of the allocated blocks
+    int blockParity = 0;                   // which counter word the next vh_render_blocks appends through
     const Voxel *viewBlocks = nullptr;     // import: the record buffer the view table's ptrs address
     int32_t viewCount = 0;                 // records of the last import (their buckets are listed in compactMask)
 };

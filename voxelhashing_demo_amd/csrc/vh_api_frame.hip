@@ -462,28 +462,26 @@ extern "C" int vh_render_blocks(vh_context *c, const float pose[16], float t_min
     bv.fx = c->rc_fx; bv.fy = c->rc_fy; bv.cx = c->rc_cx; bv.cy = c->rc_cy;
     bv.tMin = t_min;
     bv.tMax = t_max;
-    const int32_t npix = c->fp.width * c->fp.height;
-    // list of the allocated entries: room for every entry of the table, allocated on first use (synchronises once)
+    // records of the allocated blocks (20 bytes each; a table holds at most numVoxelBlocks of them, a view
+    // table one per entry) behind two counter words, allocated on first use (synchronises once)
+    const size_t capacity = c->viewBlocks ? c->numEntries : std::min<size_t>(c->numEntries, c->params.numVoxelBlocks);
     if (!c->blockList) {
         VH_HIP(hipStreamSynchronize(c->stream));
-        VH_HIP(hipMalloc((void **)&c->blockList, sizeof(int32_t) * (c->numEntries + 4)));
+        VH_HIP(hipMalloc((void **)&c->blockList, 16 + sizeof(BlockRecord) * capacity));
+        VH_HIP(hipMemsetAsync(c->blockList, 0, 16, c->stream));
+        c->blockParity = 0;
     }
-    int32_t *listCount = c->blockList;
-    int32_t *list = listCount + 4;
-    const int32_t capacity = (int32_t)c->numEntries;
-    uint32_t *front = reinterpret_cast<uint32_t *>(d_front), *back = reinterpret_cast<uint32_t *>(d_back);
-    int rc = launch(c, kPhaseRaycastBounds, blocks_init_kernel, dim3((unsigned)grid_for((size_t)npix, 256)), dim3(256), front,
-                    back, npix, listCount);
+    int32_t *counts = c->blockList;
+    BlockRecord *records = reinterpret_cast<BlockRecord *>(c->blockList + 4);
+    const int parity = c->blockParity;
     const uint32_t words = (c->ownedBuckets + 31u) / 32u;
+    int rc = launch(c, kPhaseRaycastBounds, blocks_list_kernel, dim3((unsigned)grid_for(words, 256)), dim3(256), c->fp, c->dp,
+                    bv, records, (int32_t)capacity, counts, parity);
     if (rc == VH_OK)
-        rc = launch(c, kPhaseRaycastBounds, blocks_list_kernel, dim3((unsigned)grid_for(words, 256)), dim3(256), c->fp, c->dp,
-                    list, capacity, listCount);
-    if (rc == VH_OK)
-        rc = launch(c, kPhaseRaycastBounds, blocks_raster_kernel, dim3(1024, 16), dim3(256), c->fp, c->dp, bv,
-                    (const int32_t *)list, capacity, (const int32_t *)listCount, front, back);
-    if (rc == VH_OK)
-        rc = launch(c, kPhaseRaycastBounds, blocks_finish_kernel, dim3((unsigned)grid_for((size_t)npix, 256)), dim3(256), front,
-                    npix);
+        rc = launch(c, kPhaseRaycastBounds, blocks_tile_kernel, dim3((c->fp.width + 15) / 16, (c->fp.height + 15) / 16),
+                    dim3(256), c->fp, bv, (const BlockRecord *)records, (int32_t)capacity, (const int32_t *)counts, parity,
+                    d_front, d_back);
+    c->blockParity ^= 1;
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;

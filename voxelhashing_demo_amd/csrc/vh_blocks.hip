@@ -19,34 +19,100 @@ struct BlockView {
 
 constexpr uint32_t kFrontInit = 0x7f800000u;      // +inf: no cube in front of this pixel yet
 
-__global__ __launch_bounds__(256) void blocks_init_kernel(uint32_t *front, uint32_t *back, int32_t n, int32_t *listCount)
+// Two launches.  (1) blocks_list_kernel: every allocated entry (found through the bucket-occupancy bitmap)
+// gets a 20-byte record {pos, screen bounding box of its cube's corners} unless no pixel can see it.
+// (2) blocks_tile_kernel: one wave per 8x8 pixel tile (a workgroup = a 16x16 region) runs through the
+// records -- the workgroup stages 256 at a time in LDS, each wave tests their boxes against its tile
+// (one record per lane, __ballot) and every lane ray/box-tests its pixel against the records that
+// overlap: nearest entry / farthest exit kept in registers, written once.  No atomics, no image
+// initialisation pass, no per-block load imbalance (round 1-2: one workgroup pass per block with
+// atomicMin/atomicMax per covered pixel, 232 us on C2; this form: DESIGN.md 5).  The min / max over a
+// pixel's cubes does not depend on the order, and a cube whose box misses a pixel fails that pixel's
+// ray/box test anyway, so the images equal the oracle's bit for bit.
+struct BlockRecord {
+    int32_t pos[3];
+    uint32_t xy0, xy1;       // x | y << 16: first and last pixel of the bounding box
+};
+static_assert(sizeof(BlockRecord) == 20, "BlockRecord");
+
+// the cube of block k: world [8k*vs, (8k+8)*vs] per axis (block2World of the min corner, no half-voxel shift)
+__device__ __forceinline__ void block_cube(const FrameParams &fp, const int32_t pos[3], float lo[3], float hi[3])
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) *listCount = 0;
-    if (i < n) { front[i] = kFrontInit; back[i] = 0u; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = (float)(int)((uint32_t)pos[a] * 8u) * fp.voxelSize;
+        hi[a] = ((float)(int)((uint32_t)pos[a] * 8u) + 8.0f) * fp.voxelSize;
+    }
 }
 
-// allocated entries, found through the bucket-occupancy bitmap (one lane per 32-bucket word)
-__global__ __launch_bounds__(256) void blocks_list_kernel(const FrameParams fp, const DevPtrs dp, int32_t *list,
-                                                          int32_t capacity, int32_t *listCount)
+// screen bounding box of the cube's corners (the whole image when a corner is at or behind the camera
+// plane); false when no pixel can see the cube in [tMin, tMax]
+__device__ __forceinline__ bool block_bounds(const FrameParams &fp, const BlockView &bv, const int32_t pos[3], int &x0,
+                                             int &y0, int &x1, int &y1)
+{
+    float lo[3], hi[3];
+    block_cube(fp, pos, lo, hi);
+    float zmin = 3.0e38f, zmax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float wx = (c & 1) ? hi[0] : lo[0], wy = (c & 2) ? hi[1] : lo[1], wz = (c & 4) ? hi[2] : lo[2];
+        const float x = bv.Tinv[0] * wx + bv.Tinv[1] * wy + bv.Tinv[2] * wz + bv.Tinv[3];
+        const float y = bv.Tinv[4] * wx + bv.Tinv[5] * wy + bv.Tinv[6] * wz + bv.Tinv[7];
+        const float z = bv.Tinv[8] * wx + bv.Tinv[9] * wy + bv.Tinv[10] * wz + bv.Tinv[11];
+        zmin = __builtin_fminf(zmin, z);
+        zmax = __builtin_fmaxf(zmax, z);
+        const float iz = 1.0f / __builtin_fmaxf(z, 1.0e-6f);
+        const float u = bv.fx * x * iz + bv.cx, v = bv.fy * y * iz + bv.cy;
+        umin = __builtin_fminf(umin, u); umax = __builtin_fmaxf(umax, u);
+        vmin = __builtin_fminf(vmin, v); vmax = __builtin_fmaxf(vmax, v);
+    }
+    // wholly nearer than the first sample depth (e.g. behind the camera) or beyond the last: no pixel
+    // can see it in [tMin, tMax] (camera depth along a ray = z of the point)
+    if (zmax < bv.tMin - fp.voxelSize || zmin > bv.tMax + fp.voxelSize) return false;
+    x0 = 0; x1 = fp.width - 1; y0 = 0; y1 = fp.height - 1;
+    if (zmin > 0.05f) {
+        if (umax < -2.0f || vmax < -2.0f || umin > (float)fp.width + 1.0f || vmin > (float)fp.height + 1.0f) return false;
+        x0 = max(0, (int)__builtin_floorf(umin) - 2);
+        y0 = max(0, (int)__builtin_floorf(vmin) - 2);
+        x1 = min(fp.width - 1, (int)__builtin_ceilf(__builtin_fminf(umax, 1.0e6f)) + 2);
+        y1 = min(fp.height - 1, (int)__builtin_ceilf(__builtin_fminf(vmax, 1.0e6f)) + 2);
+    }
+    return x0 <= x1 && y0 <= y1;
+}
+
+// counts: two words used in turn by successive calls (call n appends through counts[n & 1] and zeroes the
+// other for call n + 1), so no launch is spent on a reset
+__global__ __launch_bounds__(256) void blocks_list_kernel(const FrameParams fp, const DevPtrs dp, const BlockView bv,
+                                                          BlockRecord *__restrict__ records, int32_t capacity,
+                                                          int32_t *__restrict__ counts, int parity)
 {
     const uint32_t owned = fp.bucketHi - fp.bucketLo;
     const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    if (w == 0) counts[parity ^ 1] = 0;
     if (w >= (owned + 31u) / 32u) return;
     uint32_t bits = dp.bucketBits[w];
+    const bool holes = (fp.flags & kFlagOverflow) != 0u;        // entries form a prefix of the bucket unless chains leave holes
     while (bits != 0u) {
         const uint32_t bucket = w * 32u + (uint32_t)__ffs((int)bits) - 1u;
         bits &= bits - 1u;
         for (uint32_t s = 0; s < fp.bucketSize; ++s) {
-            const uint32_t e = bucket * fp.bucketSize + s;
-            if (dp.table[e].ptr == VH_FREE_BLOCK) break;               // entries form a prefix
-            const int slot = atomicAdd(listCount, 1);
-            if (slot < capacity) list[slot] = (int32_t)e;
+            const VoxelEntry e = dp.table[(size_t)bucket * fp.bucketSize + s];
+            if (e.ptr == VH_FREE_BLOCK) {
+                if (holes) continue;
+                break;
+            }
+            BlockRecord r;
+            r.pos[0] = e.pos[0]; r.pos[1] = e.pos[1]; r.pos[2] = e.pos[2];
+            int x0, y0, x1, y1;
+            if (!block_bounds(fp, bv, r.pos, x0, y0, x1, y1)) continue;
+            r.xy0 = (uint32_t)x0 | ((uint32_t)y0 << 16);
+            r.xy1 = (uint32_t)x1 | ((uint32_t)y1 << 16);
+            const int slot = atomicAdd(counts + parity, 1);
+            if (slot < capacity) records[slot] = r;
         }
     }
 }
 
-// the cube of block k: world [8k*vs, (8k+8)*vs] per axis (block2World of the min corner, no half-voxel shift)
 // same operations in the same order as the oracle's ray_box
 __device__ __forceinline__ bool ray_box(const float o[3], const float d[3], const float lo[3], const float hi[3],
                                         float &tNear, float &tFar)
@@ -66,74 +132,61 @@ __device__ __forceinline__ bool ray_box(const float o[3], const float d[3], cons
     return tNear <= tFar;
 }
 
-// one listed block per workgroup pass: screen bounding box of the cube's corners (the whole image when
-// a corner is at or behind the camera plane), every pixel in it tested exactly
-__global__ __launch_bounds__(256) void blocks_raster_kernel(const FrameParams fp, const DevPtrs dp, const BlockView bv,
-                                                            const int32_t *__restrict__ list, int32_t capacity,
-                                                            const int32_t *__restrict__ listCount,
-                                                            uint32_t *__restrict__ front, uint32_t *__restrict__ back)
+constexpr int kBlocksStage = 256;        // records staged per round (one per lane of the workgroup)
+
+__global__ __launch_bounds__(256) void blocks_tile_kernel(const FrameParams fp, const BlockView bv,
+                                                          const BlockRecord *__restrict__ records, int32_t capacity,
+                                                          const int32_t *__restrict__ counts, int parity,
+                                                          float *__restrict__ front, float *__restrict__ back)
 {
-    const int n = min(*listCount, capacity);
-    for (int b = blockIdx.x; b < n; b += gridDim.x) {
-        const VoxelEntry e = dp.table[list[b]];
-        float lo[3], hi[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = (float)(int)((uint32_t)e.pos[a] * 8u) * fp.voxelSize;
-            hi[a] = ((float)(int)((uint32_t)e.pos[a] * 8u) + 8.0f) * fp.voxelSize;
-        }
-        float zmin = 3.0e38f, zmax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float wx = (c & 1) ? hi[0] : lo[0], wy = (c & 2) ? hi[1] : lo[1], wz = (c & 4) ? hi[2] : lo[2];
-            const float x = bv.Tinv[0] * wx + bv.Tinv[1] * wy + bv.Tinv[2] * wz + bv.Tinv[3];
-            const float y = bv.Tinv[4] * wx + bv.Tinv[5] * wy + bv.Tinv[6] * wz + bv.Tinv[7];
-            const float z = bv.Tinv[8] * wx + bv.Tinv[9] * wy + bv.Tinv[10] * wz + bv.Tinv[11];
-            zmin = __builtin_fminf(zmin, z);
-            zmax = __builtin_fmaxf(zmax, z);
-            const float iz = 1.0f / __builtin_fmaxf(z, 1.0e-6f);
-            const float u = bv.fx * x * iz + bv.cx, v = bv.fy * y * iz + bv.cy;
-            umin = __builtin_fminf(umin, u); umax = __builtin_fmaxf(umax, u);
-            vmin = __builtin_fminf(vmin, v); vmax = __builtin_fmaxf(vmax, v);
-        }
-        // wholly nearer than the first sample depth (e.g. behind the camera) or beyond the last: no pixel
-        // can see it in [tMin, tMax] (camera depth along a ray = z of the point)
-        if (zmax < bv.tMin - fp.voxelSize || zmin > bv.tMax + fp.voxelSize) continue;
-        int x0 = 0, x1 = fp.width - 1, y0 = 0, y1 = fp.height - 1;
-        if (zmin > 0.05f) {
-            if (umax < -2.0f || vmax < -2.0f || umin > (float)fp.width + 1.0f || vmin > (float)fp.height + 1.0f) continue;
-            x0 = max(0, (int)__builtin_floorf(umin) - 2);
-            y0 = max(0, (int)__builtin_floorf(vmin) - 2);
-            x1 = min(fp.width - 1, (int)__builtin_ceilf(__builtin_fminf(umax, 1.0e6f)) + 2);
-            y1 = min(fp.height - 1, (int)__builtin_ceilf(__builtin_fminf(vmax, 1.0e6f)) + 2);
-        }
-        // blockIdx.y cuts the box into horizontal bands (a block next to the camera covers 10^5 pixels)
-        const int bandH = (y1 - y0 + (int)gridDim.y) / (int)gridDim.y;
-        y0 += (int)blockIdx.y * bandH;
-        y1 = min(y1, y0 + bandH - 1);
-        if (y0 > y1) continue;
-        const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
-        const float o[3] = {bv.T[3], bv.T[7], bv.T[11]};
-        for (int i = threadIdx.x; i < bw * bh; i += 256) {
-            const int py = y0 + i / bw, px = x0 + (i - (i / bw) * bw);
-            const float dx = ((float)px - bv.cx) / bv.fx, dy = ((float)py - bv.cy) / bv.fy;
-            const float d[3] = {bv.T[0] * dx + bv.T[1] * dy + bv.T[2], bv.T[4] * dx + bv.T[5] * dy + bv.T[6],
-                                bv.T[8] * dx + bv.T[9] * dy + bv.T[10]};
-            float tNear, tFar;
-            if (!ray_box(o, d, lo, hi, tNear, tFar)) continue;
-            if (tFar < bv.tMin || tNear > bv.tMax) continue;
-            const float f = __builtin_fmaxf(tNear, bv.tMin), k = __builtin_fminf(tFar, bv.tMax);
-            atomicMin(front + (size_t)py * fp.width + px, __float_as_uint(f));      // positive floats order like uints
-            atomicMax(back + (size_t)py * fp.width + px, __float_as_uint(k));
+    __shared__ BlockRecord stage[2][kBlocksStage];
+    const int n = min(counts[parity], capacity);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    // the wave's 8x8 tile inside the workgroup's 16x16 region; lane -> pixel row-major in the tile
+    const int tx0 = (int)blockIdx.x * 16 + (wave & 1) * 8, ty0 = (int)blockIdx.y * 16 + (wave >> 1) * 8;
+    const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
+    const float o[3] = {bv.T[3], bv.T[7], bv.T[11]};
+    const float dx = ((float)px - bv.cx) / bv.fx, dy = ((float)py - bv.cy) / bv.fy;
+    const float d[3] = {bv.T[0] * dx + bv.T[1] * dy + bv.T[2], bv.T[4] * dx + bv.T[5] * dy + bv.T[6],
+                        bv.T[8] * dx + bv.T[9] * dy + bv.T[10]};
+    uint32_t nearest = kFrontInit, farthest = 0u;               // positive floats order like their bit patterns
+    BlockRecord mine;
+    if ((int)threadIdx.x < n) mine = records[threadIdx.x];
+    for (int base = 0, buf = 0; base < n; base += kBlocksStage, buf ^= 1) {
+        if (base + (int)threadIdx.x < n) stage[buf][threadIdx.x] = mine;
+        const int nextIdx = base + kBlocksStage + (int)threadIdx.x;
+        if (nextIdx < n) mine = records[nextIdx];               // in flight while this round is worked through
+        __syncthreads();                                         // (two buffers: one barrier per round)
+        const int count = min(kBlocksStage, n - base);
+        for (int k = 0; k < count; k += kWave) {
+            bool overlap = false;
+            BlockRecord r;
+            if (k + lane < count) {
+                r = stage[buf][k + lane];
+                const int x0 = (int)(r.xy0 & 0xffffu), y0 = (int)(r.xy0 >> 16), x1 = (int)(r.xy1 & 0xffffu), y1 = (int)(r.xy1 >> 16);
+                overlap = x0 <= tx0 + 7 && x1 >= tx0 && y0 <= ty0 + 7 && y1 >= ty0;
+            }
+            unsigned long long mask = __ballot(overlap);
+            while (mask != 0ull) {
+                const int src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1ull;
+                const BlockRecord &q = stage[buf][k + src];      // one LDS address for the wave: broadcast read
+                const int32_t pos[3] = {q.pos[0], q.pos[1], q.pos[2]};
+                float lo[3], hi[3];
+                block_cube(fp, pos, lo, hi);
+                float tNear, tFar;
+                if (!ray_box(o, d, lo, hi, tNear, tFar)) continue;
+                if (tFar < bv.tMin || tNear > bv.tMax) continue;
+                nearest = min(nearest, __float_as_uint(__builtin_fmaxf(tNear, bv.tMin)));
+                farthest = max(farthest, __float_as_uint(__builtin_fminf(tFar, bv.tMax)));
+            }
         }
     }
-}
-
-// +inf (no cube) -> 0 in the front layer
-__global__ __launch_bounds__(256) void blocks_finish_kernel(uint32_t *front, int32_t n)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && front[i] == kFrontInit) front[i] = 0u;
+    if (px < fp.width && py < fp.height) {
+        const size_t idx = (size_t)py * fp.width + px;
+        front[idx] = nearest == kFrontInit ? 0.0f : __uint_as_float(nearest);       // no cube: 0
+        back[idx] = __uint_as_float(farthest);
+    }
 }
 
 }  // namespace vh
