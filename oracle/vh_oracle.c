@@ -1033,7 +1033,9 @@ void vho_render_blocks(const vho_table *t, const float pose[16], float t_min, fl
             float tn, tf;
             if (!ray_box(o, d, lo, hi, &tn, &tf)) continue;
             if (tf < t_min || tn > t_max) continue;
-            const float f = fmaxf(tn, t_min), k = fminf(tf, t_max);
+            /* (+ 0.0f: a face through the camera centre gives t = -0; the images hold +0 for it, so that
+             * which of two equal zeros a pixel keeps does not depend on the order of the blocks) */
+            const float f = fmaxf(tn, t_min) + 0.0f, k = fminf(tf, t_max) + 0.0f;
             float *pf = front + (size_t)py * W + px, *pb = back + (size_t)py * W + px;
             if (f < *pf) *pf = f;
             if (k > *pb) *pb = k;

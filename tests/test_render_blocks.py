@@ -70,3 +70,44 @@ def test_gpu_silhouettes_equal_oracle(oracle, vh, torch_cuda, sem):
     ot.integrate(frames[0][0] if sem == 1 else np.eye(4, dtype=np.float32), frames[0][1])
     gt.synchronize()
     assert np.array_equal(gt.hash_table()["pos"], ot.hash_table()["pos"])
+
+
+@pytest.mark.gpu
+def test_gpu_silhouettes_division_corner_cases(oracle, vh, torch_cuda):
+    """The tile pass divides by a pixel's fixed ray direction through a hoisted reciprocal; everything the
+    plain division would rescale takes the plain division.  Poses that reach those cases: an integer principal
+    point with an axis-aligned camera (a column and a row of exactly-zero direction components), a camera
+    centre exactly on cube faces (zero numerators) and 1e-30 / 1e-38 off them (tiny and denormal numerators),
+    and a rotation by 1e-25 rad (direction components far below the fast range)."""
+    torch = torch_cuda
+    ot, frames = build(oracle, 1)
+    gt = vh.SDFHashtable(vh.default_params(**KW), W, H, 1)
+    for p, v in frames:
+        gt.integrate(p, torch.from_numpy(v).cuda())
+    for t in (ot, gt):
+        t.set_raycast_intrinsics(140.0, 140.0, 80.0, 60.0)
+    front, back = torch.empty((H, W), device="cuda"), torch.empty((H, W), device="cuda")
+    corner = (ot.allocated()["pos"][len(ot.allocated()) // 2].astype(np.float32) * 8) * np.float32(0.02)
+    poses = []
+    for off in (0.0, 1e-30, -1e-38, 3e-20):
+        p = np.eye(4, dtype=np.float32)
+        p[:3, 3] = corner + np.float32(off)
+        poses.append(p)
+        q = p.copy()
+        q[:3, 3] = (np.float32(off), corner[1], np.float32(1.0) + np.float32(off))
+        poses.append(q)
+    tilt = np.eye(4, dtype=np.float32)
+    tilt[0, 2], tilt[2, 0] = np.float32(1e-25), np.float32(-1e-25)
+    tilt[:3, 3] = (0.1, 1.4, 0.2)
+    poses.append(tilt)
+    yaw = np.asarray(frames[1][0], np.float32).reshape(4, 4).copy()
+    poses.append(yaw)
+    seen = 0
+    for pose in poses:
+        gt.render_blocks(pose, front, back, 0.0, 6.0)
+        torch.cuda.synchronize()
+        of, ob = ot.render_blocks(pose, 0.0, 6.0)
+        assert np.array_equal(front.cpu().numpy().view(np.uint32), of.view(np.uint32))
+        assert np.array_equal(back.cpu().numpy().view(np.uint32), ob.view(np.uint32))
+        seen += int((ob > 0).sum())
+    assert seen > 10 * W * H // 4

@@ -462,7 +462,7 @@ extern "C" int vh_render_blocks(vh_context *c, const float pose[16], float t_min
     bv.fx = c->rc_fx; bv.fy = c->rc_fy; bv.cx = c->rc_cx; bv.cy = c->rc_cy;
     bv.tMin = t_min;
     bv.tMax = t_max;
-    // records of the allocated blocks (20 bytes each; a table holds at most numVoxelBlocks of them, a view
+    // records of the allocated blocks (32 bytes each; a table holds at most numVoxelBlocks of them, a view
     // table one per entry) behind two counter words, allocated on first use (synchronises once)
     const size_t capacity = c->viewBlocks ? c->numEntries : std::min<size_t>(c->numEntries, c->params.numVoxelBlocks);
     if (!c->blockList) {

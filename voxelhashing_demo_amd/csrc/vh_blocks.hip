@@ -20,7 +20,7 @@ struct BlockView {
 constexpr uint32_t kFrontInit = 0x7f800000u;      // +inf: no cube in front of this pixel yet
 
 // Two launches.  (1) blocks_list_kernel: every allocated entry (found through the bucket-occupancy bitmap)
-// gets a 20-byte record {pos, screen bounding box of its cube's corners} unless no pixel can see it.
+// gets a 32-byte record {cube, screen bounding box of its corners} unless no pixel can see it.
 // (2) blocks_tile_kernel: one wave per 8x8 pixel tile (a workgroup = a 16x16 region) runs through the
 // records -- the workgroup stages 256 at a time in LDS, each wave tests their boxes against its tile
 // (one record per lane, __ballot) and every lane ray/box-tests its pixel against the records that
@@ -29,11 +29,38 @@ constexpr uint32_t kFrontInit = 0x7f800000u;      // +inf: no cube in front of t
 // atomicMin/atomicMax per covered pixel, 232 us on C2; this form: DESIGN.md 5).  The min / max over a
 // pixel's cubes does not depend on the order, and a cube whose box misses a pixel fails that pixel's
 // ray/box test anyway, so the images equal the oracle's bit for bit.
-struct BlockRecord {
-    int32_t pos[3];
-    uint32_t xy0, xy1;       // x | y << 16: first and last pixel of the bounding box
+struct alignas(16) BlockRecord {
+    float lo[3];             // the cube (block_cube)
+    uint32_t xy0;            // x | y << 16: first pixel of the bounding box
+    float hi[3];
+    uint32_t xy1;            // last pixel; bit 31: every lo - o, hi - o is inside the fast-division range
 };
-static_assert(sizeof(BlockRecord) == 20, "BlockRecord");
+constexpr uint32_t kBlockFastBit = 0x80000000u;
+
+// Division by a fixed divisor.  The compiler's IEEE fp32 division is, when none of v_div_scale's rescaling
+// cases applies, exactly: r0 = rcp(d); r1 = fma(fma(-d, r0, 1), r0, r0); q0 = n * r1; q1 = fma(fma(-d, q0, n),
+// r1, q0); q = fma(fma(-d, q1, n), r1, q1).  r1 depends on the divisor alone -- here a pixel's ray direction,
+// fixed over all the cubes the pixel is tested against -- so it is computed once and a division costs 5
+// instructions instead of 13, with the same bits.  The rescaling cases (denormal or huge operands or
+// quotients, a tiny numerator) are kept out by range checks: 2^-40 <= |d| <= 2^40 per pixel (fast_divisor),
+// 2^-50 <= |n| <= 2^50 per cube (kBlockFastBit); anything else takes the plain division.
+__device__ __forceinline__ bool fast_range(float x, float lo, float hi)
+{
+    const float a = __builtin_fabsf(x);
+    return a >= lo && a <= hi;
+}
+__device__ __forceinline__ float refined_rcp(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float div_fixed(float n, float d, float r1)
+{
+    const float q0 = n * r1;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
+    return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
+}
+static_assert(sizeof(BlockRecord) == 32, "BlockRecord");
 
 // the cube of block k: world [8k*vs, (8k+8)*vs] per axis (block2World of the min corner, no half-voxel shift)
 __device__ __forceinline__ void block_cube(const FrameParams &fp, const int32_t pos[3], float lo[3], float hi[3])
@@ -102,11 +129,17 @@ __global__ __launch_bounds__(256) void blocks_list_kernel(const FrameParams fp, 
                 break;
             }
             BlockRecord r;
-            r.pos[0] = e.pos[0]; r.pos[1] = e.pos[1]; r.pos[2] = e.pos[2];
             int x0, y0, x1, y1;
-            if (!block_bounds(fp, bv, r.pos, x0, y0, x1, y1)) continue;
+            if (!block_bounds(fp, bv, e.pos, x0, y0, x1, y1)) continue;
+            block_cube(fp, e.pos, r.lo, r.hi);
             r.xy0 = (uint32_t)x0 | ((uint32_t)y0 << 16);
             r.xy1 = (uint32_t)x1 | ((uint32_t)y1 << 16);
+            bool fast = true;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                fast = fast && fast_range(r.lo[a] - bv.T[4 * a + 3], 0x1p-50f, 0x1p50f) &&
+                       fast_range(r.hi[a] - bv.T[4 * a + 3], 0x1p-50f, 0x1p50f);
+            if (fast) r.xy1 |= kBlockFastBit;
             const int slot = atomicAdd(counts + parity, 1);
             if (slot < capacity) records[slot] = r;
         }
@@ -150,6 +183,17 @@ __global__ __launch_bounds__(256) void blocks_tile_kernel(const FrameParams fp, 
     const float d[3] = {bv.T[0] * dx + bv.T[1] * dy + bv.T[2], bv.T[4] * dx + bv.T[5] * dy + bv.T[6],
                         bv.T[8] * dx + bv.T[9] * dy + bv.T[10]};
     uint32_t nearest = kFrontInit, farthest = 0u;               // positive floats order like their bit patterns
+    // per pixel and axis: a zero direction component (the slab test becomes an inside test, as in ray_box),
+    // the refined reciprocal, and whether all three divisors are inside the fast-division range
+    bool zero[3], fastPixel = true;
+    float r1[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        zero[a] = d[a] == 0.0f;
+        r1[a] = refined_rcp(d[a]);
+        fastPixel = fastPixel && (zero[a] || fast_range(d[a], 0x1p-40f, 0x1p40f));
+    }
+    const bool fastWave = __ballot(!fastPixel) == 0ull;
     BlockRecord mine;
     if ((int)threadIdx.x < n) mine = records[threadIdx.x];
     for (int base = 0, buf = 0; base < n; base += kBlocksStage, buf ^= 1) {
@@ -160,25 +204,40 @@ __global__ __launch_bounds__(256) void blocks_tile_kernel(const FrameParams fp, 
         const int count = min(kBlocksStage, n - base);
         for (int k = 0; k < count; k += kWave) {
             bool overlap = false;
-            BlockRecord r;
             if (k + lane < count) {
-                r = stage[buf][k + lane];
-                const int x0 = (int)(r.xy0 & 0xffffu), y0 = (int)(r.xy0 >> 16), x1 = (int)(r.xy1 & 0xffffu), y1 = (int)(r.xy1 >> 16);
+                const uint32_t xy0 = stage[buf][k + lane].xy0, xy1 = stage[buf][k + lane].xy1;
+                const int x0 = (int)(xy0 & 0xffffu), y0 = (int)(xy0 >> 16), x1 = (int)(xy1 & 0xffffu), y1 = (int)((xy1 >> 16) & 0x7fffu);
                 overlap = x0 <= tx0 + 7 && x1 >= tx0 && y0 <= ty0 + 7 && y1 >= ty0;
             }
             unsigned long long mask = __ballot(overlap);
             while (mask != 0ull) {
                 const int src = __ffsll((long long)mask) - 1;
                 mask &= mask - 1ull;
-                const BlockRecord &q = stage[buf][k + src];      // one LDS address for the wave: broadcast read
-                const int32_t pos[3] = {q.pos[0], q.pos[1], q.pos[2]};
-                float lo[3], hi[3];
-                block_cube(fp, pos, lo, hi);
+                const BlockRecord q = stage[buf][k + src];       // one LDS address for the wave: broadcast read
                 float tNear, tFar;
-                if (!ray_box(o, d, lo, hi, tNear, tFar)) continue;
-                if (tFar < bv.tMin || tNear > bv.tMax) continue;
-                nearest = min(nearest, __float_as_uint(__builtin_fmaxf(tNear, bv.tMin)));
-                farthest = max(farthest, __float_as_uint(__builtin_fminf(tFar, bv.tMax)));
+                bool hit;
+                if (fastWave && (q.xy1 & kBlockFastBit)) {
+                    // ray_box without branches, divisions by the pixel's fixed direction
+                    tNear = -3.0e38f;
+                    tFar = 3.0e38f;
+                    hit = true;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const float t0 = div_fixed(q.lo[a] - o[a], d[a], r1[a]), t1 = div_fixed(q.hi[a] - o[a], d[a], r1[a]);
+                        const float tn = zero[a] ? -3.0e38f : __builtin_fminf(t0, t1);
+                        const float tf = zero[a] ? 3.0e38f : __builtin_fmaxf(t0, t1);
+                        hit = hit && !(zero[a] && (o[a] < q.lo[a] || o[a] > q.hi[a]));
+                        tNear = __builtin_fmaxf(tNear, tn);
+                        tFar = __builtin_fminf(tFar, tf);
+                    }
+                    hit = hit && tNear <= tFar;
+                } else {
+                    hit = ray_box(o, d, q.lo, q.hi, tNear, tFar);
+                }
+                if (!hit || tFar < bv.tMin || tNear > bv.tMax) continue;
+                // (+ 0.0f: -0 from a face through the camera centre becomes +0, as in the oracle)
+                nearest = min(nearest, __float_as_uint(__builtin_fmaxf(tNear, bv.tMin) + 0.0f));
+                farthest = max(farthest, __float_as_uint(__builtin_fminf(tFar, bv.tMax) + 0.0f));
             }
         }
     }
