@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of raycast variants in ONE process, interleaved rounds (per-dispatch HIP event timing).
+"""A/B of a raycast / silhouette option in ONE process, interleaved rounds (per-dispatch HIP event timing).
 
-  python tools/ab_raycast.py --option raycast_patch --values 0 1
+  python tools/ab_raycast.py --option raycast_patch --values 0 1 [--workload C2]
 """
 import argparse
 import os
@@ -19,7 +19,8 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--frames", type=int, default=120)
     ap.add_argument("--rounds", type=int, default=8)
-    ap.add_argument("--per-round", type=int, default=20)
+    ap.add_argument("--per-round", type=int, default=40)
+    ap.add_argument("--blocks", action="store_true", help="time vh_render_blocks instead of vh_raycast")
     a = ap.parse_args()
     import torch
 
@@ -29,29 +30,31 @@ def main():
     wl = WORKLOADS[a.workload]
     Wd, Ht = wl["width"], wl["height"]
     dev = torch.device("cuda", 0)
-    poses = synth.camera_loop(wl["frames"])[:a.frames]
+    poses = synth.camera_loop(wl.get("loop", wl["frames"]))[:a.frames]
     prims = synth.room_primitives()
-    stream = torch.cuda.Stream(device=dev)
     t = V.SDFHashtable(V.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"]),
-                       Wd, Ht, V.SEM_PINHOLE, stream=stream)
-    for i in range(a.frames):
-        t.integrate(poses[i], synth.render_room_verts(poses[i], Wd, Ht, prims, device=dev))
+                       Wd, Ht, V.SEM_PINHOLE)
+    for p in poses:
+        t.integrate(p, synth.render_room_verts(p, Wd, Ht, prims, device=dev))
     t.synchronize()
-    depth = torch.empty((Ht, Wd), dtype=torch.float32, device=dev)
+    out, out2 = torch.empty((Ht, Wd), device=dev), torch.empty((Ht, Wd), device=dev)
     res = {v: [] for v in a.values}
+    key = "render_blocks_ms" if a.blocks else "raycast_ms"
     for r in range(a.rounds):
         for v in a.values:
             t.set_option(a.option, v)
             t.set_profiling(True)
             for i in range(a.per_round):
-                t.raycast(poses[(7 * (r * a.per_round + i)) % a.frames], depth)
+                pose = poses[(7 * (r * a.per_round + i)) % a.frames]
+                if a.blocks:
+                    t.render_blocks(pose, out, out2, 0.1, 5.0)
+                else:
+                    t.raycast(pose, out)
             kt = t.kernel_times(reset=True)
             t.set_profiling(False)
-            res[v].append(1e3 * kt["raycast_ms"] / kt["raycast_launches"])
+            res[v].append(1e3 * kt[key] / a.per_round)
     for v in a.values:
-        us = np.median(res[v])
-        print(f"{a.option}={v}: raycast med {us:.1f} us  min {np.min(res[v]):.1f} us  "
-              f"= {Wd * Ht / us:.0f} Mpix/s (kernel time)")
+        print(f"{a.option}={v}: {key[:-3]} med {np.median(res[v]):.2f} min {np.min(res[v]):.2f} us per call")
 
 
 if __name__ == "__main__":

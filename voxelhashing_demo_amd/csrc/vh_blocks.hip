@@ -35,32 +35,8 @@ struct alignas(16) BlockRecord {
     float hi[3];
     uint32_t xy1;            // last pixel; bit 31: every lo - o, hi - o is inside the fast-division range
 };
-constexpr uint32_t kBlockFastBit = 0x80000000u;
-
-// Division by a fixed divisor.  The compiler's IEEE fp32 division is, when none of v_div_scale's rescaling
-// cases applies, exactly: r0 = rcp(d); r1 = fma(fma(-d, r0, 1), r0, r0); q0 = n * r1; q1 = fma(fma(-d, q0, n),
-// r1, q0); q = fma(fma(-d, q1, n), r1, q1).  r1 depends on the divisor alone -- here a pixel's ray direction,
-// fixed over all the cubes the pixel is tested against -- so it is computed once and a division costs 5
-// instructions instead of 13, with the same bits.  The rescaling cases (denormal or huge operands or
-// quotients, a tiny numerator) are kept out by range checks: 2^-40 <= |d| <= 2^40 per pixel (fast_divisor),
-// 2^-50 <= |n| <= 2^50 per cube (kBlockFastBit); anything else takes the plain division.
-__device__ __forceinline__ bool fast_range(float x, float lo, float hi)
-{
-    const float a = __builtin_fabsf(x);
-    return a >= lo && a <= hi;
-}
-__device__ __forceinline__ float refined_rcp(float d)
-{
-    const float r0 = __builtin_amdgcn_rcpf(d);
-    return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
-}
-__device__ __forceinline__ float div_fixed(float n, float d, float r1)
-{
-    const float q0 = n * r1;
-    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
-    return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
-}
 static_assert(sizeof(BlockRecord) == 32, "BlockRecord");
+constexpr uint32_t kBlockFastBit = 0x80000000u;    // (divisions: div_fixed, vh_device.h)
 
 // the cube of block k: world [8k*vs, (8k+8)*vs] per axis (block2World of the min corner, no half-voxel shift)
 __device__ __forceinline__ void block_cube(const FrameParams &fp, const int32_t pos[3], float lo[3], float hi[3])

@@ -130,6 +130,29 @@ __device__ __forceinline__ uint32_t hash_block(int x, int y, int z, uint32_t num
     return h % numBuckets;
 }
 
+// Division by a fixed divisor.  The compiler's IEEE fp32 division is, when none of v_div_scale's rescaling
+// cases applies, exactly: r0 = rcp(d); r1 = fma(fma(-d, r0, 1), r0, r0); q0 = n * r1; q1 = fma(fma(-d, q0, n),
+// r1, q0); q = fma(fma(-d, q1, n), r1, q1).  r1 depends on the divisor alone (a pixel's ray direction over all
+// the cubes it is tested against), so it is computed once and a division costs 5 instructions instead of 13, with the same bits.  The rescaling cases (denormal or huge
+// operands or quotients, a tiny numerator) are kept out by range checks at the call sites: 2^-40 <= |d| <=
+// 2^40 and 2^-50 <= |n| <= 2^50; anything else takes the plain division.
+__device__ __forceinline__ bool fast_range(float x, float lo, float hi)
+{
+    const float a = __builtin_fabsf(x);
+    return a >= lo && a <= hi;
+}
+__device__ __forceinline__ float refined_rcp(float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float div_fixed(float n, float d, float r1)
+{
+    const float q0 = n * r1;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-d, q0, n), r1, q0);
+    return __builtin_fmaf(__builtin_fmaf(-d, q1, n), r1, q1);
+}
+
 // world2Voxel, VoxelUtils.cu:280-287: true divide, round half away from zero
 __device__ __forceinline__ int world2voxel1(float p, float voxelSize)
 {
