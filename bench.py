@@ -371,6 +371,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VH_BENCH_SHARE_GPU") == "1":          # test rig: all ranks on one device (see init_dist)
+        local_rank = 0
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -618,8 +620,15 @@ def init_dist(dist, torch, local_rank):
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     import datetime
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
-                            timeout=datetime.timedelta(seconds=300))
+    # VH_BENCH_BACKEND=gloo (with VH_BENCH_SHARE_GPU=1: every rank on cuda:0) is the test rig for the N > 1
+    # code path on a one-GPU box -- RCCL refuses two ranks on one device; device buffers are then staged
+    # through the host by the transport.  The driver's runs use the default: nccl = RCCL.
+    backend = os.environ.get("VH_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=300))
+    else:
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=300))
 
 
 def raycast_roofline(workload, kernel_us, Wd, Ht):

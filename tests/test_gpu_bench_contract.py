@@ -1,0 +1,66 @@
+"""bench.py's output contract, end to end on the GPU box: the one-GPU line and the N > 1 line the driver
+launches through torch.distributed.run.  A one-GPU box cannot run two RCCL ranks (RCCL refuses two ranks on
+one device), so the two-rank run uses bench.py's test rig: gloo as the transport (device buffers staged
+through the host) and both ranks on cuda:0 -- the same sharded code path, windows, reductions and JSON."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _line(out):
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def _check(rec, n_gpus, steps, warmup):
+    for k in REQUIRED:
+        assert k in rec, k
+    assert rec["n_gpus"] == n_gpus and rec["steps"] == steps and rec["warmup"] == warmup
+    assert rec["unit"] == "frames/s" and rec["value"] > 0 and rec["higher_is_better"] is True
+    assert rec["scaling"] == "weak" and rec["vs_baseline"] is None and rec["dtype"] == "f32" and rec["data"] == "synthetic"
+    assert "workload" in rec["config"] and "model" not in rec["config"]
+    rf = rec["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+
+
+def test_one_gpu_line(torch_cuda):
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "2", "--legs", "cpu", "--cpu-frames", "6"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = _line(p.stdout)
+    _check(rec, 1, 4, 2)
+    assert rec["roofline"]["kernel"] == "frame_pipelined_kernel" and rec["timed_s"] >= 0.3
+    assert abs(rec["value"] - 1e3 * rec["frames_per_step"] / rec["ms_per_step"]) < 0.01 * rec["value"]
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "frames/s" and cb["sample"]
+
+
+def test_two_rank_line_over_the_test_rig(torch_cuda):
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VH_BENCH_BACKEND="gloo", VH_BENCH_SHARE_GPU="1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--legs", "cpu", "--cpu-frames", "6"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    rec = _line(p.stdout)
+    _check(rec, 2, 3, 1)
+    assert rec["config"]["frames_per_step"] == 2 * rec["config"]["frames_per_camera_per_exchange"]
+    assert rec["config"]["key_bin_overflows"] == 0 and rec["config"]["occupied_blocks_all_ranks"] > 0
+    assert abs(rec["value"] - 1e3 * rec["config"]["frames_per_step"] / rec["ms_per_step"]) < 0.01 * rec["value"]
+    assert rec["cpu_baseline"] and rec["cpu_baseline"]["value"] > 0

@@ -576,6 +576,9 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     Wd, Ht = wl["width"], wl["height"]
     nframes = min(args.frames or wl["frames"], 250)
     dev = torch.device("cuda", local_rank)
+    # the few scalars the ranks agree on travel on the backend's own device (gloo: host; the test rig for
+    # several ranks on one GPU)
+    cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
     stream = torch.cuda.Stream(device=dev)
     plan = ShardPlan(wl["buckets"], world)
     # one record per 16 pixels of this camera's image, split over the owners: a wave-deduplicated room
@@ -651,7 +654,7 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             dist.barrier()
             windows.append(time.perf_counter() - t0)
             nxt += args.steps
-            go = torch.tensor([1 if (sum(windows) < 0.3 and len(windows) < 200) else 0], dtype=torch.int32, device=dev)
+            go = torch.tensor([1 if (sum(windows) < 0.3 and len(windows) < 200) else 0], dtype=torch.int32, device=cdev)
             dist.broadcast(go, 0)
             if int(go.item()) == 0:
                 break
@@ -705,15 +708,15 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             kte, ktv = shard.table.kernel_times(reset=True), view.table.kernel_times(reset=True)
             shard.table.set_profiling(False)
             view.table.set_profiling(False)
-    wt = torch.tensor(windows, dtype=torch.float64, device=dev)
+    wt = torch.tensor(windows, dtype=torch.float64, device=cdev)
     dist.all_reduce(wt, op=dist.ReduceOp.MAX)                 # every window: the slowest rank's time
     windows = [float(x) for x in wt.tolist()]
     elapsed = statistics.median(windows)
-    t = torch.tensor([rc_elapsed, rc_fixed_elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([rc_elapsed, rc_fixed_elapsed], dtype=torch.float64, device=cdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     rc_elapsed, rc_fixed_elapsed = float(t[0].item()), float(t[1].item())
     c = shard.table.counters()
-    stats = torch.tensor([c["occupied"], c["allocated_total"], c["bin_overflow"]], dtype=torch.int64, device=dev)
+    stats = torch.tensor([c["occupied"], c["allocated_total"], c["bin_overflow"]], dtype=torch.int64, device=cdev)
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     out = None
     if rank == 0:
