@@ -48,8 +48,9 @@ __device__ __forceinline__ int lookup_block(const FrameParams &fp, const DevPtrs
 // Measured and dropped: adopting the neighbouring cell after a clear single-face
 // exit without evaluating that sample (bit-equal, but the lanes of a wave then sit in different
 // code paths: 47 -> 64 us), fetching a ray's next in-block voxels together, a divide-free voxel index, and the exact
-// division by voxelSize through a hoisted refined reciprocal (div_fixed: 47.3 vs 47.3 us -- the kernel waits on
-// its dependent loads, not on VALU issue).
+// division by voxelSize through a hoisted refined reciprocal (div_fixed: 47.3 vs 47.3 us).  Half-filled waves
+// (32 rays per wave, twice the waves) take 69.7 instead of 47.0 us: the kernel is bound by instruction issue
+// per SIMD about as much as by its load chains, so more waves for the same rays do not pay.
 constexpr float kSkipMargin = 0.01f;     // voxels
 
 // kPatch: pixels of a wave inside the 16x16 tile: 0 = 16x4 rows, 1 = 8x8 square
