@@ -75,11 +75,15 @@ def test_c3_at_its_pool_size(oracle, vh, torch_cuda):
     ot = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
     gt = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
     # --- four frames of the 2000-pose path against the oracle, exact ---
+    # (two as two-launch frames, two as one pipelined batch: the 419 MB table is walked with non-temporal loads)
+    vs = {i: synth.render_room_verts(poses[i], W, H, prims, device="cuda") for i in (0, 1, 2, 40)}
+    for i in (0, 1):
+        gt.integrate(poses[i], vs[i])
+    gt.integrate_batch([poses[2], poses[40]], [vs[2], vs[40]])
     for i in (0, 1, 2, 40):
-        v = synth.render_room_verts(poses[i], W, H, prims, device="cuda")
-        gt.integrate(poses[i], v)
-        ot.integrate_mt(poses[i], v.cpu().numpy(), 8)
+        ot.integrate_mt(poses[i], vs[i].cpu().numpy(), 8)
     gt.synchronize()
+    del vs
     gtab, otab = gt.hash_table(), ot.hash_table()
     assert_slice_equals(gtab, otab, 0, 1 << 22, 5, "C3")
     assert gt.counters()["occupied"] == ot.compact_count()

@@ -21,12 +21,22 @@ def room_frames(torch, W, H, idx, loop=500):
 @pytest.mark.parametrize("sem", [0, 1])
 @pytest.mark.parametrize("chunk", [1, 2, 5])
 def test_batches_equal_oracle_frames(oracle, vh, torch_cuda, sem, chunk):
+    _batches_equal_oracle_frames(oracle, vh, torch_cuda, sem, chunk, 0)
+
+
+def test_batches_with_non_temporal_walk(oracle, vh, torch_cuda):
+    """"walk_nt" (what tables beyond the Infinity Cache get by default) on a small table."""
+    _batches_equal_oracle_frames(oracle, vh, torch_cuda, 1, 2, 1)
+
+
+def _batches_equal_oracle_frames(oracle, vh, torch_cuda, sem, chunk, walk_nt):
     """The sphere scene twice (frame 1 demands keys frame 0 is still inserting), then a moving camera:
     checked after every batch, whatever the batch length."""
     torch = torch_cuda
     kw = dict(numBuckets=1 << 15, numVoxelBlocks=1 << 13)
     ot = oracle.OracleTable(oracle.default_params(**kw), 640, 480, sem)
     gt = vh.SDFHashtable(vh.default_params(**kw), 640, 480, sem)
+    gt.set_option("walk_nt", walk_nt)
     sphere = synth.sphere_inside_scene()
     frames = [(I4, sphere)] * 3 + room_frames(torch, 640, 480, (0, 1, 2, 3, 8, 9, 10))
     for s in range(0, len(frames), chunk):
