@@ -51,6 +51,14 @@ def test_sharded_raycast_equals_oracle_raycast_of_one_table(oracle, vh, torch_cu
             ref = full.raycast(poses[r])
             assert np.array_equal(depths[r].view(np.uint32), ref.view(np.uint32)), (round_, r)
             hits += int((ref > 0).sum())
+            # the block silhouettes of a view table: every cube an in-image ray meets inside the depth range
+            # was selected for the view, so they equal the silhouettes of the one unsharded table
+            front, back = torch.empty((H, W), device="cuda"), torch.empty((H, W), device="cuda")
+            views[r].table.render_blocks(poses[r], front, back, 0.1, 5.0)
+            torch.cuda.synchronize()
+            of, ob = full.render_blocks(poses[r], 0.1, 5.0)
+            assert np.array_equal(front.cpu().numpy().view(np.uint32), of.view(np.uint32)), (round_, r)
+            assert np.array_equal(back.cpu().numpy().view(np.uint32), ob.view(np.uint32)), (round_, r)
         for v in views:
             assert v.table.counters()["bin_overflow"] == 0
     if sem == 1:

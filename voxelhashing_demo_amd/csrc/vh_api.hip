@@ -108,6 +108,7 @@ struct vh_context {
     int32_t *viewLists = nullptr;          // export: selected entry indices, [views][capacity]
     size_t viewListsSize = 0;              // in int32
     int32_t *blockList = nullptr;          // vh_render_blocks: two counter words (4 ints) + the records of the allocated blocks
+    size_t blockCapacity = 0;              // records blockList has room for
     int blockParity = 0;                   // which counter word the next vh_render_blocks appends through
     const Voxel *viewBlocks = nullptr;     // import: the record buffer the view table's ptrs address
     int32_t viewCount = 0;                 // records of the last import (their buckets are listed in compactMask)

@@ -465,10 +465,13 @@ extern "C" int vh_render_blocks(vh_context *c, const float pose[16], float t_min
     // records of the allocated blocks (32 bytes each; a table holds at most numVoxelBlocks of them, a view
     // table one per entry) behind two counter words, allocated on first use (synchronises once)
     const size_t capacity = c->viewBlocks ? c->numEntries : std::min<size_t>(c->numEntries, c->params.numVoxelBlocks);
-    if (!c->blockList) {
+    if (!c->blockList || c->blockCapacity < capacity) {      // (a view context grows from 1 to numEntries at its first import)
         VH_HIP(hipStreamSynchronize(c->stream));
+        if (c->blockList) (void)hipFree(c->blockList);
+        c->blockList = nullptr;
         VH_HIP(hipMalloc((void **)&c->blockList, 16 + sizeof(BlockRecord) * capacity));
         VH_HIP(hipMemsetAsync(c->blockList, 0, 16, c->stream));
+        c->blockCapacity = capacity;
         c->blockParity = 0;
     }
     int32_t *counts = c->blockList;
