@@ -174,3 +174,39 @@ def test_heap_shortage_refuses_whole_frames(oracle, vh, torch_cuda):
     c2 = gt.counters()
     assert len(gt.allocated()) == n0 and c2["heap_exhausted"] == c["heap_exhausted"] + more
     assert entries_as_set(gt.allocated()) == entries_as_set(ot.allocated())
+
+
+@pytest.mark.parametrize("sem", [0, 1])
+def test_ragged_empty_and_hostile_frames_pipelined(oracle, vh, torch_cuda, sem):
+    """One pipelined batch through the awkward inputs of the unpipelined suite: an image that is no multiple
+    of the 16x16 launch tile, an all-invalid frame between real ones (its deferred half has nothing to
+    commit or update), holes, and NaN / inf / huge / denormal vertex components under a non-rigid pose."""
+    torch = torch_cuda
+    W, H = 200, 150
+    kw = dict(numBuckets=1 << 12, numVoxelBlocks=8192)
+    ot = oracle.OracleTable(oracle.default_params(**kw), W, H, sem)
+    gt = vh.SDFHashtable(vh.default_params(**kw), W, H, sem)
+    empty = np.zeros((H, W, 4), np.float32)
+    empty[..., 3] = 1.0
+    holes = synth.sphere_inside_scene(W, H)
+    holes[::7, ::5, 2] = 0.0
+    hostile = synth.sphere_inside_scene(W, H)
+    rng = np.random.RandomState(5)
+    specials = np.array([np.nan, np.inf, -np.inf, 1e-42, -1e-42, 3e38, -3e38, 1e9, -1e9, 4.3e7, -4.3e7, 1e-7, -0.0,
+                         2147483.6, -2147483.6], np.float32)
+    for comp in range(4):
+        ys, xs = rng.randint(0, H, 300), rng.randint(0, W, 300)
+        hostile[ys, xs, comp] = specials[rng.randint(0, len(specials), 300)]
+    pose = np.array([[1.1, 0.05, 0, 0.1], [0, 0.9, 0.1, -0.05], [0.02, 0, 1.0, 0.2], [0, 0, 0, 1]], np.float32)
+    frames = [(I4, empty), (I4, holes), (I4, empty), (I4, empty), (pose, hostile), (I4, holes), (I4, hostile), (I4, empty)]
+    d = [torch.from_numpy(np.ascontiguousarray(v)).cuda() for _, v in frames]
+    gt.integrate_batch([p for p, _ in frames[:5]], d[:5])
+    for p, v in frames[:5]:
+        ot.integrate(p, v)
+    _compare(ot, gt)
+    gt.set_option("pipeline", 1)
+    for (p, v), dv in zip(frames[5:], d[5:]):
+        gt.integrate(p, dv)
+        ot.integrate(p, v)
+    _compare(ot, gt)                      # (reading the model flushes the empty last frame)
+    assert len(gt.allocated()) > 20 and gt.counters()["heap_exhausted"] == 0
