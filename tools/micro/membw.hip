@@ -95,6 +95,34 @@ __global__ __launch_bounds__(256) void read_ldsdma(const char *__restrict__ p, s
     if (acc == 0x12345678u) atomicAdd(out, 1u);
 }
 
+// one-shot forms: a workgroup handles kPer chunks per wave, all issued up front into kPer buffers
+template <int kNt, int kPer>
+__global__ __launch_bounds__(256) void read_ldsdma_oneshot(const char *__restrict__ p, size_t nchunks, unsigned *out)
+{
+    __shared__ __attribute__((aligned(16))) char ring[4][kPer][5120];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned acc = 0;
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+        const size_t c = ((size_t)blockIdx.x * kPer + r) * 4 + wave;
+        if (c < nchunks) {
+            const char *src = p + c * 5120 + lane * 16;
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j * 1024),
+                                                 (__attribute__((address_space(3))) void *)(&ring[wave][r][j * 1024]), 16, 0, kNt ? 2 : 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+        const int *rec = reinterpret_cast<const int *>(&ring[wave][r][0]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc ^= (unsigned)rec[(lane + 64 * j) * 5 + 3];
+    }
+    if (acc == 0x12345678u) atomicAdd(out, 1u);
+}
+
 int main(int argc, char **argv)
 {
     size_t mb = argc > 1 ? atoi(argv[1]) : 419;
@@ -123,6 +151,12 @@ int main(int argc, char **argv)
         { char nm[64]; snprintf(nm, 64, "lds-dma grid %d", g);
           timeit(nm, [&] { read_ldsdma<0><<<dim3(g), 256>>>(d, nchunks, out); }); }
     for (int g : {768, 1024})
+        { char nm[64]; snprintf(nm, 64, "lds-dma nt grid %d", g);
+          timeit(nm, [&] { read_ldsdma<1><<<dim3(g), 256>>>(d, nchunks, out); }); }
+    timeit("lds-dma nt one-shot x1", [&] { read_ldsdma_oneshot<1, 1><<<dim3((nchunks + 3) / 4), 256>>>(d, nchunks, out); });
+    timeit("lds-dma nt one-shot x2", [&] { read_ldsdma_oneshot<1, 2><<<dim3((nchunks + 7) / 8), 256>>>(d, nchunks, out); });
+    timeit("lds-dma    one-shot x2", [&] { read_ldsdma_oneshot<0, 2><<<dim3((nchunks + 7) / 8), 256>>>(d, nchunks, out); });
+    for (int g : {256, 512, 1536})
         { char nm[64]; snprintf(nm, 64, "lds-dma nt grid %d", g);
           timeit(nm, [&] { read_ldsdma<1><<<dim3(g), 256>>>(d, nchunks, out); }); }
     return 0;

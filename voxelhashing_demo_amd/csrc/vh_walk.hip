@@ -22,7 +22,9 @@ namespace vh {
 // chunk (+10 %), a per-lane hit count with one wave scan (+3 %), a "mask" form that stored allocation
 // ballots for a second launch to consume (launch 1 -0.4 us, launch 2 +8.5 us), and an LDS-DMA form
 // (global_load_lds_dwordx4, 5 KiB chunks per wave, ptr and live entries read back from LDS: C3 75.9 vs
-// 69.5 us with non-temporal loads in both, C2 17.7 vs 17.1 us).
+// 69.5 us with non-temporal loads in both, C2 17.7 vs 17.1 us; one chunk per wave and twice the workgroups:
+// C2 18.3 vs 17.0 us fused, 16.1 vs 15.8 us as a launch of its own -- at 15.8 us = 6.6 TB/s the plain walk
+// already reads the 105 MB table as fast as the best form of the ceiling probe).
 constexpr int kFlattenThreads = 256;
 #ifndef VH_ENTRIES_PER_LANE
 #define VH_ENTRIES_PER_LANE 8
