@@ -95,6 +95,7 @@ struct vh_context {
     FrameParams pipeFp;            // that frame's parameters
     int pipeSet = 0;               // counter set its claim / walk filled
     int pipeParity = 0;            // which of the two buffer sets it used
+    int claimSpanPct = 0;         // option "claim_span": share of the stream workgroups the claim tiles are spread over
     int pipeSensor = 0;            // its private depth copy: 0 = float camera-z plane, 1 = uint16 sensor image
     float pipeK[4] = {0, 0, 0, 0}; // K_inv row 2 and the depth unit of a sensor frame
     unsigned long long *claimBuf[2] = {nullptr, nullptr};

@@ -161,6 +161,24 @@ extern "C" int vh_integrate_depth_map(vh_context *c, const vh_float4 *verts)
     return VH_OK;
 }
 
+// How many of the claim + walk workgroups of a launch the claim tiles are spread over.  A claim workgroup is
+// a chain of dependent reads (vertex -> bucket -> claim word) of about 4 us; interleaved uniformly over the
+// whole grid, the ones dispatched last are the tail of the launch.  Ending them early by the share that
+// chain has of the launch (estimated from the table bytes the walk streams at ~6 TB/s) removes the tail;
+// squeezing them further starves the stream (in-process A/B, pipelined frame: C2 21.2 us uniform, 20.0
+// at 75-80 %, 20.9 at 60 %; C2 with band allocation 33.7 -> 30.4; C3, a 78 us launch: flat from 94 to
+// 100 %, +3 % at 85 %).  Option "claim_span": percent, 0 = this rule.
+static uint32_t claim_span(const vh_context *c, uint32_t claimBlocks, uint32_t walkBlocks)
+{
+    const uint32_t total = claimBlocks + walkBlocks;
+    double share = c->claimSpanPct / 100.0;
+    if (c->claimSpanPct == 0) {
+        const double walk_us = (double)c->numEntries * sizeof(VoxelEntry) / 6.0e6;     // bytes / (6 TB/s) in us
+        share = std::min(1.0, std::max(0.7, 1.0 - 4.0 / std::max(walk_us, 1.0)));
+    }
+    return std::min(total, std::max<uint32_t>(claimBlocks, (uint32_t)(share * total)));
+}
+
 // ---------------------------------------------------------------------------
 // pipelined frames (vh_frame.hip: frame_pipelined_kernel)
 // ---------------------------------------------------------------------------
@@ -235,6 +253,7 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     a.setNew = setNew; a.setOld = setOld; a.setClear = (setNew + 1) % 3;
     a.hasNew = hasNew; a.hasOld = hasOld;
     a.order = (uint32_t)c->pipeOrder;
+    a.claimSpan = claim_span(c, a.claimBlocks, a.walkBlocks);
     a.planeNew = (hasNew && !newSensor) ? c->planeBuf[newParity] : nullptr;
     a.rawNew = (hasNew && newSensor) ? c->rawBuf[newParity] : nullptr;
     const DevPtrs dpNew = pipe_view(c, newParity), dpOld = pipe_view(c, oldParity);
@@ -291,7 +310,8 @@ template <int kKind, class In>
 static int launch_scan_claim(vh_context *c, const In &in, uint32_t claimBlocks, uint32_t scanBlocks, float *planeOut)
 {
     return launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kKind, In>, dim3(claimBlocks + scanBlocks),
-                  dim3(256), c->fp, c->dp, in, (uint32_t)c->numEntries, claimBlocks, c->fusedParity, planeOut);
+                  dim3(256), c->fp, c->dp, in, (uint32_t)c->numEntries, claimBlocks, c->fusedParity, planeOut,
+                  claim_span(c, claimBlocks, scanBlocks));
 }
 
 // the packed camera-z plane launch 1 leaves for launch 2 (vertex-map input only)

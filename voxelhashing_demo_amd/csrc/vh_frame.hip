@@ -22,15 +22,19 @@ namespace vh {
 template <int kKind, class In>
 __global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams fp, const DevPtrs dp, const In in,
                                                                uint32_t numEntries, uint32_t claimBlocks,
-                                                               int parity, float *__restrict__ planeOut)
+                                                               int parity, float *__restrict__ planeOut, uint32_t claimSpan)
 {
     // The two roles are interleaved over the grid in proportion (block b is a claim block when
     // floor((b+1)*claim/total) steps): workgroups are dispatched roughly in index order, and
     // with all claim blocks in front a large image would fill the chip with latency-bound
     // pixel work before the first byte of the table is streamed.
+    // The claim tiles end before the grid does (claimSpan < total; vh_api_frame.hip: claim_span): a claim
+    // workgroup is a chain of dependent reads of ~4 us, and one dispatched among the last workgroups of a
+    // 20 us launch is its tail.
     const uint32_t total = gridDim.x;
-    const uint32_t claimBefore = (uint32_t)(((uint64_t)blockIdx.x * claimBlocks) / total);
-    const uint32_t claimAfter = (uint32_t)(((uint64_t)(blockIdx.x + 1u) * claimBlocks) / total);
+    const bool inSpan = blockIdx.x < claimSpan;
+    const uint32_t claimBefore = inSpan ? (uint32_t)(((uint64_t)blockIdx.x * claimBlocks) / claimSpan) : claimBlocks;
+    const uint32_t claimAfter = inSpan ? (uint32_t)(((uint64_t)(blockIdx.x + 1u) * claimBlocks) / claimSpan) : claimBlocks;
     if (claimAfter != claimBefore) {
         // the latency-bound pixel waves issue first when they are ready, so they are off the compute
         // unit sooner (17.9 -> 17.6 us; raising the streaming waves instead cost 0.25 us)
@@ -133,6 +137,7 @@ struct PipeArgs {
     int32_t setNew, setOld, setClear;      // counter sets: filled, consumed, cleared by this launch
     uint32_t hasNew, hasOld;               // first launch of a run: no old frame; flush launch: no new frame
     uint32_t order;                        // where the deferred half sits in the grid (see the role mapping)
+    uint32_t claimSpan;                    // claim tiles are interleaved with the first claimSpan - claimBlocks walk tiles
     float *planeNew;                       // private depth copies written by claim(new) ...
     uint16_t *rawNew;
 };
@@ -167,10 +172,15 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
         if (b < head) {
             if (b < a.commitBlocks) { role = 0; index = b; } else { role = 1; index = b - a.commitBlocks; }
         } else if (b < head + stream) {
+            // the claim tiles are spread over the first a.claimSpan of the stream workgroups (>= claimBlocks)
             const uint32_t r = b - head;
-            const uint32_t before = (uint32_t)(((uint64_t)r * a.claimBlocks) / stream);
-            const uint32_t after = (uint32_t)(((uint64_t)(r + 1u) * a.claimBlocks) / stream);
-            if (after != before) { role = 2; index = before; } else { role = 3; index = r - before; }
+            if (r < a.claimSpan) {
+                const uint32_t before = (uint32_t)(((uint64_t)r * a.claimBlocks) / a.claimSpan);
+                const uint32_t after = (uint32_t)(((uint64_t)(r + 1u) * a.claimBlocks) / a.claimSpan);
+                if (after != before) { role = 2; index = before; } else { role = 3; index = r - before; }
+            } else {
+                role = 3; index = r - a.claimBlocks;
+            }
         } else {
             const uint32_t r = b - head - stream;      // the tail
             if (a.order == 3u && r < a.commitBlocks) { role = 0; index = r; }
