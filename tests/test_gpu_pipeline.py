@@ -210,3 +210,35 @@ def test_ragged_empty_and_hostile_frames_pipelined(oracle, vh, torch_cuda, sem):
         ot.integrate(p, v)
     _compare(ot, gt)                      # (reading the model flushes the empty last frame)
     assert len(gt.allocated()) > 20 and gt.counters()["heap_exhausted"] == 0
+
+
+@pytest.mark.parametrize("pipelined", [0, 1])
+def test_lock_epoch_wrap(oracle, vh, torch_cuda, pipelined):
+    """The claim words carry a 10-bit lock epoch: after 1023 epochs the claim arrays are cleared and the
+    epoch starts over (vh_reset_mutexes).  2 100 frames with collections that empty the model just before,
+    on and after both wraps, so that insertions happen in the epochs around them; pipelined frames have
+    both claim buffers in use when the wrap comes."""
+    torch = torch_cuda
+    W, H = 160, 120
+    kw = dict(numBuckets=1 << 10, numVoxelBlocks=2048)
+    ot = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    gt = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
+    gt.set_option("pipeline", pipelined)
+    frames = room_frames(torch, W, H, (0, 5, 10, 15))
+    dv = [torch.from_numpy(np.ascontiguousarray(v)).cuda() for _, v in frames]
+    collect_at = {1010, 1019, 1021, 1023, 1026, 2040, 2044, 2047, 2050}
+    check_at = {1018, 1024, 1030, 2046, 2052, 2099}
+    inserted_near_wrap = 0
+    for f in range(2100):
+        k = f % 4
+        gt.integrate(frames[k][0], dv[k])
+        ot.integrate(frames[k][0], frames[k][1])
+        if f in collect_at:                                  # (a collection takes a lock epoch of its own)
+            freed = ot.garbage_collect(0.0)
+            gt.garbage_collect(0.0)
+            assert gt.counters()["last_freed"] == freed
+            inserted_near_wrap += freed
+        if f in check_at:
+            _compare(ot, gt)
+    assert inserted_near_wrap > 200
+    _compare(ot, gt)
