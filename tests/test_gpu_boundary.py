@@ -161,3 +161,38 @@ def test_bad_snapshots_leave_the_model_untouched(oracle, vh, torch_cuda, tmp_pat
     from test_gpu_parity import _compare
     _compare(ot, gt)
     gt.close()
+
+
+def test_batch_flush_and_fixed_slot_argument_checks(oracle, vh, torch_cuda):
+    """vh_integrate_batch / vh_integrate_depth_batch / vh_flush / vh_export_views_fixed / vh_import_views:
+    null and out-of-range arguments come back as VH_ERR_INVALID_ARGUMENT (never a crash), an empty batch
+    and a flush with nothing pending are no-ops, and a failed call leaves the model as it was."""
+    import ctypes as C
+    torch = torch_cuda
+    L = vh.load()
+    gt = vh.SDFHashtable(vh.default_params(**KW), 640, 480, 1)
+    ot = oracle.OracleTable(oracle.default_params(**KW), 640, 480, 1)
+    verts = synth.sphere_inside_scene()
+    d = torch.from_numpy(verts).cuda()
+    h = gt._h
+    pose = (C.c_float * 16)(*I4.reshape(-1))
+    ptrs = (C.c_void_p * 1)(d.data_ptr())
+    bad = 1                                                            # VH_ERR_INVALID_ARGUMENT (voxelhash.h)
+    for rc in (L.vh_integrate_batch(None, 1, pose, ptrs, None), L.vh_integrate_batch(h, -1, pose, ptrs, None),
+               L.vh_integrate_batch(h, 1, None, ptrs, None), L.vh_integrate_batch(h, 1, pose, None, None),
+               L.vh_integrate_depth_batch(h, 1, pose, None, None), L.vh_flush(None),
+               L.vh_export_views_fixed(h, None, 1, 0.1, 5.0, None, 16, None),
+               L.vh_export_views_fixed(h, d.data_ptr(), 0, 0.1, 5.0, d.data_ptr(), 16, d.data_ptr()),
+               L.vh_export_views_fixed(h, d.data_ptr(), 17, 0.1, 5.0, d.data_ptr(), 16, d.data_ptr()),
+               L.vh_export_views_fixed(h, d.data_ptr(), 1, 5.0, 0.1, d.data_ptr(), 16, d.data_ptr()),
+               L.vh_import_views(h, None, 1, 16, None), L.vh_import_views(h, d.data_ptr(), 0, 16, None),
+               L.vh_import_views(h, d.data_ptr(), 1, 0, None)):
+        assert rc == bad, rc
+    assert L.vh_integrate_batch(h, 0, None, None, None) == 0          # an empty batch
+    assert L.vh_flush(h) == 0                                          # nothing pending
+    assert gt.counters()["allocated_total"] == 0 and gt.counters()["epoch"] == 0
+    gt.integrate_batch([I4, I4], [d, d])
+    ot.integrate(I4, verts)
+    ot.integrate(I4, verts)
+    assert entries_as_set(gt.allocated()) == entries_as_set(ot.allocated()) and len(gt.allocated()) == 179
+    gt.close()
