@@ -44,7 +44,31 @@ int main(int argc, char **argv)
     hipMemcpy(depth.data(), d_depth, n * sizeof(float), hipMemcpyDeviceToHost);
     int hits = 0;
     for (float z : depth) hits += z > 0.0f;
-    std::printf("occupied=%d allocated=%d hits=%d\n", occupied, allocated, hits);
+    // a second table through the batch / pipeline / silhouette members (SDF_Hashtable.h): two frames as one
+    // batch, a third as a streaming pipelined frame left pending until flush(), then the block silhouettes
+    int allocated2 = 0, covered = 0;
+    {
+        SDF_Hashtable t2;
+        float poses[32];
+        for (int k = 0; k < 2; ++k)
+            for (int i = 0; i < 16; ++i) poses[16 * k + i] = (i % 5 == 0) ? 1.0f : 0.0f;
+        const vh_float4 *ptrs[2] = {d_verts, d_verts};
+        t2.integrateBatch(2, poses, ptrs, nullptr);
+        t2.setOption("pipeline", 1);
+        t2.integrate(pose, d_verts, (const vh_float4 *)nullptr);
+        t2.flush();
+        if (vh_download(t2.context(), VH_BUF_HASH_TABLE, entries.data(), entries.size() * sizeof(VoxelEntry)) != VH_OK)
+            return 6;
+        for (const VoxelEntry &e : entries) allocated2 += e.ptr != VH_FREE_BLOCK;
+        float *d_back = nullptr;
+        if (hipMalloc((void **)&d_back, n * sizeof(float)) != hipSuccess) return 4;
+        t2.renderBlocks(pose, d_depth, d_back);
+        vh_synchronize(t2.context());
+        hipMemcpy(depth.data(), d_depth, n * sizeof(float), hipMemcpyDeviceToHost);
+        for (float z : depth) covered += z > 0.0f;
+        hipFree(d_back);
+    }
+    std::printf("occupied=%d allocated=%d hits=%d allocated2=%d covered=%d\n", occupied, allocated, hits, allocated2, covered);
     hipFree(d_verts);
     hipFree(d_depth);
     return 0;

@@ -31,6 +31,10 @@ def test_cpp_facade_program(oracle, vh, torch_cuda, tmp_path):
     assert got["allocated"] == len(ot.allocated()) > 50
     assert got["occupied"] == len(ot.compact())
     assert got["hits"] == int((ot.raycast(I4) > 0).sum())
+    # the second table: integrateBatch + a pipelined frame + flush, then renderBlocks
+    ot.integrate(I4, verts)
+    assert got["allocated2"] == len(ot.allocated())
+    assert got["covered"] == int((ot.render_blocks(I4)[0] > 0).sum()) > 1000
 
 
 def test_cpp_tracking_program(oracle, vh, torch_cuda, tmp_path):
