@@ -329,9 +329,11 @@ struct BandWalk {
 __device__ __forceinline__ SampleKey sample_key(const FrameParams &fp, const PixelVertex &p, BandWalk &walk, int k,
                                                 int &ownX, int &ownY, int &ownZ, bool &ownHave)
 {
+    // The frustum test (:673) is a function of the key alone, so it runs after the dedup, on the few lanes
+    // that survive it (a key that fails has no leader either way): per wave one or two evaluations instead
+    // of 64 per sample.
     SampleKey r{0, 0, 0, false};
-    bool want = walk.key(fp, p, k, r.kx, r.ky, r.kz);
-    if (want) want = block_in_frustum(fp, r.kx, r.ky, r.kz);             // :673
+    const bool want = walk.key(fp, p, k, r.kx, r.ky, r.kz);
     const bool dupOwn = want && ownHave && ownX == r.kx && ownY == r.ky && ownZ == r.kz;
     if (want) { ownX = r.kx; ownY = r.ky; ownZ = r.kz; ownHave = true; }
     const int lane = threadIdx.x & (kWave - 1);
@@ -341,8 +343,11 @@ __device__ __forceinline__ SampleKey sample_key(const FrameParams &fp, const Pix
     const bool dupLeft = (lane & 15) != 0 && ((wants >> (lane - 1)) & 1ull) && lx == r.kx && ly == r.ky && lz == r.kz;
     const bool dupUp = lane >= 16 && ((wants >> (lane - 16)) & 1ull) && ux == r.kx && uy == r.ky && uz == r.kz;
     r.leader = want && !dupOwn && !dupLeft && !dupUp;
+    if (r.leader) r.leader = block_in_frustum(fp, r.kx, r.ky, r.kz);     // :673
     return r;
 }
+
+constexpr int kClaimQueue = 128;          // keys a wave queues before it probes them (band allocation)
 
 __device__ __forceinline__ uint32_t sample_rank(const PixelVertex &p, int k)
 {
@@ -360,13 +365,54 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
     walk.init(fp, p);
     int ox = 0, oy = 0, oz = 0;
     bool oh = false;
+    if (walk.nS == 1 && !walk.dda) {
+        // the reference's frame: one key per pixel, probed at once
+        const SampleKey s = sample_key(fp, p, walk, 0, ox, oy, oz, oh);
+        if (!s.leader) return;
+        const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
+        if (h < fp.bucketLo || h >= fp.bucketHi) return;                // not this shard's bucket
+        probe_and_claim(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, 0), candCounter, pend);
+        return;
+    }
+    // Band allocation: a pixel demands several keys.  Probing inside the sample loop puts one chain of
+    // dependent bucket reads behind the other (5 samples: 5 round trips per wave); instead the wave queues
+    // the keys that survive the dedup in LDS and probes them 64 at a time, one per lane, so the reads of a
+    // whole queue are in flight together.  Who wins a bucket is decided by the ranks in the claim words, not
+    // by the order of the probes.
+    __shared__ int4 queues[256 / kWave][kClaimQueue];
+    volatile int4 *queue = queues[threadIdx.x / kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    auto drain = [&](int count) {
+        for (int base = 0; base < count; base += kWave) {
+            if (base + lane < count) {
+                const int kx = queue[base + lane].x, ky = queue[base + lane].y, kz = queue[base + lane].z;
+                const uint32_t rank = (uint32_t)queue[base + lane].w;
+                probe_and_claim(fp, dp, kx, ky, kz, hash_block(kx, ky, kz, fp.numBuckets), rank, candCounter, pend);
+            }
+        }
+    };
+    int count = 0;                                                       // (wave-uniform)
     for (int k = 0; !walk.wave_done(k); ++k) {
         const SampleKey s = sample_key(fp, p, walk, k, ox, oy, oz, oh);
-        if (!s.leader) continue;
-        const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
-        if (h < fp.bucketLo || h >= fp.bucketHi) continue;              // not this shard's bucket
-        probe_and_claim(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, k), candCounter, pend);
+        bool take = s.leader;
+        if (take) {
+            const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
+            take = h >= fp.bucketLo && h < fp.bucketHi;                  // this shard's bucket
+        }
+        const unsigned long long mask = __ballot(take);
+        if (mask == 0ull) continue;
+        const int n = __popcll(mask);
+        if (count + n > kClaimQueue) {
+            drain(count);
+            count = 0;
+        }
+        if (take) {
+            const int at = count + __popcll(mask & ((1ull << lane) - 1ull));
+            queue[at].x = s.kx; queue[at].y = s.ky; queue[at].z = s.kz; queue[at].w = (int)sample_rank(p, k);
+        }
+        count += n;
     }
+    drain(count);
 }
 
 template <class In>
