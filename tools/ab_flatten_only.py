@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="C3")
-    ap.add_argument("--values", type=int, nargs="+", default=[1, 2, 3, 4])
+    ap.add_argument("--values", type=int, nargs="+", default=[3, 4, 5])
     ap.add_argument("--frames", type=int, default=40)
     a = ap.parse_args()
     import torch
