@@ -251,7 +251,7 @@ int vh_integrate_depth(vh_context *ctx, const float pose[16], const uint16_t *d_
  * the unpipelined calls.  Results equal the unpipelined frames bit for bit, with one documented
  * difference: a frame whose new blocks outnumber the free blocks of the heap allocates none of them
  * (they count as heap_exhausted and retry), where vh_integrate serves as many as there are blocks.
- * Not combined with "overflow_list", bucketSize > 8 or a flatten_variant other than 3: those frames run
+ * Not combined with "overflow_list", bucketSize > 8 or the persistent walk (flatten_variant 5): those frames run
  * unpipelined.  vh_integrate_batch / vh_integrate_depth_batch: `count` frames (poses: count*16 host
  * floats; d_verts / d_normals / d_depth: host arrays of `count` device pointers, d_normals may be NULL)
  * in count + 1 launches -- the pipeline switched on for the call and flushed at its end. */

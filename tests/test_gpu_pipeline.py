@@ -29,7 +29,14 @@ def test_batches_with_non_temporal_walk(oracle, vh, torch_cuda):
     _batches_equal_oracle_frames(oracle, vh, torch_cuda, 1, 2, 1)
 
 
-def _batches_equal_oracle_frames(oracle, vh, torch_cuda, sem, chunk, walk_nt):
+@pytest.mark.parametrize("chunk", [1, 3])
+def test_batches_with_the_occupancy_index_walk(oracle, vh, torch_cuda, chunk):
+    """flatten_variant 4 under pipelining: the walk over the bucket-occupancy bitmap skips the slot the
+    concurrent commit phase is filling, like the walk over the entries does."""
+    _batches_equal_oracle_frames(oracle, vh, torch_cuda, 1, chunk, 0, walk=4)
+
+
+def _batches_equal_oracle_frames(oracle, vh, torch_cuda, sem, chunk, walk_nt, walk=3):
     """The sphere scene twice (frame 1 demands keys frame 0 is still inserting), then a moving camera:
     checked after every batch, whatever the batch length."""
     torch = torch_cuda
@@ -37,6 +44,7 @@ def _batches_equal_oracle_frames(oracle, vh, torch_cuda, sem, chunk, walk_nt):
     ot = oracle.OracleTable(oracle.default_params(**kw), 640, 480, sem)
     gt = vh.SDFHashtable(vh.default_params(**kw), 640, 480, sem)
     gt.set_option("walk_nt", walk_nt)
+    gt.set_option("flatten_variant", walk)
     sphere = synth.sphere_inside_scene()
     frames = [(I4, sphere)] * 3 + room_frames(torch, 640, 480, (0, 1, 2, 3, 8, 9, 10))
     for s in range(0, len(frames), chunk):

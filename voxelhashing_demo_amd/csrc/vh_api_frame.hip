@@ -228,7 +228,8 @@ static DevPtrs pipe_view(const vh_context *c, int parity)
 // can this context run its frames pipelined right now?
 static bool pipeline_applies(const vh_context *c)
 {
-    return c->pipeline && c->fusedFrame && c->flattenVariant == kWalkStridedBallot && !(c->fp.flags & kFlagOverflow) &&
+    return c->pipeline && c->fusedFrame && (c->flattenVariant == kWalkStridedBallot || c->flattenVariant == kWalkIndexed) &&
+           !(c->fp.flags & kFlagOverflow) &&
            c->fp.bucketSize <= 8u && !c->viewBlocks;
 }
 
@@ -246,7 +247,8 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     const int setOld = c->pipeSet, setNew = (setOld + 1) % 3;
     PipeArgs a;
     a.claimBlocks = hasNew ? host_num_tiles(c) : 0u;
-    a.walkBlocks = hasNew ? (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane) : 0u;
+    a.walkBlocks = hasNew ? walk_blocks(c) : 0u;
+    a.walkIndexed = c->flattenVariant == kWalkIndexed ? 1u : 0u;
     a.commitBlocks = hasOld ? (uint32_t)c->commitBlocks : 0u;
     a.integrateBlocks = hasOld ? (uint32_t)c->pipeIntegrateGrid : 0u;
     a.numEntries = (uint32_t)c->numEntries;

@@ -137,6 +137,7 @@ struct PipeArgs {
     int32_t setNew, setOld, setClear;      // counter sets: filled, consumed, cleared by this launch
     uint32_t hasNew, hasOld;               // first launch of a run: no old frame; flush launch: no new frame
     uint32_t order;                        // where the deferred half sits in the grid (see the role mapping)
+    uint32_t walkIndexed;                  // flatten_variant 4: the walk role runs over the bucket-occupancy bitmap
     uint32_t claimSpan;                    // claim tiles are interleaved with the first claimSpan - claimBlocks walk tiles
     float *planeNew;                       // private depth copies written by claim(new) ...
     uint16_t *rawNew;
@@ -197,6 +198,8 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
         if (role == 2u) {
             __builtin_amdgcn_s_setprio(3);
             claim_tile(fpNew, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
+        } else if (a.walkIndexed) {
+            flatten_index_tile(fpNew, dpNew, index, kPipeScan + a.setNew, pend);   // (opt-in: not the reference's walk)
         } else {
             flatten_tile_ballot(fpNew, dpNew, a.numEntries, index, kPipeScan + a.setNew, pend);
         }

@@ -148,8 +148,12 @@ __device__ __forceinline__ void flatten_tiles_persistent(const FrameParams &fp, 
 // walk the bucket-occupancy bitmap (1 bit per bucket, maintained by the commit phase) and read
 // only the buckets that hold entries.  One lane per 32-bucket word; the compact SET is the
 // same, the bytes moved are numBuckets/8 + 100 per non-empty bucket instead of 20*N.
+// pend (pipelined frames): a bucket's slot that the concurrent commit phase is filling is not looked at
+// (nothing is allocated behind it: it is the bucket's first free slot) -- that entry is appended by the
+// commit phase itself; whether this walk already sees the bucket's occupancy bit or not makes no difference
+// (a bucket whose bit is still clear held nothing before).
 __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
-                                                   int counter)
+                                                   int counter, const Pending &pend = kNoPending)
 {
     const uint32_t owned = fp.bucketHi - fp.bucketLo;
     const uint32_t numWords = (owned + 31u) / 32u;
@@ -162,9 +166,15 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
         if (have) bits &= bits - 1u;
         bool more = have;                   // entries form a prefix of the bucket (not with the overflow list: holes)
         const bool holes = (fp.flags & kFlagOverflow) != 0u;
+        uint32_t inFlight = ~0u;            // slot of this bucket the concurrent commit phase writes
+        if (have && pend.claim && pend.live) {
+            const unsigned long long cw = pend.claim[bucket];
+            if (claim_epoch(cw) == pend.epoch) inFlight = claim_f(cw);
+        }
         for (uint32_t s = 0; s < fp.bucketSize; ++s) {
             VoxelEntry ent;
             bool hit = false;
+            if (s == inFlight) more = false;
             if (more) {
                 ent = dp.table[(size_t)bucket * fp.bucketSize + s];
                 const bool live = ent.ptr != VH_FREE_BLOCK;
