@@ -449,8 +449,9 @@ def main():
         extra["occupancy_index_variant"] = dict(
             window_stats(t_idx, args.steps, it.batch), unit="frames/s",
             flatten_bytes=wl["buckets"] // 8 + 100 * main_rec["allocated_blocks"],
-            note="vh_set_option(flatten_variant=4): walk over the bucket-occupancy bitmap (numBuckets/8 bytes) + "
-                 "the non-empty buckets instead of the 20*N-byte table walk")
+            note="vh_set_option(flatten_variant=4), pipelined like the headline path: walk over the bucket-occupancy "
+                 "bitmap (numBuckets/8 bytes) + the non-empty buckets instead of the 20*N-byte table walk; NOT the "
+                 "reference's flattenKernel, hence not `value`")
 
     # ---- the same frames straight from uint16 sensor depth (vh_integrate_depth: preProcess's vertex
     # computation inside the claim phase, no vertex map in memory), against the two-call form
