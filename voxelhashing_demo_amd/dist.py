@@ -581,10 +581,14 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
     stream = torch.cuda.Stream(device=dev)
     plan = ShardPlan(wl["buckets"], world)
-    # one record per 16 pixels of this camera's image, split over the owners: a wave-deduplicated room
-    # frame produces ~1 key per 700 pixels, so this is a ~40-fold margin (more with band allocation);
-    # the bins travel at full capacity, overflow is counted and reported
-    capacity = max(2048, -(-Wd * Ht // (16 * world)))
+    # Records per (camera, owner) key bin: one per 16 pixels, whatever the number of owners.  A
+    # wave-deduplicated 640x480 room frame yields up to ~9 400 keys, and bucket-range ownership is skewed --
+    # a camera facing a wall demands blocks whose hashes fall into few bucket ranges: with 8 owners a bin of
+    # 4 800 records (twice the fullest bin of a sampled probe) still overflowed in the full run -- so a bin
+    # must hold a whole frame's keys.  The bins travel at full capacity (19.7 MB per rank and exchange of
+    # 8 frames at 8 ranks, half of what the depth packets weigh); a key that finds its bin full is counted
+    # (key_bin_overflows) and demanded again by the next frame.
+    capacity = max(2048, -(-Wd * Ht // 16))
     poses = synth.camera_loop(wl.get("loop", wl["frames"]), phase=camera_phase(rank, world))[:nframes]
     prims = synth.room_primitives()
     verts = torch.empty((nframes, Ht, Wd, 4), dtype=torch.float32, device=dev)
