@@ -48,19 +48,20 @@ def test_one_gpu_line(torch_cuda):
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "frames/s" and cb["sample"]
 
 
-def test_two_rank_line_over_the_test_rig(torch_cuda):
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_multi_rank_line_over_the_test_rig(torch_cuda, ranks):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, VH_BENCH_BACKEND="gloo", VH_BENCH_SHARE_GPU="1")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3",
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", str(ranks), "--steps", "3",
                         "--warmup", "1", "--legs", "cpu", "--cpu-frames", "6"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
     rec = _line(p.stdout)
-    _check(rec, 2, 3, 1)
-    assert rec["config"]["frames_per_step"] == 2 * rec["config"]["frames_per_camera_per_exchange"]
+    _check(rec, ranks, 3, 1)
+    assert rec["config"]["frames_per_step"] == ranks * rec["config"]["frames_per_camera_per_exchange"]
     assert rec["config"]["key_bin_overflows"] == 0 and rec["config"]["occupied_blocks_all_ranks"] > 0
     assert abs(rec["value"] - 1e3 * rec["config"]["frames_per_step"] / rec["ms_per_step"]) < 0.01 * rec["value"]
     assert rec["cpu_baseline"] and rec["cpu_baseline"]["value"] > 0
