@@ -89,7 +89,7 @@ static uint32_t walk_blocks(const vh_context *c)
     if (c->flattenVariant == kWalkPersistent)    // resident workgroups striding over the tiles
         return std::min<uint32_t>((uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane),
                                   (uint32_t)c->persistentBlocks);
-    return (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
+    return (uint32_t)grid_for(c->numEntries, kFlattenThreads * ((c->fp.flags & kFlagWalkShort) ? kEntriesPerLaneShort : kEntriesPerLane));
 }
 
 static int launch_flatten(vh_context *c)

@@ -388,6 +388,10 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
         return VH_OK;
     }
     if (std::strcmp(name, "claim_span") == 0 && value >= 0 && value <= 100) { c->claimSpanPct = value; return VH_OK; }
+    if (std::strcmp(name, "walk_entries") == 0 && (value == kEntriesPerLaneShort || value == kEntriesPerLane)) {
+        c->fp.flags = value == kEntriesPerLaneShort ? (c->fp.flags | kFlagWalkShort) : (c->fp.flags & ~kFlagWalkShort);
+        return VH_OK;
+    }
     if (std::strcmp(name, "pipe_integrate_grid") == 0 && value > 0) { c->pipeIntegrateGrid = value; return VH_OK; }
     if (std::strcmp(name, "pipeline") == 0) {
         c->pipeline = value != 0;

@@ -51,21 +51,22 @@ __device__ __forceinline__ int reserve_compact_slots(const DevPtrs &dp, int coun
 }
 
 // strided walk with one ballot + atomic per unrolled entry slot (hits are rare on small scenes)
+template <int kN>
 __device__ __forceinline__ void walk_load_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
-                                               uint32_t tileIndex, int32_t (&ptrs)[kEntriesPerLane])
+                                               uint32_t tileIndex, int32_t (&ptrs)[kN])
 {
-    const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
+    const uint32_t tile = tileIndex * (kFlattenThreads * kN);
     const int32_t *words = reinterpret_cast<const int32_t *>(dp.table);
     if (fp.flags & kFlagWalkNt) {
 #pragma unroll
-        for (int j = 0; j < kEntriesPerLane; ++j) {
+        for (int j = 0; j < kN; ++j) {
             const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
             ptrs[j] = (e < numEntries) ? __builtin_nontemporal_load(words + (size_t)e * kEntryDwords + 3) : VH_FREE_BLOCK;
         }
         return;
     }
 #pragma unroll
-    for (int j = 0; j < kEntriesPerLane; ++j) {
+    for (int j = 0; j < kN; ++j) {
         const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
         ptrs[j] = (e < numEntries) ? words[(size_t)e * kEntryDwords + 3] : VH_FREE_BLOCK;
     }
@@ -74,18 +75,19 @@ __device__ __forceinline__ void walk_load_tile(const FrameParams &fp, const DevP
 // pend (pipelined frames only): the frame whose commit phase runs concurrently.  The entry it is
 // inserting into a bucket (slot f of the bucket's claim word of that epoch) may or may not be visible
 // yet; it is skipped here whatever the walk sees, and appended by that commit phase itself.
+template <int kN>
 __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
-                                                  const int32_t (&ptrs)[kEntriesPerLane], int counter,
+                                                  const int32_t (&ptrs)[kN], int counter,
                                                   const Pending &pend = kNoPending)
 {
-    const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
+    const uint32_t tile = tileIndex * (kFlattenThreads * kN);
     bool any = false;
 #pragma unroll
-    for (int j = 0; j < kEntriesPerLane; ++j) any |= (ptrs[j] != VH_FREE_BLOCK);
+    for (int j = 0; j < kN; ++j) any |= (ptrs[j] != VH_FREE_BLOCK);
     if (__ballot(any) == 0ull) return;
     const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll
-    for (int j = 0; j < kEntriesPerLane; ++j) {
+    for (int j = 0; j < kN; ++j) {
         bool hit = false;
         VoxelEntry ent;
         if (ptrs[j] != VH_FREE_BLOCK) {
@@ -111,12 +113,24 @@ __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const D
     }
 }
 
+// Entries per lane: 8, or 4 for tables beyond the Infinity Cache (kFlagWalkShort, set at creation, option
+// "walk_entries"): with the loads non-temporal, twice the workgroups with half the loads each stream a
+// 419 MB table 2-4 % faster (C3 pipelined launch: 77.2 vs 80.1 us; 6 per lane 78.5, 2 per lane 98.5, 16 per
+// lane 81.1 against 77.4 on another box); a resident table (C2) prefers 8 (20.6 vs 20.9 us).
+template <int kN>
+__device__ __forceinline__ void flatten_tile_ballot_n(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
+                                                      uint32_t tileIndex, int counter, const Pending &pend)
+{
+    int32_t ptrs[kN];
+    walk_load_tile(fp, dp, numEntries, tileIndex, ptrs);
+    walk_process_tile(fp, dp, tileIndex, ptrs, counter, pend);
+}
+constexpr int kEntriesPerLaneShort = 4;
 __device__ __forceinline__ void flatten_tile_ballot(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
                                                     uint32_t tileIndex, int counter, const Pending &pend = kNoPending)
 {
-    int32_t ptrs[kEntriesPerLane];
-    walk_load_tile(fp, dp, numEntries, tileIndex, ptrs);
-    walk_process_tile(fp, dp, tileIndex, ptrs, counter, pend);
+    if (fp.flags & kFlagWalkShort) flatten_tile_ballot_n<kEntriesPerLaneShort>(fp, dp, numEntries, tileIndex, counter, pend);
+    else flatten_tile_ballot_n<kEntriesPerLane>(fp, dp, numEntries, tileIndex, counter, pend);
 }
 
 // Persistent form of the same walk for tables far larger than the Infinity Cache: a workgroup
