@@ -92,16 +92,16 @@ __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const D
         VoxelEntry ent;
         if (ptrs[j] != VH_FREE_BLOCK) {
             const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
+            // the entry and the claim word of its bucket are fetched together (one round trip); what the read
+            // of a slot that is being written returns is not looked at
+            ent = dp.table[e];
             bool inFlight = false;
             if (pend.claim && pend.live) {
                 const uint32_t b = e / fp.bucketSize;
                 const unsigned long long w = pend.claim[b];
                 inFlight = claim_epoch(w) == pend.epoch && claim_f(w) == e - b * fp.bucketSize;
             }
-            if (!inFlight) {
-                ent = dp.table[e];
-                hit = block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);   // VoxelUtils.cu:732
-            }
+            if (!inFlight) hit = block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);   // VoxelUtils.cu:732
         }
         const unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;
