@@ -174,7 +174,12 @@ static uint32_t claim_span(const vh_context *c, uint32_t claimBlocks, uint32_t w
     double share = c->claimSpanPct / 100.0;
     if (c->claimSpanPct == 0) {
         const double walk_us = (double)c->numEntries * sizeof(VoxelEntry) / 6.0e6;     // bytes / (6 TB/s) in us
-        share = std::min(1.0, std::max(0.7, 1.0 - 4.0 / std::max(walk_us, 1.0)));
+        // with band allocation a pixel demands several keys: ~2 us more per sample (C2, 5 samples: 31.1 us at
+        // 80 %, 30.4 at 70 %)
+        double chain_us = 4.0;
+        if (c->fp.allocBand > 0.0f)
+            chain_us += 2.0 * std::min(8.0, 2.0 * std::ceil((double)c->fp.allocBand / (4.0 * c->fp.voxelSize)));
+        share = std::min(1.0, std::max(0.7, 1.0 - chain_us / std::max(walk_us, 1.0)));
     }
     return std::min(total, std::max<uint32_t>(claimBlocks, (uint32_t)(share * total)));
 }
