@@ -86,3 +86,41 @@ def test_c3_full_size_properties(oracle, vh, torch_cuda):
     steps = np.cumsum(np.full(64, np.float32(0.1), np.float32), dtype=np.float32)
     assert np.isin(w[w > 0], steps).all()
     assert np.isfinite(vol["sdf"]).all() and float(np.abs(vol["sdf"]).max()) <= 1.0
+
+
+def test_c2_snapshot_round_trip_and_resume(vh, torch_cuda, tmp_path):
+    """C2-size model (2^20 buckets, 2^18 blocks): save -> load into a second context -> both continue with
+    the same frames (one of them pipelined, with a collection in between): tables, free lists and every
+    allocated block stay identical.  A round trip and a resume, GPU against GPU."""
+    torch = torch_cuda
+    kw = dict(numBuckets=1 << 20, numVoxelBlocks=1 << 18)
+    a = vh.SDFHashtable(vh.default_params(**kw), 640, 480, 1)
+    frames = [(p, torch.from_numpy(v).cuda()) for p, v in _frames(640, 480, tuple(range(0, 60, 3)))]
+    for pose, dv in frames[:12]:
+        a.integrate(pose, dv)
+    path = tmp_path / "c2.snap"
+    a.save_snapshot(path)
+    b = vh.SDFHashtable(vh.default_params(**kw), 640, 480, 1)
+    b.load_snapshot(path)
+    ta, tb = a.hash_table(), b.hash_table()
+    assert np.array_equal(ta, tb) and (ta["ptr"] != -1).sum() > 400          # the round trip: ptr included
+    b.set_option("pipeline", 1)
+    for t in (a, b):
+        for pose, dv in frames[12:16]:
+            t.integrate(pose, dv)
+        t.garbage_collect(0.5)
+        for pose, dv in frames[16:]:
+            t.integrate(pose, dv)
+        t.synchronize()
+    ta, tb = a.hash_table(), b.hash_table()
+    assert np.array_equal(ta["pos"], tb["pos"]) and np.array_equal(ta["ptr"] != -1, tb["ptr"] != -1)
+    ca, cb = a.counters(), b.counters()
+    for k in ("occupied", "allocated_total", "freed_total", "heap_counter", "heap_exhausted"):
+        assert ca[k] == cb[k], k
+    pa = {tuple(e["pos"]): int(e["ptr"]) for e in ta[ta["ptr"] != -1]}
+    pb = {tuple(e["pos"]): int(e["ptr"]) for e in tb[tb["ptr"] != -1]}
+    for key in list(pa)[::9]:
+        va, vb = a.block_voxels(pa[key]), b.block_voxels(pb[key])
+        assert np.array_equal(va["sdf"].view(np.uint32), vb["sdf"].view(np.uint32)) and np.array_equal(va["weight"], vb["weight"])
+    a.close()
+    b.close()
