@@ -159,6 +159,11 @@ def main():
             d = t.raycast(I4, 0.1, 5.0)
             out["raycast_inside_pin_f2/sha"] = np.frombuffer(hashlib.sha256(d.tobytes()).digest(), np.uint8)
             out["raycast_inside_pin_f2/row240"] = d[240].view(np.uint32)
+            front, back = t.render_blocks(I4, 0.1, 5.0)            # block silhouettes (row R1) of the same model
+            out["silhouettes_inside_pin_f2/sha"] = np.frombuffer(
+                hashlib.sha256(front.tobytes() + back.tobytes()).digest(), np.uint8)
+            out["silhouettes_inside_pin_f2/front_row240"] = front[240].view(np.uint32)
+            out["silhouettes_inside_pin_f2/back_row240"] = back[240].view(np.uint32)
         t.close()
     np.savez_compressed(os.path.join(HERE, "scenes.npz"), **out)
     print("wrote", os.path.getsize(os.path.join(HERE, "scenes.npz")), "bytes")

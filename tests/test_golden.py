@@ -66,6 +66,9 @@ def test_oracle_reproduces_scene(oracle, name):
         d = t.raycast(np.eye(4, dtype=np.float32), 0.1, 5.0)
         assert np.array_equal(np.frombuffer(hashlib.sha256(d.tobytes()).digest(), np.uint8),
                               SCENES["raycast_inside_pin_f2/sha"])
+        front, back = t.render_blocks(np.eye(4, dtype=np.float32), 0.1, 5.0)
+        assert np.array_equal(np.frombuffer(hashlib.sha256(front.tobytes() + back.tobytes()).digest(), np.uint8),
+                              SCENES["silhouettes_inside_pin_f2/sha"])
     t.close()
 
 
@@ -89,4 +92,13 @@ def test_hip_reproduces_scene(vh, torch_cuda, name):
         t.raycast(np.eye(4, dtype=np.float32), d, 0.1, 5.0)
         t.synchronize()
         assert np.array_equal(d.cpu().numpy()[240].view(np.uint32), SCENES["raycast_inside_pin_f2/row240"])
+        import hashlib
+        front, back = torch.empty((480, 640), device="cuda"), torch.empty((480, 640), device="cuda")
+        t.render_blocks(np.eye(4, dtype=np.float32), front, back, 0.1, 5.0)
+        t.synchronize()
+        f, b = front.cpu().numpy(), back.cpu().numpy()
+        assert np.array_equal(f[240].view(np.uint32), SCENES["silhouettes_inside_pin_f2/front_row240"])
+        assert np.array_equal(b[240].view(np.uint32), SCENES["silhouettes_inside_pin_f2/back_row240"])
+        assert np.array_equal(np.frombuffer(hashlib.sha256(f.tobytes() + b.tobytes()).digest(), np.uint8),
+                              SCENES["silhouettes_inside_pin_f2/sha"])
     t.close()
