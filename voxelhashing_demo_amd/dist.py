@@ -647,13 +647,14 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
         drain()
         # windows of exactly K steps, each bracketed by a barrier + synchronisation on both sides, repeated
         # until ~0.3 s have been timed (every rank takes the same number: the decision is rank 0's)
-        windows, nxt = [], args.warmup
+        windows, nxt, host_enqueue = [], args.warmup, []
         while True:
             dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(args.steps):
                 step(nxt + i)
+            host_enqueue.append(time.perf_counter() - t0)     # (the host's share: enqueueing without waiting)
             drain()                  # every fed step has been applied when the clock stops
             dist.barrier()
             windows.append(time.perf_counter() - t0)
@@ -756,6 +757,7 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             ms_per_step=round(1e3 * elapsed / args.steps, 5), higher_is_better=True, scaling="weak",
             vs_baseline=None, dtype="f32", data="synthetic",
             windows=len(windows), timed_s=round(sum(windows), 4),
+            host_enqueue_ms_per_step=round(1e3 * statistics.median(host_enqueue) / args.steps, 5),
             config=dict(workload=f"{'C5' if wl_name == 'C5' else 'C4-style'}: {world} virtual {Wd}x{Ht} cameras (one per GPU) into one scene, "
                                  f"2^{int(math.log2(wl['buckets']))} buckets sharded by bucket range over {world} GPUs, "
                                  "RCCL all-to-all of block keys + all-gather of depth packets per step, PINHOLE; "
