@@ -89,7 +89,6 @@ struct vh_context {
     // pipelined frames (option "pipeline", vh_integrate_batch; vh_frame.hip)
     float *fusedPlane = nullptr;   // packed camera-z plane launch 1 of the two-launch frame leaves for launch 2 (large images)
     int pipeline = 0;
-    int pipeOrder = 0;             // role order inside a pipelined launch (0, 3, 4: vh_frame.hip)
     int pipeIntegrateGrid = 512;   // workgroups of the deferred TSDF update inside a pipelined launch (4 blocks each per pass)
     bool pipePending = false;      // the commit + TSDF update of the last frame are still to be launched
     FrameParams pipeFp;            // that frame's parameters

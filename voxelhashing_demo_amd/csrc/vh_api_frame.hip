@@ -181,7 +181,15 @@ static uint32_t claim_span(const vh_context *c, uint32_t claimBlocks, uint32_t w
             chain_us += 2.0 * std::min(8.0, 2.0 * std::ceil((double)c->fp.allocBand / (4.0 * c->fp.voxelSize)));
         share = std::min(1.0, std::max(0.7, 1.0 - chain_us / std::max(walk_us, 1.0)));
     }
-    return std::min(total, std::max<uint32_t>(claimBlocks, (uint32_t)(share * total)));
+    // (strictly more workgroups than claim tiles whenever there is a walk: claim_ratio below must stay < 2^32)
+    return std::min(total, std::max<uint32_t>(claimBlocks + (walkBlocks ? 1u : 0u), (uint32_t)(share * total)));
+}
+
+// ceil(claimBlocks * 2^32 / span): floor(r * ratio / 2^32) steps from 0 to claimBlocks in unit steps over r = 0 .. span
+static uint32_t claim_ratio(uint32_t claimBlocks, uint32_t span)
+{
+    if (span == 0 || claimBlocks >= span) return 0xffffffffu;       // (no walk workgroups: every workgroup claims; see callers)
+    return (uint32_t)((((uint64_t)claimBlocks << 32) + span - 1) / span);
 }
 
 // ---------------------------------------------------------------------------
@@ -259,8 +267,8 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     a.numEntries = (uint32_t)c->numEntries;
     a.setNew = setNew; a.setOld = setOld; a.setClear = (setNew + 1) % 3;
     a.hasNew = hasNew; a.hasOld = hasOld;
-    a.order = (uint32_t)c->pipeOrder;
     a.claimSpan = claim_span(c, a.claimBlocks, a.walkBlocks);
+    a.claimRatio = claim_ratio(a.claimBlocks, a.claimSpan);
     a.planeNew = (hasNew && !newSensor) ? c->planeBuf[newParity] : nullptr;
     a.rawNew = (hasNew && newSensor) ? c->rawBuf[newParity] : nullptr;
     const DevPtrs dpNew = pipe_view(c, newParity), dpOld = pipe_view(c, oldParity);
@@ -318,7 +326,7 @@ static int launch_scan_claim(vh_context *c, const In &in, uint32_t claimBlocks, 
 {
     return launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kKind, In>, dim3(claimBlocks + scanBlocks),
                   dim3(256), c->fp, c->dp, in, (uint32_t)c->numEntries, claimBlocks, c->fusedParity, planeOut,
-                  claim_span(c, claimBlocks, scanBlocks));
+                  claim_span(c, claimBlocks, scanBlocks), claim_ratio(claimBlocks, claim_span(c, claimBlocks, scanBlocks)));
 }
 
 // the packed camera-z plane launch 1 leaves for launch 2 (vertex-map input only)

@@ -382,7 +382,6 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
         c->flattenVariant = value;
         return VH_OK;
     }
-    if (std::strcmp(name, "pipe_order") == 0 && (value == 0 || value == 3 || value == 4)) { c->pipeOrder = value; return VH_OK; }
     if (std::strcmp(name, "walk_nt") == 0) {
         c->fp.flags = value ? (c->fp.flags | kFlagWalkNt) : (c->fp.flags & ~kFlagWalkNt);
         return VH_OK;

@@ -356,7 +356,8 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
         rc = launch(c, kPhaseFrameScanClaim, frame_multi_scan_claim_kernel,
                     dim3((uint32_t)num_bins * parts + scanBlocks), dim3(256), c->fp, c->dp, bins, capacity, bin_stride,
                     (uint32_t)num_bins, parts, (uint32_t)c->numEntries, num_cams, packets, packet_stride,
-                    c->fusedParity, claim_span(c, (uint32_t)num_bins * parts, scanBlocks));
+                    c->fusedParity, claim_span(c, (uint32_t)num_bins * parts, scanBlocks),
+                    claim_ratio((uint32_t)num_bins * parts, claim_span(c, (uint32_t)num_bins * parts, scanBlocks)));
         if (rc == VH_OK)
             rc = c->packetFormat == VH_PACKET_U16
                      ? launch(c, kPhaseFrameCommitIntegrate, frame_multi_commit_integrate_kernel<true>,

@@ -22,7 +22,8 @@ namespace vh {
 template <int kKind, class In>
 __global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams fp, const DevPtrs dp, const In in,
                                                                uint32_t numEntries, uint32_t claimBlocks,
-                                                               int parity, float *__restrict__ planeOut, uint32_t claimSpan)
+                                                               int parity, float *__restrict__ planeOut, uint32_t claimSpan,
+                                                               uint32_t claimRatio)
 {
     // The two roles are interleaved over the grid in proportion (block b is a claim block when
     // floor((b+1)*claim/total) steps): workgroups are dispatched roughly in index order, and
@@ -31,10 +32,13 @@ __global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams
     // The claim tiles end before the grid does (claimSpan < total; vh_api_frame.hip: claim_span): a claim
     // workgroup is a chain of dependent reads of ~4 us, and one dispatched among the last workgroups of a
     // 20 us launch is its tail.
+    // (claim_index: the claim tiles 0 .. claimBlocks-1 spread evenly over workgroups 0 .. claimSpan-1 by a
+    // multiply-high with claimRatio = ceil(claimBlocks * 2^32 / claimSpan) -- the host's numbers; a 64-bit
+    // division per workgroup here cost the launch 2 us)
     const uint32_t total = gridDim.x;
     const bool inSpan = blockIdx.x < claimSpan;
-    const uint32_t claimBefore = inSpan ? (uint32_t)(((uint64_t)blockIdx.x * claimBlocks) / claimSpan) : claimBlocks;
-    const uint32_t claimAfter = inSpan ? (uint32_t)(((uint64_t)(blockIdx.x + 1u) * claimBlocks) / claimSpan) : claimBlocks;
+    const uint32_t claimBefore = inSpan ? __umulhi(blockIdx.x, claimRatio) : claimBlocks;
+    const uint32_t claimAfter = inSpan ? __umulhi(blockIdx.x + 1u, claimRatio) : claimBlocks;
     if (claimAfter != claimBefore) {
         // the latency-bound pixel waves issue first when they are ready, so they are off the compute
         // unit sooner (17.9 -> 17.6 us; raising the streaming waves instead cost 0.25 us)
@@ -136,9 +140,8 @@ struct PipeArgs {
     uint32_t numEntries;
     int32_t setNew, setOld, setClear;      // counter sets: filled, consumed, cleared by this launch
     uint32_t hasNew, hasOld;               // first launch of a run: no old frame; flush launch: no new frame
-    uint32_t order;                        // where the deferred half sits in the grid (see the role mapping)
     uint32_t walkIndexed;                  // flatten_variant 4: the walk role runs over the bucket-occupancy bitmap
-    uint32_t claimSpan;                    // claim tiles are interleaved with the first claimSpan - claimBlocks walk tiles
+    uint32_t claimSpan, claimRatio;        // claim tiles are interleaved with the first claimSpan - claimBlocks walk tiles
     float *planeNew;                       // private depth copies written by claim(new) ...
     uint16_t *rawNew;
 };
@@ -156,36 +159,28 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
     const int demandedOld = a.hasOld ? counters[kPipeCand + a.setOld] : 0;
     const int candOld = min(demandedOld, (int)dpOld.candCapacity);
     const bool live = a.hasOld && counters[kPipeHeapFree + a.setOld] >= counters[kPipeWinners + a.setOld];
-    // Roles by workgroup index (a.order 0): [commit][integrate][claim and walk interleaved as in
+    // Roles by workgroup index: [commit][integrate][claim and walk interleaved as in
     // frame_scan_claim_kernel]: frame i's deferred half runs first, at full width, then the table streams.
     // In-process A/B on C2 / C3 (launch time, us): this order with 512 integrate workgroups 18.8 / 88.9; with
     // 2048 of them (mostly idle, but dispatched before the first walk tile) 19.7 / 91.9; integrate and claim
     // workgroups interleaved among the walk tiles 20.5 / 93.7 (the latency-bound block updates then hold the
     // slots the stream needs); all claim tiles before the walk 20.4 / 93.0; the deferred half at the END of
-    // the grid, where the walk drains (a.order 3; 4 = commit first, integrate last) 21.5 / 105.9 against
-    // 21.0 / 94.6 for order 0 on that (slower) box.  Option "pipe_order" keeps 0, 3 and 4 selectable.
+    // the grid, where the walk drains (or commit first, integrate last) 21.5 / 105.9 against 21.0 / 94.6 for
+    // this order on that box.  (Those orders were selectable at run time for a while; the run-time mapping
+    // with its 64-bit divisions per workgroup cost every launch 2 us and is gone.)
     const uint32_t b = blockIdx.x;
     uint32_t role, index;                          // 0 commit, 1 integrate, 2 claim, 3 walk
-    {
-        // a.order 0: [commit][integrate][claim/walk]   3: [claim/walk][commit][integrate]   4: [commit][claim/walk][integrate]
-        const uint32_t stream = a.claimBlocks + a.walkBlocks;
-        const uint32_t head = a.order == 0u ? a.commitBlocks + a.integrateBlocks : a.order == 4u ? a.commitBlocks : 0u;
-        if (b < head) {
-            if (b < a.commitBlocks) { role = 0; index = b; } else { role = 1; index = b - a.commitBlocks; }
-        } else if (b < head + stream) {
-            // the claim tiles are spread over the first a.claimSpan of the stream workgroups (>= claimBlocks)
-            const uint32_t r = b - head;
-            if (r < a.claimSpan) {
-                const uint32_t before = (uint32_t)(((uint64_t)r * a.claimBlocks) / a.claimSpan);
-                const uint32_t after = (uint32_t)(((uint64_t)(r + 1u) * a.claimBlocks) / a.claimSpan);
-                if (after != before) { role = 2; index = before; } else { role = 3; index = r - before; }
-            } else {
-                role = 3; index = r - a.claimBlocks;
-            }
+    if (b < a.commitBlocks) { role = 0; index = b; }
+    else if (b < a.commitBlocks + a.integrateBlocks) { role = 1; index = b - a.commitBlocks; }
+    else {
+        // the claim tiles are spread over the first a.claimSpan of the claim + walk workgroups (multiply-high
+        // by a.claimRatio = ceil(claimBlocks * 2^32 / claimSpan): no division in the kernel)
+        const uint32_t r = b - a.commitBlocks - a.integrateBlocks;
+        if (r < a.claimSpan) {
+            const uint32_t before = __umulhi(r, a.claimRatio), after = __umulhi(r + 1u, a.claimRatio);
+            if (after != before) { role = 2; index = before; } else { role = 3; index = r - before; }
         } else {
-            const uint32_t r = b - head - stream;      // the tail
-            if (a.order == 3u && r < a.commitBlocks) { role = 0; index = r; }
-            else { role = 1; index = a.order == 3u ? r - a.commitBlocks : r; }
+            role = 3; index = r - a.claimBlocks;
         }
     }
     // first launch of a run (no frame in flight): nobody pops the heap during it, so its first workgroup

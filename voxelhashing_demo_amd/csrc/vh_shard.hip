@@ -141,13 +141,13 @@ __global__ __launch_bounds__(256) void frame_multi_scan_claim_kernel(const Frame
                                                                      int32_t numCams,
                                                                      const float *__restrict__ packets,
                                                                      size_t packetStride, int parity,
-                                                                     uint32_t claimSpan)
+                                                                     uint32_t claimSpan, uint32_t claimRatio)
 {
     // (claim workgroups spread over the first claimSpan workgroups of the grid, as in frame_scan_claim_kernel)
     const uint32_t claimBlocks = numBins * partsPerBin;
     const bool inSpan = blockIdx.x < claimSpan;
-    const uint32_t claimBefore = inSpan ? (uint32_t)(((uint64_t)blockIdx.x * claimBlocks) / claimSpan) : claimBlocks;
-    const uint32_t claimAfter = inSpan ? (uint32_t)(((uint64_t)(blockIdx.x + 1u) * claimBlocks) / claimSpan) : claimBlocks;
+    const uint32_t claimBefore = inSpan ? __umulhi(blockIdx.x, claimRatio) : claimBlocks;
+    const uint32_t claimAfter = inSpan ? __umulhi(blockIdx.x + 1u, claimRatio) : claimBlocks;
     if (claimAfter != claimBefore)
         claim_bin_slice(fp, dp, bins, capacity, binStride, claimBefore / partsPerBin, claimBefore % partsPerBin,
                         partsPerBin, kFusedCand + parity);
