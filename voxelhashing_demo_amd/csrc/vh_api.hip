@@ -329,7 +329,8 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     // at 7.0 instead of 6.0 TB/s that way (tools/micro/membw.hip) and the voxel blocks stay cached across
     // frames (C3: launch 1 76.2 -> 70.2 us, launch 2 13.5 -> 11.7 us); a resident table (C2, 105 MB) loses
     // 2 % with them.  Option "walk_nt" overrides.
-    if (c->numEntries * sizeof(VoxelEntry) > ((size_t)256 << 20)) fp.flags |= kFlagWalkNt | kFlagWalkShort;
+    if (c->numEntries * sizeof(VoxelEntry) > ((size_t)256 << 20)) fp.flags |= kFlagWalkNt;
+    fp.flags |= kFlagWalkShort;          // 4 entries per lane in the frame's walk (option "walk_entries": 4 | 8)
     const size_t npix = (size_t)cfg->width * cfg->height;
     DevPtrs &dp = c->dp;
     dp = DevPtrs{};

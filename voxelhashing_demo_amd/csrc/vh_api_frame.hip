@@ -165,21 +165,21 @@ extern "C" int vh_integrate_depth_map(vh_context *c, const vh_float4 *verts)
 // a chain of dependent reads (vertex -> bucket -> claim word) of about 4 us; interleaved uniformly over the
 // whole grid, the ones dispatched last are the tail of the launch.  Ending them early by the share that
 // chain has of the launch (estimated from the table bytes the walk streams at ~6 TB/s) removes the tail;
-// squeezing them further starves the stream (in-process A/B, pipelined frame: C2 21.2 us uniform, 20.0
-// at 75-80 %, 20.9 at 60 %; C2 with band allocation 33.7 -> 30.4; C3, a 78 us launch: flat from 94 to
-// 100 %, +3 % at 85 %).  Option "claim_span": percent, 0 = this rule.
+// squeezing them further starves the stream.  In-process A/B of the pipelined launch (4 entries per lane in
+// the walk): C2 19.5 us uniform, 18.6 by this rule (77 %), 18.9 at 65 % or 85 %; C2 with band allocation (a
+// claim tile then runs ~12 us) 29.0 uniform, 26.2 at 70 %, 24.3 at 50 %, 24.6 at 40 %, 26.6 at 30 %; C3, a
+// 72 us launch: 72.5 uniform, 72.2 by the rule (94 %).  Option "claim_span": percent, 0 = this rule.
 static uint32_t claim_span(const vh_context *c, uint32_t claimBlocks, uint32_t walkBlocks)
 {
     const uint32_t total = claimBlocks + walkBlocks;
     double share = c->claimSpanPct / 100.0;
     if (c->claimSpanPct == 0) {
         const double walk_us = (double)c->numEntries * sizeof(VoxelEntry) / 6.0e6;     // bytes / (6 TB/s) in us
-        // with band allocation a pixel demands several keys: ~2 us more per sample (C2, 5 samples: 31.1 us at
-        // 80 %, 30.4 at 70 %)
+        // with band allocation a pixel demands several keys: ~2 us more per sample
         double chain_us = 4.0;
         if (c->fp.allocBand > 0.0f)
             chain_us += 2.0 * std::min(8.0, 2.0 * std::ceil((double)c->fp.allocBand / (4.0 * c->fp.voxelSize)));
-        share = std::min(1.0, std::max(0.7, 1.0 - chain_us / std::max(walk_us, 1.0)));
+        share = std::min(1.0, std::max(0.5, 1.0 - chain_us / std::max(walk_us, 1.0)));
     }
     // (strictly more workgroups than claim tiles whenever there is a walk: claim_ratio below must stay < 2^32)
     return std::min(total, std::max<uint32_t>(claimBlocks + (walkBlocks ? 1u : 0u), (uint32_t)(share * total)));

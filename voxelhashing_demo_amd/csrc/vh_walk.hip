@@ -113,10 +113,11 @@ __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const D
     }
 }
 
-// Entries per lane: 8, or 4 for tables beyond the Infinity Cache (kFlagWalkShort, set at creation, option
-// "walk_entries"): with the loads non-temporal, twice the workgroups with half the loads each stream a
-// 419 MB table 2-4 % faster (C3 pipelined launch: 77.2 vs 80.1 us; 6 per lane 78.5, 2 per lane 98.5, 16 per
-// lane 81.1 against 77.4 on another box); a resident table (C2) prefers 8 (20.6 vs 20.9 us).
+// Entries per lane of the frame's walk: 4 (kFlagWalkShort, set at creation; option "walk_entries" 4 | 8).
+// Twice the workgroups with half the loads each stream faster than 8 per lane once a workgroup costs
+// nothing before its first load (in-process, pipelined launch: C2 18.8 vs 19.4 us, C3 72.3 vs 75.4;
+// 3 per lane 18.8 / 75.1, 6 per lane 19.1 / 74.7, 2 per lane 19.5 / 79.6).  The multi-camera walk of the
+// sharded path and the view selection keep 8 (16.4 vs 16.5-16.9 us with 4).
 template <int kN>
 __device__ __forceinline__ void flatten_tile_ballot_n(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
                                                       uint32_t tileIndex, int counter, const Pending &pend)
