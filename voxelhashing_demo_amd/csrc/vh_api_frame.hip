@@ -265,7 +265,7 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     a.commitBlocks = hasOld ? (uint32_t)c->commitBlocks : 0u;
     a.integrateBlocks = hasOld ? (uint32_t)c->pipeIntegrateGrid : 0u;
     a.numEntries = (uint32_t)c->numEntries;
-    a.setNew = setNew; a.setOld = setOld; a.setClear = (setNew + 1) % 3;
+    a.setNew = kPipeSetStride * setNew; a.setOld = kPipeSetStride * setOld; a.setClear = kPipeSetStride * ((setNew + 1) % 3);
     a.hasNew = hasNew; a.hasOld = hasOld;
     a.claimSpan = claim_span(c, a.claimBlocks, a.walkBlocks);
     a.claimRatio = claim_ratio(a.claimBlocks, a.claimSpan);

@@ -43,13 +43,18 @@ enum Counter : int {
     kCandOverflow = 18,    // contenders dropped because the candidate list was full (never cleared)
     // pipelined frames (vh_integrate_batch): three rotating sets -- the launch of frame i+1 fills set
     // (i+1)%3 (claim / walk), consumes set i%3 (commit / integrate of frame i) and clears set (i+2)%3
-    kPipeScan = 20,        // [3]
-    kPipeNew = 23,         // [3]
-    kPipeCand = 26,        // [3]
-    kPipeHeapFree = 29,    // [3] free blocks on the heap when the launch that consumes the set began (written by the
-                           //     last commit workgroup of the launch before, into the set the next launch consumes)
-    kPipeWinners = 32,     // [3] buckets claimed in the frame = entries its commit phase will insert
-    kNumCounters = 36
+    // Each set has a 128-byte line of its own (kPipeSetStride ints apart; the host hands the kernel set * stride):
+    // the words of the set a launch only READS (every workgroup looks at the old frame's candidate count,
+    // free-block count and winner count) then do not share a cache line with the words the same launch
+    // increments atomically.
+    kPipeScan = 64,
+    kPipeNew = 65,
+    kPipeCand = 66,
+    kPipeHeapFree = 67,    // free blocks on the heap when the launch that consumes the set began (written by the
+                           // last commit workgroup of the launch before, into the set the next launch consumes)
+    kPipeWinners = 68,     // buckets claimed in the frame = entries its commit phase will insert
+    kPipeSetStride = 32,
+    kNumCounters = 64 + 3 * 32
 };
 
 // Everything a kernel needs about the frame, passed by value in the kernel
