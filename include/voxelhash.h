@@ -276,6 +276,11 @@ int vh_raycast(vh_context *ctx, const float pose[16], float t_min, float t_max,
 int vh_render_blocks(vh_context *ctx, const float pose[16], float t_min, float t_max, float *d_front,
                      float *d_back);
 
+/* The compact table (d_compactifiedHashTable, VH_BUF_COMPACT) as the reference leaves it -- `occupied` dense
+ * entries from index 0 -- is what vh_download, vh_get_device_pointers, vh_flush and vh_synchronize hand over:
+ * inside a fused frame the list is kept with two ends (two counters instead of one hot word) and these calls
+ * fold it first.  A raw pointer obtained earlier is good for the dense list after the next vh_flush /
+ * vh_synchronize. */
 int vh_synchronize(vh_context *ctx);
 int vh_get_counters(vh_context *ctx, vh_counters *out);              /* synchronises */
 int vh_get_params(vh_context *ctx, HashTableParams *out);

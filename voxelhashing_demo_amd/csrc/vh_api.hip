@@ -109,6 +109,7 @@ struct vh_context {
     size_t viewListsSize = 0;              // in int32
     int32_t *blockList = nullptr;          // vh_render_blocks: two counter words (4 ints) + the records of the allocated blocks
     size_t blockCapacity = 0;              // records blockList has room for
+    int foldA = -1, foldB = -1, foldNew = -1;   // counters of the last frame's two-ended compact list while it is unfolded (foldA < 0: dense)
     int blockParity = 0;                   // which counter word the next vh_render_blocks appends through
     const Voxel *viewBlocks = nullptr;     // import: the record buffer the view table's ptrs address
     int32_t viewCount = 0;                 // records of the last import (their buckets are listed in compactMask)
@@ -234,6 +235,7 @@ static void default_projection(vh_context *c)
 }
 
 static int flush_pending(vh_context *c);       // vh_api_frame.hip: launches a pipelined frame's deferred half
+static int settle(vh_context *c);              // ... and folds a two-ended compact list into the dense one (observers)
 
 static int free_buffers(vh_context *c)
 {

@@ -137,6 +137,7 @@ extern "C" int vh_flatten(vh_context *c, int32_t *occupied_out)
         VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));   // :760
     c->compactArmed = false;
     c->occupiedCounter = kCompactCount;
+    c->foldA = -1;                                   // (the step kernel writes one dense list)
     int rc = launch_flatten(c);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
@@ -154,7 +155,7 @@ extern "C" int vh_integrate_depth_map(vh_context *c, const vh_float4 *verts)
 {
     if (!c || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(c->device);
-    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
+    { const int frc = settle(c); if (frc != VH_OK) return frc; }
     int rc = launch_integrate(c, vertex_depth(reinterpret_cast<const float4 *>(verts)));
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
@@ -285,6 +286,7 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
                     c->pipeFp, dpOld, d, a);
     }
     if (rc != VH_OK) return rc;
+    if (hasOld) { c->foldA = kPipeScan + a.setOld; c->foldB = kPipeScanB + a.setOld; c->foldNew = kPipeNew + a.setOld; }
     if (hasNew) {
         c->pipePending = true;
         c->pipeFp = c->fp;
@@ -312,11 +314,26 @@ static int flush_pending(vh_context *c)
     return VH_OK;
 }
 
+// For whoever looks at the compact list from outside a frame (download, device pointers, the step-level TSDF
+// update, collection, an explicit flush or synchronisation): the pending half first, then end B of the
+// two-ended list (vh_walk.hip: CompactOut) behind end A -- the reference's dense list [0, occupied).
+static int settle(vh_context *c)
+{
+    int rc = flush_pending(c);
+    if (rc != VH_OK || c->foldA < 0) return rc;
+    rc = launch(c, kPhaseFlatten, compact_fold_kernel, dim3(64), dim3(256), c->dp, (uint32_t)c->numEntries, c->foldA, c->foldB,
+                c->foldNew);
+    c->foldA = -1;
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
 extern "C" int vh_flush(vh_context *c)
 {
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     DeviceGuard guard(c->device);
-    return flush_pending(c);
+    return settle(c);
 }
 
 // One frame (pose and lock epoch already set): In = where the claim phase reads a pixel's vertex,
@@ -380,10 +397,12 @@ static int run_frame(vh_context *c, const In &in, const Depth &depth)
                     dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, plane_depth(depth, plane),
                     commitBlocks, c->fusedParity);
         if (rc != VH_OK) return rc;
+        c->foldA = kScanCount + c->fusedParity; c->foldB = kScanCountB + c->fusedParity; c->foldNew = kNewCount + c->fusedParity;
         c->fusedParity ^= 1;       // this frame cleared the other counter set for the next one
         c->compactArmed = false;
     } else {
         // alloc_commit re-arms the compact counter, so no memset node is needed here
+        c->foldA = -1;
         if ((rc = launch_alloc(c, in)) != VH_OK) return rc;
         c->compactArmed = false;
         if ((rc = launch_flatten(c)) != VH_OK) return rc;

@@ -29,7 +29,7 @@ extern "C" int vh_delete_blocks(vh_context *c, const int32_t *d_keys, int32_t n)
     if (!c || (!d_keys && n > 0) || n < 0) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table owns no blocks");
     DeviceGuard guard(c->device);
-    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
+    { const int frc = settle(c); if (frc != VH_OK) return frc; }
     {   // the sweep list is built under a fresh lock epoch (with the wrap handling of the frame's epochs)
         const int rc = vh_reset_mutexes(c);
         if (rc != VH_OK) return rc;
@@ -47,7 +47,7 @@ extern "C" int vh_garbage_collect(vh_context *c, float sdf_threshold)
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table owns no blocks");
     DeviceGuard guard(c->device);
-    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
+    { const int frc = settle(c); if (frc != VH_OK) return frc; }
     {
         const int rc = vh_reset_mutexes(c);
         if (rc != VH_OK) return rc;
@@ -65,7 +65,7 @@ extern "C" int vh_synchronize(vh_context *c)
 {
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     DeviceGuard guard(c->device);
-    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
+    { const int frc = settle(c); if (frc != VH_OK) return frc; }
     VH_HIP(hipStreamSynchronize(c->stream));
     return VH_OK;
 }
@@ -102,6 +102,7 @@ extern "C" int vh_get_params(vh_context *c, HashTableParams *out)
 extern "C" int vh_get_device_pointers(vh_context *c, PtrContainer *out)
 {
     if (!c || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    { DeviceGuard guard(c->device); const int frc = settle(c); if (frc != VH_OK) return frc; }   // the dense compact list
     out->d_heap = c->dp.heap;
     out->d_hashTable = c->dp.table;
     out->d_compactifiedHashTable = c->dp.compact;
@@ -131,7 +132,7 @@ static int download_range(vh_context *c, int which, size_t offset, void *dst, si
     }
     if (offset > avail || bytes > avail - offset) return fail(VH_ERR_INVALID_ARGUMENT, "download past the end of the buffer");
     DeviceGuard guard(c->device);
-    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
+    { const int frc = settle(c); if (frc != VH_OK) return frc; }
     VH_HIP(hipMemcpyAsync(dst, src + offset, bytes, hipMemcpyDeviceToHost, c->stream));
     VH_HIP(hipStreamSynchronize(c->stream));
     return VH_OK;
@@ -263,6 +264,7 @@ static hipError_t reset_model(vh_context *c)
     c->pipePending = false;
     c->compactArmed = false;
     c->occupiedCounter = kCompactCount;
+    c->foldA = -1;
     if (e == hipSuccess && c->claimBuf[1])
         e = hipMemset(c->claimBuf[1 - (c->dp.claim == c->claimBuf[1] ? 1 : 0)], 0, sizeof(unsigned long long) * (size_t)c->ownedBuckets);
     return e;

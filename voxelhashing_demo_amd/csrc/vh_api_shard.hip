@@ -370,6 +370,7 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
         c->fusedParity ^= 1;
         c->compactArmed = false;
         c->occupiedCounter = kCompactCount;
+        c->foldA = -1;
         if (c->profiling) c->profiledFrames += 1;
     }
     VH_HIP(hipGetLastError());
@@ -413,6 +414,7 @@ extern "C" int vh_integrate_packets(vh_context *c, int32_t num_cams, const float
         VH_HIP(hipMemsetAsync(c->dp.counters + kCompactCount, 0, sizeof(int32_t), c->stream));
     c->compactArmed = false;
     c->occupiedCounter = kCompactCount;
+    c->foldA = -1;
     int rc = launch(c, kPhaseFlatten, flatten_multi_kernel,
                     dim3(grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane)), dim3(kFlattenThreads), c->fp,
                     c->dp, (uint32_t)c->numEntries, num_cams, d_packets, stride);

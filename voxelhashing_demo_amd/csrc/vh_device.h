@@ -32,7 +32,8 @@ enum Counter : int {
     // fused frame: per-frame counters, double-buffered by epoch parity so that no workgroup
     // has to wait for all others before they can be re-armed (frame f's second launch
     // clears the set frame f+1 will use)
-    kScanCount = 8,        // [2] entries found by the table walk
+    kScanCount = 8,        // [2] entries found by the table walk: list A, growing up from compact[0]
+    kScanCountB = 40,      // [2] ... list B, growing down from the last compact entry (its own cache line, see CompactOut)
     kNewCount = 10,        // [2] entries inserted (and appended) by the commit phase
     kFusedCand = 12,       // [2] contenders recorded by the claim phase
     // deletion / garbage collection (vh_gc.hip)
@@ -54,7 +55,8 @@ enum Counter : int {
                            // last commit workgroup of the launch before, into the set the next launch consumes)
     kPipeWinners = 68,     // buckets claimed in the frame = entries its commit phase will insert
     kPipeSetStride = 32,
-    kNumCounters = 64 + 3 * 32
+    kPipeScanB = 64 + 3 * 32,   // list B of the set (a second line per set, kPipeSetStride apart like the first)
+    kNumCounters = 64 + 6 * 32
 };
 
 // Everything a kernel needs about the frame, passed by value in the kernel

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams
         __builtin_amdgcn_s_setprio(3);
         claim_tile(fp, dp, in, claimBefore, kFusedCand + parity, kNoPending, planeOut);
     } else {
-        flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x - claimBefore, kScanCount + parity, total - claimBlocks);
+        flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x - claimBefore,
+                            CompactOut{kScanCount + parity, kScanCountB + parity, numEntries}, total - claimBlocks);
     }
 }
 
@@ -60,9 +61,11 @@ template <class Depth>
 __device__ __forceinline__ void frame_commit_integrate(const FrameParams &fp, const DevPtrs &dp, const Depth &verts,
                                                        uint32_t commitBlocks, int parity)
 {
-    const int scanCount = dp.counters[kScanCount + parity];
+    const int scanCount = dp.counters[kScanCount + parity];          // end A of the list; end B:
+    const int scanCountB = dp.counters[kScanCountB + parity];
     if (blockIdx.x >= commitBlocks) {
-        integrate_list(fp, dp, dp.compact, scanCount, (int)(blockIdx.x - commitBlocks), (int)(gridDim.x - commitBlocks), verts);
+        integrate_list(fp, dp, dp.compact, scanCount, (int)(blockIdx.x - commitBlocks), (int)(gridDim.x - commitBlocks), verts,
+                       scanCountB, owned_entries(fp));
         return;
     }
     __shared__ VoxelEntry newEntry;
@@ -91,9 +94,10 @@ __device__ __forceinline__ void frame_commit_integrate(const FrameParams &fp, co
         __threadfence();
         const int ticket = atomicAdd(dp.counters + kCommitTicket, 1);
         if (ticket == workers - 1) {
-            dp.counters[kCompactCount] = scanCount + atomicAdd(dp.counters + kNewCount + parity, 0);
+            dp.counters[kCompactCount] = scanCount + scanCountB + atomicAdd(dp.counters + kNewCount + parity, 0);
             dp.counters[kLastCandidates] = demanded;
             dp.counters[kScanCount + (parity ^ 1)] = 0;
+            dp.counters[kScanCountB + (parity ^ 1)] = 0;
             dp.counters[kNewCount + (parity ^ 1)] = 0;
             dp.counters[kFusedCand + (parity ^ 1)] = 0;
             dp.counters[kCommitTicket] = 0;
@@ -194,9 +198,11 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
             __builtin_amdgcn_s_setprio(3);
             claim_tile(fpNew, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
         } else if (a.walkIndexed) {
-            flatten_index_tile(fpNew, dpNew, index, kPipeScan + a.setNew, pend);   // (opt-in: not the reference's walk)
+            flatten_index_tile(fpNew, dpNew, index, CompactOut{kPipeScan + a.setNew, kPipeScanB + a.setNew, a.numEntries},
+                               pend);                                              // (opt-in: not the reference's walk)
         } else {
-            flatten_tile_ballot(fpNew, dpNew, a.numEntries, index, kPipeScan + a.setNew, pend);
+            flatten_tile_ballot(fpNew, dpNew, a.numEntries, index,
+                                CompactOut{kPipeScan + a.setNew, kPipeScanB + a.setNew, a.numEntries}, pend);
         }
         return;
     }
@@ -204,7 +210,8 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
     const int scanOld = counters[kPipeScan + a.setOld];
     if (role == 1u) {
         // ---- frame i: TSDF update of the blocks its walk (and commit(i-1)) listed ----
-        integrate_list(fpOld, dpOld, dpOld.compact, scanOld, (int)index, (int)a.integrateBlocks, depthOld);
+        integrate_list(fpOld, dpOld, dpOld.compact, scanOld, (int)index, (int)a.integrateBlocks, depthOld,
+                       counters[kPipeScanB + a.setOld], a.numEntries);
         return;
     }
     // ---- frame i: commit ----
@@ -240,14 +247,16 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
         __threadfence();
         const int ticket = atomicAdd(counters + kCommitTicket, 1);
         if (ticket == workers - 1) {
-            counters[kCompactCount] = scanOld + atomicAdd(counters + kPipeNew + a.setOld, 0);
+            counters[kCompactCount] = scanOld + counters[kPipeScanB + a.setOld] + atomicAdd(counters + kPipeNew + a.setOld, 0);
             counters[kLastCandidates] = demandedOld;
             counters[kPipeScan + a.setClear] = 0;
+            counters[kPipeScanB + a.setClear] = 0;
             counters[kPipeNew + a.setClear] = 0;
             counters[kPipeCand + a.setClear] = 0;
             counters[kPipeWinners + a.setClear] = 0;
             if (!a.hasNew) {                       // flush launch: the set a new frame would have filled is unused: the next
                 counters[kPipeScan + a.setNew] = 0;    // run starts on it (the host keeps rotating), and finds it empty
+                counters[kPipeScanB + a.setNew] = 0;
                 counters[kPipeNew + a.setNew] = 0;
                 counters[kPipeCand + a.setNew] = 0;
                 counters[kPipeWinners + a.setNew] = 0;

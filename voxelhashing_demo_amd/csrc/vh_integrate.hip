@@ -102,10 +102,24 @@ __device__ __forceinline__ void integrate_block(const FrameParams &fp, const Dev
 // other's chains); staging the 4 KiB through LDS was not tried on top: every voxel is read once and
 // written once by the same lane.
 template <class Depth>
+// countB > 0: the list has two ends (CompactOut, vh_walk.hip): entries 0 .. count-1 from the front, countB more
+// from the back of the numEntries-entry buffer
 __device__ __forceinline__ void integrate_list(const FrameParams &fp, const DevPtrs &dp, const VoxelEntry *__restrict__ list,
-                                               int count, int first, int stride, const Depth &src)
+                                               int count, int first, int stride, const Depth &src, int countB = 0,
+                                               uint32_t numEntries = 0)
 {
-    for (int k = first; k < count; k += stride) integrate_block(fp, dp, list[k], src);
+    for (int k = first; k < count + countB; k += stride)
+        integrate_block(fp, dp, k < count ? list[k] : list[numEntries - 1u - (uint32_t)(k - count)], src);
+}
+
+// end B of a two-ended list behind end A and what the commit phase appended to it: the dense list of the boundary
+__global__ __launch_bounds__(256) void compact_fold_kernel(const DevPtrs dp, uint32_t numEntries, int counterA,
+                                                           int counterB, int counterNew)
+{
+    const int nB = dp.counters[counterB];
+    const int base = dp.counters[counterA] + dp.counters[counterNew];
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < nB; k += gridDim.x * 256)
+        dp.compact[base + k] = dp.compact[numEntries - 1u - (uint32_t)k];
 }
 
 // DepthPlane over the .z of a float4 vertex map

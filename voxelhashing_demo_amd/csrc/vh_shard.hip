@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void frame_multi_commit_integrate_kernel(const
             dp.counters[kCompactCount] = scanCount + atomicAdd(dp.counters + kNewCount + parity, 0);
             dp.counters[kLastCandidates] = demanded;
             dp.counters[kScanCount + (parity ^ 1)] = 0;
+            dp.counters[kScanCountB + (parity ^ 1)] = 0;      // (end B of the single-camera frame's list, vh_walk.hip)
             dp.counters[kNewCount + (parity ^ 1)] = 0;
             dp.counters[kFusedCand + (parity ^ 1)] = 0;
             dp.counters[kCommitTicket] = 0;

@@ -50,6 +50,33 @@ __device__ __forceinline__ int reserve_compact_slots(const DevPtrs &dp, int coun
     return base + incl - myCount;
 }
 
+// Where the fused launches append the entries they list.  One counter takes ~90 returning atomics per
+// microsecond, and every wave that finds visible entries needs one: on C3 (5 400 visible entries in a 60 us
+// walk) that rate IS the walk's speed -- switching the compaction off took the walk from 65.9 to 58.8 us, two
+// counters instead of one from 65.9 to 60.5 (eight: 60.3).  So the list has two ends: workgroups with an even
+// tile index append upwards from compact[0] through counter A, the odd ones downwards from the last entry of
+// the buffer through counter B (on another cache line).  The consumers inside the frame (integrate_list) read
+// both ends; for everyone else the host folds end B behind end A first (compact_fold_kernel, fold_compact), so
+// the boundary still sees the reference's dense list [0, occupied).  counterB < 0: one dense list (step API).
+struct CompactOut {
+    int counterA, counterB;
+    uint32_t numEntries;        // entries of the compact buffer
+};
+__device__ __forceinline__ void compact_append(const DevPtrs &dp, const CompactOut &out, uint32_t tileIndex,
+                                               unsigned long long mask, bool hit, const VoxelEntry &ent)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool toB = out.counterB >= 0 && (tileIndex & 1u);
+    int base = 0;
+    const int leaderLane = __ffsll((long long)mask) - 1;
+    if (lane == leaderLane) base = atomicAdd(dp.counters + (toB ? out.counterB : out.counterA), __popcll(mask));
+    base = __shfl(base, leaderLane);
+    if (hit) {
+        const uint32_t pos = (uint32_t)base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        dp.compact[toB ? out.numEntries - 1u - pos : pos] = ent;
+    }
+}
+
 // strided walk with one ballot + atomic per unrolled entry slot (hits are rare on small scenes)
 template <int kN>
 __device__ __forceinline__ void walk_load_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
@@ -77,7 +104,7 @@ __device__ __forceinline__ void walk_load_tile(const FrameParams &fp, const DevP
 // yet; it is skipped here whatever the walk sees, and appended by that commit phase itself.
 template <int kN>
 __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
-                                                  const int32_t (&ptrs)[kN], int counter,
+                                                  const int32_t (&ptrs)[kN], const CompactOut &out,
                                                   const Pending &pend = kNoPending)
 {
     const uint32_t tile = tileIndex * (kFlattenThreads * kN);
@@ -85,7 +112,6 @@ __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const D
 #pragma unroll
     for (int j = 0; j < kN; ++j) any |= (ptrs[j] != VH_FREE_BLOCK);
     if (__ballot(any) == 0ull) return;
-    const int lane = threadIdx.x & (kWave - 1);
 #pragma unroll
     for (int j = 0; j < kN; ++j) {
         bool hit = false;
@@ -105,11 +131,7 @@ __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const D
         }
         const unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;
-        int base = 0;
-        const int leaderLane = __ffsll((long long)mask) - 1;
-        if (lane == leaderLane) base = atomicAdd(dp.counters + counter, __popcll(mask));
-        base = __shfl(base, leaderLane);
-        if (hit) dp.compact[base + __popcll(mask & ((1ull << lane) - 1ull))] = ent;
+        compact_append(dp, out, tileIndex, mask, hit, ent);
     }
 }
 
@@ -120,18 +142,19 @@ __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const D
 // sharded path and the view selection keep 8 (16.4 vs 16.5-16.9 us with 4).
 template <int kN>
 __device__ __forceinline__ void flatten_tile_ballot_n(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
-                                                      uint32_t tileIndex, int counter, const Pending &pend)
+                                                      uint32_t tileIndex, const CompactOut &out, const Pending &pend)
 {
     int32_t ptrs[kN];
     walk_load_tile(fp, dp, numEntries, tileIndex, ptrs);
-    walk_process_tile(fp, dp, tileIndex, ptrs, counter, pend);
+    walk_process_tile(fp, dp, tileIndex, ptrs, out, pend);
 }
 constexpr int kEntriesPerLaneShort = 4;
 __device__ __forceinline__ void flatten_tile_ballot(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
-                                                    uint32_t tileIndex, int counter, const Pending &pend = kNoPending)
+                                                    uint32_t tileIndex, const CompactOut &out,
+                                                    const Pending &pend = kNoPending)
 {
-    if (fp.flags & kFlagWalkShort) flatten_tile_ballot_n<kEntriesPerLaneShort>(fp, dp, numEntries, tileIndex, counter, pend);
-    else flatten_tile_ballot_n<kEntriesPerLane>(fp, dp, numEntries, tileIndex, counter, pend);
+    if (fp.flags & kFlagWalkShort) flatten_tile_ballot_n<kEntriesPerLaneShort>(fp, dp, numEntries, tileIndex, out, pend);
+    else flatten_tile_ballot_n<kEntriesPerLane>(fp, dp, numEntries, tileIndex, out, pend);
 }
 
 // Persistent form of the same walk for tables far larger than the Infinity Cache: a workgroup
@@ -140,7 +163,7 @@ __device__ __forceinline__ void flatten_tile_ballot(const FrameParams &fp, const
 // latency during which the one-shot form has no streaming loads in flight).
 __device__ __forceinline__ void flatten_tiles_persistent(const FrameParams &fp, const DevPtrs &dp,
                                                          uint32_t numEntries, uint32_t firstTile, uint32_t stride,
-                                                         int counter)
+                                                         const CompactOut &out)
 {
     const uint32_t numTiles = (numEntries + kFlattenThreads * kEntriesPerLane - 1) / (kFlattenThreads * kEntriesPerLane);
     uint32_t t = firstTile;
@@ -151,7 +174,7 @@ __device__ __forceinline__ void flatten_tiles_persistent(const FrameParams &fp, 
         const uint32_t n = t + stride;
         const bool more = n < numTiles;
         if (more) walk_load_tile(fp, dp, numEntries, n, nxt);
-        walk_process_tile(fp, dp, t, cur, counter);
+        walk_process_tile(fp, dp, t, cur, out);
         if (!more) break;
 #pragma unroll
         for (int j = 0; j < kEntriesPerLane; ++j) cur[j] = nxt[j];
@@ -168,13 +191,12 @@ __device__ __forceinline__ void flatten_tiles_persistent(const FrameParams &fp, 
 // commit phase itself; whether this walk already sees the bucket's occupancy bit or not makes no difference
 // (a bucket whose bit is still clear held nothing before).
 __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
-                                                   int counter, const Pending &pend = kNoPending)
+                                                   const CompactOut &out, const Pending &pend = kNoPending)
 {
     const uint32_t owned = fp.bucketHi - fp.bucketLo;
     const uint32_t numWords = (owned + 31u) / 32u;
     const uint32_t w = tileIndex * kFlattenThreads + threadIdx.x;
     uint32_t bits = (w < numWords) ? dp.bucketBits[w] : 0u;
-    const int lane = threadIdx.x & (kWave - 1);
     while (__ballot(bits != 0u) != 0ull) {
         const bool have = bits != 0u;
         const uint32_t bucket = w * 32u + (have ? (uint32_t)__ffs((int)bits) - 1u : 0u);
@@ -199,11 +221,7 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
             const unsigned long long mask = __ballot(hit);
             if (__ballot(more) == 0ull && mask == 0ull) break;
             if (mask == 0ull) continue;
-            int base = 0;
-            const int leaderLane = __ffsll((long long)mask) - 1;
-            if (lane == leaderLane) base = atomicAdd(dp.counters + counter, __popcll(mask));
-            base = __shfl(base, leaderLane);
-            if (hit) dp.compact[base + __popcll(mask & ((1ull << lane) - 1ull))] = ent;
+            compact_append(dp, out, tileIndex, mask, hit, ent);
         }
     }
 }
@@ -211,21 +229,21 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
 // tileIndex: index of this workgroup among the `walkBlocks` workgroups doing the walk
 template <int kKind>
 __device__ __forceinline__ void flatten_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
-                                             uint32_t tileIndex, int counter, uint32_t walkBlocks)
+                                             uint32_t tileIndex, const CompactOut &out, uint32_t walkBlocks)
 {
     if constexpr (kKind == kWalkPersistent)
-        flatten_tiles_persistent(fp, dp, numEntries, tileIndex, walkBlocks, counter);
+        flatten_tiles_persistent(fp, dp, numEntries, tileIndex, walkBlocks, out);
     else if constexpr (kKind == kWalkIndexed)
-        flatten_index_tile(fp, dp, tileIndex, counter);
+        flatten_index_tile(fp, dp, tileIndex, out);
     else
-        flatten_tile_ballot(fp, dp, numEntries, tileIndex, counter);
+        flatten_tile_ballot(fp, dp, numEntries, tileIndex, out);
 }
 
 template <int kKind>
 __global__ __launch_bounds__(kFlattenThreads) void flatten_kernel(const FrameParams fp, const DevPtrs dp,
                                                                   uint32_t numEntries)
 {
-    flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x, kCompactCount, gridDim.x);
+    flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x, CompactOut{kCompactCount, -1, numEntries}, gridDim.x);
 }
 
 }  // namespace vh
