@@ -196,3 +196,53 @@ def test_batch_flush_and_fixed_slot_argument_checks(oracle, vh, torch_cuda):
     ot.integrate(I4, verts)
     assert entries_as_set(gt.allocated()) == entries_as_set(ot.allocated()) and len(gt.allocated()) == 179
     gt.close()
+
+
+@pytest.mark.parametrize("pipelined", [0, 1])
+def test_compact_table_is_dense_for_every_observer(oracle, vh, torch_cuda, pipelined):
+    """Inside a fused frame the compact list has two ends (two counters instead of one hot word); whoever looks
+    from outside gets the reference's dense list: the raw d_compactifiedHashTable pointer after vh_flush, a second
+    look (nothing is folded twice), vh_download, and the step-level integrateDepthMap over the last frame's list
+    (which the oracle replays as a second TSDF update of the same frame)."""
+    import ctypes as C
+    torch = torch_cuda
+    from voxelhashing_demo_amd import _lib
+    L = vh.load()
+    hip = C.CDLL("libamdhip64.so")
+    kw = dict(numBuckets=1 << 14, numVoxelBlocks=8192)
+    W, H = 320, 240
+    ot = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    gt = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
+    gt.set_option("pipeline", pipelined)
+    prims, poses = synth.room_primitives(), synth.camera_loop(60)
+    for i in (0, 3, 6, 9):
+        v = synth.render_room_verts(poses[i], W, H, prims).numpy()
+        gt.integrate(poses[i], torch.from_numpy(v).cuda())
+        ot.integrate(poses[i], v)
+    want = entries_as_set(ot.compact())
+    assert len(want) > 200
+    pc = _lib.PtrContainer()
+    assert L.vh_get_device_pointers(gt._h, C.byref(pc)) == 0      # (flushes the pending frame and folds)
+    torch.cuda.synchronize()
+    n = gt.counters()["occupied"]
+    assert n == len(want)
+    for _ in range(2):
+        raw = np.zeros(n, vh.ENTRY_DTYPE)
+        assert L.vh_flush(gt._h) == 0
+        torch.cuda.synchronize()
+        assert hip.hipMemcpy(raw.ctypes.data_as(C.c_void_p), C.c_void_p(pc.d_compactifiedHashTable), raw.nbytes, 2) == 0
+        assert entries_as_set(raw) == want and (raw["ptr"] != -1).all()
+    assert entries_as_set(gt.compact()) == want
+    # integrateDepthMap over that list: the last frame's TSDF update once more
+    gt.integrate_depth_map(torch.from_numpy(v).cuda())
+    ot.integrate_depth_map(v)
+    gt.synchronize()
+    gtab, otab = gt.hash_table(), ot.hash_table()
+    assert np.array_equal(gtab["pos"], otab["pos"])
+    gvol, ovol = gt.sdf_blocks(), ot.sdf_blocks()
+    omap = {tuple(e["pos"]): int(e["ptr"]) for e in otab[otab["ptr"] != -1]}
+    for e in gtab[gtab["ptr"] != -1][::5]:
+        a = gvol[int(e["ptr"]):int(e["ptr"]) + 512]
+        b = ovol[omap[tuple(e["pos"])]:omap[tuple(e["pos"])] + 512]
+        assert np.array_equal(a["sdf"].view(np.uint32), b["sdf"].view(np.uint32)) and np.array_equal(a["weight"], b["weight"])
+    gt.close()
