@@ -246,3 +246,87 @@ def test_compact_table_is_dense_for_every_observer(oracle, vh, torch_cuda, pipel
         b = ovol[omap[tuple(e["pos"])]:omap[tuple(e["pos"])] + 512]
         assert np.array_equal(a["sdf"].view(np.uint32), b["sdf"].view(np.uint32)) and np.array_equal(a["weight"], b["weight"])
     gt.close()
+
+
+def test_raw_pointers_fetched_once_stay_good_across_pipelined_frames(oracle, vh, torch_cuda):
+    """The reference fetches its PtrContainer ONCE (deviceAllocate, VoxelUtils.cu:141-148).  Pipelined frames
+    alternate between two compact / claim buffers internally; after ANY number of them (odd counts leave the
+    frame's list in the second buffer) a vh_flush must leave the dense list behind the pointer fetched at the
+    start, and vh_get_device_pointers must keep returning the same addresses."""
+    import ctypes as C
+    torch = torch_cuda
+    from voxelhashing_demo_amd import _lib
+    L = vh.load()
+    hip = C.CDLL("libamdhip64.so")
+    kw = dict(numBuckets=1 << 14, numVoxelBlocks=8192)
+    W, H = 320, 240
+    ot = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    gt = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
+    pc0 = _lib.PtrContainer()
+    assert L.vh_get_device_pointers(gt._h, C.byref(pc0)) == 0          # before the first frame, as the reference does
+    prims, poses = synth.room_primitives(), synth.camera_loop(60)
+    frame = 0
+    for count in (1, 3, 2, 1, 5):                                      # odd and even runs of pipelined frames
+        ps, vs = [], []
+        for _ in range(count):
+            v = synth.render_room_verts(poses[3 * frame], W, H, prims).numpy()
+            ot.integrate(poses[3 * frame], v)
+            ps.append(poses[3 * frame])
+            vs.append(torch.from_numpy(v).cuda())
+            frame += 1
+        gt.integrate_batch(ps, vs)                                     # (ends with vh_flush)
+        torch.cuda.synchronize()
+        want = entries_as_set(ot.compact())
+        cnt = np.zeros(1, np.int32)
+        assert hip.hipMemcpy(cnt.ctypes.data_as(C.c_void_p), C.c_void_p(pc0.d_compactifiedHashCounter), 4, 2) == 0
+        assert int(cnt[0]) == len(want)
+        raw = np.zeros(len(want), vh.ENTRY_DTYPE)
+        assert hip.hipMemcpy(raw.ctypes.data_as(C.c_void_p), C.c_void_p(pc0.d_compactifiedHashTable), raw.nbytes, 2) == 0
+        assert entries_as_set(raw) == want and (raw["ptr"] != -1).all(), f"after a run of {count} pipelined frames"
+        pc = _lib.PtrContainer()
+        assert L.vh_get_device_pointers(gt._h, C.byref(pc)) == 0
+        for name, _ in _lib.PtrContainer._fields_:
+            assert getattr(pc, name) == getattr(pc0, name), name
+    # a two-launch frame and a step-level flatten after an odd pipelined run also end in the home buffer
+    v = synth.render_room_verts(poses[3 * frame], W, H, prims).numpy()
+    gt.integrate_batch([poses[3 * frame]], [torch.from_numpy(v).cuda()])
+    ot.integrate(poses[3 * frame], v)
+    gt.integrate(poses[3 * frame + 3], torch.from_numpy(v).cuda())
+    ot.integrate(poses[3 * frame + 3], v)
+    for step_level in (0, 1):
+        if step_level:
+            gt.set_pose(poses[3 * frame + 6]); ot.set_pose(poses[3 * frame + 6])
+            gt.flatten(); ot.flatten()
+        assert L.vh_flush(gt._h) == 0
+        torch.cuda.synchronize()
+        want = entries_as_set(ot.compact())
+        raw = np.zeros(len(want), vh.ENTRY_DTYPE)
+        assert hip.hipMemcpy(raw.ctypes.data_as(C.c_void_p), C.c_void_p(pc0.d_compactifiedHashTable), raw.nbytes, 2) == 0
+        assert entries_as_set(raw) == want, f"step_level={step_level}"
+    gt.close()
+
+
+def test_compact_fold_on_a_nearly_full_table(oracle, vh, torch_cuda):
+    """End B of the two-ended compact list is folded behind end A in place; on a small, dense table (more than
+    two thirds of the entries visible) the two ends meet and source and destination of a naive fold overlap.
+    2 560 entries = three walk tiles (ends A, B, A), 85 % of them allocated and visible: the dense list must hold
+    each exactly once, in both frame forms."""
+    torch = torch_cuda
+    kw = dict(numBuckets=512, bucketSize=5, numVoxelBlocks=4096, voxelSize=0.005)
+    ot = oracle.OracleTable(oracle.default_params(**kw), 640, 480, 1)
+    gt = vh.SDFHashtable(vh.default_params(**kw), 640, 480, 1)
+    verts = synth.sphere_inside_scene()
+    d = torch.from_numpy(verts).cuda()
+    for pipelined in (0, 1, 0, 1, 1, 0):
+        for _ in range(2):                       # one insertion per bucket and frame: a few frames fill the table
+            ot.integrate(I4, verts)
+        if pipelined:
+            gt.integrate_batch([I4] * 2, [d] * 2)
+        else:
+            for _ in range(2):
+                gt.integrate(I4, d)
+        got, want = gt.compact(), ot.compact()
+        assert len(got) == len(want) and entries_as_set(got) == entries_as_set(want)
+        assert len(entries_as_set(got)) == len(got), "an entry is listed twice"
+    assert len(want) > 2 * 2560 // 3 + 300, len(want)
+    gt.close()

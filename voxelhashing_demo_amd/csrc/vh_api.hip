@@ -100,6 +100,7 @@ struct vh_context {
     unsigned long long *claimBuf[2] = {nullptr, nullptr};
     int4 *candBuf[2] = {nullptr, nullptr};
     VoxelEntry *compactBuf[2] = {nullptr, nullptr};
+    VoxelEntry *compactHome = nullptr;     // the compact buffer of creation: what PtrContainer names, where settle() leaves the dense list
     float *planeBuf[2] = {nullptr, nullptr};
     uint16_t *rawBuf[2] = {nullptr, nullptr};
     int occupiedCounter = kCompactCount;   // which device counter holds the occupied count of the last frame
@@ -373,6 +374,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     if (e == hipSuccess) e = hipMemsetAsync(dp.macroBits, 0, kMacroBits / 8, s);
     if (e == hipSuccess) e = hipMemsetAsync(dp.gcMarks, 0, sizeof(uint32_t) * ((c->numEntries + 31) / 32), s);
     if (e == hipSuccess) e = hipMemsetAsync(dp.blocks, 0, sizeof(Voxel) * (size_t)p.numVoxelBlocks * kBlockVoxels, s);
+    c->compactHome = dp.compact;
     int32_t h_counters[kNumCounters] = {0};
     h_counters[kHeapCounter] = (int32_t)p.numVoxelBlocks - 1;               // :207
     if (e == hipSuccess) e = hipMemcpyAsync(dp.counters, h_counters, sizeof h_counters, hipMemcpyHostToDevice, s);

@@ -316,15 +316,29 @@ static int flush_pending(vh_context *c)
 
 // For whoever looks at the compact list from outside a frame (download, device pointers, the step-level TSDF
 // update, collection, an explicit flush or synchronisation): the pending half first, then end B of the
-// two-ended list (vh_walk.hip: CompactOut) behind end A -- the reference's dense list [0, occupied).
+// two-ended list (vh_walk.hip: CompactOut) behind end A -- the reference's dense list [0, occupied) -- and
+// always in the buffer the context was created with (c->compactHome): pipelined frames alternate between two
+// compact buffers, but a PtrContainer fetched once (as the reference does, VoxelUtils.cu:141-148) must stay
+// good for the dense list after every later vh_flush / vh_synchronize.  Once no frame is pending the two
+// buffers are interchangeable, so the home buffer becomes the current one again.
 static int settle(vh_context *c)
 {
     int rc = flush_pending(c);
-    if (rc != VH_OK || c->foldA < 0) return rc;
-    rc = launch(c, kPhaseFlatten, compact_fold_kernel, dim3(64), dim3(256), c->dp, (uint32_t)c->numEntries, c->foldA, c->foldB,
-                c->foldNew);
+    if (rc != VH_OK) return rc;
+    VoxelEntry *home = c->compactHome;
+    const bool away = c->dp.compact != home;
+    if (c->foldA < 0 && !away) return VH_OK;
+    rc = c->foldA >= 0 ? launch(c, kPhaseFlatten, compact_fold_kernel, dim3(64), dim3(256), c->dp, home, (uint32_t)c->numEntries,
+                                c->foldA, c->foldB, c->foldNew)
+                       : launch(c, kPhaseFlatten, compact_fold_kernel, dim3(64), dim3(256), c->dp, home, (uint32_t)c->numEntries,
+                                c->occupiedCounter, -1, -1);
     c->foldA = -1;
     if (rc != VH_OK) return rc;
+    if (away) {
+        c->compactBuf[c->pipeParity ^ 1] = c->dp.compact;       // (compactBuf[] exist: only pipelined frames move dp.compact)
+        c->compactBuf[c->pipeParity] = home;
+        c->dp.compact = home;
+    }
     VH_HIP(hipGetLastError());
     return VH_OK;
 }

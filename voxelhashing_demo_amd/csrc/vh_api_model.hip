@@ -105,8 +105,10 @@ extern "C" int vh_get_device_pointers(vh_context *c, PtrContainer *out)
     { DeviceGuard guard(c->device); const int frc = settle(c); if (frc != VH_OK) return frc; }   // the dense compact list
     out->d_heap = c->dp.heap;
     out->d_hashTable = c->dp.table;
-    out->d_compactifiedHashTable = c->dp.compact;
-    out->d_hashTableBucketMutex = reinterpret_cast<uint64_t *>(c->dp.claim);
+    out->d_compactifiedHashTable = c->compactHome;          // (= c->dp.compact after settle(): stable for the context's life)
+    // stable too: the claim array of creation.  Pipelined frames stake the claims of consecutive lock epochs
+    // alternately in this array and in a second one (every word carries its epoch in its top 10 bits).
+    out->d_hashTableBucketMutex = reinterpret_cast<uint64_t *>(c->claimBuf[0] ? c->claimBuf[0] : c->dp.claim);
     out->d_SDFBlocks = c->dp.blocks;
     out->d_heapCounter = c->dp.counters + kHeapCounter;
     out->d_compactifiedHashCounter = c->dp.counters + kCompactCount;
@@ -446,9 +448,17 @@ extern "C" int vh_set_profiling(vh_context *c, int enabled)
 static int accumulate_times(vh_context *c)
 {
     VH_HIP(hipStreamSynchronize(c->stream));
-    for (auto &t : c->timed) {
+    // every pair leaves `timed` before it is looked at and goes back to the pool whatever hipEventElapsedTime
+    // says, so a failure part-way never leaves a pair listed twice (launch() would reuse it while still listed,
+    // drop_events() destroy it twice)
+    std::vector<TimedLaunch> done;
+    done.swap(c->timed);
+    hipError_t firstError = hipSuccess;
+    for (auto &t : done) {
         float ms = 0;
-        VH_HIP(hipEventElapsedTime(&ms, t.start, t.stop));
+        const hipError_t e = hipEventElapsedTime(&ms, t.start, t.stop);
+        c->eventPool.emplace_back(t.start, t.stop);
+        if (e != hipSuccess) { if (firstError == hipSuccess) firstError = e; continue; }
         switch (t.phase) {
             case kPhaseClaim: c->times.alloc_claim_ms += ms; break;
             case kPhaseCommit: c->times.alloc_commit_ms += ms; break;
@@ -464,11 +474,10 @@ static int accumulate_times(vh_context *c)
             case kPhaseFramePipelined: c->times.frame_pipelined_ms += ms; break;
             default: break;
         }
-        c->eventPool.emplace_back(t.start, t.stop);
     }
-    c->timed.clear();
     c->times.launches += c->profiledFrames;
     c->profiledFrames = 0;
+    if (firstError != hipSuccess) return fail(VH_ERR_HIP, "hipEventElapsedTime", firstError);
     return VH_OK;
 }
 

@@ -69,11 +69,11 @@ extern "C" int vh_import_view(vh_context *c, const vh_view_record *d_records, in
     if (c->fp.bucketLo != 0 || c->fp.bucketHi != c->fp.numBuckets)
         return fail(VH_ERR_INVALID_ARGUMENT, "a view table is unsharded");
     if (c->epochTotal != 0) return fail(VH_ERR_INVALID_ARGUMENT, "this context has integrated frames: use a dedicated view context");
+    DeviceGuard guard(c->device);             // (before ensure_candidates: it allocates and synchronises on c's device)
     if ((size_t)count > c->candAllocated && (c->fp.flags & kFlagOverflow)) {
         const int rc = ensure_candidates(c, (size_t)count);
         if (rc != VH_OK) return rc;
     }
-    DeviceGuard guard(c->device);
     { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     if (c->viewCount > 0) {
         const int rc = launch(c, kPhaseViewImport, view_clear_kernel, dim3((unsigned)grid_for((size_t)c->viewCount, 256)),

@@ -112,14 +112,27 @@ __device__ __forceinline__ void integrate_list(const FrameParams &fp, const DevP
         integrate_block(fp, dp, k < count ? list[k] : list[numEntries - 1u - (uint32_t)(k - count)], src);
 }
 
-// end B of a two-ended list behind end A and what the commit phase appended to it: the dense list of the boundary
-__global__ __launch_bounds__(256) void compact_fold_kernel(const DevPtrs dp, uint32_t numEntries, int counterA,
-                                                           int counterB, int counterNew)
+// The dense list of the boundary: end B of a two-ended list moved behind end A and what the commit phase appended
+// to it.  The order inside the list is free (the reference's is an atomic race, VoxelUtils.cu:737-746), so only the
+// entries of end B that lie beyond the dense range [0, total) move, into the gap [base, ...) below end B: source and
+// destination ranges never overlap, however full the table is (end B = [n - nB, n), gap = [base, n - nB) when the
+// two ends have met past `total`).  dst != dp.compact (the frame's list sits in the second buffer of the pipelined
+// frames, the boundary's pointer names the first): end A is copied too and all of end B moves.
+// counterB < 0: the list is dense already (step-level flatten); only the copy to dst remains.
+__global__ __launch_bounds__(256) void compact_fold_kernel(const DevPtrs dp, VoxelEntry *dst, uint32_t numEntries,
+                                                           int counterA, int counterB, int counterNew)
 {
-    const int nB = dp.counters[counterB];
-    const int base = dp.counters[counterA] + dp.counters[counterNew];
-    for (int k = blockIdx.x * 256 + threadIdx.x; k < nB; k += gridDim.x * 256)
-        dp.compact[base + k] = dp.compact[numEntries - 1u - (uint32_t)k];
+    const uint32_t nB = counterB >= 0 ? (uint32_t)dp.counters[counterB] : 0u;
+    const uint32_t base = (uint32_t)dp.counters[counterA] + (counterNew >= 0 ? (uint32_t)dp.counters[counterNew] : 0u);
+    const uint32_t total = base + nB;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x, stride = gridDim.x * 256u;
+    if (dst != dp.compact) {
+        for (uint32_t k = t; k < base; k += stride) dst[k] = dp.compact[k];
+        for (uint32_t k = t; k < nB; k += stride) dst[base + k] = dp.compact[numEntries - nB + k];
+        return;
+    }
+    const uint32_t lo = max(total, numEntries - nB);          // entries of end B at or beyond `total`: [lo, n)
+    for (uint32_t k = t; k < numEntries - lo; k += stride) dst[base + k] = dp.compact[lo + k];
 }
 
 // DepthPlane over the .z of a float4 vertex map

@@ -366,12 +366,13 @@ def sharded_raycast_fixed(shard, view, transport: TorchDistTransport, pose, capa
         st.update(capacity=capacity, world=world,
                   pose_all=torch.empty((world, 16), dtype=torch.float32, device=dev),
                   pose_mine=torch.empty((16,), dtype=torch.float32, device=dev),
-                  pose_host=torch.empty((16,), dtype=torch.float32).pin_memory(),
                   send=torch.zeros((world * capacity, VIEW_RECORD_BYTES), dtype=torch.uint8, device=dev),
                   recv=torch.zeros((world * capacity, VIEW_RECORD_BYTES), dtype=torch.uint8, device=dev),
                   counts=torch.zeros((world,), dtype=torch.int32, device=dev))
-    st["pose_host"].copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))))
-    st["pose_mine"].copy_(st["pose_host"], non_blocking=True)               # pinned -> device, no synchronisation
+    # From PAGEABLE host memory: the runtime stages the 64 bytes before the call returns, so the next round may
+    # overwrite its own pose at once.  (A single pinned staging buffer copied with non_blocking=True is read by the
+    # DMA whenever the stream gets there -- back-to-back rounds then exported the blocks of the NEXT round's view.)
+    st["pose_mine"].copy_(torch.from_numpy(np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))))
     transport.dist.all_gather_into_tensor(st["pose_all"].view(-1), st["pose_mine"], group=transport.group)
     shard.table.export_views_fixed(st["pose_all"], world, st["send"], capacity, st["counts"], t_min, t_max)
     # one payload collective: the counts ride in the spare header word of each slot range's first record
