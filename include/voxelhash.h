@@ -279,8 +279,11 @@ int vh_render_blocks(vh_context *ctx, const float pose[16], float t_min, float t
 /* The compact table (d_compactifiedHashTable, VH_BUF_COMPACT) as the reference leaves it -- `occupied` dense
  * entries from index 0 -- is what vh_download, vh_get_device_pointers, vh_flush and vh_synchronize hand over:
  * inside a fused frame the list is kept with two ends (two counters instead of one hot word) and these calls
- * fold it first.  A raw pointer obtained earlier is good for the dense list after the next vh_flush /
- * vh_synchronize. */
+ * fold it first.  The addresses in a PtrContainer never change during the life of a context (fetch it once, as
+ * the reference does, VoxelUtils.cu:141-148): pipelined frames alternate between two compact buffers and two
+ * claim arrays internally, and vh_flush / vh_synchronize leave the dense list in the buffer
+ * d_compactifiedHashTable names; d_hashTableBucketMutex names the first of the two claim arrays (consecutive lock
+ * epochs of pipelined frames stake their claims in the two arrays alternately; every word carries its epoch). */
 int vh_synchronize(vh_context *ctx);
 int vh_get_counters(vh_context *ctx, vh_counters *out);              /* synchronises */
 int vh_get_params(vh_context *ctx, HashTableParams *out);
