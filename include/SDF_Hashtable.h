@@ -53,6 +53,9 @@ public:
      * map in memory; Application.cpp:73-74,84); kInv: row-major 3x3 */
     void integrate(const float4x4 &deltaT, const uint16_t *d_depth, const float kInv[9]);
     void raycast(const float4x4 &pose, float *d_depth_out, float zNear = 0.1f, float zFar = 5.0f);
+    /* raycast(pose, d_depth_out, d_normal_out) -- depth and, from the same pass, the camera-frame
+     * normal of every hit (TSDF gradient; vh_raycast_normals) */
+    void raycast(const float4x4 &pose, float *d_depth_out, vh_float4 *d_normal_out, float zNear = 0.1f, float zFar = 5.0f);
     /* depth plus camera-frame vertex and normal maps of the view (what CameraTracking::Align takes as target) */
     void raycast(const float4x4 &pose, float *d_depth_out, vh_float4 *d_vertices_out, vh_float4 *d_normals_out,
                  float zNear = 0.1f, float zFar = 5.0f);

@@ -263,9 +263,26 @@ int vh_integrate_depth_batch(vh_context *ctx, int32_t count, const float *poses,
 
 /* Stand-in for SDFRenderer::render (SDFRenderer.cpp:210-255): one ray per pixel
  * from `pose`, camera depth of the first +/- zero crossing into d_depth_out
- * (width*height floats, 0 = no hit).  Spec: DESIGN.md "raycast". */
+ * (width*height floats, 0 = no hit).  Spec: DESIGN.md "raycast".
+ * Two traversals, chosen with vh_set_option(ctx, "raycast_mode", ...):
+ *   VH_RAYCAST_DDA (default)  the voxel DDA the reference's shader intends (raycastSDF.frag:121-177,
+ *       Amanatides-Woo between the ray's two ends): every voxel the ray passes through between t_min and
+ *       t_max, in order, each a sample with the voxel's own {sdf, weight} placed at the camera depth of the
+ *       voxel's centre; crossing times are functions of the integer voxel coordinate (no accumulated tMax),
+ *       ties as at :156-170; absent blocks and empty 4x4x4-block cells are left in one exact step.
+ *   VH_RAYCAST_FIXED_STEP     rounds 1-2: samples at camera depth t_min + i*voxelSize, nearest voxel each.
+ * Both: first pair of consecutive valid samples (block allocated, weight > 0) with sdf_prev > 0 >= sdf_cur,
+ * linear interpolation.  The DDA refuses views of more than 2^22 voxel steps per ray.
+ * vh_raycast_normals (DDA only) also writes, in the same pass, the normal of every hit: the TSDF gradient at
+ * the second voxel of the pair (central differences where both neighbours are valid, one-sided otherwise),
+ * normalised, in the CAMERA frame with w = 0 (the convention of calculateNormals, CameraTrackingUtils.cu:
+ * 75-113); zeros for a miss or when an axis has no valid neighbour. */
+#define VH_RAYCAST_FIXED_STEP 0
+#define VH_RAYCAST_DDA        1
 int vh_raycast(vh_context *ctx, const float pose[16], float t_min, float t_max,
                float *d_depth_out);
+int vh_raycast_normals(vh_context *ctx, const float pose[16], float t_min, float t_max,
+                       float *d_depth_out, vh_float4 *d_normals_out);
 
 /* Block silhouettes: the reference's one working render pass (SDFRenderer::drawToFrontAndBack,
  * SDFRenderer.cpp:165-208: one cube per entry -- block k covers world [8k, 8k+8]*voxelSize,

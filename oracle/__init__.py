@@ -20,6 +20,7 @@ SEM_PINHOLE = 1
 FREE_BLOCK = -1
 BAND_RAY, BAND_NORMAL_DDA = 0, 1
 INT_DEPTH_TRUNCATION, INT_WEIGHT_SAMPLE = 1, 2
+RAYCAST_FIXED_STEP, RAYCAST_DDA = 0, 1
 POS_SENTINEL = 0x7FFFFFFF
 
 ENTRY_DTYPE = np.dtype([("pos", "<i4", (3,)), ("ptr", "<i4"), ("offset", "<i4")])
@@ -101,6 +102,8 @@ def lib():
         L.vho_integrate_mt.argtypes = [C.c_void_p, fp, fp, C.c_int, C.POINTER(FrameStats)]
         L.vho_integrate_mt.restype = C.c_int
         L.vho_raycast.argtypes = [C.c_void_p, fp, C.c_float, C.c_float, fp]
+        L.vho_raycast_dda.argtypes = [C.c_void_p, fp, C.c_float, C.c_float, C.c_int, fp, fp]
+        L.vho_raycast_dda.restype = None
         L.vho_get_params.restype = C.POINTER(Params)
         L.vho_get_params.argtypes = [C.c_void_p]
         for name in ("vho_hash_table", "vho_compact_table", "vho_sdf_blocks", "vho_heap"):
@@ -349,11 +352,24 @@ class OracleTable:
         self.last_stats = st.as_dict()
         return int(occ)
 
-    def raycast(self, pose, t_min: float = 0.1, t_max: float = 5.0) -> np.ndarray:
+    def set_raycast_mode(self, mode: int):
+        """RAYCAST_DDA (default: the voxel DDA of raycastSDF.frag:121-177) or RAYCAST_FIXED_STEP (rounds 1-2)."""
+        self.raycast_mode = int(mode)
+
+    def raycast(self, pose, t_min: float = 0.1, t_max: float = 5.0, jumps: bool = True, normals: bool = False):
+        """Depth image (and, with normals=True, the camera-frame normal map [H, W, 4]) in the table's raycast
+        mode.  jumps=False walks absent blocks voxel by voxel (same bits; the defining form of the DDA)."""
         pose = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
         out = np.zeros((self.height, self.width), np.float32)
-        lib().vho_raycast(self._h, _fptr(pose), t_min, t_max, _fptr(out))
-        return out
+        if getattr(self, "raycast_mode", RAYCAST_DDA) == RAYCAST_FIXED_STEP:
+            if normals:
+                raise ValueError("the fixed-step march has no normal output")
+            lib().vho_raycast(self._h, _fptr(pose), t_min, t_max, _fptr(out))
+            return out
+        nrm = np.zeros((self.height, self.width, 4), np.float32) if normals else None
+        lib().vho_raycast_dda(self._h, _fptr(pose), t_min, t_max, 1 if jumps else 0, _fptr(out),
+                              _fptr(nrm) if normals else None)
+        return (out, nrm) if normals else out
 
     # ---- deletion / garbage collection ----
     def delete_blocks(self, keys) -> int:

@@ -961,6 +961,186 @@ void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max, f
 }
 
 /* ------------------------------------------------------------------ */
+/* raycast as a voxel DDA: the traversal the reference's shader intends  */
+/* (raycastSDF.frag:121-177, Amanatides-Woo between the ray's two ends;  */
+/* disabled and self-declared broken there, so the spec is this build's) */
+/* ------------------------------------------------------------------ */
+/* Ray of pixel (u,v): world point at camera depth t is o + D*t with o = pose translation and
+ * D = R*((u-cx)/fx, (v-cy)/fy, 1).  In voxel-grid coordinates g(t) = G + E*t, G = o/voxelSize + 0.5,
+ * E = D/voxelSize, and voxel i covers [i, i+1) of g, i.e. world [(i-0.5), (i+0.5))*voxelSize around
+ * its centre i*voxelSize (what world2Voxel's rounding maps to i).  The ray visits, in order, every voxel it
+ * passes through between t_min and t_max:
+ *   - a crossing EVENT of axis a out of coordinate c happens at tnext_a(c) = (c - Gs_a) * (1/E_a), Gs_a = G_a - 1
+ *     (E_a > 0: the plane is c + 1) or G_a (E_a < 0): a pure function of the integer coordinate, never accumulated (the shader's
+ *     tMax += tDelta, :159-169, drifts), so the traversal is the merge of three monotone event sequences;
+ *   - events are merged by (t, axis priority y < z < x): exactly the shader's choice at :156-170 (x only when
+ *     strictly first, z before x on a tie, y before both);
+ *   - an axis with |E_a| <= 1e-20 never steps (:141-148).
+ * Every visited voxel is a sample with the voxel's own {sdf, weight} (un-interpolated, :101-105), placed at the
+ * camera depth of the voxel's CENTRE (row 2 of the cofactor inverse of the pose, scaled to voxel units: a TSDF
+ * value is what integrateDepthMap measured at that centre along the camera axis, VoxelUtils.cu:797-813; against
+ * the analytic room this halves the depth error of a mid-segment placement); valid = block allocated and
+ * weight > 0.  Surface = first pair of consecutive
+ * valid samples with sdf_prev > 0 >= sdf_cur; depth = t_prev + (t_cur - t_prev)*sdf_prev / (sdf_prev - sdf_cur);
+ * 0 = miss.  Optional normal of a hit: gradient of the TSDF at the second voxel of the pair (central
+ * differences where both neighbours are valid, one-sided otherwise), normalised, in the CAMERA frame, w = 0
+ * (the convention of calculateNormals, CameraTrackingUtils.cu:75-113: towards the camera); zeros when an axis
+ * has no valid neighbour or the gradient vanishes.
+ *
+ * jumps != 0: an absent block is left in one go.  The state after the jump is computed from the merge order
+ * itself -- the exit event is the first of the three block-boundary events, every other axis advances past
+ * exactly those of its events that precede it -- so the visited voxel sequence outside the empty block and
+ * hence the image are IDENTICAL to the plain walk (tests/test_raycast_dda_cpu.py asserts the
+ * bits).  That is what allows the HIP kernel to skip absent blocks and empty 4x4x4-block macro cells through
+ * hashed bitmaps whose stale or colliding bits only make it skip less. */
+typedef struct {
+    float G[3], E[3], invE[3];
+    float Gs[3];                 /* G - 1 for an axis that steps up (its crossing plane is c + 1), G otherwise */
+    int   s[3], active[3];
+} dda_ray;
+
+static float dda_tnext(const dda_ray *r, int a, int32_t c)
+{
+    if (!r->active[a]) return VHO_INF_F;
+    return ((float)c - r->Gs[a]) * r->invE[a];
+}
+
+/* event (tb, axis b) is merged before event (ta, axis a), a != b */
+static int dda_before(float tb, int b, float ta, int a)
+{
+    static const int prio[3] = { 2, 0, 1 };      /* x, y, z: raycastSDF.frag:156-170 */
+    return tb < ta || (tb == ta && prio[b] < prio[a]);
+}
+
+static int dda_first(const float t[3])           /* raycastSDF.frag:156,161,166 */
+{
+    if (t[0] < t[1] && t[0] < t[2]) return 0;
+    if (t[2] < t[1]) return 2;
+    return 1;
+}
+
+static int32_t floor_div8(int32_t v) { return v >> 3; }      /* = voxel2Block for two's complement ints (:37-42) */
+
+/* the voxel (block allocated, weight > 0)? */
+static int dda_voxel(const vho_table *t, const int32_t v[3], vho_voxel *out)
+{
+    const int32_t key[3] = { floor_div8(v[0]), floor_div8(v[1]), floor_div8(v[2]) };
+    const int64_t idx = lookup_block(t, key);
+    if (idx < 0) return 0;
+    const vho_voxel *vol = t->view_blocks ? t->view_blocks : t->blocks;
+    *out = vol[(size_t)t->table[idx].ptr + (size_t)((v[2] & 7) * 64 + (v[1] & 7) * 8 + (v[0] & 7))];
+    return out->weight > 0.0f;
+}
+
+#define VHO_DDA_MAX_STEPS (1L << 22)
+
+void vho_raycast_dda(vho_table *t, const float pose[16], float t_min, float t_max, int jumps, float *depth_out,
+                     float *normal_out /* W*H*4 or NULL */)
+{
+    const int W = t->width, H = t->height;
+    const float vs = t->p.voxelSize;
+    float inv[16];
+    vho_invert4x4(pose, inv);                      /* cofactor inverse, as SDF_Hashtable::integrate takes it */
+    const float zrow[4] = { inv[8] * vs, inv[9] * vs, inv[10] * vs, inv[11] };
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int v = 0; v < H; ++v)
+    for (int u = 0; u < W; ++u) {
+        const float dx = ((float)u - t->rc_cx) / t->rc_fx;
+        const float dy = ((float)v - t->rc_cy) / t->rc_fy;
+        dda_ray r;
+        int32_t c[3];
+        float tn[3];
+        for (int a = 0; a < 3; ++a) {
+            const float D = pose[4*a+0] * dx + pose[4*a+1] * dy + pose[4*a+2];
+            r.G[a] = pose[4*a+3] / vs + 0.5f;
+            r.E[a] = D / vs;
+            r.active[a] = fabsf(r.E[a]) > 1.0e-20f;
+            r.invE[a] = r.active[a] ? 1.0f / r.E[a] : 0.0f;
+            r.s[a] = r.E[a] > 0.0f ? 1 : -1;
+            r.Gs[a] = r.E[a] > 0.0f ? r.G[a] - 1.0f : r.G[a];
+            c[a] = vho_float2int_rz(floorf(r.G[a] + r.E[a] * t_min));
+        }
+        for (int a = 0; a < 3; ++a) tn[a] = dda_tnext(&r, a, c[a]);
+        float hit = 0.0f, prev_sdf = 0.0f, prev_t = 0.0f;
+        int prev_valid = 0, have_key = 0, found = 0;
+        int32_t ckey[3] = {0, 0, 0};
+        int64_t cidx = -1;
+        for (long it = 0; it < VHO_DDA_MAX_STEPS; ++it) {
+            const int32_t key[3] = { floor_div8(c[0]), floor_div8(c[1]), floor_div8(c[2]) };
+            if (!have_key || key[0] != ckey[0] || key[1] != ckey[1] || key[2] != ckey[2]) {
+                ckey[0] = key[0]; ckey[1] = key[1]; ckey[2] = key[2];
+                cidx = lookup_block(t, key);
+                have_key = 1;
+            }
+            if (cidx < 0 && jumps) {
+                int32_t cs[3];
+                float te[3];
+                for (int a = 0; a < 3; ++a) {
+                    cs[a] = wrap_add(wrap_mul(key[a], 8), r.s[a] > 0 ? 7 : 0);     /* last coordinate inside the block */
+                    te[a] = dda_tnext(&r, a, cs[a]);
+                }
+                const int x = dda_first(te);
+                if (!(te[x] < t_max)) break;                   /* the ray ends inside the empty block */
+                for (int b = 0; b < 3; ++b) {
+                    if (b == x) continue;
+                    while (c[b] != cs[b] && dda_before(dda_tnext(&r, b, c[b]), b, te[x], x)) c[b] = wrap_add(c[b], r.s[b]);
+                }
+                c[x] = wrap_add(cs[x], r.s[x]);
+                for (int a = 0; a < 3; ++a) tn[a] = dda_tnext(&r, a, c[a]);
+                prev_valid = 0;
+                continue;
+            }
+            const int a = dda_first(tn);
+            const float t_out = tn[a];
+            if (cidx >= 0) {
+                const vho_voxel *vol = t->view_blocks ? t->view_blocks : t->blocks;
+                const vho_voxel sv = vol[(size_t)t->table[cidx].ptr + (size_t)((c[2] & 7) * 64 + (c[1] & 7) * 8 + (c[0] & 7))];
+                if (sv.weight > 0.0f) {
+                    /* the sample sits at the voxel's centre: its camera depth (row 2 of the inverse pose) */
+                    const float t_mid = ((zrow[0] * (float)c[0] + zrow[1] * (float)c[1]) + zrow[2] * (float)c[2]) + zrow[3];
+                    if (prev_valid && prev_sdf > 0.0f && sv.sdf <= 0.0f) {
+                        hit = prev_t + ((t_mid - prev_t) * prev_sdf) / (prev_sdf - sv.sdf);
+                        found = 1;
+                        break;
+                    }
+                    prev_valid = 1; prev_sdf = sv.sdf; prev_t = t_mid;
+                } else prev_valid = 0;
+            } else prev_valid = 0;
+            if (!(t_out < t_max)) break;
+            c[a] = wrap_add(c[a], r.s[a]);
+            tn[a] = dda_tnext(&r, a, c[a]);
+        }
+        depth_out[(size_t)v * W + u] = hit;
+        if (!normal_out) continue;
+        float n[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if (found) {
+            vho_voxel here, sp, sm;
+            float g[3];
+            int ok = dda_voxel(t, c, &here);           /* (the hit voxel itself: valid by construction) */
+            for (int a = 0; a < 3 && ok; ++a) {
+                int32_t vp[3] = { c[0], c[1], c[2] }, vm[3] = { c[0], c[1], c[2] };
+                vp[a] = wrap_add(vp[a], 1);
+                vm[a] = wrap_sub(vm[a], 1);
+                const int hp = dda_voxel(t, vp, &sp), hm = dda_voxel(t, vm, &sm);
+                if (hp && hm) g[a] = (sp.sdf - sm.sdf) * 0.5f;
+                else if (hp) g[a] = sp.sdf - here.sdf;
+                else if (hm) g[a] = here.sdf - sm.sdf;
+                else ok = 0;
+            }
+            if (ok) {
+                const float len = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+                if (len > 0.0f) {
+                    const float w[3] = { g[0] / len, g[1] / len, g[2] / len };
+                    for (int i = 0; i < 3; ++i)          /* R^T * w: world -> camera */
+                        n[i] = pose[0*4+i] * w[0] + pose[1*4+i] * w[1] + pose[2*4+i] * w[2];
+                }
+            }
+        }
+        memcpy(normal_out + 4 * ((size_t)v * W + u), n, sizeof n);
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* block silhouettes: the reference's one       */
 /* working render pass, SDFRenderer::drawToFrontAndBack                 */
 /* (SDFRenderer.cpp:165-208, depthWrite.*; back layer: notes.md:3-16)   */

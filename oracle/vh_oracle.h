@@ -111,8 +111,14 @@ int  vho_integrate_mt(vho_table *t, const float pose[16], const float *verts, in
                       vho_frame_stats *stats);
 
 /* ---- raycast (build spec; self-pinned) ---- */
+/* fixed-step march (rounds 1-2): samples at camera depth t_min + i*voxelSize, nearest voxel each */
 void vho_raycast(vho_table *t, const float pose[16], float t_min, float t_max,
                  float *depth_out /* W*H */);
+/* voxel DDA (raycastSDF.frag:121-177): every voxel the ray passes through, in order; optional camera-frame
+ * normals of the hits (W*H float4, w = 0; NULL = none).  jumps != 0 leaves absent blocks in one go -- the
+ * image has the same bits either way (the accelerated form the HIP kernel mirrors). */
+void vho_raycast_dda(vho_table *t, const float pose[16], float t_min, float t_max, int jumps,
+                     float *depth_out /* W*H */, float *normal_out /* W*H*4 or NULL */);
 
 /* ---- block silhouettes (SDFRenderer::drawToFrontAndBack) ---- */
 void vho_render_blocks(const vho_table *t, const float pose[16], float t_min, float t_max, float *front, float *back);

@@ -156,9 +156,15 @@ def main():
         for k, v in digest_scene(t).items():
             out[f"{name}/{k}"] = v
         if name == "inside_pin_f2":
+            t.set_raycast_mode(O.RAYCAST_FIXED_STEP)              # the march of rounds 1-2
             d = t.raycast(I4, 0.1, 5.0)
             out["raycast_inside_pin_f2/sha"] = np.frombuffer(hashlib.sha256(d.tobytes()).digest(), np.uint8)
             out["raycast_inside_pin_f2/row240"] = d[240].view(np.uint32)
+            t.set_raycast_mode(O.RAYCAST_DDA)                     # the voxel DDA (default), with its normal map
+            d, n = t.raycast(I4, 0.1, 5.0, normals=True)
+            out["raycast_dda_inside_pin_f2/sha"] = np.frombuffer(hashlib.sha256(d.tobytes() + n.tobytes()).digest(), np.uint8)
+            out["raycast_dda_inside_pin_f2/row240"] = d[240].view(np.uint32)
+            out["raycast_dda_inside_pin_f2/normals_row240"] = n[240].view(np.uint32)
             front, back = t.render_blocks(I4, 0.1, 5.0)            # block silhouettes (row R1) of the same model
             out["silhouettes_inside_pin_f2/sha"] = np.frombuffer(
                 hashlib.sha256(front.tobytes() + back.tobytes()).digest(), np.uint8)

@@ -63,9 +63,15 @@ def test_oracle_reproduces_scene(oracle, name):
     _check(name, t)
     if name == "inside_pin_f2":
         import hashlib
+        t.set_raycast_mode(oracle.RAYCAST_FIXED_STEP)
         d = t.raycast(np.eye(4, dtype=np.float32), 0.1, 5.0)
         assert np.array_equal(np.frombuffer(hashlib.sha256(d.tobytes()).digest(), np.uint8),
                               SCENES["raycast_inside_pin_f2/sha"])
+        t.set_raycast_mode(oracle.RAYCAST_DDA)
+        for jumps in (True, False):
+            d, n = t.raycast(np.eye(4, dtype=np.float32), 0.1, 5.0, jumps=jumps, normals=True)
+            assert np.array_equal(np.frombuffer(hashlib.sha256(d.tobytes() + n.tobytes()).digest(), np.uint8),
+                                  SCENES["raycast_dda_inside_pin_f2/sha"])
         front, back = t.render_blocks(np.eye(4, dtype=np.float32), 0.1, 5.0)
         assert np.array_equal(np.frombuffer(hashlib.sha256(front.tobytes() + back.tobytes()).digest(), np.uint8),
                               SCENES["silhouettes_inside_pin_f2/sha"])
@@ -88,11 +94,21 @@ def test_hip_reproduces_scene(vh, torch_cuda, name):
     t = G.run_scene(name, lambda kw, sem: GT(vh.default_params(**kw), 640, 480, sem))
     _check(name, t)
     if name == "inside_pin_f2":
+        import hashlib
         d = torch.empty((480, 640), dtype=torch.float32, device="cuda")
+        t.set_raycast_mode(vh.RAYCAST_FIXED_STEP)
         t.raycast(np.eye(4, dtype=np.float32), d, 0.1, 5.0)
         t.synchronize()
         assert np.array_equal(d.cpu().numpy()[240].view(np.uint32), SCENES["raycast_inside_pin_f2/row240"])
-        import hashlib
+        t.set_raycast_mode(vh.RAYCAST_DDA)
+        n = torch.empty((480, 640, 4), dtype=torch.float32, device="cuda")
+        t.raycast_normals(np.eye(4, dtype=np.float32), d, n, 0.1, 5.0)
+        t.synchronize()
+        dn, nn = d.cpu().numpy(), n.cpu().numpy()
+        assert np.array_equal(dn[240].view(np.uint32), SCENES["raycast_dda_inside_pin_f2/row240"])
+        assert np.array_equal(nn[240].view(np.uint32), SCENES["raycast_dda_inside_pin_f2/normals_row240"])
+        assert np.array_equal(np.frombuffer(hashlib.sha256(dn.tobytes() + nn.tobytes()).digest(), np.uint8),
+                              SCENES["raycast_dda_inside_pin_f2/sha"])
         front, back = torch.empty((480, 640), device="cuda"), torch.empty((480, 640), device="cuda")
         t.render_blocks(np.eye(4, dtype=np.float32), front, back, 0.1, 5.0)
         t.synchronize()

@@ -237,11 +237,14 @@ def test_device_scalar_helpers(oracle, vh, torch_cuda):
         assert out[i, 7] == oracle.float2int_rz(p[3])
 
 
-def test_raycast_matches_oracle_and_geometry(oracle, vh, torch_cuda):
-    """Raycast spec (self-pinned, the reference's pass is disabled): bit-equal to the oracle,
-    and within a voxel of the analytic depth of the scene that was fused."""
+@pytest.mark.parametrize("mode", [1, 0])
+def test_raycast_matches_oracle_and_geometry(oracle, vh, torch_cuda, mode):
+    """Raycast spec (self-pinned, the reference's pass is disabled), voxel DDA (1) and fixed-step march (0):
+    bit-equal to the oracle, and within a voxel of the analytic depth of the scene that was fused."""
     torch = torch_cuda
     ot, gt = _pair(oracle, vh, 1)
+    ot.set_raycast_mode(mode)
+    gt.set_raycast_mode(mode)
     verts = synth.sphere_inside_scene()
     _run(ot, gt, torch, [(I4, verts)] * 3)
     d_depth = torch.empty((480, 640), dtype=torch.float32, device="cuda")
@@ -294,12 +297,16 @@ def test_drop_in_names(oracle, vh, torch_cuda):
         L.deviceFree()
 
 
-def test_raycast_room_scene_moving_camera(oracle, vh, torch_cuda):
+@pytest.mark.parametrize("mode", [1, 0])
+def test_raycast_room_scene_moving_camera(oracle, vh, torch_cuda, mode):
     """Raycast of the fused room (thousands of blocks, rays crossing long stretches of empty
-    space, so the empty-block skip and the bucket bitmap are exercised) from poses on and off the
-    integration path: bit-equal to the oracle, which evaluates every sample."""
+    space, so the empty-block / empty-macro-cell skips and the bucket bitmap are exercised) from poses on
+    and off the integration path: bit-equal to the oracle (DDA: which leaves absent blocks only, through
+    exact look-ups; fixed step: which evaluates every sample)."""
     torch = torch_cuda
     ot, gt = _pair(oracle, vh, 1, numVoxelBlocks=1 << 14)
+    ot.set_raycast_mode(mode)
+    gt.set_raycast_mode(mode)
     poses = synth.camera_loop(500)
     prims = synth.room_primitives()
     frames = [(poses[i], synth.render_room_verts(poses[i], prims=prims).numpy()) for i in (0, 3, 6, 30)]

@@ -6,3 +6,5 @@ SDF_Hashtable class: C++ (include/SDF_Hashtable.h) and Python (hashtable.py).
 """
 from ._lib import (SEM_PINHOLE, SEM_REFERENCE, HashTableParams, VoxelHashError, load)  # noqa: F401
 from .hashtable import ENTRY_DTYPE, VOXEL_DTYPE, SDFHashtable, default_params, preprocess  # noqa: F401
+
+RAYCAST_FIXED_STEP, RAYCAST_DDA = 0, 1      # vh_set_option(ctx, "raycast_mode", ...), include/voxelhash.h

@@ -57,6 +57,11 @@ void SDF_Hashtable::raycast(const float4x4 &pose, float *d_depth_out, float zNea
     check(vh_raycast(ctx_, pose.entries, zNear, zFar, d_depth_out), "raycast");
 }
 
+void SDF_Hashtable::raycast(const float4x4 &pose, float *d_depth_out, vh_float4 *d_normal_out, float zNear, float zFar)
+{
+    check(vh_raycast_normals(ctx_, pose.entries, zNear, zFar, d_depth_out, d_normal_out), "raycast");
+}
+
 void SDF_Hashtable::raycast(const float4x4 &pose, float *d_depth_out, vh_float4 *d_vertices_out, vh_float4 *d_normals_out,
                             float zNear, float zFar)
 {

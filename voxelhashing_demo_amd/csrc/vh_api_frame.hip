@@ -490,28 +490,76 @@ extern "C" int vh_integrate_depth_batch(vh_context *c, int32_t count, const floa
     return rc;
 }
 
-extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, float t_max, float *d_depth_out)
+// The raycast in the context's mode (option "raycast_mode"): the voxel DDA (default), optionally with the normal
+// map of the hits written by the same pass, or the fixed-step march of rounds 1-2.
+static int raycast_impl(vh_context *c, const float pose[16], float t_min, float t_max, float *d_depth_out,
+                        vh_float4 *d_normals_out)
 {
     if (!c || !pose || !d_depth_out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     if (!(t_max > t_min)) return fail(VH_ERR_INVALID_ARGUMENT, "t_max must exceed t_min");
+    if (c->raycastMode == VH_RAYCAST_FIXED_STEP && d_normals_out)
+        return fail(VH_ERR_INVALID_ARGUMENT, "the fixed-step march has no normal output (raycast_mode 0)");
     DeviceGuard guard(c->device);
     { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     FrameParams fp = c->fp;
     std::memcpy(fp.T, pose, sizeof fp.T);
-    const float q = (t_max - t_min) / fp.voxelSize;
-    int nsteps = (q >= 2147483648.0f) ? 0x7fffffff : (int)q;
-    nsteps += 1;
     dim3 grid((fp.width + 15) / 16, (fp.height + 15) / 16);
     DevPtrs dp = c->dp;
     if (c->viewBlocks) dp.blocks = const_cast<Voxel *>(c->viewBlocks);     // view table: voxels live in the records
-    const int rc = c->raycastPatch
-                       ? launch(c, kPhaseRaycast, raycast_kernel<1>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy,
-                                c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out, c->raycastXcd)
-                       : launch(c, kPhaseRaycast, raycast_kernel<0>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy,
-                                c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out, c->raycastXcd);
+    int rc;
+    if (c->raycastMode == VH_RAYCAST_FIXED_STEP) {
+        const float q = (t_max - t_min) / fp.voxelSize;
+        int nsteps = (q >= 2147483648.0f) ? 0x7fffffff : (int)q;
+        nsteps += 1;
+        rc = c->raycastPatch
+                 ? launch(c, kPhaseRaycast, raycast_kernel<1>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy,
+                          c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out, c->raycastXcd)
+                 : launch(c, kPhaseRaycast, raycast_kernel<0>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy,
+                          c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out, c->raycastXcd);
+    } else {
+        RaycastArgs ra;
+        ra.fx = c->rc_fx; ra.fy = c->rc_fy; ra.cx = c->rc_cx; ra.cy = c->rc_cy;
+        ra.tMin = t_min; ra.tMax = t_max;
+        float inv[16];
+        invert4x4(pose, inv);                      // cofactor inverse (cuda_SimpleMatrixUtil.h:944-1069), as vh_set_pose
+        ra.zrow[0] = inv[8] * fp.voxelSize; ra.zrow[1] = inv[9] * fp.voxelSize; ra.zrow[2] = inv[10] * fp.voxelSize;
+        ra.zrow[3] = inv[11];
+        // Hang guard, never reached by a ray: a ray changes voxel coordinate a at most (t_max - t_min) * |E_a| + 1
+        // times, |E_a| <= (|T_a0| max|dx| + |T_a1| max|dy| + |T_a2|) / voxelSize.  A view whose bound is not finite
+        // or beyond 2^22 steps is refused (the oracle walks at most that many voxels per ray).
+        const double mdx = std::max(std::fabs((0.0 - ra.cx) / ra.fx), std::fabs(((double)fp.width - 1.0 - ra.cx) / ra.fx));
+        const double mdy = std::max(std::fabs((0.0 - ra.cy) / ra.fy), std::fabs(((double)fp.height - 1.0 - ra.cy) / ra.fy));
+        double steps = 16.0;
+        for (int a = 0; a < 3; ++a)
+            steps += 1.01 * ((double)t_max - (double)t_min) *
+                     (std::fabs((double)pose[4 * a]) * mdx + std::fabs((double)pose[4 * a + 1]) * mdy + std::fabs((double)pose[4 * a + 2])) /
+                     (double)fp.voxelSize + 2.0;
+        if (!(steps < 4194304.0)) return fail(VH_ERR_INVALID_ARGUMENT, "view too deep for the voxel size (more than 2^22 voxel steps per ray) or not finite");
+        ra.budget = (int)steps;
+        ra.xcdAware = c->raycastXcd;
+        float4 *nrm = reinterpret_cast<float4 *>(d_normals_out);
+        if (nrm)
+            rc = c->raycastPatch ? launch(c, kPhaseRaycast, raycast_dda_kernel<1, true>, grid, dim3(256), fp, dp, ra, d_depth_out, nrm)
+                                 : launch(c, kPhaseRaycast, raycast_dda_kernel<0, true>, grid, dim3(256), fp, dp, ra, d_depth_out, nrm);
+        else
+            rc = c->raycastPatch ? launch(c, kPhaseRaycast, raycast_dda_kernel<1, false>, grid, dim3(256), fp, dp, ra, d_depth_out, nrm)
+                                 : launch(c, kPhaseRaycast, raycast_dda_kernel<0, false>, grid, dim3(256), fp, dp, ra, d_depth_out, nrm);
+    }
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
+}
+
+extern "C" int vh_raycast(vh_context *c, const float pose[16], float t_min, float t_max, float *d_depth_out)
+{
+    return raycast_impl(c, pose, t_min, t_max, d_depth_out, nullptr);
+}
+
+extern "C" int vh_raycast_normals(vh_context *c, const float pose[16], float t_min, float t_max, float *d_depth_out,
+                                  vh_float4 *d_normals_out)
+{
+    if (!d_normals_out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    return raycast_impl(c, pose, t_min, t_max, d_depth_out, d_normals_out);
 }
 
 // Block silhouettes: SDFRenderer::drawToFrontAndBack, SDFRenderer.cpp:165-208.

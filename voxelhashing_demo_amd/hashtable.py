@@ -148,6 +148,17 @@ class SDFHashtable:
         L.check(self._lib.vh_raycast(self._h, pp, t_min, t_max, _dev_ptr(out)), "vh_raycast")
         return out
 
+    def raycast_normals(self, pose, out, normals, t_min: float = 0.1, t_max: float = 5.0):
+        """The DDA raycast with the camera-frame normal map [H, W, 4] of the hits written by the same pass."""
+        _, pp = _pose16(pose)
+        L.check(self._lib.vh_raycast_normals(self._h, pp, t_min, t_max, _dev_ptr(out), _dev_ptr(normals)),
+                "vh_raycast_normals")
+        return out, normals
+
+    def set_raycast_mode(self, mode: int):
+        """RAYCAST_DDA (default) / RAYCAST_FIXED_STEP."""
+        self.set_option("raycast_mode", int(mode))
+
     def raycast_maps(self, pose, depth, vertices, normals, t_min: float = 0.1, t_max: float = 5.0):
         """raycast + camera-frame vertex and normal maps of the same view (an ICP target)."""
         _, pp = _pose16(pose)
