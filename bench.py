@@ -644,14 +644,15 @@ def raycast_roofline(workload, kernel_us, Wd, Ht):
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get(workload + "_raycast", {})
         valu_per_wave = pmc.get("raycast_kernel_valu_per_wave")
+        kernel = pmc.get("kernel", "raycast_kernel")
     except Exception:
-        valu_per_wave = None
+        valu_per_wave, kernel = None, "raycast_dda_kernel"
     waves = math.ceil(Wd / 16) * math.ceil(Ht / 16) * 4
     if not valu_per_wave or kernel_us <= 0:
-        return dict(bound="valu-issue", kernel="raycast_kernel", achieved=None, peak=round(peak, 1),
+        return dict(bound="valu-issue", kernel=kernel, achieved=None, peak=round(peak, 1),
                     unit="G wave-instr/s", frac=None, traffic=None, note="no VALU count in profiles/pmc_latest.json")
     achieved = valu_per_wave * waves / (kernel_us * 1e-6) / 1e9
-    return dict(bound="valu-issue", kernel="raycast_kernel", achieved=round(achieved, 1), peak=round(peak, 1),
+    return dict(bound="valu-issue", kernel=kernel, achieved=round(achieved, 1), peak=round(peak, 1),
                 unit="G wave-instr/s", frac=round(achieved / peak, 4), traffic=None, valu_per_wave=valu_per_wave, waves=waves,
                 us_per_launch=round(kernel_us, 2))
 

@@ -313,6 +313,9 @@ int vh_download_range(vh_context *ctx, int which, size_t offset_bytes, void *hos
 /* test hook: evaluates the device scalar helpers on n points; writes 8 int32 per
  * point: block x,y,z, hash, blockInFrustum, project() x,y, float->int of .w */
 int vh_debug_eval(vh_context *ctx, const vh_float4 *d_points, int32_t n, int32_t *d_out);
+/* diagnostics hook: the DDA raycast records per wave {start, end (100 MHz clock), voxel steps + jumps of lane 0,
+ * pixel patch x | y << 16} in d_stamps (4 uint64 per wave, workgroups in launch order); NULL = off */
+int vh_debug_set_raycast_stamps(vh_context *ctx, void *d_stamps);
 
 /* Options.  Tuning knobs for A/B measurements, results never change: "fused_frame" (1: two launches
  * per frame, 0: the four step kernels), "flatten_variant" (3 = the walk over every VoxelEntry, default;

@@ -49,9 +49,10 @@ for wl in sys.argv[2:]:
     if os.path.exists(valu):
         v = json.load(open(valu))
         for k, cs in v.items():
-            if k.startswith("raycast_kernel") and "SQ_INSTS_VALU" in cs and "SQ_WAVES" in cs:
+            if k.startswith(("raycast_dda_kernel", "raycast_kernel")) and "SQ_INSTS_VALU" in cs and "SQ_WAVES" in cs:
                 out[wl + "_raycast"] = {
                     "source": f"{src}: rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES, bench.py --legs raycast --workload {wl}",
+                    "kernel": k.split("<")[0].split("(")[0],
                     "raycast_kernel_valu_insts": cs["SQ_INSTS_VALU"]["mean"], "raycast_kernel_waves": cs["SQ_WAVES"]["mean"],
                     "raycast_kernel_valu_per_wave": round(cs["SQ_INSTS_VALU"]["mean"] / max(1.0, cs["SQ_WAVES"]["mean"]), 1)}
 json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of one DDA raycast launch on C2 (vh_debug_set_raycast_stamps): when each wave started and ended
+on the 100 MHz constant clock, so that dispatch ramp, mean wave lifetime and the tail can be told apart."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import voxelhashing_demo_amd as V
+from bench import WORKLOADS
+from voxelhashing_demo_amd import synth
+wl = WORKLOADS["C2"]
+poses = synth.camera_loop(500)[:120]
+prims = synth.room_primitives()
+t = V.SDFHashtable(V.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"]), 640, 480, V.SEM_PINHOLE)
+for p in poses:
+    t.integrate(p, synth.render_room_verts(p, 640, 480, prims, device="cuda"))
+depth = torch.empty((480, 640), dtype=torch.float32, device="cuda")
+nw = 40 * 30 * 4
+st = torch.zeros((nw, 4), dtype=torch.int64, device="cuda")
+for i in range(5):
+    t.raycast(poses[(7 * i) % 120], depth)
+t.synchronize()
+L = V.load()
+for k in (0, 35, 77):
+    assert L.vh_debug_set_raycast_stamps(t._h, st.data_ptr()) == 0
+    t.raycast(poses[k], depth)
+    t.synchronize()
+    L.vh_debug_set_raycast_stamps(t._h, None)
+    s = st.cpu().numpy()
+    t0 = s[:, 0].min()
+    start, end = (s[:, 0] - t0) / 100.0, (s[:, 1] - t0) / 100.0          # microseconds
+    life = end - start
+    print(f"pose {k}: kernel span {end.max():.1f} us; wave start: median {np.median(start):.1f} p90 {np.percentile(start, 90):.1f} max {start.max():.1f}; "
+          f"lifetime: mean {life.mean():.1f} median {np.median(life):.1f} p90 {np.percentile(life, 90):.1f} p99 {np.percentile(life, 99):.1f} max {life.max():.1f} us")
+    order = np.argsort(-life)[:6]
+    print("   slowest waves (life us, start us, steps of lane 0, patch x,y):",
+          [(round(float(life[i]), 1), round(float(start[i]), 1), int(s[i, 2]), int(s[i, 3] & 0xffff), int(s[i, 3] >> 16)) for i in order])
+    h, _ = np.histogram(end, bins=10, range=(0, end.max()))
+    print("   waves ending per tenth of the span:", h.tolist())

@@ -102,6 +102,7 @@ SIGNATURES = {
     "vh_integrate_depth": (C.c_int, [_vp, _fp, _vp, _fp]),
     "vh_raycast": (C.c_int, [_vp, _fp, _f, _f, _vp]),
     "vh_raycast_normals": (C.c_int, [_vp, _fp, _f, _f, _vp, _vp]),
+    "vh_debug_set_raycast_stamps": (C.c_int, [_vp, _vp]),
     "vh_render_blocks": (C.c_int, [_vp, _fp, _f, _f, _vp, _vp]),
     "vh_icp_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "vh_icp_destroy": (C.c_int, [_vp]),

@@ -537,6 +537,21 @@ static int raycast_impl(vh_context *c, const float pose[16], float t_min, float 
         if (!(steps < 4194304.0)) return fail(VH_ERR_INVALID_ARGUMENT, "view too deep for the voxel size (more than 2^22 voxel steps per ray) or not finite");
         ra.budget = (int)steps;
         ra.xcdAware = c->raycastXcd;
+        // The camera centre in voxel-grid units, and the domain: inside an allocated block the kernel steps the voxel
+        // coordinate as a float (exact below 2^24), so a view that can reach |coordinate| >= 2^23 is refused.
+        double reach = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            ra.G[a] = pose[4 * a + 3] / fp.voxelSize + 0.5f;
+            reach = std::max(reach, std::fabs((double)ra.G[a]) + std::fabs((double)t_max) *
+                                        (std::fabs((double)pose[4 * a]) * mdx + std::fabs((double)pose[4 * a + 1]) * mdy +
+                                         std::fabs((double)pose[4 * a + 2])) / (double)fp.voxelSize + std::fabs((double)t_min) *
+                                        (std::fabs((double)pose[4 * a]) * mdx + std::fabs((double)pose[4 * a + 1]) * mdy +
+                                         std::fabs((double)pose[4 * a + 2])) / (double)fp.voxelSize);
+        }
+        if (!(reach < 8388608.0)) return fail(VH_ERR_INVALID_ARGUMENT, "view reaches beyond 2^23 voxels from the origin");
+        ra.invVs = 1.0f / fp.voxelSize;
+        ra.stamps = reinterpret_cast<unsigned long long *>(c->raycastStamps);
+        ra.beam = (c->raycastBeam && t_min > 0.0f) ? 1 : 0;
         float4 *nrm = reinterpret_cast<float4 *>(d_normals_out);
         if (nrm)
             rc = c->raycastPatch ? launch(c, kPhaseRaycast, raycast_dda_kernel<1, true>, grid, dim3(256), fp, dp, ra, d_depth_out, nrm)

@@ -428,6 +428,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (std::strcmp(name, "fused_frame") == 0) { c->fusedFrame = value; return VH_OK; }
     if (std::strcmp(name, "raycast_patch") == 0) { c->raycastPatch = value; return VH_OK; }
     if (std::strcmp(name, "raycast_xcd") == 0) { c->raycastXcd = value; return VH_OK; }
+    if (std::strcmp(name, "raycast_beam") == 0) { c->raycastBeam = value != 0; return VH_OK; }
     if (std::strcmp(name, "raycast_mode") == 0 && (value == VH_RAYCAST_DDA || value == VH_RAYCAST_FIXED_STEP)) {
         c->raycastMode = value;
         return VH_OK;
@@ -493,6 +494,15 @@ extern "C" int vh_get_kernel_times(vh_context *c, vh_kernel_times *out, int rese
     if (rc != VH_OK) return rc;
     *out = c->times;
     if (reset) c->times = vh_kernel_times{};
+    return VH_OK;
+}
+
+// diagnostics hook (tools/raycast_stamps.py): the DDA raycast writes {start, end (s_memrealtime, 100 MHz), steps, patch}
+// per wave into d_stamps (4 uint64 per wave, waves in workgroup order); NULL switches it off
+extern "C" int vh_debug_set_raycast_stamps(vh_context *c, void *d_stamps)
+{
+    if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
+    c->raycastStamps = d_stamps;
     return VH_OK;
 }
 

@@ -158,15 +158,15 @@ __global__ __launch_bounds__(256) void raycast_kernel(const FrameParams fp, cons
 // visited voxel of an allocated block with weight > 0 is a sample placed at the camera depth of the voxel's
 // centre; first + -> - pair of consecutive valid samples = surface, linear interpolation.
 //
-// Because the state of the walk is (integer voxel, tnext of three integer coordinates), leaving an empty cell
-// in ONE step can be made exact: the exit event is the first of the cell's three boundary events in merge order,
-// and every other axis advances past exactly those of its events that precede it (a float estimate of the
-// coordinate, then the merge predicate itself decides, so the estimate's rounding never matters).  The image
-// therefore does not depend on which cells are skipped, and the kernel may skip on hashed bitmaps whose stale or
-// colliding bits only make it skip less: an empty 4x4x4-block macro cell (32 voxels) or an absent block (8).
-// Instruction budget per ray on C2 (PMC, profiles/): a handful of macro-cell jumps, a few block look-ups, then
-// ~10-20 voxel steps of ~30 VALU instructions inside the surface block -- against 40 fully re-derived samples
-// (4x4 transform, three IEEE divisions, three floor divisions: ~100 instructions each) of the fixed-step march.
+// Because the state of the walk is (integer voxel, tnext of three integer coordinates) and the order of the
+// crossing events is a total order, the state after ANY prefix of the events can be computed directly:
+//   * leaving an empty cell in one step: the exit event is the first of the cell's three boundary events, every
+//     other axis advances past exactly those of its events that precede it (dda_advance: a float estimate of the
+//     coordinate, then the merge predicate itself decides, so the estimate's rounding never matters);
+//   * starting at a later depth tau: every axis advances past its events with t < tau (dda_start).
+// The image therefore does not depend on what is skipped, as long as nothing allocated is: the kernel skips on
+// hashed bitmaps whose stale or colliding bits only make it skip less -- empty 4x4x4-block macro cells (32
+// voxels), absent blocks (8) -- and on a conservative beam test that the 64 rays of a wave share (below).
 struct DdaAxis {
     float G, E, invE, Gs;     // invE = 0: the axis never steps (|E| <= 1e-20)
     int s;                    // +1 / -1
@@ -196,12 +196,28 @@ __device__ __forceinline__ int dda_advance(const DdaAxis &ax, int prioB, int cur
     return e;
 }
 
+// the coordinate of axis b once every event with t < tau has been taken, starting from `cur` (its coordinate at
+// t_min): the first c from `cur` on, in the axis' direction, whose own crossing is not before tau
+__device__ __forceinline__ int dda_start(const DdaAxis &ax, int cur, float tau)
+{
+    if (ax.invE == 0.0f) return cur;
+    int e = f2i_rz(__builtin_floorf(ax.G + ax.E * tau));
+    e = ax.s > 0 ? max(e, cur) : min(e, cur);
+    while (dda_tnext(ax, e) < tau) e += ax.s;
+    while (e != cur && !(dda_tnext(ax, e - ax.s) < tau)) e -= ax.s;
+    return e;
+}
+
 struct RaycastArgs {
     float fx, fy, cx, cy;
     float tMin, tMax;
     float zrow[4];            // row 2 of the inverse pose, first three scaled by voxelSize: camera depth of a voxel centre
+    float G[3];               // pose translation / voxelSize + 0.5: the camera centre in voxel-grid units (same for every ray)
+    float invVs;              // 1 / voxelSize (beam boxes only)
     int budget;               // hang guard: more steps than any ray of this view can take (host: vh_raycast)
     int xcdAware;
+    int beam;                 // 0: no beam front end (A/B, and views with t_min <= 0)
+    unsigned long long *stamps;   // diagnostics (tools/raycast_stamps.py): per wave {start, end} of s_memrealtime (100 MHz), or null
 };
 
 // voxel (vx,vy,vz) if its block is allocated and its weight > 0 (normals: the neighbours of the hit voxel)
@@ -217,11 +233,103 @@ __device__ __forceinline__ bool dda_voxel(const FrameParams &fp, const DevPtrs &
     return s.weight > 0.0f;
 }
 
+// Beam front end.  The 64 rays of a wave (an 8x8 or 16x4 pixel patch) are nearly parallel and a few voxels apart,
+// and each of them spends most of its look-ups on the empty space in front of the first surface.  That part of
+// the march is done ONCE per wave and in parallel instead of 64 times in sequence: lane i takes slab i of the
+// depth range, bounds the part of the beam (all rays of the patch) inside the slab by a box in voxel-grid units,
+// and tests the cells that box touches -- one load round trip for all 64 slabs; the first slab with a set bit
+// (ballot) gives a depth tau before which no ray of the wave can meet an allocated block, and every lane starts
+// its own exact walk there (dda_start).  Level 1 tests macro-cell bits over the whole range, level 2 bucket bits
+// in half-block slabs behind it.  Conservative by construction: the box is grown by 2 % of a voxel plus 1e-5 of
+// its coordinates (the rounding of this arithmetic and of the walk's crossing times is 1e-7 of them), a box that
+// touches more than 27 cells counts as occupied.
+struct Beam {
+    float dx0, dx1, dy0, dy1;             // direction bounds of the patch's rays, camera frame (z = 1)
+};
+
+// kLevel 1: macro-cell bits (cells of 32 voxels); 2: bucket bits of the blocks (8 voxels)
+template <int kLevel>
+__device__ __forceinline__ bool beam_slab_occupied(const FrameParams &fp, const DevPtrs &dp, const RaycastArgs &ra,
+                                                   const Beam &bm, float ta, float tb)
+{
+    // camera-frame box of the beam between depths ta and tb
+    const float xa0 = bm.dx0 * ta, xa1 = bm.dx0 * tb, xb0 = bm.dx1 * ta, xb1 = bm.dx1 * tb;
+    const float ya0 = bm.dy0 * ta, ya1 = bm.dy0 * tb, yb0 = bm.dy1 * ta, yb1 = bm.dy1 * tb;
+    const float lo[3] = {__builtin_fminf(__builtin_fminf(xa0, xa1), __builtin_fminf(xb0, xb1)),
+                         __builtin_fminf(__builtin_fminf(ya0, ya1), __builtin_fminf(yb0, yb1)), __builtin_fminf(ta, tb)};
+    const float hi[3] = {__builtin_fmaxf(__builtin_fmaxf(xa0, xa1), __builtin_fmaxf(xb0, xb1)),
+                         __builtin_fmaxf(__builtin_fmaxf(ya0, ya1), __builtin_fmaxf(yb0, yb1)), __builtin_fmaxf(ta, tb)};
+    const float invVs = ra.invVs;                 // (approximate is fine: the box is grown)
+    constexpr int kShift = kLevel == 1 ? 5 : 3;
+    int c0[3], c1[3];
+    bool huge = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float wl = 0.0f, wh = 0.0f;                   // R_a . box, interval arithmetic
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float r = fp.T[4 * a + j] * invVs;
+            const float p = r * lo[j], q = r * hi[j];
+            wl += __builtin_fminf(p, q);
+            wh += __builtin_fmaxf(p, q);
+        }
+        const float gl = ra.G[a] + wl, gh = ra.G[a] + wh;
+        const float m = 0.02f + 1.0e-5f * __builtin_fmaxf(__builtin_fabsf(gl), __builtin_fabsf(gh));
+        c0[a] = f2i_rz(__builtin_floorf(gl - m)) >> kShift;
+        c1[a] = f2i_rz(__builtin_floorf(gh + m)) >> kShift;
+        huge |= !(c1[a] - c0[a] <= 2) || !(gl == gl) || !(gh == gh);      // more than 3 cells on an axis, or NaN
+    }
+    if (huge) return true;
+    bool any = false;
+    for (int z = c0[2]; z <= c1[2]; ++z)
+        for (int y = c0[1]; y <= c1[1]; ++y)
+            for (int x = c0[0]; x <= c1[0]; ++x) {
+                if (kLevel == 1) {
+                    const uint32_t hm = macro_hash(x, y, z);
+                    any |= ((dp.macroBits[hm >> 5] >> (hm & 31u)) & 1u) != 0u;
+                } else {
+                    const uint32_t h = hash_block(x, y, z, fp.numBuckets);
+                    if (h >= fp.bucketLo && h < fp.bucketHi) {
+                        const uint32_t local = h - fp.bucketLo;
+                        any |= ((dp.bucketBits[local >> 5] >> (local & 31u)) & 1u) != 0u;
+                    }
+                }
+            }
+    return any;
+}
+
+// Shape of the kernel.  A ray's work is small (C2: ~4 macro-cell jumps, ~4 block look-ups, 1.5 allocated blocks,
+// ~9 voxels) but every piece is a dependent memory round trip, and the 64 rays of a wave are each at a different
+// piece at any moment: a loop that lets every lane do "its next thing" executes the jump path AND a whole block
+// walk per iteration (first version: 67 us on C2, slower than the fixed-step march's 47).  So, after the beam
+// front end, the wave alternates between two phases that every lane runs together:
+//   skip   every lane that does not stand in an allocated block looks its cell up (macro-cell bit and bucket bit
+//          fetched together, then the bucket's entries) and leaves it in one exact step if it is empty -- until no
+//          lane of the wave needs a look-up;
+//   walk   every lane that stands in an allocated block walks it: up to kDdaChunk voxel steps of pure arithmetic
+//          (the walk does not depend on the voxels' contents), then the voxel loads together (one round trip
+//          instead of kDdaChunk), then the samples are judged in order -- until no lane is inside a block.
+// Inside a block the walk keeps the voxel as float coordinates (exact below 2^24: the host refuses views beyond
+// 2^23), the local position as three 5-bit fields (value 8..15 = inside; one mask test tells when the ray has
+// left the block) packed with the linear voxel index, and steps all of it without a branch.
+#ifndef VH_DDA_CHUNK
+#define VH_DDA_CHUNK 8
+#endif
+#ifndef VH_DDA_BLOCKS
+#define VH_DDA_BLOCKS 4
+#endif
+constexpr int kDdaBlocks = VH_DDA_BLOCKS;
+#ifndef VH_DDA_WAVES
+#define VH_DDA_WAVES 4      // waves per SIMD the register budget must allow (4 800 waves of a 640x480 view = 4.7 per SIMD; 4 vs 5 vs 6 measured equal: the launch is as long as its slowest wave)
+#endif
+constexpr int kDdaChunk = VH_DDA_CHUNK;
+
 template <int kPatch, bool kNormals>
-__global__ __launch_bounds__(256) void raycast_dda_kernel(const FrameParams fp, const DevPtrs dp, const RaycastArgs ra,
+__global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const FrameParams fp, const DevPtrs dp, const RaycastArgs ra,
                                                           float *__restrict__ depthOut, float4 *__restrict__ normalOut)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long stamp0 = ra.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     int tx = blockIdx.x, ty = blockIdx.y;
     if (ra.xcdAware) {                       // each XCD (own L2) renders a contiguous run of image tiles
         const int n = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
@@ -231,97 +339,264 @@ __global__ __launch_bounds__(256) void raycast_dda_kernel(const FrameParams fp, 
             tx = r - ty * (int)gridDim.x;
         }
     }
-    const int u = tx * 16 + (kPatch == 0 ? (int)(threadIdx.x & 15) : (wave & 1) * 8 + (lane & 7));
-    const int v = ty * 16 + (kPatch == 0 ? (int)(threadIdx.x >> 4) : (wave >> 1) * 8 + (lane >> 3));
-    if (u >= fp.width || v >= fp.height) return;
+    // the wave's pixel patch
+    const int pu = tx * 16 + (kPatch == 0 ? 0 : (wave & 1) * 8), pv = ty * 16 + (kPatch == 0 ? wave * 4 : (wave >> 1) * 8);
+    const int u = pu + (kPatch == 0 ? (lane & 15) : (lane & 7));
+    const int v = pv + (kPatch == 0 ? (lane >> 4) : (lane >> 3));
+    const bool inImage = u < fp.width && v < fp.height;
     const float dx = ((float)u - ra.cx) / ra.fx;
     const float dy = ((float)v - ra.cy) / ra.fy;
     const float vs = fp.voxelSize;
     DdaAxis ax[3];
     int c[3];
-    float tn[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const float D = fp.T[4 * a + 0] * dx + fp.T[4 * a + 1] * dy + fp.T[4 * a + 2];
-        ax[a].G = fp.T[4 * a + 3] / vs + 0.5f;
+        ax[a].G = ra.G[a];
         ax[a].E = D / vs;
         const bool active = __builtin_fabsf(ax[a].E) > 1.0e-20f;
         ax[a].invE = active ? 1.0f / ax[a].E : 0.0f;
         ax[a].s = ax[a].E > 0.0f ? 1 : -1;
         ax[a].Gs = ax[a].E > 0.0f ? ax[a].G - 1.0f : ax[a].G;
         c[a] = f2i_rz(__builtin_floorf(ax[a].G + ax[a].E * ra.tMin));
-        tn[a] = dda_tnext(ax[a], c[a]);
+    }
+    bool live = inImage;
+    // ---- beam front end: the depth before which no ray of this wave can meet an allocated block ----
+    if (ra.beam) {
+        Beam bm;
+        // (the corner rays' directions are those of the patch's corner lanes: no division here)
+        const float a0 = __shfl(dx, 0), a1 = __shfl(dx, kPatch == 0 ? 15 : 7);
+        const float b0 = __shfl(dy, 0), b1 = __shfl(dy, kPatch == 0 ? 48 : 56);
+        bm.dx0 = __builtin_fminf(a0, a1); bm.dx1 = __builtin_fmaxf(a0, a1);
+        bm.dy0 = __builtin_fminf(b0, b1); bm.dy1 = __builtin_fmaxf(b0, b1);
+        float tau = ra.tMin;
+        const float range = ra.tMax - ra.tMin;
+        const float dt2 = 4.0f * vs;                                   // level 2: half-block slabs
+        if (64.0f * dt2 < range) {                                      // level 1 pays when level 2 cannot span the range
+            const float dt1 = range * (1.0f / 64.0f);
+            const float ta = ra.tMin + (float)lane * dt1;
+            const bool occ = beam_slab_occupied<1>(fp, dp, ra, bm, ta - 1.0e-4f * dt1, ta + 1.0001f * dt1);
+            const unsigned long long m = __ballot(occ);
+            if (m == 0ull) live = false;                                // no macro cell with a block along any ray
+            else tau = ra.tMin + (float)(__ffsll((long long)m) - 1) * dt1;
+        }
+        if (__ballot(live) != 0ull) {
+            const float ta = tau + (float)lane * dt2;
+            const bool occ = ta < ra.tMax && beam_slab_occupied<2>(fp, dp, ra, bm, ta - 1.0e-4f * dt2, ta + 1.0001f * dt2);
+            const unsigned long long m = __ballot(occ);
+            const float t2 = tau + (m == 0ull ? 64.0f : (float)(__ffsll((long long)m) - 1)) * dt2;
+            if (!(t2 < ra.tMax)) live = false;                          // nothing allocated before the rays end
+            else tau = t2;
+        }
+        if (live && tau > ra.tMin) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) c[a] = dda_start(ax[a], c[a], tau);
+        }
     }
     const int prio[3] = {2, 0, 1};
-    bool prevValid = false, found = false, done = false;
-    float prevSdf = 0.0f, prevT = 0.0f, hit = 0.0f;
-    int hx = 0, hy = 0, hz = 0, hptr = VH_FREE_BLOCK;          // the hit voxel and its block (normals)
-    bool haveMacro = false, macroEmpty = false;
-    int cmx = 0, cmy = 0, cmz = 0;
+    bool atBlock = false, prevValid = false, found = false;
+    float prevSdf = 0.0f, hit = 0.0f;
+    int hx = 0, hy = 0, hz = 0, hptr = VH_FREE_BLOCK;          // the last valid sample's voxel; after a hit: the hit voxel and its block
+    int cptr = VH_FREE_BLOCK, kx = 0, ky = 0, kz = 0;          // the allocated block the ray stands in
     int budget = ra.budget;
-    while (!done && budget > 0) {
-        // ---- the cell the ray stands in: macro cell first, then the block ----
-        const int kx = c[0] >> 3, ky = c[1] >> 3, kz = c[2] >> 3;          // voxel2Block for two's complement ints
-        const int mx = kx >> 2, my = ky >> 2, mz = kz >> 2;
-        if (!haveMacro || mx != cmx || my != cmy || mz != cmz) {
-            cmx = mx; cmy = my; cmz = mz;
-            haveMacro = true;
-            const uint32_t hm = macro_hash(mx, my, mz);
-            macroEmpty = !((dp.macroBits[hm >> 5] >> (hm & 31u)) & 1u);
-        }
-        const int cptr = macroEmpty ? VH_FREE_BLOCK : lookup_block(fp, dp, kx, ky, kz);
-        if (cptr == VH_FREE_BLOCK) {
-            // ---- leave the empty cell in one step ----
-            --budget;
-            prevValid = false;
-            const int shift = macroEmpty ? 5 : 3, span = macroEmpty ? 31 : 7;
-            int cs[3];
-            float te[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                cs[a] = (int)((uint32_t)(c[a] >> shift) << shift) + (ax[a].s > 0 ? span : 0);   // last coordinate inside the cell
-                te[a] = dda_tnext(ax[a], cs[a]);
-            }
-            const int x = (te[0] < te[1] && te[0] < te[2]) ? 0 : (te[2] < te[1]) ? 2 : 1;
-            const float tex = x == 0 ? te[0] : x == 1 ? te[1] : te[2];
-            if (!(tex < ra.tMax)) { done = true; break; }            // the ray ends inside the empty cell
-            const int px = x == 0 ? 2 : x == 1 ? 0 : 1;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                c[a] = (a == x) ? cs[a] + ax[a].s : dda_advance(ax[a], prio[a], c[a], cs[a], tex, px);
-                tn[a] = dda_tnext(ax[a], c[a]);
-            }
-            continue;
-        }
-        // ---- an allocated block: voxel by voxel until the ray leaves it ----
+    // skip phase: the ray stands in voxel c (haveVoxel) or, after absent blocks, at block (bk0, bk1, bk2), entered at
+    // event (entryT, axis entryX)
+    bool haveVoxel = true;
+    int bk0 = 0, bk1 = 0, bk2 = 0, entryX = -1;
+    float entryT = 0.0f;
+    while (__ballot(live) != 0ull) {
+        // ---- skip: block by block until every live lane stands in an allocated block ----
+        // A block-level DDA: the crossing out of block coordinate k on axis a is the voxel-level event out of the
+        // block's last coordinate on that axis, again a pure function of an integer, and the block-boundary events are
+        // a subsequence of the voxel events -- so merging them in the same order visits exactly the blocks the voxel
+        // walk visits, at ~25 instructions per block instead of an exact cell exit (two dda_advance) each.  The voxel
+        // coordinates are rebuilt only when an allocated block is entered: on the entry axis the block's first
+        // coordinate, on the others the first coordinate of the block whose own crossing is not before the entry event.
+        // kDdaBlocks blocks ahead are enumerated without a memory access, their bucket bits fetched together, then
+        // judged in order.
         for (;;) {
-            --budget;
-            const Voxel s = dp.blocks[(size_t)cptr + (size_t)(((c[2] & 7) << 6) | ((c[1] & 7) << 3) | (c[0] & 7))];
-            const float tc = ((ra.zrow[0] * (float)c[0] + ra.zrow[1] * (float)c[1]) + ra.zrow[2] * (float)c[2]) + ra.zrow[3];
-            const int vx = c[0], vy = c[1], vz = c[2];
-            // the crossing that ends this voxel (raycastSDF.frag:156-170), taken before the sample is looked at:
-            // the step does not depend on the voxel's contents, so it runs under the load
-            const int a = (tn[0] < tn[1] && tn[0] < tn[2]) ? 0 : (tn[2] < tn[1]) ? 2 : 1;
-            const float tOut = a == 0 ? tn[0] : a == 1 ? tn[1] : tn[2];
-            bool left;
-            if (a == 0) { c[0] += ax[0].s; tn[0] = dda_tnext(ax[0], c[0]); left = (c[0] >> 3) != kx; }
-            else if (a == 1) { c[1] += ax[1].s; tn[1] = dda_tnext(ax[1], c[1]); left = (c[1] >> 3) != ky; }
-            else { c[2] += ax[2].s; tn[2] = dda_tnext(ax[2], c[2]); left = (c[2] >> 3) != kz; }
-            if (s.weight > 0.0f) {
-                if (prevValid && prevSdf > 0.0f && s.sdf <= 0.0f) {
-                    hit = prevT + ((tc - prevT) * prevSdf) / (prevSdf - s.sdf);
-                    found = true; done = true;
-                    hx = vx; hy = vy; hz = vz; hptr = cptr;
-                    break;
+            const bool need = live && !atBlock;
+            if (__ballot(need) == 0ull) break;
+            if (!need) continue;
+            int kb[3] = {c[0] >> 3, c[1] >> 3, c[2] >> 3};                   // voxel2Block for two's complement ints
+            if (!haveVoxel) { kb[0] = bk0; kb[1] = bk1; kb[2] = bk2; }
+            float tb0 = dda_tnext(ax[0], (kb[0] << 3) + (ax[0].s > 0 ? 7 : 0));
+            float tb1 = dda_tnext(ax[1], (kb[1] << 3) + (ax[1].s > 0 ? 7 : 0));
+            float tb2 = dda_tnext(ax[2], (kb[2] << 3) + (ax[2].s > 0 ? 7 : 0));
+            int ck[kDdaBlocks][3];
+            float ct[kDdaBlocks];
+            int cx[kDdaBlocks];
+            uint32_t cl[kDdaBlocks], cw[kDdaBlocks];
+            int nc = 0;
+            bool more = true, ends = false;
+            float tE = entryT;
+            int xE = haveVoxel ? -1 : entryX;
+#pragma unroll
+            for (int j = 0; j < kDdaBlocks; ++j) {
+                if (more) {
+                    ck[j][0] = kb[0]; ck[j][1] = kb[1]; ck[j][2] = kb[2];
+                    ct[j] = tE; cx[j] = xE;
+                    const uint32_t h = hash_block(kb[0], kb[1], kb[2], fp.numBuckets);
+                    const bool mine = h >= fp.bucketLo && h < fp.bucketHi;
+                    cl[j] = mine ? h - fp.bucketLo : ~0u;
+                    cw[j] = mine ? dp.bucketBits[(h - fp.bucketLo) >> 5] : 0u;
+                    nc = j + 1;
+                    // the crossing that ends this block
+                    const bool m0 = tb0 < tb1 && tb0 < tb2;
+                    const bool m2 = !m0 && tb2 < tb1;
+                    const bool m1 = !m0 && !m2;
+                    tE = m0 ? tb0 : m2 ? tb2 : tb1;
+                    xE = m0 ? 0 : m2 ? 2 : 1;
+                    kb[0] += m0 ? ax[0].s : 0; kb[1] += m1 ? ax[1].s : 0; kb[2] += m2 ? ax[2].s : 0;
+                    if (m0) tb0 = dda_tnext(ax[0], (kb[0] << 3) + (ax[0].s > 0 ? 7 : 0));
+                    else if (m1) tb1 = dda_tnext(ax[1], (kb[1] << 3) + (ax[1].s > 0 ? 7 : 0));
+                    else tb2 = dda_tnext(ax[2], (kb[2] << 3) + (ax[2].s > 0 ? 7 : 0));
+                    ends = !(tE < ra.tMax);
+                    more = !ends;
                 }
-                prevValid = true; prevSdf = s.sdf; prevT = tc;
-            } else {
-                prevValid = false;
             }
-            if (!(tOut < ra.tMax)) { done = true; break; }
-            if (left || budget <= 0) break;
+            budget -= nc;
+            // judged in order: the first candidate whose bucket holds its key
+            int got = -1, ptr = VH_FREE_BLOCK;
+#pragma unroll
+            for (int j = 0; j < kDdaBlocks; ++j) {
+                if (j < nc && got < 0 && cl[j] != ~0u && ((cw[j] >> (cl[j] & 31u)) & 1u)) {
+                    const int qx = ck[j][0], qy = ck[j][1], qz = ck[j][2];
+                    if (fp.flags & kFlagOverflow) {
+                        uint32_t prev;
+                        const uint32_t at = find_entry_overflow(fp, dp.table, owned_entries(fp), cl[j], qx, qy, qz, prev);
+                        if (at != ~0u) { ptr = dp.table[at].ptr; got = j; }
+                    } else {
+                        const VoxelEntry *bucket = dp.table + (size_t)cl[j] * fp.bucketSize;
+                        for (uint32_t i = 0; i < fp.bucketSize; ++i) {        // getVoxelEntry4Block, VoxelUtils.cu:362-382
+                            const VoxelEntry e = bucket[i];
+                            if (e.ptr == VH_FREE_BLOCK) break;                // prefix property
+                            if (e.pos[0] == qx && e.pos[1] == qy && e.pos[2] == qz) { ptr = e.ptr; got = j; break; }
+                        }
+                    }
+                }
+            }
+            if (got < 0) {
+                // nothing allocated among them: the ray stands at the block behind the last candidate (or has ended)
+                prevValid = false;
+                if (ends || budget < 0) { live = false; continue; }
+                haveVoxel = false;
+                bk0 = kb[0]; bk1 = kb[1]; bk2 = kb[2];
+                entryT = tE; entryX = xE;
+                continue;
+            }
+            int gk[3] = {ck[0][0], ck[0][1], ck[0][2]};
+            float gT = ct[0];
+            int gX = cx[0];
+#pragma unroll
+            for (int j = 1; j < kDdaBlocks; ++j)
+                if (got == j) { gk[0] = ck[j][0]; gk[1] = ck[j][1]; gk[2] = ck[j][2]; gT = ct[j]; gX = cx[j]; }
+            if (got > 0) prevValid = false;
+            if (gX >= 0) {
+                // voxel coordinates at the entry event (gT, axis gX)
+                const int pX = gX == 0 ? 2 : gX == 1 ? 0 : 1;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int nearC = (gk[a] << 3) + (ax[a].s > 0 ? 0 : 7), farC = (gk[a] << 3) + (ax[a].s > 0 ? 7 : 0);
+                    c[a] = (a == gX) ? nearC : (ax[a].invE == 0.0f ? c[a] : dda_advance(ax[a], prio[a], nearC, farC, gT, pX));
+                }
+            }
+            kx = gk[0]; ky = gk[1]; kz = gk[2];
+            cptr = ptr;
+            atBlock = true;
+        }
+        // ---- walk: the allocated blocks, a chunk of voxels at a time, until every lane has left its block ----
+        // float coordinates, crossing times, packed local position | linear index << 16
+        float fc0 = (float)c[0], fc1 = (float)c[1], fc2 = (float)c[2];
+        float tn0 = dda_tnext(ax[0], c[0]), tn1 = dda_tnext(ax[1], c[1]), tn2 = dda_tnext(ax[2], c[2]);
+        const float f0 = (float)ax[0].s, f1 = (float)ax[1].s, f2 = (float)ax[2].s;
+        // an axis that never steps: invE = 0 would give tnext = 0; (c + 2^100) * inf = inf instead
+        const float ie0 = ax[0].invE != 0.0f ? ax[0].invE : __builtin_inff(), gs0 = ax[0].invE != 0.0f ? ax[0].Gs : -1.0e30f;
+        const float ie1 = ax[1].invE != 0.0f ? ax[1].invE : __builtin_inff(), gs1 = ax[1].invE != 0.0f ? ax[1].Gs : -1.0e30f;
+        const float ie2 = ax[2].invE != 0.0f ? ax[2].invE : __builtin_inff(), gs2 = ax[2].invE != 0.0f ? ax[2].Gs : -1.0e30f;
+        const int d0 = ax[0].s * ((1 << 16) + 1), d1 = ax[1].s * ((8 << 16) + (1 << 5)), d2 = ax[2].s * ((64 << 16) + (1 << 10));
+        int pl = 0;
+        bool fresh = true;                       // pl has to be rebuilt from c (a new block)
+        for (;;) {
+            const bool walking = live && atBlock;
+            if (__ballot(walking) == 0ull) break;
+            if (!walking) continue;
+            if (fresh) {
+                const int lx = c[0] & 7, ly = c[1] & 7, lz = c[2] & 7;
+                pl = ((lx | (ly << 3) | (lz << 6)) << 16) | (lx + 8) | ((ly + 8) << 5) | ((lz + 8) << 10);
+                fresh = false;
+            }
+            int pls[kDdaChunk];
+            int n = 0;
+            bool more = true, ends = false, left = false;
+#pragma unroll
+            for (int k = 0; k < kDdaChunk; ++k) {
+                if (more) {
+                    pls[k] = pl;
+                    n = k + 1;
+                    // the crossing that ends this voxel (raycastSDF.frag:156-170): x only when strictly first, z before x
+                    // on a tie, y before both
+                    const bool m0 = tn0 < tn1 && tn0 < tn2;
+                    const bool m2 = !m0 && tn2 < tn1;
+                    const bool m1 = !m0 && !m2;
+                    const float tOut = m0 ? tn0 : m2 ? tn2 : tn1;
+                    pl += m0 ? d0 : m2 ? d2 : d1;
+                    fc0 += m0 ? f0 : 0.0f; fc1 += m1 ? f1 : 0.0f; fc2 += m2 ? f2 : 0.0f;
+                    tn0 = (fc0 - gs0) * ie0; tn1 = (fc1 - gs1) * ie1; tn2 = (fc2 - gs2) * ie2;
+                    left = (pl & 0x6318) != 0x2108;
+                    ends = !(tOut < ra.tMax);
+                    more = !ends && !left;
+                }
+            }
+            budget -= n;
+            Voxel s[kDdaChunk];
+#pragma unroll
+            for (int k = 0; k < kDdaChunk; ++k)
+                if (k < n) s[k] = dp.blocks[(size_t)cptr + (size_t)((uint32_t)pls[k] >> 16)];
+            // judged in order.  Only the two samples of the hit need their voxel coordinates (depth of the centres):
+            // the last valid sample is remembered as a linear index while it lies in this chunk (prevLin >= 0) and
+            // as coordinates (hx, hy, hz) once the chunk is left.
+            const int bx0 = kx << 3, by0 = ky << 3, bz0 = kz << 3;
+            int prevLin = -1;
+#pragma unroll
+            for (int k = 0; k < kDdaChunk; ++k) {
+                if (k < n && !found) {
+                    if (s[k].weight > 0.0f) {
+                        const int lin = (int)((uint32_t)pls[k] >> 16);
+                        if (prevValid && prevSdf > 0.0f && s[k].sdf <= 0.0f) {
+                            if (prevLin >= 0) { hx = bx0 + (prevLin & 7); hy = by0 + ((prevLin >> 3) & 7); hz = bz0 + (prevLin >> 6); }
+                            const int vx = bx0 + (lin & 7), vy = by0 + ((lin >> 3) & 7), vz = bz0 + (lin >> 6);
+                            // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
+                            const float tc = ((ra.zrow[0] * (float)vx + ra.zrow[1] * (float)vy) + ra.zrow[2] * (float)vz) + ra.zrow[3];
+                            const float tp = ((ra.zrow[0] * (float)hx + ra.zrow[1] * (float)hy) + ra.zrow[2] * (float)hz) + ra.zrow[3];
+                            hit = tp + ((tc - tp) * prevSdf) / (prevSdf - s[k].sdf);
+                            found = true;
+                            hx = vx; hy = vy; hz = vz; hptr = cptr;
+                        } else {
+                            prevValid = true; prevSdf = s[k].sdf; prevLin = lin;
+                        }
+                    } else {
+                        prevValid = false;
+                    }
+                }
+            }
+            if (!found && prevValid && prevLin >= 0) { hx = bx0 + (prevLin & 7); hy = by0 + ((prevLin >> 3) & 7); hz = bz0 + (prevLin >> 6); }
+            if (found || ends || budget < 0) { live = false; continue; }
+            if (left) {
+                // back to integer coordinates for the next look-up
+                c[0] = f2i_rz(fc0); c[1] = f2i_rz(fc1); c[2] = f2i_rz(fc2);
+                atBlock = false;
+                haveVoxel = true;
+                fresh = true;
+            }
         }
     }
+    if (ra.stamps && lane == 0) {
+        const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;
+        ra.stamps[w] = stamp0; ra.stamps[w + 1] = __builtin_amdgcn_s_memrealtime();
+        ra.stamps[w + 2] = (unsigned long long)(ra.budget - budget); ra.stamps[w + 3] = (unsigned long long)(pu | (pv << 16));
+    }
+    if (!inImage) return;
     depthOut[(size_t)v * fp.width + u] = hit;
     if (!kNormals) return;
     // ---- normal of the hit: TSDF gradient at the hit voxel, normalised, camera frame, w = 0 ----
