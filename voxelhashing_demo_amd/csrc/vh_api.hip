@@ -361,7 +361,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     VH_ALLOC(dp.candTarget, sizeof(uint32_t) * npix);
     VH_ALLOC(dp.gcMarks, sizeof(uint32_t) * ((c->numEntries + 31) / 32));
     VH_ALLOC(dp.compactMask, sizeof(uint32_t) * c->numEntries);
-    VH_ALLOC(dp.bucketBits, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32));
+    VH_ALLOC(dp.bucketBits, sizeof(uint32_t) * (((size_t)c->ownedBuckets + 31) / 32 + 1));   // (+1: the DDA raycast reads it with 8-byte loads)
     VH_ALLOC(dp.macroBits, kMacroBits / 8);
 #undef VH_ALLOC
 

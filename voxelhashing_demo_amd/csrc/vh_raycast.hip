@@ -394,203 +394,123 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
         }
     }
     const int prio[3] = {2, 0, 1};
-    bool atBlock = false, prevValid = false, found = false;
+    // ---- the walk: one cell per iteration, at block level (sh = 3) through absent blocks, at voxel level (sh = 0)
+    // inside allocated ones.  Both levels are the same merge of three monotone crossing-time sequences -- the
+    // crossing out of block coordinate k is the voxel-level event out of the block's last coordinate, so the block
+    // events are a subsequence of the voxel events and merging them in the same order visits exactly the blocks the
+    // voxel walk visits -- and one instruction sequence serves both: no lane waits for another lane's phase.  Voxel
+    // coordinates are rebuilt only when an allocated block is entered from an absent one: on the entry axis the
+    // block's first coordinate, on the others the first coordinate of the block whose own crossing is not before
+    // the entry event (dda_advance).
+    // The loop body is written as straight-line selects with ONE rare branch (a hit, or a bucket bit that is set):
+    // on this chip a wave's scalar instructions -- mask logic and the exec-mask bookkeeping of every divergent
+    // branch -- cost as much issue time as its vector instructions (one scalar unit per CU for four SIMDs), and the
+    // branchy form of this loop spent 3 000 scalar against 2 900 vector instructions per wave.  The voxel of an
+    // allocated block and the bucket-bit word of a block are fetched by the SAME load instruction (address select;
+    // the bitmap has a word of padding).
+    bool found = false;
+    int prevValid = 0;
     float prevSdf = 0.0f, hit = 0.0f;
     int hx = 0, hy = 0, hz = 0, hptr = VH_FREE_BLOCK;          // the last valid sample's voxel; after a hit: the hit voxel and its block
-    int cptr = VH_FREE_BLOCK, kx = 0, ky = 0, kz = 0;          // the allocated block the ray stands in
+    int cptr = 0, kx = 0, ky = 0, kz = 0;                      // the allocated block the ray stands in (voxel level)
     int budget = ra.budget;
-    // skip phase: the ray stands in voxel c (haveVoxel) or, after absent blocks, at block (bk0, bk1, bk2), entered at
-    // event (entryT, axis entryX)
-    bool haveVoxel = true;
-    int bk0 = 0, bk1 = 0, bk2 = 0, entryX = -1;
-    float entryT = 0.0f;
-    while (__ballot(live) != 0ull) {
-        // ---- skip: block by block until every live lane stands in an allocated block ----
-        // A block-level DDA: the crossing out of block coordinate k on axis a is the voxel-level event out of the
-        // block's last coordinate on that axis, again a pure function of an integer, and the block-boundary events are
-        // a subsequence of the voxel events -- so merging them in the same order visits exactly the blocks the voxel
-        // walk visits, at ~25 instructions per block instead of an exact cell exit (two dda_advance) each.  The voxel
-        // coordinates are rebuilt only when an allocated block is entered: on the entry axis the block's first
-        // coordinate, on the others the first coordinate of the block whose own crossing is not before the entry event.
-        // kDdaBlocks blocks ahead are enumerated without a memory access, their bucket bits fetched together, then
-        // judged in order.
-        for (;;) {
-            const bool need = live && !atBlock;
-            if (__ballot(need) == 0ull) break;
-            if (!need) continue;
-            int kb[3] = {c[0] >> 3, c[1] >> 3, c[2] >> 3};                   // voxel2Block for two's complement ints
-            if (!haveVoxel) { kb[0] = bk0; kb[1] = bk1; kb[2] = bk2; }
-            float tb0 = dda_tnext(ax[0], (kb[0] << 3) + (ax[0].s > 0 ? 7 : 0));
-            float tb1 = dda_tnext(ax[1], (kb[1] << 3) + (ax[1].s > 0 ? 7 : 0));
-            float tb2 = dda_tnext(ax[2], (kb[2] << 3) + (ax[2].s > 0 ? 7 : 0));
-            int ck[kDdaBlocks][3];
-            float ct[kDdaBlocks];
-            int cx[kDdaBlocks];
-            uint32_t cl[kDdaBlocks], cw[kDdaBlocks];
-            int nc = 0;
-            bool more = true, ends = false;
-            float tE = entryT;
-            int xE = haveVoxel ? -1 : entryX;
-#pragma unroll
-            for (int j = 0; j < kDdaBlocks; ++j) {
-                if (more) {
-                    ck[j][0] = kb[0]; ck[j][1] = kb[1]; ck[j][2] = kb[2];
-                    ct[j] = tE; cx[j] = xE;
-                    const uint32_t h = hash_block(kb[0], kb[1], kb[2], fp.numBuckets);
-                    const bool mine = h >= fp.bucketLo && h < fp.bucketHi;
-                    cl[j] = mine ? h - fp.bucketLo : ~0u;
-                    cw[j] = mine ? dp.bucketBits[(h - fp.bucketLo) >> 5] : 0u;
-                    nc = j + 1;
-                    // the crossing that ends this block
-                    const bool m0 = tb0 < tb1 && tb0 < tb2;
-                    const bool m2 = !m0 && tb2 < tb1;
-                    const bool m1 = !m0 && !m2;
-                    tE = m0 ? tb0 : m2 ? tb2 : tb1;
-                    xE = m0 ? 0 : m2 ? 2 : 1;
-                    kb[0] += m0 ? ax[0].s : 0; kb[1] += m1 ? ax[1].s : 0; kb[2] += m2 ? ax[2].s : 0;
-                    if (m0) tb0 = dda_tnext(ax[0], (kb[0] << 3) + (ax[0].s > 0 ? 7 : 0));
-                    else if (m1) tb1 = dda_tnext(ax[1], (kb[1] << 3) + (ax[1].s > 0 ? 7 : 0));
-                    else tb2 = dda_tnext(ax[2], (kb[2] << 3) + (ax[2].s > 0 ? 7 : 0));
-                    ends = !(tE < ra.tMax);
-                    more = !ends;
+    int sh = 3;                                                // level: 3 = blocks, 0 = voxels
+    int q0 = c[0] >> 3, q1 = c[1] >> 3, q2 = c[2] >> 3;        // the cell at that level (voxel2Block for two's complement ints)
+    int c0 = c[0], c1 = c[1], c2 = c[2];                       // block level with haveVoxel: the exact voxel the ray stands in
+    int haveVoxel = 1;
+    float entryT = 0.0f;                                       // block level, !haveVoxel: the event that entered the block
+    int entryX = 0;
+    // level-generic crossing time: out of cell q on axis a = voxel event out of (q << sh) + (s > 0 ? 2^sh - 1 : 0)
+    const int s0 = ax[0].s, s1 = ax[1].s, s2 = ax[2].s;
+    const int o0 = s0 > 0 ? 7 : 0, o1 = s1 > 0 ? 7 : 0, o2 = s2 > 0 ? 7 : 0;
+    const float ie0 = ax[0].invE != 0.0f ? ax[0].invE : __builtin_inff(), gs0 = ax[0].invE != 0.0f ? ax[0].Gs : -1.0e30f;
+    const float ie1 = ax[1].invE != 0.0f ? ax[1].invE : __builtin_inff(), gs1 = ax[1].invE != 0.0f ? ax[1].Gs : -1.0e30f;
+    const float ie2 = ax[2].invE != 0.0f ? ax[2].invE : __builtin_inff(), gs2 = ax[2].invE != 0.0f ? ax[2].Gs : -1.0e30f;
+#define VH_DDA_TN(q, o, gs, ie) (((float)(((q) << sh) + (sh ? (o) : 0)) - (gs)) * (ie))
+    float tn0 = VH_DDA_TN(q0, o0, gs0, ie0), tn1 = VH_DDA_TN(q1, o1, gs1, ie1), tn2 = VH_DDA_TN(q2, o2, gs2, ie2);
+    const bool pow2 = (fp.numBuckets & (fp.numBuckets - 1u)) == 0u;
+    while (live) {
+        const bool isV = sh == 0;
+        // ---- one load: the voxel (voxel level) or the bucket-bit word of the block (block level) ----
+        const uint32_t hh = ((uint32_t)q0 * 73856093u) ^ ((uint32_t)q1 * 19349669u) ^ ((uint32_t)q2 * 83492791u);   // calculateHash, VoxelUtils.cu:250-259
+        const uint32_t h = pow2 ? (hh & (fp.numBuckets - 1u)) : (hh % fp.numBuckets);
+        const bool mine = h >= fp.bucketLo && h < fp.bucketHi;
+        const uint32_t local = mine ? h - fp.bucketLo : 0u;
+        const uint32_t lin = (uint32_t)(((q2 & 7) << 6) | ((q1 & 7) << 3) | (q0 & 7));
+        const char *addr = isV ? reinterpret_cast<const char *>(dp.blocks + ((size_t)cptr + lin))
+                               : reinterpret_cast<const char *>(dp.bucketBits + (local >> 5));
+        const uint2 w = *reinterpret_cast<const uint2 *>(addr);
+        const float sdf = __uint_as_float(w.x), wgt = __uint_as_float(w.y);
+        const bool valid = isV && wgt > 0.0f;
+        const bool isHit = valid && prevValid && prevSdf > 0.0f && sdf <= 0.0f;
+        const bool bitSet = !isV && mine && ((w.x >> (local & 31u)) & 1u);
+        if (isHit || bitSet) {
+            if (isHit) {
+                // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
+                const float tc = ((ra.zrow[0] * (float)q0 + ra.zrow[1] * (float)q1) + ra.zrow[2] * (float)q2) + ra.zrow[3];
+                const float tp = ((ra.zrow[0] * (float)hx + ra.zrow[1] * (float)hy) + ra.zrow[2] * (float)hz) + ra.zrow[3];
+                hit = tp + ((tc - tp) * prevSdf) / (prevSdf - sdf);
+                found = true;
+                hx = q0; hy = q1; hz = q2; hptr = cptr;
+                break;
+            }
+            int ptr = VH_FREE_BLOCK;
+            if (fp.flags & kFlagOverflow) {
+                uint32_t prev;
+                const uint32_t at = find_entry_overflow(fp, dp.table, owned_entries(fp), local, q0, q1, q2, prev);
+                if (at != ~0u) ptr = dp.table[at].ptr;
+            } else {
+                const VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
+                for (uint32_t i = 0; i < fp.bucketSize; ++i) {            // getVoxelEntry4Block, VoxelUtils.cu:362-382
+                    const VoxelEntry e = bucket[i];
+                    if (e.ptr == VH_FREE_BLOCK) break;                    // prefix property
+                    if (e.pos[0] == q0 && e.pos[1] == q1 && e.pos[2] == q2) { ptr = e.ptr; break; }
                 }
             }
-            budget -= nc;
-            // judged in order: the first candidate whose bucket holds its key
-            int got = -1, ptr = VH_FREE_BLOCK;
+            if (ptr != VH_FREE_BLOCK) {
+                // down to voxel level: where the ray stands inside the block
+                kx = q0; ky = q1; kz = q2;
+                cptr = ptr;
+                if (!haveVoxel) {
+                    const int pX = entryX == 0 ? 2 : entryX == 1 ? 0 : 1;
+                    const int gk[3] = {q0, q1, q2};
+                    int cc[3] = {c0, c1, c2};
 #pragma unroll
-            for (int j = 0; j < kDdaBlocks; ++j) {
-                if (j < nc && got < 0 && cl[j] != ~0u && ((cw[j] >> (cl[j] & 31u)) & 1u)) {
-                    const int qx = ck[j][0], qy = ck[j][1], qz = ck[j][2];
-                    if (fp.flags & kFlagOverflow) {
-                        uint32_t prev;
-                        const uint32_t at = find_entry_overflow(fp, dp.table, owned_entries(fp), cl[j], qx, qy, qz, prev);
-                        if (at != ~0u) { ptr = dp.table[at].ptr; got = j; }
-                    } else {
-                        const VoxelEntry *bucket = dp.table + (size_t)cl[j] * fp.bucketSize;
-                        for (uint32_t i = 0; i < fp.bucketSize; ++i) {        // getVoxelEntry4Block, VoxelUtils.cu:362-382
-                            const VoxelEntry e = bucket[i];
-                            if (e.ptr == VH_FREE_BLOCK) break;                // prefix property
-                            if (e.pos[0] == qx && e.pos[1] == qy && e.pos[2] == qz) { ptr = e.ptr; got = j; break; }
-                        }
+                    for (int a = 0; a < 3; ++a) {
+                        const int nearC = (gk[a] << 3) + (ax[a].s > 0 ? 0 : 7), farC = (gk[a] << 3) + (ax[a].s > 0 ? 7 : 0);
+                        cc[a] = (a == entryX) ? nearC : (ax[a].invE == 0.0f ? c[a] : dda_advance(ax[a], prio[a], nearC, farC, entryT, pX));
                     }
+                    c0 = cc[0]; c1 = cc[1]; c2 = cc[2];
                 }
-            }
-            if (got < 0) {
-                // nothing allocated among them: the ray stands at the block behind the last candidate (or has ended)
-                prevValid = false;
-                if (ends || budget < 0) { live = false; continue; }
-                haveVoxel = false;
-                bk0 = kb[0]; bk1 = kb[1]; bk2 = kb[2];
-                entryT = tE; entryX = xE;
-                continue;
-            }
-            int gk[3] = {ck[0][0], ck[0][1], ck[0][2]};
-            float gT = ct[0];
-            int gX = cx[0];
-#pragma unroll
-            for (int j = 1; j < kDdaBlocks; ++j)
-                if (got == j) { gk[0] = ck[j][0]; gk[1] = ck[j][1]; gk[2] = ck[j][2]; gT = ct[j]; gX = cx[j]; }
-            if (got > 0) prevValid = false;
-            if (gX >= 0) {
-                // voxel coordinates at the entry event (gT, axis gX)
-                const int pX = gX == 0 ? 2 : gX == 1 ? 0 : 1;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const int nearC = (gk[a] << 3) + (ax[a].s > 0 ? 0 : 7), farC = (gk[a] << 3) + (ax[a].s > 0 ? 7 : 0);
-                    c[a] = (a == gX) ? nearC : (ax[a].invE == 0.0f ? c[a] : dda_advance(ax[a], prio[a], nearC, farC, gT, pX));
-                }
-            }
-            kx = gk[0]; ky = gk[1]; kz = gk[2];
-            cptr = ptr;
-            atBlock = true;
-        }
-        // ---- walk: the allocated blocks, a chunk of voxels at a time, until every lane has left its block ----
-        // float coordinates, crossing times, packed local position | linear index << 16
-        float fc0 = (float)c[0], fc1 = (float)c[1], fc2 = (float)c[2];
-        float tn0 = dda_tnext(ax[0], c[0]), tn1 = dda_tnext(ax[1], c[1]), tn2 = dda_tnext(ax[2], c[2]);
-        const float f0 = (float)ax[0].s, f1 = (float)ax[1].s, f2 = (float)ax[2].s;
-        // an axis that never steps: invE = 0 would give tnext = 0; (c + 2^100) * inf = inf instead
-        const float ie0 = ax[0].invE != 0.0f ? ax[0].invE : __builtin_inff(), gs0 = ax[0].invE != 0.0f ? ax[0].Gs : -1.0e30f;
-        const float ie1 = ax[1].invE != 0.0f ? ax[1].invE : __builtin_inff(), gs1 = ax[1].invE != 0.0f ? ax[1].Gs : -1.0e30f;
-        const float ie2 = ax[2].invE != 0.0f ? ax[2].invE : __builtin_inff(), gs2 = ax[2].invE != 0.0f ? ax[2].Gs : -1.0e30f;
-        const int d0 = ax[0].s * ((1 << 16) + 1), d1 = ax[1].s * ((8 << 16) + (1 << 5)), d2 = ax[2].s * ((64 << 16) + (1 << 10));
-        int pl = 0;
-        bool fresh = true;                       // pl has to be rebuilt from c (a new block)
-        for (;;) {
-            const bool walking = live && atBlock;
-            if (__ballot(walking) == 0ull) break;
-            if (!walking) continue;
-            if (fresh) {
-                const int lx = c[0] & 7, ly = c[1] & 7, lz = c[2] & 7;
-                pl = ((lx | (ly << 3) | (lz << 6)) << 16) | (lx + 8) | ((ly + 8) << 5) | ((lz + 8) << 10);
-                fresh = false;
-            }
-            int pls[kDdaChunk];
-            int n = 0;
-            bool more = true, ends = false, left = false;
-#pragma unroll
-            for (int k = 0; k < kDdaChunk; ++k) {
-                if (more) {
-                    pls[k] = pl;
-                    n = k + 1;
-                    // the crossing that ends this voxel (raycastSDF.frag:156-170): x only when strictly first, z before x
-                    // on a tie, y before both
-                    const bool m0 = tn0 < tn1 && tn0 < tn2;
-                    const bool m2 = !m0 && tn2 < tn1;
-                    const bool m1 = !m0 && !m2;
-                    const float tOut = m0 ? tn0 : m2 ? tn2 : tn1;
-                    pl += m0 ? d0 : m2 ? d2 : d1;
-                    fc0 += m0 ? f0 : 0.0f; fc1 += m1 ? f1 : 0.0f; fc2 += m2 ? f2 : 0.0f;
-                    tn0 = (fc0 - gs0) * ie0; tn1 = (fc1 - gs1) * ie1; tn2 = (fc2 - gs2) * ie2;
-                    left = (pl & 0x6318) != 0x2108;
-                    ends = !(tOut < ra.tMax);
-                    more = !ends && !left;
-                }
-            }
-            budget -= n;
-            Voxel s[kDdaChunk];
-#pragma unroll
-            for (int k = 0; k < kDdaChunk; ++k)
-                if (k < n) s[k] = dp.blocks[(size_t)cptr + (size_t)((uint32_t)pls[k] >> 16)];
-            // judged in order.  Only the two samples of the hit need their voxel coordinates (depth of the centres):
-            // the last valid sample is remembered as a linear index while it lies in this chunk (prevLin >= 0) and
-            // as coordinates (hx, hy, hz) once the chunk is left.
-            const int bx0 = kx << 3, by0 = ky << 3, bz0 = kz << 3;
-            int prevLin = -1;
-#pragma unroll
-            for (int k = 0; k < kDdaChunk; ++k) {
-                if (k < n && !found) {
-                    if (s[k].weight > 0.0f) {
-                        const int lin = (int)((uint32_t)pls[k] >> 16);
-                        if (prevValid && prevSdf > 0.0f && s[k].sdf <= 0.0f) {
-                            if (prevLin >= 0) { hx = bx0 + (prevLin & 7); hy = by0 + ((prevLin >> 3) & 7); hz = bz0 + (prevLin >> 6); }
-                            const int vx = bx0 + (lin & 7), vy = by0 + ((lin >> 3) & 7), vz = bz0 + (lin >> 6);
-                            // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
-                            const float tc = ((ra.zrow[0] * (float)vx + ra.zrow[1] * (float)vy) + ra.zrow[2] * (float)vz) + ra.zrow[3];
-                            const float tp = ((ra.zrow[0] * (float)hx + ra.zrow[1] * (float)hy) + ra.zrow[2] * (float)hz) + ra.zrow[3];
-                            hit = tp + ((tc - tp) * prevSdf) / (prevSdf - s[k].sdf);
-                            found = true;
-                            hx = vx; hy = vy; hz = vz; hptr = cptr;
-                        } else {
-                            prevValid = true; prevSdf = s[k].sdf; prevLin = lin;
-                        }
-                    } else {
-                        prevValid = false;
-                    }
-                }
-            }
-            if (!found && prevValid && prevLin >= 0) { hx = bx0 + (prevLin & 7); hy = by0 + ((prevLin >> 3) & 7); hz = bz0 + (prevLin >> 6); }
-            if (found || ends || budget < 0) { live = false; continue; }
-            if (left) {
-                // back to integer coordinates for the next look-up
-                c[0] = f2i_rz(fc0); c[1] = f2i_rz(fc1); c[2] = f2i_rz(fc2);
-                atBlock = false;
-                haveVoxel = true;
-                fresh = true;
+                q0 = c0; q1 = c1; q2 = c2;
+                sh = 0;
+                tn0 = VH_DDA_TN(q0, o0, gs0, ie0); tn1 = VH_DDA_TN(q1, o1, gs1, ie1); tn2 = VH_DDA_TN(q2, o2, gs2, ie2);
+                continue;                                        // (its first voxel is looked at by the next iteration)
             }
         }
+        // the sample's (or the absent block's) effect on the pair test
+        prevValid = valid ? 1 : 0;
+        prevSdf = valid ? sdf : prevSdf;
+        hx = valid ? q0 : hx; hy = valid ? q1 : hy; hz = valid ? q2 : hz;
+        // ---- the crossing that ends this cell (raycastSDF.frag:156-170): x only when strictly first, z before x on a
+        // tie, y before both ----
+        const bool m0 = tn0 < tn1 && tn0 < tn2;
+        const bool m2 = !m0 && tn2 < tn1;
+        const bool m1 = !m0 && !m2;
+        const float tOut = m0 ? tn0 : m2 ? tn2 : tn1;
+        if (!(tOut < ra.tMax) || --budget < 0) break;
+        q0 += m0 ? s0 : 0; q1 += m1 ? s1 : 0; q2 += m2 ? s2 : 0;
+        // voxel level: left the block?  Then up to block level, the exact voxel kept in case the next block is allocated too
+        const bool left = isV && ((((q0 >> 3) ^ kx) | ((q1 >> 3) ^ ky) | ((q2 >> 3) ^ kz)) != 0);
+        c0 = left ? q0 : c0; c1 = left ? q1 : c1; c2 = left ? q2 : c2;
+        q0 = left ? q0 >> 3 : q0; q1 = left ? q1 >> 3 : q1; q2 = left ? q2 >> 3 : q2;
+        sh = left ? 3 : sh;
+        haveVoxel = isV ? 1 : 0;
+        entryT = isV ? entryT : tOut;
+        entryX = isV ? entryX : (m0 ? 0 : m2 ? 2 : 1);
+        tn0 = VH_DDA_TN(q0, o0, gs0, ie0); tn1 = VH_DDA_TN(q1, o1, gs1, ie1); tn2 = VH_DDA_TN(q2, o2, gs2, ie2);
     }
+#undef VH_DDA_TN
     if (ra.stamps && lane == 0) {
         const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;
         ra.stamps[w] = stamp0; ra.stamps[w + 1] = __builtin_amdgcn_s_memrealtime();
