@@ -33,7 +33,13 @@ for k in (0, 35, 77):
     print(f"pose {k}: kernel span {end.max():.1f} us; wave start: median {np.median(start):.1f} p90 {np.percentile(start, 90):.1f} max {start.max():.1f}; "
           f"lifetime: mean {life.mean():.1f} median {np.median(life):.1f} p90 {np.percentile(life, 90):.1f} p99 {np.percentile(life, 99):.1f} max {life.max():.1f} us")
     order = np.argsort(-life)[:6]
-    print("   slowest waves (life us, start us, steps of lane 0, patch x,y):",
-          [(round(float(life[i]), 1), round(float(start[i]), 1), int(s[i, 2]), int(s[i, 3] & 0xffff), int(s[i, 3] >> 16)) for i in order])
+    rounds = (s[:, 2] >> 32).astype(np.float64)
+    print("   slowest waves (life us, start us, steps of lane 0, loop rounds of the wave, patch x,y):",
+          [(round(float(life[i]), 1), round(float(start[i]), 1), int(s[i, 2] & 0xffffffff), int(rounds[i]), int(s[i, 3] & 0xffff), int((s[i, 3] >> 16) & 0xffff)) for i in order])
+    front = (s[:, 3] >> 32) / 100.0
+    print(f"   prologue + beam front end per wave: mean {front.mean():.2f} p99 {np.percentile(front, 99):.2f} max {front.max():.2f} us")
+    ok = rounds > 0
+    print(f"   loop rounds per wave: mean {rounds[ok].mean():.1f} p99 {np.percentile(rounds[ok], 99):.0f} max {rounds.max():.0f}; "
+          f"us per round: mean wave {((life[ok] - front[ok]) / rounds[ok]).mean():.2f}, slowest waves {np.mean([(life[i] - front[i]) / max(1, rounds[i]) for i in order]):.2f}")
     h, _ = np.histogram(end, bins=10, range=(0, end.max()))
     print("   waves ending per tenth of the span:", h.tolist())

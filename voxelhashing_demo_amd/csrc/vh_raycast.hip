@@ -242,7 +242,7 @@ __device__ __forceinline__ bool dda_voxel(const FrameParams &fp, const DevPtrs &
 // its own exact walk there (dda_start).  Level 1 tests macro-cell bits over the whole range, level 2 bucket bits
 // in half-block slabs behind it.  Conservative by construction: the box is grown by 2 % of a voxel plus 1e-5 of
 // its coordinates (the rounding of this arithmetic and of the walk's crossing times is 1e-7 of them), a box that
-// touches more than 27 cells counts as occupied.
+// spans more than two cells on an axis counts as occupied.
 struct Beam {
     float dx0, dx1, dy0, dy1;             // direction bounds of the patch's rays, camera frame (z = 1)
 };
@@ -277,24 +277,30 @@ __device__ __forceinline__ bool beam_slab_occupied(const FrameParams &fp, const 
         const float m = 0.02f + 1.0e-5f * __builtin_fmaxf(__builtin_fabsf(gl), __builtin_fabsf(gh));
         c0[a] = f2i_rz(__builtin_floorf(gl - m)) >> kShift;
         c1[a] = f2i_rz(__builtin_floorf(gh + m)) >> kShift;
-        huge |= !(c1[a] - c0[a] <= 2) || !(gl == gl) || !(gh == gh);      // more than 3 cells on an axis, or NaN
+        huge |= !(c1[a] - c0[a] <= 1) || !(gl == gl) || !(gh == gh);      // more than 2 cells on an axis, or NaN
     }
     if (huge) return true;
+    // the (at most) 2 x 2 x 2 cells of the box: eight independent loads, one round trip (a loop over the cells with a
+    // load in its body made them eight -- or, with 3 cells per axis, 27 -- round trips: 4-13 us per wave)
+    uint32_t word[8], bit[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int x = (k & 1) ? c1[0] : c0[0], y = (k & 2) ? c1[1] : c0[1], z = (k & 4) ? c1[2] : c0[2];
+        if (kLevel == 1) {
+            const uint32_t hm = macro_hash(x, y, z);
+            word[k] = dp.macroBits[hm >> 5];
+            bit[k] = hm & 31u;
+        } else {
+            const uint32_t h = hash_block(x, y, z, fp.numBuckets);
+            const bool mine = h >= fp.bucketLo && h < fp.bucketHi;
+            const uint32_t local = mine ? h - fp.bucketLo : 0u;
+            word[k] = mine ? dp.bucketBits[local >> 5] : 0u;
+            bit[k] = local & 31u;
+        }
+    }
     bool any = false;
-    for (int z = c0[2]; z <= c1[2]; ++z)
-        for (int y = c0[1]; y <= c1[1]; ++y)
-            for (int x = c0[0]; x <= c1[0]; ++x) {
-                if (kLevel == 1) {
-                    const uint32_t hm = macro_hash(x, y, z);
-                    any |= ((dp.macroBits[hm >> 5] >> (hm & 31u)) & 1u) != 0u;
-                } else {
-                    const uint32_t h = hash_block(x, y, z, fp.numBuckets);
-                    if (h >= fp.bucketLo && h < fp.bucketHi) {
-                        const uint32_t local = h - fp.bucketLo;
-                        any |= ((dp.bucketBits[local >> 5] >> (local & 31u)) & 1u) != 0u;
-                    }
-                }
-            }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) any |= ((word[k] >> bit[k]) & 1u) != 0u;
     return any;
 }
 
@@ -315,6 +321,13 @@ __device__ __forceinline__ bool beam_slab_occupied(const FrameParams &fp, const 
 #ifndef VH_DDA_CHUNK
 #define VH_DDA_CHUNK 8
 #endif
+#ifndef VH_DDA_K
+#define VH_DDA_K 2
+#endif
+#ifndef VH_DDA_PRIO
+#define VH_DDA_PRIO 0
+#endif
+constexpr int kDdaK = VH_DDA_K;
 #ifndef VH_DDA_BLOCKS
 #define VH_DDA_BLOCKS 4
 #endif
@@ -393,6 +406,7 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
             for (int a = 0; a < 3; ++a) c[a] = dda_start(ax[a], c[a], tau);
         }
     }
+    const unsigned long long stamp1 = ra.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int prio[3] = {2, 0, 1};
     // ---- the walk: one cell per iteration, at block level (sh = 3) through absent blocks, at voxel level (sh = 0)
     // inside allocated ones.  Both levels are the same merge of three monotone crossing-time sequences -- the
@@ -429,92 +443,158 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
 #define VH_DDA_TN(q, o, gs, ie) (((float)(((q) << sh) + (sh ? (o) : 0)) - (gs)) * (ie))
     float tn0 = VH_DDA_TN(q0, o0, gs0, ie0), tn1 = VH_DDA_TN(q1, o1, gs1, ie1), tn2 = VH_DDA_TN(q2, o2, gs2, ie2);
     const bool pow2 = (fp.numBuckets & (fp.numBuckets - 1u)) == 0u;
+    // kDdaK cells ahead per iteration: the walk does not depend on what the cells hold, so the next kDdaK cells at
+    // the current level are enumerated by arithmetic alone, their kDdaK loads issued together (one memory round trip
+    // instead of kDdaK: a wave's 64 lanes gather 64 different cache lines per load, ~500 cycles each time), then judged
+    // in order.  A chunk ends early where the level changes (the ray leaves its block) or the ray ends; an allocated
+    // block found among the candidates discards the steps enumerated behind it.
+    int round = 0;
     while (live) {
+        // The launch is as long as its slowest wave (per-wave timeline, tools/raycast_stamps.py: mean 25 us, slowest 70),
+        // and while the SIMDs are full every wave gets a fifth of the issue slots: a wave that is still walking after
+        // many rounds is one of the long ones (silhouette and grazing patches) and moves ahead of the short ones.
+        ++round;
+        if (VH_DDA_PRIO) {
+            if (round == 12) __builtin_amdgcn_s_setprio(1);
+            else if (round == 24) __builtin_amdgcn_s_setprio(2);
+            else if (round == 40) __builtin_amdgcn_s_setprio(3);
+        }
         const bool isV = sh == 0;
-        // ---- one load: the voxel (voxel level) or the bucket-bit word of the block (block level) ----
-        const uint32_t hh = ((uint32_t)q0 * 73856093u) ^ ((uint32_t)q1 * 19349669u) ^ ((uint32_t)q2 * 83492791u);   // calculateHash, VoxelUtils.cu:250-259
-        const uint32_t h = pow2 ? (hh & (fp.numBuckets - 1u)) : (hh % fp.numBuckets);
-        const bool mine = h >= fp.bucketLo && h < fp.bucketHi;
-        const uint32_t local = mine ? h - fp.bucketLo : 0u;
-        const uint32_t lin = (uint32_t)(((q2 & 7) << 6) | ((q1 & 7) << 3) | (q0 & 7));
-        const char *addr = isV ? reinterpret_cast<const char *>(dp.blocks + ((size_t)cptr + lin))
-                               : reinterpret_cast<const char *>(dp.bucketBits + (local >> 5));
-        const uint2 w = *reinterpret_cast<const uint2 *>(addr);
-        const float sdf = __uint_as_float(w.x), wgt = __uint_as_float(w.y);
-        const bool valid = isV && wgt > 0.0f;
-        const bool isHit = valid && prevValid && prevSdf > 0.0f && sdf <= 0.0f;
-        const bool bitSet = !isV && mine && ((w.x >> (local & 31u)) & 1u);
-        if (isHit || bitSet) {
-            if (isHit) {
+        int cq0[kDdaK], cq1[kDdaK], cq2[kDdaK], cx[kDdaK];
+        float ct[kDdaK];
+        uint32_t cl[kDdaK];
+        uint2 cw[kDdaK];
+        int n = 0;
+        bool more = true, ends = false, left = false;
+        float eT = entryT;
+        int eX = haveVoxel ? -1 : entryX;
+#pragma unroll
+        for (int j = 0; j < kDdaK; ++j) {
+            if (more) {
+                cq0[j] = q0; cq1[j] = q1; cq2[j] = q2; ct[j] = eT; cx[j] = eX;
+                const uint32_t hh = ((uint32_t)q0 * 73856093u) ^ ((uint32_t)q1 * 19349669u) ^ ((uint32_t)q2 * 83492791u);   // calculateHash, VoxelUtils.cu:250-259
+                const uint32_t h = pow2 ? (hh & (fp.numBuckets - 1u)) : (hh % fp.numBuckets);
+                const bool mine = h >= fp.bucketLo && h < fp.bucketHi;
+                const uint32_t local = mine ? h - fp.bucketLo : 0u;
+                cl[j] = mine ? local : ~0u;
+                const uint32_t lin = (uint32_t)(((q2 & 7) << 6) | ((q1 & 7) << 3) | (q0 & 7));
+                const char *addr = isV ? reinterpret_cast<const char *>(dp.blocks + ((size_t)cptr + lin))
+                                       : reinterpret_cast<const char *>(dp.bucketBits + (local >> 5));
+                cw[j] = *reinterpret_cast<const uint2 *>(addr);
+                n = j + 1;
+                // the crossing that ends this cell (raycastSDF.frag:156-170): x only when strictly first, z before x on a
+                // tie, y before both
+                const bool m0 = tn0 < tn1 && tn0 < tn2;
+                const bool m2 = !m0 && tn2 < tn1;
+                const bool m1 = !m0 && !m2;
+                const float tOut = m0 ? tn0 : m2 ? tn2 : tn1;
+                ends = !(tOut < ra.tMax);
+                q0 += m0 ? s0 : 0; q1 += m1 ? s1 : 0; q2 += m2 ? s2 : 0;
+                left = isV && ((((q0 >> 3) ^ kx) | ((q1 >> 3) ^ ky) | ((q2 >> 3) ^ kz)) != 0);
+                eT = tOut; eX = m0 ? 0 : m2 ? 2 : 1;
+                more = !ends && !left;
+                if (more) { tn0 = VH_DDA_TN(q0, o0, gs0, ie0); tn1 = VH_DDA_TN(q1, o1, gs1, ie1); tn2 = VH_DDA_TN(q2, o2, gs2, ie2); }
+            }
+        }
+        budget -= n;
+        // ---- judged in order ----
+        int ev = -1;                         // first candidate that is a hit (voxel level) / whose bucket bit is set (block level)
+#pragma unroll
+        for (int j = 0; j < kDdaK; ++j) {
+            if (j < n && ev < 0) {
+                const float sdf = __uint_as_float(cw[j].x), wgt = __uint_as_float(cw[j].y);
+                const bool valid = isV && wgt > 0.0f;
+                const bool isHit = valid && prevValid && prevSdf > 0.0f && sdf <= 0.0f;
+                const bool bitSet = !isV && cl[j] != ~0u && ((cw[j].x >> (cl[j] & 31u)) & 1u);
+                if (isHit || bitSet) {
+                    ev = j;
+                } else {
+                    prevValid = valid ? 1 : 0;                       // (an absent block: no valid sample)
+                    prevSdf = valid ? sdf : prevSdf;
+                    hx = valid ? cq0[j] : hx; hy = valid ? cq1[j] : hy; hz = valid ? cq2[j] : hz;
+                }
+            }
+        }
+        if (ev >= 0) {
+            int e0 = cq0[0], e1 = cq1[0], e2 = cq2[0], eX2 = cx[0];
+            float eT2 = ct[0], eSdf = __uint_as_float(cw[0].x);
+            uint32_t eL = cl[0];
+#pragma unroll
+            for (int j = 1; j < kDdaK; ++j)
+                if (ev == j) { e0 = cq0[j]; e1 = cq1[j]; e2 = cq2[j]; eX2 = cx[j]; eT2 = ct[j]; eSdf = __uint_as_float(cw[j].x); eL = cl[j]; }
+            if (isV) {
                 // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
-                const float tc = ((ra.zrow[0] * (float)q0 + ra.zrow[1] * (float)q1) + ra.zrow[2] * (float)q2) + ra.zrow[3];
+                const float tc = ((ra.zrow[0] * (float)e0 + ra.zrow[1] * (float)e1) + ra.zrow[2] * (float)e2) + ra.zrow[3];
                 const float tp = ((ra.zrow[0] * (float)hx + ra.zrow[1] * (float)hy) + ra.zrow[2] * (float)hz) + ra.zrow[3];
-                hit = tp + ((tc - tp) * prevSdf) / (prevSdf - sdf);
+                hit = tp + ((tc - tp) * prevSdf) / (prevSdf - eSdf);
                 found = true;
-                hx = q0; hy = q1; hz = q2; hptr = cptr;
+                hx = e0; hy = e1; hz = e2; hptr = cptr;
                 break;
             }
             int ptr = VH_FREE_BLOCK;
             if (fp.flags & kFlagOverflow) {
                 uint32_t prev;
-                const uint32_t at = find_entry_overflow(fp, dp.table, owned_entries(fp), local, q0, q1, q2, prev);
+                const uint32_t at = find_entry_overflow(fp, dp.table, owned_entries(fp), eL, e0, e1, e2, prev);
                 if (at != ~0u) ptr = dp.table[at].ptr;
             } else {
-                const VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
+                const VoxelEntry *bucket = dp.table + (size_t)eL * fp.bucketSize;
                 for (uint32_t i = 0; i < fp.bucketSize; ++i) {            // getVoxelEntry4Block, VoxelUtils.cu:362-382
                     const VoxelEntry e = bucket[i];
                     if (e.ptr == VH_FREE_BLOCK) break;                    // prefix property
-                    if (e.pos[0] == q0 && e.pos[1] == q1 && e.pos[2] == q2) { ptr = e.ptr; break; }
+                    if (e.pos[0] == e0 && e.pos[1] == e1 && e.pos[2] == e2) { ptr = e.ptr; break; }
                 }
             }
+            // the steps enumerated behind candidate ev are dropped either way: the walk resumes AT it
             if (ptr != VH_FREE_BLOCK) {
                 // down to voxel level: where the ray stands inside the block
-                kx = q0; ky = q1; kz = q2;
+                kx = e0; ky = e1; kz = e2;
                 cptr = ptr;
-                if (!haveVoxel) {
-                    const int pX = entryX == 0 ? 2 : entryX == 1 ? 0 : 1;
-                    const int gk[3] = {q0, q1, q2};
+                if (eX2 >= 0) {
+                    prevValid = 0;                                  // (absent blocks lie behind: entered from outside)
+                    const int pX = eX2 == 0 ? 2 : eX2 == 1 ? 0 : 1;
+                    const int gk[3] = {e0, e1, e2};
                     int cc[3] = {c0, c1, c2};
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
                         const int nearC = (gk[a] << 3) + (ax[a].s > 0 ? 0 : 7), farC = (gk[a] << 3) + (ax[a].s > 0 ? 7 : 0);
-                        cc[a] = (a == entryX) ? nearC : (ax[a].invE == 0.0f ? c[a] : dda_advance(ax[a], prio[a], nearC, farC, entryT, pX));
+                        cc[a] = (a == eX2) ? nearC : (ax[a].invE == 0.0f ? c[a] : dda_advance(ax[a], prio[a], nearC, farC, eT2, pX));
                     }
                     c0 = cc[0]; c1 = cc[1]; c2 = cc[2];
                 }
                 q0 = c0; q1 = c1; q2 = c2;
                 sh = 0;
+                haveVoxel = 1;
+            } else {
+                // a bucket that holds other keys: the block is absent; resume the block walk behind it
+                prevValid = 0;
+                q0 = e0; q1 = e1; q2 = e2;
                 tn0 = VH_DDA_TN(q0, o0, gs0, ie0); tn1 = VH_DDA_TN(q1, o1, gs1, ie1); tn2 = VH_DDA_TN(q2, o2, gs2, ie2);
-                continue;                                        // (its first voxel is looked at by the next iteration)
+                const bool m0 = tn0 < tn1 && tn0 < tn2;
+                const bool m2 = !m0 && tn2 < tn1;
+                const bool m1 = !m0 && !m2;
+                const float tOut = m0 ? tn0 : m2 ? tn2 : tn1;
+                if (!(tOut < ra.tMax)) break;
+                q0 += m0 ? s0 : 0; q1 += m1 ? s1 : 0; q2 += m2 ? s2 : 0;
+                haveVoxel = 0; entryT = tOut; entryX = m0 ? 0 : m2 ? 2 : 1;
             }
+            tn0 = VH_DDA_TN(q0, o0, gs0, ie0); tn1 = VH_DDA_TN(q1, o1, gs1, ie1); tn2 = VH_DDA_TN(q2, o2, gs2, ie2);
+            continue;
         }
-        // the sample's (or the absent block's) effect on the pair test
-        prevValid = valid ? 1 : 0;
-        prevSdf = valid ? sdf : prevSdf;
-        hx = valid ? q0 : hx; hy = valid ? q1 : hy; hz = valid ? q2 : hz;
-        // ---- the crossing that ends this cell (raycastSDF.frag:156-170): x only when strictly first, z before x on a
-        // tie, y before both ----
-        const bool m0 = tn0 < tn1 && tn0 < tn2;
-        const bool m2 = !m0 && tn2 < tn1;
-        const bool m1 = !m0 && !m2;
-        const float tOut = m0 ? tn0 : m2 ? tn2 : tn1;
-        if (!(tOut < ra.tMax) || --budget < 0) break;
-        q0 += m0 ? s0 : 0; q1 += m1 ? s1 : 0; q2 += m2 ? s2 : 0;
+        if (ends || budget < 0) break;
         // voxel level: left the block?  Then up to block level, the exact voxel kept in case the next block is allocated too
-        const bool left = isV && ((((q0 >> 3) ^ kx) | ((q1 >> 3) ^ ky) | ((q2 >> 3) ^ kz)) != 0);
         c0 = left ? q0 : c0; c1 = left ? q1 : c1; c2 = left ? q2 : c2;
         q0 = left ? q0 >> 3 : q0; q1 = left ? q1 >> 3 : q1; q2 = left ? q2 >> 3 : q2;
         sh = left ? 3 : sh;
         haveVoxel = isV ? 1 : 0;
-        entryT = isV ? entryT : tOut;
-        entryX = isV ? entryX : (m0 ? 0 : m2 ? 2 : 1);
-        tn0 = VH_DDA_TN(q0, o0, gs0, ie0); tn1 = VH_DDA_TN(q1, o1, gs1, ie1); tn2 = VH_DDA_TN(q2, o2, gs2, ie2);
+        entryT = isV ? entryT : eT;
+        entryX = isV ? entryX : eX;
+        if (left) { tn0 = VH_DDA_TN(q0, o0, gs0, ie0); tn1 = VH_DDA_TN(q1, o1, gs1, ie1); tn2 = VH_DDA_TN(q2, o2, gs2, ie2); }
     }
 #undef VH_DDA_TN
     if (ra.stamps && lane == 0) {
         const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;
         ra.stamps[w] = stamp0; ra.stamps[w + 1] = __builtin_amdgcn_s_memrealtime();
-        ra.stamps[w + 2] = (unsigned long long)(ra.budget - budget); ra.stamps[w + 3] = (unsigned long long)(pu | (pv << 16));
+        ra.stamps[w + 2] = (unsigned long long)(ra.budget - budget) | ((unsigned long long)round << 32); ra.stamps[w + 3] = (unsigned long long)(pu | (pv << 16)) | ((stamp1 - stamp0) << 32);
     }
     if (!inImage) return;
     depthOut[(size_t)v * fp.width + u] = hit;
