@@ -551,7 +551,7 @@ static int raycast_impl(vh_context *c, const float pose[16], float t_min, float 
         if (!(reach < 8388608.0)) return fail(VH_ERR_INVALID_ARGUMENT, "view reaches beyond 2^23 voxels from the origin");
         ra.invVs = 1.0f / fp.voxelSize;
         ra.stamps = reinterpret_cast<unsigned long long *>(c->raycastStamps);
-        ra.beam = (c->raycastBeam && t_min > 0.0f) ? 1 : 0;
+        ra.beam = t_min > 0.0f ? c->raycastBeam : 0;
         float4 *nrm = reinterpret_cast<float4 *>(d_normals_out);
         if (nrm)
             rc = c->raycastPatch ? launch(c, kPhaseRaycast, raycast_dda_kernel<1, true>, grid, dim3(256), fp, dp, ra, d_depth_out, nrm)

@@ -216,7 +216,8 @@ struct RaycastArgs {
     float invVs;              // 1 / voxelSize (beam boxes only)
     int budget;               // hang guard: more steps than any ray of this view can take (host: vh_raycast)
     int xcdAware;
-    int beam;                 // 0: no beam front end (A/B, and views with t_min <= 0)
+    int beam;                 // 2: the cooperative form (one block list per wave); 1: per-lane walk behind a beam front end; 0: per-lane walk
+                              // from t_min (A/B; views with t_min <= 0)
     unsigned long long *stamps;   // diagnostics (tools/raycast_stamps.py): per wave {start, end} of s_memrealtime (100 MHz), or null
 };
 
@@ -304,6 +305,59 @@ __device__ __forceinline__ bool beam_slab_occupied(const FrameParams &fp, const 
     return any;
 }
 
+
+// ---------------------------------------------------------------------------
+// The cooperative form (RaycastArgs::beam == 2, the default): one block list per wave
+// ---------------------------------------------------------------------------
+// The per-lane walk above spends its time where the 64 rays of a wave do the same thing 64 times, out of step with
+// each other: stepping through the absent blocks in front of the surface, looking buckets up, rebuilding voxel
+// coordinates -- with a dependent gather (64 different cache lines, ~500 cycles) at every step, and with the rare
+// path (a bucket bit is set) entered in most rounds because SOME lane needs it (per-wave timeline on C2: 10-16 loop
+// rounds of 1.6 us each; the launch is as long as its slowest wave, 60-70 us, the fixed-step march 47).  The rays
+// of a patch are a few voxels apart, though, and meet the same handful of blocks.  So the wave finds those blocks
+// ONCE, together, and every ray is then tested against each of them directly:
+//   1. beam: lane i bounds the part of the beam inside half-block slab i of the depth range by a box in voxel-grid
+//      units and tests the (at most 2 x 2 x 2) blocks the box touches: eight independent bucket-bit loads, one round
+//      trip for all 64 slabs.  Cells with a set bit go into a wave-local set in LDS (compare-and-swap on a 32-bit tag
+//      that IS the key: block coordinates relative to the wave's first block, 10 bits each);
+//   2. the set's cells are resolved against the hash table, four per lane, their bucket's first entry fetched
+//      together (getVoxelEntry4Block, VoxelUtils.cu:362-382): the allocated ones form the wave's block list;
+//   3. for every block of the list (a wave-uniform loop: its key and its voxel pointer are scalars) each lane
+//      computes, in the walk's own arithmetic, whether and where its ray enters the block -- the ray is inside the
+//      block's slab on axis a between the event that steps c_a into it and the event that steps c_a out; it visits
+//      the block iff the last of the three entering events precedes the first of the three leaving events in the
+//      merge order; the voxel it enters at follows from dda_advance as in the per-lane walk -- and walks its voxels.
+// The blocks are judged independently, in whatever order the list has: a pair of consecutive valid samples lies
+// inside one block, or its first sample is the voxel the ray was in before the block's entry event -- looked up
+// through the same set -- so every block yields its candidate hits without knowing what came before, each candidate
+// carries the event at which the ray arrived in its voxel, and the ray's hit is the candidate with the earliest
+// arrival (events are totally ordered).  Complete by construction: the slabs cover [t_min, t_max] (several windows
+// of 64 when the range is longer), the boxes are conservative, so every allocated block any ray of the wave visits
+// is in the list.  Whenever the preconditions fail -- a box spans more than two blocks on an axis, the set
+// overflows, a block lies more than 511 blocks from the wave's first -- the wave falls back to the per-lane walk.
+constexpr int kCoopSlots = 256;                       // per wave: cells with a set bucket bit
+constexpr uint32_t kCoopUnresolved = 0x7ffffffeu;     // sPtr: not looked up yet
+struct CoopShared {
+    uint32_t tag[4][kCoopSlots];
+    uint32_t ptr[4][kCoopSlots];
+    uint16_t list[4][kCoopSlots];
+};
+
+__device__ __forceinline__ uint32_t coop_tag(int rx, int ry, int rz) { return 1u + (uint32_t)rx + ((uint32_t)ry << 10) + ((uint32_t)rz << 20); }
+
+// slot of `tag` in the wave's set, or -1
+__device__ __forceinline__ int coop_find(const uint32_t *tags, uint32_t tag)
+{
+    uint32_t h = (tag * 2654435761u) >> 24;
+    for (int probe = 0; probe < 16; ++probe) {
+        const uint32_t t = tags[h];
+        if (t == tag) return (int)h;
+        if (t == 0u) return -1;
+        h = (h + 1u) & (kCoopSlots - 1);
+    }
+    return -1;
+}
+
 // Shape of the kernel.  A ray's work is small (C2: ~4 macro-cell jumps, ~4 block look-ups, 1.5 allocated blocks,
 // ~9 voxels) but every piece is a dependent memory round trip, and the 64 rays of a wave are each at a different
 // piece at any moment: a loop that lets every lane do "its next thing" executes the jump path AND a whole block
@@ -374,8 +428,282 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
         c[a] = f2i_rz(__builtin_floorf(ax[a].G + ax[a].E * ra.tMin));
     }
     bool live = inImage;
+    bool found = false;
+    float hit = 0.0f;
+    int hx = 0, hy = 0, hz = 0, hptr = VH_FREE_BLOCK;          // (per-lane walk: the last valid sample's voxel;) after a hit: the hit voxel and its block
+    const int prio[3] = {2, 0, 1};
+    bool coopDone = false;
+    if (ra.beam == 2) {
+        __shared__ CoopShared sh_;
+        uint32_t *tags = sh_.tag[wave], *ptrs = sh_.ptr[wave];
+        uint16_t *list = sh_.list[wave];
+#pragma unroll
+        for (int r = 0; r < kCoopSlots / 64; ++r) { tags[lane + 64 * r] = 0u; ptrs[lane + 64 * r] = kCoopUnresolved; }
+        Beam bm;
+        const float a0 = __shfl(dx, 0), a1 = __shfl(dx, kPatch == 0 ? 15 : 7);
+        const float b0 = __shfl(dy, 0), b1 = __shfl(dy, kPatch == 0 ? 48 : 56);
+        bm.dx0 = __builtin_fminf(a0, a1); bm.dx1 = __builtin_fmaxf(a0, a1);
+        bm.dy0 = __builtin_fminf(b0, b1); bm.dy1 = __builtin_fmaxf(b0, b1);
+        const int base0 = (__shfl(c[0], 0) >> 3) - 512, base1 = (__shfl(c[1], 0) >> 3) - 512, base2 = (__shfl(c[2], 0) >> 3) - 512;
+        const float dt2 = 4.0f * vs;                               // half-block slabs
+        bool fail = false;
+        float bestT = __builtin_inff();                            // arrival event of the best candidate's hit voxel
+        int bestP = 3;
+        int nList = 0;
+        bool final_ = !inImage;
+        __builtin_amdgcn_wave_barrier();
+        for (float tw = ra.tMin; tw < ra.tMax && !fail; tw += 64.0f * dt2) {
+            // ---- 1. beam: the blocks slab `lane` of this window can touch ----
+            const float ta = tw + (float)lane * dt2;
+            if (ta < ra.tMax) {
+                const float tA = ta - 1.0e-4f * dt2, tB = ta + 1.0001f * dt2;
+                const float xa0 = bm.dx0 * tA, xa1 = bm.dx0 * tB, xb0 = bm.dx1 * tA, xb1 = bm.dx1 * tB;
+                const float ya0 = bm.dy0 * tA, ya1 = bm.dy0 * tB, yb0 = bm.dy1 * tA, yb1 = bm.dy1 * tB;
+                const float lo[3] = {__builtin_fminf(__builtin_fminf(xa0, xa1), __builtin_fminf(xb0, xb1)),
+                                     __builtin_fminf(__builtin_fminf(ya0, ya1), __builtin_fminf(yb0, yb1)), tA};
+                const float hi[3] = {__builtin_fmaxf(__builtin_fmaxf(xa0, xa1), __builtin_fmaxf(xb0, xb1)),
+                                     __builtin_fmaxf(__builtin_fmaxf(ya0, ya1), __builtin_fmaxf(yb0, yb1)), tB};
+                int k0[3], k1[3];
+                bool huge = false;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    float wl = 0.0f, wh = 0.0f;                   // R_a . box, interval arithmetic
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float r = fp.T[4 * a + j] * ra.invVs;
+                        const float p = r * lo[j], q = r * hi[j];
+                        wl += __builtin_fminf(p, q);
+                        wh += __builtin_fmaxf(p, q);
+                    }
+                    const float gl = ra.G[a] + wl, gh = ra.G[a] + wh;
+                    const float m = 0.02f + 1.0e-5f * __builtin_fmaxf(__builtin_fabsf(gl), __builtin_fabsf(gh));
+                    k0[a] = f2i_rz(__builtin_floorf(gl - m)) >> 3;
+                    k1[a] = f2i_rz(__builtin_floorf(gh + m)) >> 3;
+                    huge |= !(k1[a] - k0[a] <= 1) || !(gl == gl) || !(gh == gh);
+                }
+                const int r0 = k0[0] - base0, r1 = k0[1] - base1, r2 = k0[2] - base2;
+                huge |= (uint32_t)r0 >= 1022u || (uint32_t)r1 >= 1022u || (uint32_t)r2 >= 1022u;
+                if (huge) {
+                    fail = true;
+                } else {
+                    uint32_t word[8], bit[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int x = (k & 1) ? k1[0] : k0[0], y = (k & 2) ? k1[1] : k0[1], z = (k & 4) ? k1[2] : k0[2];
+                        const uint32_t h = hash_block(x, y, z, fp.numBuckets);
+                        const bool mine = h >= fp.bucketLo && h < fp.bucketHi;
+                        const uint32_t local = mine ? h - fp.bucketLo : 0u;
+                        word[k] = mine ? dp.bucketBits[local >> 5] : 0u;
+                        bit[k] = local & 31u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        // (a box one block wide on an axis names each cell twice: only its first name is taken)
+                        const bool dup = ((k & 1) && k1[0] == k0[0]) || ((k & 2) && k1[1] == k0[1]) || ((k & 4) && k1[2] == k0[2]);
+                        if (!dup && ((word[k] >> bit[k]) & 1u)) {
+                            const uint32_t tag = coop_tag(r0 + (k & 1), r1 + ((k >> 1) & 1), r2 + ((k >> 2) & 1));
+                            uint32_t h = (tag * 2654435761u) >> 24;
+                            bool placed = false;
+                            for (int probe = 0; probe < 16 && !placed; ++probe) {
+                                const uint32_t old = atomicCAS(&tags[h], 0u, tag);
+                                placed = old == 0u || old == tag;
+                                h = (h + 1u) & (kCoopSlots - 1);
+                            }
+                            if (!placed) fail = true;
+                        }
+                    }
+                }
+            }
+            fail = __ballot(fail) != 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (fail) break;
+            // ---- 2. the new cells, four per lane: allocated? ----
+            const int listBegin = nList;
+            {
+                uint32_t myLocal[kCoopSlots / 64];
+                int myKey[kCoopSlots / 64][3];
+                VoxelEntry first[kCoopSlots / 64];
+                bool todo[kCoopSlots / 64];
+#pragma unroll
+                for (int r = 0; r < kCoopSlots / 64; ++r) {
+                    const int slot = lane + 64 * r;
+                    const uint32_t tg = tags[slot];
+                    todo[r] = tg != 0u && ptrs[slot] == kCoopUnresolved;
+                    const uint32_t t = tg - 1u;
+                    myKey[r][0] = base0 + (int)(t & 1023u); myKey[r][1] = base1 + (int)((t >> 10) & 1023u); myKey[r][2] = base2 + (int)(t >> 20);
+                    const uint32_t h = hash_block(myKey[r][0], myKey[r][1], myKey[r][2], fp.numBuckets);
+                    myLocal[r] = h - fp.bucketLo;                       // (a set bit: the bucket is this shard's)
+                    first[r].ptr = VH_FREE_BLOCK; first[r].pos[0] = first[r].pos[1] = first[r].pos[2] = 0; first[r].offset = 0;
+                    if (todo[r]) first[r] = dp.table[(size_t)myLocal[r] * fp.bucketSize];      // (the four fetched together)
+                }
+#pragma unroll
+                for (int r = 0; r < kCoopSlots / 64; ++r) {
+                    int ptr = VH_FREE_BLOCK;
+                    if (todo[r]) {
+                        const int qx = myKey[r][0], qy = myKey[r][1], qz = myKey[r][2];
+                        if (fp.flags & kFlagOverflow) {
+                            uint32_t prev;
+                            const uint32_t at = find_entry_overflow(fp, dp.table, owned_entries(fp), myLocal[r], qx, qy, qz, prev);
+                            if (at != ~0u) ptr = dp.table[at].ptr;
+                        } else if (first[r].ptr != VH_FREE_BLOCK) {             // prefix property: a free first slot = an empty bucket
+                            if (first[r].pos[0] == qx && first[r].pos[1] == qy && first[r].pos[2] == qz) ptr = first[r].ptr;
+                            else {
+                                const VoxelEntry *bucket = dp.table + (size_t)myLocal[r] * fp.bucketSize;
+                                for (uint32_t i = 1; i < fp.bucketSize; ++i) {    // getVoxelEntry4Block, VoxelUtils.cu:362-382
+                                    const VoxelEntry e = bucket[i];
+                                    if (e.ptr == VH_FREE_BLOCK) break;
+                                    if (e.pos[0] == qx && e.pos[1] == qy && e.pos[2] == qz) { ptr = e.ptr; break; }
+                                }
+                            }
+                        }
+                        ptrs[lane + 64 * r] = (uint32_t)ptr;
+                    }
+                    // the allocated ones join the wave's list
+                    const bool isNew = todo[r] && ptr != VH_FREE_BLOCK;
+                    const unsigned long long m = __ballot(isNew);
+                    if (isNew) list[nList + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(lane + 64 * r);
+                    nList += __popcll(m);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- 3. every ray against every new block of the list ----
+            for (int i = listBegin; i < nList; ++i) {
+                if (__ballot(!final_) == 0ull) break;
+                const int slot = __builtin_amdgcn_readfirstlane((int)list[i]);
+                const uint32_t tg = (uint32_t)__builtin_amdgcn_readfirstlane((int)tags[slot]) - 1u;
+                const int bptr = __builtin_amdgcn_readfirstlane((int)ptrs[slot]);
+                const int kk[3] = {base0 + (int)(tg & 1023u), base1 + (int)((tg >> 10) & 1023u), base2 + (int)(tg >> 20)};
+                // where the ray is inside the block's slab on each axis: from the event that steps into it to the event that
+                // steps out of it
+                float tIn[3], tOut[3];
+                bool startIn[3];
+                bool miss = final_;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int lo = kk[a] << 3, hi = lo + 7;
+                    if (ax[a].invE == 0.0f) {
+                        startIn[a] = c[a] >= lo && c[a] <= hi;
+                        miss |= !startIn[a];
+                        tIn[a] = -__builtin_inff(); tOut[a] = __builtin_inff();
+                    } else if (ax[a].s > 0) {
+                        miss |= c[a] > hi;
+                        startIn[a] = c[a] >= lo;
+                        tIn[a] = startIn[a] ? -__builtin_inff() : dda_tnext(ax[a], lo - 1);
+                        tOut[a] = dda_tnext(ax[a], hi);
+                    } else {
+                        miss |= c[a] < lo;
+                        startIn[a] = c[a] <= hi;
+                        tIn[a] = startIn[a] ? -__builtin_inff() : dda_tnext(ax[a], hi + 1);
+                        tOut[a] = dda_tnext(ax[a], lo);
+                    }
+                }
+                // the LAST entering event and the FIRST leaving event in merge order
+                int xe = dda_before(tIn[0], 2, tIn[1], 0) ? 1 : 0;
+                {
+                    const float t01 = xe ? tIn[1] : tIn[0];
+                    if (dda_before(t01, xe ? 0 : 2, tIn[2], 1)) xe = 2;
+                }
+                const int xo = (tOut[0] < tOut[1] && tOut[0] < tOut[2]) ? 0 : (tOut[2] < tOut[1]) ? 2 : 1;
+                const float tE = xe == 0 ? tIn[0] : xe == 1 ? tIn[1] : tIn[2];
+                const float tO = xo == 0 ? tOut[0] : xo == 1 ? tOut[1] : tOut[2];
+                const int pE = xe == 0 ? 2 : xe == 1 ? 0 : 1, pO = xo == 0 ? 2 : xo == 1 ? 0 : 1;
+                const bool inside = tE == -__builtin_inff();                          // the ray starts inside the block
+                bool enters = !miss && (inside || xe == xo || dda_before(tE, pE, tO, pO)) && (inside || tE < ra.tMax);
+                enters = enters && dda_before(tE, pE, bestT, bestP);                  // (not behind the best candidate so far)
+                if (__ballot(enters) == 0ull) continue;
+                if (!enters) continue;
+                // the voxel the ray enters at
+                int q[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const int lo = kk[a] << 3, hi = lo + 7;
+                    const int nearC = ax[a].s > 0 ? lo : hi, farC = ax[a].s > 0 ? hi : lo;
+                    if (inside || ax[a].invE == 0.0f) q[a] = c[a];
+                    else if (a == xe) q[a] = nearC;
+                    else q[a] = dda_advance(ax[a], prio[a], startIn[a] ? c[a] : nearC, farC, tE, pE);
+                }
+                float tn0 = dda_tnext(ax[0], q[0]), tn1 = dda_tnext(ax[1], q[1]), tn2 = dda_tnext(ax[2], q[2]);
+                float tArr = tE;
+                int pArr = pE;
+                bool pv = false, firstVoxel = !inside, walking = true;
+                float ps = 0.0f;
+                int p0 = 0, p1 = 0, p2 = 0;
+                while (walking) {
+                    int vq0[kDdaK], vq1[kDdaK], vq2[kDdaK], vp[kDdaK];
+                    float vt[kDdaK];
+                    Voxel vv[kDdaK];
+                    int n = 0;
+                    bool more = true;
+#pragma unroll
+                    for (int j = 0; j < kDdaK; ++j) {
+                        if (more) {
+                            vq0[j] = q[0]; vq1[j] = q[1]; vq2[j] = q[2]; vt[j] = tArr; vp[j] = pArr;
+                            vv[j] = dp.blocks[(size_t)bptr + (size_t)(((q[2] & 7) << 6) | ((q[1] & 7) << 3) | (q[0] & 7))];
+                            n = j + 1;
+                            // the crossing that ends this voxel (raycastSDF.frag:156-170)
+                            const bool m0 = tn0 < tn1 && tn0 < tn2;
+                            const bool m2 = !m0 && tn2 < tn1;
+                            const bool m1 = !m0 && !m2;
+                            tArr = m0 ? tn0 : m2 ? tn2 : tn1;
+                            pArr = m0 ? 2 : m2 ? 1 : 0;
+                            q[0] += m0 ? ax[0].s : 0; q[1] += m1 ? ax[1].s : 0; q[2] += m2 ? ax[2].s : 0;
+                            const bool left = (((q[0] >> 3) ^ kk[0]) | ((q[1] >> 3) ^ kk[1]) | ((q[2] >> 3) ^ kk[2])) != 0;
+                            more = tArr < ra.tMax && !left;             // (a voxel is visited iff the ray arrives before t_max)
+                            if (more) { tn0 = dda_tnext(ax[0], q[0]); tn1 = dda_tnext(ax[1], q[1]); tn2 = dda_tnext(ax[2], q[2]); }
+                        }
+                    }
+                    walking = more;
+#pragma unroll
+                    for (int j = 0; j < kDdaK; ++j) {
+                        if (j < n) {
+                            const bool valid = vv[j].weight > 0.0f;
+                            if (valid && vv[j].sdf <= 0.0f) {
+                                if (firstVoxel) {
+                                    // the voxel the ray was in before the entry event: one step back on the entry axis, in the
+                                    // neighbouring block -- allocated iff it is in the wave's set
+                                    const int n0 = vq0[j] - (xe == 0 ? ax[0].s : 0), n1 = vq1[j] - (xe == 1 ? ax[1].s : 0), n2 = vq2[j] - (xe == 2 ? ax[2].s : 0);
+                                    const int fs = coop_find(tags, coop_tag((n0 >> 3) - base0, (n1 >> 3) - base1, (n2 >> 3) - base2));
+                                    pv = false;
+                                    if (fs >= 0) {
+                                        const uint32_t np = ptrs[fs];
+                                        if (np != (uint32_t)VH_FREE_BLOCK && np != kCoopUnresolved) {
+                                            const Voxel nb = dp.blocks[(size_t)np + (size_t)(((n2 & 7) << 6) | ((n1 & 7) << 3) | (n0 & 7))];
+                                            pv = nb.weight > 0.0f; ps = nb.sdf; p0 = n0; p1 = n1; p2 = n2;
+                                        }
+                                    }
+                                }
+                                if (pv && ps > 0.0f) {
+                                    if (dda_before(vt[j], vp[j], bestT, bestP)) {
+                                        bestT = vt[j]; bestP = vp[j];
+                                        // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
+                                        const float tc = ((ra.zrow[0] * (float)vq0[j] + ra.zrow[1] * (float)vq1[j]) + ra.zrow[2] * (float)vq2[j]) + ra.zrow[3];
+                                        const float tp = ((ra.zrow[0] * (float)p0 + ra.zrow[1] * (float)p1) + ra.zrow[2] * (float)p2) + ra.zrow[3];
+                                        hit = tp + ((tc - tp) * ps) / (ps - vv[j].sdf);
+                                        found = true;
+                                        hx = vq0[j]; hy = vq1[j]; hz = vq2[j]; hptr = bptr;
+                                    }
+                                    walking = false;                   // (the block's first pair: nothing earlier behind it)
+                                    n = j;                             // (stops the judging)
+                                }
+                            }
+                            pv = valid; ps = vv[j].sdf; p0 = vq0[j]; p1 = vq1[j]; p2 = vq2[j];
+                            firstVoxel = false;
+                        }
+                    }
+                }
+            }
+            // a candidate that arrived before this window's end cannot be beaten by a block found later
+            final_ = final_ || bestT < tw + 64.0f * dt2;
+            if (__ballot(!final_) == 0ull) break;
+        }
+        if (!fail) { coopDone = true; live = false; }
+    }
     // ---- beam front end: the depth before which no ray of this wave can meet an allocated block ----
-    if (ra.beam) {
+    if (ra.beam && !coopDone) {
         Beam bm;
         // (the corner rays' directions are those of the patch's corner lanes: no division here)
         const float a0 = __shfl(dx, 0), a1 = __shfl(dx, kPatch == 0 ? 15 : 7);
@@ -407,7 +735,6 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
         }
     }
     const unsigned long long stamp1 = ra.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const int prio[3] = {2, 0, 1};
     // ---- the walk: one cell per iteration, at block level (sh = 3) through absent blocks, at voxel level (sh = 0)
     // inside allocated ones.  Both levels are the same merge of three monotone crossing-time sequences -- the
     // crossing out of block coordinate k is the voxel-level event out of the block's last coordinate, so the block
@@ -422,10 +749,8 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
     // branchy form of this loop spent 3 000 scalar against 2 900 vector instructions per wave.  The voxel of an
     // allocated block and the bucket-bit word of a block are fetched by the SAME load instruction (address select;
     // the bitmap has a word of padding).
-    bool found = false;
     int prevValid = 0;
-    float prevSdf = 0.0f, hit = 0.0f;
-    int hx = 0, hy = 0, hz = 0, hptr = VH_FREE_BLOCK;          // the last valid sample's voxel; after a hit: the hit voxel and its block
+    float prevSdf = 0.0f;
     int cptr = 0, kx = 0, ky = 0, kz = 0;                      // the allocated block the ray stands in (voxel level)
     int budget = ra.budget;
     int sh = 3;                                                // level: 3 = blocks, 0 = voxels
