@@ -16,7 +16,7 @@ for p in poses:
     t.integrate(p, synth.render_room_verts(p, 640, 480, prims, device="cuda"))
 depth = torch.empty((480, 640), dtype=torch.float32, device="cuda")
 nw = 40 * 30 * 4
-st = torch.zeros((nw, 4), dtype=torch.int64, device="cuda")
+st = torch.zeros((nw, 8), dtype=torch.int64, device="cuda")
 for i in range(5):
     t.raycast(poses[(7 * i) % 120], depth)
 t.synchronize()
@@ -38,7 +38,15 @@ for k in (0, 35, 77):
           [(round(float(life[i]), 1), round(float(start[i]), 1), int(s[i, 2] & 0xffffffff), int(rounds[i]), int(s[i, 3] & 0xffff), int((s[i, 3] >> 16) & 0xffff)) for i in order])
     front = (s[:, 3] >> 32) / 100.0
     print(f"   prologue + beam front end per wave: mean {front.mean():.2f} p99 {np.percentile(front, 99):.2f} max {front.max():.2f} us")
+    if s[:, 6].max() > 0:
+        tA, tB = s[:, 4] / 100.0, s[:, 5] / 100.0
+        print(f"   cooperative form: set built after {tA.mean():.2f} us (max {tA.max():.2f}), list resolved after {tB.mean():.2f} (max {tB.max():.2f}); "
+              f"list length mean {s[:, 6].mean():.1f} p99 {np.percentile(s[:, 6], 99):.0f} max {s[:, 6].max()}; blocks walked by some lane: mean {s[:, 7].mean():.1f} max {s[:, 7].max()}")
+        slow = np.argsort(-life)[:6]
+        print("   slowest waves: (life, list, walked)", [(round(float(life[i]), 1), int(s[i, 6]), int(s[i, 7])) for i in slow])
     ok = rounds > 0
+    if not ok.any():
+        continue
     print(f"   loop rounds per wave: mean {rounds[ok].mean():.1f} p99 {np.percentile(rounds[ok], 99):.0f} max {rounds.max():.0f}; "
           f"us per round: mean wave {((life[ok] - front[ok]) / rounds[ok]).mean():.2f}, slowest waves {np.mean([(life[i] - front[i]) / max(1, rounds[i]) for i in order]):.2f}")
     h, _ = np.histogram(end, bins=10, range=(0, end.max()))

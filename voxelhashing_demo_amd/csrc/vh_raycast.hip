@@ -335,12 +335,22 @@ __device__ __forceinline__ bool beam_slab_occupied(const FrameParams &fp, const 
 // of 64 when the range is longer), the boxes are conservative, so every allocated block any ray of the wave visits
 // is in the list.  Whenever the preconditions fail -- a box spans more than two blocks on an axis, the set
 // overflows, a block lies more than 511 blocks from the wave's first -- the wave falls back to the per-lane walk.
+#ifndef VH_COOP_LDS
+#define VH_COOP_LDS 0      // 1: the walked block is staged in LDS (4 KiB per wave), 0: its voxels are gathered VH_COOP_K at a time
+#endif
+#ifndef VH_COOP_K
+#define VH_COOP_K 2
+#endif
+constexpr int kCoopK = VH_COOP_K;
 constexpr int kCoopSlots = 256;                       // per wave: cells with a set bucket bit
 constexpr uint32_t kCoopUnresolved = 0x7ffffffeu;     // sPtr: not looked up yet
 struct CoopShared {
     uint32_t tag[4][kCoopSlots];
     uint32_t ptr[4][kCoopSlots];
     uint16_t list[4][kCoopSlots];
+#if VH_COOP_LDS
+    Voxel block[4][kBlockVoxels];     // the block the wave is walking (4 KiB per wave)
+#endif
 };
 
 __device__ __forceinline__ uint32_t coop_tag(int rx, int ry, int rz) { return 1u + (uint32_t)rx + ((uint32_t)ry << 10) + ((uint32_t)rz << 20); }
@@ -433,6 +443,8 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
     int hx = 0, hy = 0, hz = 0, hptr = VH_FREE_BLOCK;          // (per-lane walk: the last valid sample's voxel;) after a hit: the hit voxel and its block
     const int prio[3] = {2, 0, 1};
     bool coopDone = false;
+    unsigned long long stampA = stamp0, stampB = stamp0;      // diagnostics: the set is built / the list is resolved
+    int coopList = 0, coopWalks = 0;
     if (ra.beam == 2) {
         __shared__ CoopShared sh_;
         uint32_t *tags = sh_.tag[wave], *ptrs = sh_.ptr[wave];
@@ -519,6 +531,7 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (fail) break;
+            if (ra.stamps) stampA = __builtin_amdgcn_s_memrealtime();
             // ---- 2. the new cells, four per lane: allocated? ----
             const int listBegin = nList;
             {
@@ -570,6 +583,7 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (ra.stamps) { stampB = __builtin_amdgcn_s_memrealtime(); coopList = nList; }
             // ---- 3. every ray against every new block of the list ----
             for (int i = listBegin; i < nList; ++i) {
                 if (__ballot(!final_) == 0ull) break;
@@ -615,6 +629,22 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
                 bool enters = !miss && (inside || xe == xo || dda_before(tE, pE, tO, pO)) && (inside || tE < ra.tMax);
                 enters = enters && dda_before(tE, pE, bestT, bestP);                  // (not behind the best candidate so far)
                 if (__ballot(enters) == 0ull) continue;
+                ++coopWalks;
+#if VH_COOP_LDS
+                // the block's 4 KiB into LDS, 64 bytes per lane (one coalesced round trip; the walks then read it at LDS
+                // latency instead of gathering 64 cache lines per step)
+                {
+                    __builtin_amdgcn_wave_barrier();               // (the previous block's walks are done with the buffer)
+                    const float4 *src = reinterpret_cast<const float4 *>(dp.blocks + (size_t)bptr) + lane * 4;
+                    float4 *dst = reinterpret_cast<float4 *>(sh_.block[wave]) + lane * 4;
+                    const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                    dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                const Voxel *blk = sh_.block[wave];
+#endif
                 if (!enters) continue;
                 // the voxel the ray enters at
                 int q[3];
@@ -626,6 +656,61 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
                     else if (a == xe) q[a] = nearC;
                     else q[a] = dda_advance(ax[a], prio[a], startIn[a] ? c[a] : nearC, farC, tE, pE);
                 }
+#if VH_COOP_LDS
+                float tn0 = dda_tnext(ax[0], q[0]), tn1 = dda_tnext(ax[1], q[1]), tn2 = dda_tnext(ax[2], q[2]);
+                float tArr = tE;
+                int pArr = pE;
+                bool pv = false, firstVoxel = !inside;
+                float ps = 0.0f;
+                int p0 = 0, p1 = 0, p2 = 0;
+                for (;;) {
+                    const Voxel sv = blk[((q[2] & 7) << 6) | ((q[1] & 7) << 3) | (q[0] & 7)];
+                    const bool valid = sv.weight > 0.0f;
+                    if (valid && sv.sdf <= 0.0f) {
+                        if (firstVoxel) {
+                            // the voxel the ray was in before the entry event: one step back on the entry axis, in the
+                            // neighbouring block -- allocated iff it is in the wave's set
+                            const int n0 = q[0] - (xe == 0 ? ax[0].s : 0), n1 = q[1] - (xe == 1 ? ax[1].s : 0), n2 = q[2] - (xe == 2 ? ax[2].s : 0);
+                            const int fs = coop_find(tags, coop_tag((n0 >> 3) - base0, (n1 >> 3) - base1, (n2 >> 3) - base2));
+                            pv = false;
+                            if (fs >= 0) {
+                                const uint32_t np = ptrs[fs];
+                                if (np != (uint32_t)VH_FREE_BLOCK && np != kCoopUnresolved) {
+                                    const Voxel nb = dp.blocks[(size_t)np + (size_t)(((n2 & 7) << 6) | ((n1 & 7) << 3) | (n0 & 7))];
+                                    pv = nb.weight > 0.0f; ps = nb.sdf; p0 = n0; p1 = n1; p2 = n2;
+                                }
+                            }
+                        }
+                        if (pv && ps > 0.0f) {
+                            if (dda_before(tArr, pArr, bestT, bestP)) {
+                                bestT = tArr; bestP = pArr;
+                                // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
+                                const float tc = ((ra.zrow[0] * (float)q[0] + ra.zrow[1] * (float)q[1]) + ra.zrow[2] * (float)q[2]) + ra.zrow[3];
+                                const float tp = ((ra.zrow[0] * (float)p0 + ra.zrow[1] * (float)p1) + ra.zrow[2] * (float)p2) + ra.zrow[3];
+                                hit = tp + ((tc - tp) * ps) / (ps - sv.sdf);
+                                found = true;
+                                hx = q[0]; hy = q[1]; hz = q[2]; hptr = bptr;
+                            }
+                            break;                                   // (the block's first pair: nothing earlier behind it)
+                        }
+                    }
+                    pv = valid; ps = sv.sdf; p0 = q[0]; p1 = q[1]; p2 = q[2];
+                    firstVoxel = false;
+                    // the crossing that ends this voxel (raycastSDF.frag:156-170)
+                    const bool m0 = tn0 < tn1 && tn0 < tn2;
+                    const bool m2 = !m0 && tn2 < tn1;
+                    tArr = m0 ? tn0 : m2 ? tn2 : tn1;
+                    pArr = m0 ? 2 : m2 ? 1 : 0;
+                    // (one recomputed crossing time, selected in and out: no three-way branch)
+                    const int sa = m0 ? ax[0].s : m2 ? ax[2].s : ax[1].s;
+                    const int qa = (m0 ? q[0] : m2 ? q[2] : q[1]) + sa;
+                    const float gsa = m0 ? ax[0].Gs : m2 ? ax[2].Gs : ax[1].Gs, iea = m0 ? ax[0].invE : m2 ? ax[2].invE : ax[1].invE;
+                    const float tnew = ((float)qa - gsa) * iea;
+                    q[0] = m0 ? qa : q[0]; q[2] = m2 ? qa : q[2]; q[1] = (m0 || m2) ? q[1] : qa;
+                    tn0 = m0 ? tnew : tn0; tn2 = m2 ? tnew : tn2; tn1 = (m0 || m2) ? tn1 : tnew;
+                    if (!(tArr < ra.tMax) || ((qa >> 3) != (m0 ? kk[0] : m2 ? kk[2] : kk[1]))) break;   // (visited iff the ray arrives before t_max)
+                }
+            #else
                 float tn0 = dda_tnext(ax[0], q[0]), tn1 = dda_tnext(ax[1], q[1]), tn2 = dda_tnext(ax[2], q[2]);
                 float tArr = tE;
                 int pArr = pE;
@@ -633,13 +718,13 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
                 float ps = 0.0f;
                 int p0 = 0, p1 = 0, p2 = 0;
                 while (walking) {
-                    int vq0[kDdaK], vq1[kDdaK], vq2[kDdaK], vp[kDdaK];
-                    float vt[kDdaK];
-                    Voxel vv[kDdaK];
+                    int vq0[kCoopK], vq1[kCoopK], vq2[kCoopK], vp[kCoopK];
+                    float vt[kCoopK];
+                    Voxel vv[kCoopK];
                     int n = 0;
                     bool more = true;
 #pragma unroll
-                    for (int j = 0; j < kDdaK; ++j) {
+                    for (int j = 0; j < kCoopK; ++j) {
                         if (more) {
                             vq0[j] = q[0]; vq1[j] = q[1]; vq2[j] = q[2]; vt[j] = tArr; vp[j] = pArr;
                             vv[j] = dp.blocks[(size_t)bptr + (size_t)(((q[2] & 7) << 6) | ((q[1] & 7) << 3) | (q[0] & 7))];
@@ -658,7 +743,7 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
                     }
                     walking = more;
 #pragma unroll
-                    for (int j = 0; j < kDdaK; ++j) {
+                    for (int j = 0; j < kCoopK; ++j) {
                         if (j < n) {
                             const bool valid = vv[j].weight > 0.0f;
                             if (valid && vv[j].sdf <= 0.0f) {
@@ -695,6 +780,7 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
                         }
                     }
                 }
+            #endif
             }
             // a candidate that arrived before this window's end cannot be beaten by a block found later
             final_ = final_ || bestT < tw + 64.0f * dt2;
@@ -917,9 +1003,10 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
     }
 #undef VH_DDA_TN
     if (ra.stamps && lane == 0) {
-        const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 4;
+        const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
         ra.stamps[w] = stamp0; ra.stamps[w + 1] = __builtin_amdgcn_s_memrealtime();
         ra.stamps[w + 2] = (unsigned long long)(ra.budget - budget) | ((unsigned long long)round << 32); ra.stamps[w + 3] = (unsigned long long)(pu | (pv << 16)) | ((stamp1 - stamp0) << 32);
+        ra.stamps[w + 4] = stampA - stamp0; ra.stamps[w + 5] = stampB - stamp0; ra.stamps[w + 6] = (unsigned long long)coopList; ra.stamps[w + 7] = (unsigned long long)coopWalks;
     }
     if (!inImage) return;
     depthOut[(size_t)v * fp.width + u] = hit;
