@@ -1,0 +1,105 @@
+"""The DDA raycast on the GPU (vh_raycast / vh_raycast_normals, raycast_mode = VH_RAYCAST_DDA): every form the kernel has --
+the cooperative form (one block list per wave), the per-lane walk behind the beam front end, the per-lane walk from t_min --
+must give the oracle's bits (oracle/vh_oracle.c: vho_raycast_dda, which walks voxel by voxel and leaves absent blocks only
+through exact look-ups), depth and normals, also where the cooperative form falls back (boxes wider than two blocks, views
+with t_min = 0, several depth windows)."""
+import numpy as np
+import pytest
+
+from voxelhashing_demo_amd import synth
+
+pytestmark = pytest.mark.gpu
+I4 = np.eye(4, dtype=np.float32)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _room(oracle, vh, torch, W, H, voxel, buckets, blocks, frames):
+    kw = dict(numBuckets=buckets, numVoxelBlocks=blocks, voxelSize=voxel)
+    ot = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    gt = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
+    poses, prims = synth.camera_loop(500), synth.room_primitives()
+    for i in frames:
+        v = synth.render_room_verts(poses[i], W, H, prims).numpy()
+        ot.integrate_mt(poses[i], v, 8)
+        gt.integrate(poses[i], torch.from_numpy(v).cuda())
+    gt.synchronize()
+    return ot, gt, poses
+
+
+@pytest.mark.parametrize("beam", [2, 1, 0])
+def test_every_form_of_the_kernel_equals_the_oracle(oracle, vh, torch_cuda, beam):
+    torch = torch_cuda
+    W, H = 640, 480
+    ot, gt, poses = _room(oracle, vh, torch, W, H, 0.02, 1 << 18, 1 << 14, (0, 3, 6, 9, 30, 33))
+    gt.set_option("raycast_beam", beam)
+    d = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    n = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    views = [(poses[3], 0.1, 5.0), (poses[20], 0.1, 5.0), (synth.yaw_pose(200.0, (0.3, 0.1, -0.4)), 0.1, 5.0),
+             (poses[6], 0.0, 5.0),                    # t_min = 0: the beam is off, the per-lane walk runs
+             (poses[9], 0.5, 2.0), (poses[31], 0.1, 12.0)]      # a short range; a range of three depth windows
+    for pose, t0, t1 in views:
+        gt.raycast_normals(pose, d, n, t0, t1)
+        gt.synchronize()
+        od, on = ot.raycast(pose, t0, t1, normals=True)
+        assert np.array_equal(_bits(d.cpu().numpy()), _bits(od)), (beam, t0, t1)
+        assert np.array_equal(_bits(n.cpu().numpy()), _bits(on)), (beam, t0, t1)
+        gt.raycast(pose, d, t0, t1)                   # (the kernel without the normal output)
+        gt.synchronize()
+        assert np.array_equal(_bits(d.cpu().numpy()), _bits(od))
+    assert (od > 0).mean() > 0.3
+    gt.close()
+    ot.close()
+
+
+def test_small_voxels_wide_beams_and_odd_image_sizes(oracle, vh, torch_cuda):
+    """5 mm voxels at 320x240 (a patch's beam is wider than two blocks far from the camera: those waves fall back to the
+    per-lane walk), an image whose size is not a multiple of the 16x16 tile, and intrinsics of a different camera."""
+    torch = torch_cuda
+    for (W, H, voxel) in ((320, 240, 0.005), (200, 150, 0.02)):
+        ot, gt, poses = _room(oracle, vh, torch, W, H, voxel, 1 << 16, 1 << 14, (0, 4, 8))
+        if W == 200:
+            for t in (ot, gt):
+                t.set_raycast_intrinsics(150.0, 160.0, 97.3, 71.9)
+        d = torch.empty((H, W), dtype=torch.float32, device="cuda")
+        n = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+        for pose in (poses[4], poses[15]):
+            gt.raycast_normals(pose, d, n, 0.1, 5.0)
+            gt.synchronize()
+            od, on = ot.raycast(pose, 0.1, 5.0, normals=True)
+            assert np.array_equal(_bits(d.cpu().numpy()), _bits(od)) and np.array_equal(_bits(n.cpu().numpy()), _bits(on))
+        assert (od > 0).mean() > 0.2
+        gt.close()
+        ot.close()
+
+
+def test_views_the_dda_refuses_and_option_checks(vh, torch_cuda):
+    torch = torch_cuda
+    gt = vh.SDFHashtable(vh.default_params(numBuckets=1 << 12, numVoxelBlocks=256), 64, 48, 1)
+    d = torch.empty((48, 64), dtype=torch.float32, device="cuda")
+    n = torch.empty((48, 64, 4), dtype=torch.float32, device="cuda")
+    with pytest.raises(vh.VoxelHashError):
+        gt.raycast(I4, d, 0.1, 1.0e6)                 # more than 2^22 voxel steps per ray
+    far = I4.copy()
+    far[0, 3] = 1.0e9
+    with pytest.raises(vh.VoxelHashError):
+        gt.raycast(far, d, 0.1, 5.0)                  # beyond 2^23 voxels from the origin
+    bad = I4.copy()
+    bad[1, 1] = np.nan
+    with pytest.raises(vh.VoxelHashError):
+        gt.raycast(bad, d, 0.1, 5.0)
+    with pytest.raises(vh.VoxelHashError):
+        gt.set_option("raycast_mode", 2)
+    with pytest.raises(vh.VoxelHashError):
+        gt.set_option("raycast_beam", 3)
+    gt.set_raycast_mode(vh.RAYCAST_FIXED_STEP)
+    with pytest.raises(vh.VoxelHashError):
+        gt.raycast_normals(I4, d, n)                  # the march has no normal output
+    gt.raycast(I4, d)                                 # ... but still renders (an empty model: no hit)
+    gt.set_raycast_mode(vh.RAYCAST_DDA)
+    gt.raycast_normals(I4, d, n)
+    gt.synchronize()
+    assert float(d.abs().max()) == 0.0 and float(n.abs().max()) == 0.0
+    gt.close()

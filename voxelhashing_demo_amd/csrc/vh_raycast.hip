@@ -368,38 +368,28 @@ __device__ __forceinline__ int coop_find(const uint32_t *tags, uint32_t tag)
     return -1;
 }
 
-// Shape of the kernel.  A ray's work is small (C2: ~4 macro-cell jumps, ~4 block look-ups, 1.5 allocated blocks,
-// ~9 voxels) but every piece is a dependent memory round trip, and the 64 rays of a wave are each at a different
-// piece at any moment: a loop that lets every lane do "its next thing" executes the jump path AND a whole block
-// walk per iteration (first version: 67 us on C2, slower than the fixed-step march's 47).  So, after the beam
-// front end, the wave alternates between two phases that every lane runs together:
-//   skip   every lane that does not stand in an allocated block looks its cell up (macro-cell bit and bucket bit
-//          fetched together, then the bucket's entries) and leaves it in one exact step if it is empty -- until no
-//          lane of the wave needs a look-up;
-//   walk   every lane that stands in an allocated block walks it: up to kDdaChunk voxel steps of pure arithmetic
-//          (the walk does not depend on the voxels' contents), then the voxel loads together (one round trip
-//          instead of kDdaChunk), then the samples are judged in order -- until no lane is inside a block.
-// Inside a block the walk keeps the voxel as float coordinates (exact below 2^24: the host refuses views beyond
-// 2^23), the local position as three 5-bit fields (value 8..15 = inside; one mask test tells when the ray has
-// left the block) packed with the linear voxel index, and steps all of it without a branch.
-#ifndef VH_DDA_CHUNK
-#define VH_DDA_CHUNK 8
-#endif
+// Shape of the kernel.  A ray's work is small (C2: ~25 absent blocks stepped over, 1.5 allocated blocks, ~10 voxels)
+// but what was measured on the way here (per-wave timeline, tools/raycast_stamps.py; counters, profiles/) is that the
+// launch is as long as its SLOWEST wave -- silhouette and grazing patches -- and that a wave advances at ~4 cycles per
+// instruction whatever its neighbours do: a per-lane loop with exact cell exits took 67 us on C2, two-phase
+// (skip / walk) loops with 8-voxel chunks 73-81, the block-level DDA 72, chunks of 2 cells 60 (4: 70, 8: 89), the
+// fixed-step march 47.  What made the difference was to stop doing the search 64 times per wave: the cooperative form
+// (above; the default) at 46 us.  The per-lane walk below remains as its fall-back and as raycast_beam 1 / 0:
+//   * behind a beam front end (beam = 1) or from t_min (0), one loop serves two levels: blocks (sh = 3) through
+//     absent space, voxels (sh = 0) inside allocated blocks; both are the same merge of three monotone crossing-time
+//     sequences (a block's crossing is the voxel event out of its last coordinate), so no lane waits for another
+//     lane's phase; kDdaK cells ahead are enumerated by arithmetic alone, their loads issued together, then judged
+//     in order; voxel coordinates are rebuilt only when an allocated block is entered from an absent one.
 #ifndef VH_DDA_K
 #define VH_DDA_K 2
 #endif
 #ifndef VH_DDA_PRIO
-#define VH_DDA_PRIO 0
+#define VH_DDA_PRIO 0       // 1: a wave that is still walking after 12 / 24 / 40 rounds raises its priority (measured: no gain)
 #endif
 constexpr int kDdaK = VH_DDA_K;
-#ifndef VH_DDA_BLOCKS
-#define VH_DDA_BLOCKS 4
-#endif
-constexpr int kDdaBlocks = VH_DDA_BLOCKS;
 #ifndef VH_DDA_WAVES
 #define VH_DDA_WAVES 4      // waves per SIMD the register budget must allow (4 800 waves of a 640x480 view = 4.7 per SIMD; 4 vs 5 vs 6 measured equal: the launch is as long as its slowest wave)
 #endif
-constexpr int kDdaChunk = VH_DDA_CHUNK;
 
 template <int kPatch, bool kNormals>
 __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const FrameParams fp, const DevPtrs dp, const RaycastArgs ra,
