@@ -1,0 +1,168 @@
+"""Every number of the bench line has an oracle test at its own configuration and call form.
+
+bench.py times, on C2 (BASELINE.json configs[1]: 640x480, 2^20 buckets x 5, 2^18 voxel blocks, 2 cm voxels, PINHOLE),
+  value / roofline        vh_integrate_batch(8) over consecutive frames of the 500-pose loop
+  loaded_integrate        the same with vh_set_alloc_band(0.1)
+  sensor_depth_input      vh_integrate_depth_batch / vh_integrate_depth on uint16 sensor images
+  sharded_world1          the bucket-range-sharded step (key bins + sensor packets) with one rank over RCCL
+  raycast                 vh_raycast on the model those frames built
+Here each of them runs from a FRESH table (so the frames that insert blocks are inside) over 96 frames of that loop in
+batches of 8, next to the oracle (vho_integrate_mt: identical results on several host threads), and is compared slot for
+slot, every 7th block bit for bit, the compact set, the counters, and one raycast (depth and normals)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import entries_as_set
+from voxelhashing_demo_amd import synth
+
+pytestmark = pytest.mark.gpu
+W, H = 640, 480
+KW = dict(numBuckets=1 << 20, numVoxelBlocks=1 << 18)
+FRAMES, BATCH = 96, 8
+THREADS = 16
+
+
+@pytest.fixture(scope="module")
+def loop_frames():
+    """The first 96 poses of the C2 loop and their vertex maps, rendered on the host (the GPU and the oracle must consume
+    the same bits: torch renders the scene with a last-ulp difference between CPU and GPU)."""
+    poses = synth.camera_loop(500)[:FRAMES]
+    prims = synth.room_primitives()
+    return poses, [synth.render_room_verts(p, W, H, prims).numpy() for p in poses]
+
+
+def _compare_light(ot, gt, every=7, min_blocks=500):
+    """_compare of test_gpu_parity without the 1 GiB volume download: all slots, every `every`-th block's bits."""
+    otab, gtab = ot.hash_table(), gt.hash_table()
+    assert np.array_equal(otab["ptr"] != -1, gtab["ptr"] != -1)
+    assert np.array_equal(otab["pos"], gtab["pos"])
+    assert np.array_equal(otab["offset"], gtab["offset"])
+    live = np.nonzero(gtab["ptr"] != -1)[0]
+    assert len(live) >= min_blocks
+    assert len(set(gtab["ptr"][live].tolist())) == len(live), "two entries share a voxel block"
+    ovol = ot.sdf_blocks()
+    for i in live[::every]:
+        g = gt.block_voxels(int(gtab["ptr"][i]))
+        o = ovol[int(otab["ptr"][i]):int(otab["ptr"][i]) + 512]
+        assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), f"block {tuple(gtab['pos'][i])} differs in bits"
+    ocomp, gcomp = ot.compact(), gt.compact()
+    assert len(ocomp) == len(gcomp) and entries_as_set(ocomp) == entries_as_set(gcomp)
+    c = gt.counters()
+    assert c["heap_counter"] == ot.heap_counter() and c["heap_exhausted"] == 0 and c["cand_overflow"] == 0
+    assert c["allocated_total"] - c["freed_total"] == len(live)
+    return len(live)
+
+
+def _raycast_equal(ot, gt, torch, pose):
+    d = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    n = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    gt.raycast_normals(pose, d, n)
+    gt.synchronize()
+    od, on = ot.raycast(pose, normals=True)
+    assert np.array_equal(d.cpu().numpy().view(np.uint32), od.view(np.uint32))
+    assert np.array_equal(n.cpu().numpy().view(np.uint32), on.view(np.uint32))
+    assert (od > 0).mean() > 0.5
+
+
+@pytest.mark.parametrize("band", [0.0, 0.1])
+def test_c2_integrate_batch_from_a_fresh_table(oracle, vh, torch_cuda, loop_frames, band):
+    """`value` (band 0) and `loaded_integrate` (band 0.1): vh_integrate_batch(8), pipelined frames, fresh table."""
+    torch = torch_cuda
+    poses, verts = loop_frames
+    ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+    gt = vh.SDFHashtable(vh.default_params(**KW), W, H, 1)
+    gt.set_option("pipeline", 1)                       # as bench.py's Integrator does
+    if band:
+        ot.set_alloc_band(band)
+        gt.set_alloc_band(band)
+    d_verts = [torch.from_numpy(v).cuda() for v in verts]
+    torch.cuda.synchronize()
+    for k in range(0, FRAMES, BATCH):
+        gt.integrate_batch(poses[k:k + BATCH], d_verts[k:k + BATCH])
+        for j in range(k, k + BATCH):
+            ot.integrate_mt(poses[j], verts[j], THREADS)
+    gt.synchronize()
+    blocks = _compare_light(ot, gt, min_blocks=2000 if band else 500)
+    assert gt.counters()["epoch"] == FRAMES
+    _raycast_equal(ot, gt, torch, poses[40])
+    print(f"band {band}: {blocks} blocks after {FRAMES} frames")
+    gt.close()
+    ot.close()
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_c2_sensor_depth_frames_from_a_fresh_table(oracle, vh, torch_cuda, loop_frames, batched):
+    """`sensor_depth_input`: the frames straight from uint16 sensor images (vh_integrate_depth_batch of 8 / vh_integrate_depth
+    one by one, pipelined), against the oracle fed with vho_preprocess's vertex maps of the same images."""
+    torch = torch_cuda
+    poses, verts = loop_frames
+    kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+    d16 = [np.round(v[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for v in verts[:48]]
+    ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+    gt = vh.SDFHashtable(vh.default_params(**KW), W, H, 1)
+    gt.set_option("pipeline", 1)
+    dd = [torch.from_numpy(d).cuda() for d in d16]
+    torch.cuda.synchronize()
+    for k in range(0, 48, BATCH):
+        if batched:
+            gt.integrate_depth_batch(poses[k:k + BATCH], dd[k:k + BATCH], kinv)
+        else:
+            for j in range(k, k + BATCH):
+                gt.integrate_depth(poses[j], dd[j], kinv)
+        for j in range(k, k + BATCH):
+            ot.integrate_mt(poses[j], oracle.preprocess(d16[j], kinv)[0], THREADS)
+    gt.synchronize()
+    _compare_light(ot, gt)
+    _raycast_equal(ot, gt, torch, poses[20])
+    gt.close()
+    ot.close()
+
+
+def test_c2_sharded_world1_over_rccl(oracle, vh, torch_cuda, loop_frames):
+    """`sharded_world1`: the code path of the N > 1 lines with one rank -- key generation from the sensor images, the
+    all-to-all of the key bins and the all-gather of the sensor packets over RCCL, vh_apply_frames_batch -- through the
+    three-stream pipeline bench.py uses, at C2's table size, batches of 8."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from voxelhashing_demo_amd import dist as vdist
+    torch = torch_cuda
+    poses, verts = loop_frames
+    kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+    n = 48
+    d16 = [np.round(v[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for v in verts[:n]]
+    pre = [oracle.preprocess(d, kinv)[0] for d in d16]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        plan = vdist.ShardPlan(KW["numBuckets"], 1)
+        transport = vdist.TorchDistTransport()
+        table_stream, front = torch.cuda.Stream(), torch.cuda.Stream()
+        capacity = max(2048, -(-W * H // 16))                  # bench_sharded's bin size
+        sh = vdist.HipShard(vh.default_params(**KW), W, H, 1, plan, 0, capacity, batch=BATCH, stream=table_stream, sets=2,
+                            sensor_k_inv=kinv)
+        pipe = vdist.ShardedPipeline(sh, transport, table_stream, front)
+        dv = [torch.from_numpy(v).cuda() for v in pre]
+        dd = [torch.from_numpy(d).cuda() for d in d16]
+        torch.cuda.synchronize()
+        ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+        for k in range(0, n, BATCH):
+            pipe.feed(poses[k:k + BATCH], dv[k:k + BATCH], dd[k:k + BATCH])
+            for j in range(k, k + BATCH):
+                ot.integrate_mt(poses[j], pre[j], THREADS)     # one camera: the multi-camera frame is integrate()
+        pipe.flush()
+        torch.cuda.synchronize()
+        assert sh.table.counters()["bin_overflow"] == 0
+        _compare_light(ot, sh.table)
+        sh.table.close()
+        ot.close()
+    finally:
+        dist.destroy_process_group()
