@@ -139,6 +139,11 @@ __global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const Frame
 //     winners count as heap_exhausted and retry next frame): then claim(i+1) knows -- from two numbers
 //     that are stable while the launch runs -- that nothing is in flight and reads the table as it is.
 //     (vh_integrate without the pipeline serves as many winners as there are blocks.)
+// (Round 3 measured the slimmer argument block the round-2 review asked for -- one FrameParams, one DevPtrs, and of the
+// pending frame only its inverse pose, lock epoch and three alternating pointers: 0.55 instead of 0.8 KB, scalar spills
+// 173-208 -> 129-137 -- side by side with this form on one box (tools/ab_commits.sh): C2 18.6 vs 18.0 us, C3 70.6 vs
+// 70.3, C2 with band allocation 24.1 vs 23.9.  Slower, so the two-struct form stays; the spills sit in the role
+// prologues, outside every loop.)
 struct PipeArgs {
     uint32_t claimBlocks, walkBlocks, commitBlocks, integrateBlocks;
     uint32_t numEntries;
