@@ -77,6 +77,8 @@ def parse_args():
                          "all-to-all + all-gather (sharded path)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="sharded path: do not overlap key generation + RCCL with the table work")
+    ap.add_argument("--python-exchange", action="store_true",
+                    help="sharded path: round 2's Python host (torch.distributed collectives) instead of vh_dist_* inside the library")
     ap.add_argument("--float-packets", action="store_true",
                     help="sharded path: float vertex maps and float camera-z packets instead of uint16 sensor depth")
     ap.add_argument("--sharded-raycast", action="store_true",

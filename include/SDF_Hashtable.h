@@ -17,6 +17,7 @@
 #include <cstdint>
 
 #include "voxelhash.h"
+#include "voxelhash_dist.h"
 
 /* row-major 4x4, the only part of cuda_SimpleMatrixUtil.h:800-1100 the path uses */
 struct float4x4 {
@@ -32,11 +33,24 @@ class SDFRenderer;   /* not part of this build; kept so signatures compile */
 
 class SDF_Hashtable {
     vh_context *ctx_;
+    vh_dist *dist_;                                    /* multi-GPU constructor: this rank of the sharded table (owns ctx_) */
     HashTableParams h_hashtableParams;
 
 public:
     SDF_Hashtable();                                   /* common.h:39-50, 640x480, REFERENCE semantics */
     SDF_Hashtable(const HashTableParams &params, int width, int height, int semantics);
+    /* One rank of ONE logical table sharded by bucket range over `world` GPUs, one camera per rank (voxelhash_dist.h):
+     * params.numBuckets = all buckets, params.numVoxelBlocks = per rank; uniqueId: the 128 bytes of
+     * SDF_Hashtable::uniqueId() drawn by one rank and handed to all (any out-of-band channel); `batch` frames per
+     * camera travel in one exchange; kInv: K^-1 of the cameras (the frames are uint16 sensor images).  The frames enter
+     * through integrateExchange(); raycast() renders this rank's view through the whole table. */
+    SDF_Hashtable(const HashTableParams &params, int width, int height, int semantics, int rank, int world, int batch,
+                  const char uniqueId[VH_DIST_ID_BYTES], const float kInv[9], int device = -1);
+    static void uniqueId(char id[VH_DIST_ID_BYTES]);
+    /* `batch` frames of this rank's camera (poses: batch*16 row-major floats; d_depth: batch device pointers): queues
+     * this exchange and applies the previous one; flush() completes what is in flight.  Collective over the ranks. */
+    void integrateExchange(const float *poses, const uint16_t *const *d_depth);
+    bool sharded() const { return dist_ != nullptr; }
     ~SDF_Hashtable();
     SDF_Hashtable(const SDF_Hashtable &) = delete;
     SDF_Hashtable &operator=(const SDF_Hashtable &) = delete;

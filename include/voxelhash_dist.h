@@ -1,0 +1,79 @@
+/*
+ * voxelhash_dist.h -- C-ABI of the multi-GPU host of libvoxelhash_hip.so: one logical voxel-hash table cut into
+ * bucket ranges, one process (or thread) per GPU, the per-frame exchange on RCCL over xGMI.
+ *
+ * The reference's host is C++ (SDF_Hashtable.cpp:11-40) and drives ONE GPU.  This is the same integrate() for R
+ * cameras into one table sharded over R GPUs: rank r owns buckets [r*per, (r+1)*per) -- entries, heap
+ * and voxel blocks of every key that hashes there -- and holds camera r.  A step is a batch of `batch` multi-camera
+ * frames (voxelhash.h, "bucket-range sharding"):
+ *
+ *     generate   this rank's frames -> block keys binned by owner + camera packets        (vh_generate_keys_*_batch)
+ *     exchange   ncclAllToAll of the key bins, ncclAllGather of the packets               (RCCL, its own stream)
+ *     apply      on the owner: lock epoch, insert, walk + TSDF update for all cameras      (vh_apply_frames_batch)
+ *
+ * software-pipelined inside the library over three HIP streams and two buffer sets with events, exactly as the Python
+ * host of round 2 did it (voxelhashing_demo_amd/dist.py: ShardedPipeline) -- but one C call per exchange instead of a
+ * dozen Python calls and four torch collectives (host cost per exchange of 8 frames: 0.185 ms there).  The table sees its
+ * operations in the order of the plain step sequence, so results do not depend on the pipelining.
+ *
+ * RCCL is bound at run time (dlopen of librccl.so.1, or whatever copy the process has loaded already -- torch's): the
+ * library has no link-time dependency on it, and single-GPU users never load it.  No torch types anywhere.
+ */
+#ifndef VOXELHASH_DIST_H
+#define VOXELHASH_DIST_H
+
+#include "voxelhash.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VH_DIST_ID_BYTES 128            /* = NCCL_UNIQUE_ID_BYTES */
+
+typedef struct vh_dist vh_dist;
+
+typedef struct vh_dist_config {
+    vh_config table;          /* the LOGICAL table (params.numBuckets = all buckets; numVoxelBlocks = per rank), image size,
+                                 semantics, device of this rank */
+    int32_t rank, world;      /* this rank's index and the number of ranks = cameras = shards (<= VH_MAX_CAMERAS) */
+    int32_t batch;            /* frames per camera and exchange (>= 1) */
+    int32_t key_capacity;     /* records per (camera, owner, frame) key bin; 0 = max(2048, W*H/16) */
+    int32_t packet_format;    /* VH_PACKET_U16: frames are uint16 sensor images (k_inv used), packets carry the image;
+                                 VH_PACKET_F32: frames are float4 vertex maps, packets carry a float camera-z plane */
+    float   k_inv[9];         /* row-major K^-1 of the cameras (VH_PACKET_U16) */
+} vh_dist_config;
+
+/* ncclGetUniqueId: one rank calls it, every rank passes the same bytes to vh_dist_create (exchanged out of band: MPI,
+ * a file, torch.distributed over gloo ...).  world == 1 needs no exchange. */
+int vh_dist_unique_id(char id[VH_DIST_ID_BYTES]);
+
+/* Creates this rank's shard (vh_create_shard over its bucket range), the communicator (ncclCommInitRank with `id`; or
+ * adopts `nccl_comm`, an ncclComm_t the caller owns, when it is not NULL), streams, events and the exchange buffers.
+ * Collective: every rank calls it. */
+int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_ID_BYTES], void *nccl_comm, vh_dist **out);
+int vh_dist_destroy(vh_dist *d);
+
+/* this rank's shard: counters, download, snapshot, options (set before the first step) ... go through voxelhash.h */
+vh_context *vh_dist_shard(vh_dist *d);
+
+/* One exchange: `batch` frames of THIS rank's camera (poses: batch*16 host floats; d_frames: host array of `batch`
+ * device pointers -- uint16 sensor images or float4 vertex maps by packet_format).  Enqueues the generation and the
+ * collectives of this exchange and the application of the PREVIOUS one; returns without waiting.  Collective. */
+int vh_dist_step_batch(vh_dist *d, const float *poses, const void *const *d_frames);
+/* applies the exchange in flight and waits for the three streams */
+int vh_dist_flush(vh_dist *d);
+
+/* Raycast of this rank's view through the WHOLE sharded table (voxelhash.h: vh_export_views_fixed / vh_import_views):
+ * all-gather of the R view poses, one walk of the shard for all views, ncclAllToAll of fixed record slots, import into a
+ * private view table, vh_raycast -- one stream, no host synchronisation.  capacity: records per (shard, view) slot range.
+ * d_lost (device int32, nullable): records this view's sources selected beyond the capacity.  Collective. */
+int vh_dist_raycast(vh_dist *d, const float pose[16], float t_min, float t_max, int32_t capacity, float *d_depth_out,
+                    int32_t *d_lost);
+
+/* host seconds spent inside vh_dist_step_batch since creation / the number of calls (diagnostics for bench.py) */
+int vh_dist_host_stats(vh_dist *d, double *seconds, uint64_t *calls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXELHASH_DIST_H */

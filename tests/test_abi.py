@@ -11,8 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "voxelhash.h")
 
 
-def declared_functions():
-    src = open(HEADER).read()
+DIST_HEADER = os.path.join(ROOT, "include", "voxelhash_dist.h")
+
+
+def declared_functions(header=HEADER):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = re.findall(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b(\w+)\s*\([^;{]*\)\s*;", src, flags=re.M)
     return sorted(set(n for n in names if n not in ("defined",)))
@@ -36,6 +39,14 @@ def test_library_exports_every_declared_symbol(vh):
     assert not missing, f"declared in voxelhash.h but not exported: {missing}"
     # and the Python binding covers the same set
     assert sorted(_lib.SIGNATURES) == declared_functions()
+    # the multi-GPU host (include/voxelhash_dist.h): exported, bound, and RCCL is NOT a link-time dependency
+    dist = declared_functions(DIST_HEADER)
+    assert "vh_dist_step_batch" in dist and len(dist) == 8
+    assert not [n for n in dist if not hasattr(L, n)]
+    assert sorted(_lib.DIST_SIGNATURES) == dist
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()
 
 
 def test_record_layouts(vh):
@@ -91,7 +102,7 @@ def test_headers_compile_as_c99_and_cxx11(tmp_path):
     import subprocess
     inc = os.path.join(ROOT, "include")
     c = tmp_path / "t.c"
-    c.write_text('#include "voxelhash.h"\nint main(void) { return (int)sizeof(vh_icp_system) + (int)sizeof(vh_view_record); }\n')
+    c.write_text('#include "voxelhash.h"\n#include "voxelhash_dist.h"\nint main(void) { return (int)sizeof(vh_icp_system) + (int)sizeof(vh_view_record) + (int)sizeof(vh_dist_config); }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(c)], check=True)
     cpp = tmp_path / "t.cpp"
     cpp.write_text('#include "voxelhash.h"\n#include "SDF_Hashtable.h"\n#include "CameraTracking.h"\nint main() { return 0; }\n')

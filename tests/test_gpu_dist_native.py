@@ -1,0 +1,144 @@
+"""The multi-GPU host inside the library (include/voxelhash_dist.h: vh_dist_* on RCCL directly), with one rank on the GPU
+box: the pipelined exchange (generate -> ncclAllToAll + ncclAllGather -> apply, three streams) must leave the oracle's
+table, in both packet formats; vh_dist_raycast must render the oracle's image; and a plain C++ program drives it without
+Python or torch (tests/cpp/sharded_demo.cpp).  The N > 1 exchange logic is covered by the gloo tests
+(tests/test_sharding_cpu.py) and by the loop-back shards on one GPU (tests/test_gpu_sharding.py)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from test_sharding_cpu import check_shard_against_full
+from voxelhashing_demo_amd import dist as vdist
+from voxelhashing_demo_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, H = 320, 240
+KW = dict(numBuckets=1 << 14, numVoxelBlocks=1 << 13)
+
+
+def _frames(n):
+    poses = synth.camera_loop(120)[:n]
+    prims = synth.room_primitives()
+    return poses, [synth.render_room_verts(p, W, H, prims).numpy() for p in poses]
+
+
+@pytest.mark.parametrize("sensor", [True, False])
+def test_native_exchange_with_one_rank_equals_the_oracle(oracle, vh, torch_cuda, sensor):
+    torch = torch_cuda
+    batch, steps = 3, 5
+    poses, verts = _frames(batch * steps)
+    kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+    ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+    if sensor:
+        d16 = [np.round(v[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for v in verts]
+        verts = [oracle.preprocess(d, kinv)[0] for d in d16]
+        frames = [torch.from_numpy(d).cuda() for d in d16]
+    else:
+        frames = [torch.from_numpy(v).cuda() for v in verts]
+    torch.cuda.synchronize()
+    nd = vdist.NativeDist(vh.default_params(**KW), W, H, 1, 0, 1, batch, vdist.unique_id(), sensor_k_inv=kinv if sensor else None)
+    for s in range(steps):
+        k = s * batch
+        nd.step(poses[k:k + batch], frames[k:k + batch])
+        for j in range(k, k + batch):
+            ot.integrate(poses[j], verts[j])            # one camera: the multi-camera frame is integrate()
+    nd.flush()
+    assert check_shard_against_full(nd.table, ot, 0, KW["numBuckets"], 5) > 100
+    c = nd.table.counters()
+    assert c["bin_overflow"] == 0 and c["epoch"] == batch * steps
+    sec, calls = nd.host_stats()
+    assert calls == steps and sec > 0
+    # the raycast round: pose all-gather, export, all-to-all of record slots, import, raycast -- on the device throughout
+    depth = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    lost = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for pose in (poses[2], poses[9], poses[2]):           # (back-to-back rounds: the pose travels by value)
+        nd.raycast(pose, depth, 2048, lost=lost)
+    nd.flush()
+    torch.cuda.synchronize()
+    want = ot.raycast(poses[2])
+    assert np.array_equal(depth.cpu().numpy().view(np.uint32), want.view(np.uint32)) and (want > 0).mean() > 0.3
+    assert int(lost.item()) == 0
+    nd.raycast(poses[9], depth, 16, lost=lost)            # far too few record slots: reported, not fatal
+    torch.cuda.synchronize()
+    assert int(lost.item()) > 0
+    nd.close()
+    ot.close()
+
+
+def test_native_exchange_equals_the_python_pipeline(oracle, vh, torch_cuda):
+    """Same frames through dist.ShardedPipeline (Python host, torch collectives) and through vh_dist_*: the same table."""
+    import socket
+
+    import torch.distributed as dist
+    torch = torch_cuda
+    batch, steps = 2, 4
+    poses, verts = _frames(batch * steps)
+    kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+    d16 = [np.round(v[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for v in verts]
+    dd = [torch.from_numpy(d).cuda() for d in d16]
+    dv = [torch.from_numpy(oracle.preprocess(d, kinv)[0]).cuda() for d in d16]
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        uid = vdist.unique_id(0, vdist.torch_broadcast_bytes())
+        nd = vdist.NativeDist(vh.default_params(**KW), W, H, 1, 0, 1, batch, uid, sensor_k_inv=kinv, key_capacity=W * H // 4)
+        plan = vdist.ShardPlan(KW["numBuckets"], 1)
+        ts, fs = torch.cuda.Stream(), torch.cuda.Stream()
+        sh = vdist.HipShard(vh.default_params(**KW), W, H, 1, plan, 0, W * H // 4, batch=batch, stream=ts, sets=2, sensor_k_inv=kinv)
+        pipe = vdist.ShardedPipeline(sh, vdist.TorchDistTransport(), ts, fs)
+        torch.cuda.synchronize()
+        for s in range(steps):
+            k = s * batch
+            nd.step(poses[k:k + batch], dd[k:k + batch])
+            pipe.feed(poses[k:k + batch], dv[k:k + batch], dd[k:k + batch])
+        nd.flush()
+        pipe.flush()
+        a, b = nd.table.hash_table(), sh.table.hash_table()
+        assert np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["ptr"] != -1, b["ptr"] != -1) and (a["ptr"] != -1).sum() > 100
+        for i in np.nonzero(a["ptr"] != -1)[0][::5]:
+            assert np.array_equal(nd.table.block_voxels(a["ptr"][i]).view(np.uint32), sh.table.block_voxels(b["ptr"][i]).view(np.uint32))
+        nd.close()
+        sh.table.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cpp_sharded_program(oracle, vh, torch_cuda, tmp_path):
+    """tests/cpp/sharded_demo.cpp: a C++ host (no Python, no torch in that process) creates the communicator, feeds
+    batches of sensor frames through SDF_Hashtable's multi-GPU constructor and prints what it built."""
+    lib = os.path.join(ROOT, "voxelhashing_demo_amd", "lib")
+    exe = tmp_path / "sharded_demo"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "sharded_demo.cpp"), "-o", str(exe),
+                    "-L", lib, "-lsdf_hashtable", "-lvoxelhash_hip", f"-Wl,-rpath,{lib}"], check=True)
+    batch, steps = 4, 3
+    poses, verts = _frames(batch * steps)
+    kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+    d16 = [np.round(v[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for v in verts]
+    np.asarray(poses, np.float32).tofile(tmp_path / "poses.bin")
+    np.stack(d16).tofile(tmp_path / "depth.bin")
+    kinv.tofile(tmp_path / "kinv.bin")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([str(exe), str(tmp_path / "poses.bin"), str(tmp_path / "depth.bin"), str(tmp_path / "kinv.bin"),
+                          str(W), str(H), str(batch), str(steps), str(KW["numBuckets"]), str(KW["numVoxelBlocks"]),
+                          str(tmp_path / "table.bin"), str(tmp_path / "depth_out.bin")],
+                         check=True, capture_output=True, text=True, env=env).stdout
+    got = dict((k, int(v)) for k, v in re.findall(r"(\w+)=(\d+)", out))
+    ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+    for p, d in zip(poses, d16):
+        ot.integrate(p, oracle.preprocess(d, kinv)[0])
+    otab = ot.hash_table()
+    assert got["allocated"] == int((otab["ptr"] != -1).sum()) > 100 and got["bin_overflow"] == 0
+    tab = np.fromfile(tmp_path / "table.bin", dtype=vh.ENTRY_DTYPE)
+    assert np.array_equal(tab["pos"], otab["pos"])
+    depth = np.fromfile(tmp_path / "depth_out.bin", dtype=np.float32).reshape(H, W)
+    assert np.array_equal(depth.view(np.uint32), ot.raycast(poses[5]).view(np.uint32))
+    ot.close()

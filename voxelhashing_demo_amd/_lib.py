@@ -164,6 +164,26 @@ SIGNATURES = {
     "vh_default_context": (_vp, []),
 }
 
+
+
+class DistConfig(C.Structure):
+    """vh_dist_config of include/voxelhash_dist.h."""
+    _fields_ = [("table", Config), ("rank", C.c_int32), ("world", C.c_int32), ("batch", C.c_int32),
+                ("key_capacity", C.c_int32), ("packet_format", C.c_int32), ("k_inv", C.c_float * 9)]
+
+
+# every symbol include/voxelhash_dist.h declares (the multi-GPU host on RCCL)
+DIST_SIGNATURES = {
+    "vh_dist_unique_id": (C.c_int, [C.c_char_p]),
+    "vh_dist_create": (C.c_int, [C.POINTER(DistConfig), C.c_char_p, _vp, C.POINTER(_vp)]),
+    "vh_dist_destroy": (C.c_int, [_vp]),
+    "vh_dist_shard": (_vp, [_vp]),
+    "vh_dist_step_batch": (C.c_int, [_vp, _fp, C.POINTER(_vp)]),
+    "vh_dist_flush": (C.c_int, [_vp]),
+    "vh_dist_raycast": (C.c_int, [_vp, _fp, _f, _f, C.c_int32, _vp, _vp]),
+    "vh_dist_host_stats": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+}
+
 _lib = None
 
 
@@ -188,7 +208,9 @@ def load():
         except ImportError:
             pass
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(DIST_SIGNATURES.items()):
+            if name in DIST_SIGNATURES and not hasattr(L, name):
+                continue                   # (a tuning build of an older commit, tools/ab_commits.sh)
             fn = getattr(L, name)          # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args

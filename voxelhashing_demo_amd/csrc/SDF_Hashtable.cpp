@@ -14,7 +14,7 @@ static void check(int rc, const char *where)
     std::exit(EXIT_FAILURE);
 }
 
-SDF_Hashtable::SDF_Hashtable() : ctx_(nullptr)
+SDF_Hashtable::SDF_Hashtable() : ctx_(nullptr), dist_(nullptr)
 {
     vh_default_params(&h_hashtableParams);             // SDF_Hashtable.cpp:62-73
     vh_config cfg;
@@ -26,7 +26,7 @@ SDF_Hashtable::SDF_Hashtable() : ctx_(nullptr)
     check(vh_create(&cfg, &ctx_), "deviceAllocate");   // :75-79
 }
 
-SDF_Hashtable::SDF_Hashtable(const HashTableParams &params, int width, int height, int semantics) : ctx_(nullptr)
+SDF_Hashtable::SDF_Hashtable(const HashTableParams &params, int width, int height, int semantics) : ctx_(nullptr), dist_(nullptr)
 {
     h_hashtableParams = params;
     vh_config cfg;
@@ -38,7 +38,41 @@ SDF_Hashtable::SDF_Hashtable(const HashTableParams &params, int width, int heigh
     check(vh_create(&cfg, &ctx_), "deviceAllocate");
 }
 
-SDF_Hashtable::~SDF_Hashtable() { vh_destroy(ctx_); }   // :83-89
+// One rank of a table sharded over `world` GPUs (include/voxelhash_dist.h)
+SDF_Hashtable::SDF_Hashtable(const HashTableParams &params, int width, int height, int semantics, int rank, int world, int batch,
+                             const char uniqueId[VH_DIST_ID_BYTES], const float kInv[9], int device)
+    : ctx_(nullptr), dist_(nullptr)
+{
+    h_hashtableParams = params;
+    vh_dist_config cfg;
+    cfg.table.params = params;
+    cfg.table.width = width;
+    cfg.table.height = height;
+    cfg.table.semantics = semantics;
+    cfg.table.device = device;
+    cfg.rank = rank;
+    cfg.world = world;
+    cfg.batch = batch;
+    cfg.key_capacity = 0;
+    cfg.packet_format = VH_PACKET_U16;
+    for (int i = 0; i < 9; ++i) cfg.k_inv[i] = kInv[i];
+    check(vh_dist_create(&cfg, uniqueId, nullptr, &dist_), "vh_dist_create");
+    ctx_ = vh_dist_shard(dist_);
+}
+
+void SDF_Hashtable::uniqueId(char id[VH_DIST_ID_BYTES]) { check(vh_dist_unique_id(id), "vh_dist_unique_id"); }
+
+void SDF_Hashtable::integrateExchange(const float *poses, const uint16_t *const *d_depth)
+{
+    check(dist_ ? vh_dist_step_batch(dist_, poses, reinterpret_cast<const void *const *>(d_depth)) : VH_ERR_INVALID_ARGUMENT,
+          "integrateExchange");
+}
+
+SDF_Hashtable::~SDF_Hashtable()                          // :83-89
+{
+    if (dist_) vh_dist_destroy(dist_);                   // (owns the shard context)
+    else vh_destroy(ctx_);
+}
 
 void SDF_Hashtable::integrate(const float4x4 &viewMat, const vh_float4 *verts, const vh_float4 *normals)
 {
@@ -54,7 +88,8 @@ void SDF_Hashtable::integrate(const float4x4 &viewMat, const uint16_t *d_depth, 
 
 void SDF_Hashtable::raycast(const float4x4 &pose, float *d_depth_out, float zNear, float zFar)
 {
-    check(vh_raycast(ctx_, pose.entries, zNear, zFar, d_depth_out), "raycast");
+    if (dist_) check(vh_dist_raycast(dist_, pose.entries, zNear, zFar, 4096, d_depth_out, nullptr), "raycast");   // through all shards
+    else check(vh_raycast(ctx_, pose.entries, zNear, zFar, d_depth_out), "raycast");
 }
 
 void SDF_Hashtable::raycast(const float4x4 &pose, float *d_depth_out, vh_float4 *d_normal_out, float zNear, float zFar)
@@ -89,7 +124,7 @@ int SDF_Hashtable::occupiedBlockCount()
 void SDF_Hashtable::setStream(void *s) { check(vh_set_stream(ctx_, s), "set_stream"); }
 void SDF_Hashtable::setOption(const char *name, int value) { check(vh_set_option(ctx_, name, value), "set_option"); }
 void SDF_Hashtable::setAllocBand(float bandMetres) { check(vh_set_alloc_band(ctx_, bandMetres), "set_alloc_band"); }
-void SDF_Hashtable::flush() { check(vh_flush(ctx_), "flush"); }
+void SDF_Hashtable::flush() { check(dist_ ? vh_dist_flush(dist_) : vh_flush(ctx_), "flush"); }
 void SDF_Hashtable::integrateBatch(int count, const float *poses, const vh_float4 *const *d_verts,
                                    const vh_float4 *const *d_normals)
 {

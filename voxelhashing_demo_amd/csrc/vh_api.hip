@@ -512,3 +512,4 @@ static int ensure_candidates(vh_context *c, size_t need)
 #include "vh_api_model.hip"
 #include "vh_api_dropin.hip"
 #include "vh_api_icp.hip"
+#include "vh_api_dist.hip"

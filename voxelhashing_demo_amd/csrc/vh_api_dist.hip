@@ -1,0 +1,341 @@
+// vh_api_dist.hip -- C-ABI, the multi-GPU host (include/voxelhash_dist.h): bucket-range shards, the per-frame exchange
+// on RCCL, pipelined over three HIP streams.  Included by vh_api.hip (same translation unit: shares fail(), VH_HIP,
+// DeviceGuard and the context).
+#include <dlfcn.h>
+
+#include <chrono>
+
+#include <rccl/rccl.h>          // types and prototypes only: the library is bound at run time (rccl_load)
+
+#include "../../include/voxelhash_dist.h"
+
+// ---------------------------------------------------------------------------
+// RCCL, bound at run time
+// ---------------------------------------------------------------------------
+// A process that already holds a copy of RCCL (torch's bundled librccl.so) must keep using THAT copy -- two collective
+// libraries in one process each build their own view of the devices -- so the symbols are looked up in the already
+// loaded image first (RTLD_NOLOAD), then in librccl.so.1 by name, then in the ROCm install.
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+    decltype(&ncclCommInitRank) commInitRank = nullptr;
+    decltype(&ncclCommDestroy) commDestroy = nullptr;
+    decltype(&ncclAllToAll) allToAll = nullptr;
+    decltype(&ncclAllGather) allGather = nullptr;
+    decltype(&ncclGetErrorString) getErrorString = nullptr;
+    bool ok = false;
+};
+Rccl g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.ok) return VH_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = nullptr;
+    for (const char *n : names)
+        if ((lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) != nullptr) break;
+    for (size_t i = 0; !lib && i < sizeof names / sizeof names[0]; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(VH_ERR_HIP, "librccl.so.1 could not be loaded (the multi-GPU host needs RCCL)");
+    g_rccl.lib = lib;
+#define VH_RCCL_SYM(field, name)                                                     \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, name));       \
+    if (!g_rccl.field) return fail(VH_ERR_HIP, "RCCL symbol missing: " name)
+    VH_RCCL_SYM(getUniqueId, "ncclGetUniqueId");
+    VH_RCCL_SYM(commInitRank, "ncclCommInitRank");
+    VH_RCCL_SYM(commDestroy, "ncclCommDestroy");
+    VH_RCCL_SYM(allToAll, "ncclAllToAll");
+    VH_RCCL_SYM(allGather, "ncclAllGather");
+    VH_RCCL_SYM(getErrorString, "ncclGetErrorString");
+#undef VH_RCCL_SYM
+    g_rccl.ok = true;
+    return VH_OK;
+}
+
+int rccl_fail(const char *what, ncclResult_t r)
+{
+    g_last_error = what;
+    g_last_error += ": ";
+    g_last_error += g_rccl.getErrorString ? g_rccl.getErrorString(r) : "RCCL error";
+    return VH_ERR_HIP;
+}
+#define VH_RCCL(call)                                         \
+    do {                                                      \
+        const ncclResult_t r_ = (call);                       \
+        if (r_ != ncclSuccess) return rccl_fail(#call, r_);   \
+    } while (0)
+}  // namespace
+
+// the view pose of a raycast round into device memory without a staging buffer: 16 floats in the kernel arguments
+struct Pose16 { float m[16]; };
+__global__ void dist_store_pose_kernel(const Pose16 p, float *__restrict__ out)
+{
+    if (threadIdx.x < 16) out[threadIdx.x] = p.m[threadIdx.x];
+}
+// records this view's sources selected beyond the slot capacity (the count travels in the first record's spare word)
+__global__ void dist_lost_kernel(const uint8_t *__restrict__ records, int32_t numSources, int32_t capacity, int32_t *lost)
+{
+    if (threadIdx.x == 0) {
+        int32_t n = 0;
+        for (int s = 0; s < numSources; ++s) {
+            const int32_t c = *reinterpret_cast<const int32_t *>(records + (size_t)s * capacity * sizeof(vh_view_record) + 12);
+            n += c > capacity ? c - capacity : 0;
+        }
+        *lost = n;
+    }
+}
+
+struct vh_dist {
+    vh_dist_config cfg;
+    vh_context *shard = nullptr;
+    vh_context *view = nullptr;            // raycast over the shards: the private view table (first vh_dist_raycast)
+    ncclComm_t comm = nullptr;
+    bool ownComm = false;
+    int device = 0;
+    int capacity = 0;                      // records per key bin
+    size_t packetUnits = 0;                // 4-byte units of one camera packet
+    hipStream_t sGen = nullptr, sComm = nullptr, sTable = nullptr;
+    hipEvent_t generated[2] = {nullptr, nullptr}, ready[2] = {nullptr, nullptr}, applied[2] = {nullptr, nullptr};
+    struct Set {
+        int32_t *binsSend = nullptr, *binsRecv = nullptr;      // [world][batch][capacity][4]
+        float *packet = nullptr, *packets = nullptr;          // [batch][P], [world][batch][P]
+    } set[2];
+    uint64_t count = 0;                    // exchanges fed
+    int pending = -1;                      // buffer set whose exchange is in flight / landed but not applied
+    // raycast round
+    float *poseMine = nullptr, *poseAll = nullptr;
+    vh_view_record *viewSend = nullptr, *viewRecv = nullptr;
+    int32_t *viewCounts = nullptr;
+    int32_t viewCapacity = 0;
+    double hostSeconds = 0.0;
+    uint64_t hostCalls = 0;
+};
+
+static void dist_free(vh_dist *d)
+{
+    if (!d) return;
+    DeviceGuard guard(d->device);
+    (void)hipDeviceSynchronize();
+    if (d->view) vh_destroy(d->view);
+    if (d->shard) vh_destroy(d->shard);
+    for (auto &s : d->set) {
+        if (s.binsSend) (void)hipFree(s.binsSend);
+        if (s.binsRecv) (void)hipFree(s.binsRecv);
+        if (s.packet) (void)hipFree(s.packet);
+        if (s.packets) (void)hipFree(s.packets);
+    }
+    for (void *p : {(void *)d->poseMine, (void *)d->poseAll, (void *)d->viewSend, (void *)d->viewRecv, (void *)d->viewCounts})
+        if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i)
+        for (hipEvent_t e : {d->generated[i], d->ready[i], d->applied[i]})
+            if (e) (void)hipEventDestroy(e);
+    if (d->comm && d->ownComm && g_rccl.commDestroy) (void)g_rccl.commDestroy(d->comm);
+    for (hipStream_t s : {d->sGen, d->sComm, d->sTable})
+        if (s) (void)hipStreamDestroy(s);
+    delete d;
+}
+
+extern "C" int vh_dist_unique_id(char id[VH_DIST_ID_BYTES])
+{
+    if (!id) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    const int rc = rccl_load();
+    if (rc != VH_OK) return rc;
+    static_assert(sizeof(ncclUniqueId) == VH_DIST_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    VH_RCCL(g_rccl.getUniqueId(&u));
+    std::memcpy(id, &u, sizeof u);
+    return VH_OK;
+}
+
+extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_ID_BYTES], void *nccl_comm, vh_dist **out)
+{
+    if (!cfg || !out || (!id && !nccl_comm)) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (cfg->world < 1 || cfg->world > VH_MAX_CAMERAS || cfg->rank < 0 || cfg->rank >= cfg->world || cfg->batch < 1)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad rank / world / batch");
+    if (cfg->packet_format != VH_PACKET_U16 && cfg->packet_format != VH_PACKET_F32)
+        return fail(VH_ERR_INVALID_ARGUMENT, "bad packet format");
+    const size_t npix = (size_t)cfg->table.width * cfg->table.height;
+    if (cfg->packet_format == VH_PACKET_U16 && npix % 2) return fail(VH_ERR_INVALID_ARGUMENT, "sensor-depth packets need an even number of pixels");
+    int rc = rccl_load();
+    if (rc != VH_OK) return rc;
+    // bucket range of this rank: owner(h) = h / ceil(numBuckets / world)  (dist.py: ShardPlan)
+    const uint32_t nb = cfg->table.params.numBuckets, R = (uint32_t)cfg->world;
+    if (nb < R) return fail(VH_ERR_INVALID_ARGUMENT, "need at least one bucket per rank");
+    const uint32_t per = (nb + R - 1) / R;
+    const uint32_t lo = (uint32_t)cfg->rank * per, hi = std::min(nb, lo + per);
+    if (lo >= hi) return fail(VH_ERR_INVALID_ARGUMENT, "this rank owns no bucket");
+
+    vh_dist *d = new vh_dist();
+    d->cfg = *cfg;
+    rc = vh_create_shard(&cfg->table, lo, hi, &d->shard);
+    if (rc != VH_OK) { dist_free(d); return rc; }
+    d->device = d->shard->device;
+    DeviceGuard guard(d->device);
+    if (cfg->packet_format == VH_PACKET_U16) d->shard->packetFormat = VH_PACKET_U16;
+    d->capacity = cfg->key_capacity > 0 ? cfg->key_capacity : (int)std::max<size_t>(2048, (npix + 15) / 16);
+    d->packetUnits = cfg->packet_format == VH_PACKET_U16 ? (size_t)kPacketHeaderU16 + npix / 2 : (size_t)kPacketHeader + npix;
+    const size_t B = (size_t)cfg->batch;
+    const size_t binBytes = (size_t)R * B * (size_t)d->capacity * 4 * sizeof(int32_t);
+    const size_t pkBytes = B * d->packetUnits * sizeof(float);
+#define VH_DIST_TRY(call)                                                                            \
+    do {                                                                                             \
+        const hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                      \
+            dist_free(d);                                                                            \
+            return fail(e_ == hipErrorOutOfMemory ? VH_ERR_OUT_OF_MEMORY : VH_ERR_HIP, #call, e_);   \
+        }                                                                                            \
+    } while (0)
+    for (hipStream_t *s : {&d->sGen, &d->sComm, &d->sTable}) VH_DIST_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        for (hipEvent_t *e : {&d->generated[i], &d->ready[i], &d->applied[i]}) VH_DIST_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        VH_DIST_TRY(hipMalloc((void **)&d->set[i].binsSend, binBytes));
+        VH_DIST_TRY(hipMalloc((void **)&d->set[i].binsRecv, binBytes));
+        VH_DIST_TRY(hipMalloc((void **)&d->set[i].packet, pkBytes));
+        VH_DIST_TRY(hipMalloc((void **)&d->set[i].packets, pkBytes * R));
+        VH_DIST_TRY(hipMemset(d->set[i].binsSend, 0, binBytes));
+        VH_DIST_TRY(hipMemset(d->set[i].binsRecv, 0, binBytes));
+    }
+    VH_DIST_TRY(hipDeviceSynchronize());
+#undef VH_DIST_TRY
+    if (nccl_comm) {
+        d->comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+    } else {
+        ncclUniqueId u;
+        std::memcpy(&u, id, sizeof u);
+        const ncclResult_t r = g_rccl.commInitRank(&d->comm, cfg->world, u, cfg->rank);
+        if (r != ncclSuccess) { dist_free(d); return rccl_fail("ncclCommInitRank", r); }
+        d->ownComm = true;
+    }
+    d->shard->stream = d->sTable;
+    *out = d;
+    return VH_OK;
+}
+
+extern "C" int vh_dist_destroy(vh_dist *d)
+{
+    dist_free(d);
+    return VH_OK;
+}
+
+extern "C" vh_context *vh_dist_shard(vh_dist *d) { return d ? d->shard : nullptr; }
+
+static int dist_apply(vh_dist *d, int s)
+{
+    VH_HIP(hipStreamWaitEvent(d->sTable, d->ready[s], 0));
+    d->shard->stream = d->sTable;
+    const int rc = vh_apply_frames_batch(d->shard, d->cfg.batch, d->set[s].binsRecv, d->cfg.world, d->capacity, 0, 0, d->cfg.world,
+                                         d->set[s].packets, 0, 0);
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipEventRecord(d->applied[s], d->sTable));
+    return VH_OK;
+}
+
+extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *const *d_frames)
+{
+    if (!d || !poses || !d_frames) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    DeviceGuard guard(d->device);
+    const int s = (int)(d->count & 1u);
+    const int B = d->cfg.batch, R = d->cfg.world;
+    vh_dist::Set &set = d->set[s];
+    int rc;
+    // generate: keys binned by owner + this camera's packets.  The set's send buffers were last read by the collectives
+    // of exchange count-2.
+    if (d->count >= 2) VH_HIP(hipStreamWaitEvent(d->sGen, d->ready[s], 0));
+    d->shard->stream = d->sGen;
+    if (d->cfg.packet_format == VH_PACKET_U16)
+        rc = vh_generate_keys_depth_batch(d->shard, B, poses, reinterpret_cast<const uint16_t *const *>(d_frames), d->cfg.k_inv,
+                                          (uint32_t)d->cfg.rank, R, set.binsSend, d->capacity, 0, 0, set.packet, 0);
+    else
+        rc = vh_generate_keys_batch(d->shard, B, poses, reinterpret_cast<const vh_float4 *const *>(d_frames), (uint32_t)d->cfg.rank, R,
+                                    set.binsSend, d->capacity, 0, 0, set.packet, 0);
+    d->shard->stream = d->sTable;
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipEventRecord(d->generated[s], d->sGen));
+    // exchange: the receive buffers of this set were last consumed by the application of exchange count-2
+    VH_HIP(hipStreamWaitEvent(d->sComm, d->generated[s], 0));
+    if (d->count >= 2) VH_HIP(hipStreamWaitEvent(d->sComm, d->applied[s], 0));
+    VH_RCCL(g_rccl.allToAll(set.binsSend, set.binsRecv, (size_t)B * d->capacity * 4, ncclInt32, d->comm, d->sComm));
+    VH_RCCL(g_rccl.allGather(set.packet, set.packets, (size_t)B * d->packetUnits, ncclFloat32, d->comm, d->sComm));
+    VH_HIP(hipEventRecord(d->ready[s], d->sComm));
+    // apply the previous exchange while this one travels
+    if (d->pending >= 0 && (rc = dist_apply(d, d->pending)) != VH_OK) return rc;
+    d->pending = s;
+    d->count += 1;
+    d->hostSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    d->hostCalls += 1;
+    return VH_OK;
+}
+
+extern "C" int vh_dist_flush(vh_dist *d)
+{
+    if (!d) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(d->device);
+    if (d->pending >= 0) {
+        const int rc = dist_apply(d, d->pending);
+        if (rc != VH_OK) return rc;
+        d->pending = -1;
+    }
+    VH_HIP(hipStreamSynchronize(d->sTable));
+    VH_HIP(hipStreamSynchronize(d->sComm));
+    VH_HIP(hipStreamSynchronize(d->sGen));
+    return VH_OK;
+}
+
+extern "C" int vh_dist_raycast(vh_dist *d, const float pose[16], float t_min, float t_max, int32_t capacity, float *d_depth_out,
+                               int32_t *d_lost)
+{
+    if (!d || !pose || !d_depth_out || capacity < 1) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(d->device);
+    int rc = vh_dist_flush(d);                      // the model as of every fed exchange
+    if (rc != VH_OK) return rc;
+    const int R = d->cfg.world;
+    if (R > 16) return fail(VH_ERR_INVALID_ARGUMENT, "the fixed-slot raycast round serves at most 16 views");
+    if (!d->view) {
+        vh_config vc = d->cfg.table;
+        vc.params.numVoxelBlocks = 1;               // the voxels of a view table stay in the received records
+        vc.device = d->device;
+        if ((rc = vh_create(&vc, &d->view)) != VH_OK) return rc;
+        d->view->stream = d->sTable;
+        d->view->rc_fx = d->shard->rc_fx; d->view->rc_fy = d->shard->rc_fy; d->view->rc_cx = d->shard->rc_cx; d->view->rc_cy = d->shard->rc_cy;
+        d->view->raycastMode = d->shard->raycastMode;
+        if (d->shard->fp.flags & kFlagOverflow) { d->view->fp.flags |= kFlagOverflow; d->view->fp.listSize = d->shard->fp.listSize; }
+        VH_HIP(hipMalloc((void **)&d->poseMine, 16 * sizeof(float)));
+        VH_HIP(hipMalloc((void **)&d->poseAll, (size_t)R * 16 * sizeof(float)));
+        VH_HIP(hipMalloc((void **)&d->viewCounts, (size_t)R * sizeof(int32_t)));
+    }
+    if (d->viewCapacity < capacity) {
+        VH_HIP(hipStreamSynchronize(d->sTable));
+        if (d->viewSend) (void)hipFree(d->viewSend);
+        if (d->viewRecv) (void)hipFree(d->viewRecv);
+        d->viewSend = d->viewRecv = nullptr;
+        d->viewCapacity = 0;
+        const size_t bytes = (size_t)R * capacity * sizeof(vh_view_record);
+        VH_HIP(hipMalloc((void **)&d->viewSend, bytes));
+        VH_HIP(hipMalloc((void **)&d->viewRecv, bytes));
+        VH_HIP(hipMemsetAsync(d->viewSend, 0, bytes, d->sTable));
+        VH_HIP(hipMemsetAsync(d->viewRecv, 0, bytes, d->sTable));
+        d->viewCapacity = capacity;
+    }
+    Pose16 p;
+    std::memcpy(p.m, pose, sizeof p.m);
+    dist_store_pose_kernel<<<1, 64, 0, d->sTable>>>(p, d->poseMine);
+    VH_RCCL(g_rccl.allGather(d->poseMine, d->poseAll, 16, ncclFloat32, d->comm, d->sTable));
+    d->shard->stream = d->sTable;
+    if ((rc = vh_export_views_fixed(d->shard, d->poseAll, R, t_min, t_max, d->viewSend, capacity, d->viewCounts)) != VH_OK) return rc;
+    VH_RCCL(g_rccl.allToAll(d->viewSend, d->viewRecv, (size_t)capacity * sizeof(vh_view_record), ncclUint8, d->comm, d->sTable));
+    if ((rc = vh_import_views(d->view, d->viewRecv, R, capacity, nullptr)) != VH_OK) return rc;
+    if ((rc = vh_raycast(d->view, pose, t_min, t_max, d_depth_out)) != VH_OK) return rc;
+    if (d_lost) dist_lost_kernel<<<1, 64, 0, d->sTable>>>(reinterpret_cast<const uint8_t *>(d->viewRecv), R, capacity, d_lost);
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+extern "C" int vh_dist_host_stats(vh_dist *d, double *seconds, uint64_t *calls)
+{
+    if (!d) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (seconds) *seconds = d->hostSeconds;
+    if (calls) *calls = d->hostCalls;
+    return VH_OK;
+}

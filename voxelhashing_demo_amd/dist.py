@@ -268,6 +268,102 @@ class HipShard:
 
 
 # ----------------------------------------------------------------------------
+# the native host (include/voxelhash_dist.h): the same pipeline inside the library, on RCCL directly
+# ----------------------------------------------------------------------------
+def unique_id(rank: int = 0, broadcast=None) -> bytes:
+    """The 128 bytes every rank hands to NativeDist: rank 0 draws them (ncclGetUniqueId), `broadcast(bytes or None)
+    -> bytes` carries them to the others (torch.distributed, MPI, a file ...).  One rank: no exchange."""
+    import ctypes as C
+
+    from . import _lib as L
+    buf = None
+    if rank == 0:
+        raw = C.create_string_buffer(128)
+        L.check(L.load().vh_dist_unique_id(raw), "vh_dist_unique_id")
+        buf = raw.raw
+    return broadcast(buf) if broadcast is not None else buf
+
+
+def torch_broadcast_bytes(group=None):
+    """A `broadcast` for unique_id over torch.distributed (any backend)."""
+    def bc(buf):
+        import torch
+        import torch.distributed as dist
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.zeros(128, dtype=torch.uint8) if buf is None else torch.frombuffer(bytearray(buf), dtype=torch.uint8)
+        t = t.to(dev)
+        dist.broadcast(t, 0, group=group)
+        return bytes(t.cpu().numpy().tobytes())
+    return bc
+
+
+class NativeDist:
+    """This rank of the sharded table, driven through ONE C call per exchange: generation, the RCCL all-to-all of the key
+    bins and all-gather of the packets, and the application run inside libvoxelhash_hip.so on three HIP streams
+    (include/voxelhash_dist.h).  What ShardedPipeline + HipShard + TorchDistTransport do from Python, minus a dozen
+    interpreter round trips and four torch collectives per exchange."""
+
+    def __init__(self, params, width, height, semantics, rank: int, world: int, batch: int, uid: bytes,
+                 sensor_k_inv=None, key_capacity: int = 0, device: int = -1):
+        import ctypes as C
+
+        from . import _lib as L
+        from .hashtable import SDFHashtable
+        self._L, self._lib = L, L.load()
+        cfg = L.DistConfig()
+        cfg.table = L.Config(params, width, height, semantics, device)
+        cfg.rank, cfg.world, cfg.batch, cfg.key_capacity = rank, world, batch, key_capacity
+        cfg.packet_format = 1 if sensor_k_inv is not None else 0
+        if sensor_k_inv is not None:
+            cfg.k_inv = (C.c_float * 9)(*np.asarray(sensor_k_inv, np.float32).reshape(9))
+        h = C.c_void_p()
+        L.check(self._lib.vh_dist_create(C.byref(cfg), uid, None, C.byref(h)), "vh_dist_create")
+        self._h, self.rank, self.world, self.batch = h, rank, world, batch
+        plan = ShardPlan(params.numBuckets, world)
+        self.table = SDFHashtable.borrowed(self._lib.vh_dist_shard(h), params, width, height, semantics, plan.bucket_range(rank))
+
+    def step(self, poses, frames):
+        """One exchange: `batch` poses and device tensors (uint16 sensor images, or float4 vertex maps) of THIS rank's camera."""
+        import ctypes as C
+        p16 = np.ascontiguousarray(np.asarray(poses, np.float32).reshape(self.batch, 16))
+        ptrs = (C.c_void_p * self.batch)(*[f.data_ptr() for f in frames])
+        self.step_raw(p16.ctypes.data_as(C.POINTER(C.c_float)), ptrs)
+
+    def step_raw(self, pose_ptr, frame_ptrs):
+        rc = self._lib.vh_dist_step_batch(self._h, pose_ptr, frame_ptrs)
+        if rc != 0:
+            self._L.check(rc, "vh_dist_step_batch")
+
+    def flush(self):
+        self._L.check(self._lib.vh_dist_flush(self._h), "vh_dist_flush")
+
+    def raycast(self, pose, out, capacity: int, t_min: float = 0.1, t_max: float = 5.0, lost=None):
+        import ctypes as C
+        p = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
+        self._L.check(self._lib.vh_dist_raycast(self._h, p.ctypes.data_as(C.POINTER(C.c_float)), t_min, t_max, capacity,
+                                                out.data_ptr(), None if lost is None else lost.data_ptr()), "vh_dist_raycast")
+        return out
+
+    def host_stats(self):
+        import ctypes as C
+        s, n = C.c_double(), C.c_uint64()
+        self._L.check(self._lib.vh_dist_host_stats(self._h, C.byref(s), C.byref(n)), "vh_dist_host_stats")
+        return s.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.table.close()
+            self._lib.vh_dist_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------
 # raycast over shards (SURVEY.md 8(e)): a ray samples blocks of every shard, so the rank that
 # renders a view gathers the blocks the view can touch and raycasts a private view table.
 #   1. all-gather of the view poses (every rank renders its own camera's view)
@@ -611,13 +707,37 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     transport = TorchDistTransport()
     batch = max(1, args.batch)
     pipelined = not getattr(args, "no_pipeline", False)
+    # The exchange runs inside the library on RCCL directly (include/voxelhash_dist.h: one C call per exchange, three
+    # HIP streams and two buffer sets in C++) unless --python-exchange asks for round 2's Python host (ShardedPipeline
+    # over torch.distributed collectives), kept for comparison.
+    native = not getattr(args, "python_exchange", False) and pipelined
     front = torch.cuda.Stream(device=dev)
+    import ctypes as C
     with torch.cuda.stream(stream):
-        shard = HipShard(params, Wd, Ht, SEM_PINHOLE, plan, rank, capacity, batch=batch, device=dev, stream=stream,
-                         sets=2 if pipelined else 1, sensor_k_inv=k_inv if sensor else None)
-        pipe = ShardedPipeline(shard, transport, stream, front) if pipelined else None
+        if native:
+            uid = unique_id(rank, torch_broadcast_bytes())
+            nd = NativeDist(params, Wd, Ht, SEM_PINHOLE, rank, world, batch, uid, sensor_k_inv=k_inv if sensor else None,
+                            key_capacity=capacity, device=local_rank)
+
+            class _Shard:          # what the rest of this function reads of a HipShard
+                table, packet_floats = nd.table, (36 + Wd * Ht // 2) if sensor else (32 + Wd * Ht)
+            shard, pipe = _Shard, None
+            # argument blocks of every start frame, prepared once (as the single-GPU Integrator does)
+            src = depth16 if sensor else verts
+            pose_blocks = [np.ascontiguousarray(np.stack([poses[(k + j) % nframes] for j in range(batch)]).reshape(batch, 16))
+                           for k in range(nframes)]
+            pose_ptrs = [a.ctypes.data_as(C.POINTER(C.c_float)) for a in pose_blocks]
+            frame_ptrs = [(C.c_void_p * batch)(*[src[(k + j) % nframes].data_ptr() for j in range(batch)]) for k in range(nframes)]
+        else:
+            shard = HipShard(params, Wd, Ht, SEM_PINHOLE, plan, rank, capacity, batch=batch, device=dev, stream=stream,
+                             sets=2 if pipelined else 1, sensor_k_inv=k_inv if sensor else None)
+            pipe = ShardedPipeline(shard, transport, stream, front) if pipelined else None
 
         def step(i):
+            if native:
+                k = (i * batch) % nframes
+                nd.step_raw(pose_ptrs[k], frame_ptrs[k])
+                return
             ks = [(i * batch + b) % nframes for b in range(batch)]
             depths = [depth16[k] for k in ks] if sensor else None
             if pipe:
@@ -626,7 +746,9 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
                 sharded_step(shard, transport, [poses[k] for k in ks], [verts[k] for k in ks], depths)
 
         def drain():
-            if pipe:
+            if native:
+                nd.flush()
+            elif pipe:
                 pipe.flush()
             shard.table.synchronize()
             torch.cuda.synchronize()
@@ -678,7 +800,31 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
         do_raycast = world == 1 or getattr(args, "sharded_raycast", False)
         rc_elapsed, rc_iters, lost_total, view_cap, kte, ktv, view = 0.0, 20, 0, 8192, None, None, None
         rc_fixed_elapsed, lost_fixed, fixed_cap = 0.0, 0, 2048
-        if do_raycast:
+        if do_raycast and native:
+            # the raycast round inside the library (vh_dist_raycast): pose all-gather, export, ncclAllToAll of fixed record
+            # slots, import, raycast on one stream, the pose by value -- no host synchronisation, no Python in between
+            ray_depth = torch.empty((Ht, Wd), dtype=torch.float32, device=dev)
+            lost_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            for i in range(2):
+                nd.raycast(poses[i], ray_depth, fixed_cap, lost=lost_dev)
+            nd.flush()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t2 = time.perf_counter()
+            for i in range(rc_iters):
+                nd.raycast(poses[(7 * i) % nframes], ray_depth, fixed_cap, lost=lost_dev)
+            nd.flush()
+            torch.cuda.synchronize()
+            dist.barrier()
+            rc_fixed_elapsed = time.perf_counter() - t2
+            lost_fixed = int(lost_dev.item())
+            shard.table.set_profiling(True)
+            for i in range(3):
+                nd.raycast(poses[(7 * i) % nframes], ray_depth, fixed_cap)
+            nd.flush()
+            kte = shard.table.kernel_times(reset=True)
+            shard.table.set_profiling(False)
+        elif do_raycast:
             view = HipViewTable(params, Wd, Ht, SEM_PINHOLE, world, view_cap, device=dev, stream=stream)
             for i in range(2):
                 sharded_raycast(shard, view, transport, poses[i], view_cap)
@@ -759,6 +905,8 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             vs_baseline=None, dtype="f32", data="synthetic",
             windows=len(windows), timed_s=round(sum(windows), 4),
             host_enqueue_ms_per_step=round(1e3 * statistics.median(host_enqueue) / args.steps, 5),
+            exchange_host="libvoxelhash_hip.so: vh_dist_step_batch on RCCL directly (include/voxelhash_dist.h)" if native
+            else "Python: dist.ShardedPipeline over torch.distributed collectives (--python-exchange / --no-pipeline)",
             config=dict(workload=f"{'C5' if wl_name == 'C5' else 'C4-style'}: {world} virtual {Wd}x{Ht} cameras (one per GPU) into one scene, "
                                  f"2^{int(math.log2(wl['buckets']))} buckets sharded by bucket range over {world} GPUs, "
                                  "RCCL all-to-all of block keys + all-gather of depth packets per step, PINHOLE; "
@@ -771,7 +919,17 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
                         key_bin_overflows=int(stats[2]), voxel_size=wl["voxel"],
                         voxel_blocks_per_rank=wl["blocks"]),
             roofline=roofline, cpu_baseline=None)
-        if do_raycast:
+        if do_raycast and native:
+            out["sharded_raycast"] = dict(
+                mpix_per_s=round(world * rc_iters * Wd * Ht / rc_fixed_elapsed / 1e6, 1), views_per_round=world,
+                ms_per_round=round(1e3 * rc_fixed_elapsed / rc_iters, 4), lost_records=lost_fixed,
+                record_capacity_per_shard_and_view=fixed_cap, payload_bytes_per_rank=world * fixed_cap * VIEW_RECORD_BYTES,
+                rank0_export_us=round(1e3 * kte["view_export_ms"] / 3, 2),
+                note="vh_dist_raycast: every rank renders its own camera's view of the whole table inside the library -- "
+                     "ncclAllGather of the poses, one walk of the shard for all views, ncclAllToAll of fixed slots of "
+                     "{key, 512 voxels} records, import into a view table, raycast; one stream, no host synchronisation; "
+                     "bit-equal to a raycast of the unsharded table")
+        elif do_raycast:
             out["sharded_raycast"] = dict(
                 mpix_per_s=round(world * rc_iters * Wd * Ht / rc_elapsed / 1e6, 1), views_per_round=world,
                 ms_per_round=round(1e3 * rc_elapsed / rc_iters, 4), lost_records=lost_total,
@@ -793,7 +951,10 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     # already have released)
     if view is not None:
         view.table.close()
-    shard.table.close()
+    if native:
+        nd.close()
+    else:
+        shard.table.close()
     torch.cuda.synchronize()
     dist.barrier()
     return out if rank == 0 else None

@@ -80,10 +80,23 @@ class SDFHashtable:
         if stream is not None:
             self.set_stream(stream)
 
+    @classmethod
+    def borrowed(cls, handle, params, width, height, semantics, bucket_range):
+        """A view of a context somebody else owns (a vh_dist's shard): every query and option works, close() leaves it."""
+        t = cls.__new__(cls)
+        t._lib = L.load()
+        t.params, t.width, t.height, t.semantics = params, width, height, semantics
+        t.bucket_range = tuple(bucket_range)
+        t._h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+        t._borrowed = True
+        t.stream_handle = 0
+        return t
+
     # ---- lifecycle ----
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.vh_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.vh_destroy(self._h)
             self._h = None
 
     def __del__(self):
