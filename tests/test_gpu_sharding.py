@@ -270,3 +270,87 @@ def test_two_processes_on_one_gpu(oracle, vh, torch_cuda, sensor):
     for r in results:
         assert r[1] == "ok", r[2]
     assert sum(r[2] for r in results) == results[0][3] > 100
+
+
+def test_one_launch_multi_camera_frames(oracle, vh, torch_cuda):
+    """vh_apply_frames_batch runs a batch of B multi-camera frames as B + 1 launches (frame_multi_pipelined_kernel: the
+    commit + TSDF update of frame b ride in the launch of frame b + 1; option "pipeline_shards", on by default) or as 2 B
+    (option off).  Same frames through both on two shards: the same tables, equal to the slices of ONE oracle table --
+    with batches of 1, 2 and 5, new blocks in every frame (the cameras move), a collection in between and single-camera
+    pipelined frames on the same contexts before and after (the two pipelines share their buffers and counter sets)."""
+    torch = torch_cuda
+    world = 2
+    plan = vdist.ShardPlan(KW["numBuckets"], world)
+    full = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+    runs = {}
+    for mode in (1, 0):
+        shards = [vdist.HipShard(vh.default_params(**KW), W, H, 1, plan, r, W * H // 4, batch=5) for r in range(world)]
+        for sh in shards:
+            sh.table.set_option("pipeline_shards", mode)
+        step = 0
+        for batch in (1, 2, 5, 1, 5):
+            for sh in shards:
+                sh.batch = batch
+            frames = [cameras(world, step + b) for b in range(batch)]
+            # (HipShard's buffers are sized for batch 5: smaller batches use the dense prefix)
+            for r, sh in enumerate(shards):
+                sh.table.set_pose(frames[0][r][0])
+            sub = [vdist.HipShard.__new__(vdist.HipShard) for _ in shards]
+            for s2, sh in zip(sub, shards):
+                s2.__dict__.update(sh.__dict__)
+                s2.batch = batch
+                s2.bins_send, s2.bins_recv = sh.bins_send[:, :batch].contiguous(), sh.bins_recv[:, :batch].contiguous()
+                s2.packet, s2.packets = sh.packet[:batch].contiguous(), sh.packets[:, :batch].contiguous()
+            vdist.loopback_step(sub, [[frames[b][r][0] for b in range(batch)] for r in range(world)],
+                                [[torch.from_numpy(frames[b][r][1]).cuda() for b in range(batch)] for r in range(world)])
+            if mode == 1:
+                for cams in frames:
+                    vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+            step += batch
+            if step == 3:
+                for sh in shards:
+                    sh.table.garbage_collect(0.05)
+                if mode == 1:
+                    full.garbage_collect(0.05)
+        for sh in shards:
+            sh.table.synchronize()
+        runs[mode] = shards
+    total = 0
+    for r in range(world):
+        lo, hi = plan.bucket_range(r)
+        total += check_shard_against_full(runs[1][r].table, full, lo, hi, 5)
+        check_shard_against_full(runs[0][r].table, full, lo, hi, 5)
+        assert runs[1][r].table.counters()["occupied"] == runs[0][r].table.counters()["occupied"]
+        assert entries_as_set_(runs[1][r].table.compact()) == entries_as_set_(runs[0][r].table.compact())
+    assert total == len(full.allocated()) > 100
+    for m in runs:
+        for sh in runs[m]:
+            sh.table.close()
+
+
+def entries_as_set_(entries):
+    return set(map(tuple, np.asarray(entries["pos"]).reshape(-1, 3).tolist()))
+
+
+def test_one_launch_multi_camera_frames_across_the_epoch_wrap(oracle, vh, torch_cuda):
+    """The claim words carry a 10-bit lock epoch; at the wrap they are cleared -- which the frame whose deferred half is
+    still pending must not see: 1 040 multi-camera frames (one shard, batches of 8) straddle the wrap at frame 1 023."""
+    torch = torch_cuda
+    kw = dict(numBuckets=1 << 10, numVoxelBlocks=4096)            # (a heap that never runs dry: 1 024 blocks did)
+    w, h = 64, 48
+    plan = vdist.ShardPlan(kw["numBuckets"], 1)
+    prims = synth.room_primitives()
+    poses = synth.camera_loop(40)
+    verts = [synth.render_room_verts(p, w, h, prims).numpy() for p in poses]
+    dv = [torch.from_numpy(v).cuda() for v in verts]
+    sh = vdist.HipShard(vh.default_params(**kw), w, h, 1, plan, 0, w * h // 2, batch=8)
+    full = oracle.OracleTable(oracle.default_params(**kw), w, h, 1)
+    for step in range(130):
+        ks = [(8 * step + b) % 40 for b in range(8)]
+        vdist.loopback_step([sh], [[poses[k] for k in ks]], [[dv[k] for k in ks]])
+        for k in ks:
+            full.integrate(poses[k], verts[k])
+    sh.table.synchronize()
+    assert sh.table.counters()["epoch"] == 1040 and sh.table.counters()["heap_exhausted"] == 0
+    assert check_shard_against_full(sh.table, full, 0, kw["numBuckets"], 5) > 20
+    sh.table.close()

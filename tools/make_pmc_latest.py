@@ -40,8 +40,9 @@ for wl in sys.argv[2:]:
             d["algorithmic_bytes_per_launch"] = line["roofline"]["bytes_per_launch"]
             # key without template arguments, as dist.bench_sharded looks it up
             for k in list(d):
-                if k.startswith("frame_multi_scan_claim_kernel") and k.endswith("_hbm_bytes_per_launch"):
-                    d["frame_multi_scan_claim_kernel_hbm_bytes_per_launch"] = d[k]
+                for base in ("frame_multi_scan_claim_kernel", "frame_multi_pipelined_kernel"):
+                    if k.startswith(base) and k.endswith("_hbm_bytes_per_launch"):
+                        d[base + "_hbm_bytes_per_launch"] = d[k]
         except Exception as e:
             d["algorithmic_bytes_per_launch_error"] = repr(e)
     out[wl] = d

@@ -580,23 +580,26 @@ __device__ __forceinline__ uint32_t macro_hash(int mx, int my, int mz)
 // `index`: position of the candidate in dp.candidates (its look-ahead target sits beside it)
 // consume = false (pipelined frames): the claim words stay as they are -- the claim phase and the
 // walk of the NEXT frame read them while this commit runs; nobody stakes a claim in this epoch any more.
+// epoch / claim: the lock epoch and claim array of the frame being committed (fp.epoch / dp.claim; a pipelined multi-camera
+// launch passes the previous frame's)
 __device__ __forceinline__ bool commit_candidate(const FrameParams &fp, const DevPtrs &dp, const int4 k,
-                                                 VoxelEntry &e, uint32_t index, bool consume = true)
+                                                 VoxelEntry &e, uint32_t index, bool consume, uint32_t epoch,
+                                                 unsigned long long *__restrict__ claim)
 {
     const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
     const uint32_t local = h - fp.bucketLo;
-    const unsigned long long w = dp.claim[local];
-    if (claim_epoch(w) != fp.epoch || claim_slot(w) != index || w == consumed_word(fp.epoch)) return false;   // lost the bucket this frame
-    if (consume) dp.claim[local] = consumed_word(fp.epoch);                      // locked until the next epoch
+    const unsigned long long w = claim[local];
+    if (claim_epoch(w) != epoch || claim_slot(w) != index || w == consumed_word(epoch)) return false;   // lost the bucket this frame
+    if (consume) claim[local] = consumed_word(epoch);                            // locked until the next epoch
     const uint32_t target = (fp.flags & kFlagOverflow) ? dp.candTarget[index] : ~0u;
     if (target != ~0u) {
         // home bucket full: the entry goes to the free slot found behind it and to the FRONT of the
         // bucket's chain -- if this contender also holds the bucket of that slot
         const uint32_t tb = target / fp.bucketSize;
-        const unsigned long long wt = dp.claim[tb];
-        if (claim_epoch(wt) != fp.epoch || claim_slot(wt) != index || wt == consumed_word(fp.epoch))
+        const unsigned long long wt = claim[tb];
+        if (claim_epoch(wt) != epoch || claim_slot(wt) != index || wt == consumed_word(epoch))
             return false;                                                        // the home bucket stays locked, as in the reference
-        dp.claim[tb] = consumed_word(fp.epoch);
+        claim[tb] = consumed_word(epoch);
         const int addr = atomicSub(dp.counters + kHeapCounter, 1);
         if (addr < 0) {
             atomicAdd(dp.counters + kHeapCounter, 1);
@@ -635,6 +638,12 @@ __device__ __forceinline__ bool commit_candidate(const FrameParams &fp, const De
         return true;
     }
     return false;
+}
+
+__device__ __forceinline__ bool commit_candidate(const FrameParams &fp, const DevPtrs &dp, const int4 k,
+                                                 VoxelEntry &e, uint32_t index, bool consume = true)
+{
+    return commit_candidate(fp, dp, k, e, index, consume, fp.epoch, dp.claim);
 }
 
 __global__ __launch_bounds__(256) void alloc_commit_kernel(const FrameParams fp, const DevPtrs dp)

@@ -103,6 +103,8 @@ struct vh_context {
     unsigned long long *claimBuf[2] = {nullptr, nullptr};
     int4 *candBuf[2] = {nullptr, nullptr};
     VoxelEntry *compactBuf[2] = {nullptr, nullptr};
+    uint32_t *maskBuf2 = nullptr;          // pipelined multi-camera frames: the camera masks of the second compact buffer
+    int pipelineShards = 1;                // option "pipeline_shards": vh_apply_frames_batch runs a batch of B multi-camera frames as B + 1 launches
     VoxelEntry *compactHome = nullptr;     // the compact buffer of creation: what PtrContainer names, where settle() leaves the dense list
     float *planeBuf[2] = {nullptr, nullptr};
     uint16_t *rawBuf[2] = {nullptr, nullptr};
@@ -267,6 +269,8 @@ static int free_buffers(vh_context *c)
     if (c->dp.macroBits) (void)hipFree(c->dp.macroBits);
     if (c->fusedPlane) (void)hipFree(c->fusedPlane);
     c->fusedPlane = nullptr;
+    if (c->maskBuf2) (void)hipFree(c->maskBuf2);
+    c->maskBuf2 = nullptr;
     if (c->viewSet) (void)hipFree(c->viewSet);
     c->viewSet = nullptr;
     if (c->viewLists) (void)hipFree(c->viewLists);

@@ -396,6 +396,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
         return VH_OK;
     }
     if (std::strcmp(name, "pipe_integrate_grid") == 0 && value > 0) { c->pipeIntegrateGrid = value; return VH_OK; }
+    if (std::strcmp(name, "pipeline_shards") == 0) { c->pipelineShards = value != 0; return VH_OK; }
     if (std::strcmp(name, "pipeline") == 0) {
         c->pipeline = value != 0;
         return VH_OK;                // (a pending frame was flushed at the top of this call)

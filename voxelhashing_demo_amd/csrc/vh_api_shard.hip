@@ -348,6 +348,74 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
     if (parts < 1) parts = 1;
     const uint32_t scanBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
     const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
+    // One launch per multi-camera frame (frame_multi_pipelined_kernel, vh_shard.hip): the commit + TSDF update of frame
+    // b ride in the launch of frame b+1, a last launch serves the batch's last frame: B + 1 launches instead of 2 B.
+    // Same conditions as the single-camera pipeline (no overflow list, bucketSize <= 8, not a view table).
+    if (c->pipelineShards && !(c->fp.flags & kFlagOverflow) && c->fp.bucketSize <= 8u && !c->viewBlocks) {
+        int rc = ensure_pipeline_buffers(c);
+        if (rc != VH_OK) return rc;
+        if (!c->maskBuf2) VH_HIP(hipMalloc((void **)&c->maskBuf2, sizeof(uint32_t) * c->numEntries));
+        uint32_t *maskOf[2] = {c->dp.compactMask, c->maskBuf2};
+        bool pending = false;
+        uint32_t epochOld = 0;
+        const float *packetsOld = nullptr;
+        int b = 0;
+        while (b < batch || pending) {
+            const bool hasOld = pending;
+            bool doNew = b < batch;
+            // at the epoch wrap vh_reset_mutexes clears the claim words, which the pending frame still needs: it is
+            // served by a launch of its own first
+            if (doNew && pending && c->fp.epoch >= kMaxClaimEpoch) doNew = false;
+            if (doNew && (rc = vh_reset_mutexes(c)) != VH_OK) return rc;
+            const int oldParity = c->pipeParity, newParity = oldParity ^ 1;
+            const int setOld = c->pipeSet, setNew = (setOld + 1) % 3;
+            MultiPipeArgs a;
+            std::memset(&a, 0, sizeof a);
+            a.claimBlocks = doNew ? (uint32_t)num_bins * parts : 0u;
+            a.walkBlocks = doNew ? scanBlocks : 0u;
+            a.commitBlocks = hasOld ? commitBlocks : 0u;
+            a.integrateBlocks = hasOld ? (uint32_t)c->pipeIntegrateGrid : 0u;
+            a.partsPerBin = parts; a.numBins = (uint32_t)num_bins; a.numEntries = (uint32_t)c->numEntries;
+            a.capacity = capacity; a.binStride = bin_stride; a.numCams = num_cams;
+            a.setNew = kPipeSetStride * setNew; a.setOld = kPipeSetStride * setOld; a.setClear = kPipeSetStride * ((setNew + 1) % 3);
+            a.hasNew = doNew; a.hasOld = hasOld;
+            a.claimSpan = claim_span(c, a.claimBlocks, a.walkBlocks);
+            a.claimRatio = claim_ratio(a.claimBlocks, a.claimSpan);
+            a.epochOld = epochOld;
+            const int bb = std::min(b, batch - 1);
+            a.binsNew = reinterpret_cast<const int4 *>(d_bins) + (size_t)frame_stride * bb;
+            a.packetsNew = d_packets + packet_frame_stride * bb;
+            a.packetsOld = packetsOld;
+            a.packetStride = packet_stride;
+            DevPtrs dpNew = pipe_view(c, newParity);
+            dpNew.compactMask = maskOf[newParity];
+            const DevPtrs dpOld = pipe_view(c, oldParity);
+            a.claimOld = dpOld.claim; a.candOld = dpOld.candidates; a.compactOld = dpOld.compact; a.maskOld = maskOf[oldParity];
+            a.candCapacityOld = dpOld.candCapacity;
+            const dim3 grid(a.commitBlocks + a.integrateBlocks + a.claimBlocks + a.walkBlocks);
+            rc = c->packetFormat == VH_PACKET_U16
+                     ? launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<true>, grid, dim3(256), c->fp, dpNew, a)
+                     : launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<false>, grid, dim3(256), c->fp, dpNew, a);
+            if (rc != VH_OK) return rc;
+            if (doNew) {
+                pending = true;
+                epochOld = c->fp.epoch;
+                packetsOld = a.packetsNew;
+                c->pipeSet = setNew;
+                c->pipeParity = newParity;
+                c->dp.claim = dpNew.claim; c->dp.candidates = dpNew.candidates; c->dp.compact = dpNew.compact;
+                ++b;
+            } else {
+                pending = false;
+            }
+            c->occupiedCounter = kCompactCount;
+            c->compactArmed = false;
+            c->foldA = -1;
+            if (c->profiling && hasOld) c->profiledFrames += 1;
+        }
+        VH_HIP(hipGetLastError());
+        return VH_OK;
+    }
     for (int b = 0; b < batch; ++b) {
         int rc = vh_reset_mutexes(c);
         if (rc != VH_OK) return rc;

@@ -13,7 +13,8 @@ namespace vh {
 // (binIndex, part, parts): this workgroup handles every parts-th 256-record slice of the bin.
 __device__ __forceinline__ void claim_bin_slice(const FrameParams &fp, const DevPtrs &dp,
                                                 const int4 *__restrict__ bins, int32_t capacity, int32_t binStride,
-                                                uint32_t binIndex, uint32_t part, uint32_t parts, int candCounter)
+                                                uint32_t binIndex, uint32_t part, uint32_t parts, int candCounter,
+                                                const Pending &pend = kNoPending)
 {
     const int4 *bin = bins + (size_t)binIndex * binStride;
     int n = bin[0].x;
@@ -25,7 +26,7 @@ __device__ __forceinline__ void claim_bin_slice(const FrameParams &fp, const Dev
         const int4 k = bin[1 + i];
         const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
         if (h < fp.bucketLo || h >= fp.bucketHi) continue;
-        probe_and_claim(fp, dp, k.x, k.y, k.z, h, (uint32_t)k.w, candCounter);
+        probe_and_claim(fp, dp, k.x, k.y, k.z, h, (uint32_t)k.w, candCounter, pend);
     }
 }
 
@@ -54,7 +55,7 @@ __device__ __forceinline__ uint32_t camera_mask(const FrameParams &fp, const int
 __device__ __forceinline__ void flatten_multi_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
                                                    uint32_t tileIndex, int32_t numCams,
                                                    const float *__restrict__ packets, size_t packetStride,
-                                                   int counter)
+                                                   int counter, const Pending &pend = kNoPending)
 {
     const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
     int32_t ptrs[kEntriesPerLane];
@@ -65,7 +66,15 @@ __device__ __forceinline__ void flatten_multi_tile(const FrameParams &fp, const 
     for (int j = 0; j < kEntriesPerLane; ++j) {
         seen[j] = 0;
         if (ptrs[j] == VH_FREE_BLOCK) continue;
-        const VoxelEntry ent = dp.table[tile + j * kFlattenThreads + threadIdx.x];
+        const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
+        const VoxelEntry ent = dp.table[e];
+        // (pipelined frames: the entry the concurrent commit phase is writing is skipped whatever is seen of it --
+        // that commit phase appends it itself, vh_walk.hip: walk_process_tile)
+        if (pend.claim && pend.live) {
+            const uint32_t b = e / fp.bucketSize;
+            const unsigned long long w = pend.claim[b];
+            if (claim_epoch(w) == pend.epoch && claim_f(w) == e - b * fp.bucketSize) continue;
+        }
         seen[j] = camera_mask(fp, ent.pos, numCams, packets, packetStride);
         myCount += seen[j] != 0u;
     }
@@ -210,6 +219,131 @@ __global__ __launch_bounds__(256) void frame_multi_commit_integrate_kernel(const
             dp.counters[kNewCount + (parity ^ 1)] = 0;
             dp.counters[kFusedCand + (parity ^ 1)] = 0;
             dp.counters[kCommitTicket] = 0;
+        }
+    }
+}
+
+// The multi-camera frame in ONE launch (vh_apply_frames_batch with the option "pipeline_shards", on by default): the
+// launch of frame i+1 carries the deferred half of frame i, exactly as frame_pipelined_kernel does for the single-camera
+// frame (vh_frame.hip, where the argument for its exactness is written out):
+//     launch i+1 = { commit(i) + TSDF update(i) || claim the bins of frame i+1 || walk the shard for frame i+1's cameras }
+// The two frames differ in their lock epoch, their bins and packets (both lie in the batch's receive buffers, which
+// stay valid until the batch has been applied) and in the three buffers that alternate (claim words, candidate list,
+// compact list with its camera masks); the poses travel inside the packets.  A batch of B frames is B + 1 launches.
+struct MultiPipeArgs {
+    uint32_t claimBlocks, walkBlocks, commitBlocks, integrateBlocks;     // roles by workgroup index, in this order: commit, integrate, claim/walk interleaved
+    uint32_t partsPerBin, numBins, numEntries;
+    int32_t capacity, binStride, numCams;
+    int32_t setNew, setOld, setClear;
+    uint32_t hasNew, hasOld;
+    uint32_t claimSpan, claimRatio;
+    uint32_t epochOld;
+    const int4 *binsNew;
+    const float *packetsNew, *packetsOld;
+    size_t packetStride;
+    unsigned long long *claimOld;
+    int4 *candOld;
+    VoxelEntry *compactOld;
+    uint32_t *maskOld;
+    uint32_t candCapacityOld;
+};
+
+template <bool kSensor>
+__global__ __launch_bounds__(256) void frame_multi_pipelined_kernel(const FrameParams fp, const DevPtrs dp, const MultiPipeArgs a)
+{
+    int32_t *counters = dp.counters;
+    const int demandedOld = a.hasOld ? counters[kPipeCand + a.setOld] : 0;
+    const int candOld = min(demandedOld, (int)a.candCapacityOld);
+    const bool live = a.hasOld && counters[kPipeHeapFree + a.setOld] >= counters[kPipeWinners + a.setOld];
+    const uint32_t b = blockIdx.x;
+    if (!a.hasOld && b == 0u && threadIdx.x == 0) counters[kPipeHeapFree + a.setNew] = counters[kHeapCounter] + 1;
+    if (b >= a.commitBlocks + a.integrateBlocks) {
+        // ---- frame i+1: claim its bins || walk the shard for its cameras ----
+        if (!a.hasNew) return;
+        const Pending pend{a.hasOld ? a.claimOld : nullptr, a.candOld, a.epochOld, live, kPipeWinners + a.setNew};
+        const uint32_t r = b - a.commitBlocks - a.integrateBlocks;
+        uint32_t before = a.claimBlocks, after = a.claimBlocks;
+        if (r < a.claimSpan) { before = __umulhi(r, a.claimRatio); after = __umulhi(r + 1u, a.claimRatio); }
+        if (after != before) {
+            __builtin_amdgcn_s_setprio(3);
+            claim_bin_slice(fp, dp, a.binsNew, a.capacity, a.binStride, before / a.partsPerBin, before % a.partsPerBin, a.partsPerBin,
+                            kPipeCand + a.setNew, pend);
+        } else {
+            flatten_multi_tile(fp, dp, a.numEntries, r - before, a.numCams, a.packetsNew, a.packetStride, kPipeScan + a.setNew, pend);
+        }
+        return;
+    }
+    if (!a.hasOld) return;
+    const int scanOld = counters[kPipeScan + a.setOld];
+    if (b >= a.commitBlocks) {
+        // ---- frame i: TSDF update of the blocks its walk (and commit(i-1)) listed, cameras in order ----
+        for (int k = (int)(b - a.commitBlocks); k < scanOld; k += (int)a.integrateBlocks)
+            integrate_block_multi<kSensor>(fp, dp, a.compactOld[k], a.maskOld[k], a.numCams, a.packetsOld, a.packetStride);
+        return;
+    }
+    // ---- frame i: commit ----
+    __shared__ VoxelEntry newEntry;
+    __shared__ uint32_t newMask;
+    __shared__ int inserted;
+    const int workers = max(1, min(candOld, (int)a.commitBlocks));
+    if ((int)b >= workers) return;
+    for (int i = (int)b; i < candOld; i += (int)a.commitBlocks) {
+        if (threadIdx.x == 0) {
+            inserted = 0;
+            newMask = 0u;
+            const int4 k = a.candOld[i];
+            if (live) {
+                VoxelEntry e;
+                inserted = commit_candidate(fp, dp, k, e, (uint32_t)i, false, a.epochOld, a.claimOld) ? 1 : 0;
+                if (inserted) {
+                    const uint32_t seen = camera_mask(fp, e.pos, a.numCams, a.packetsOld, a.packetStride);
+                    newEntry = e;
+                    newMask = seen;
+                    if (seen != 0u) {                   // what walk(i) would have listed had it seen the entry
+                        const int slot = scanOld + atomicAdd(counters + kPipeNew + a.setOld, 1);
+                        a.compactOld[slot] = e;
+                        a.maskOld[slot] = seen;
+                    }
+                    if (a.hasNew) {                     // ... and what walk(i+1) would have: that walk skipped it
+                        const uint32_t next = camera_mask(fp, e.pos, a.numCams, a.packetsNew, a.packetStride);
+                        if (next != 0u) {
+                            const int slot = atomicAdd(counters + kPipeScan + a.setNew, 1);
+                            dp.compact[slot] = e;
+                            dp.compactMask[slot] = next;
+                        }
+                    }
+                }
+            } else {
+                const uint32_t local = hash_block(k.x, k.y, k.z, fp.numBuckets) - fp.bucketLo;
+                const unsigned long long w = a.claimOld[local];
+                if (claim_epoch(w) == a.epochOld && claim_slot(w) == (uint32_t)i) atomicAdd(counters + kHeapExhausted, 1);
+            }
+        }
+        __syncthreads();
+        if (inserted && newMask != 0u)
+            integrate_block_multi<kSensor>(fp, dp, newEntry, newMask, a.numCams, a.packetsOld, a.packetStride);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const int ticket = atomicAdd(counters + kCommitTicket, 1);
+        if (ticket == workers - 1) {
+            counters[kCompactCount] = scanOld + atomicAdd(counters + kPipeNew + a.setOld, 0);
+            counters[kLastCandidates] = demandedOld;
+            counters[kPipeScan + a.setClear] = 0;
+            counters[kPipeScanB + a.setClear] = 0;
+            counters[kPipeNew + a.setClear] = 0;
+            counters[kPipeCand + a.setClear] = 0;
+            counters[kPipeWinners + a.setClear] = 0;
+            if (!a.hasNew) {
+                counters[kPipeScan + a.setNew] = 0;
+                counters[kPipeScanB + a.setNew] = 0;
+                counters[kPipeNew + a.setNew] = 0;
+                counters[kPipeCand + a.setNew] = 0;
+                counters[kPipeWinners + a.setNew] = 0;
+            }
+            counters[kPipeHeapFree + a.setNew] = atomicAdd(counters + kHeapCounter, 0) + 1;
+            counters[kCommitTicket] = 0;
         }
     }
 }

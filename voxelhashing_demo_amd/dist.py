@@ -874,10 +874,23 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     if rank == 0:
         frames = args.steps * world * batch
         launches = max(1, kt["launches"])
-        walk_us = 1e3 * kt["frame_scan_claim_ms"] / launches
-        # rank 0's dominant table launch: one pass over its shard of the VoxelEntry array for all
-        # cameras (20 B per owned entry) + the compact entries written
-        walk_bytes = 20 * shard.table.num_entries + 24 * c["occupied"]
+        occ = c["occupied"]
+        one_launch = kt.get("frame_pipelined_ms", 0) > 0
+        if one_launch:
+            # the ONE launch of a multi-camera frame (frame_multi_pipelined_kernel: commit + TSDF update of frame b with the
+            # claim + walk of frame b+1): one pass over rank 0's shard of the VoxelEntry array for all cameras (20 B per
+            # owned entry), the compact entries + camera masks written (24 B), per visible block its entry and 4 KiB read +
+            # 4 KiB written (cameras applied in registers)
+            kname = "frame_multi_pipelined_kernel (rank 0)"
+            walk_us = 1e3 * kt["frame_pipelined_ms"] / launches
+            walk_bytes = 20 * shard.table.num_entries + 24 * occ + occ * (20 + 4096 + 4096)
+            pmc_key = "frame_multi_pipelined_kernel"
+        else:
+            # two launches per multi-camera frame: the dominant one = claim the bins || walk the shard for all cameras
+            kname = "frame_multi_scan_claim_kernel (rank 0)"
+            walk_us = 1e3 * kt["frame_scan_claim_ms"] / launches
+            walk_bytes = 20 * shard.table.num_entries + 24 * occ
+            pmc_key = "frame_multi_scan_claim_kernel"
         achieved = walk_bytes / (walk_us * 1e-6) / 1e9 if walk_us > 0 else 0.0
         # HBM traffic: rocprofv3 --pmc passes are single-process runs, so the counter figure is the one-rank
         # run's (profiles/pmc_latest.json, "<workload>sharded"): its measured bytes / algorithmic bytes ratio
@@ -886,18 +899,19 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
         try:
             pmc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
                                               "pmc_latest.json"))).get(wl_name + "sharded", {})
-            m, a = pmc.get("frame_multi_scan_claim_kernel_hbm_bytes_per_launch"), pmc.get("algorithmic_bytes_per_launch")
+            m, a = pmc.get(pmc_key + "_hbm_bytes_per_launch"), pmc.get("algorithmic_bytes_per_launch")
             if m and a:
                 traffic = int(round(walk_bytes * m / a)) if world > 1 else int(m)
                 traffic_source = ("rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of the one-rank run" if world == 1 else
                                   f"one-rank PMC ratio {m / a:.3f} x this rank's algorithmic bytes")
         except Exception:
             pass
-        roofline = dict(bound="hbm", kernel="frame_multi_scan_claim_kernel (rank 0)", achieved=round(achieved, 1),
+        roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1),
                         peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4), traffic=traffic,
                         traffic_source=traffic_source,
                         bytes_per_launch=walk_bytes, us_per_launch=round(walk_us, 2),
-                        commit_integrate_us=round(1e3 * kt["frame_commit_integrate_ms"] / launches, 2))
+                        launches_per_frame=1 if one_launch else 2,
+                        commit_integrate_us=None if one_launch else round(1e3 * kt["frame_commit_integrate_ms"] / launches, 2))
         out = dict(
             metric=args.metric_name,
             value=round(frames / elapsed, 1), unit="frames/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
