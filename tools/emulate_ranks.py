@@ -19,6 +19,9 @@ plan = vdist.ShardPlan(1 << 20, R)
 cap = max(2048, -(-W * H // (16 * R)))
 shards = [vdist.HipShard(V.default_params(numBuckets=1 << 20, numVoxelBlocks=1 << 16), W, H, 1, plan, r, cap, batch=B,
                          sensor_k_inv=kinv) for r in range(R)]
+if len(sys.argv) > 3:
+    for sh in shards:
+        sh.table.set_option("pipeline_shards", int(sys.argv[3]))      # 0: two launches per multi-camera frame
 nf = 64
 poses = [synth.camera_loop(500, phase=vdist.camera_phase(r, R))[:nf] for r in range(R)]
 depth = [[(synth.render_room_verts(p, W, H, prims, device="cuda")[..., 2] * 5000).round().clamp(0, 65535).to(torch.uint16)
@@ -42,8 +45,9 @@ for i in range(n):
 torch.cuda.synchronize()
 kt = shards[0].table.kernel_times(reset=True)
 frames = n * B
-print(f"R={R} batch={B}: rank 0 per multi-camera frame ({R} cameras): scan+claim {1e3*kt['frame_scan_claim_ms']/frames:.2f} us, "
-      f"commit+integrate {1e3*kt['frame_commit_integrate_ms']/frames:.2f} us; shard {shards[0].table.num_entries*20/1e6:.1f} MB, "
+print(f"R={R} batch={B}: rank 0 per multi-camera frame ({R} cameras): one-launch frames {1e3*kt['frame_pipelined_ms']/frames:.2f} us "
+      f"(B + 1 launches per batch; two-launch form: scan+claim {1e3*kt['frame_scan_claim_ms']/frames:.2f} us, "
+      f"commit+integrate {1e3*kt['frame_commit_integrate_ms']/frames:.2f} us); shard {shards[0].table.num_entries*20/1e6:.1f} MB, "
       f"occupied {shards[0].table.counters()['occupied']}, bins {cap*16*R*B/1e6:.2f} MB and packets {shards[0].packet_floats*4*R*B/1e6:.1f} MB received per exchange")
 # key generation of a batch, timed on the device
 sh = shards[0]
