@@ -521,6 +521,24 @@ def main():
                   achieved_gbs=round(ray_bytes / (raycast_us * 1e-6) / 1e9, 1) if raycast_us > 0 else None,
                   note="kernel_us is the mean HIP-event duration over the same poses as the end-to-end loop")
         rc["roofline"] = raycast_roofline(name, raycast_us, Wd, Ht)
+        rc["traversal"] = ("voxel DDA (raycastSDF.frag:121-177 re-specified; cooperative form: one block list per wave), "
+                           "vh_set_option raycast_mode = VH_RAYCAST_DDA, the default")
+        # the same poses with the normal map written by the same pass, and with the fixed-step march of rounds 1-2
+        normals = torch.empty((Ht, Wd, 4), dtype=torch.float32, device=dev)
+        variants = {}
+        for label, mode, with_normals in (("dda_with_normals", 1, True), ("fixed_step_march", 0, False)):
+            table.set_option("raycast_mode", mode)
+            table.set_profiling(True)
+            for k in ray_poses:
+                if with_normals:
+                    lib.vh_raycast_normals(h, pose_ptrs[k], 0.1, 5.0, dptr, normals.data_ptr())
+                else:
+                    lib.vh_raycast(h, pose_ptrs[k], 0.1, 5.0, dptr)
+            kt_v = table.kernel_times(reset=True)
+            table.set_profiling(False)
+            variants[label] = round(1e3 * kt_v["raycast_ms"] / max(1, kt_v["raycast_launches"]), 2)
+        table.set_option("raycast_mode", 1)
+        rc["variants_kernel_us"] = variants
         extra["raycast"] = rc
 
     # ---- loaded integrate: truncation-band allocation on (every pixel demands the blocks within

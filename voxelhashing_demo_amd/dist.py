@@ -710,7 +710,8 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     # The exchange runs inside the library on RCCL directly (include/voxelhash_dist.h: one C call per exchange, three
     # HIP streams and two buffer sets in C++) unless --python-exchange asks for round 2's Python host (ShardedPipeline
     # over torch.distributed collectives), kept for comparison.
-    native = not getattr(args, "python_exchange", False) and pipelined
+    # (the N > 1 test rig -- gloo, every rank on one GPU, which RCCL refuses -- goes through the Python host too)
+    native = not getattr(args, "python_exchange", False) and pipelined and dist.get_backend() == "nccl"
     front = torch.cuda.Stream(device=dev)
     import ctypes as C
     with torch.cuda.stream(stream):
