@@ -355,12 +355,32 @@ __device__ __forceinline__ uint32_t sample_rank(const PixelVertex &p, int k)
 }
 
 // the claim phase for one 16x16 launch tile = one 256-lane workgroup (alloc_claim_kernel and the fused frame)
+#ifdef VH_CLAIM_STAMPS
+// diagnostics build (tools/ab_variants.sh build stamps -DVH_CLAIM_STAMPS; tools/claim_stamps.py): per claim tile the 100 MHz
+// clock at its start, after the vertex load, after the sample loop and at its end, in the macro-cell bitmap's spare tail
+__device__ unsigned long long *g_claimStamps = nullptr;
+#define VH_CLAIM_STAMP(i) do { if (g_claimStamps && threadIdx.x == 0) g_claimStamps[(size_t)tile * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define VH_CLAIM_STAMP(i) do { } while (0)
+#endif
+// Where a band-allocation tile's time goes, measured with per-tile time stamps (tools/claim_stamps.py) on C2 with a 10 cm
+// band (5 samples per pixel): vertex load 2.3 us, the SAMPLE LOOP 8.5 us, drain of the key queue 1.8 us -- 12.6 us per
+// tile, the last tile ending at 21.6 us of a 25 us launch whose walk needs 17.  The loop is instruction issue (~300
+// instructions per sample and wave: three IEEE divisions, the frustum test of the leaders, six cross-lane moves), not a
+// latency chain: splitting a tile's samples over two or three workgroups (shorter chains, the vertices read again) made
+// the launch SLOWER (26.2 -> 29.2 -> 33.3 us), and so did fetching the bucket's first slot together with the pending
+// frame's claim word in the drain (24.0 -> 26.1 us: more registers for every role of the fused kernel).
 template <class In>
 __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs &dp, const In &in, uint32_t tile,
                                            int candCounter, const Pending &pend = kNoPending,
                                            float *__restrict__ outDepth = nullptr, uint16_t *__restrict__ outRaw = nullptr)
 {
+    VH_CLAIM_STAMP(0);
     const PixelVertex p = load_pixel(fp, in, tile, threadIdx.x, outDepth, outRaw);
+#ifdef VH_CLAIM_STAMPS
+    if (p.v.z == 12345.678f) return;       // (forces the load to complete before the next stamp)
+#endif
+    VH_CLAIM_STAMP(1);
     BandWalk walk;
     walk.init(fp, p);
     int ox = 0, oy = 0, oz = 0;
@@ -412,7 +432,10 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
         }
         count += n;
     }
+    VH_CLAIM_STAMP(2);
     drain(count);
+    __builtin_amdgcn_s_waitcnt(0);
+    VH_CLAIM_STAMP(3);
 }
 
 template <class In>

@@ -104,6 +104,7 @@ struct vh_context {
     int4 *candBuf[2] = {nullptr, nullptr};
     VoxelEntry *compactBuf[2] = {nullptr, nullptr};
     uint32_t *maskBuf2 = nullptr;          // pipelined multi-camera frames: the camera masks of the second compact buffer
+    int debugSkipRoles = 0;                // diagnostics: roles of the pipelined launch that return at once (timing only; the model is wrong)
     int pipelineShards = 1;                // option "pipeline_shards": vh_apply_frames_batch runs a batch of B multi-camera frames as B + 1 launches
     VoxelEntry *compactHome = nullptr;     // the compact buffer of creation: what PtrContainer names, where settle() leaves the dense list
     float *planeBuf[2] = {nullptr, nullptr};

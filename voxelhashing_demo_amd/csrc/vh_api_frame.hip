@@ -272,6 +272,7 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     a.claimRatio = claim_ratio(a.claimBlocks, a.claimSpan);
     a.planeNew = (hasNew && !newSensor) ? c->planeBuf[newParity] : nullptr;
     a.rawNew = (hasNew && newSensor) ? c->rawBuf[newParity] : nullptr;
+    a.skipRoles = (uint32_t)c->debugSkipRoles;
     const DevPtrs dpNew = pipe_view(c, newParity), dpOld = pipe_view(c, oldParity);
     const dim3 grid(a.commitBlocks + a.integrateBlocks + a.claimBlocks + a.walkBlocks);
     In inNew{};

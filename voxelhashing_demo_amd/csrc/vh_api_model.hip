@@ -396,6 +396,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
         return VH_OK;
     }
     if (std::strcmp(name, "pipe_integrate_grid") == 0 && value > 0) { c->pipeIntegrateGrid = value; return VH_OK; }
+    if (std::strcmp(name, "debug_skip_roles") == 0 && value >= 0 && value < 16) { c->debugSkipRoles = value; return VH_OK; }
     if (std::strcmp(name, "pipeline_shards") == 0) { c->pipelineShards = value != 0; return VH_OK; }
     if (std::strcmp(name, "pipeline") == 0) {
         c->pipeline = value != 0;
@@ -497,6 +498,13 @@ extern "C" int vh_get_kernel_times(vh_context *c, vh_kernel_times *out, int rese
     if (reset) c->times = vh_kernel_times{};
     return VH_OK;
 }
+
+#ifdef VH_CLAIM_STAMPS
+extern "C" int vh_debug_set_claim_stamps(void *d_stamps)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(vh::g_claimStamps), &d_stamps, sizeof d_stamps) == hipSuccess ? VH_OK : VH_ERR_HIP;
+}
+#endif
 
 // diagnostics hook (tools/raycast_stamps.py): the DDA raycast writes {start, end (s_memrealtime, 100 MHz), steps, patch}
 // per wave into d_stamps (4 uint64 per wave, waves in workgroup order); NULL switches it off

@@ -153,6 +153,8 @@ struct PipeArgs {
     uint32_t claimSpan, claimRatio;        // claim tiles are interleaved with the first claimSpan - claimBlocks walk tiles
     float *planeNew;                       // private depth copies written by claim(new) ...
     uint16_t *rawNew;
+    uint32_t skipRoles;                    // diagnostics (option "debug_skip_roles"): bit r set = workgroups of role r return at once
+                                           // (0 commit, 1 integrate, 2 claim, 3 walk): what the launch costs without them
 };
 
 template <class In, class Depth>
@@ -192,6 +194,7 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
             role = 3; index = r - a.claimBlocks;
         }
     }
+    if (a.skipRoles & (1u << role)) return;
     // first launch of a run (no frame in flight): nobody pops the heap during it, so its first workgroup
     // leaves the free-block count the NEXT launch will test frame i+1's insertions against
     if (!a.hasOld && b == 0u && threadIdx.x == 0) counters[kPipeHeapFree + a.setNew] = counters[kHeapCounter] + 1;
