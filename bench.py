@@ -147,6 +147,19 @@ def pmc_traffic(workload, kernel):
     return None
 
 
+def rocprof_mean_us(workload, kernel):
+    """Average dispatch duration of `kernel` in the committed `rocprofv3 --kernel-trace --stats` summary of this workload
+    (profiles/kernel_stats_latest.json, written by tools/make_pmc_latest.py from the round's kernel_stats CSV), or None."""
+    try:
+        ks = json.load(open(os.path.join(ROOT, "profiles", "kernel_stats_latest.json"))).get(workload, {})
+    except Exception:
+        return None
+    for k, v in ks.items():
+        if k.startswith(kernel):
+            return v.get("avg_us")
+    return None
+
+
 def render_frames(synth, wl, nframes, dev, torch):
     poses = synth.camera_loop(wl["loop"])[:nframes]
     prims = synth.room_primitives()
@@ -248,9 +261,20 @@ class Integrator:
                                         traffic=pmc_traffic(workload, "frame_commit_integrate_kernel"),
                                         bytes_per_launch=bytes2, us_per_launch=round(us2, 2))
         achieved = nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
-        return dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(workload, kname),
-                    bytes_per_launch=nbytes, us_per_launch=round(us, 2), residency=residency)
+        # SURVEY.md 8(d) "HBM-read roofline": the frame's bytes without its write terms (compact entries and voxels written)
+        read_bytes = nbytes - 20 * occ - (4096 * occ if kname == "frame_pipelined_kernel" else 0)
+        out = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                   frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic(workload, kname),
+                   bytes_per_launch=nbytes, us_per_launch=round(us, 2),
+                   hbm_read_frac=round(read_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None,
+                   residency=residency)
+        # the same fraction on the average duration rocprofv3 reported for this kernel in the committed profile of this
+        # workload (another box, the whole run's dispatches): the figure a reader recomputes from profiles/
+        rp = rocprof_mean_us(workload, kname)
+        if rp:
+            out["rocprofv3_us_per_launch"] = rp
+            out["frac_at_rocprofv3_mean"] = round(nbytes / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        return out
 
     def close(self):
         self.table.close()

@@ -13,3 +13,6 @@ timeout 900 python bench.py > $OUT/bench_default.log 2>&1; echo "bench exit $?"
 grep '"metric"' $OUT/bench_default.log > $OUT/bench_default.json; tail -c 3000 $OUT/bench_default.log
 timeout 900 bash tools/profile_round.sh $TAG C2 > $OUT/profile_C2.log 2>&1; tail -25 $OUT/profile_C2.log
 timeout 900 bash tools/profile_round.sh $TAG C3 > $OUT/profile_C3.log 2>&1; tail -12 $OUT/profile_C3.log
+timeout 900 bash tools/profile_round.sh $TAG C2band > $OUT/profile_C2band.log 2>&1; tail -6 $OUT/profile_C2band.log
+timeout 600 bash tools/pmc_raycast_quick.sh $TAG 1 > $OUT/pmc_raycast.log 2>&1; tail -20 $OUT/pmc_raycast.log
+timeout 300 python3 tools/raycast_stamps.py > $OUT/raycast_stamps.txt 2>&1; tail -12 $OUT/raycast_stamps.txt

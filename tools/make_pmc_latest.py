@@ -57,4 +57,22 @@ for wl in sys.argv[2:]:
                     "raycast_kernel_valu_insts": cs["SQ_INSTS_VALU"]["mean"], "raycast_kernel_waves": cs["SQ_WAVES"]["mean"],
                     "raycast_kernel_valu_per_wave": round(cs["SQ_INSTS_VALU"]["mean"] / max(1.0, cs["SQ_WAVES"]["mean"]), 1)}
 json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
+# profiles/kernel_stats_latest.json: average dispatch duration per kernel and workload from the same round's
+# rocprofv3 --kernel-trace --stats summaries (kernel_stats_<WL>.csv), for bench.py's frac_at_rocprofv3_mean
+import csv
+ks_path = os.path.join(root, "profiles", "kernel_stats_latest.json")
+ks = json.load(open(ks_path)) if os.path.exists(ks_path) else {}
+for wl in sys.argv[2:]:
+    f = os.path.join(src, f"kernel_stats_{wl}.csv")
+    if not os.path.exists(f):
+        continue
+    rows = [r for r in csv.DictReader(l for l in open(f) if not l.startswith("#"))]
+    d = {"source": f"{f}: rocprofv3 --kernel-trace --stats of bench.py --legs none --workload {wl}"}
+    for r in rows:
+        name = r["Name"]
+        i = name.find("vh::")
+        short = name[i + 4:].split("(")[0] if i >= 0 else name
+        d[short] = {"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 3)}
+    ks[wl] = d
+json.dump(ks, open(ks_path, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

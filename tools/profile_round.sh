@@ -3,7 +3,7 @@
 # workload, then separate PMC passes (FETCH_SIZE, WRITE_SIZE cannot share a pass on gfx950),
 # condensed into gpurun_out/$1/.  Copy what should be judged into profiles/ afterwards
 # (tools/make_pmc_latest.py builds profiles/pmc_latest.json from the PMC summaries).
-#   tools/profile_round.sh r02 [C2|C3|C2band]
+#   tools/profile_round.sh r03 [C2|C3|C2band]
 # The traced command is `python3 bench.py --legs none --workload WL`: the timed windows and the
 # per-dispatch profile of ONE workload, so a kernel's average is not a mix of C2 and C3 launches.
 set -u
