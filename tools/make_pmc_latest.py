@@ -49,13 +49,15 @@ for wl in sys.argv[2:]:
     valu = os.path.join(src, f"pmc_VALU_raycast_{wl}.json")
     if os.path.exists(valu):
         v = json.load(open(valu))
-        for k, cs in v.items():
+        # (the raycast leg also times the fixed-step march on the same poses: the DDA kernel, the default, is the one reported)
+        for k, cs in sorted(v.items(), key=lambda kv: 0 if kv[0].startswith("raycast_dda_kernel<1, false>") else 1 if kv[0].startswith("raycast_dda") else 2):
             if k.startswith(("raycast_dda_kernel", "raycast_kernel")) and "SQ_INSTS_VALU" in cs and "SQ_WAVES" in cs:
                 out[wl + "_raycast"] = {
                     "source": f"{src}: rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES, bench.py --legs raycast --workload {wl}",
-                    "kernel": k.split("<")[0].split("(")[0],
+                    "kernel": k.split("(")[0],
                     "raycast_kernel_valu_insts": cs["SQ_INSTS_VALU"]["mean"], "raycast_kernel_waves": cs["SQ_WAVES"]["mean"],
                     "raycast_kernel_valu_per_wave": round(cs["SQ_INSTS_VALU"]["mean"] / max(1.0, cs["SQ_WAVES"]["mean"]), 1)}
+                break
 json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
 # profiles/kernel_stats_latest.json: average dispatch duration per kernel and workload from the same round's
 # rocprofv3 --kernel-trace --stats summaries (kernel_stats_<WL>.csv), for bench.py's frac_at_rocprofv3_mean
