@@ -701,14 +701,31 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
                     if (!(tArr < ra.tMax) || ((qa >> 3) != (m0 ? kk[0] : m2 ? kk[2] : kk[1]))) break;   // (visited iff the ray arrives before t_max)
                 }
             #else
-                float tn0 = dda_tnext(ax[0], q[0]), tn1 = dda_tnext(ax[1], q[1]), tn2 = dda_tnext(ax[2], q[2]);
+                // Inside the block the walk keeps the voxel as float coordinates (exact below 2^24: the host refuses views
+                // beyond 2^23), the local position as three 5-bit fields (value 8..15 = inside: ONE mask test tells when the
+                // ray has left the block) packed with the linear voxel index, and steps all of it without a branch:
+                // ~27 vector instructions per voxel instead of ~45 with integer coordinates and per-axis branches.
+                const int bx0 = kk[0] << 3, by0 = kk[1] << 3, bz0 = kk[2] << 3;
+                int pl;
+                {
+                    const int lx = q[0] & 7, ly = q[1] & 7, lz = q[2] & 7;
+                    pl = ((lx | (ly << 3) | (lz << 6)) << 16) | (lx + 8) | ((ly + 8) << 5) | ((lz + 8) << 10);
+                }
+                float fc0 = (float)q[0], fc1 = (float)q[1], fc2 = (float)q[2];
+                const float f0 = (float)ax[0].s, f1 = (float)ax[1].s, f2 = (float)ax[2].s;
+                // (an axis that never steps: invE = 0 would give a crossing time of 0; (c + 1e30) * inf = inf instead)
+                const float ie0 = ax[0].invE != 0.0f ? ax[0].invE : __builtin_inff(), gs0 = ax[0].invE != 0.0f ? ax[0].Gs : -1.0e30f;
+                const float ie1 = ax[1].invE != 0.0f ? ax[1].invE : __builtin_inff(), gs1 = ax[1].invE != 0.0f ? ax[1].Gs : -1.0e30f;
+                const float ie2 = ax[2].invE != 0.0f ? ax[2].invE : __builtin_inff(), gs2 = ax[2].invE != 0.0f ? ax[2].Gs : -1.0e30f;
+                const int d0 = ax[0].s * ((1 << 16) + 1), d1 = ax[1].s * ((8 << 16) + (1 << 5)), d2 = ax[2].s * ((64 << 16) + (1 << 10));
+                float tn0 = (fc0 - gs0) * ie0, tn1 = (fc1 - gs1) * ie1, tn2 = (fc2 - gs2) * ie2;
                 float tArr = tE;
                 int pArr = pE;
                 bool pv = false, firstVoxel = !inside, walking = true;
                 float ps = 0.0f;
-                int p0 = 0, p1 = 0, p2 = 0;
+                int prevLin = -1, p0 = 0, p1 = 0, p2 = 0;     // the previous sample: a voxel of this block (prevLin) or the neighbour (p0..2)
                 while (walking) {
-                    int vq0[kCoopK], vq1[kCoopK], vq2[kCoopK], vp[kCoopK];
+                    int pls[kCoopK], vp[kCoopK];
                     float vt[kCoopK];
                     Voxel vv[kCoopK];
                     int n = 0;
@@ -716,8 +733,8 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
 #pragma unroll
                     for (int j = 0; j < kCoopK; ++j) {
                         if (more) {
-                            vq0[j] = q[0]; vq1[j] = q[1]; vq2[j] = q[2]; vt[j] = tArr; vp[j] = pArr;
-                            vv[j] = dp.blocks[(size_t)bptr + (size_t)(((q[2] & 7) << 6) | ((q[1] & 7) << 3) | (q[0] & 7))];
+                            pls[j] = pl; vt[j] = tArr; vp[j] = pArr;
+                            vv[j] = dp.blocks[(size_t)bptr + (size_t)((uint32_t)pl >> 16)];
                             n = j + 1;
                             // the crossing that ends this voxel (raycastSDF.frag:156-170)
                             const bool m0 = tn0 < tn1 && tn0 < tn2;
@@ -725,10 +742,10 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
                             const bool m1 = !m0 && !m2;
                             tArr = m0 ? tn0 : m2 ? tn2 : tn1;
                             pArr = m0 ? 2 : m2 ? 1 : 0;
-                            q[0] += m0 ? ax[0].s : 0; q[1] += m1 ? ax[1].s : 0; q[2] += m2 ? ax[2].s : 0;
-                            const bool left = (((q[0] >> 3) ^ kk[0]) | ((q[1] >> 3) ^ kk[1]) | ((q[2] >> 3) ^ kk[2])) != 0;
-                            more = tArr < ra.tMax && !left;             // (a voxel is visited iff the ray arrives before t_max)
-                            if (more) { tn0 = dda_tnext(ax[0], q[0]); tn1 = dda_tnext(ax[1], q[1]); tn2 = dda_tnext(ax[2], q[2]); }
+                            pl += m0 ? d0 : m2 ? d2 : d1;
+                            fc0 += m0 ? f0 : 0.0f; fc1 += m1 ? f1 : 0.0f; fc2 += m2 ? f2 : 0.0f;
+                            tn0 = (fc0 - gs0) * ie0; tn1 = (fc1 - gs1) * ie1; tn2 = (fc2 - gs2) * ie2;
+                            more = tArr < ra.tMax && (pl & 0x6318) == 0x2108;     // (a voxel is visited iff the ray arrives before t_max)
                         }
                     }
                     walking = more;
@@ -736,36 +753,39 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
                     for (int j = 0; j < kCoopK; ++j) {
                         if (j < n) {
                             const bool valid = vv[j].weight > 0.0f;
+                            const int lin = (int)((uint32_t)pls[j] >> 16);
                             if (valid && vv[j].sdf <= 0.0f) {
+                                const int vx = bx0 + (lin & 7), vy = by0 + ((lin >> 3) & 7), vz = bz0 + (lin >> 6);
                                 if (firstVoxel) {
                                     // the voxel the ray was in before the entry event: one step back on the entry axis, in the
                                     // neighbouring block -- allocated iff it is in the wave's set
-                                    const int n0 = vq0[j] - (xe == 0 ? ax[0].s : 0), n1 = vq1[j] - (xe == 1 ? ax[1].s : 0), n2 = vq2[j] - (xe == 2 ? ax[2].s : 0);
+                                    const int n0 = vx - (xe == 0 ? ax[0].s : 0), n1 = vy - (xe == 1 ? ax[1].s : 0), n2 = vz - (xe == 2 ? ax[2].s : 0);
                                     const int fs = coop_find(tags, coop_tag((n0 >> 3) - base0, (n1 >> 3) - base1, (n2 >> 3) - base2));
                                     pv = false;
                                     if (fs >= 0) {
                                         const uint32_t np = ptrs[fs];
                                         if (np != (uint32_t)VH_FREE_BLOCK && np != kCoopUnresolved) {
                                             const Voxel nb = dp.blocks[(size_t)np + (size_t)(((n2 & 7) << 6) | ((n1 & 7) << 3) | (n0 & 7))];
-                                            pv = nb.weight > 0.0f; ps = nb.sdf; p0 = n0; p1 = n1; p2 = n2;
+                                            pv = nb.weight > 0.0f; ps = nb.sdf; p0 = n0; p1 = n1; p2 = n2; prevLin = -1;
                                         }
                                     }
                                 }
                                 if (pv && ps > 0.0f) {
                                     if (dda_before(vt[j], vp[j], bestT, bestP)) {
                                         bestT = vt[j]; bestP = vp[j];
+                                        if (prevLin >= 0) { p0 = bx0 + (prevLin & 7); p1 = by0 + ((prevLin >> 3) & 7); p2 = bz0 + (prevLin >> 6); }
                                         // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
-                                        const float tc = ((ra.zrow[0] * (float)vq0[j] + ra.zrow[1] * (float)vq1[j]) + ra.zrow[2] * (float)vq2[j]) + ra.zrow[3];
+                                        const float tc = ((ra.zrow[0] * (float)vx + ra.zrow[1] * (float)vy) + ra.zrow[2] * (float)vz) + ra.zrow[3];
                                         const float tp = ((ra.zrow[0] * (float)p0 + ra.zrow[1] * (float)p1) + ra.zrow[2] * (float)p2) + ra.zrow[3];
                                         hit = tp + ((tc - tp) * ps) / (ps - vv[j].sdf);
                                         found = true;
-                                        hx = vq0[j]; hy = vq1[j]; hz = vq2[j]; hptr = bptr;
+                                        hx = vx; hy = vy; hz = vz; hptr = bptr;
                                     }
                                     walking = false;                   // (the block's first pair: nothing earlier behind it)
                                     n = j;                             // (stops the judging)
                                 }
                             }
-                            pv = valid; ps = vv[j].sdf; p0 = vq0[j]; p1 = vq1[j]; p2 = vq2[j];
+                            pv = valid; ps = vv[j].sdf; prevLin = lin;
                             firstVoxel = false;
                         }
                     }
