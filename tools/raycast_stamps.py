@@ -42,6 +42,12 @@ for k in (0, 35, 77):
         tA, tB = s[:, 4] / 100.0, s[:, 5] / 100.0
         print(f"   cooperative form: set built after {tA.mean():.2f} us (max {tA.max():.2f}), list resolved after {tB.mean():.2f} (max {tB.max():.2f}); "
               f"list length mean {s[:, 6].mean():.1f} p99 {np.percentile(s[:, 6], 99):.0f} max {s[:, 6].max()}; blocks walked by some lane: mean {s[:, 7].mean():.1f} max {s[:, 7].max()}")
+        early, late = start < 2.0, start > 6.0
+        for name, m in (("first round of waves", early), ("waves started later", late)):
+            if m.any():
+                print(f"      {name} ({int(m.sum())}): set built after {tA[m].mean():.2f}, list after {tB[m].mean():.2f}, life {life[m].mean():.2f} us; "
+                      f"list {s[m, 6].mean():.1f}; after the list: {((life[m] - tB[m]) / np.maximum(1, s[m, 6])).mean():.2f} us per listed block")
+        print(f'      ray set-up done after {((s[:, 2] & 0xffffffff) / 100.0).mean():.2f} us')
         slow = np.argsort(-life)[:6]
         print("   slowest waves: (life, list, walked)", [(round(float(life[i]), 1), int(s[i, 6]), int(s[i, 7])) for i in slow])
     ok = rounds > 0

@@ -554,12 +554,15 @@ static int raycast_impl(vh_context *c, const float pose[16], float t_min, float 
         ra.stamps = reinterpret_cast<unsigned long long *>(c->raycastStamps);
         ra.beam = t_min > 0.0f ? c->raycastBeam : 0;
         float4 *nrm = reinterpret_cast<float4 *>(d_normals_out);
+        const dim3 block(64 * kDdaBlockWaves);
+        if (kDdaBlockWaves == 1)
+            grid = c->raycastPatch ? dim3((fp.width + 7) / 8, (fp.height + 7) / 8) : dim3((fp.width + 15) / 16, (fp.height + 3) / 4);
         if (nrm)
-            rc = c->raycastPatch ? launch(c, kPhaseRaycast, raycast_dda_kernel<1, true>, grid, dim3(256), fp, dp, ra, d_depth_out, nrm)
-                                 : launch(c, kPhaseRaycast, raycast_dda_kernel<0, true>, grid, dim3(256), fp, dp, ra, d_depth_out, nrm);
+            rc = c->raycastPatch ? launch(c, kPhaseRaycast, raycast_dda_kernel<1, true>, grid, block, fp, dp, ra, d_depth_out, nrm)
+                                 : launch(c, kPhaseRaycast, raycast_dda_kernel<0, true>, grid, block, fp, dp, ra, d_depth_out, nrm);
         else
-            rc = c->raycastPatch ? launch(c, kPhaseRaycast, raycast_dda_kernel<1, false>, grid, dim3(256), fp, dp, ra, d_depth_out, nrm)
-                                 : launch(c, kPhaseRaycast, raycast_dda_kernel<0, false>, grid, dim3(256), fp, dp, ra, d_depth_out, nrm);
+            rc = c->raycastPatch ? launch(c, kPhaseRaycast, raycast_dda_kernel<1, false>, grid, block, fp, dp, ra, d_depth_out, nrm)
+                                 : launch(c, kPhaseRaycast, raycast_dda_kernel<0, false>, grid, block, fp, dp, ra, d_depth_out, nrm);
     }
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());

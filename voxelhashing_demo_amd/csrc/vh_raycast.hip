@@ -335,22 +335,22 @@ __device__ __forceinline__ bool beam_slab_occupied(const FrameParams &fp, const 
 // of 64 when the range is longer), the boxes are conservative, so every allocated block any ray of the wave visits
 // is in the list.  Whenever the preconditions fail -- a box spans more than two blocks on an axis, the set
 // overflows, a block lies more than 511 blocks from the wave's first -- the wave falls back to the per-lane walk.
-#ifndef VH_COOP_LDS
-#define VH_COOP_LDS 0      // 1: the walked block is staged in LDS (4 KiB per wave), 0: its voxels are gathered VH_COOP_K at a time
-#endif
 #ifndef VH_COOP_K
 #define VH_COOP_K 2
 #endif
 constexpr int kCoopK = VH_COOP_K;
+#ifndef VH_DDA_BLOCK_WAVES
+#define VH_DDA_BLOCK_WAVES 4    // waves (pixel patches) per workgroup: 4 = a 16x16 tile, 1 = a patch of its own
+#endif
+constexpr int kDdaBlockWaves = VH_DDA_BLOCK_WAVES;
 constexpr int kCoopSlots = 256;                       // per wave: cells with a set bucket bit
 constexpr uint32_t kCoopUnresolved = 0x7ffffffeu;     // sPtr: not looked up yet
 struct CoopShared {
-    uint32_t tag[4][kCoopSlots];
-    uint32_t ptr[4][kCoopSlots];
-    uint16_t list[4][kCoopSlots];
-#if VH_COOP_LDS
-    Voxel block[4][kBlockVoxels];     // the block the wave is walking (4 KiB per wave)
-#endif
+    uint32_t tag[kDdaBlockWaves][kCoopSlots];
+    uint32_t ptr[kDdaBlockWaves][kCoopSlots];
+    uint32_t list[kDdaBlockWaves][kCoopSlots];     // allocated cells: slot | depth key << 16 (the list is walked front to back)
+    uint16_t cells[kDdaBlockWaves][kCoopSlots];    // the set's occupied slots in order of insertion (what step 2 resolves)
+    uint32_t count[kDdaBlockWaves];
 };
 
 __device__ __forceinline__ uint32_t coop_tag(int rx, int ry, int rz) { return 1u + (uint32_t)rx + ((uint32_t)ry << 10) + ((uint32_t)rz << 20); }
@@ -366,6 +366,56 @@ __device__ __forceinline__ int coop_find(const uint32_t *tags, uint32_t tag)
         h = (h + 1u) & (kCoopSlots - 1);
     }
     return -1;
+}
+
+// Whether and where a ray enters block kk: the ray is inside the block's slab on axis a from the event that steps c_a
+// into it to the event that steps c_a out of it, and it visits the block iff the LAST of the three entering events
+// precedes the FIRST of the three leaving events in the merge order (or is the same event).
+struct CoopEntry {
+    float tE;              // the entering event (-inf: the ray starts inside the block)
+    int pE, xe;            // its priority and axis
+    bool inside, enters;
+    bool startIn[3];       // the ray starts inside the slab of axis a
+};
+__device__ __forceinline__ CoopEntry coop_entry(const DdaAxis (&ax)[3], const int (&c)[3], const int (&kk)[3], float tMax)
+{
+    CoopEntry r;
+    float tIn[3], tOut[3];
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int lo = kk[a] << 3, hi = lo + 7;
+        if (ax[a].invE == 0.0f) {
+            r.startIn[a] = c[a] >= lo && c[a] <= hi;
+            miss |= !r.startIn[a];
+            tIn[a] = -__builtin_inff(); tOut[a] = __builtin_inff();
+        } else if (ax[a].s > 0) {
+            miss |= c[a] > hi;
+            r.startIn[a] = c[a] >= lo;
+            tIn[a] = r.startIn[a] ? -__builtin_inff() : dda_tnext(ax[a], lo - 1);
+            tOut[a] = dda_tnext(ax[a], hi);
+        } else {
+            miss |= c[a] < lo;
+            r.startIn[a] = c[a] <= hi;
+            tIn[a] = r.startIn[a] ? -__builtin_inff() : dda_tnext(ax[a], hi + 1);
+            tOut[a] = dda_tnext(ax[a], lo);
+        }
+    }
+    // the LAST entering event and the FIRST leaving event in merge order
+    int xe = dda_before(tIn[0], 2, tIn[1], 0) ? 1 : 0;
+    {
+        const float t01 = xe ? tIn[1] : tIn[0];
+        if (dda_before(t01, xe ? 0 : 2, tIn[2], 1)) xe = 2;
+    }
+    const int xo = (tOut[0] < tOut[1] && tOut[0] < tOut[2]) ? 0 : (tOut[2] < tOut[1]) ? 2 : 1;
+    r.tE = xe == 0 ? tIn[0] : xe == 1 ? tIn[1] : tIn[2];
+    const float tO = xo == 0 ? tOut[0] : xo == 1 ? tOut[1] : tOut[2];
+    r.pE = xe == 0 ? 2 : xe == 1 ? 0 : 1;
+    const int pO = xo == 0 ? 2 : xo == 1 ? 0 : 1;
+    r.xe = xe;
+    r.inside = r.tE == -__builtin_inff();
+    r.enters = !miss && (r.inside || xe == xo || dda_before(r.tE, r.pE, tO, pO)) && (r.inside || r.tE < tMax);
+    return r;
 }
 
 // Shape of the kernel.  A ray's work is small (C2: ~25 absent blocks stepped over, 1.5 allocated blocks, ~10 voxels)
@@ -392,7 +442,7 @@ constexpr int kDdaK = VH_DDA_K;
 #endif
 
 template <int kPatch, bool kNormals>
-__global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const FrameParams fp, const DevPtrs dp, const RaycastArgs ra,
+__global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda_kernel(const FrameParams fp, const DevPtrs dp, const RaycastArgs ra,
                                                           float *__restrict__ depthOut, float4 *__restrict__ normalOut)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -407,7 +457,8 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
         }
     }
     // the wave's pixel patch
-    const int pu = tx * 16 + (kPatch == 0 ? 0 : (wave & 1) * 8), pv = ty * 16 + (kPatch == 0 ? wave * 4 : (wave >> 1) * 8);
+    const int pu = kDdaBlockWaves == 1 ? tx * (kPatch == 0 ? 16 : 8) : tx * 16 + (kPatch == 0 ? 0 : (wave & 1) * 8);
+    const int pv = kDdaBlockWaves == 1 ? ty * (kPatch == 0 ? 4 : 8) : ty * 16 + (kPatch == 0 ? wave * 4 : (wave >> 1) * 8);
     const int u = pu + (kPatch == 0 ? (lane & 15) : (lane & 7));
     const int v = pv + (kPatch == 0 ? (lane >> 4) : (lane >> 3));
     const bool inImage = u < fp.width && v < fp.height;
@@ -433,51 +484,57 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
     int hx = 0, hy = 0, hz = 0, hptr = VH_FREE_BLOCK;          // (per-lane walk: the last valid sample's voxel;) after a hit: the hit voxel and its block
     const int prio[3] = {2, 0, 1};
     bool coopDone = false;
+    unsigned long long stampP1 = 0ull;                        // diagnostics: the ray set-up is done
     unsigned long long stampA = stamp0, stampB = stamp0;      // diagnostics: the set is built / the list is resolved
     int coopList = 0, coopWalks = 0;
     if (ra.beam == 2) {
         __shared__ CoopShared sh_;
         uint32_t *tags = sh_.tag[wave], *ptrs = sh_.ptr[wave];
-        uint16_t *list = sh_.list[wave];
+        uint32_t *list = sh_.list[wave];
 #pragma unroll
-        for (int r = 0; r < kCoopSlots / 64; ++r) { tags[lane + 64 * r] = 0u; ptrs[lane + 64 * r] = kCoopUnresolved; }
-        Beam bm;
-        const float a0 = __shfl(dx, 0), a1 = __shfl(dx, kPatch == 0 ? 15 : 7);
-        const float b0 = __shfl(dy, 0), b1 = __shfl(dy, kPatch == 0 ? 48 : 56);
-        bm.dx0 = __builtin_fminf(a0, a1); bm.dx1 = __builtin_fmaxf(a0, a1);
-        bm.dy0 = __builtin_fminf(b0, b1); bm.dy1 = __builtin_fmaxf(b0, b1);
+        for (int r = 0; r < kCoopSlots / 64; ++r) tags[lane + 64 * r] = 0u;
+        uint16_t *cells = sh_.cells[wave];
+        uint32_t *count = &sh_.count[wave];
+        if (lane == 0) *count = 0u;
+        int nCells = 0;
+        float eMin[3], eMax[3];                                    // wave-uniform: the patch's corner rays
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float e0 = __shfl(ax[a].E, 0), e1 = __shfl(ax[a].E, kPatch == 0 ? 15 : 7);
+            const float e2 = __shfl(ax[a].E, kPatch == 0 ? 48 : 56), e3 = __shfl(ax[a].E, 63);
+            eMin[a] = __builtin_fminf(__builtin_fminf(e0, e1), __builtin_fminf(e2, e3));
+            eMax[a] = __builtin_fmaxf(__builtin_fmaxf(e0, e1), __builtin_fmaxf(e2, e3));
+        }
         const int base0 = (__shfl(c[0], 0) >> 3) - 512, base1 = (__shfl(c[1], 0) >> 3) - 512, base2 = (__shfl(c[2], 0) >> 3) - 512;
         const float dt2 = 4.0f * vs;                               // half-block slabs
+        // the walk's per-ray constants
+        const float f0 = (float)ax[0].s, f1 = (float)ax[1].s, f2 = (float)ax[2].s;
+        // (an axis that never steps: invE = 0 would give a crossing time of 0; (c + 1e30) * inf = inf instead)
+        const float ie0 = ax[0].invE != 0.0f ? ax[0].invE : __builtin_inff(), gs0 = ax[0].invE != 0.0f ? ax[0].Gs : -1.0e30f;
+        const float ie1 = ax[1].invE != 0.0f ? ax[1].invE : __builtin_inff(), gs1 = ax[1].invE != 0.0f ? ax[1].Gs : -1.0e30f;
+        const float ie2 = ax[2].invE != 0.0f ? ax[2].invE : __builtin_inff(), gs2 = ax[2].invE != 0.0f ? ax[2].Gs : -1.0e30f;
+        const int d0 = ax[0].s * ((1 << 16) + 1), d1 = ax[1].s * ((8 << 16) + (1 << 5)), d2 = ax[2].s * ((64 << 16) + (1 << 10));
         bool fail = false;
         float bestT = __builtin_inff();                            // arrival event of the best candidate's hit voxel
         int bestP = 3;
         int nList = 0;
         bool final_ = !inImage;
         __builtin_amdgcn_wave_barrier();
+        stampP1 = ra.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
         for (float tw = ra.tMin; tw < ra.tMax && !fail; tw += 64.0f * dt2) {
             // ---- 1. beam: the blocks slab `lane` of this window can touch ----
             const float ta = tw + (float)lane * dt2;
             if (ta < ra.tMax) {
-                const float tA = ta - 1.0e-4f * dt2, tB = ta + 1.0001f * dt2;
-                const float xa0 = bm.dx0 * tA, xa1 = bm.dx0 * tB, xb0 = bm.dx1 * tA, xb1 = bm.dx1 * tB;
-                const float ya0 = bm.dy0 * tA, ya1 = bm.dy0 * tB, yb0 = bm.dy1 * tA, yb1 = bm.dy1 * tB;
-                const float lo[3] = {__builtin_fminf(__builtin_fminf(xa0, xa1), __builtin_fminf(xb0, xb1)),
-                                     __builtin_fminf(__builtin_fminf(ya0, ya1), __builtin_fminf(yb0, yb1)), tA};
-                const float hi[3] = {__builtin_fmaxf(__builtin_fmaxf(xa0, xa1), __builtin_fmaxf(xb0, xb1)),
-                                     __builtin_fmaxf(__builtin_fmaxf(ya0, ya1), __builtin_fmaxf(yb0, yb1)), tB};
+                // g = G + E t is affine in the pixel, so over the patch each component of E lies between its values on the
+                // four corner rays, and over the slab (t >= 0) g_a lies between G_a + t eMin_a and G_a + t eMax_a at the
+                // slab's ends: the exact hull of the beam's part, grown by the margin
+                const float tA = __builtin_fmaxf(ta - 1.0e-4f * dt2, 0.0f), tB = ta + 1.0001f * dt2;
                 int k0[3], k1[3];
                 bool huge = false;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    float wl = 0.0f, wh = 0.0f;                   // R_a . box, interval arithmetic
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const float r = fp.T[4 * a + j] * ra.invVs;
-                        const float p = r * lo[j], q = r * hi[j];
-                        wl += __builtin_fminf(p, q);
-                        wh += __builtin_fmaxf(p, q);
-                    }
-                    const float gl = ra.G[a] + wl, gh = ra.G[a] + wh;
+                    const float gl = ra.G[a] + __builtin_fminf(tA * eMin[a], tB * eMin[a]);
+                    const float gh = ra.G[a] + __builtin_fmaxf(tA * eMax[a], tB * eMax[a]);
                     const float m = 0.02f + 1.0e-5f * __builtin_fmaxf(__builtin_fabsf(gl), __builtin_fabsf(gh));
                     k0[a] = f2i_rz(__builtin_floorf(gl - m)) >> 3;
                     k1[a] = f2i_rz(__builtin_floorf(gh + m)) >> 3;
@@ -489,30 +546,45 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
                     fail = true;
                 } else {
                     uint32_t word[8], bit[8];
+                    // (the eight hashes share their products: the second cell of an axis is the first plus one)
+                    const uint32_t hx0 = (uint32_t)k0[0] * 73856093u, hy0 = (uint32_t)k0[1] * 19349669u, hz0 = (uint32_t)k0[2] * 83492791u;
+                    const uint32_t hx1 = hx0 + (k1[0] != k0[0] ? 73856093u : 0u), hy1 = hy0 + (k1[1] != k0[1] ? 19349669u : 0u),
+                                   hz1 = hz0 + (k1[2] != k0[2] ? 83492791u : 0u);
+                    const bool pow2 = (fp.numBuckets & (fp.numBuckets - 1u)) == 0u;
+                    uint32_t mineMask = 0u;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        const int x = (k & 1) ? k1[0] : k0[0], y = (k & 2) ? k1[1] : k0[1], z = (k & 4) ? k1[2] : k0[2];
-                        const uint32_t h = hash_block(x, y, z, fp.numBuckets);
+                        const uint32_t hh = ((k & 1) ? hx1 : hx0) ^ ((k & 2) ? hy1 : hy0) ^ ((k & 4) ? hz1 : hz0);      // calculateHash, VoxelUtils.cu:250-259
+                        const uint32_t h = pow2 ? hh & (fp.numBuckets - 1u) : hh % fp.numBuckets;
+                        // (a bucket of another shard reads word 0 and masks the bit out: no branch around the load)
                         const bool mine = h >= fp.bucketLo && h < fp.bucketHi;
                         const uint32_t local = mine ? h - fp.bucketLo : 0u;
-                        word[k] = mine ? dp.bucketBits[local >> 5] : 0u;
+                        word[k] = dp.bucketBits[local >> 5];
                         bit[k] = local & 31u;
+                        mineMask |= mine ? 1u << k : 0u;
                     }
+                    // (a box one block wide on an axis names each cell twice: only its first name is taken)
+                    uint32_t setMask = 0u;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        // (a box one block wide on an axis names each cell twice: only its first name is taken)
-                        const bool dup = ((k & 1) && k1[0] == k0[0]) || ((k & 2) && k1[1] == k0[1]) || ((k & 4) && k1[2] == k0[2]);
-                        if (!dup && ((word[k] >> bit[k]) & 1u)) {
-                            const uint32_t tag = coop_tag(r0 + (k & 1), r1 + ((k >> 1) & 1), r2 + ((k >> 2) & 1));
-                            uint32_t h = (tag * 2654435761u) >> 24;
-                            bool placed = false;
-                            for (int probe = 0; probe < 16 && !placed; ++probe) {
-                                const uint32_t old = atomicCAS(&tags[h], 0u, tag);
-                                placed = old == 0u || old == tag;
-                                h = (h + 1u) & (kCoopSlots - 1);
+                    for (int k = 0; k < 8; ++k) setMask |= ((word[k] >> bit[k]) & 1u) << k;
+                    setMask &= mineMask;
+                    setMask &= ~((k1[0] == k0[0] ? 0xaau : 0u) | (k1[1] == k0[1] ? 0xccu : 0u) | (k1[2] == k0[2] ? 0xf0u : 0u));
+                    while (setMask) {
+                        const int k = __builtin_ctz(setMask);
+                        setMask &= setMask - 1u;
+                        const uint32_t tag = coop_tag(r0 + (k & 1), r1 + ((k >> 1) & 1), r2 + ((k >> 2) & 1));
+                        uint32_t h = (tag * 2654435761u) >> 24;
+                        bool placed = false;
+                        for (int probe = 0; probe < 16 && !placed; ++probe) {
+                            const uint32_t old = atomicCAS(&tags[h], 0u, tag);
+                            if (old == 0u) {                       // a new cell: queued for step 2
+                                ptrs[h] = kCoopUnresolved;
+                                cells[atomicAdd(count, 1u)] = (uint16_t)h;
                             }
-                            if (!placed) fail = true;
+                            placed = old == 0u || old == tag;
+                            h = (h + 1u) & (kCoopSlots - 1);
                         }
+                        if (!placed) fail = true;
                     }
                 }
             }
@@ -522,275 +594,178 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (fail) break;
             if (ra.stamps) stampA = __builtin_amdgcn_s_memrealtime();
-            // ---- 2. the new cells, four per lane: allocated? ----
+            // ---- 2. the new cells, one per lane: allocated? ----
             const int listBegin = nList;
-            {
-                uint32_t myLocal[kCoopSlots / 64];
-                int myKey[kCoopSlots / 64][3];
-                VoxelEntry first[kCoopSlots / 64];
-                bool todo[kCoopSlots / 64];
-#pragma unroll
-                for (int r = 0; r < kCoopSlots / 64; ++r) {
-                    const int slot = lane + 64 * r;
-                    const uint32_t tg = tags[slot];
-                    todo[r] = tg != 0u && ptrs[slot] == kCoopUnresolved;
-                    const uint32_t t = tg - 1u;
-                    myKey[r][0] = base0 + (int)(t & 1023u); myKey[r][1] = base1 + (int)((t >> 10) & 1023u); myKey[r][2] = base2 + (int)(t >> 20);
-                    const uint32_t h = hash_block(myKey[r][0], myKey[r][1], myKey[r][2], fp.numBuckets);
-                    myLocal[r] = h - fp.bucketLo;                       // (a set bit: the bucket is this shard's)
-                    first[r].ptr = VH_FREE_BLOCK; first[r].pos[0] = first[r].pos[1] = first[r].pos[2] = 0; first[r].offset = 0;
-                    if (todo[r]) first[r] = dp.table[(size_t)myLocal[r] * fp.bucketSize];      // (the four fetched together)
-                }
-#pragma unroll
-                for (int r = 0; r < kCoopSlots / 64; ++r) {
-                    int ptr = VH_FREE_BLOCK;
-                    if (todo[r]) {
-                        const int qx = myKey[r][0], qy = myKey[r][1], qz = myKey[r][2];
-                        if (fp.flags & kFlagOverflow) {
-                            uint32_t prev;
-                            const uint32_t at = find_entry_overflow(fp, dp.table, owned_entries(fp), myLocal[r], qx, qy, qz, prev);
-                            if (at != ~0u) ptr = dp.table[at].ptr;
-                        } else if (first[r].ptr != VH_FREE_BLOCK) {             // prefix property: a free first slot = an empty bucket
-                            if (first[r].pos[0] == qx && first[r].pos[1] == qy && first[r].pos[2] == qz) ptr = first[r].ptr;
-                            else {
-                                const VoxelEntry *bucket = dp.table + (size_t)myLocal[r] * fp.bucketSize;
-                                for (uint32_t i = 1; i < fp.bucketSize; ++i) {    // getVoxelEntry4Block, VoxelUtils.cu:362-382
-                                    const VoxelEntry e = bucket[i];
-                                    if (e.ptr == VH_FREE_BLOCK) break;
-                                    if (e.pos[0] == qx && e.pos[1] == qy && e.pos[2] == qz) { ptr = e.ptr; break; }
-                                }
-                            }
+            const int cellBegin = nCells;
+            nCells = __builtin_amdgcn_readfirstlane((int)*count);
+            for (int cb = cellBegin; cb < nCells; cb += 64) {
+                const bool todo = cb + lane < nCells;
+                const int slot = todo ? (int)cells[cb + lane] : 0;
+                const uint32_t t = tags[slot] - 1u;
+                const int qx = base0 + (int)(t & 1023u), qy = base1 + (int)((t >> 10) & 1023u), qz = base2 + (int)(t >> 20);
+                const uint32_t myLocal = hash_block(qx, qy, qz, fp.numBuckets) - fp.bucketLo;      // (a set bit: the bucket is this shard's)
+                int ptr = VH_FREE_BLOCK;
+                if (todo) {
+                    if (fp.flags & kFlagOverflow) {
+                        uint32_t prev;
+                        const uint32_t at = find_entry_overflow(fp, dp.table, owned_entries(fp), myLocal, qx, qy, qz, prev);
+                        if (at != ~0u) ptr = dp.table[at].ptr;
+                    } else {
+                        const VoxelEntry *bucket = dp.table + (size_t)myLocal * fp.bucketSize;
+                        for (uint32_t i = 0; i < fp.bucketSize; ++i) {        // getVoxelEntry4Block, VoxelUtils.cu:362-382
+                            const VoxelEntry e = bucket[i];
+                            if (e.ptr == VH_FREE_BLOCK) break;                // prefix property: a free slot ends the bucket
+                            if (e.pos[0] == qx && e.pos[1] == qy && e.pos[2] == qz) { ptr = e.ptr; break; }
                         }
-                        ptrs[lane + 64 * r] = (uint32_t)ptr;
                     }
-                    // the allocated ones join the wave's list
-                    const bool isNew = todo[r] && ptr != VH_FREE_BLOCK;
-                    const unsigned long long m = __ballot(isNew);
-                    if (isNew) list[nList + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(lane + 64 * r);
-                    nList += __popcll(m);
+                    ptrs[slot] = (uint32_t)ptr;
                 }
+                // the allocated ones join the wave's list
+                const bool isNew = todo && ptr != VH_FREE_BLOCK;
+                const unsigned long long m = __ballot(isNew);
+                if (isNew) {
+                    // camera depth of the block's centre in voxels beyond t_min: the order the blocks are walked in
+                    const float zc = ((ra.zrow[0] * ((float)(qx << 3) + 3.5f) + ra.zrow[1] * ((float)(qy << 3) + 3.5f))
+                                      + ra.zrow[2] * ((float)(qz << 3) + 3.5f)) + ra.zrow[3];
+                    const float kq = __builtin_fminf(__builtin_fmaxf((zc - ra.tMin) * ra.invVs, 0.0f), 65535.0f);
+                    list[nList + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)slot | ((uint32_t)f2i_rz(kq) << 16);
+                }
+                nList += __popcll(m);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (ra.stamps) { stampB = __builtin_amdgcn_s_memrealtime(); coopList = nList; }
-            // ---- 3. every ray against every new block of the list ----
-            for (int i = listBegin; i < nList; ++i) {
-                if (__ballot(!final_) == 0ull) break;
-                const int slot = __builtin_amdgcn_readfirstlane((int)list[i]);
-                const uint32_t tg = (uint32_t)__builtin_amdgcn_readfirstlane((int)tags[slot]) - 1u;
-                const int bptr = __builtin_amdgcn_readfirstlane((int)ptrs[slot]);
-                const int kk[3] = {base0 + (int)(tg & 1023u), base1 + (int)((tg >> 10) & 1023u), base2 + (int)(tg >> 20)};
-                // where the ray is inside the block's slab on each axis: from the event that steps into it to the event that
-                // steps out of it
-                float tIn[3], tOut[3];
-                bool startIn[3];
-                bool miss = final_;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const int lo = kk[a] << 3, hi = lo + 7;
-                    if (ax[a].invE == 0.0f) {
-                        startIn[a] = c[a] >= lo && c[a] <= hi;
-                        miss |= !startIn[a];
-                        tIn[a] = -__builtin_inff(); tOut[a] = __builtin_inff();
-                    } else if (ax[a].s > 0) {
-                        miss |= c[a] > hi;
-                        startIn[a] = c[a] >= lo;
-                        tIn[a] = startIn[a] ? -__builtin_inff() : dda_tnext(ax[a], lo - 1);
-                        tOut[a] = dda_tnext(ax[a], hi);
-                    } else {
-                        miss |= c[a] < lo;
-                        startIn[a] = c[a] <= hi;
-                        tIn[a] = startIn[a] ? -__builtin_inff() : dda_tnext(ax[a], hi + 1);
-                        tOut[a] = dda_tnext(ax[a], lo);
-                    }
-                }
-                // the LAST entering event and the FIRST leaving event in merge order
-                int xe = dda_before(tIn[0], 2, tIn[1], 0) ? 1 : 0;
-                {
-                    const float t01 = xe ? tIn[1] : tIn[0];
-                    if (dda_before(t01, xe ? 0 : 2, tIn[2], 1)) xe = 2;
-                }
-                const int xo = (tOut[0] < tOut[1] && tOut[0] < tOut[2]) ? 0 : (tOut[2] < tOut[1]) ? 2 : 1;
-                const float tE = xe == 0 ? tIn[0] : xe == 1 ? tIn[1] : tIn[2];
-                const float tO = xo == 0 ? tOut[0] : xo == 1 ? tOut[1] : tOut[2];
-                const int pE = xe == 0 ? 2 : xe == 1 ? 0 : 1, pO = xo == 0 ? 2 : xo == 1 ? 0 : 1;
-                const bool inside = tE == -__builtin_inff();                          // the ray starts inside the block
-                bool enters = !miss && (inside || xe == xo || dda_before(tE, pE, tO, pO)) && (inside || tE < ra.tMax);
-                enters = enters && dda_before(tE, pE, bestT, bestP);                  // (not behind the best candidate so far)
-                if (__ballot(enters) == 0ull) continue;
-                ++coopWalks;
-#if VH_COOP_LDS
-                // the block's 4 KiB into LDS, 64 bytes per lane (one coalesced round trip; the walks then read it at LDS
-                // latency instead of gathering 64 cache lines per step)
-                {
-                    __builtin_amdgcn_wave_barrier();               // (the previous block's walks are done with the buffer)
-                    const float4 *src = reinterpret_cast<const float4 *>(dp.blocks + (size_t)bptr) + lane * 4;
-                    float4 *dst = reinterpret_cast<float4 *>(sh_.block[wave]) + lane * 4;
-                    const float4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-                    dst[0] = v0; dst[1] = v1; dst[2] = v2; dst[3] = v3;
+            // Front to back: a ray that has found its hit skips every block it enters after it, so the blocks behind the
+            // surface are walked only by the rays that missed it (the outcome does not depend on the order: the earliest
+            // arrival wins whichever block is judged first).  Rank = number of smaller words, all distinct.
+            {
+                const int n = nList - listBegin;
+                if (n > 1 && n <= 64) {
+                    const uint32_t mine = lane < n ? list[listBegin + lane] : 0xffffffffu;
+                    int rank = 0;
+                    for (int i = 0; i < n; ++i) rank += (uint32_t)__builtin_amdgcn_readlane((int)mine, i) < mine ? 1 : 0;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < n) list[listBegin + rank] = mine;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
-                const Voxel *blk = sh_.block[wave];
-#endif
-                if (!enters) continue;
-                // the voxel the ray enters at
-                int q[3];
+            }
+            if (ra.stamps) { stampB = __builtin_amdgcn_s_memrealtime(); coopList = nList; }
+            // ---- 3. every ray against every new block of the list ----
+            // (a wave-uniform loop: the block's key and voxel pointer are scalars.  Measured alternative: every ray walking
+            // its OWN blocks, one per round -- the busiest ray of a wave enters as many blocks as the wave walks, 2.1 vs 2.2
+            // rounds, and the per-lane block pointer made it 44.7 us against 40.2)
+            {
+                for (int i = listBegin; i < nList; ++i) {
+                    if (__ballot(!final_) == 0ull) break;
+                    const int slot = __builtin_amdgcn_readfirstlane((int)(list[i] & 0xffffu));
+                    const uint32_t tg = (uint32_t)__builtin_amdgcn_readfirstlane((int)tags[slot]) - 1u;
+                    const int bptr = __builtin_amdgcn_readfirstlane((int)ptrs[slot]);
+                    const int kk[3] = {base0 + (int)(tg & 1023u), base1 + (int)((tg >> 10) & 1023u), base2 + (int)(tg >> 20)};
+                    const CoopEntry e = coop_entry(ax, c, kk, ra.tMax);
+                    const float tE = e.tE;
+                    const int pE = e.pE, xe = e.xe;
+                    const bool inside = e.inside;
+                    const bool enters = e.enters && !final_ && dda_before(tE, pE, bestT, bestP);      // (not behind the best candidate so far)
+                    if (__ballot(enters) == 0ull) continue;
+                    ++coopWalks;
+                    if (!enters) continue;
+                    // the voxel the ray enters at
+                    int q[3];
 #pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    const int lo = kk[a] << 3, hi = lo + 7;
-                    const int nearC = ax[a].s > 0 ? lo : hi, farC = ax[a].s > 0 ? hi : lo;
-                    if (inside || ax[a].invE == 0.0f) q[a] = c[a];
-                    else if (a == xe) q[a] = nearC;
-                    else q[a] = dda_advance(ax[a], prio[a], startIn[a] ? c[a] : nearC, farC, tE, pE);
-                }
-#if VH_COOP_LDS
-                float tn0 = dda_tnext(ax[0], q[0]), tn1 = dda_tnext(ax[1], q[1]), tn2 = dda_tnext(ax[2], q[2]);
-                float tArr = tE;
-                int pArr = pE;
-                bool pv = false, firstVoxel = !inside;
-                float ps = 0.0f;
-                int p0 = 0, p1 = 0, p2 = 0;
-                for (;;) {
-                    const Voxel sv = blk[((q[2] & 7) << 6) | ((q[1] & 7) << 3) | (q[0] & 7)];
-                    const bool valid = sv.weight > 0.0f;
-                    if (valid && sv.sdf <= 0.0f) {
-                        if (firstVoxel) {
-                            // the voxel the ray was in before the entry event: one step back on the entry axis, in the
-                            // neighbouring block -- allocated iff it is in the wave's set
-                            const int n0 = q[0] - (xe == 0 ? ax[0].s : 0), n1 = q[1] - (xe == 1 ? ax[1].s : 0), n2 = q[2] - (xe == 2 ? ax[2].s : 0);
-                            const int fs = coop_find(tags, coop_tag((n0 >> 3) - base0, (n1 >> 3) - base1, (n2 >> 3) - base2));
-                            pv = false;
-                            if (fs >= 0) {
-                                const uint32_t np = ptrs[fs];
-                                if (np != (uint32_t)VH_FREE_BLOCK && np != kCoopUnresolved) {
-                                    const Voxel nb = dp.blocks[(size_t)np + (size_t)(((n2 & 7) << 6) | ((n1 & 7) << 3) | (n0 & 7))];
-                                    pv = nb.weight > 0.0f; ps = nb.sdf; p0 = n0; p1 = n1; p2 = n2;
-                                }
+                    for (int a = 0; a < 3; ++a) {
+                        const int lo = kk[a] << 3, hi = lo + 7;
+                        const int nearC = ax[a].s > 0 ? lo : hi, farC = ax[a].s > 0 ? hi : lo;
+                        if (inside || ax[a].invE == 0.0f) q[a] = c[a];
+                        else if (a == xe) q[a] = nearC;
+                        else q[a] = dda_advance(ax[a], prio[a], e.startIn[a] ? c[a] : nearC, farC, tE, pE);
+                    }
+                    // Inside the block the walk keeps the voxel as float coordinates (exact below 2^24: the host refuses views
+                    // beyond 2^23), the local position as three 5-bit fields (value 8..15 = inside: ONE mask test tells when the
+                    // ray has left the block) packed with the linear voxel index, and steps all of it without a branch:
+                    // ~27 vector instructions per voxel instead of ~45 with integer coordinates and per-axis branches.
+                    const int bx0 = kk[0] << 3, by0 = kk[1] << 3, bz0 = kk[2] << 3;
+                    int pl;
+                    {
+                        const int lx = q[0] & 7, ly = q[1] & 7, lz = q[2] & 7;
+                        pl = ((lx | (ly << 3) | (lz << 6)) << 16) | (lx + 8) | ((ly + 8) << 5) | ((lz + 8) << 10);
+                    }
+                    float fc0 = (float)q[0], fc1 = (float)q[1], fc2 = (float)q[2];
+                    float tn0 = (fc0 - gs0) * ie0, tn1 = (fc1 - gs1) * ie1, tn2 = (fc2 - gs2) * ie2;
+                    float tArr = tE;
+                    int pArr = pE;
+                    bool pv = false, firstVoxel = !inside, walking = true;
+                    float ps = 0.0f;
+                    int prevLin = -1, p0 = 0, p1 = 0, p2 = 0;     // the previous sample: a voxel of this block (prevLin) or the neighbour (p0..2)
+                    const Voxel *blk = dp.blocks + (size_t)bptr;
+                    while (walking) {
+                        int pls[kCoopK], vp[kCoopK];
+                        float vt[kCoopK];
+                        Voxel vv[kCoopK];
+                        int n = 0;
+                        bool more = true;
+#pragma unroll
+                        for (int j = 0; j < kCoopK; ++j) {
+                            if (more) {
+                                pls[j] = pl; vt[j] = tArr; vp[j] = pArr;
+                                vv[j] = blk[(uint32_t)pl >> 16];
+                                n = j + 1;
+                                // the crossing that ends this voxel (raycastSDF.frag:156-170)
+                                const bool m0 = tn0 < tn1 && tn0 < tn2;
+                                const bool m2 = !m0 && tn2 < tn1;
+                                const bool m1 = !m0 && !m2;
+                                tArr = m0 ? tn0 : m2 ? tn2 : tn1;
+                                pArr = m0 ? 2 : m2 ? 1 : 0;
+                                pl += m0 ? d0 : m2 ? d2 : d1;
+                                fc0 += m0 ? f0 : 0.0f; fc1 += m1 ? f1 : 0.0f; fc2 += m2 ? f2 : 0.0f;
+                                tn0 = (fc0 - gs0) * ie0; tn1 = (fc1 - gs1) * ie1; tn2 = (fc2 - gs2) * ie2;
+                                more = tArr < ra.tMax && (pl & 0x6318) == 0x2108;     // (a voxel is visited iff the ray arrives before t_max)
                             }
                         }
-                        if (pv && ps > 0.0f) {
-                            if (dda_before(tArr, pArr, bestT, bestP)) {
-                                bestT = tArr; bestP = pArr;
-                                // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
-                                const float tc = ((ra.zrow[0] * (float)q[0] + ra.zrow[1] * (float)q[1]) + ra.zrow[2] * (float)q[2]) + ra.zrow[3];
-                                const float tp = ((ra.zrow[0] * (float)p0 + ra.zrow[1] * (float)p1) + ra.zrow[2] * (float)p2) + ra.zrow[3];
-                                hit = tp + ((tc - tp) * ps) / (ps - sv.sdf);
-                                found = true;
-                                hx = q[0]; hy = q[1]; hz = q[2]; hptr = bptr;
-                            }
-                            break;                                   // (the block's first pair: nothing earlier behind it)
-                        }
-                    }
-                    pv = valid; ps = sv.sdf; p0 = q[0]; p1 = q[1]; p2 = q[2];
-                    firstVoxel = false;
-                    // the crossing that ends this voxel (raycastSDF.frag:156-170)
-                    const bool m0 = tn0 < tn1 && tn0 < tn2;
-                    const bool m2 = !m0 && tn2 < tn1;
-                    tArr = m0 ? tn0 : m2 ? tn2 : tn1;
-                    pArr = m0 ? 2 : m2 ? 1 : 0;
-                    // (one recomputed crossing time, selected in and out: no three-way branch)
-                    const int sa = m0 ? ax[0].s : m2 ? ax[2].s : ax[1].s;
-                    const int qa = (m0 ? q[0] : m2 ? q[2] : q[1]) + sa;
-                    const float gsa = m0 ? ax[0].Gs : m2 ? ax[2].Gs : ax[1].Gs, iea = m0 ? ax[0].invE : m2 ? ax[2].invE : ax[1].invE;
-                    const float tnew = ((float)qa - gsa) * iea;
-                    q[0] = m0 ? qa : q[0]; q[2] = m2 ? qa : q[2]; q[1] = (m0 || m2) ? q[1] : qa;
-                    tn0 = m0 ? tnew : tn0; tn2 = m2 ? tnew : tn2; tn1 = (m0 || m2) ? tn1 : tnew;
-                    if (!(tArr < ra.tMax) || ((qa >> 3) != (m0 ? kk[0] : m2 ? kk[2] : kk[1]))) break;   // (visited iff the ray arrives before t_max)
-                }
-            #else
-                // Inside the block the walk keeps the voxel as float coordinates (exact below 2^24: the host refuses views
-                // beyond 2^23), the local position as three 5-bit fields (value 8..15 = inside: ONE mask test tells when the
-                // ray has left the block) packed with the linear voxel index, and steps all of it without a branch:
-                // ~27 vector instructions per voxel instead of ~45 with integer coordinates and per-axis branches.
-                const int bx0 = kk[0] << 3, by0 = kk[1] << 3, bz0 = kk[2] << 3;
-                int pl;
-                {
-                    const int lx = q[0] & 7, ly = q[1] & 7, lz = q[2] & 7;
-                    pl = ((lx | (ly << 3) | (lz << 6)) << 16) | (lx + 8) | ((ly + 8) << 5) | ((lz + 8) << 10);
-                }
-                float fc0 = (float)q[0], fc1 = (float)q[1], fc2 = (float)q[2];
-                const float f0 = (float)ax[0].s, f1 = (float)ax[1].s, f2 = (float)ax[2].s;
-                // (an axis that never steps: invE = 0 would give a crossing time of 0; (c + 1e30) * inf = inf instead)
-                const float ie0 = ax[0].invE != 0.0f ? ax[0].invE : __builtin_inff(), gs0 = ax[0].invE != 0.0f ? ax[0].Gs : -1.0e30f;
-                const float ie1 = ax[1].invE != 0.0f ? ax[1].invE : __builtin_inff(), gs1 = ax[1].invE != 0.0f ? ax[1].Gs : -1.0e30f;
-                const float ie2 = ax[2].invE != 0.0f ? ax[2].invE : __builtin_inff(), gs2 = ax[2].invE != 0.0f ? ax[2].Gs : -1.0e30f;
-                const int d0 = ax[0].s * ((1 << 16) + 1), d1 = ax[1].s * ((8 << 16) + (1 << 5)), d2 = ax[2].s * ((64 << 16) + (1 << 10));
-                float tn0 = (fc0 - gs0) * ie0, tn1 = (fc1 - gs1) * ie1, tn2 = (fc2 - gs2) * ie2;
-                float tArr = tE;
-                int pArr = pE;
-                bool pv = false, firstVoxel = !inside, walking = true;
-                float ps = 0.0f;
-                int prevLin = -1, p0 = 0, p1 = 0, p2 = 0;     // the previous sample: a voxel of this block (prevLin) or the neighbour (p0..2)
-                while (walking) {
-                    int pls[kCoopK], vp[kCoopK];
-                    float vt[kCoopK];
-                    Voxel vv[kCoopK];
-                    int n = 0;
-                    bool more = true;
+                        walking = more;
 #pragma unroll
-                    for (int j = 0; j < kCoopK; ++j) {
-                        if (more) {
-                            pls[j] = pl; vt[j] = tArr; vp[j] = pArr;
-                            vv[j] = dp.blocks[(size_t)bptr + (size_t)((uint32_t)pl >> 16)];
-                            n = j + 1;
-                            // the crossing that ends this voxel (raycastSDF.frag:156-170)
-                            const bool m0 = tn0 < tn1 && tn0 < tn2;
-                            const bool m2 = !m0 && tn2 < tn1;
-                            const bool m1 = !m0 && !m2;
-                            tArr = m0 ? tn0 : m2 ? tn2 : tn1;
-                            pArr = m0 ? 2 : m2 ? 1 : 0;
-                            pl += m0 ? d0 : m2 ? d2 : d1;
-                            fc0 += m0 ? f0 : 0.0f; fc1 += m1 ? f1 : 0.0f; fc2 += m2 ? f2 : 0.0f;
-                            tn0 = (fc0 - gs0) * ie0; tn1 = (fc1 - gs1) * ie1; tn2 = (fc2 - gs2) * ie2;
-                            more = tArr < ra.tMax && (pl & 0x6318) == 0x2108;     // (a voxel is visited iff the ray arrives before t_max)
-                        }
-                    }
-                    walking = more;
-#pragma unroll
-                    for (int j = 0; j < kCoopK; ++j) {
-                        if (j < n) {
-                            const bool valid = vv[j].weight > 0.0f;
-                            const int lin = (int)((uint32_t)pls[j] >> 16);
-                            if (valid && vv[j].sdf <= 0.0f) {
-                                const int vx = bx0 + (lin & 7), vy = by0 + ((lin >> 3) & 7), vz = bz0 + (lin >> 6);
-                                if (firstVoxel) {
-                                    // the voxel the ray was in before the entry event: one step back on the entry axis, in the
-                                    // neighbouring block -- allocated iff it is in the wave's set
-                                    const int n0 = vx - (xe == 0 ? ax[0].s : 0), n1 = vy - (xe == 1 ? ax[1].s : 0), n2 = vz - (xe == 2 ? ax[2].s : 0);
-                                    const int fs = coop_find(tags, coop_tag((n0 >> 3) - base0, (n1 >> 3) - base1, (n2 >> 3) - base2));
-                                    pv = false;
-                                    if (fs >= 0) {
-                                        const uint32_t np = ptrs[fs];
-                                        if (np != (uint32_t)VH_FREE_BLOCK && np != kCoopUnresolved) {
-                                            const Voxel nb = dp.blocks[(size_t)np + (size_t)(((n2 & 7) << 6) | ((n1 & 7) << 3) | (n0 & 7))];
-                                            pv = nb.weight > 0.0f; ps = nb.sdf; p0 = n0; p1 = n1; p2 = n2; prevLin = -1;
+                        for (int j = 0; j < kCoopK; ++j) {
+                            if (j < n) {
+                                const bool valid = vv[j].weight > 0.0f;
+                                const int lin = (int)((uint32_t)pls[j] >> 16);
+                                if (valid && vv[j].sdf <= 0.0f) {
+                                    const int vx = bx0 + (lin & 7), vy = by0 + ((lin >> 3) & 7), vz = bz0 + (lin >> 6);
+                                    if (firstVoxel) {
+                                        // the voxel the ray was in before the entry event: one step back on the entry axis, in the
+                                        // neighbouring block -- allocated iff it is in the wave's set
+                                        const int n0 = vx - (xe == 0 ? ax[0].s : 0), n1 = vy - (xe == 1 ? ax[1].s : 0), n2 = vz - (xe == 2 ? ax[2].s : 0);
+                                        const int fs = coop_find(tags, coop_tag((n0 >> 3) - base0, (n1 >> 3) - base1, (n2 >> 3) - base2));
+                                        pv = false;
+                                        if (fs >= 0) {
+                                            const uint32_t np = ptrs[fs];
+                                            if (np != (uint32_t)VH_FREE_BLOCK && np != kCoopUnresolved) {
+                                                const Voxel nb = dp.blocks[(size_t)np + (size_t)(((n2 & 7) << 6) | ((n1 & 7) << 3) | (n0 & 7))];
+                                                pv = nb.weight > 0.0f; ps = nb.sdf; p0 = n0; p1 = n1; p2 = n2; prevLin = -1;
+                                            }
                                         }
                                     }
-                                }
-                                if (pv && ps > 0.0f) {
-                                    if (dda_before(vt[j], vp[j], bestT, bestP)) {
-                                        bestT = vt[j]; bestP = vp[j];
-                                        if (prevLin >= 0) { p0 = bx0 + (prevLin & 7); p1 = by0 + ((prevLin >> 3) & 7); p2 = bz0 + (prevLin >> 6); }
-                                        // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
-                                        const float tc = ((ra.zrow[0] * (float)vx + ra.zrow[1] * (float)vy) + ra.zrow[2] * (float)vz) + ra.zrow[3];
-                                        const float tp = ((ra.zrow[0] * (float)p0 + ra.zrow[1] * (float)p1) + ra.zrow[2] * (float)p2) + ra.zrow[3];
-                                        hit = tp + ((tc - tp) * ps) / (ps - vv[j].sdf);
-                                        found = true;
-                                        hx = vx; hy = vy; hz = vz; hptr = bptr;
+                                    if (pv && ps > 0.0f) {
+                                        if (dda_before(vt[j], vp[j], bestT, bestP)) {
+                                            bestT = vt[j]; bestP = vp[j];
+                                            if (prevLin >= 0) { p0 = bx0 + (prevLin & 7); p1 = by0 + ((prevLin >> 3) & 7); p2 = bz0 + (prevLin >> 6); }
+                                            // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
+                                            const float tc = ((ra.zrow[0] * (float)vx + ra.zrow[1] * (float)vy) + ra.zrow[2] * (float)vz) + ra.zrow[3];
+                                            const float tp = ((ra.zrow[0] * (float)p0 + ra.zrow[1] * (float)p1) + ra.zrow[2] * (float)p2) + ra.zrow[3];
+                                            hit = tp + ((tc - tp) * ps) / (ps - vv[j].sdf);
+                                            found = true;
+                                            hx = vx; hy = vy; hz = vz; hptr = bptr;
+                                        }
+                                        walking = false;                   // (the block's first pair: nothing earlier behind it)
+                                        n = j;                             // (stops the judging)
                                     }
-                                    walking = false;                   // (the block's first pair: nothing earlier behind it)
-                                    n = j;                             // (stops the judging)
                                 }
+                                pv = valid; ps = vv[j].sdf; prevLin = lin;
+                                firstVoxel = false;
                             }
-                            pv = valid; ps = vv[j].sdf; prevLin = lin;
-                            firstVoxel = false;
                         }
                     }
                 }
-            #endif
             }
             // a candidate that arrived before this window's end cannot be beaten by a block found later
             final_ = final_ || bestT < tw + 64.0f * dt2;
@@ -1013,9 +988,9 @@ __global__ __launch_bounds__(256, VH_DDA_WAVES) void raycast_dda_kernel(const Fr
     }
 #undef VH_DDA_TN
     if (ra.stamps && lane == 0) {
-        const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kDdaBlockWaves + wave) * 8;
         ra.stamps[w] = stamp0; ra.stamps[w + 1] = __builtin_amdgcn_s_memrealtime();
-        ra.stamps[w + 2] = (unsigned long long)(ra.budget - budget) | ((unsigned long long)round << 32); ra.stamps[w + 3] = (unsigned long long)(pu | (pv << 16)) | ((stamp1 - stamp0) << 32);
+        ra.stamps[w + 2] = coopDone ? (stampP1 - stamp0) : (unsigned long long)(ra.budget - budget) | ((unsigned long long)round << 32); ra.stamps[w + 3] = (unsigned long long)(pu | (pv << 16)) | ((stamp1 - stamp0) << 32);
         ra.stamps[w + 4] = stampA - stamp0; ra.stamps[w + 5] = stampB - stamp0; ra.stamps[w + 6] = (unsigned long long)coopList; ra.stamps[w + 7] = (unsigned long long)coopWalks;
     }
     if (!inImage) return;
