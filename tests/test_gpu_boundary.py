@@ -64,7 +64,7 @@ def test_ptr_container_layout_and_contents(vh, torch_cuda):
     # upper half is the lock epoch: a bucket that received an entry in the last frame carries it
     h = first // 5
     word = struct.unpack("<Q", _hip_memcpy_d2h(vh, p.d_hashTableBucketMutex + 8 * h, 8))[0]
-    assert 1 <= (word >> 54) <= c["epoch"] == 2            # top 10 bits: the lock epoch
+    assert 1 <= (word >> 55) <= c["epoch"] == 2            # top 9 bits: the lock epoch
     gt.close()
 
 

@@ -75,6 +75,28 @@ def test_collision_stress_pipelined(oracle, vh, torch_cuda):
         assert len(gt.allocated()) == 101
 
 
+@pytest.mark.parametrize("bucket_size", [10, 16])
+def test_wide_buckets_run_pipelined(oracle, vh, torch_cuda, bucket_size):
+    """The claim word names the slot an insertion in flight takes with 4 bits: buckets of up to 16 slots are
+    pipelined (one launch per frame) like the 5-slot ones.  Few buckets, so that insertions land deep in them."""
+    torch = torch_cuda
+    kw = dict(numBuckets=32, bucketSize=bucket_size, numVoxelBlocks=1024)
+    ot = oracle.OracleTable(oracle.default_params(**kw), 640, 480, 0)
+    gt = vh.SDFHashtable(vh.default_params(**kw), 640, 480, 0)
+    gt.set_profiling(True)
+    verts = synth.sphere_inside_scene()
+    d = torch.from_numpy(verts).cuda()
+    for _ in range(4):
+        gt.integrate_batch([I4] * 5, [d] * 5)
+        for _ in range(5):
+            ot.integrate(I4, verts)
+        _compare(ot, gt)
+    times = gt.kernel_times()
+    assert times["frame_pipelined_ms"] > 0.0 and times["frame_commit_integrate_ms"] == 0.0, times
+    slots = np.flatnonzero(gt.hash_table()["ptr"] != -1) % bucket_size          # (VH_FREE_BLOCK)
+    assert slots.max() >= 8                                 # (entries beyond slot 7: the fourth bit is in use)
+
+
 def test_pipeline_option_streaming_and_reused_buffer(oracle, vh, torch_cuda):
     """option "pipeline": plain vh_integrate / vh_integrate_depth calls, ONE device buffer overwritten for
     every frame (the deferred half works from a private copy), observers flush on their own."""
@@ -222,9 +244,9 @@ def test_ragged_empty_and_hostile_frames_pipelined(oracle, vh, torch_cuda, sem):
 
 @pytest.mark.parametrize("pipelined", [0, 1])
 def test_lock_epoch_wrap(oracle, vh, torch_cuda, pipelined):
-    """The claim words carry a 10-bit lock epoch: after 1023 epochs the claim arrays are cleared and the
+    """The claim words carry a 9-bit lock epoch: after 511 epochs the claim arrays are cleared and the
     epoch starts over (vh_reset_mutexes).  2 100 frames with collections that empty the model just before,
-    on and after both wraps, so that insertions happen in the epochs around them; pipelined frames have
+    on and after the wraps, so that insertions happen in the epochs around them; pipelined frames have
     both claim buffers in use when the wrap comes."""
     torch = torch_cuda
     W, H = 160, 120
@@ -234,8 +256,8 @@ def test_lock_epoch_wrap(oracle, vh, torch_cuda, pipelined):
     gt.set_option("pipeline", pipelined)
     frames = room_frames(torch, W, H, (0, 5, 10, 15))
     dv = [torch.from_numpy(np.ascontiguousarray(v)).cuda() for _, v in frames]
-    collect_at = {1010, 1019, 1021, 1023, 1026, 2040, 2044, 2047, 2050}
-    check_at = {1018, 1024, 1030, 2046, 2052, 2099}
+    collect_at = {500, 506, 508, 510, 512, 515, 1010, 1015, 1019, 1021, 1023, 1026, 2030, 2036, 2040, 2044, 2047, 2050}
+    check_at = {507, 513, 520, 1018, 1024, 1030, 2038, 2046, 2052, 2099}
     inserted_near_wrap = 0
     for f in range(2100):
         k = f % 4

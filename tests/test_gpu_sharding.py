@@ -333,8 +333,8 @@ def entries_as_set_(entries):
 
 
 def test_one_launch_multi_camera_frames_across_the_epoch_wrap(oracle, vh, torch_cuda):
-    """The claim words carry a 10-bit lock epoch; at the wrap they are cleared -- which the frame whose deferred half is
-    still pending must not see: 1 040 multi-camera frames (one shard, batches of 8) straddle the wrap at frame 1 023."""
+    """The claim words carry a 9-bit lock epoch; at the wrap they are cleared -- which the frame whose deferred half is
+    still pending must not see: 1 040 multi-camera frames (one shard, batches of 8) straddle the wraps at frames 511 and 1 022."""
     torch = torch_cuda
     kw = dict(numBuckets=1 << 10, numVoxelBlocks=4096)            # (a heap that never runs dry: 1 024 blocks did)
     w, h = 64, 48

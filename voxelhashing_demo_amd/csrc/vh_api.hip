@@ -88,7 +88,7 @@ struct vh_context {
     int flattenVariant = 3;
     uint32_t candAllocated = 0;    // records the candidate buffer holds (dp.candCapacity <= this)
     uint32_t allocEpoch = 0;       // lock epoch (epochTotal) of the last allocBlocks (overflow list: one per epoch)
-    uint32_t epochTotal = 0;       // lock epochs since creation (fp.epoch is the 10-bit epoch of the claim words)
+    uint32_t epochTotal = 0;       // lock epochs since creation (fp.epoch is the 9-bit epoch of the claim words)
     // pipelined frames (option "pipeline", vh_integrate_batch; vh_frame.hip)
     float *fusedPlane = nullptr;   // packed camera-z plane launch 1 of the two-launch frame leaves for launch 2 (large images)
     int pipeline = 0;

@@ -244,7 +244,7 @@ static bool pipeline_applies(const vh_context *c)
 {
     return c->pipeline && c->fusedFrame && (c->flattenVariant == kWalkStridedBallot || c->flattenVariant == kWalkIndexed) &&
            !(c->fp.flags & kFlagOverflow) &&
-           c->fp.bucketSize <= 8u && !c->viewBlocks;
+           c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks;
 }
 
 // One launch: {claim || walk} of the new frame (in != nullptr) and {commit + integrate} of the pending one.

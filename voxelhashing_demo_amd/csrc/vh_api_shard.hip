@@ -350,8 +350,8 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
     const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
     // One launch per multi-camera frame (frame_multi_pipelined_kernel, vh_shard.hip): the commit + TSDF update of frame
     // b ride in the launch of frame b+1, a last launch serves the batch's last frame: B + 1 launches instead of 2 B.
-    // Same conditions as the single-camera pipeline (no overflow list, bucketSize <= 8, not a view table).
-    if (c->pipelineShards && !(c->fp.flags & kFlagOverflow) && c->fp.bucketSize <= 8u && !c->viewBlocks) {
+    // Same conditions as the single-camera pipeline (no overflow list, bucketSize <= 16, not a view table).
+    if (c->pipelineShards && !(c->fp.flags & kFlagOverflow) && c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks) {
         int rc = ensure_pipeline_buffers(c);
         if (rc != VH_OK) return rc;
         if (!c->maskBuf2) VH_HIP(hipMalloc((void **)&c->maskBuf2, sizeof(uint32_t) * c->numEntries));

@@ -256,24 +256,26 @@ __device__ __forceinline__ uint32_t launch_rank(int x, int y, int width)
 // been served the word is replaced by the epoch's largest value, so the bucket stays locked for the
 // rest of the epoch even if allocBlocks runs again before the next reset (the reference's mutex is
 // never released within a frame).
-constexpr uint32_t kMaxClaimEpoch = 1023u;
-constexpr uint32_t kClaimSlotBits = 19, kClaimFBits = 3;
+// Layout: epoch 9 bits | 0xfffffffe - rank 32 bits | f 4 bits (buckets of up to 16 slots) | slot 19 bits.
+constexpr uint32_t kClaimSlotBits = 19, kClaimFBits = 4, kClaimRankShift = kClaimSlotBits + kClaimFBits, kClaimEpochShift = kClaimRankShift + 32;
+constexpr uint32_t kMaxClaimEpoch = (1u << (64 - kClaimEpochShift)) - 1u;      // 511: after that many epochs the words are cleared
 constexpr uint32_t kMaxCandidates = (1u << kClaimSlotBits) - 1u;      // candidate records per lock epoch
+constexpr uint32_t kMaxPipelinedBucket = 1u << kClaimFBits;           // f must name every slot of the bucket
 
 __device__ __forceinline__ unsigned long long claim_word(uint32_t epoch, uint32_t rank, uint32_t f, uint32_t slot)
 {
-    return ((unsigned long long)epoch << 54) | ((unsigned long long)(0xfffffffeu - rank) << 22) |
-           ((unsigned long long)(f & 7u) << kClaimSlotBits) | (unsigned long long)slot;
+    return ((unsigned long long)epoch << kClaimEpochShift) | ((unsigned long long)(0xfffffffeu - rank) << kClaimRankShift) |
+           ((unsigned long long)(f & (kMaxPipelinedBucket - 1u)) << kClaimSlotBits) | (unsigned long long)slot;
 }
 
 __device__ __forceinline__ unsigned long long consumed_word(uint32_t epoch)
 {
-    return ((unsigned long long)epoch << 54) | 0x3fffffffffffffull;
+    return ((unsigned long long)epoch << kClaimEpochShift) | ((1ull << kClaimEpochShift) - 1ull);
 }
 
-__device__ __forceinline__ uint32_t claim_epoch(unsigned long long w) { return (uint32_t)(w >> 54); }
+__device__ __forceinline__ uint32_t claim_epoch(unsigned long long w) { return (uint32_t)(w >> kClaimEpochShift); }
 __device__ __forceinline__ uint32_t claim_slot(unsigned long long w) { return (uint32_t)w & kMaxCandidates; }
-__device__ __forceinline__ uint32_t claim_f(unsigned long long w) { return (uint32_t)(w >> kClaimSlotBits) & 7u; }
+__device__ __forceinline__ uint32_t claim_f(unsigned long long w) { return (uint32_t)(w >> kClaimSlotBits) & (kMaxPipelinedBucket - 1u); }
 
 // ---- overflow list (kFlagOverflow) -------------------------------------------------------------
 // The entries of one home bucket that did not fit its slots form a chain that starts in the bucket's
