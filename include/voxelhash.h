@@ -251,7 +251,7 @@ int vh_integrate_depth(vh_context *ctx, const float pose[16], const uint16_t *d_
  * the unpipelined calls.  Results equal the unpipelined frames bit for bit, with one documented
  * difference: a frame whose new blocks outnumber the free blocks of the heap allocates none of them
  * (they count as heap_exhausted and retry), where vh_integrate serves as many as there are blocks.
- * Not combined with "overflow_list", bucketSize > 8 or the persistent walk (flatten_variant 5): those frames run
+ * Not combined with "overflow_list", bucketSize > 16 or the persistent walk (flatten_variant 5): those frames run
  * unpipelined.  vh_integrate_batch / vh_integrate_depth_batch: `count` frames (poses: count*16 host
  * floats; d_verts / d_normals / d_depth: host arrays of `count` device pointers, d_normals may be NULL)
  * in count + 1 launches -- the pipeline switched on for the call and flushed at its end. */
@@ -373,9 +373,16 @@ int vh_integrate_packets(vh_context *ctx, int32_t num_cams, const float *d_packe
  * vh_generate_keys_batch: poses = batch*16 host floats, d_verts = host array of `batch`
  * device pointers; the packets written are this camera's (d_packets[b*packet_frame_stride]).
  * vh_apply_frames_batch: for b = 0..batch-1: new lock epoch, insert the num_bins bins of
- * frame b, walk + TSDF update for the num_cams packets of frame b -- two launches per frame
- * ({claim || walk}, {commit + integrate}); equals vh_reset_mutexes + vh_insert_bins +
- * vh_integrate_packets per frame. */
+ * frame b, walk + TSDF update for the num_cams packets of frame b; equals vh_reset_mutexes +
+ * vh_insert_bins + vh_integrate_packets per frame.  Launches, option "pipeline_shards":
+ *   1 (default) one launch per frame ({claim || walk} of frame b with {commit + TSDF update} of frame
+ *               b-1) plus one for the batch's last frame: batch + 1;
+ *   2           that last half stays pending and rides in the first launch of the NEXT call (batch
+ *               launches per call); it is launched by vh_flush and by every call that reads or changes the
+ *               model, like a pipelined single-camera frame.  The packets of the batch's LAST frame must
+ *               stay valid and unchanged until then (vh_dist_* keeps three buffer sets for this);
+ *   0           two launches per frame ({claim || walk}, {commit + integrate}).
+ * Tables with "overflow_list", bucketSize > 16 or a view table always take two launches per frame. */
 int vh_generate_keys_batch(vh_context *ctx, int32_t batch, const float *poses,
                            const vh_float4 *const *d_verts, uint32_t camera_id, int32_t num_shards,
                            int32_t *d_bins, int32_t capacity, int32_t bin_stride, int32_t frame_stride,

@@ -274,8 +274,8 @@ def test_two_processes_on_one_gpu(oracle, vh, torch_cuda, sensor):
 
 def test_one_launch_multi_camera_frames(oracle, vh, torch_cuda):
     """vh_apply_frames_batch runs a batch of B multi-camera frames as B + 1 launches (frame_multi_pipelined_kernel: the
-    commit + TSDF update of frame b ride in the launch of frame b + 1; option "pipeline_shards", on by default) or as 2 B
-    (option off).  Same frames through both on two shards: the same tables, equal to the slices of ONE oracle table --
+    commit + TSDF update of frame b ride in the launch of frame b + 1; option "pipeline_shards", on by default), as B
+    (option 2: the last frame's half rides in the first launch of the next batch) or as 2 B (option off).  Same frames through both on two shards: the same tables, equal to the slices of ONE oracle table --
     with batches of 1, 2 and 5, new blocks in every frame (the cameras move), a collection in between and single-camera
     pipelined frames on the same contexts before and after (the two pipelines share their buffers and counter sets)."""
     torch = torch_cuda
@@ -283,7 +283,8 @@ def test_one_launch_multi_camera_frames(oracle, vh, torch_cuda):
     plan = vdist.ShardPlan(KW["numBuckets"], world)
     full = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
     runs = {}
-    for mode in (1, 0):
+    keep = []            # (pipeline_shards 2: the last frame's packets stay valid until the next call or flush)
+    for mode in (1, 0, 2):
         shards = [vdist.HipShard(vh.default_params(**KW), W, H, 1, plan, r, W * H // 4, batch=5) for r in range(world)]
         for sh in shards:
             sh.table.set_option("pipeline_shards", mode)
@@ -301,6 +302,7 @@ def test_one_launch_multi_camera_frames(oracle, vh, torch_cuda):
                 s2.batch = batch
                 s2.bins_send, s2.bins_recv = sh.bins_send[:, :batch].contiguous(), sh.bins_recv[:, :batch].contiguous()
                 s2.packet, s2.packets = sh.packet[:batch].contiguous(), sh.packets[:, :batch].contiguous()
+            keep.append(sub)
             vdist.loopback_step(sub, [[frames[b][r][0] for b in range(batch)] for r in range(world)],
                                 [[torch.from_numpy(frames[b][r][1]).cuda() for b in range(batch)] for r in range(world)])
             if mode == 1:
@@ -319,9 +321,10 @@ def test_one_launch_multi_camera_frames(oracle, vh, torch_cuda):
     for r in range(world):
         lo, hi = plan.bucket_range(r)
         total += check_shard_against_full(runs[1][r].table, full, lo, hi, 5)
-        check_shard_against_full(runs[0][r].table, full, lo, hi, 5)
-        assert runs[1][r].table.counters()["occupied"] == runs[0][r].table.counters()["occupied"]
-        assert entries_as_set_(runs[1][r].table.compact()) == entries_as_set_(runs[0][r].table.compact())
+        for other in (0, 2):
+            check_shard_against_full(runs[other][r].table, full, lo, hi, 5)
+            assert runs[1][r].table.counters()["occupied"] == runs[other][r].table.counters()["occupied"]
+            assert entries_as_set_(runs[1][r].table.compact()) == entries_as_set_(runs[other][r].table.compact())
     assert total == len(full.allocated()) > 100
     for m in runs:
         for sh in runs[m]:

@@ -56,6 +56,15 @@ struct TimedLaunch {
     hipEvent_t start, stop;
 };
 
+struct MultiPending {
+    bool active = false;
+    uint32_t epochOld = 0;
+    const float *packetsOld = nullptr;     // the caller's packets of that frame: valid until the half has been launched
+    size_t packetStride = 0;
+    int32_t numCams = 0;
+    int packetFormat = 0;
+};
+
 struct vh_context {
     HashTableParams params;
     FrameParams fp;
@@ -105,7 +114,9 @@ struct vh_context {
     VoxelEntry *compactBuf[2] = {nullptr, nullptr};
     uint32_t *maskBuf2 = nullptr;          // pipelined multi-camera frames: the camera masks of the second compact buffer
     int debugSkipRoles = 0;                // diagnostics: roles of the pipelined launch that return at once (timing only; the model is wrong)
-    int pipelineShards = 1;                // option "pipeline_shards": vh_apply_frames_batch runs a batch of B multi-camera frames as B + 1 launches
+    int pipelineShards = 1;                // option "pipeline_shards": vh_apply_frames_batch runs a batch of B multi-camera frames as B + 1 launches (1) or B (2: the last frame's half stays pending across calls)
+    MultiPending multiPend;                // the multi-camera frame whose commit + TSDF update have not been launched yet
+    void *multiFirstEvent = nullptr;       // hipEvent_t recorded behind the first launch of every vh_apply_frames_batch (vh_dist: the previous batch's packets are free)
     VoxelEntry *compactHome = nullptr;     // the compact buffer of creation: what PtrContainer names, where settle() leaves the dense list
     float *planeBuf[2] = {nullptr, nullptr};
     uint16_t *rawBuf[2] = {nullptr, nullptr};
@@ -242,6 +253,8 @@ static void default_projection(vh_context *c)
 }
 
 static int flush_pending(vh_context *c);       // vh_api_frame.hip: launches a pipelined frame's deferred half
+static int flush_single_pending(vh_context *c);
+static int flush_multi_pending(vh_context *c);     // vh_api_shard.hip: the same for a multi-camera frame (pipeline_shards 2)
 static int settle(vh_context *c);              // ... and folds a two-ended compact list into the dense one (observers)
 
 static int free_buffers(vh_context *c)

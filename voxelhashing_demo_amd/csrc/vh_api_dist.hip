@@ -95,11 +95,15 @@ struct vh_dist {
     int capacity = 0;                      // records per key bin
     size_t packetUnits = 0;                // 4-byte units of one camera packet
     hipStream_t sGen = nullptr, sComm = nullptr, sTable = nullptr;
-    hipEvent_t generated[2] = {nullptr, nullptr}, ready[2] = {nullptr, nullptr}, applied[2] = {nullptr, nullptr};
+    // Three buffer sets: while exchange n travels into one, the frames of exchange n-1 are applied from the second, and the
+    // last frame of exchange n-2 -- whose commit + TSDF update ride in the first launch of n-1's frames (pipeline_shards 2) --
+    // still reads its packets in the third.
+    static constexpr int kSets = 3;
+    hipEvent_t generated[kSets] = {}, ready[kSets] = {}, first[kSets] = {};     // first: behind the first launch of the set's frames
     struct Set {
         int32_t *binsSend = nullptr, *binsRecv = nullptr;      // [world][batch][capacity][4]
         float *packet = nullptr, *packets = nullptr;          // [batch][P], [world][batch][P]
-    } set[2];
+    } set[kSets];
     uint64_t count = 0;                    // exchanges fed
     int pending = -1;                      // buffer set whose exchange is in flight / landed but not applied
     // raycast round
@@ -126,8 +130,8 @@ static void dist_free(vh_dist *d)
     }
     for (void *p : {(void *)d->poseMine, (void *)d->poseAll, (void *)d->viewSend, (void *)d->viewRecv, (void *)d->viewCounts})
         if (p) (void)hipFree(p);
-    for (int i = 0; i < 2; ++i)
-        for (hipEvent_t e : {d->generated[i], d->ready[i], d->applied[i]})
+    for (int i = 0; i < vh_dist::kSets; ++i)
+        for (hipEvent_t e : {d->generated[i], d->ready[i], d->first[i]})
             if (e) (void)hipEventDestroy(e);
     if (d->comm && d->ownComm && g_rccl.commDestroy) (void)g_rccl.commDestroy(d->comm);
     for (hipStream_t s : {d->sGen, d->sComm, d->sTable})
@@ -187,8 +191,8 @@ extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_I
         }                                                                                            \
     } while (0)
     for (hipStream_t *s : {&d->sGen, &d->sComm, &d->sTable}) VH_DIST_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-        for (hipEvent_t *e : {&d->generated[i], &d->ready[i], &d->applied[i]}) VH_DIST_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (int i = 0; i < vh_dist::kSets; ++i) {
+        for (hipEvent_t *e : {&d->generated[i], &d->ready[i], &d->first[i]}) VH_DIST_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
         VH_DIST_TRY(hipMalloc((void **)&d->set[i].binsSend, binBytes));
         VH_DIST_TRY(hipMalloc((void **)&d->set[i].binsRecv, binBytes));
         VH_DIST_TRY(hipMalloc((void **)&d->set[i].packet, pkBytes));
@@ -208,6 +212,7 @@ extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_I
         d->ownComm = true;
     }
     d->shard->stream = d->sTable;
+    d->shard->pipelineShards = 2;          // a batch's last frame rides in the first launch of the next batch
     *out = d;
     return VH_OK;
 }
@@ -224,11 +229,11 @@ static int dist_apply(vh_dist *d, int s)
 {
     VH_HIP(hipStreamWaitEvent(d->sTable, d->ready[s], 0));
     d->shard->stream = d->sTable;
+    d->shard->multiFirstEvent = d->first[s];
     const int rc = vh_apply_frames_batch(d->shard, d->cfg.batch, d->set[s].binsRecv, d->cfg.world, d->capacity, 0, 0, d->cfg.world,
                                          d->set[s].packets, 0, 0);
-    if (rc != VH_OK) return rc;
-    VH_HIP(hipEventRecord(d->applied[s], d->sTable));
-    return VH_OK;
+    d->shard->multiFirstEvent = nullptr;
+    return rc;
 }
 
 extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *const *d_frames)
@@ -236,13 +241,13 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     if (!d || !poses || !d_frames) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     const auto t0 = std::chrono::steady_clock::now();
     DeviceGuard guard(d->device);
-    const int s = (int)(d->count & 1u);
+    const int s = (int)(d->count % vh_dist::kSets);
     const int B = d->cfg.batch, R = d->cfg.world;
     vh_dist::Set &set = d->set[s];
     int rc;
     // generate: keys binned by owner + this camera's packets.  The set's send buffers were last read by the collectives
-    // of exchange count-2.
-    if (d->count >= 2) VH_HIP(hipStreamWaitEvent(d->sGen, d->ready[s], 0));
+    // of exchange count-3.
+    if (d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sGen, d->ready[s], 0));
     d->shard->stream = d->sGen;
     if (d->cfg.packet_format == VH_PACKET_U16)
         rc = vh_generate_keys_depth_batch(d->shard, B, poses, reinterpret_cast<const uint16_t *const *>(d_frames), d->cfg.k_inv,
@@ -253,9 +258,10 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     d->shard->stream = d->sTable;
     if (rc != VH_OK) return rc;
     VH_HIP(hipEventRecord(d->generated[s], d->sGen));
-    // exchange: the receive buffers of this set were last consumed by the application of exchange count-2
+    // exchange: the receive buffers of this set were last read by the frames of exchange count-3, the last of which rode in
+    // the first launch of exchange count-2's frames (queued by the previous call)
     VH_HIP(hipStreamWaitEvent(d->sComm, d->generated[s], 0));
-    if (d->count >= 2) VH_HIP(hipStreamWaitEvent(d->sComm, d->applied[s], 0));
+    if (d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sComm, d->first[(s + 1) % vh_dist::kSets], 0));
     VH_RCCL(g_rccl.allToAll(set.binsSend, set.binsRecv, (size_t)B * d->capacity * 4, ncclInt32, d->comm, d->sComm));
     VH_RCCL(g_rccl.allGather(set.packet, set.packets, (size_t)B * d->packetUnits, ncclFloat32, d->comm, d->sComm));
     VH_HIP(hipEventRecord(d->ready[s], d->sComm));
@@ -277,6 +283,7 @@ extern "C" int vh_dist_flush(vh_dist *d)
         if (rc != VH_OK) return rc;
         d->pending = -1;
     }
+    { const int rc = flush_pending(d->shard); if (rc != VH_OK) return rc; }      // the last frame's deferred half
     VH_HIP(hipStreamSynchronize(d->sTable));
     VH_HIP(hipStreamSynchronize(d->sComm));
     VH_HIP(hipStreamSynchronize(d->sGen));

@@ -306,13 +306,20 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     return VH_OK;
 }
 
-static int flush_pending(vh_context *c)
+static int flush_single_pending(vh_context *c)
 {
     if (!c->pipePending) return VH_OK;
     const int rc = launch_pipelined<VertexMap>(c, nullptr, 0, nullptr);
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());
     return VH_OK;
+}
+
+// (at most one of the two is pending: every entry point that starts a frame of one kind flushes the other)
+static int flush_pending(vh_context *c)
+{
+    const int rc = flush_single_pending(c);
+    return rc != VH_OK ? rc : flush_multi_pending(c);
 }
 
 // For whoever looks at the compact list from outside a frame (download, device pointers, the step-level TSDF

@@ -397,7 +397,12 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     }
     if (std::strcmp(name, "pipe_integrate_grid") == 0 && value > 0) { c->pipeIntegrateGrid = value; return VH_OK; }
     if (std::strcmp(name, "debug_skip_roles") == 0 && value >= 0 && value < 16) { c->debugSkipRoles = value; return VH_OK; }
-    if (std::strcmp(name, "pipeline_shards") == 0) { c->pipelineShards = value != 0; return VH_OK; }
+    if (std::strcmp(name, "pipeline_shards") == 0) {
+        if (value < 0 || value > 2) return fail(VH_ERR_INVALID_ARGUMENT, "pipeline_shards: 0, 1 or 2");
+        if (value < 2) { DeviceGuard g(c->device); const int frc = flush_multi_pending(c); if (frc != VH_OK) return frc; }
+        c->pipelineShards = value;
+        return VH_OK;
+    }
     if (std::strcmp(name, "pipeline") == 0) {
         c->pipeline = value != 0;
         return VH_OK;                // (a pending frame was flushed at the top of this call)

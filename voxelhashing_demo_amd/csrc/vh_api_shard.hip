@@ -321,6 +321,90 @@ extern "C" int vh_write_packets_u16_batch(vh_context *c, int32_t batch, const fl
     return VH_OK;
 }
 
+// One launch of the multi-camera pipeline: {claim || walk} of frame b of batch `mb` (null: none) and {commit + TSDF
+// update} of the frame that is pending (c->multiPend), if any.
+struct MultiBatch {
+    const int4 *bins;
+    const float *packets;
+    int32_t numBins, capacity, binStride, frameStride, numCams;
+    size_t packetStride, packetFrameStride;
+};
+
+static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b)
+{
+    MultiPending &mp = c->multiPend;
+    const bool doNew = mb != nullptr, hasOld = mp.active;
+    if (!doNew && !hasOld) return VH_OK;
+    int rc;
+    if (doNew && (rc = vh_reset_mutexes(c)) != VH_OK) return rc;
+    uint32_t *maskOf[2] = {c->dp.compactMask, c->maskBuf2};
+    const int oldParity = c->pipeParity, newParity = oldParity ^ 1;
+    const int setOld = c->pipeSet, setNew = (setOld + 1) % 3;
+    MultiPipeArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.numEntries = (uint32_t)c->numEntries;
+    a.numCams = doNew ? mb->numCams : mp.numCams;
+    a.packetStride = doNew ? mb->packetStride : mp.packetStride;
+    if (doNew) {
+        uint32_t parts = (uint32_t)grid_for((size_t)mb->capacity, 256 * 4);
+        if (parts < 1) parts = 1;
+        a.claimBlocks = (uint32_t)mb->numBins * parts;
+        a.walkBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
+        a.partsPerBin = parts; a.numBins = (uint32_t)mb->numBins;
+        a.capacity = mb->capacity; a.binStride = mb->binStride;
+        a.binsNew = mb->bins + (size_t)mb->frameStride * b;
+        a.packetsNew = mb->packets + mb->packetFrameStride * b;
+    }
+    a.commitBlocks = hasOld ? (uint32_t)c->commitBlocks : 0u;
+    a.integrateBlocks = hasOld ? (uint32_t)c->pipeIntegrateGrid : 0u;
+    a.setNew = kPipeSetStride * setNew; a.setOld = kPipeSetStride * setOld; a.setClear = kPipeSetStride * ((setNew + 1) % 3);
+    a.hasNew = doNew; a.hasOld = hasOld;
+    a.claimSpan = claim_span(c, a.claimBlocks, a.walkBlocks);
+    a.claimRatio = claim_ratio(a.claimBlocks, a.claimSpan);
+    a.epochOld = mp.epochOld;
+    a.packetsOld = mp.packetsOld;
+    DevPtrs dpNew = pipe_view(c, newParity);
+    dpNew.compactMask = maskOf[newParity];
+    const DevPtrs dpOld = pipe_view(c, oldParity);
+    a.claimOld = dpOld.claim; a.candOld = dpOld.candidates; a.compactOld = dpOld.compact; a.maskOld = maskOf[oldParity];
+    a.candCapacityOld = dpOld.candCapacity;
+    const dim3 grid(a.commitBlocks + a.integrateBlocks + a.claimBlocks + a.walkBlocks);
+    const int format = doNew ? c->packetFormat : mp.packetFormat;
+    rc = format == VH_PACKET_U16
+             ? launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<true>, grid, dim3(256), c->fp, dpNew, a)
+             : launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<false>, grid, dim3(256), c->fp, dpNew, a);
+    if (rc != VH_OK) return rc;
+    if (doNew) {
+        mp.active = true;
+        mp.epochOld = c->fp.epoch;
+        mp.packetsOld = a.packetsNew;
+        mp.packetStride = mb->packetStride;
+        mp.numCams = mb->numCams;
+        mp.packetFormat = c->packetFormat;
+        c->pipeSet = setNew;
+        c->pipeParity = newParity;
+        c->dp.claim = dpNew.claim; c->dp.candidates = dpNew.candidates; c->dp.compact = dpNew.compact;
+    } else {
+        mp.active = false;
+    }
+    c->occupiedCounter = kCompactCount;
+    c->compactArmed = false;
+    c->foldA = -1;
+    if (c->profiling && hasOld) c->profiledFrames += 1;
+    return VH_OK;
+}
+
+// the pending multi-camera frame's deferred half in a launch of its own (flush_pending: every observer comes through it)
+static int flush_multi_pending(vh_context *c)
+{
+    if (!c->multiPend.active) return VH_OK;
+    const int rc = launch_multi_pipelined(c, nullptr, 0);
+    if (rc != VH_OK) return rc;
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
+
+
 // `batch` multi-camera frames applied one after the other, each as the fused pair of launches
 // (new lock epoch; {claim bins || walk}; {commit + integrate}).
 extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t *d_bins, int32_t num_bins,
@@ -339,7 +423,7 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
         packet_stride < (size_t)batch * packet_frame_stride)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
     DeviceGuard guard(c->device);
-    { const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
+    { const int frc = flush_single_pending(c); if (frc != VH_OK) return frc; }    // (a pending multi-camera half rides along)
     {
         const int rc = ensure_candidates(c, (size_t)num_bins * (size_t)(capacity - 1));
         if (rc != VH_OK) return rc;
@@ -349,70 +433,36 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
     const uint32_t scanBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
     const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
     // One launch per multi-camera frame (frame_multi_pipelined_kernel, vh_shard.hip): the commit + TSDF update of frame
-    // b ride in the launch of frame b+1, a last launch serves the batch's last frame: B + 1 launches instead of 2 B.
+    // b ride in the launch of frame b+1.  pipeline_shards 1: a last launch serves the batch's last frame, B + 1 launches
+    // instead of 2 B; 2: that half stays pending across calls (launch_multi_pipelined) and rides in the first launch of
+    // the next batch -- B launches -- or in the flush any observer does first.
     // Same conditions as the single-camera pipeline (no overflow list, bucketSize <= 16, not a view table).
     if (c->pipelineShards && !(c->fp.flags & kFlagOverflow) && c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks) {
         int rc = ensure_pipeline_buffers(c);
         if (rc != VH_OK) return rc;
         if (!c->maskBuf2) VH_HIP(hipMalloc((void **)&c->maskBuf2, sizeof(uint32_t) * c->numEntries));
-        uint32_t *maskOf[2] = {c->dp.compactMask, c->maskBuf2};
-        bool pending = false;
-        uint32_t epochOld = 0;
-        const float *packetsOld = nullptr;
+        MultiPending &mp = c->multiPend;
+        // a pending half of another shape (camera count, packet layout) cannot share a launch with this batch's frames
+        if (mp.active && (mp.numCams != num_cams || mp.packetStride != packet_stride || mp.packetFormat != c->packetFormat) &&
+            (rc = flush_multi_pending(c)) != VH_OK)
+            return rc;
+        MultiBatch mb;
+        mb.bins = reinterpret_cast<const int4 *>(d_bins); mb.packets = d_packets;
+        mb.numBins = num_bins; mb.capacity = capacity; mb.binStride = bin_stride; mb.frameStride = frame_stride;
+        mb.numCams = num_cams; mb.packetStride = packet_stride; mb.packetFrameStride = packet_frame_stride;
         int b = 0;
-        while (b < batch || pending) {
-            const bool hasOld = pending;
-            bool doNew = b < batch;
+        while (b < batch) {
+            bool doNew = true;
             // at the epoch wrap vh_reset_mutexes clears the claim words, which the pending frame still needs: it is
             // served by a launch of its own first
-            if (doNew && pending && c->fp.epoch >= kMaxClaimEpoch) doNew = false;
-            if (doNew && (rc = vh_reset_mutexes(c)) != VH_OK) return rc;
-            const int oldParity = c->pipeParity, newParity = oldParity ^ 1;
-            const int setOld = c->pipeSet, setNew = (setOld + 1) % 3;
-            MultiPipeArgs a;
-            std::memset(&a, 0, sizeof a);
-            a.claimBlocks = doNew ? (uint32_t)num_bins * parts : 0u;
-            a.walkBlocks = doNew ? scanBlocks : 0u;
-            a.commitBlocks = hasOld ? commitBlocks : 0u;
-            a.integrateBlocks = hasOld ? (uint32_t)c->pipeIntegrateGrid : 0u;
-            a.partsPerBin = parts; a.numBins = (uint32_t)num_bins; a.numEntries = (uint32_t)c->numEntries;
-            a.capacity = capacity; a.binStride = bin_stride; a.numCams = num_cams;
-            a.setNew = kPipeSetStride * setNew; a.setOld = kPipeSetStride * setOld; a.setClear = kPipeSetStride * ((setNew + 1) % 3);
-            a.hasNew = doNew; a.hasOld = hasOld;
-            a.claimSpan = claim_span(c, a.claimBlocks, a.walkBlocks);
-            a.claimRatio = claim_ratio(a.claimBlocks, a.claimSpan);
-            a.epochOld = epochOld;
-            const int bb = std::min(b, batch - 1);
-            a.binsNew = reinterpret_cast<const int4 *>(d_bins) + (size_t)frame_stride * bb;
-            a.packetsNew = d_packets + packet_frame_stride * bb;
-            a.packetsOld = packetsOld;
-            a.packetStride = packet_stride;
-            DevPtrs dpNew = pipe_view(c, newParity);
-            dpNew.compactMask = maskOf[newParity];
-            const DevPtrs dpOld = pipe_view(c, oldParity);
-            a.claimOld = dpOld.claim; a.candOld = dpOld.candidates; a.compactOld = dpOld.compact; a.maskOld = maskOf[oldParity];
-            a.candCapacityOld = dpOld.candCapacity;
-            const dim3 grid(a.commitBlocks + a.integrateBlocks + a.claimBlocks + a.walkBlocks);
-            rc = c->packetFormat == VH_PACKET_U16
-                     ? launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<true>, grid, dim3(256), c->fp, dpNew, a)
-                     : launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<false>, grid, dim3(256), c->fp, dpNew, a);
-            if (rc != VH_OK) return rc;
+            if (mp.active && c->fp.epoch >= kMaxClaimEpoch) doNew = false;
+            if ((rc = launch_multi_pipelined(c, doNew ? &mb : nullptr, b)) != VH_OK) return rc;
             if (doNew) {
-                pending = true;
-                epochOld = c->fp.epoch;
-                packetsOld = a.packetsNew;
-                c->pipeSet = setNew;
-                c->pipeParity = newParity;
-                c->dp.claim = dpNew.claim; c->dp.candidates = dpNew.candidates; c->dp.compact = dpNew.compact;
+                if (b == 0 && c->multiFirstEvent) VH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(c->multiFirstEvent), c->stream));
                 ++b;
-            } else {
-                pending = false;
             }
-            c->occupiedCounter = kCompactCount;
-            c->compactArmed = false;
-            c->foldA = -1;
-            if (c->profiling && hasOld) c->profiledFrames += 1;
         }
+        if (c->pipelineShards < 2 && (rc = flush_multi_pending(c)) != VH_OK) return rc;
         VH_HIP(hipGetLastError());
         return VH_OK;
     }
@@ -441,6 +491,7 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
         c->foldA = -1;
         if (c->profiling) c->profiledFrames += 1;
     }
+    if (c->multiFirstEvent) VH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(c->multiFirstEvent), c->stream));
     VH_HIP(hipGetLastError());
     return VH_OK;
 }
