@@ -246,10 +246,15 @@ struct BandWalk {
     int cur[3], end[3], st[3];
     float tmax[3], tdelta[3];
     bool more;          // the walk has not ended
+    // ray band: the two divisions of a sample by values that do not change from sample to sample (div_fixed, vh_device.h)
+    float vsR1, zR1;
+    bool vsOk, zOk;
 
     __device__ __forceinline__ void init(const FrameParams &fp, const PixelVertex &p)
     {
         nS = band_samples(fp, step);
+        vsR1 = refined_rcp(fp.voxelSize); vsOk = fast_range(fp.voxelSize, 0x1p-40f, 0x1p40f);
+        zR1 = refined_rcp(p.v.z); zOk = fast_range(p.v.z, 0x1p-40f, 0x1p40f);
         dda = (fp.flags & kFlagBandDda) && fp.allocBand > 0.0f;
         more = false;
         if (!dda || !p.valid) return;
@@ -307,11 +312,13 @@ struct BandWalk {
         if (!(k == half || s > 0.0f)) return false;                      // the surface sample is never filtered (:621 only tests z != 0)
         float x = p.v.x, y = p.v.y, z = p.v.z;                           // k == half: the vertex itself, bit for bit
         if (k != half) {                                                 // wave-uniform; no divide on the reference path
-            const float scale = s / p.v.z;
+            const float scale = (zOk && fast_range(s, 0x1p-50f, 0x1p50f)) ? div_fixed(s, p.v.z, zR1) : s / p.v.z;
             x = p.v.x * scale; y = p.v.y * scale; z = s;
         }
         const float4 g = mat4_mul(fp.T, x, y, z, p.v.w);                 // :622, w as stored
-        const int3_ b = world2block(g.x, g.y, g.z, fp.voxelSize);        // :636
+        FixedDivisor vs(fp.voxelSize);
+        vs.r1 = vsR1; vs.ok = vsOk;
+        const int3_ b = world2block(g.x, g.y, g.z, vs);                  // :636
         kx = b.x; ky = b.y; kz = b.z;
         return true;
     }
@@ -326,6 +333,7 @@ struct BandWalk {
 
 // Sample k of this lane's pixel, frustum-tested and de-duplicated against the lane's own previous
 // sample and against sample k of the lanes to the left and above (see the header comment).
+template <bool kFrustumTest = true>
 __device__ __forceinline__ SampleKey sample_key(const FrameParams &fp, const PixelVertex &p, BandWalk &walk, int k,
                                                 int &ownX, int &ownY, int &ownZ, bool &ownHave)
 {
@@ -343,7 +351,7 @@ __device__ __forceinline__ SampleKey sample_key(const FrameParams &fp, const Pix
     const bool dupLeft = (lane & 15) != 0 && ((wants >> (lane - 1)) & 1ull) && lx == r.kx && ly == r.ky && lz == r.kz;
     const bool dupUp = lane >= 16 && ((wants >> (lane - 16)) & 1ull) && ux == r.kx && uy == r.ky && uz == r.kz;
     r.leader = want && !dupOwn && !dupLeft && !dupUp;
-    if (r.leader) r.leader = block_in_frustum(fp, r.kx, r.ky, r.kz);     // :673
+    if (kFrustumTest && r.leader) r.leader = block_in_frustum(fp, r.kx, r.ky, r.kz);     // :673
     return r;
 }
 
@@ -407,13 +415,16 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
             if (base + lane < count) {
                 const int kx = queue[base + lane].x, ky = queue[base + lane].y, kz = queue[base + lane].z;
                 const uint32_t rank = (uint32_t)queue[base + lane].w;
-                probe_and_claim(fp, dp, kx, ky, kz, hash_block(kx, ky, kz, fp.numBuckets), rank, candCounter, pend);
+                // the frustum test (:673) of the queued keys, one per lane: in the sample loop it ran for the one or two
+                // leaders of a wave at a time
+                if (block_in_frustum(fp, kx, ky, kz))
+                    probe_and_claim(fp, dp, kx, ky, kz, hash_block(kx, ky, kz, fp.numBuckets), rank, candCounter, pend);
             }
         }
     };
     int count = 0;                                                       // (wave-uniform)
     for (int k = 0; !walk.wave_done(k); ++k) {
-        const SampleKey s = sample_key(fp, p, walk, k, ox, oy, oz, oh);
+        const SampleKey s = sample_key<false>(fp, p, walk, k, ox, oy, oz, oh);
         bool take = s.leader;
         if (take) {
             const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);

@@ -175,6 +175,35 @@ __device__ __forceinline__ int voxel2block1(int v)
     return v / 8;
 }
 
+// world2Block with the division by voxelSize as div_fixed (r1 = refined_rcp(voxelSize), ok = voxelSize within its
+// range): the same bits, 5 instructions per division instead of 13; a coordinate outside the numerator's range
+// (0 included) takes the plain division
+struct FixedDivisor {
+    float d, r1;
+    bool ok;
+    __device__ __forceinline__ explicit FixedDivisor(float divisor)
+        : d(divisor), r1(refined_rcp(divisor)), ok(fast_range(divisor, 0x1p-40f, 0x1p40f)) {}
+    __device__ __forceinline__ float divide(float n) const
+    {
+        return (ok && fast_range(n, 0x1p-50f, 0x1p50f)) ? div_fixed(n, d, r1) : n / d;
+    }
+};
+
+__device__ __forceinline__ int world2voxel1(float p, const FixedDivisor &vs)
+{
+    const float q = vs.divide(p);
+    return f2i_rz(q + __builtin_copysignf(0.5f, q));
+}
+
+__device__ __forceinline__ int3_ world2block(float x, float y, float z, const FixedDivisor &vs)
+{
+    int3_ b;
+    b.x = voxel2block1(world2voxel1(x, vs));
+    b.y = voxel2block1(world2voxel1(y, vs));
+    b.z = voxel2block1(world2voxel1(z, vs));
+    return b;
+}
+
 __device__ __forceinline__ int3_ world2block(float x, float y, float z, float voxelSize)
 {
     int3_ b;
