@@ -16,3 +16,4 @@ timeout 900 bash tools/profile_round.sh $TAG C3 > $OUT/profile_C3.log 2>&1; tail
 timeout 900 bash tools/profile_round.sh $TAG C2band > $OUT/profile_C2band.log 2>&1; tail -6 $OUT/profile_C2band.log
 timeout 600 bash tools/pmc_raycast_quick.sh $TAG 1 > $OUT/pmc_raycast.log 2>&1; tail -20 $OUT/pmc_raycast.log
 timeout 300 python3 tools/raycast_stamps.py > $OUT/raycast_stamps.txt 2>&1; tail -12 $OUT/raycast_stamps.txt
+timeout 300 bash tools/trace_sharded.sh $TAG > $OUT/trace_sharded_tail.txt 2>&1; tail -4 $OUT/trace_sharded_tail.txt
