@@ -11,9 +11,11 @@
  *     exchange   ncclAllToAll of the key bins, ncclAllGather of the packets               (RCCL, its own stream)
  *     apply      on the owner: lock epoch, insert, walk + TSDF update for all cameras      (vh_apply_frames_batch)
  *
- * software-pipelined inside the library over three HIP streams and two buffer sets with events, exactly as the Python
- * host of round 2 did it (voxelhashing_demo_amd/dist.py: ShardedPipeline) -- but one C call per exchange instead of a
- * dozen Python calls and four torch collectives (host cost per exchange of 8 frames: 0.185 ms there).  The table sees its
+ * software-pipelined inside the library over three HIP streams and three buffer sets with events (while exchange n travels
+ * into one set, the frames of exchange n-1 are applied from the second, one launch per multi-camera frame, and the last
+ * frame of exchange n-2 -- whose commit + TSDF update ride in the first launch of n-1's frames -- still reads its packets in
+ * the third), as the Python host of round 2 did it with two (voxelhashing_demo_amd/dist.py: ShardedPipeline) -- but one C
+ * call per exchange instead of a dozen Python calls and four torch collectives.  The table sees its
  * operations in the order of the plain step sequence, so results do not depend on the pipelining.
  *
  * RCCL is bound at run time (dlopen of librccl.so.1, or whatever copy the process has loaded already -- torch's): the
