@@ -338,6 +338,7 @@ int vh_get_kernel_times(vh_context *ctx, vh_kernel_times *out, int reset);  /* s
  * bucket), then flatten + TSDF update camera by camera.  With R = 1 it is the
  * reference's integrate().  The table is cut into bucket ranges, one per GPU. */
 #define VH_MAX_CAMERAS 32
+#define VH_BIN_PER_BATCH (-1)      /* frame_stride of the batched shard calls: one key bin per shard for the whole batch */
 #define VH_PACKET_HEADER_FLOATS 32   /* camera packet: pose[16], inverse[16], then W*H camera-z */
 
 /* Restrict this context to the buckets [lo, hi) of a logical table of
@@ -372,6 +373,13 @@ int vh_integrate_packets(vh_context *ctx, int32_t num_cams, const float *d_packe
  * packet_frame_stride = 32 + W*H, packet_stride = batch*packet_frame_stride).
  * vh_generate_keys_batch: poses = batch*16 host floats, d_verts = host array of `batch`
  * device pointers; the packets written are this camera's (d_packets[b*packet_frame_stride]).
+ * frame_stride = VH_BIN_PER_BATCH: ONE bin per shard/source for the whole batch (at d_bins[s*bin_stride*4], capacity
+ * records for all `batch` frames together, batch <= 32): a record carries its frame index in the rank's camera bits
+ * (the camera is the source of the bin), and the launch of frame b claims the records of frame b.  Same tables as
+ * per-frame bins; the point is the exchange: a fixed-size bin must hold the worst case of what it may receive, and
+ * the worst case of a batch is much closer to its mean than the worst case of a single frame is (vh_dist_* sizes a
+ * per-batch bin at 1.5 x batch x W*H/16 / shards records: 3.7 MB of bins per rank and exchange at 8 ranks, batch 8,
+ * 640x480, against 19.7 MB with per-frame bins of W*H/16).
  * vh_apply_frames_batch: for b = 0..batch-1: new lock epoch, insert the num_bins bins of
  * frame b, walk + TSDF update for the num_cams packets of frame b; equals vh_reset_mutexes +
  * vh_insert_bins + vh_integrate_packets per frame.  Launches, option "pipeline_shards":

@@ -201,6 +201,53 @@ def test_sensor_depth_packets(oracle, vh, torch_cuda, world, batch, sem, calls):
         sh.table.close()
 
 
+@pytest.mark.parametrize("world,batch,mode", [(2, 3, 1), (4, 2, 0), (2, 5, 2)])
+def test_one_key_bin_per_owner_and_batch(oracle, vh, torch_cuda, world, batch, mode):
+    """VH_BIN_PER_BATCH: the keys of all frames of a batch travel in ONE bin per owner, each record with its frame index
+    where a per-frame bin's record has the camera id; the launch of frame b claims the records of frame b.  Same tables as
+    with per-frame bins = the one oracle table, with pipelined launches (1), two launches per frame (0) and the last frame
+    pending across calls (2), with an allocation band (several keys per pixel: the sample bits of the rank)."""
+    torch = torch_cuda
+    K = synth.K_matrix(W, H)
+    kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    plan = vdist.ShardPlan(KW["numBuckets"], world)
+    kw = dict(numBuckets=KW["numBuckets"], numVoxelBlocks=1 << 14)       # (per-shard heaps that the band never exhausts)
+    shards = [vdist.HipShard(vh.default_params(**kw), W, H, 1, plan, r, batch * W * H // 8, batch=batch, sensor_k_inv=kinv,
+                             per_batch_bins=True, sets=2) for r in range(world)]
+    full = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    full.set_alloc_band(0.1)
+    for sh in shards:
+        sh.table.set_option("pipeline_shards", mode)
+        sh.table.set_alloc_band(0.1)
+        assert sh.bins_send.shape == (world, 1, batch * W * H // 8, 4)
+    fills = []
+    for step in range(0, 2 * batch, batch):
+        for sh in shards:                                # (mode 2: the previous batch's last packets stay where they are)
+            sh.use_set((step // batch) % 2)
+        frames = []
+        for b in range(batch):
+            cams = []
+            for pose, verts in cameras(world, step + b):
+                d16 = np.round(verts[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16)
+                cams.append((pose, oracle.preprocess(d16, kinv)[0], d16))
+            frames.append(cams)
+        vdist.loopback_step(shards, [[frames[b][r][0] for b in range(batch)] for r in range(world)],
+                            [[None] * batch for _ in range(world)],
+                            [[torch.from_numpy(frames[b][r][2]).cuda() for b in range(batch)] for r in range(world)])
+        fills.append(int(shards[0].bins_recv[:, 0, 0, 0].sum().item()))
+        for cams in frames:
+            vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+    total = 0
+    for r, sh in enumerate(shards):
+        sh.table.synchronize()
+        total += check_shard_against_full(sh.table, full, *plan.bucket_range(r), 5)
+        assert sh.table.counters()["bin_overflow"] == 0 and sh.table.counters()["heap_exhausted"] == 0
+    assert total == len(full.allocated()) > 300
+    assert min(fills) > 100 * batch                      # (the bins really carried the whole batch)
+    for sh in shards:
+        sh.table.close()
+
+
 def _hip_gloo_worker(rank, world, port, q, sensor):
     """One rank of a two-process run on ONE GPU: real HIP shards, real processes, gloo with host staging
     for the exchange (RCCL refuses two ranks on one device).  Checks its shard against the oracle."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """R bucket-range shards on ONE GPU with the in-process exchange: what a rank's kernels cost per
 multi-camera frame when the table is cut R ways (the collectives are not part of this).
-   tools/emulate_ranks.py [R=8] [batch=8]"""
+   tools/emulate_ranks.py [R=8] [batch=8] [pipeline_shards=1] [per_batch_bins=0]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,9 +16,11 @@ K = synth.K_matrix(W, H)
 kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
 prims = synth.room_primitives()
 plan = vdist.ShardPlan(1 << 20, R)
-cap = max(2048, -(-W * H // (16 * R)))
+PER_BATCH = len(sys.argv) > 4 and int(sys.argv[4]) != 0
+# per-frame bins: one record per 16 pixels whatever the number of owners (bench.py's size); per-batch bins: vh_dist's default
+cap = max(2048, (-(-W * H // 16) * B * 3 // 2 + R - 1) // R + 1) if PER_BATCH else max(2048, -(-W * H // 16))
 shards = [vdist.HipShard(V.default_params(numBuckets=1 << 20, numVoxelBlocks=1 << 16), W, H, 1, plan, r, cap, batch=B,
-                         sensor_k_inv=kinv) for r in range(R)]
+                         sensor_k_inv=kinv, per_batch_bins=PER_BATCH) for r in range(R)]
 if len(sys.argv) > 3:
     for sh in shards:
         sh.table.set_option("pipeline_shards", int(sys.argv[3]))      # 0: two launches per multi-camera frame
@@ -48,7 +50,10 @@ frames = n * B
 print(f"R={R} batch={B}: rank 0 per multi-camera frame ({R} cameras): one-launch frames {1e3*kt['frame_pipelined_ms']/frames:.2f} us "
       f"(B + 1 launches per batch; two-launch form: scan+claim {1e3*kt['frame_scan_claim_ms']/frames:.2f} us, "
       f"commit+integrate {1e3*kt['frame_commit_integrate_ms']/frames:.2f} us); shard {shards[0].table.num_entries*20/1e6:.1f} MB, "
-      f"occupied {shards[0].table.counters()['occupied']}, bins {cap*16*R*B/1e6:.2f} MB and packets {shards[0].packet_floats*4*R*B/1e6:.1f} MB received per exchange")
+      f"occupied {shards[0].table.counters()['occupied']}, bins {cap*16*R*(1 if PER_BATCH else B)/1e6:.2f} MB "
+      f"({'one per (owner, batch)' if PER_BATCH else 'one per (owner, frame)'}, {cap} records) and packets {shards[0].packet_floats*4*R*B/1e6:.1f} MB received per exchange")
+fill = max(int(sh.bins_recv[:, :, 0, 0].max().item()) for sh in shards)
+print(f"fullest bin of the last exchange: {fill} of {cap - 1} records; bin overflows over the run: {sum(sh.table.counters()['bin_overflow'] for sh in shards)}")
 # key generation of a batch, timed on the device
 sh = shards[0]
 ks = list(range(B))

@@ -545,8 +545,10 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_batch_kernel(FrameP
         outDepth[(int)threadIdx.x - kPacketHeader] = threadIdx.x < 16 ? fr.T[b][threadIdx.x] : fr.Tinv[b][threadIdx.x - 16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { fp.T[i] = fr.T[b][i]; fp.Tinv[i] = fr.Tinv[b][i]; }
-    generate_keys_tile(fp, VertexMap{fr.verts[b], nullptr}, numShards, outBins + (size_t)frameStride * b, outCapacity,
-                       outBinStride, outDepth, rankBase, blockIdx.x);
+    // (frameStride < 0: one bin per owner for the whole batch; rankBase then carries the frame index where the camera id sits)
+    generate_keys_tile(fp, VertexMap{fr.verts[b], nullptr}, numShards, frameStride < 0 ? outBins : outBins + (size_t)frameStride * b,
+                       outCapacity, outBinStride, outDepth,
+                       frameStride < 0 ? rankBase + ((uint32_t)b << kRankCameraShift) : rankBase, blockIdx.x);
 }
 
 // The same from uint16 sensor images: vertices computed in place (SensorImage), and the packet of
@@ -589,8 +591,8 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_sensor_batch_kernel
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) { fp.T[i] = fr.T[b][i]; fp.Tinv[i] = fr.Tinv[b][i]; }
-    generate_keys_tile(fp, in, numShards, outBins + (size_t)frameStride * b, outCapacity, outBinStride, nullptr,
-                       rankBase, blockIdx.x);
+    generate_keys_tile(fp, in, numShards, frameStride < 0 ? outBins : outBins + (size_t)frameStride * b, outCapacity, outBinStride,
+                       nullptr, frameStride < 0 ? rankBase + ((uint32_t)b << kRankCameraShift) : rankBase, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------

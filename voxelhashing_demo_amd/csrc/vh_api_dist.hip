@@ -155,7 +155,7 @@ extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_I
 {
     if (!cfg || !out || (!id && !nccl_comm)) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
-    if (cfg->world < 1 || cfg->world > VH_MAX_CAMERAS || cfg->rank < 0 || cfg->rank >= cfg->world || cfg->batch < 1)
+    if (cfg->world < 1 || cfg->world > VH_MAX_CAMERAS || cfg->rank < 0 || cfg->rank >= cfg->world || cfg->batch < 1 || cfg->batch > VH_MAX_CAMERAS)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad rank / world / batch");
     if (cfg->packet_format != VH_PACKET_U16 && cfg->packet_format != VH_PACKET_F32)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad packet format");
@@ -177,10 +177,14 @@ extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_I
     d->device = d->shard->device;
     DeviceGuard guard(d->device);
     if (cfg->packet_format == VH_PACKET_U16) d->shard->packetFormat = VH_PACKET_U16;
-    d->capacity = cfg->key_capacity > 0 ? cfg->key_capacity : (int)std::max<size_t>(2048, (npix + 15) / 16);
+    // one key bin per (owner, batch): 1.5 x the records a batch yields per owner when a frame yields W*H/16 (twice what the
+    // 2-D wave dedup leaves of a room frame) and the owners share them evenly; bucket-range ownership is skewed by up to
+    // ~2.5 x the even share on walls (the 8-rank rig), hence the factor on top.  Overflows are counted, never silent.
+    const size_t perOwner = ((npix + 15) / 16 * (size_t)cfg->batch * 3 / 2 + (size_t)cfg->world - 1) / (size_t)cfg->world;
+    d->capacity = cfg->key_capacity > 0 ? cfg->key_capacity : (int)std::max<size_t>(2048, perOwner + 1);
     d->packetUnits = cfg->packet_format == VH_PACKET_U16 ? (size_t)kPacketHeaderU16 + npix / 2 : (size_t)kPacketHeader + npix;
     const size_t B = (size_t)cfg->batch;
-    const size_t binBytes = (size_t)R * B * (size_t)d->capacity * 4 * sizeof(int32_t);
+    const size_t binBytes = (size_t)R * (size_t)d->capacity * 4 * sizeof(int32_t);      // [peer][capacity] records of 16 bytes
     const size_t pkBytes = B * d->packetUnits * sizeof(float);
 #define VH_DIST_TRY(call)                                                                            \
     do {                                                                                             \
@@ -230,8 +234,8 @@ static int dist_apply(vh_dist *d, int s)
     VH_HIP(hipStreamWaitEvent(d->sTable, d->ready[s], 0));
     d->shard->stream = d->sTable;
     d->shard->multiFirstEvent = d->first[s];
-    const int rc = vh_apply_frames_batch(d->shard, d->cfg.batch, d->set[s].binsRecv, d->cfg.world, d->capacity, 0, 0, d->cfg.world,
-                                         d->set[s].packets, 0, 0);
+    const int rc = vh_apply_frames_batch(d->shard, d->cfg.batch, d->set[s].binsRecv, d->cfg.world, d->capacity, 0, VH_BIN_PER_BATCH,
+                                         d->cfg.world, d->set[s].packets, 0, 0);
     d->shard->multiFirstEvent = nullptr;
     return rc;
 }
@@ -251,10 +255,10 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     d->shard->stream = d->sGen;
     if (d->cfg.packet_format == VH_PACKET_U16)
         rc = vh_generate_keys_depth_batch(d->shard, B, poses, reinterpret_cast<const uint16_t *const *>(d_frames), d->cfg.k_inv,
-                                          (uint32_t)d->cfg.rank, R, set.binsSend, d->capacity, 0, 0, set.packet, 0);
+                                          (uint32_t)d->cfg.rank, R, set.binsSend, d->capacity, 0, VH_BIN_PER_BATCH, set.packet, 0);
     else
         rc = vh_generate_keys_batch(d->shard, B, poses, reinterpret_cast<const vh_float4 *const *>(d_frames), (uint32_t)d->cfg.rank, R,
-                                    set.binsSend, d->capacity, 0, 0, set.packet, 0);
+                                    set.binsSend, d->capacity, 0, VH_BIN_PER_BATCH, set.packet, 0);
     d->shard->stream = d->sTable;
     if (rc != VH_OK) return rc;
     VH_HIP(hipEventRecord(d->generated[s], d->sGen));
@@ -262,7 +266,7 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     // the first launch of exchange count-2's frames (queued by the previous call)
     VH_HIP(hipStreamWaitEvent(d->sComm, d->generated[s], 0));
     if (d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sComm, d->first[(s + 1) % vh_dist::kSets], 0));
-    VH_RCCL(g_rccl.allToAll(set.binsSend, set.binsRecv, (size_t)B * d->capacity * 4, ncclInt32, d->comm, d->sComm));
+    VH_RCCL(g_rccl.allToAll(set.binsSend, set.binsRecv, (size_t)d->capacity * 4, ncclInt32, d->comm, d->sComm));
     VH_RCCL(g_rccl.allGather(set.packet, set.packets, (size_t)B * d->packetUnits, ncclFloat32, d->comm, d->sComm));
     VH_HIP(hipEventRecord(d->ready[s], d->sComm));
     // apply the previous exchange while this one travels

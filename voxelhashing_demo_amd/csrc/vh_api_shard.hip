@@ -210,15 +210,20 @@ extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float 
     if (!c || !poses || !d_verts || !d_bins || batch <= 0 || num_shards <= 0 || num_shards > VH_MAX_CAMERAS ||
         capacity < 2 || camera_id >= VH_MAX_CAMERAS)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    const bool perBatch = frame_stride == VH_BIN_PER_BATCH;            // one bin per owner for all frames of the batch
+    if (perBatch && batch > (int32_t)VH_MAX_CAMERAS) return fail(VH_ERR_INVALID_ARGUMENT, "a per-batch bin holds at most 32 frames");
     if (frame_stride == 0) frame_stride = capacity;
-    if (bin_stride == 0) bin_stride = batch * frame_stride;
+    if (bin_stride == 0) bin_stride = perBatch ? capacity : batch * frame_stride;
     const size_t dense = (size_t)kPacketHeader + (size_t)c->fp.width * c->fp.height;
     if (packet_frame_stride == 0) packet_frame_stride = dense;
-    if (frame_stride < capacity || bin_stride < batch * frame_stride || (d_packets && packet_frame_stride < dense))
+    if ((!perBatch && (frame_stride < capacity || bin_stride < batch * frame_stride)) || (perBatch && bin_stride < capacity) || (d_packets && packet_frame_stride < dense))
         return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
     DeviceGuard guard(c->device);
-    prepare_bins_kernel<<<grid_for((size_t)num_shards * batch, 256), 256, 0, c->stream>>>(
-        reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, batch, frame_stride);
+    if (perBatch)
+        prepare_bins_kernel<<<1, 64, 0, c->stream>>>(reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, 1, 0);
+    else
+        prepare_bins_kernel<<<grid_for((size_t)num_shards * batch, 256), 256, 0, c->stream>>>(
+            reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, batch, frame_stride);
     for (int b0 = 0; b0 < batch; b0 += kGenBatch) {
         const int n = std::min<int>(kGenBatch, batch - b0);
         GenFrames fr;
@@ -232,9 +237,9 @@ extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float 
             fr.verts[j] = reinterpret_cast<const float4 *>(d_verts[b0 + j]);
         }
         generate_keys_batch_kernel<<<dim3((unsigned)grid_for(host_num_tiles(c), kGenTiles), (unsigned)n), kGenThreads, 0, c->stream>>>(
-            c->fp, fr, num_shards, reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
-            frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
-            camera_id << kRankCameraShift);
+            c->fp, fr, num_shards, perBatch ? reinterpret_cast<int4 *>(d_bins) : reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
+            perBatch ? -1 : frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
+            perBatch ? (uint32_t)b0 << kRankCameraShift : camera_id << kRankCameraShift);
     }
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -252,15 +257,20 @@ extern "C" int vh_generate_keys_depth_batch(vh_context *c, int32_t batch, const 
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     const size_t npix = (size_t)c->fp.width * c->fp.height;
     if (d_packets && npix % 2) return fail(VH_ERR_INVALID_ARGUMENT, "sensor-depth packets need an even number of pixels");
+    const bool perBatch = frame_stride == VH_BIN_PER_BATCH;            // one bin per owner for all frames of the batch
+    if (perBatch && batch > (int32_t)VH_MAX_CAMERAS) return fail(VH_ERR_INVALID_ARGUMENT, "a per-batch bin holds at most 32 frames");
     if (frame_stride == 0) frame_stride = capacity;
-    if (bin_stride == 0) bin_stride = batch * frame_stride;
+    if (bin_stride == 0) bin_stride = perBatch ? capacity : batch * frame_stride;
     const size_t dense = (size_t)kPacketHeaderU16 + npix / 2;
     if (packet_frame_stride == 0) packet_frame_stride = dense;
-    if (frame_stride < capacity || bin_stride < batch * frame_stride || (d_packets && packet_frame_stride < dense))
+    if ((!perBatch && (frame_stride < capacity || bin_stride < batch * frame_stride)) || (perBatch && bin_stride < capacity) || (d_packets && packet_frame_stride < dense))
         return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
     DeviceGuard guard(c->device);
-    prepare_bins_kernel<<<grid_for((size_t)num_shards * batch, 256), 256, 0, c->stream>>>(
-        reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, batch, frame_stride);
+    if (perBatch)
+        prepare_bins_kernel<<<1, 64, 0, c->stream>>>(reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, 1, 0);
+    else
+        prepare_bins_kernel<<<grid_for((size_t)num_shards * batch, 256), 256, 0, c->stream>>>(
+            reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, batch, frame_stride);
     for (int b0 = 0; b0 < batch; b0 += kGenBatch) {
         const int n = std::min<int>(kGenBatch, batch - b0);
         GenSensorFrames fr;
@@ -277,9 +287,9 @@ extern "C" int vh_generate_keys_depth_batch(vh_context *c, int32_t batch, const 
         }
         generate_keys_sensor_batch_kernel<<<dim3((unsigned)grid_for(host_num_tiles(c), kGenTiles), (unsigned)n), kGenThreads, 0,
                                             c->stream>>>(
-            c->fp, fr, num_shards, reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
-            frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
-            camera_id << kRankCameraShift);
+            c->fp, fr, num_shards, perBatch ? reinterpret_cast<int4 *>(d_bins) : reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
+            perBatch ? -1 : frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
+            perBatch ? (uint32_t)b0 << kRankCameraShift : camera_id << kRankCameraShift);
     }
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -328,6 +338,7 @@ struct MultiBatch {
     const float *packets;
     int32_t numBins, capacity, binStride, frameStride, numCams;
     size_t packetStride, packetFrameStride;
+    bool perBatch;           // the bins hold the whole batch (frameStride 0): a launch claims the records of its frame
 };
 
 static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b)
@@ -353,6 +364,7 @@ static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b)
         a.partsPerBin = parts; a.numBins = (uint32_t)mb->numBins;
         a.capacity = mb->capacity; a.binStride = mb->binStride;
         a.binsNew = mb->bins + (size_t)mb->frameStride * b;
+        a.binFrame = mb->perBatch ? b : -1;
         a.packetsNew = mb->packets + mb->packetFrameStride * b;
     }
     a.commitBlocks = hasOld ? (uint32_t)c->commitBlocks : 0u;
@@ -415,11 +427,13 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
         num_cams > VH_MAX_CAMERAS)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     const size_t dense = packet_units(c);
+    const bool perBatch = frame_stride == VH_BIN_PER_BATCH;            // one bin per source for all frames of the batch
+    if (perBatch && batch > (int32_t)VH_MAX_CAMERAS) return fail(VH_ERR_INVALID_ARGUMENT, "a per-batch bin holds at most 32 frames");
     if (frame_stride == 0) frame_stride = capacity;
-    if (bin_stride == 0) bin_stride = batch * frame_stride;
+    if (bin_stride == 0) bin_stride = perBatch ? capacity : batch * frame_stride;
     if (packet_frame_stride == 0) packet_frame_stride = dense;
     if (packet_stride == 0) packet_stride = (size_t)batch * packet_frame_stride;
-    if (frame_stride < capacity || bin_stride < batch * frame_stride || packet_frame_stride < dense ||
+    if ((!perBatch && (frame_stride < capacity || bin_stride < batch * frame_stride)) || (perBatch && bin_stride < capacity) || packet_frame_stride < dense ||
         packet_stride < (size_t)batch * packet_frame_stride)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad stride");
     DeviceGuard guard(c->device);
@@ -448,7 +462,8 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
             return rc;
         MultiBatch mb;
         mb.bins = reinterpret_cast<const int4 *>(d_bins); mb.packets = d_packets;
-        mb.numBins = num_bins; mb.capacity = capacity; mb.binStride = bin_stride; mb.frameStride = frame_stride;
+        mb.numBins = num_bins; mb.capacity = capacity; mb.binStride = bin_stride; mb.frameStride = perBatch ? 0 : frame_stride;
+        mb.perBatch = perBatch;
         mb.numCams = num_cams; mb.packetStride = packet_stride; mb.packetFrameStride = packet_frame_stride;
         int b = 0;
         while (b < batch) {
@@ -469,13 +484,13 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
     for (int b = 0; b < batch; ++b) {
         int rc = vh_reset_mutexes(c);
         if (rc != VH_OK) return rc;
-        const int4 *bins = reinterpret_cast<const int4 *>(d_bins) + (size_t)frame_stride * b;
+        const int4 *bins = reinterpret_cast<const int4 *>(d_bins) + (perBatch ? (size_t)0 : (size_t)frame_stride * b);
         const float *packets = d_packets + packet_frame_stride * b;
         rc = launch(c, kPhaseFrameScanClaim, frame_multi_scan_claim_kernel,
                     dim3((uint32_t)num_bins * parts + scanBlocks), dim3(256), c->fp, c->dp, bins, capacity, bin_stride,
                     (uint32_t)num_bins, parts, (uint32_t)c->numEntries, num_cams, packets, packet_stride,
                     c->fusedParity, claim_span(c, (uint32_t)num_bins * parts, scanBlocks),
-                    claim_ratio((uint32_t)num_bins * parts, claim_span(c, (uint32_t)num_bins * parts, scanBlocks)));
+                    claim_ratio((uint32_t)num_bins * parts, claim_span(c, (uint32_t)num_bins * parts, scanBlocks)), perBatch ? b : -1);
         if (rc == VH_OK)
             rc = c->packetFormat == VH_PACKET_U16
                      ? launch(c, kPhaseFrameCommitIntegrate, frame_multi_commit_integrate_kernel<true>,

@@ -14,8 +14,10 @@ namespace vh {
 __device__ __forceinline__ void claim_bin_slice(const FrameParams &fp, const DevPtrs &dp,
                                                 const int4 *__restrict__ bins, int32_t capacity, int32_t binStride,
                                                 uint32_t binIndex, uint32_t part, uint32_t parts, int candCounter,
-                                                const Pending &pend = kNoPending)
+                                                const Pending &pend = kNoPending, int frame = -1)
 {
+    // frame >= 0: ONE bin per (source, batch) -- the records of all frames of the batch, each with its frame index where a
+    // per-frame bin's record has the camera id (the camera IS the source: bin index); this launch serves `frame` only
     const int4 *bin = bins + (size_t)binIndex * binStride;
     int n = bin[0].x;
     if (n > capacity - 1) {
@@ -24,9 +26,14 @@ __device__ __forceinline__ void claim_bin_slice(const FrameParams &fp, const Dev
     }
     for (int i = (int)part * 256 + (int)threadIdx.x; i < n; i += (int)parts * 256) {
         const int4 k = bin[1 + i];
+        uint32_t rank = (uint32_t)k.w;
+        if (frame >= 0) {
+            if ((rank >> kRankCameraShift) != (uint32_t)frame) continue;
+            rank = (binIndex << kRankCameraShift) | (rank & ((1u << kRankCameraShift) - 1u));
+        }
         const uint32_t h = hash_block(k.x, k.y, k.z, fp.numBuckets);
         if (h < fp.bucketLo || h >= fp.bucketHi) continue;
-        probe_and_claim(fp, dp, k.x, k.y, k.z, h, (uint32_t)k.w, candCounter, pend);
+        probe_and_claim(fp, dp, k.x, k.y, k.z, h, rank, candCounter, pend);
     }
 }
 
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(256) void frame_multi_scan_claim_kernel(const Frame
                                                                      int32_t numCams,
                                                                      const float *__restrict__ packets,
                                                                      size_t packetStride, int parity,
-                                                                     uint32_t claimSpan, uint32_t claimRatio)
+                                                                     uint32_t claimSpan, uint32_t claimRatio, int binFrame)
 {
     // (claim workgroups spread over the first claimSpan workgroups of the grid, as in frame_scan_claim_kernel)
     const uint32_t claimBlocks = numBins * partsPerBin;
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void frame_multi_scan_claim_kernel(const Frame
     const uint32_t claimAfter = inSpan ? __umulhi(blockIdx.x + 1u, claimRatio) : claimBlocks;
     if (claimAfter != claimBefore)
         claim_bin_slice(fp, dp, bins, capacity, binStride, claimBefore / partsPerBin, claimBefore % partsPerBin,
-                        partsPerBin, kFusedCand + parity);
+                        partsPerBin, kFusedCand + parity, kNoPending, binFrame);
     else
         flatten_multi_tile(fp, dp, numEntries, blockIdx.x - claimBefore, numCams, packets, packetStride,
                            kScanCount + parity);
@@ -234,6 +241,7 @@ struct MultiPipeArgs {
     uint32_t claimBlocks, walkBlocks, commitBlocks, integrateBlocks;     // roles by workgroup index, in this order: commit, integrate, claim/walk interleaved
     uint32_t partsPerBin, numBins, numEntries;
     int32_t capacity, binStride, numCams;
+    int32_t binFrame;            // >= 0: the bins hold the whole batch, this launch claims the records of that frame
     int32_t setNew, setOld, setClear;
     uint32_t hasNew, hasOld;
     uint32_t claimSpan, claimRatio;
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(256) void frame_multi_pipelined_kernel(const FrameP
         if (after != before) {
             __builtin_amdgcn_s_setprio(3);
             claim_bin_slice(fp, dp, a.binsNew, a.capacity, a.binStride, before / a.partsPerBin, before % a.partsPerBin, a.partsPerBin,
-                            kPipeCand + a.setNew, pend);
+                            kPipeCand + a.setNew, pend, a.binFrame);
         } else {
             flatten_multi_tile(fp, dp, a.numEntries, r - before, a.numCams, a.packetsNew, a.packetStride, kPipeScan + a.setNew, pend);
         }

@@ -165,9 +165,11 @@ class HipShard:
 
     def __init__(self, params, width, height, semantics, plan: ShardPlan, rank: int, capacity: int,
                  batch: int = 1, device=None, stream=None, sets: int = 1, batched_calls: bool = True,
-                 sensor_k_inv=None):
+                 sensor_k_inv=None, per_batch_bins: bool = False):
         """sensor_k_inv: K^-1 (3x3) of the camera -> packets carry the uint16 sensor image (VH_PACKET_U16,
-        half the bytes of the float camera-z plane); generate_* then also need the depth images."""
+        half the bytes of the float camera-z plane); generate_* then also need the depth images.
+        per_batch_bins: one key bin of `capacity` records per (owner, batch) instead of per (owner, frame)
+        (VH_BIN_PER_BATCH; batched calls only): bins_send / bins_recv are [R, 1, capacity, 4]."""
         import torch
 
         from .hashtable import SDFHashtable
@@ -175,6 +177,8 @@ class HipShard:
         self.sensor_k_inv = None if sensor_k_inv is None else np.ascontiguousarray(
             np.asarray(sensor_k_inv, np.float32).reshape(9))
         self.batched_calls = batched_calls     # False: per-frame step calls (4 + 2 launches per frame)
+        self.per_batch_bins = bool(per_batch_bins)
+        assert batched_calls or not per_batch_bins
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.table = SDFHashtable(params, width, height, semantics, device=self.device.index,
                                   bucket_range=plan.bucket_range(rank), stream=stream)
@@ -185,15 +189,16 @@ class HipShard:
         else:
             self.packet_floats = P = 32 + width * height
         R, B = plan.world, batch
+        BB = 1 if self.per_batch_bins else B           # bins per (owner, exchange)
         # `sets` independent buffer sets: the pipelined step fills one while the other is consumed
         self.sets = []
         for _ in range(max(1, sets)):
-            s = dict(bins_send=torch.zeros((R, B, capacity, 4), dtype=torch.int32, device=self.device),
-                     bins_recv=torch.zeros((R, B, capacity, 4), dtype=torch.int32, device=self.device),
+            s = dict(bins_send=torch.zeros((R, BB, capacity, 4), dtype=torch.int32, device=self.device),
+                     bins_recv=torch.zeros((R, BB, capacity, 4), dtype=torch.int32, device=self.device),
                      packet=torch.zeros((B, P), dtype=torch.float32, device=self.device),
                      packets=torch.zeros((R, B, P), dtype=torch.float32, device=self.device))
-            s["send_b"] = [s["bins_send"][0, b].data_ptr() for b in range(B)]
-            s["recv_b"] = [s["bins_recv"][0, b].data_ptr() for b in range(B)]
+            s["send_b"] = [s["bins_send"][0, b].data_ptr() for b in range(BB)]
+            s["recv_b"] = [s["bins_recv"][0, b].data_ptr() for b in range(BB)]
             s["packet_b"] = [s["packet"][b].data_ptr() for b in range(B)]
             s["packets_b"] = [s["packets"][0, b].data_ptr() for b in range(B)]
             self.sets.append(s)
@@ -239,12 +244,12 @@ class HipShard:
         if self.sensor_k_inv is None:
             ptrs = (C.c_void_p * self.batch)(*[v.data_ptr() for v in verts_list])
             self.table.generate_keys_batch(p16, ptrs, self.rank, self.plan.world, self.bins_send, self.capacity,
-                                           self.packet, self.batch)
+                                           self.packet, self.batch, self.per_batch_bins)
             return
         # keys and packets from the sensor images alone, one launch per 8 frames (verts_list is not read)
         dptrs = (C.c_void_p * self.batch)(*[d.data_ptr() for d in depth_list])
         self.table.generate_keys_depth_batch(p16, dptrs, self.sensor_k_inv, self.rank, self.plan.world, self.bins_send,
-                                             self.capacity, self.packet, self.batch)
+                                             self.capacity, self.packet, self.batch, self.per_batch_bins)
 
     def apply_all(self):
         if not self.batched_calls:
@@ -252,7 +257,7 @@ class HipShard:
                 self.apply(b)
             return
         self.table.apply_frames_batch(self.bins_recv, self.plan.world, self.capacity, self.plan.world, self.packets,
-                                      self.batch)
+                                      self.batch, self.per_batch_bins)
 
 
     # raycast over shards: this shard's blocks that each of the world's views can touch
@@ -708,7 +713,7 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     batch = max(1, args.batch)
     pipelined = not getattr(args, "no_pipeline", False)
     # The exchange runs inside the library on RCCL directly (include/voxelhash_dist.h: one C call per exchange, three
-    # HIP streams and two buffer sets in C++) unless --python-exchange asks for round 2's Python host (ShardedPipeline
+    # HIP streams and three buffer sets in C++) unless --python-exchange asks for round 2's Python host (ShardedPipeline
     # over torch.distributed collectives), kept for comparison.
     # (the N > 1 test rig -- gloo, every rank on one GPU, which RCCL refuses -- goes through the Python host too)
     native = not getattr(args, "python_exchange", False) and pipelined and dist.get_backend() == "nccl"
@@ -717,8 +722,10 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     with torch.cuda.stream(stream):
         if native:
             uid = unique_id(rank, torch_broadcast_bytes())
+            # (key bins: the library's default -- ONE bin per (owner, batch) of 1.5 x batch x W*H/16 / world records)
+            native_capacity = max(2048, (-(-Wd * Ht // 16) * batch * 3 // 2 + world - 1) // world + 1)
             nd = NativeDist(params, Wd, Ht, SEM_PINHOLE, rank, world, batch, uid, sensor_k_inv=k_inv if sensor else None,
-                            key_capacity=capacity, device=local_rank)
+                            key_capacity=0, device=local_rank)
 
             class _Shard:          # what the rest of this function reads of a HipShard
                 table, packet_floats = nd.table, (36 + Wd * Ht // 2) if sensor else (32 + Wd * Ht)
@@ -928,7 +935,10 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
                                  + ("uint16 sensor depth, vertex maps by vh_preprocess, packets carry the uint16 image"
                                     if sensor else "float vertex maps, packets carry a float camera-z plane"),
                         frames_per_step=world * batch, frames_per_camera_per_exchange=batch,
-                        resident_frames=nframes, key_bin_capacity=capacity, pipelined=pipelined,
+                        resident_frames=nframes, key_bin_capacity=native_capacity if native else capacity,
+                        key_bins="one per (owner, batch), records carry the frame (VH_BIN_PER_BATCH)" if native else "one per (owner, frame)",
+                        key_bin_bytes_per_rank_and_exchange=16 * world * (native_capacity if native else capacity * batch),
+                        pipelined=pipelined,
                         packet_bytes=4 * shard.packet_floats,
                         occupied_blocks_all_ranks=int(stats[0]), allocated_blocks_all_ranks=int(stats[1]),
                         key_bin_overflows=int(stats[2]), voxel_size=wl["voxel"],

@@ -258,22 +258,23 @@ class SDFHashtable:
                 "vh_integrate_packets")
 
     def generate_keys_batch(self, poses16, vert_ptrs, camera_id: int, num_shards: int, bins_out, capacity: int,
-                            packets_out, batch: int):
+                            packets_out, batch: int, per_batch_bins: bool = False):
         """`batch` frames of this camera in one call.  poses16: float32 [batch, 16] (contiguous numpy),
         vert_ptrs: ctypes array of `batch` device addresses; bins_out [num_shards, batch, capacity, 4],
-        packets_out [batch, 32 + W*H] (dense layouts)."""
+        packets_out [batch, 32 + W*H] (dense layouts).  per_batch_bins: bins_out [num_shards, capacity, 4], one bin per
+        shard for the whole batch (VH_BIN_PER_BATCH)."""
         L.check(self._lib.vh_generate_keys_batch(
             self._h, batch, poses16.ctypes.data_as(C.POINTER(C.c_float)), vert_ptrs, camera_id, num_shards,
-            _dev_ptr(bins_out), capacity, 0, 0, _dev_ptr(packets_out), 0), "vh_generate_keys_batch")
+            _dev_ptr(bins_out), capacity, 0, -1 if per_batch_bins else 0, _dev_ptr(packets_out), 0), "vh_generate_keys_batch")
 
     def generate_keys_depth_batch(self, poses16, depth_ptrs, k_inv, camera_id: int, num_shards: int, bins_out,
-                                  capacity: int, packets_out, batch: int):
+                                  capacity: int, packets_out, batch: int, per_batch_bins: bool = False):
         """Keys + sensor-depth packets of `batch` frames from the uint16 images alone (dense layouts)."""
         k = np.ascontiguousarray(np.asarray(k_inv, np.float32).reshape(9))
         L.check(self._lib.vh_generate_keys_depth_batch(
             self._h, batch, poses16.ctypes.data_as(C.POINTER(C.c_float)), depth_ptrs,
-            k.ctypes.data_as(C.POINTER(C.c_float)), camera_id, num_shards, _dev_ptr(bins_out), capacity, 0, 0,
-            _dev_ptr(packets_out), 0), "vh_generate_keys_depth_batch")
+            k.ctypes.data_as(C.POINTER(C.c_float)), camera_id, num_shards, _dev_ptr(bins_out), capacity, 0,
+            -1 if per_batch_bins else 0, _dev_ptr(packets_out), 0), "vh_generate_keys_depth_batch")
 
     def write_packets_u16_batch(self, poses16, depth_ptrs, k_inv, packets_out, batch: int, packet_frame_stride: int = 0):
         """Sensor-depth packets (VH_PACKET_U16) of `batch` frames: depth_ptrs = ctypes array of device
@@ -284,11 +285,13 @@ class SDFHashtable:
             k.ctypes.data_as(C.POINTER(C.c_float)), _dev_ptr(packets_out), packet_frame_stride),
             "vh_write_packets_u16_batch")
 
-    def apply_frames_batch(self, bins, num_bins: int, capacity: int, num_cams: int, packets, batch: int):
-        """Apply `batch` multi-camera frames: bins [num_bins, batch, capacity, 4], packets
-        [num_cams, batch, 32 + W*H] (dense layouts)."""
-        L.check(self._lib.vh_apply_frames_batch(self._h, batch, _dev_ptr(bins), num_bins, capacity, 0, 0, num_cams,
-                                                _dev_ptr(packets), 0, 0), "vh_apply_frames_batch")
+    def apply_frames_batch(self, bins, num_bins: int, capacity: int, num_cams: int, packets, batch: int,
+                           per_batch_bins: bool = False):
+        """Apply `batch` multi-camera frames: bins [num_bins, batch, capacity, 4] (per_batch_bins: [num_bins, capacity, 4]),
+        packets [num_cams, batch, 32 + W*H] (dense layouts)."""
+        L.check(self._lib.vh_apply_frames_batch(self._h, batch, _dev_ptr(bins), num_bins, capacity, 0,
+                                                -1 if per_batch_bins else 0, num_cams, _dev_ptr(packets), 0, 0),
+                "vh_apply_frames_batch")
 
     # ---- model dump / checkpoint ----
     def dump_sdf_text(self, path: str):
