@@ -339,6 +339,9 @@ __device__ __forceinline__ bool beam_slab_occupied(const FrameParams &fp, const 
 #define VH_COOP_K 2
 #endif
 constexpr int kCoopK = VH_COOP_K;
+#ifndef VH_COOP_RESOLVE
+#define VH_COOP_RESOLVE 1    // 1: the set's cells are looked up eight lanes per bucket (0: one lane per cell, slot after slot)
+#endif
 #ifndef VH_DDA_BLOCK_WAVES
 #define VH_DDA_BLOCK_WAVES 4    // waves (pixel patches) per workgroup: 4 = a 16x16 tile, 1 = a patch of its own
 #endif
@@ -594,15 +597,63 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (fail) break;
             if (ra.stamps) stampA = __builtin_amdgcn_s_memrealtime();
-            // ---- 2. the new cells, one per lane: allocated? ----
+            // ---- 2. the new cells: allocated? ----
             const int listBegin = nList;
             const int cellBegin = nCells;
             nCells = __builtin_amdgcn_readfirstlane((int)*count);
+#if VH_COOP_RESOLVE
+            // Wave-cooperative bucket scan: eight lanes per cell, lane j of a group reads slot j (+8, ...) of the cell's bucket,
+            // so a bucket costs one round trip however full it is (getVoxelEntry4Block's slot loop, VoxelUtils.cu:374-381,
+            // turned sideways; keys are unique, so at most one lane of a group matches and it publishes the pointer; the
+            // group's share of the ballot says whether anyone did).  The chain behind the bucket's last slot (:384-411, overflow
+            // list) is a linked list: one lane of the group follows it.
+            for (int cb = cellBegin; cb < nCells; cb += 8) {
+                const int ci = cb + (lane >> 3);
+                const uint32_t sub = (uint32_t)lane & 7u;
+                const bool has = ci < nCells;
+                const int slot = has ? (int)cells[ci] : 0;
+                const uint32_t t = tags[slot] - 1u;
+                const int qx = base0 + (int)(t & 1023u), qy = base1 + (int)((t >> 10) & 1023u), qz = base2 + (int)(t >> 20);
+                const uint32_t myLocal = hash_block(qx, qy, qz, fp.numBuckets) - fp.bucketLo;      // (a set bit: the bucket is this shard's)
+                const uint32_t start = myLocal * fp.bucketSize;
+                bool foundHere = false;
+                for (uint32_t sb = 0; sb < fp.bucketSize; sb += 8u) {
+                    const uint32_t i = sb + sub;
+                    bool match = false;
+                    if (has && i < fp.bucketSize) {
+                        const VoxelEntry e = dp.table[start + i];
+                        match = entry_is(e, qx, qy, qz);
+                        if (match) ptrs[slot] = (uint32_t)e.ptr;
+                    }
+                    foundHere |= ((uint32_t)(__ballot(match) >> (lane & ~7)) & 0xffu) != 0u;
+                }
+                if (has && !foundHere && sub == 0u) {
+                    int ptr = VH_FREE_BLOCK;
+                    if (fp.flags & kFlagOverflow) {
+                        const uint32_t last = start + fp.bucketSize - 1u, n = owned_entries(fp);
+                        uint32_t i = last;
+                        for (uint32_t iter = 0; iter < fp.listSize; ++iter) {                 // :391-392
+                            const VoxelEntry curr = dp.table[i];
+                            if (entry_is(curr, qx, qy, qz)) { ptr = curr.ptr; break; }
+                            if (curr.offset == 0) break;                                      // :396
+                            i = chain_slot(last, curr.offset, n);                             // :398-399
+                        }
+                    }
+                    ptrs[slot] = (uint32_t)ptr;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
             for (int cb = cellBegin; cb < nCells; cb += 64) {
                 const bool todo = cb + lane < nCells;
                 const int slot = todo ? (int)cells[cb + lane] : 0;
                 const uint32_t t = tags[slot] - 1u;
                 const int qx = base0 + (int)(t & 1023u), qy = base1 + (int)((t >> 10) & 1023u), qz = base2 + (int)(t >> 20);
+#if VH_COOP_RESOLVE
+                const int ptr = todo ? (int)ptrs[slot] : VH_FREE_BLOCK;
+#else
                 const uint32_t myLocal = hash_block(qx, qy, qz, fp.numBuckets) - fp.bucketLo;      // (a set bit: the bucket is this shard's)
                 int ptr = VH_FREE_BLOCK;
                 if (todo) {
@@ -620,6 +671,7 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                     }
                     ptrs[slot] = (uint32_t)ptr;
                 }
+#endif
                 // the allocated ones join the wave's list
                 const bool isNew = todo && ptr != VH_FREE_BLOCK;
                 const unsigned long long m = __ballot(isNew);
