@@ -719,13 +719,29 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     native = not getattr(args, "python_exchange", False) and pipelined and dist.get_backend() == "nccl"
     front = torch.cuda.Stream(device=dev)
     import ctypes as C
-    with torch.cuda.stream(stream):
-        if native:
+    native_error = None
+    nd = None
+    if native:
+        # every rank must take the same path: a rank whose library cannot bind RCCL (or whose communicator fails) sends all
+        # of them to the Python host instead of leaving the others waiting in a collective
+        try:
             uid = unique_id(rank, torch_broadcast_bytes())
-            # (key bins: the library's default -- ONE bin per (owner, batch) of 1.5 x batch x W*H/16 / world records)
-            native_capacity = max(2048, (-(-Wd * Ht // 16) * batch * 3 // 2 + world - 1) // world + 1)
             nd = NativeDist(params, Wd, Ht, SEM_PINHOLE, rank, world, batch, uid, sensor_k_inv=k_inv if sensor else None,
                             key_capacity=0, device=local_rank)
+        except Exception as e:          # noqa: BLE001 -- reported in the line
+            native_error = repr(e)
+        ok = torch.tensor([0 if nd is None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if nd is not None:
+                nd.close()
+                nd = None
+            native = False
+            native_error = native_error or "another rank could not create its vh_dist"
+    with torch.cuda.stream(stream):
+        if native:
+            # (key bins: the library's default -- ONE bin per (owner, batch) of 1.5 x batch x W*H/16 / world records)
+            native_capacity = max(2048, (-(-Wd * Ht // 16) * batch * 3 // 2 + world - 1) // world + 1)
 
             class _Shard:          # what the rest of this function reads of a HipShard
                 table, packet_floats = nd.table, (36 + Wd * Ht // 2) if sensor else (32 + Wd * Ht)
@@ -928,7 +944,8 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             windows=len(windows), timed_s=round(sum(windows), 4),
             host_enqueue_ms_per_step=round(1e3 * statistics.median(host_enqueue) / args.steps, 5),
             exchange_host="libvoxelhash_hip.so: vh_dist_step_batch on RCCL directly (include/voxelhash_dist.h)" if native
-            else "Python: dist.ShardedPipeline over torch.distributed collectives (--python-exchange / --no-pipeline)",
+            else "Python: dist.ShardedPipeline over torch.distributed collectives (--python-exchange / --no-pipeline)"
+                 + (f"; the native exchange was not available: {native_error}" if native_error else ""),
             config=dict(workload=f"{'C5' if wl_name == 'C5' else 'C4-style'}: {world} virtual {Wd}x{Ht} cameras (one per GPU) into one scene, "
                                  f"2^{int(math.log2(wl['buckets']))} buckets sharded by bucket range over {world} GPUs, "
                                  "RCCL all-to-all of block keys + all-gather of depth packets per step, PINHOLE; "
