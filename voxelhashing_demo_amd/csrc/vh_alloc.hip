@@ -253,8 +253,11 @@ struct BandWalk {
     __device__ __forceinline__ void init(const FrameParams &fp, const PixelVertex &p)
     {
         nS = band_samples(fp, step);
-        vsR1 = refined_rcp(fp.voxelSize); vsOk = fast_range(fp.voxelSize, 0x1p-40f, 0x1p40f);
-        zR1 = refined_rcp(p.v.z); zOk = fast_range(p.v.z, 0x1p-40f, 0x1p40f);
+        vsR1 = zR1 = 0.0f; vsOk = zOk = false;
+        if (nS > 1) {            // (the reference's frame, one sample per pixel, keeps the plain divisions: nothing to hoist them out of)
+            vsR1 = refined_rcp(fp.voxelSize); vsOk = fast_range(fp.voxelSize, 0x1p-40f, 0x1p40f);
+            zR1 = refined_rcp(p.v.z); zOk = fast_range(p.v.z, 0x1p-40f, 0x1p40f);
+        }
         dda = (fp.flags & kFlagBandDda) && fp.allocBand > 0.0f;
         more = false;
         if (!dda || !p.valid) return;
@@ -316,9 +319,13 @@ struct BandWalk {
             x = p.v.x * scale; y = p.v.y * scale; z = s;
         }
         const float4 g = mat4_mul(fp.T, x, y, z, p.v.w);                 // :622, w as stored
-        FixedDivisor vs(fp.voxelSize);
-        vs.r1 = vsR1; vs.ok = vsOk;
-        const int3_ b = world2block(g.x, g.y, g.z, vs);                  // :636
+        int3_ b;
+        if (nS > 1) {            // (wave-uniform)
+            const FixedDivisor vs(fp.voxelSize, vsR1, vsOk);
+            b = world2block(g.x, g.y, g.z, vs);                          // :636
+        } else {
+            b = world2block(g.x, g.y, g.z, fp.voxelSize);                // :636
+        }
         kx = b.x; ky = b.y; kz = b.z;
         return true;
     }
@@ -378,7 +385,10 @@ __device__ unsigned long long *g_claimStamps = nullptr;
 // latency chain: splitting a tile's samples over two or three workgroups (shorter chains, the vertices read again) made
 // the launch SLOWER (26.2 -> 29.2 -> 33.3 us), and so did fetching the bucket's first slot together with the pending
 // frame's claim word in the drain (24.0 -> 26.1 us: more registers for every role of the fused kernel).
-template <class In>
+// kBand = false: the reference's frame only (one key per pixel; the caller guarantees fp.allocBand == 0): none of the band
+// code is compiled in -- the pipelined kernel is 60 KB of instructions with it, about what a CU's instruction cache holds,
+// and every role of the launch runs a different part of it at the same time
+template <class In, bool kBand = true>
 __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs &dp, const In &in, uint32_t tile,
                                            int candCounter, const Pending &pend = kNoPending,
                                            float *__restrict__ outDepth = nullptr, uint16_t *__restrict__ outRaw = nullptr)
@@ -389,6 +399,26 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
     if (p.v.z == 12345.678f) return;       // (forces the load to complete before the next stamp)
 #endif
     VH_CLAIM_STAMP(1);
+    if (!kBand) {
+        // the surface sample alone: the vertex itself (:622), its block (:636), 2-D wave dedup, frustum test (:673), probe
+        SampleKey s{0, 0, 0, false};
+        if (p.valid) {
+            const float4 g = mat4_mul(fp.T, p.v.x, p.v.y, p.v.z, p.v.w);
+            const int3_ b = world2block(g.x, g.y, g.z, fp.voxelSize);
+            s.kx = b.x; s.ky = b.y; s.kz = b.z;
+        }
+        const int ln = threadIdx.x & (kWave - 1);
+        const unsigned long long wants = __ballot(p.valid);
+        const int lx = __shfl_up(s.kx, 1), ly = __shfl_up(s.ky, 1), lz = __shfl_up(s.kz, 1);
+        const int ux = __shfl_up(s.kx, 16), uy = __shfl_up(s.ky, 16), uz = __shfl_up(s.kz, 16);
+        const bool dupLeft = (ln & 15) != 0 && ((wants >> (ln - 1)) & 1ull) && lx == s.kx && ly == s.ky && lz == s.kz;
+        const bool dupUp = ln >= 16 && ((wants >> (ln - 16)) & 1ull) && ux == s.kx && uy == s.ky && uz == s.kz;
+        if (!p.valid || dupLeft || dupUp || !block_in_frustum(fp, s.kx, s.ky, s.kz)) return;
+        const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
+        if (h < fp.bucketLo || h >= fp.bucketHi) return;                // not this shard's bucket
+        probe_and_claim(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, 0), candCounter, pend);
+        return;
+    }
     BandWalk walk;
     walk.init(fp, p);
     int ox = 0, oy = 0, oz = 0;

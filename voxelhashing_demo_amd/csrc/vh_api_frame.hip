@@ -272,19 +272,26 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     a.claimRatio = claim_ratio(a.claimBlocks, a.claimSpan);
     a.planeNew = (hasNew && !newSensor) ? c->planeBuf[newParity] : nullptr;
     a.rawNew = (hasNew && newSensor) ? c->rawBuf[newParity] : nullptr;
+#ifdef VH_DEBUG_SKIP_ROLES
     a.skipRoles = (uint32_t)c->debugSkipRoles;
+#endif
     const DevPtrs dpNew = pipe_view(c, newParity), dpOld = pipe_view(c, oldParity);
     const dim3 grid(a.commitBlocks + a.integrateBlocks + a.claimBlocks + a.walkBlocks);
     In inNew{};
     if (hasNew) inNew = *in;
+    const bool band = c->fp.allocBand > 0.0f;       // (the new frame's; the pending frame's claims are done)
     if (hasOld && c->pipeSensor) {
         const DepthSensor d{c->rawBuf[oldParity], c->pipeK[0], c->pipeK[1], c->pipeK[2], c->pipeK[3]};
-        rc = launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DepthSensor>, grid, dim3(256), c->fp, dpNew, inNew,
-                    c->pipeFp, dpOld, d, a);
+        rc = band ? launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DepthSensor, true>, grid, dim3(256), c->fp, dpNew, inNew,
+                           c->pipeFp, dpOld, d, a)
+                  : launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DepthSensor, false>, grid, dim3(256), c->fp, dpNew, inNew,
+                           c->pipeFp, dpOld, d, a);
     } else {
         const DepthPlane d{c->planeBuf[oldParity], 1};
-        rc = launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DepthPlane>, grid, dim3(256), c->fp, dpNew, inNew,
-                    c->pipeFp, dpOld, d, a);
+        rc = band ? launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DepthPlane, true>, grid, dim3(256), c->fp, dpNew, inNew,
+                           c->pipeFp, dpOld, d, a)
+                  : launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DepthPlane, false>, grid, dim3(256), c->fp, dpNew, inNew,
+                           c->pipeFp, dpOld, d, a);
     }
     if (rc != VH_OK) return rc;
     if (hasOld) { c->foldA = kPipeScan + a.setOld; c->foldB = kPipeScanB + a.setOld; c->foldNew = kPipeNew + a.setOld; }

@@ -183,6 +183,7 @@ struct FixedDivisor {
     bool ok;
     __device__ __forceinline__ explicit FixedDivisor(float divisor)
         : d(divisor), r1(refined_rcp(divisor)), ok(fast_range(divisor, 0x1p-40f, 0x1p40f)) {}
+    __device__ __forceinline__ FixedDivisor(float divisor, float refined, bool inRange) : d(divisor), r1(refined), ok(inRange) {}
     __device__ __forceinline__ float divide(float n) const
     {
         return (ok && fast_range(n, 0x1p-50f, 0x1p50f)) ? div_fixed(n, d, r1) : n / d;

@@ -153,11 +153,13 @@ struct PipeArgs {
     uint32_t claimSpan, claimRatio;        // claim tiles are interleaved with the first claimSpan - claimBlocks walk tiles
     float *planeNew;                       // private depth copies written by claim(new) ...
     uint16_t *rawNew;
-    uint32_t skipRoles;                    // diagnostics (option "debug_skip_roles"): bit r set = workgroups of role r return at once
+#ifdef VH_DEBUG_SKIP_ROLES
+    uint32_t skipRoles;                    // diagnostics build (option "debug_skip_roles"): bit r set = workgroups of role r return at once
+#endif
                                            // (0 commit, 1 integrate, 2 claim, 3 walk): what the launch costs without them
 };
 
-template <class In, class Depth>
+template <class In, class Depth, bool kBand>
 __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const DevPtrs &dpNew, const In &inNew,
                                                 const FrameParams &fpOld, const DevPtrs &dpOld, const Depth &depthOld,
                                                 const PipeArgs &a)
@@ -194,7 +196,9 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
             role = 3; index = r - a.claimBlocks;
         }
     }
+#ifdef VH_DEBUG_SKIP_ROLES
     if (a.skipRoles & (1u << role)) return;
+#endif
     // first launch of a run (no frame in flight): nobody pops the heap during it, so its first workgroup
     // leaves the free-block count the NEXT launch will test frame i+1's insertions against
     if (!a.hasOld && b == 0u && threadIdx.x == 0) counters[kPipeHeapFree + a.setNew] = counters[kHeapCounter] + 1;
@@ -204,7 +208,7 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
         const Pending pend{a.hasOld ? dpOld.claim : nullptr, dpOld.candidates, fpOld.epoch, live, kPipeWinners + a.setNew};
         if (role == 2u) {
             __builtin_amdgcn_s_setprio(3);
-            claim_tile(fpNew, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
+            claim_tile<In, kBand>(fpNew, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
         } else if (a.walkIndexed) {
             flatten_index_tile(fpNew, dpNew, index, CompactOut{kPipeScan + a.setNew, kPipeScanB + a.setNew, a.numEntries},
                                pend);                                              // (opt-in: not the reference's walk)
@@ -275,12 +279,13 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
     }
 }
 
-template <class In, class Depth>
+// kBand: the new frame allocates a truncation band (vh_set_alloc_band > 0); false = the reference's frame, without the band code
+template <class In, class Depth, bool kBand>
 __global__ __launch_bounds__(256) void frame_pipelined_kernel(const FrameParams fpNew, const DevPtrs dpNew, const In inNew,
                                                               const FrameParams fpOld, const DevPtrs dpOld,
                                                               const Depth depthOld, const PipeArgs a)
 {
-    frame_pipelined(fpNew, dpNew, inNew, fpOld, dpOld, depthOld, a);
+    frame_pipelined<In, Depth, kBand>(fpNew, dpNew, inNew, fpOld, dpOld, depthOld, a);
 }
 
 }  // namespace vh
