@@ -287,7 +287,10 @@ __device__ __forceinline__ uint32_t launch_rank(int x, int y, int width)
 // rest of the epoch even if allocBlocks runs again before the next reset (the reference's mutex is
 // never released within a frame).
 // Layout: epoch 9 bits | 0xfffffffe - rank 32 bits | f 4 bits (buckets of up to 16 slots) | slot 19 bits.
-constexpr uint32_t kClaimSlotBits = 19, kClaimFBits = 4, kClaimRankShift = kClaimSlotBits + kClaimFBits, kClaimEpochShift = kClaimRankShift + 32;
+#ifndef VH_CLAIM_F_BITS
+#define VH_CLAIM_F_BITS 4
+#endif
+constexpr uint32_t kClaimSlotBits = 19, kClaimFBits = VH_CLAIM_F_BITS, kClaimRankShift = kClaimSlotBits + kClaimFBits, kClaimEpochShift = kClaimRankShift + 32;
 constexpr uint32_t kMaxClaimEpoch = (1u << (64 - kClaimEpochShift)) - 1u;      // 511: after that many epochs the words are cleared
 constexpr uint32_t kMaxCandidates = (1u << kClaimSlotBits) - 1u;      // candidate records per lock epoch
 constexpr uint32_t kMaxPipelinedBucket = 1u << kClaimFBits;           // f must name every slot of the bucket
