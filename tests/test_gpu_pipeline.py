@@ -163,6 +163,27 @@ def test_band_allocation_pipelined(oracle, vh, torch_cuda):
     assert len(gt.allocated()) > 500
 
 
+def test_band_switched_between_pipelined_frames(oracle, vh, torch_cuda):
+    """The pipelined launch comes in two builds, with and without the band code; which one runs follows the NEW frame's band,
+    while the half it carries for the pending frame does not depend on it: band on and off from frame to frame."""
+    torch = torch_cuda
+    W, H = 320, 240
+    kw = dict(numBuckets=1 << 14, numVoxelBlocks=1 << 14)
+    ot = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    gt = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
+    gt.set_option("pipeline", 1)
+    frames = room_frames(torch, W, H, (0, 1, 2, 3, 4, 5, 6))
+    for i, (p, v) in enumerate(frames):
+        band = 0.15 if i in (1, 2, 5) else 0.0
+        ot.set_alloc_band(band)
+        gt.set_alloc_band(band)                             # (does not flush: frame i-1's half rides in frame i's launch)
+        gt.integrate(p, torch.from_numpy(v).cuda())
+        ot.integrate(p, v)
+        if i in (2, 6):
+            _compare(ot, gt)
+    assert len(gt.allocated()) > 500
+
+
 def test_heap_shortage_refuses_whole_frames(oracle, vh, torch_cuda):
     """The documented difference: a pipelined frame whose new blocks outnumber the free blocks allocates
     none of them.  Until then the batch equals the oracle; afterwards the model stays consistent, and
