@@ -336,7 +336,7 @@ __device__ __forceinline__ bool beam_slab_occupied(const FrameParams &fp, const 
 // is in the list.  Whenever the preconditions fail -- a box spans more than two blocks on an axis, the set
 // overflows, a block lies more than 511 blocks from the wave's first -- the wave falls back to the per-lane walk.
 #ifndef VH_COOP_K
-#define VH_COOP_K 2
+#define VH_COOP_K 1             // voxels fetched per round trip in the block walk (with 5 waves per SIMD: 1: 35.3 us, 2: 38.1; with 4: 38.9 / 40.6)
 #endif
 constexpr int kCoopK = VH_COOP_K;
 #ifndef VH_COOP_RESOLVE
@@ -441,7 +441,9 @@ __device__ __forceinline__ CoopEntry coop_entry(const DdaAxis (&ax)[3], const in
 #endif
 constexpr int kDdaK = VH_DDA_K;
 #ifndef VH_DDA_WAVES
-#define VH_DDA_WAVES 4      // waves per SIMD the register budget must allow (4 800 waves of a 640x480 view = 4.7 per SIMD; 4 vs 5 vs 6 measured equal: the launch is as long as its slowest wave)
+#define VH_DDA_WAVES 5      // waves per SIMD the register budget must allow.  A 640x480 view is 4 800 waves = 4.7 per SIMD: with 4 resident the
+                            // last 704 start when the first ones end (12-20 us into a 40 us launch); with 5 (96 registers, 6-9 of them spilled
+                            // once the front end had been slimmed) all start at once: 40.6 -> 35.3 us.  6 (80 registers, 30-60 spilled): slower.
 #endif
 
 template <int kPatch, bool kNormals>
