@@ -339,6 +339,9 @@ __device__ __forceinline__ bool beam_slab_occupied(const FrameParams &fp, const 
 #define VH_COOP_K 1             // voxels fetched per round trip in the block walk (with 5 waves per SIMD: 1: 35.3 us, 2: 38.1; with 4: 38.9 / 40.6)
 #endif
 constexpr int kCoopK = VH_COOP_K;
+#ifndef VH_COOP_PRIO
+#define VH_COOP_PRIO 1
+#endif
 #ifndef VH_COOP_RESOLVE
 #define VH_COOP_RESOLVE 1    // 1: the set's cells are looked up eight lanes per bucket (0: one lane per cell, slot after slot)
 #endif
@@ -706,6 +709,14 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                 }
             }
             if (ra.stamps) { stampB = __builtin_amdgcn_s_memrealtime(); coopList = nList; }
+#if VH_COOP_PRIO
+            // The launch is as long as its slowest wave, and the slowest waves are the ones with the longest lists: they get the
+            // issue slots first (s_setprio; 35.6 -> 32.6 us; thresholds 6/4/3, 7/5/3 and 10/7/5 measured the same).
+            {
+                const int n = nList - listBegin;
+                if (n >= 8) __builtin_amdgcn_s_setprio(3); else if (n >= 6) __builtin_amdgcn_s_setprio(2); else if (n >= 4) __builtin_amdgcn_s_setprio(1);
+            }
+#endif
             // ---- 3. every ray against every new block of the list ----
             // (a wave-uniform loop: the block's key and voxel pointer are scalars.  Measured alternative: every ray walking
             // its OWN blocks, one per round -- the busiest ray of a wave enters as many blocks as the wave walks, 2.1 vs 2.2
