@@ -251,8 +251,9 @@ int vh_integrate_depth(vh_context *ctx, const float pose[16], const uint16_t *d_
  * the unpipelined calls.  Results equal the unpipelined frames bit for bit, with one documented
  * difference: a frame whose new blocks outnumber the free blocks of the heap allocates none of them
  * (they count as heap_exhausted and retry), where vh_integrate serves as many as there are blocks.
- * Not combined with "overflow_list", bucketSize > 16 or the persistent walk (flatten_variant 5): those frames run
- * unpipelined.  vh_integrate_batch / vh_integrate_depth_batch: `count` frames (poses: count*16 host
+ * With "overflow_list" the frames are still one launch each, but serialised inside it: the claim and walk workgroups of
+ * the new frame start when the commit phase of the pending one has finished (and that phase serves as many winners as the
+ * heap has blocks, like the unpipelined frame).  bucketSize > 16 and the persistent walk (flatten_variant 5) run unpipelined.  vh_integrate_batch / vh_integrate_depth_batch: `count` frames (poses: count*16 host
  * floats; d_verts / d_normals / d_depth: host arrays of `count` device pointers, d_normals may be NULL)
  * in count + 1 launches -- the pipeline switched on for the call and flushed at its end. */
 int vh_flush(vh_context *ctx);
@@ -390,7 +391,8 @@ int vh_integrate_packets(vh_context *ctx, int32_t num_cams, const float *d_packe
  *               model, like a pipelined single-camera frame.  The packets of the batch's LAST frame must
  *               stay valid and unchanged until then (vh_dist_* keeps three buffer sets for this);
  *   0           two launches per frame ({claim || walk}, {commit + integrate}).
- * Tables with "overflow_list", bucketSize > 16 or a view table always take two launches per frame. */
+ * Tables with bucketSize > 16 and view tables always take two launches per frame; with "overflow_list" the frames of
+ * options 1 and 2 are serialised inside their launch (see the pipelined single-camera frame). */
 int vh_generate_keys_batch(vh_context *ctx, int32_t batch, const float *poses,
                            const vh_float4 *const *d_verts, uint32_t camera_id, int32_t num_shards,
                            int32_t *d_bins, int32_t capacity, int32_t bin_stride, int32_t frame_stride,

@@ -11,15 +11,18 @@ from voxelhashing_demo_amd import synth
 
 pytestmark = pytest.mark.gpu
 I4 = np.eye(4, dtype=np.float32)
-VARIANTS = {"fused-ballot-walk": (1, 3), "four-kernel-persistent-walk": (0, 5), "fused-indexed-walk": (1, 4)}
+VARIANTS = {"fused-ballot-walk": (1, 3), "four-kernel-persistent-walk": (0, 5), "fused-indexed-walk": (1, 4),
+            "pipelined-ballot-walk": (1, 3, 1), "pipelined-indexed-walk": (1, 4, 1)}
 
 
 def pair(oracle, vh, variant, W=640, H=480, sem=0, overflow=True, **kw):
     ot = oracle.OracleTable(oracle.default_params(**kw), W, H, sem)
     gt = vh.SDFHashtable(vh.default_params(**kw), W, H, sem)
-    fused, walk = VARIANTS[variant]
+    fused, walk = VARIANTS[variant][:2]
     gt.set_option("fused_frame", fused)
     gt.set_option("flatten_variant", walk)
+    if len(VARIANTS[variant]) > 2:           # one launch per frame: with the overflow list, serialised inside the launch
+        gt.set_option("pipeline", 1)
     if overflow:
         ot.set_overflow(True)
         gt.set_option("overflow_list", 1)
@@ -51,7 +54,39 @@ def test_overflow_list_collision_scene(oracle, vh, torch_cuda, variant, nb, bs, 
     assert gt.counters()["cand_overflow"] == 0
 
 
-@pytest.mark.parametrize("variant", ["fused-ballot-walk", "four-kernel-persistent-walk"])
+@pytest.mark.parametrize("walk", [3, 4])
+@pytest.mark.parametrize("nb,bs,L,chunk", [(48, 5, 6, 5), (96, 2, 8, 3), (64, 4, 4, 1)])
+def test_overflow_list_pipelined_batches(oracle, vh, torch_cuda, walk, nb, bs, L, chunk):
+    """One launch per frame with the list on: the claim and walk workgroups of frame i+1 wait inside the launch until
+    commit(i) has published its tag, then read the settled table.  Batches without an observer in between (so that
+    commit(i) and claim(i+1) really share launches), the collision scene and then a moving camera."""
+    torch = torch_cuda
+    kw = dict(numBuckets=nb, bucketSize=bs, numVoxelBlocks=1024, attachedLinkedListSize=L)
+    ot = oracle.OracleTable(oracle.default_params(**kw), 640, 480, 1)
+    gt = vh.SDFHashtable(vh.default_params(**kw), 640, 480, 1)
+    ot.set_overflow(True)
+    gt.set_option("overflow_list", 1)
+    gt.set_option("flatten_variant", walk)
+    gt.set_profiling(True)
+    sphere = synth.sphere_inside_scene()
+    from test_gpu_pipeline import room_frames
+    frames = [(I4, sphere)] * 7 + room_frames(torch, 640, 480, (0, 1, 2, 3, 4, 8, 9))
+    refused = 0
+    for s0 in range(0, len(frames), chunk):
+        part = frames[s0:s0 + chunk]
+        gt.integrate_batch([p for p, _ in part], [torch.from_numpy(np.ascontiguousarray(v)).cuda() for _, v in part])
+        for p, v in part:
+            ot.integrate(p, v)
+            refused += ot.last_stats["heap_exhausted"]
+        _compare(ot, gt)
+    chains_ok(oracle, ot)
+    t = gt.kernel_times()
+    assert t["frame_pipelined_ms"] > 0.0 and t["frame_commit_integrate_ms"] == 0.0
+    assert (gt.hash_table()["offset"] != 0).sum() >= 3
+    assert gt.counters()["heap_exhausted"] == refused == 0
+
+
+@pytest.mark.parametrize("variant", ["fused-ballot-walk", "four-kernel-persistent-walk", "pipelined-ballot-walk"])
 def test_overflow_delete_and_collect(oracle, vh, torch_cuda, variant):
     """Deleting heads with followers, chained entries and plain slots; then garbage collection; then
     fusing on -- the table stays equal to the oracle's slot for slot."""
@@ -142,8 +177,8 @@ def test_overflow_raycast_and_snapshot(oracle, vh, torch_cuda, tmp_path):
         again.set_option("overflow_list", 0)
 
 
-@pytest.mark.parametrize("world,calls", [(2, "batched"), (4, "stepwise")])
-def test_overflow_on_shards(oracle, vh, torch_cuda, world, calls):
+@pytest.mark.parametrize("world,calls,batch", [(2, "batched", 1), (4, "stepwise", 1), (2, "batched", 3)])
+def test_overflow_on_shards(oracle, vh, torch_cuda, world, calls, batch):
     """Bucket-range shards with the list on: chains wrap inside a shard; R HIP shards equal ONE oracle
     table whose chains wrap inside segments of the shard size; the raycast over the shards (view
     tables with chains of their own) equals the oracle's raycast of that table."""
@@ -151,7 +186,8 @@ def test_overflow_on_shards(oracle, vh, torch_cuda, world, calls):
     W, H = 160, 120
     kw = dict(numBuckets=512, bucketSize=2, numVoxelBlocks=4096, attachedLinkedListSize=8)
     plan = vdist.ShardPlan(kw["numBuckets"], world)
-    shards = [vdist.HipShard(vh.default_params(**kw), W, H, 1, plan, r, W * H, batched_calls=(calls == "batched"))
+    # (batch 3: multi-camera frames share launches -- commit(b) with claim(b+1), serialised inside the launch by the list)
+    shards = [vdist.HipShard(vh.default_params(**kw), W, H, 1, plan, r, W * H, batch=batch, batched_calls=(calls == "batched"))
               for r in range(world)]
     full = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
     full.set_overflow(True, plan.per_shard)
@@ -159,14 +195,19 @@ def test_overflow_on_shards(oracle, vh, torch_cuda, world, calls):
         sh.table.set_option("overflow_list", 1)
     prims = synth.room_primitives()
     poses = None
-    for step in range(6):
-        cams = []
-        for r in range(world):
-            pose = synth.camera_loop(40, phase=vdist.camera_phase(r, world))[(3 * step) % 40]
-            cams.append((pose, synth.render_room_verts(pose, W, H, prims).numpy()))
-        vdist.loopback_step(shards, [[c[0]] for c in cams], [[torch.from_numpy(c[1]).cuda()] for c in cams])
-        vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
-        poses = [c[0] for c in cams]
+    for step in range(0, 6, batch):
+        frames = []
+        for b in range(batch):
+            cams = []
+            for r in range(world):
+                pose = synth.camera_loop(40, phase=vdist.camera_phase(r, world))[(3 * (step + b)) % 40]
+                cams.append((pose, synth.render_room_verts(pose, W, H, prims).numpy()))
+            frames.append(cams)
+        vdist.loopback_step(shards, [[frames[b][r][0] for b in range(batch)] for r in range(world)],
+                            [[torch.from_numpy(frames[b][r][1]).cuda() for b in range(batch)] for r in range(world)])
+        for cams in frames:
+            vdist.reference_multi_camera_frame(full, [c[0] for c in cams], [c[1] for c in cams])
+        poses = [c[0] for c in frames[-1]]
     ftab, fvol = full.hash_table(), full.sdf_blocks()
     total = 0
     for r, sh in enumerate(shards):

@@ -59,6 +59,7 @@ struct TimedLaunch {
 struct MultiPending {
     bool active = false;
     uint32_t epochOld = 0;
+    int32_t doneTag = 0;                   // what that frame's commit phase publishes (overflow list)
     const float *packetsOld = nullptr;     // the caller's packets of that frame: valid until the half has been launched
     size_t packetStride = 0;
     int32_t numCams = 0;
@@ -104,6 +105,7 @@ struct vh_context {
     int pipeIntegrateGrid = 512;   // workgroups of the deferred TSDF update inside a pipelined launch (4 blocks each per pass)
     bool pipePending = false;      // the commit + TSDF update of the last frame are still to be launched
     FrameParams pipeFp;            // that frame's parameters
+    int32_t pipeDoneTag = 0;       // ... and its tag (lock epochs since creation): what its commit phase publishes (overflow list)
     int pipeSet = 0;               // counter set its claim / walk filled
     int pipeParity = 0;            // which of the two buffer sets it used
     int claimSpanPct = 0;         // option "claim_span": share of the stream workgroups the claim tiles are spread over

@@ -243,7 +243,6 @@ static DevPtrs pipe_view(const vh_context *c, int parity)
 static bool pipeline_applies(const vh_context *c)
 {
     return c->pipeline && c->fusedFrame && (c->flattenVariant == kWalkStridedBallot || c->flattenVariant == kWalkIndexed) &&
-           !(c->fp.flags & kFlagOverflow) &&
            c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks;
 }
 
@@ -272,6 +271,7 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     a.claimRatio = claim_ratio(a.claimBlocks, a.claimSpan);
     a.planeNew = (hasNew && !newSensor) ? c->planeBuf[newParity] : nullptr;
     a.rawNew = (hasNew && newSensor) ? c->rawBuf[newParity] : nullptr;
+    a.doneTag = c->pipeDoneTag;
 #ifdef VH_DEBUG_SKIP_ROLES
     a.skipRoles = (uint32_t)c->debugSkipRoles;
 #endif
@@ -280,24 +280,25 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     In inNew{};
     if (hasNew) inNew = *in;
     const bool band = c->fp.allocBand > 0.0f;       // (the new frame's; the pending frame's claims are done)
+    const bool serial = (c->fp.flags & kFlagOverflow) != 0u;
+#define VH_LAUNCH_PIPELINED(DEPTH, BAND, SERIAL) \
+    launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DEPTH, BAND, SERIAL>, grid, dim3(256), c->fp, dpNew, inNew, c->pipeFp, dpOld, d, a)
     if (hasOld && c->pipeSensor) {
         const DepthSensor d{c->rawBuf[oldParity], c->pipeK[0], c->pipeK[1], c->pipeK[2], c->pipeK[3]};
-        rc = band ? launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DepthSensor, true>, grid, dim3(256), c->fp, dpNew, inNew,
-                           c->pipeFp, dpOld, d, a)
-                  : launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DepthSensor, false>, grid, dim3(256), c->fp, dpNew, inNew,
-                           c->pipeFp, dpOld, d, a);
+        rc = serial ? (band ? VH_LAUNCH_PIPELINED(DepthSensor, true, true) : VH_LAUNCH_PIPELINED(DepthSensor, false, true))
+                    : (band ? VH_LAUNCH_PIPELINED(DepthSensor, true, false) : VH_LAUNCH_PIPELINED(DepthSensor, false, false));
     } else {
         const DepthPlane d{c->planeBuf[oldParity], 1};
-        rc = band ? launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DepthPlane, true>, grid, dim3(256), c->fp, dpNew, inNew,
-                           c->pipeFp, dpOld, d, a)
-                  : launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DepthPlane, false>, grid, dim3(256), c->fp, dpNew, inNew,
-                           c->pipeFp, dpOld, d, a);
+        rc = serial ? (band ? VH_LAUNCH_PIPELINED(DepthPlane, true, true) : VH_LAUNCH_PIPELINED(DepthPlane, false, true))
+                    : (band ? VH_LAUNCH_PIPELINED(DepthPlane, true, false) : VH_LAUNCH_PIPELINED(DepthPlane, false, false));
     }
+#undef VH_LAUNCH_PIPELINED
     if (rc != VH_OK) return rc;
     if (hasOld) { c->foldA = kPipeScan + a.setOld; c->foldB = kPipeScanB + a.setOld; c->foldNew = kPipeNew + a.setOld; }
     if (hasNew) {
         c->pipePending = true;
         c->pipeFp = c->fp;
+        c->pipeDoneTag = (int32_t)(c->epochTotal & 0x7fffffffu) | 0x40000000;      // (never 0, the counter's initial value)
         c->pipeSet = setNew;
         c->pipeParity = newParity;
         c->pipeSensor = newSensor;

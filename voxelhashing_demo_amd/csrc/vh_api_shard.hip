@@ -374,6 +374,7 @@ static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b)
     a.claimSpan = claim_span(c, a.claimBlocks, a.walkBlocks);
     a.claimRatio = claim_ratio(a.claimBlocks, a.claimSpan);
     a.epochOld = mp.epochOld;
+    a.doneTag = mp.doneTag;
     a.packetsOld = mp.packetsOld;
     DevPtrs dpNew = pipe_view(c, newParity);
     dpNew.compactMask = maskOf[newParity];
@@ -382,13 +383,17 @@ static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b)
     a.candCapacityOld = dpOld.candCapacity;
     const dim3 grid(a.commitBlocks + a.integrateBlocks + a.claimBlocks + a.walkBlocks);
     const int format = doNew ? c->packetFormat : mp.packetFormat;
+    const bool serial = (c->fp.flags & kFlagOverflow) != 0u;
     rc = format == VH_PACKET_U16
-             ? launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<true>, grid, dim3(256), c->fp, dpNew, a)
-             : launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<false>, grid, dim3(256), c->fp, dpNew, a);
+             ? (serial ? launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<true, true>, grid, dim3(256), c->fp, dpNew, a)
+                       : launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<true, false>, grid, dim3(256), c->fp, dpNew, a))
+             : (serial ? launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<false, true>, grid, dim3(256), c->fp, dpNew, a)
+                       : launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<false, false>, grid, dim3(256), c->fp, dpNew, a));
     if (rc != VH_OK) return rc;
     if (doNew) {
         mp.active = true;
         mp.epochOld = c->fp.epoch;
+        mp.doneTag = (int32_t)(c->epochTotal & 0x7fffffffu) | 0x40000000;
         mp.packetsOld = a.packetsNew;
         mp.packetStride = mb->packetStride;
         mp.numCams = mb->numCams;
@@ -450,8 +455,9 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
     // b ride in the launch of frame b+1.  pipeline_shards 1: a last launch serves the batch's last frame, B + 1 launches
     // instead of 2 B; 2: that half stays pending across calls (launch_multi_pipelined) and rides in the first launch of
     // the next batch -- B launches -- or in the flush any observer does first.
-    // Same conditions as the single-camera pipeline (no overflow list, bucketSize <= 16, not a view table).
-    if (c->pipelineShards && !(c->fp.flags & kFlagOverflow) && c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks) {
+    // Same conditions as the single-camera pipeline (bucketSize <= 16, not a view table; with the overflow list the frames are
+    // serialised inside the launch).
+    if (c->pipelineShards && c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks) {
         int rc = ensure_pipeline_buffers(c);
         if (rc != VH_OK) return rc;
         if (!c->maskBuf2) VH_HIP(hipMalloc((void **)&c->maskBuf2, sizeof(uint32_t) * c->numEntries));

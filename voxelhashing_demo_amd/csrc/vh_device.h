@@ -56,7 +56,9 @@ enum Counter : int {
     kPipeWinners = 68,     // buckets claimed in the frame = entries its commit phase will insert
     kPipeSetStride = 32,
     kPipeScanB = 64 + 3 * 32,   // list B of the set (a second line per set, kPipeSetStride apart like the first)
-    kNumCounters = 64 + 6 * 32
+    kPipeCommitDone = 64 + 6 * 32,   // overflow list, pipelined: tag of the frame whose commit phase has finished (a line of its own: every
+                                     // claim / walk workgroup of the launch polls it)
+    kNumCounters = 64 + 7 * 32
 };
 
 // Everything a kernel needs about the frame, passed by value in the kernel

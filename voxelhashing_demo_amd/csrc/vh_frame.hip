@@ -153,13 +153,14 @@ struct PipeArgs {
     uint32_t claimSpan, claimRatio;        // claim tiles are interleaved with the first claimSpan - claimBlocks walk tiles
     float *planeNew;                       // private depth copies written by claim(new) ...
     uint16_t *rawNew;
+    int32_t doneTag;                       // overflow list: the pending frame's tag (lock epochs since creation), published when its commit phase ends
 #ifdef VH_DEBUG_SKIP_ROLES
     uint32_t skipRoles;                    // diagnostics build (option "debug_skip_roles"): bit r set = workgroups of role r return at once
 #endif
                                            // (0 commit, 1 integrate, 2 claim, 3 walk): what the launch costs without them
 };
 
-template <class In, class Depth, bool kBand>
+template <class In, class Depth, bool kBand, bool kSerial>
 __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const DevPtrs &dpNew, const In &inNew,
                                                 const FrameParams &fpOld, const DevPtrs &dpOld, const Depth &depthOld,
                                                 const PipeArgs &a)
@@ -171,7 +172,15 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
     // launch does not write.
     const int demandedOld = a.hasOld ? counters[kPipeCand + a.setOld] : 0;
     const int candOld = min(demandedOld, (int)dpOld.candCapacity);
-    const bool live = a.hasOld && counters[kPipeHeapFree + a.setOld] >= counters[kPipeWinners + a.setOld];
+    // With the overflow list an insertion in flight can change a chain link and a slot behind another bucket, which the
+    // claim phase cannot substitute from the claim words alone.  Those frames are serialised INSIDE the launch instead: the
+    // claim and walk workgroups of frame i+1 start when commit(i) has published its tag, and then read the table as it
+    // is -- one launch per frame still, TSDF update(i) still beside walk(i+1); commit(i) serves as many winners as the heap
+    // has blocks, like the unpipelined frame (no whole-frame refusal), and leaves its new entries for walk(i+1) to find.
+    // (kSerial = the context has the list on: a build of its own -- the code of this launch is weighed by the microsecond:
+    // the run-time form of this switch cost the C2 launch 0.7 us)
+    constexpr bool serial = kSerial;
+    const bool live = serial ? a.hasOld != 0u : a.hasOld && counters[kPipeHeapFree + a.setOld] >= counters[kPipeWinners + a.setOld];
     // Roles by workgroup index: [commit][integrate][claim and walk interleaved as in
     // frame_scan_claim_kernel]: frame i's deferred half runs first, at full width, then the table streams.
     // In-process A/B on C2 / C3 (launch time, us): this order with 512 integrate workgroups 18.8 / 88.9; with
@@ -205,7 +214,16 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
     if (role >= 2u) {
         // ---- frame i+1: claim || walk ----
         if (!a.hasNew) return;
-        const Pending pend{a.hasOld ? dpOld.claim : nullptr, dpOld.candidates, fpOld.epoch, live, kPipeWinners + a.setNew};
+        if (serial && a.hasOld) {
+            // (the commit and integrate workgroups have the lowest indices of the grid: they are running or done when this one starts)
+            if (threadIdx.x == 0)
+                while (__hip_atomic_load(counters + kPipeCommitDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.doneTag)
+                    __builtin_amdgcn_s_sleep(8);
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        const Pending pend{a.hasOld && !serial ? dpOld.claim : nullptr, dpOld.candidates, fpOld.epoch, live,
+                           serial ? -1 : kPipeWinners + a.setNew};
         if (role == 2u) {
             __builtin_amdgcn_s_setprio(3);
             claim_tile<In, kBand>(fpNew, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
@@ -242,7 +260,7 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
                     newEntry = e;
                     dpOld.compact[scanOld + atomicAdd(counters + kPipeNew + a.setOld, 1)] = e;
                     // what walk(i+1) would have listed had it seen the entry
-                    if (a.hasNew && block_in_frustum(fpNew, e.pos[0], e.pos[1], e.pos[2]))
+                    if (a.hasNew && !serial && block_in_frustum(fpNew, e.pos[0], e.pos[1], e.pos[2]))
                         dpNew.compact[atomicAdd(counters + kPipeScan + a.setNew, 1)] = e;
                 }
             } else {
@@ -275,17 +293,21 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
             }
             counters[kPipeHeapFree + a.setNew] = atomicAdd(counters + kHeapCounter, 0) + 1;   // what the next launch starts with
             counters[kCommitTicket] = 0;
+            if (serial) {                          // every committer fenced before its ticket: the table is settled
+                __threadfence();
+                __hip_atomic_store(counters + kPipeCommitDone, a.doneTag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
 
 // kBand: the new frame allocates a truncation band (vh_set_alloc_band > 0); false = the reference's frame, without the band code
-template <class In, class Depth, bool kBand>
+template <class In, class Depth, bool kBand, bool kSerial>
 __global__ __launch_bounds__(256) void frame_pipelined_kernel(const FrameParams fpNew, const DevPtrs dpNew, const In inNew,
                                                               const FrameParams fpOld, const DevPtrs dpOld,
                                                               const Depth depthOld, const PipeArgs a)
 {
-    frame_pipelined<In, Depth, kBand>(fpNew, dpNew, inNew, fpOld, dpOld, depthOld, a);
+    frame_pipelined<In, Depth, kBand, kSerial>(fpNew, dpNew, inNew, fpOld, dpOld, depthOld, a);
 }
 
 }  // namespace vh

@@ -242,6 +242,7 @@ struct MultiPipeArgs {
     uint32_t partsPerBin, numBins, numEntries;
     int32_t capacity, binStride, numCams;
     int32_t binFrame;            // >= 0: the bins hold the whole batch, this launch claims the records of that frame
+    int32_t doneTag;             // overflow list: the pending frame's tag, published when its commit phase ends (vh_frame.hip)
     int32_t setNew, setOld, setClear;
     uint32_t hasNew, hasOld;
     uint32_t claimSpan, claimRatio;
@@ -256,19 +257,28 @@ struct MultiPipeArgs {
     uint32_t candCapacityOld;
 };
 
-template <bool kSensor>
+template <bool kSensor, bool kSerial>
 __global__ __launch_bounds__(256) void frame_multi_pipelined_kernel(const FrameParams fp, const DevPtrs dp, const MultiPipeArgs a)
 {
     int32_t *counters = dp.counters;
     const int demandedOld = a.hasOld ? counters[kPipeCand + a.setOld] : 0;
     const int candOld = min(demandedOld, (int)a.candCapacityOld);
-    const bool live = a.hasOld && counters[kPipeHeapFree + a.setOld] >= counters[kPipeWinners + a.setOld];
+    // (overflow list: frames serialised inside the launch, as in frame_pipelined: claim and walk wait for commit(i)'s tag)
+    constexpr bool serial = kSerial;
+    const bool live = serial ? a.hasOld != 0u : a.hasOld && counters[kPipeHeapFree + a.setOld] >= counters[kPipeWinners + a.setOld];
     const uint32_t b = blockIdx.x;
     if (!a.hasOld && b == 0u && threadIdx.x == 0) counters[kPipeHeapFree + a.setNew] = counters[kHeapCounter] + 1;
     if (b >= a.commitBlocks + a.integrateBlocks) {
         // ---- frame i+1: claim its bins || walk the shard for its cameras ----
         if (!a.hasNew) return;
-        const Pending pend{a.hasOld ? a.claimOld : nullptr, a.candOld, a.epochOld, live, kPipeWinners + a.setNew};
+        if (serial && a.hasOld) {
+            if (threadIdx.x == 0)
+                while (__hip_atomic_load(counters + kPipeCommitDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.doneTag)
+                    __builtin_amdgcn_s_sleep(8);
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        const Pending pend{a.hasOld && !serial ? a.claimOld : nullptr, a.candOld, a.epochOld, live, serial ? -1 : kPipeWinners + a.setNew};
         const uint32_t r = b - a.commitBlocks - a.integrateBlocks;
         uint32_t before = a.claimBlocks, after = a.claimBlocks;
         if (r < a.claimSpan) { before = __umulhi(r, a.claimRatio); after = __umulhi(r + 1u, a.claimRatio); }
@@ -312,7 +322,7 @@ __global__ __launch_bounds__(256) void frame_multi_pipelined_kernel(const FrameP
                         a.compactOld[slot] = e;
                         a.maskOld[slot] = seen;
                     }
-                    if (a.hasNew) {                     // ... and what walk(i+1) would have: that walk skipped it
+                    if (a.hasNew && !serial) {          // ... and what walk(i+1) would have: that walk skipped it
                         const uint32_t next = camera_mask(fp, e.pos, a.numCams, a.packetsNew, a.packetStride);
                         if (next != 0u) {
                             const int slot = atomicAdd(counters + kPipeScan + a.setNew, 1);
@@ -352,6 +362,10 @@ __global__ __launch_bounds__(256) void frame_multi_pipelined_kernel(const FrameP
             }
             counters[kPipeHeapFree + a.setNew] = atomicAdd(counters + kHeapCounter, 0) + 1;
             counters[kCommitTicket] = 0;
+            if (serial) {
+                __threadfence();
+                __hip_atomic_store(counters + kPipeCommitDone, a.doneTag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
