@@ -24,6 +24,9 @@ shards = [vdist.HipShard(V.default_params(numBuckets=1 << 20, numVoxelBlocks=1 <
 if len(sys.argv) > 3:
     for sh in shards:
         sh.table.set_option("pipeline_shards", int(sys.argv[3]))      # 0: two launches per multi-camera frame
+if os.environ.get("VH_LEAN") is not None:
+    for sh in shards:
+        sh.table.set_option("lean_kernels", int(os.environ["VH_LEAN"]))
 nf = 64
 poses = [synth.camera_loop(500, phase=vdist.camera_phase(r, R))[:nf] for r in range(R)]
 depth = [[(synth.render_room_verts(p, W, H, prims, device="cuda")[..., 2] * 5000).round().clamp(0, 65535).to(torch.uint16)

@@ -115,6 +115,7 @@ struct vh_context {
     int4 *candBuf[2] = {nullptr, nullptr};
     VoxelEntry *compactBuf[2] = {nullptr, nullptr};
     uint32_t *maskBuf2 = nullptr;          // pipelined multi-camera frames: the camera masks of the second compact buffer
+    int leanKernels = 1;                   // option "lean_kernels": builds of the pipelined launch with the option flags folded in (A/B switch)
     int debugSkipRoles = 0;                // diagnostics: roles of the pipelined launch that return at once (timing only; the model is wrong)
     int pipelineShards = 1;                // option "pipeline_shards": vh_apply_frames_batch runs a batch of B multi-camera frames as B + 1 launches (1) or B (2: the last frame's half stays pending across calls)
     MultiPending multiPend;                // the multi-camera frame whose commit + TSDF update have not been launched yet
@@ -322,6 +323,7 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     if (dev >= ndev) return fail(VH_ERR_INVALID_ARGUMENT, "device ordinal out of range");
 
     vh_context *c = new vh_context();
+    if (const char *e = std::getenv("VOXELHASH_LEAN_KERNELS")) c->leanKernels = std::atoi(e) != 0;      // A/B switch (also option "lean_kernels")
     c->device = dev;
     DeviceGuard guard(dev);
     if (!guard.ok) { delete c; return fail(VH_ERR_NO_DEVICE, "hipSetDevice"); }

@@ -281,17 +281,27 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     if (hasNew) inNew = *in;
     const bool band = c->fp.allocBand > 0.0f;       // (the new frame's; the pending frame's claims are done)
     const bool serial = (c->fp.flags & kFlagOverflow) != 0u;
-#define VH_LAUNCH_PIPELINED(DEPTH, BAND, SERIAL) \
-    launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DEPTH, BAND, SERIAL>, grid, dim3(256), c->fp, dpNew, inNew, c->pipeFp, dpOld, d, a)
+    // the lean builds (vh_frame.hip): no band, no list, the reference's walk, and both frames' option flags exactly the walk's
+    int lean = 0;
+    if (!band && !serial && !a.walkIndexed && c->leanKernels) {
+        const uint32_t fo = hasOld ? c->pipeFp.flags : c->fp.flags;
+        if (c->fp.flags == kFlagWalkShort && fo == kFlagWalkShort) lean = 1;
+        else if (c->fp.flags == (kFlagWalkShort | kFlagWalkNt) && fo == (kFlagWalkShort | kFlagWalkNt)) lean = 2;
+    }
+#define VH_LAUNCH_PIPELINED(DEPTH, BAND, SERIAL, LEAN) \
+    launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DEPTH, BAND, SERIAL, LEAN>, grid, dim3(256), c->fp, dpNew, inNew, c->pipeFp, dpOld, d, a)
+#define VH_LAUNCH_PIPELINED_ANY(DEPTH) \
+    (lean == 1 ? VH_LAUNCH_PIPELINED(DEPTH, false, false, 1) : lean == 2 ? VH_LAUNCH_PIPELINED(DEPTH, false, false, 2) \
+     : serial ? (band ? VH_LAUNCH_PIPELINED(DEPTH, true, true, 0) : VH_LAUNCH_PIPELINED(DEPTH, false, true, 0)) \
+              : (band ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 0) : VH_LAUNCH_PIPELINED(DEPTH, false, false, 0)))
     if (hasOld && c->pipeSensor) {
         const DepthSensor d{c->rawBuf[oldParity], c->pipeK[0], c->pipeK[1], c->pipeK[2], c->pipeK[3]};
-        rc = serial ? (band ? VH_LAUNCH_PIPELINED(DepthSensor, true, true) : VH_LAUNCH_PIPELINED(DepthSensor, false, true))
-                    : (band ? VH_LAUNCH_PIPELINED(DepthSensor, true, false) : VH_LAUNCH_PIPELINED(DepthSensor, false, false));
+        rc = VH_LAUNCH_PIPELINED_ANY(DepthSensor);
     } else {
         const DepthPlane d{c->planeBuf[oldParity], 1};
-        rc = serial ? (band ? VH_LAUNCH_PIPELINED(DepthPlane, true, true) : VH_LAUNCH_PIPELINED(DepthPlane, false, true))
-                    : (band ? VH_LAUNCH_PIPELINED(DepthPlane, true, false) : VH_LAUNCH_PIPELINED(DepthPlane, false, false));
+        rc = VH_LAUNCH_PIPELINED_ANY(DepthPlane);
     }
+#undef VH_LAUNCH_PIPELINED_ANY
 #undef VH_LAUNCH_PIPELINED
     if (rc != VH_OK) return rc;
     if (hasOld) { c->foldA = kPipeScan + a.setOld; c->foldB = kPipeScanB + a.setOld; c->foldNew = kPipeNew + a.setOld; }

@@ -399,6 +399,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
 #ifdef VH_DEBUG_SKIP_ROLES      // diagnostics builds only (make EXTRA=-DVH_DEBUG_SKIP_ROLES): the check costs the product launch a scalar load per workgroup
     if (std::strcmp(name, "debug_skip_roles") == 0 && value >= 0 && value < 16) { c->debugSkipRoles = value; return VH_OK; }
 #endif
+    if (std::strcmp(name, "lean_kernels") == 0) { c->leanKernels = value != 0; return VH_OK; }
     if (std::strcmp(name, "pipeline_shards") == 0) {
         if (value < 0 || value > 2) return fail(VH_ERR_INVALID_ARGUMENT, "pipeline_shards: 0, 1 or 2");
         if (value < 2) { DeviceGuard g(c->device); const int frc = flush_multi_pending(c); if (frc != VH_OK) return frc; }

@@ -302,11 +302,23 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
 }
 
 // kBand: the new frame allocates a truncation band (vh_set_alloc_band > 0); false = the reference's frame, without the band code
-template <class In, class Depth, bool kBand, bool kSerial>
-__global__ __launch_bounds__(256) void frame_pipelined_kernel(const FrameParams fpNew, const DevPtrs dpNew, const In inNew,
-                                                              const FrameParams fpOld, const DevPtrs dpOld,
-                                                              const Depth depthOld, const PipeArgs a)
+// kLean != 0: the option flags of both frames are known when the kernel is BUILT -- 1: only the 4-entries-per-lane walk
+// (the default of a table inside the Infinity Cache), 2: that plus non-temporal walk loads (a table beyond it) -- and the walk
+// is the reference's: everything the flags guard (overflow list, DDA band, TSDF-update variants, the other walk forms) is
+// folded away by the compiler: 3.3 k instead of 6.8 k instructions; same box, same process: C2 18.35 -> 17.57 us, C3 69.4 ->
+// 68.4.  The host picks this build when the context's flags are exactly those.  (Folding the semantics and a bucket size of
+// 5 in as well: C2 17.2 but C3 70.2 -- not done.)
+template <class In, class Depth, bool kBand, bool kSerial, int kLean>
+__global__ __launch_bounds__(256) void frame_pipelined_kernel(FrameParams fpNew, const DevPtrs dpNew, const In inNew,
+                                                              FrameParams fpOld, const DevPtrs dpOld,
+                                                              const Depth depthOld, PipeArgs a)
 {
+    if (kLean != 0) {
+        constexpr uint32_t flags = kLean == 2 ? (kFlagWalkShort | kFlagWalkNt) : kFlagWalkShort;
+        fpNew.flags = flags;
+        fpOld.flags = flags;
+        a.walkIndexed = 0u;
+    }
     frame_pipelined<In, Depth, kBand, kSerial>(fpNew, dpNew, inNew, fpOld, dpOld, depthOld, a);
 }
 
