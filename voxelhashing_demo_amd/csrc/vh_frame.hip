@@ -307,7 +307,8 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
 // is the reference's: everything the flags guard (overflow list, DDA band, TSDF-update variants, the other walk forms) is
 // folded away by the compiler: 3.3 k instead of 6.8 k instructions; same box, same process: C2 18.35 -> 17.57 us, C3 69.4 ->
 // 68.4.  The host picks this build when the context's flags are exactly those.  (Folding the semantics and a bucket size of
-// 5 in as well: C2 17.2 but C3 70.2 -- not done.)
+// 5 in as well: C2 17.2 but C3 70.2; one at a time: the semantics C2 17.9 / C3 68.4, the bucket size 17.8 / 75.2, the shard's
+// bucket range 17.45 / 69.0 against 17.6 / 68.5 -- not done: what the compiler makes of a smaller kernel is not monotone.)
 template <class In, class Depth, bool kBand, bool kSerial, int kLean>
 __global__ __launch_bounds__(256) void frame_pipelined_kernel(FrameParams fpNew, const DevPtrs dpNew, const In inNew,
                                                               FrameParams fpOld, const DevPtrs dpOld,
