@@ -378,10 +378,10 @@ extern "C" int vh_flush(vh_context *c)
 
 // One frame (pose and lock epoch already set): In = where the claim phase reads a pixel's vertex,
 // Depth = where the TSDF update reads a pixel's camera z.  Honours "fused_frame" and "flatten_variant".
-template <int kKind, class In, int kLean = 0>
+template <int kKind, class In>
 static int launch_scan_claim(vh_context *c, const In &in, uint32_t claimBlocks, uint32_t scanBlocks, float *planeOut)
 {
-    return launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kKind, In, kLean>, dim3(claimBlocks + scanBlocks),
+    return launch(c, kPhaseFrameScanClaim, frame_scan_claim_kernel<kKind, In>, dim3(claimBlocks + scanBlocks),
                   dim3(256), c->fp, c->dp, in, (uint32_t)c->numEntries, claimBlocks, c->fusedParity, planeOut,
                   claim_span(c, claimBlocks, scanBlocks), claim_ratio(claimBlocks, claim_span(c, claimBlocks, scanBlocks)));
 }
@@ -425,28 +425,17 @@ static int run_frame(vh_context *c, const In &in, const Depth &depth)
         // map through launch 2 (C3: 72 MB of counter traffic for 40 MB of algorithmic bytes).  In-process A/B:
         // C3 (1.2 M pixels) launch 1 +1.4 us, launch 2 -2.9 us; C2 (0.3 M) +0.7 / -0.1 us: hence the size rule.
         float *plane = (size_t)c->fp.width * c->fp.height >= ((size_t)1 << 20) ? fused_plane(c, in) : nullptr;
-        // (lean builds, vh_frame.hip: no band, the reference's walk, the context's option flags exactly the walk's)
-        const int lean = (!c->leanKernels || c->fp.allocBand > 0.0f || c->flattenVariant != kWalkStridedBallot) ? 0
-                         : c->fp.flags == kFlagWalkShort ? 1 : c->fp.flags == (kFlagWalkShort | kFlagWalkNt) ? 2 : 0;
         if (c->flattenVariant == kWalkIndexed)
             rc = launch_scan_claim<kWalkIndexed>(c, in, claimBlocks, scanBlocks, plane);
         else if (c->flattenVariant == kWalkPersistent)
             rc = launch_scan_claim<kWalkPersistent>(c, in, claimBlocks, scanBlocks, plane);
-        else if (lean == 1)
-            rc = launch_scan_claim<kWalkStridedBallot, In, 1>(c, in, claimBlocks, scanBlocks, plane);
-        else if (lean == 2)
-            rc = launch_scan_claim<kWalkStridedBallot, In, 2>(c, in, claimBlocks, scanBlocks, plane);
         else
             rc = launch_scan_claim<kWalkStridedBallot>(c, in, claimBlocks, scanBlocks, plane);
         if (rc != VH_OK) return rc;
         const uint32_t commitBlocks = (uint32_t)c->commitBlocks;
-        const dim3 grid2(commitBlocks + (uint32_t)c->integrateGrid);
-        rc = lean == 1 ? launch(c, kPhaseFrameCommitIntegrate, frame_commit_integrate_kernel<Depth, 1>, grid2, dim3(256), c->fp, c->dp,
-                                plane_depth(depth, plane), commitBlocks, c->fusedParity)
-           : lean == 2 ? launch(c, kPhaseFrameCommitIntegrate, frame_commit_integrate_kernel<Depth, 2>, grid2, dim3(256), c->fp, c->dp,
-                                plane_depth(depth, plane), commitBlocks, c->fusedParity)
-                       : launch(c, kPhaseFrameCommitIntegrate, frame_commit_integrate_kernel<Depth>, grid2, dim3(256), c->fp, c->dp,
-                                plane_depth(depth, plane), commitBlocks, c->fusedParity);
+        rc = launch(c, kPhaseFrameCommitIntegrate, frame_commit_integrate_kernel<Depth>,
+                    dim3(commitBlocks + (uint32_t)c->integrateGrid), dim3(256), c->fp, c->dp, plane_depth(depth, plane),
+                    commitBlocks, c->fusedParity);
         if (rc != VH_OK) return rc;
         c->foldA = kScanCount + c->fusedParity; c->foldB = kScanCountB + c->fusedParity; c->foldNew = kNewCount + c->fusedParity;
         c->fusedParity ^= 1;       // this frame cleared the other counter set for the next one

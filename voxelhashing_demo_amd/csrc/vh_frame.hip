@@ -19,15 +19,12 @@ namespace vh {
 // planeOut (nullable): the claim half also leaves the camera z of every pixel in a packed float plane
 // for launch 2 to gather from -- 4 bytes per pixel written once here instead of a 16-byte-strided
 // gather from the vertex map there (C3, launch 2: 72 MB of traffic for 40 MB of algorithmic bytes).
-// kLean != 0: no band, and the option flags known at build time (1: the 4-entries-per-lane walk, 2: + non-temporal loads), as
-// in frame_pipelined_kernel below
-template <int kKind, class In, int kLean = 0>
-__global__ __launch_bounds__(256) void frame_scan_claim_kernel(FrameParams fp, const DevPtrs dp, const In in,
+template <int kKind, class In>
+__global__ __launch_bounds__(256) void frame_scan_claim_kernel(const FrameParams fp, const DevPtrs dp, const In in,
                                                                uint32_t numEntries, uint32_t claimBlocks,
                                                                int parity, float *__restrict__ planeOut, uint32_t claimSpan,
                                                                uint32_t claimRatio)
 {
-    if (kLean != 0) fp.flags = kLean == 2 ? (kFlagWalkShort | kFlagWalkNt) : kFlagWalkShort;
     // The two roles are interleaved over the grid in proportion (block b is a claim block when
     // floor((b+1)*claim/total) steps): workgroups are dispatched roughly in index order, and
     // with all claim blocks in front a large image would fill the chip with latency-bound
@@ -46,7 +43,7 @@ __global__ __launch_bounds__(256) void frame_scan_claim_kernel(FrameParams fp, c
         // the latency-bound pixel waves issue first when they are ready, so they are off the compute
         // unit sooner (17.9 -> 17.6 us; raising the streaming waves instead cost 0.25 us)
         __builtin_amdgcn_s_setprio(3);
-        claim_tile<In, kLean == 0>(fp, dp, in, claimBefore, kFusedCand + parity, kNoPending, planeOut);
+        claim_tile(fp, dp, in, claimBefore, kFusedCand + parity, kNoPending, planeOut);
     } else {
         flatten_tile<kKind>(fp, dp, numEntries, blockIdx.x - claimBefore,
                             CompactOut{kScanCount + parity, kScanCountB + parity, numEntries}, total - claimBlocks);
@@ -108,12 +105,11 @@ __device__ __forceinline__ void frame_commit_integrate(const FrameParams &fp, co
     }
 }
 
-template <class Depth, int kLean = 0>
-__global__ __launch_bounds__(256) void frame_commit_integrate_kernel(FrameParams fp, const DevPtrs dp,
+template <class Depth>
+__global__ __launch_bounds__(256) void frame_commit_integrate_kernel(const FrameParams fp, const DevPtrs dp,
                                                                      const Depth verts, uint32_t commitBlocks,
                                                                      int parity)
 {
-    if (kLean != 0) fp.flags = kLean == 2 ? (kFlagWalkShort | kFlagWalkNt) : kFlagWalkShort;
     frame_commit_integrate(fp, dp, verts, commitBlocks, parity);
 }
 
@@ -312,7 +308,8 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
 // folded away by the compiler: 3.3 k instead of 6.8 k instructions; same box, same process: C2 18.35 -> 17.57 us, C3 69.4 ->
 // 68.4.  The host picks this build when the context's flags are exactly those.  (Folding the semantics and a bucket size of
 // 5 in as well: C2 17.2 but C3 70.2; one at a time: the semantics C2 17.9 / C3 68.4, the bucket size 17.8 / 75.2, the shard's
-// bucket range 17.45 / 69.0 against 17.6 / 68.5 -- not done: what the compiler makes of a smaller kernel is not monotone.)
+// bucket range 17.45 / 69.0 against 17.6 / 68.5 -- not done: what the compiler makes of a smaller kernel is not monotone.
+// The same builds of the two-launch kernels: no difference (C2 16.27 + 4.45 us either way, C3 63.0 + 11.7 / 63.4 + 11.4).)
 template <class In, class Depth, bool kBand, bool kSerial, int kLean>
 __global__ __launch_bounds__(256) void frame_pipelined_kernel(FrameParams fpNew, const DevPtrs dpNew, const In inNew,
                                                               FrameParams fpOld, const DevPtrs dpOld,
