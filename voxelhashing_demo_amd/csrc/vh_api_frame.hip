@@ -283,7 +283,7 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     const bool serial = (c->fp.flags & kFlagOverflow) != 0u;
     // the lean builds (vh_frame.hip): no band, no list, the reference's walk, and both frames' option flags exactly the walk's
     int lean = 0;
-    if (!band && !serial && !a.walkIndexed && c->leanKernels) {
+    if (!serial && !a.walkIndexed && c->leanKernels) {      // (with a band: the ray band only -- kFlagBandDda is a flag like the others)
         const uint32_t fo = hasOld ? c->pipeFp.flags : c->fp.flags;
         if (c->fp.flags == kFlagWalkShort && fo == kFlagWalkShort) lean = 1;
         else if (c->fp.flags == (kFlagWalkShort | kFlagWalkNt) && fo == (kFlagWalkShort | kFlagWalkNt)) lean = 2;
@@ -291,7 +291,8 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
 #define VH_LAUNCH_PIPELINED(DEPTH, BAND, SERIAL, LEAN) \
     launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DEPTH, BAND, SERIAL, LEAN>, grid, dim3(256), c->fp, dpNew, inNew, c->pipeFp, dpOld, d, a)
 #define VH_LAUNCH_PIPELINED_ANY(DEPTH) \
-    (lean == 1 ? VH_LAUNCH_PIPELINED(DEPTH, false, false, 1) : lean == 2 ? VH_LAUNCH_PIPELINED(DEPTH, false, false, 2) \
+    (lean == 1 ? (band ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 1) : VH_LAUNCH_PIPELINED(DEPTH, false, false, 1)) \
+     : lean == 2 ? (band ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 2) : VH_LAUNCH_PIPELINED(DEPTH, false, false, 2)) \
      : serial ? (band ? VH_LAUNCH_PIPELINED(DEPTH, true, true, 0) : VH_LAUNCH_PIPELINED(DEPTH, false, true, 0)) \
               : (band ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 0) : VH_LAUNCH_PIPELINED(DEPTH, false, false, 0)))
     if (hasOld && c->pipeSensor) {
