@@ -495,9 +495,13 @@ __global__ __launch_bounds__(256) void alloc_claim_kernel(const FrameParams fp, 
 #define VH_GEN_THREADS 1024
 #endif
 constexpr int kGenThreads = VH_GEN_THREADS;   // tuning knob (make EXTRA=-DVH_GEN_THREADS=n); a multiple of 256
+// The batched kernels choose between this and half of it by the number of owners: what bounds them is the returning atomic on
+// the bin headers (~90 per microsecond and address).  One owner: every workgroup of the batch hits ONE word, so fewer, larger
+// workgroups win (8 frames of 640x480: 38.9 us with 1024 lanes, 60 with 512, 110 with 256); eight owners: the words share the
+// load and shorter chains win (38.4 / 28.3 / 33.6 us).
 constexpr int kGenTiles = kGenThreads / 256;
 
-template <class In>
+template <class In, int kThreads = kGenThreads>
 __device__ __forceinline__ void generate_keys_tile(const FrameParams &fp, const In &verts,
                                                    int32_t numShards, int4 *__restrict__ outBins,
                                                    int32_t outCapacity, int32_t outBinStride,
@@ -505,7 +509,7 @@ __device__ __forceinline__ void generate_keys_tile(const FrameParams &fp, const 
 {
     __shared__ int ldsCount[VH_MAX_CAMERAS];
     __shared__ int ldsBase[VH_MAX_CAMERAS];
-    const PixelVertex p = load_pixel(fp, verts, group * kGenTiles + (threadIdx.x >> 8), threadIdx.x & 255u, outDepth);
+    const PixelVertex p = load_pixel(fp, verts, group * (kThreads / 256) + (threadIdx.x >> 8), threadIdx.x & 255u, outDepth);
     BandWalk walk;
     walk.init(fp, p);
     const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
@@ -559,7 +563,8 @@ struct GenFrames {
     const float4 *verts[kGenBatch];
 };
 
-__global__ __launch_bounds__(kGenThreads) void generate_keys_batch_kernel(FrameParams fp, const GenFrames fr,
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void generate_keys_batch_kernel(FrameParams fp, const GenFrames fr,
                                                                           int32_t numShards,
                                                                           int4 *__restrict__ outBins,
                                                                           int32_t outCapacity, int32_t outBinStride,
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_batch_kernel(FrameP
 #pragma unroll
     for (int i = 0; i < 16; ++i) { fp.T[i] = fr.T[b][i]; fp.Tinv[i] = fr.Tinv[b][i]; }
     // (frameStride < 0: one bin per owner for the whole batch; rankBase then carries the frame index where the camera id sits)
-    generate_keys_tile(fp, VertexMap{fr.verts[b], nullptr}, numShards, frameStride < 0 ? outBins : outBins + (size_t)frameStride * b,
+    generate_keys_tile<VertexMap, kThreads>(fp, VertexMap{fr.verts[b], nullptr}, numShards, frameStride < 0 ? outBins : outBins + (size_t)frameStride * b,
                        outCapacity, outBinStride, outDepth,
                        frameStride < 0 ? rankBase + ((uint32_t)b << kRankCameraShift) : rankBase, blockIdx.x);
 }
@@ -592,7 +597,8 @@ struct GenSensorFrames {
     float unit;
 };
 
-__global__ __launch_bounds__(kGenThreads) void generate_keys_sensor_batch_kernel(FrameParams fp, const GenSensorFrames fr,
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void generate_keys_sensor_batch_kernel(FrameParams fp, const GenSensorFrames fr,
                                                                                  int32_t numShards,
                                                                                  int4 *__restrict__ outBins,
                                                                                  int32_t outCapacity,
@@ -616,12 +622,12 @@ __global__ __launch_bounds__(kGenThreads) void generate_keys_sensor_batch_kernel
                                                                                   : t == 34 ? fr.k[8] : fr.unit;
         }
         // straight copy of the image, one pixel per lane (the grid covers ceil(tiles/4)*1024 >= W*H lanes)
-        const int idx = blockIdx.x * kGenThreads + threadIdx.x;
+        const int idx = blockIdx.x * kThreads + threadIdx.x;
         if (idx < fp.width * fp.height) reinterpret_cast<uint16_t *>(pk + kPacketHeaderU16)[idx] = in.depth[idx];
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) { fp.T[i] = fr.T[b][i]; fp.Tinv[i] = fr.Tinv[b][i]; }
-    generate_keys_tile(fp, in, numShards, frameStride < 0 ? outBins : outBins + (size_t)frameStride * b, outCapacity, outBinStride,
+    generate_keys_tile<SensorImage, kThreads>(fp, in, numShards, frameStride < 0 ? outBins : outBins + (size_t)frameStride * b, outCapacity, outBinStride,
                        nullptr, frameStride < 0 ? rankBase + ((uint32_t)b << kRankCameraShift) : rankBase, blockIdx.x);
 }
 

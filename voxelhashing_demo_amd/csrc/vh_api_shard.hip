@@ -236,7 +236,13 @@ extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float 
             std::memcpy(fr.Tinv[j], c->fp.Tinv, sizeof fr.Tinv[j]);
             fr.verts[j] = reinterpret_cast<const float4 *>(d_verts[b0 + j]);
         }
-        generate_keys_batch_kernel<<<dim3((unsigned)grid_for(host_num_tiles(c), kGenTiles), (unsigned)n), kGenThreads, 0, c->stream>>>(
+        if (num_shards >= 4)
+            generate_keys_batch_kernel<kGenThreads / 2><<<dim3((unsigned)grid_for(host_num_tiles(c), kGenTiles / 2), (unsigned)n), kGenThreads / 2, 0, c->stream>>>(
+            c->fp, fr, num_shards, perBatch ? reinterpret_cast<int4 *>(d_bins) : reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
+            perBatch ? -1 : frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
+            perBatch ? (uint32_t)b0 << kRankCameraShift : camera_id << kRankCameraShift);
+        else
+            generate_keys_batch_kernel<kGenThreads><<<dim3((unsigned)grid_for(host_num_tiles(c), kGenTiles), (unsigned)n), kGenThreads, 0, c->stream>>>(
             c->fp, fr, num_shards, perBatch ? reinterpret_cast<int4 *>(d_bins) : reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
             perBatch ? -1 : frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
             perBatch ? (uint32_t)b0 << kRankCameraShift : camera_id << kRankCameraShift);
@@ -285,8 +291,15 @@ extern "C" int vh_generate_keys_depth_batch(vh_context *c, int32_t batch, const 
             std::memcpy(fr.Tinv[j], c->fp.Tinv, sizeof fr.Tinv[j]);
             fr.depth[j] = d_depth[b0 + j];
         }
-        generate_keys_sensor_batch_kernel<<<dim3((unsigned)grid_for(host_num_tiles(c), kGenTiles), (unsigned)n), kGenThreads, 0,
-                                            c->stream>>>(
+        if (num_shards >= 4)
+            generate_keys_sensor_batch_kernel<kGenThreads / 2><<<dim3((unsigned)grid_for(host_num_tiles(c), kGenTiles / 2), (unsigned)n), kGenThreads / 2, 0,
+                                                                 c->stream>>>(
+            c->fp, fr, num_shards, perBatch ? reinterpret_cast<int4 *>(d_bins) : reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
+            perBatch ? -1 : frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
+            perBatch ? (uint32_t)b0 << kRankCameraShift : camera_id << kRankCameraShift);
+        else
+            generate_keys_sensor_batch_kernel<kGenThreads><<<dim3((unsigned)grid_for(host_num_tiles(c), kGenTiles), (unsigned)n), kGenThreads, 0,
+                                                             c->stream>>>(
             c->fp, fr, num_shards, perBatch ? reinterpret_cast<int4 *>(d_bins) : reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
             perBatch ? -1 : frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
             perBatch ? (uint32_t)b0 << kRankCameraShift : camera_id << kRankCameraShift);
