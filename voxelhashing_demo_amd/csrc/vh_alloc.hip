@@ -540,6 +540,57 @@ __device__ __forceinline__ void generate_keys_tile(const FrameParams &fp, const 
     }
 }
 
+// The reference's frame (one key per pixel, fp.allocBand == 0) with kGroups pixel groups per workgroup: the keys of all groups
+// are counted in LDS first and the workgroup takes ONE global atomicAdd per owner for all of them -- the returning atomics on
+// the bin headers are what bounds the launch (above), and this divides their number by kGroups.
+template <class In, int kThreads, int kGroups>
+__device__ __forceinline__ void generate_keys_groups(const FrameParams &fp, const In &verts, int32_t numShards,
+                                                     int4 *__restrict__ outBins, int32_t outCapacity, int32_t outBinStride,
+                                                     float *__restrict__ outDepth, uint32_t rankBase, uint32_t firstGroup)
+{
+    __shared__ int ldsCount[VH_MAX_CAMERAS];
+    __shared__ int ldsBase[VH_MAX_CAMERAS];
+    if (threadIdx.x < VH_MAX_CAMERAS) ldsCount[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
+    const int ln = threadIdx.x & (kWave - 1);
+    int4 rec[kGroups];
+    int where[kGroups];                       // owner << 20 | index among the workgroup's keys for that owner; -1: no key
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+        const PixelVertex p = load_pixel(fp, verts, (firstGroup + (uint32_t)g) * (kThreads / 256) + (threadIdx.x >> 8), threadIdx.x & 255u, outDepth);
+        int kx = 0, ky = 0, kz = 0;
+        if (p.valid) {
+            const float4 w = mat4_mul(fp.T, p.v.x, p.v.y, p.v.z, p.v.w);               // :622
+            const int3_ b = world2block(w.x, w.y, w.z, fp.voxelSize);                   // :636
+            kx = b.x; ky = b.y; kz = b.z;
+        }
+        const unsigned long long wants = __ballot(p.valid);
+        const int lx = __shfl_up(kx, 1), ly = __shfl_up(ky, 1), lz = __shfl_up(kz, 1);
+        const int ux = __shfl_up(kx, 16), uy = __shfl_up(ky, 16), uz = __shfl_up(kz, 16);
+        const bool dupLeft = (ln & 15) != 0 && ((wants >> (ln - 1)) & 1ull) && lx == kx && ly == ky && lz == kz;
+        const bool dupUp = ln >= 16 && ((wants >> (ln - 16)) & 1ull) && ux == kx && uy == ky && uz == kz;
+        where[g] = -1;
+        if (p.valid && !dupLeft && !dupUp && block_in_frustum(fp, kx, ky, kz)) {          // :673
+            const uint32_t owner = hash_block(kx, ky, kz, fp.numBuckets) / perShard;
+            where[g] = (int)(owner << 20) | atomicAdd(&ldsCount[owner], 1);
+            rec[g] = make_int4(kx, ky, kz, (int)(rankBase + sample_rank(p, 0)));
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < numShards && ldsCount[threadIdx.x] > 0)
+        ldsBase[threadIdx.x] = atomicAdd(&outBins[(size_t)threadIdx.x * outBinStride].x, ldsCount[threadIdx.x]);
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+        if (where[g] >= 0) {
+            const uint32_t owner = (uint32_t)where[g] >> 20;
+            const int slot = ldsBase[owner] + (where[g] & 0xfffff) + 1;                    // record 0 = {count,0,0,0}
+            if (slot < outCapacity) outBins[(size_t)owner * outBinStride + slot] = rec[g];
+        }
+    }
+}
+
 __global__ __launch_bounds__(kGenThreads) void generate_keys_kernel(const FrameParams fp,
                                                                     const float4 *__restrict__ verts,
                                                                     int32_t numShards, int4 *__restrict__ outBins,
@@ -597,7 +648,7 @@ struct GenSensorFrames {
     float unit;
 };
 
-template <int kThreads>
+template <int kThreads, int kGroups = 0>        // kGroups > 0: no band (the caller checks), kGroups pixel groups per workgroup
 __global__ __launch_bounds__(kThreads) void generate_keys_sensor_batch_kernel(FrameParams fp, const GenSensorFrames fr,
                                                                                  int32_t numShards,
                                                                                  int4 *__restrict__ outBins,
@@ -622,13 +673,18 @@ __global__ __launch_bounds__(kThreads) void generate_keys_sensor_batch_kernel(Fr
                                                                                   : t == 34 ? fr.k[8] : fr.unit;
         }
         // straight copy of the image, one pixel per lane (the grid covers ceil(tiles/4)*1024 >= W*H lanes)
-        const int idx = blockIdx.x * kThreads + threadIdx.x;
-        if (idx < fp.width * fp.height) reinterpret_cast<uint16_t *>(pk + kPacketHeaderU16)[idx] = in.depth[idx];
+#pragma unroll
+        for (int g = 0; g < (kGroups > 0 ? kGroups : 1); ++g) {
+            const int idx = (blockIdx.x * (kGroups > 0 ? kGroups : 1) + g) * kThreads + threadIdx.x;
+            if (idx < fp.width * fp.height) reinterpret_cast<uint16_t *>(pk + kPacketHeaderU16)[idx] = in.depth[idx];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) { fp.T[i] = fr.T[b][i]; fp.Tinv[i] = fr.Tinv[b][i]; }
-    generate_keys_tile<SensorImage, kThreads>(fp, in, numShards, frameStride < 0 ? outBins : outBins + (size_t)frameStride * b, outCapacity, outBinStride,
-                       nullptr, frameStride < 0 ? rankBase + ((uint32_t)b << kRankCameraShift) : rankBase, blockIdx.x);
+    int4 *bins = frameStride < 0 ? outBins : outBins + (size_t)frameStride * b;
+    const uint32_t base = frameStride < 0 ? rankBase + ((uint32_t)b << kRankCameraShift) : rankBase;
+    if (kGroups > 0) generate_keys_groups<SensorImage, kThreads, (kGroups > 0 ? kGroups : 1)>(fp, in, numShards, bins, outCapacity, outBinStride, nullptr, base, blockIdx.x * (uint32_t)kGroups);
+    else generate_keys_tile<SensorImage, kThreads>(fp, in, numShards, bins, outCapacity, outBinStride, nullptr, base, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------

@@ -253,6 +253,26 @@ extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float 
 
 // Keys and sensor-depth packets of `batch` frames of this camera from the uint16 images alone: one
 // launch per kGenBatch frames (no vertex map, no separate packet pass).
+template <int kThreads, int kGroups>
+static void launch_gen_sensor(vh_context *c, int n, const GenSensorFrames &fr, int32_t numShards, int4 *bins, int32_t capacity,
+                              int32_t binStride, int32_t frameStride, float *packets, size_t packetFrameStride, uint32_t rankBase)
+{
+    const unsigned perGroup = (unsigned)(kThreads / 256) * (unsigned)(kGroups > 0 ? kGroups : 1);
+    generate_keys_sensor_batch_kernel<kThreads, kGroups><<<dim3((unsigned)grid_for(host_num_tiles(c), perGroup), (unsigned)n), kThreads, 0, c->stream>>>(
+        c->fp, fr, numShards, bins, capacity, binStride, frameStride, packets, packetFrameStride, rankBase);
+}
+
+#ifndef VH_GEN_THREADS_ONE
+#define VH_GEN_THREADS_ONE (kGenThreads / 2)
+#endif
+#ifndef VH_GEN_GROUPS_ONE
+#define VH_GEN_GROUPS_ONE 8        // pixel groups per key-generation workgroup, fewer than four owners (R = 1, batch of 8: 35.7 us;
+                                   // 1024 lanes x 2 / 4 / 8 groups 38.2 / 38.7 / 41.5, 512 x 4 39.0, 256 x 8 / 16 37.1 / 43.6)
+#endif
+#ifndef VH_GEN_GROUPS_MANY
+#define VH_GEN_GROUPS_MANY 2       // ... four owners or more (512-lane workgroups; R = 8: 23.6 us with 1, 2 or 4 groups -- most of the
+                                   // step from 28.1 is the band code this path does not carry)
+#endif
 extern "C" int vh_generate_keys_depth_batch(vh_context *c, int32_t batch, const float *poses,
                                             const uint16_t *const *d_depth, const float k_inv[9], uint32_t camera_id,
                                             int32_t num_shards, int32_t *d_bins, int32_t capacity, int32_t bin_stride,
@@ -291,18 +311,16 @@ extern "C" int vh_generate_keys_depth_batch(vh_context *c, int32_t batch, const 
             std::memcpy(fr.Tinv[j], c->fp.Tinv, sizeof fr.Tinv[j]);
             fr.depth[j] = d_depth[b0 + j];
         }
-        if (num_shards >= 4)
-            generate_keys_sensor_batch_kernel<kGenThreads / 2><<<dim3((unsigned)grid_for(host_num_tiles(c), kGenTiles / 2), (unsigned)n), kGenThreads / 2, 0,
-                                                                 c->stream>>>(
-            c->fp, fr, num_shards, perBatch ? reinterpret_cast<int4 *>(d_bins) : reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
-            perBatch ? -1 : frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
-            perBatch ? (uint32_t)b0 << kRankCameraShift : camera_id << kRankCameraShift);
-        else
-            generate_keys_sensor_batch_kernel<kGenThreads><<<dim3((unsigned)grid_for(host_num_tiles(c), kGenTiles), (unsigned)n), kGenThreads, 0,
-                                                             c->stream>>>(
-            c->fp, fr, num_shards, perBatch ? reinterpret_cast<int4 *>(d_bins) : reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
-            perBatch ? -1 : frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
-            perBatch ? (uint32_t)b0 << kRankCameraShift : camera_id << kRankCameraShift);
+        // no band: several pixel groups per workgroup, one atomic per owner for all of them (vh_alloc.hip)
+        int4 *bins0 = perBatch ? reinterpret_cast<int4 *>(d_bins) : reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0;
+        float *pk0 = d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr;
+        const uint32_t rank0 = perBatch ? (uint32_t)b0 << kRankCameraShift : camera_id << kRankCameraShift;
+        const int fs = perBatch ? -1 : frame_stride;
+        const bool band = c->fp.allocBand > 0.0f, many = num_shards >= 4;
+        if (band && many) launch_gen_sensor<kGenThreads / 2, 0>(c, n, fr, num_shards, bins0, capacity, bin_stride, fs, pk0, packet_frame_stride, rank0);
+        else if (band) launch_gen_sensor<kGenThreads, 0>(c, n, fr, num_shards, bins0, capacity, bin_stride, fs, pk0, packet_frame_stride, rank0);
+        else if (many) launch_gen_sensor<kGenThreads / 2, VH_GEN_GROUPS_MANY>(c, n, fr, num_shards, bins0, capacity, bin_stride, fs, pk0, packet_frame_stride, rank0);
+        else launch_gen_sensor<VH_GEN_THREADS_ONE, VH_GEN_GROUPS_ONE>(c, n, fr, num_shards, bins0, capacity, bin_stride, fs, pk0, packet_frame_stride, rank0);
     }
     VH_HIP(hipGetLastError());
     return VH_OK;
