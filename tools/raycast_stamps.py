@@ -48,6 +48,12 @@ for k in (0, 35, 77):
                 print(f"      {name} ({int(m.sum())}): set built after {tA[m].mean():.2f}, list after {tB[m].mean():.2f}, life {life[m].mean():.2f} us; "
                       f"list {s[m, 6].mean():.1f}; after the list: {((life[m] - tB[m]) / np.maximum(1, s[m, 6])).mean():.2f} us per listed block")
         print(f'      ray set-up done after {((s[:, 2] & 0xffffffff) / 100.0).mean():.2f} us')
+        # what sharing the listed blocks inside a 16x16 tile (4 waves) could give: a tile as long as its waves' mean, not their max
+        t4 = life.reshape(-1, 4); f4 = tB.reshape(-1, 4)
+        walk4 = (t4 - f4)
+        shared = f4.max(axis=1) + walk4.mean(axis=1)
+        print(f"      tiles: slowest wave per tile mean {t4.max(axis=1).mean():.1f} max {t4.max(axis=1).max():.1f} us; with the walks of a tile shared evenly: "
+              f"mean {shared.mean():.1f} max {shared.max():.1f} us; the ten slowest tiles now {np.sort(t4.max(axis=1))[-10:].round(1).tolist()} shared {np.sort(shared)[-10:].round(1).tolist()}")
         slow = np.argsort(-life)[:6]
         print("   slowest waves: (life, list, walked)", [(round(float(life[i]), 1), int(s[i, 6]), int(s[i, 7])) for i in slow])
     ok = rounds > 0
