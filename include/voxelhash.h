@@ -324,7 +324,9 @@ int vh_debug_set_raycast_stamps(vh_context *ctx, void *d_stamps);
  * "commit_blocks", "persistent_blocks", "raycast_patch", "raycast_xcd", "walk_nt" (non-temporal loads in
  * the table walk; on by default when the table exceeds the 256 MiB Infinity Cache), "claim_span" (percent
  * of a launch's claim + walk workgroups the claim tiles are spread over; 0 = by the size rule), "walk_entries"
- * (4 or 8 table entries per lane of the frame's walk; default 4).  They apply to vh_integrate and
+ * (4 or 8 table entries per lane of the frame's walk; default 4), "lean_kernels" (1, default: the pipelined launch
+ * runs the build that has the context's option flags folded in when such a build exists; 0: always the generic
+ * build; environment VOXELHASH_LEAN_KERNELS overrides the default at vh_create).  They apply to vh_integrate and
  * vh_integrate_depth alike.  "cand_capacity" shrinks the candidate list (test hook for
  * vh_counters.cand_overflow).  Format switch: "packet_format" (VH_PACKET_F32 / VH_PACKET_U16, below). */
 int vh_set_option(vh_context *ctx, const char *name, int value);
