@@ -163,6 +163,27 @@ def test_band_allocation_pipelined(oracle, vh, torch_cuda):
     assert len(gt.allocated()) > 500
 
 
+@pytest.mark.parametrize("band", [0.0, 0.15])
+def test_generic_and_lean_builds_of_the_pipelined_launch(oracle, vh, torch_cuda, band):
+    """The pipelined launch has builds with the context's option flags folded in (the default when such a build exists)
+    and the generic one (option lean_kernels 0): the same frames through both, switched in the middle of a run."""
+    torch = torch_cuda
+    W, H = 320, 240
+    kw = dict(numBuckets=1 << 14, numVoxelBlocks=1 << 14)
+    ot = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    gt = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
+    gt.set_option("pipeline", 1)
+    ot.set_alloc_band(band)
+    gt.set_alloc_band(band)
+    for i, (p, v) in enumerate(room_frames(torch, W, H, (0, 1, 2, 3, 4, 5, 6, 7))):
+        gt.set_option("lean_kernels", 0 if i in (2, 3, 6) else 1)        # (no flush: the pending half rides in the other build's launch)
+        gt.integrate(p, torch.from_numpy(v).cuda())
+        ot.integrate(p, v)
+        if i in (3, 7):
+            _compare(ot, gt)
+    assert len(gt.allocated()) > 200
+
+
 def test_band_switched_between_pipelined_frames(oracle, vh, torch_cuda):
     """The pipelined launch comes in two builds, with and without the band code; which one runs follows the NEW frame's band,
     while the half it carries for the pending frame does not depend on it: band on and off from frame to frame."""
