@@ -277,7 +277,10 @@ int vh_integrate_depth_batch(vh_context *ctx, int32_t count, const float *poses,
  * vh_raycast_normals (DDA only) also writes, in the same pass, the normal of every hit: the TSDF gradient at
  * the second voxel of the pair (central differences where both neighbours are valid, one-sided otherwise),
  * normalised, in the CAMERA frame with w = 0 (the convention of calculateNormals, CameraTrackingUtils.cu:
- * 75-113); zeros for a miss or when an axis has no valid neighbour. */
+ * 75-113); zeros for a miss or when an axis has no valid neighbour.
+ * How the DDA is executed does not change a bit of the image; option "raycast_beam" picks the form: 2 = one block
+ * list per 8x8-pixel wave, 1 = a walk per ray behind a per-wave beam front end, 0 = a walk per ray from t_min,
+ * 3 (default) = by the view: 2 when 64 half-block slabs span [t_min, t_max] (coarse voxels), else 1. */
 #define VH_RAYCAST_FIXED_STEP 0
 #define VH_RAYCAST_DDA        1
 int vh_raycast(vh_context *ctx, const float pose[16], float t_min, float t_max,

@@ -29,7 +29,7 @@ def _room(oracle, vh, torch, W, H, voxel, buckets, blocks, frames):
     return ot, gt, poses
 
 
-@pytest.mark.parametrize("beam", [2, 1, 0])
+@pytest.mark.parametrize("beam", [2, 1, 0, 3])              # (3 = chosen by the view, the default)
 def test_every_form_of_the_kernel_equals_the_oracle(oracle, vh, torch_cuda, beam):
     torch = torch_cuda
     W, H = 640, 480
@@ -93,7 +93,7 @@ def test_views_the_dda_refuses_and_option_checks(vh, torch_cuda):
     with pytest.raises(vh.VoxelHashError):
         gt.set_option("raycast_mode", 2)
     with pytest.raises(vh.VoxelHashError):
-        gt.set_option("raycast_beam", 3)
+        gt.set_option("raycast_beam", 4)
     gt.set_raycast_mode(vh.RAYCAST_FIXED_STEP)
     with pytest.raises(vh.VoxelHashError):
         gt.raycast_normals(I4, d, n)                  # the march has no normal output

@@ -85,7 +85,8 @@ struct vh_context {
     int raycastPatch = 1;          // pixels of a raycast wave: 1 = 8x8 square, 0 = 16x4 rows
     int raycastXcd = 1;            // tiles renumbered so that each XCD (own L2) renders a contiguous part of the image
     void *raycastStamps = nullptr; // diagnostics: device buffer of 4 uint64 per wave (vh_debug_set_raycast_stamps)
-    int raycastBeam = 2;           // DDA: 2 = cooperative form (one block list per wave), 1 = per-lane walk behind the beam front end, 0 = per-lane walk (option "raycast_beam")
+    int raycastBeam = 3;           // DDA: 2 = cooperative form (one block list per wave), 1 = per-lane walk behind the beam front end, 0 = per-lane walk,
+                                   // 3 = by the view: cooperative when 64 half-block slabs span [t_min, t_max], else 1 (option "raycast_beam")
     int raycastMode = VH_RAYCAST_DDA;   // option "raycast_mode": voxel DDA (raycastSDF.frag:121-177) or the fixed-step march
     int packetFormat = VH_PACKET_F32;   // what vh_integrate_packets / vh_apply_frames_batch read
     int fusedFrame = 1;            // vh_integrate as two launches (0: the four step kernels)

@@ -438,7 +438,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (std::strcmp(name, "fused_frame") == 0) { c->fusedFrame = value; return VH_OK; }
     if (std::strcmp(name, "raycast_patch") == 0) { c->raycastPatch = value; return VH_OK; }
     if (std::strcmp(name, "raycast_xcd") == 0) { c->raycastXcd = value; return VH_OK; }
-    if (std::strcmp(name, "raycast_beam") == 0 && value >= 0 && value <= 2) { c->raycastBeam = value; return VH_OK; }
+    if (std::strcmp(name, "raycast_beam") == 0 && value >= 0 && value <= 3) { c->raycastBeam = value; return VH_OK; }
     if (std::strcmp(name, "raycast_mode") == 0 && (value == VH_RAYCAST_DDA || value == VH_RAYCAST_FIXED_STEP)) {
         c->raycastMode = value;
         return VH_OK;

@@ -339,6 +339,10 @@ __device__ __forceinline__ bool beam_slab_occupied(const FrameParams &fp, const 
 #define VH_COOP_K 1             // voxels fetched per round trip in the block walk (with 5 waves per SIMD: 1: 35.3 us, 2: 38.1; with 4: 38.9 / 40.6)
 #endif
 constexpr int kCoopK = VH_COOP_K;
+#ifndef VH_COOP_SUBS
+#define VH_COOP_SUBS 4
+#endif
+constexpr int kCoopSubs = VH_COOP_SUBS;        // slabs per lane and window of the cooperative raycast (64 x this many half-block slabs)
 #ifndef VH_COOP_LDS
 #define VH_COOP_LDS 0      // 1: the walked block is staged in LDS (4 KiB per wave, one coalesced round trip), 0: its voxels are gathered (35.0 vs 32.4 us: 19 registers spilled instead of 8)
 #endif
@@ -535,9 +539,16 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
         bool final_ = !inImage;
         __builtin_amdgcn_wave_barrier();
         stampP1 = ra.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        for (float tw = ra.tMin; tw < ra.tMax && !fail; tw += 64.0f * dt2) {
-            // ---- 1. beam: the blocks slab `lane` of this window can touch ----
-            const float ta = tw + (float)lane * dt2;
+        // A window = the slabs one pass of step 1 covers: 64 per sub-pass, up to kCoopSubs sub-passes when the range is longer
+        // (finer voxels).  One window for the whole range beats several (640x480, 60 frames, per call: 2 windows of 64 slabs
+        // 65.5 us, 3: 83.6, 4: 102.0 -- every window pays the front end again, and the per-lane walk behind a beam front end,
+        // 58.9 / 74.3 / 92.5, was faster); what lies behind a ray's hit is then listed too, but skipped by its arrival event.
+        const int nSub = max(1, min(kCoopSubs, (int)__builtin_ceilf((ra.tMax - ra.tMin) / (64.0f * dt2))));
+        const float window = 64.0f * (float)nSub * dt2;
+        for (float tw = ra.tMin; tw < ra.tMax && !fail; tw += window) {
+            // ---- 1. beam: the blocks slab `lane` (+ 64 per sub-pass) of this window can touch ----
+            for (int sub = 0; sub < nSub; ++sub) {
+            const float ta = tw + (float)(lane + 64 * sub) * dt2;
             if (ta < ra.tMax) {
                 // g = G + E t is affine in the pixel, so over the patch each component of E lies between its values on the
                 // four corner rays, and over the slab (t >= 0) g_a lies between G_a + t eMin_a and G_a + t eMax_a at the
@@ -601,6 +612,7 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                         if (!placed) fail = true;
                     }
                 }
+            }
             }
             fail = __ballot(fail) != 0ull;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -857,7 +869,7 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                 }
             }
             // a candidate that arrived before this window's end cannot be beaten by a block found later
-            final_ = final_ || bestT < tw + 64.0f * dt2;
+            final_ = final_ || bestT < tw + window;
             if (__ballot(!final_) == 0ull) break;
         }
         if (!fail) { coopDone = true; live = false; }
