@@ -601,6 +601,28 @@ def main():
             c3_rec["two_launch_frame"] = two_launch_record(
                 args, c3_it, "C3", c3_rec["occupied_blocks"], max(50, min(args.steps, 200)), min(args.warmup, 20),
                 lambda: (c3_it.sync(), torch.cuda.synchronize()))
+        if "raycast" in legs:
+            # the raycast of the C3 model (1280x960, 5 mm voxels: the per-lane walk behind the beam front end, chosen by the view)
+            W3, H3 = WORKLOADS["C3"]["width"], WORKLOADS["C3"]["height"]
+            d3 = torch.empty((H3, W3), dtype=torch.float32, device=dev)
+            c3_it.table.set_profiling(True)
+            stats = {}
+            for mode, label in ((V.RAYCAST_DDA, "dda"), (V.RAYCAST_FIXED_STEP, "fixed_step_march")):
+                c3_it.table.set_raycast_mode(mode)
+                c3_it.table.raycast(c3_poses[0], d3)
+                c3_it.table.kernel_times()
+                for k in range(0, min(len(c3_poses), 60), 3):
+                    c3_it.table.raycast(c3_poses[k], d3)
+                c3_it.table.synchronize()
+                kt3 = c3_it.table.kernel_times()
+                stats[label] = round(1e3 * kt3["raycast_ms"] / max(1, kt3["raycast_launches"]), 2)
+            c3_it.table.set_raycast_mode(V.RAYCAST_DDA)
+            c3_it.table.set_profiling(False)
+            c3_rec["raycast"] = dict(kernel_us=stats["dda"], kernel_mpix_per_s=round(W3 * H3 / stats["dda"], 1), poses=20,
+                                     variants_kernel_us={"fixed_step_march": stats["fixed_step_march"]},
+                                     traversal="voxel DDA; form chosen by the view (raycast_beam 3): 64 half-block slabs do not span "
+                                               "0.1-5 m at 5 mm voxels, so every ray walks behind its wave's beam front end")
+            del d3
         extra["configs"] = {"C3": c3_rec}
         c3_it.close()
         del c3_verts

@@ -126,7 +126,12 @@ def test_cpp_sharded_program(oracle, vh, torch_cuda, tmp_path):
     np.asarray(poses, np.float32).tofile(tmp_path / "poses.bin")
     np.stack(d16).tofile(tmp_path / "depth.bin")
     kinv.tofile(tmp_path / "kinv.bin")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (the program takes its HIP runtime and RCCL from the files this test session has already mapped -- torch's copies --
+    # instead of paging the ROCm install's copies in from a cold disk: minutes on a fresh box)
+    import torch
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               LD_LIBRARY_PATH=tlib + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
     out = subprocess.run([str(exe), str(tmp_path / "poses.bin"), str(tmp_path / "depth.bin"), str(tmp_path / "kinv.bin"),
                           str(W), str(H), str(batch), str(steps), str(KW["numBuckets"]), str(KW["numVoxelBlocks"]),
                           str(tmp_path / "table.bin"), str(tmp_path / "depth_out.bin")],
