@@ -388,8 +388,37 @@ def cpu_baseline_leg(args, name, poses, verts):
                        f"(gcc -O2 -ffp-contract=off -fopenmp), {os.cpu_count()} logical host cores")
 
 
+def launcher_command(argv, gpus, port):
+    """What `python bench.py --gpus N` starts when it was not itself started by a launcher: the driver's own command line,
+    one rank per GPU of this node (argv = this process's arguments, passed through unchanged)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without WORLD_SIZE: start the N ranks as a CHILD process (never exec: this process must not be replaced,
+    and it never touches the GPU itself -- no torch import here), relay their output and rank 0's JSON line, return the
+    child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = launcher_command(argv, args.gpus, port)
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
+    child = subprocess.Popen(cmd, env=env)
+    try:
+        return child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        return child.wait()
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
     import torch
     import torch.distributed as dist
 
@@ -403,8 +432,12 @@ def main():
     if os.environ.get("VH_BENCH_SHARE_GPU") == "1":          # test rig: all ranks on one device (see init_dist)
         local_rank = 0
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
+    # (device_count() does not initialise the GPU: a rank that cannot have a device of its own says so before any HIP call)
+    visible = torch.cuda.device_count()
+    if os.environ.get("VH_BENCH_SHARE_GPU") != "1" and visible < world:
+        raise SystemExit(f"bench.py: {world} GPUs requested (--gpus {world}), {visible} visible on this node: "
+                         "one rank per GPU is needed (RCCL refuses two ranks on one device)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)

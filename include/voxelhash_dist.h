@@ -50,6 +50,26 @@ typedef struct vh_dist_config {
  * a file, torch.distributed over gloo ...).  world == 1 needs no exchange. */
 int vh_dist_unique_id(char id[VH_DIST_ID_BYTES]);
 
+/* Loads RCCL and resolves its symbols without creating anything and without any collective: lets every rank find out
+ * locally whether vh_dist_create can work before the ranks agree to call it (a rank that fails inside a collective
+ * leaves the others waiting). */
+int vh_dist_probe(void);
+
+/* The transports.  vh_dist reaches its peers through two stream-ordered collectives only (all-to-all, all-gather), and
+ * vh_dist_create picks who carries them from the id:
+ *   - an id of vh_dist_unique_id (or an adopted ncclComm_t): RCCL over xGMI, one process per GPU -- the default;
+ *   - an id of vh_dist_loopback_id: the LOOP-BACK transport, which joins the `world` vh_dist instances of ONE process,
+ *     usually all on one device: peer buffers are copied with hipMemcpyAsync on the calling rank's stream, ordered by
+ *     events.  Every collective call (vh_dist_step_batch, vh_dist_raycast) must then be made by `world` host threads,
+ *     one per rank, as it would be by `world` processes (a rank that does not arrive within 120 s -- environment
+ *     VOXELHASH_LOOPBACK_TIMEOUT_S -- fails the call for all).  Everything but the bytes' way across is the code the RCCL ranks run -- buffer sets, events, deferred
+ *     frames -- which is what the transport is for: the N > 1 exchange under test on a single-GPU box. */
+int vh_dist_loopback_id(char id[VH_DIST_ID_BYTES]);
+/* "rccl" | "loopback" */
+const char *vh_dist_transport_name(vh_dist *d);
+/* rank and size as the transport itself reports them (ncclCommUserRank / ncclCommCount; loop-back: ranks that have joined) */
+int vh_dist_comm_info(vh_dist *d, int32_t *rank, int32_t *world);
+
 /* Creates this rank's shard (vh_create_shard over its bucket range), the communicator (ncclCommInitRank with `id`; or
  * adopts `nccl_comm`, an ncclComm_t the caller owns, when it is not NULL), streams, events and the exchange buffers.
  * Collective: every rank calls it. */
@@ -58,6 +78,16 @@ int vh_dist_destroy(vh_dist *d);
 
 /* this rank's shard: counters, download, snapshot, options (set before the first step) ... go through voxelhash.h */
 vh_context *vh_dist_shard(vh_dist *d);
+
+/* STREAM CONTRACT.  vh_dist works on three private non-blocking streams.  Without a user stream the caller owns the
+ * ordering: the frames passed to vh_dist_step_batch must be complete before the call and must stay untouched until a
+ * later vh_dist_flush (or until the next-but-two vh_dist_step_batch has returned and the device has caught up), and the
+ * image of vh_dist_raycast is valid after vh_dist_flush / a device synchronisation.  With a user stream
+ * (enable != 0; `stream` may be the null stream) the calls are ordered against it like ordinary stream work:
+ * vh_dist_step_batch reads the frames behind everything queued on `stream` so far and makes `stream` wait until they have
+ * been consumed (work queued on it afterwards may overwrite them); vh_dist_raycast writes d_depth_out / d_lost behind
+ * `stream`'s queued work and makes `stream` wait for the image. */
+int vh_dist_set_user_stream(vh_dist *d, void *stream, int32_t enable);
 
 /* One exchange: `batch` frames of THIS rank's camera (poses: batch*16 host floats; d_frames: host array of `batch`
  * device pointers -- uint16 sensor images or float4 vertex maps by packet_format).  Enqueues the generation and the

@@ -1,0 +1,36 @@
+"""`python bench.py --gpus N` as typed (no launcher around it): the parent starts the N ranks as a child process
+(torch.distributed.run, one rank per GPU) without touching the GPU itself, relays the child's output and exit code.  Here,
+without a GPU, every rank must say how many GPUs were asked for and how many it sees -- not print launcher instructions."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_launcher_command_is_the_drivers():
+    import bench
+    cmd = bench.launcher_command(["--gpus", "4", "--steps", "7", "--warmup", "2", "--workload", "C5"], 4, 29517)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2", "--workload", "C5"]     # arguments pass through unchanged
+
+
+def test_gpus_2_without_a_launcher_starts_its_own_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""                # (whatever this machine has: the ranks must see fewer GPUs than asked)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "torch.distributed.run" in p.stderr and "--nproc-per-node=2" in p.stderr      # the parent said what it started
+    assert "2 GPUs requested (--gpus 2), 0 visible" in p.stderr
+    assert "launch with" not in p.stderr and '"metric"' not in p.stdout
+
+
+def test_world_size_mismatch_is_named():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "--gpus 2 but the launcher started 1 rank(s)" in p.stderr

@@ -65,3 +65,31 @@ def test_multi_rank_line_over_the_test_rig(torch_cuda, ranks):
     assert rec["config"]["key_bin_overflows"] == 0 and rec["config"]["occupied_blocks_all_ranks"] > 0
     assert abs(rec["value"] - 1e3 * rec["config"]["frames_per_step"] / rec["ms_per_step"]) < 0.01 * rec["value"]
     assert rec["cpu_baseline"] and rec["cpu_baseline"]["value"] > 0
+
+
+def test_gpus_2_as_typed_on_a_one_gpu_box(torch_cuda):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts the ranks as a child process; on a box with
+    one GPU the ranks say so (and nothing touched the GPU twice); with the test rig (gloo, both ranks on cuda:0) the same
+    command yields the two-rank line."""
+    import torch
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--legs", "cpu", "--cpu-frames", "6"]
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=base)
+        assert p.returncode != 0 and f"2 GPUs requested (--gpus 2), {torch.cuda.device_count()} visible" in p.stderr
+        assert "launch with" not in p.stderr
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=dict(base, VH_BENCH_BACKEND="gloo", VH_BENCH_SHARE_GPU="1"))
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    rec = _line(p.stdout)
+    _check(rec, 2, 3, 1)
+    assert rec["exchange_ranks"]["ranks"] == 2 and rec["cpu_baseline"]["value"] > 0
+
+
+def test_sharded_line_names_its_transport(torch_cuda):
+    """One rank over RCCL: the line says which transport carried the exchange and how many ranks the communicator has."""
+    p = subprocess.run([sys.executable, "bench.py", "--sharded", "--steps", "3", "--warmup", "1", "--legs", "none"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rec = _line(p.stdout)
+    assert rec["exchange_ranks"] == {"transport": "rccl", "ranks": 1}

@@ -4,6 +4,10 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <map>
+#include <memory>
+#include <mutex>
 
 #include <rccl/rccl.h>          // types and prototypes only: the library is bound at run time (rccl_load)
 
@@ -24,12 +28,16 @@ struct Rccl {
     decltype(&ncclAllToAll) allToAll = nullptr;
     decltype(&ncclAllGather) allGather = nullptr;
     decltype(&ncclGetErrorString) getErrorString = nullptr;
+    decltype(&ncclCommCount) commCount = nullptr;
+    decltype(&ncclCommUserRank) commUserRank = nullptr;
     bool ok = false;
 };
 Rccl g_rccl;
+std::mutex g_rccl_mutex;          // vh_dist_create may be called by one thread per GPU
 
 int rccl_load()
 {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.ok) return VH_OK;
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;
@@ -47,6 +55,8 @@ int rccl_load()
     VH_RCCL_SYM(allToAll, "ncclAllToAll");
     VH_RCCL_SYM(allGather, "ncclAllGather");
     VH_RCCL_SYM(getErrorString, "ncclGetErrorString");
+    VH_RCCL_SYM(commCount, "ncclCommCount");
+    VH_RCCL_SYM(commUserRank, "ncclCommUserRank");
 #undef VH_RCCL_SYM
     g_rccl.ok = true;
     return VH_OK;
@@ -64,6 +74,73 @@ int rccl_fail(const char *what, ncclResult_t r)
         const ncclResult_t r_ = (call);                       \
         if (r_ != ncclSuccess) return rccl_fail(#call, r_);   \
     } while (0)
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// Transports: the two stream-ordered collectives the exchange is made of
+// ---------------------------------------------------------------------------
+// vh_dist talks to its peers through this table only.  Both calls are collective, enqueue on `s` and return without
+// waiting for the device; when the work on `s` completes, `recv` holds every peer's part and `send` may be overwritten.
+//   all_to_all:  recv[p] (bytes each) = peer p's send[rank]
+//   all_gather:  recv[p] (bytes each) = peer p's send
+// RCCL over xGMI is the default entry (one process per GPU).  The loop-back entry joins the R vh_dist instances of ONE
+// process on ONE device -- one host thread per rank, like one process per GPU -- so that the code of vh_dist_step_batch /
+// vh_dist_raycast runs with R > 1 on a single-GPU box: the three buffer sets, the generated / ready / first events, the
+// deferred frame of pipeline_shards 2 and the fixed-slot view round are exercised exactly as over RCCL; only the bytes
+// travel by hipMemcpyAsync instead of by a collective kernel.
+struct Transport {
+    const char *name;
+    int (*all_to_all)(vh_dist *d, const void *send, void *recv, size_t bytes, hipStream_t s);
+    int (*all_gather)(vh_dist *d, const void *send, void *recv, size_t bytes, hipStream_t s);
+    void (*leave)(vh_dist *d);
+};
+
+namespace {
+// One collective of a loop-back group: every rank publishes its buffers and an event behind what its stream has queued
+// so far (`posted`: the send buffer is final), the ranks meet on the host, every rank queues its R copies behind the
+// peers' `posted` events and records `done`; a second meeting, and every rank's stream waits for all `done` events --
+// its send buffer has been read by everyone, which is what the completion of an RCCL collective means.
+struct LoopGroup {
+    std::mutex m;
+    std::condition_variable cv;
+    int world = 0, joined = 0, arrived = 0;
+    uint64_t phase = 0, serial = 0;
+    bool broken = false;
+    struct Post {
+        const void *send = nullptr;
+        void *recv = nullptr;
+        size_t bytes = 0;
+        int kind = 0;
+        hipEvent_t posted = nullptr, done = nullptr;
+        bool present = false;
+    } post[VH_MAX_CAMERAS];
+};
+std::mutex g_loop_mutex;
+std::map<uint64_t, std::shared_ptr<LoopGroup>> g_loops;
+uint64_t g_loop_serial = 0;
+const char kLoopMagic[8] = {'V', 'H', 'L', 'O', 'O', 'P', 'B', 'K'};
+
+bool loop_meet(LoopGroup *g)
+{
+    std::unique_lock<std::mutex> lk(g->m);
+    if (g->broken) return false;
+    const uint64_t ph = g->phase;
+    if (++g->arrived == g->world) {
+        g->arrived = 0;
+        g->phase += 1;
+        g->cv.notify_all();
+        return true;
+    }
+    // a rank that never arrives (an error on its side, a host that drives the ranks from one thread) must not hang the rest
+    const char *env = std::getenv("VOXELHASH_LOOPBACK_TIMEOUT_S");
+    const int seconds = env && std::atoi(env) > 0 ? std::atoi(env) : 120;
+    if (!g->cv.wait_for(lk, std::chrono::seconds(seconds), [&] { return g->phase != ph || g->broken; })) {
+        g->broken = true;
+        g->cv.notify_all();
+        return false;
+    }
+    return !g->broken;
+}
 }  // namespace
 
 // the view pose of a raycast round into device memory without a staging buffer: 16 floats in the kernel arguments
@@ -89,8 +166,13 @@ struct vh_dist {
     vh_dist_config cfg;
     vh_context *shard = nullptr;
     vh_context *view = nullptr;            // raycast over the shards: the private view table (first vh_dist_raycast)
+    const Transport *transport = nullptr;  // chosen in vh_dist_create: RCCL unless the id names a loop-back group
     ncclComm_t comm = nullptr;
     bool ownComm = false;
+    std::shared_ptr<LoopGroup> loop;       // loop-back transport: the group this rank has joined
+    hipStream_t userStream = nullptr;      // vh_dist_set_user_stream: the caller's stream the frames / images are ordered against
+    bool haveUser = false;
+    hipEvent_t userEvent = nullptr, outEvent = nullptr;
     int device = 0;
     int capacity = 0;                      // records per key bin
     size_t packetUnits = 0;                // 4-byte units of one camera packet
@@ -115,6 +197,102 @@ struct vh_dist {
     uint64_t hostCalls = 0;
 };
 
+// ---------------------------------------------------------------------------
+// transport entries
+// ---------------------------------------------------------------------------
+static int rccl_all_to_all(vh_dist *d, const void *send, void *recv, size_t bytes, hipStream_t s)
+{
+    if (bytes % 4 == 0) VH_RCCL(g_rccl.allToAll(send, recv, bytes / 4, ncclInt32, d->comm, s));
+    else VH_RCCL(g_rccl.allToAll(send, recv, bytes, ncclUint8, d->comm, s));
+    return VH_OK;
+}
+static int rccl_all_gather(vh_dist *d, const void *send, void *recv, size_t bytes, hipStream_t s)
+{
+    if (bytes % 4 == 0) VH_RCCL(g_rccl.allGather(send, recv, bytes / 4, ncclInt32, d->comm, s));
+    else VH_RCCL(g_rccl.allGather(send, recv, bytes, ncclUint8, d->comm, s));
+    return VH_OK;
+}
+static void rccl_leave(vh_dist *d)
+{
+    if (d->comm && d->ownComm && g_rccl.commDestroy) (void)g_rccl.commDestroy(d->comm);
+    d->comm = nullptr;
+}
+static const Transport kRcclTransport = {"rccl", rccl_all_to_all, rccl_all_gather, rccl_leave};
+
+// kind 0: all-to-all, 1: all-gather
+static int loop_collective(vh_dist *d, int kind, const void *send, void *recv, size_t bytes, hipStream_t s)
+{
+    LoopGroup *g = d->loop.get();
+    const int r = d->cfg.rank, R = d->cfg.world;
+    LoopGroup::Post &mine = g->post[r];
+    mine.send = send; mine.recv = recv; mine.bytes = bytes; mine.kind = kind;
+    VH_HIP(hipEventRecord(mine.posted, s));
+    if (!loop_meet(g)) return fail(VH_ERR_HIP, "loop-back transport: a rank of the group did not arrive at the collective (one host thread per rank is needed)");
+    for (int i = 0; i < R; ++i) {
+        const int p = (r + i) % R;                    // own part first, then the peers round the ring
+        const LoopGroup::Post &peer = g->post[p];
+        if (peer.kind != kind || peer.bytes != bytes) {
+            { std::lock_guard<std::mutex> lk(g->m); g->broken = true; }
+            g->cv.notify_all();
+            return fail(VH_ERR_INVALID_ARGUMENT, "loop-back transport: the ranks disagree on the collective");
+        }
+        if (p != r) VH_HIP(hipStreamWaitEvent(s, peer.posted, 0));
+        const uint8_t *src = static_cast<const uint8_t *>(peer.send) + (kind == 0 ? (size_t)r * bytes : 0);
+        VH_HIP(hipMemcpyAsync(static_cast<uint8_t *>(recv) + (size_t)p * bytes, src, bytes, hipMemcpyDeviceToDevice, s));
+    }
+    VH_HIP(hipEventRecord(mine.done, s));
+    if (!loop_meet(g)) return fail(VH_ERR_HIP, "loop-back transport: a rank of the group left the collective");
+    for (int p = 0; p < R; ++p)
+        if (p != r) VH_HIP(hipStreamWaitEvent(s, g->post[p].done, 0));
+    return VH_OK;
+}
+static int loop_all_to_all(vh_dist *d, const void *send, void *recv, size_t bytes, hipStream_t s) { return loop_collective(d, 0, send, recv, bytes, s); }
+static int loop_all_gather(vh_dist *d, const void *send, void *recv, size_t bytes, hipStream_t s) { return loop_collective(d, 1, send, recv, bytes, s); }
+static void loop_leave(vh_dist *d)
+{
+    if (!d->loop) return;
+    LoopGroup *g = d->loop.get();
+    bool last = false;
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        LoopGroup::Post &mine = g->post[d->cfg.rank];
+        if (mine.posted) (void)hipEventDestroy(mine.posted);
+        if (mine.done) (void)hipEventDestroy(mine.done);
+        mine = LoopGroup::Post{};
+        last = --g->joined == 0;
+    }
+    if (last) {
+        std::lock_guard<std::mutex> lk(g_loop_mutex);
+        g_loops.erase(g->serial);
+    }
+    d->loop.reset();
+}
+static const Transport kLoopTransport = {"loopback", loop_all_to_all, loop_all_gather, loop_leave};
+
+static int loop_join(vh_dist *d, const char id[VH_DIST_ID_BYTES])
+{
+    uint64_t serial;
+    std::memcpy(&serial, id + sizeof kLoopMagic, sizeof serial);
+    std::shared_ptr<LoopGroup> g;
+    {
+        std::lock_guard<std::mutex> lk(g_loop_mutex);
+        auto it = g_loops.find(serial);
+        if (it == g_loops.end()) return fail(VH_ERR_INVALID_ARGUMENT, "loop-back id not issued by vh_dist_loopback_id of this process (or its group has been destroyed)");
+        g = it->second;
+    }
+    std::lock_guard<std::mutex> lk(g->m);
+    if (g->world == 0) g->world = d->cfg.world;
+    if (g->world != d->cfg.world) return fail(VH_ERR_INVALID_ARGUMENT, "loop-back group: the ranks disagree on the world size");
+    LoopGroup::Post &mine = g->post[d->cfg.rank];
+    if (mine.present) return fail(VH_ERR_INVALID_ARGUMENT, "loop-back group: this rank has joined already");
+    VH_HIP(hipEventCreateWithFlags(&mine.posted, hipEventDisableTiming));
+    VH_HIP(hipEventCreateWithFlags(&mine.done, hipEventDisableTiming));
+    mine.present = true;
+    g->joined += 1;
+    d->loop = g;
+    return VH_OK;
+}
+
 static void dist_free(vh_dist *d)
 {
     if (!d) return;
@@ -133,7 +311,9 @@ static void dist_free(vh_dist *d)
     for (int i = 0; i < vh_dist::kSets; ++i)
         for (hipEvent_t e : {d->generated[i], d->ready[i], d->first[i]})
             if (e) (void)hipEventDestroy(e);
-    if (d->comm && d->ownComm && g_rccl.commDestroy) (void)g_rccl.commDestroy(d->comm);
+    for (hipEvent_t e : {d->userEvent, d->outEvent})
+        if (e) (void)hipEventDestroy(e);
+    if (d->transport) d->transport->leave(d);
     for (hipStream_t s : {d->sGen, d->sComm, d->sTable})
         if (s) (void)hipStreamDestroy(s);
     delete d;
@@ -151,6 +331,26 @@ extern "C" int vh_dist_unique_id(char id[VH_DIST_ID_BYTES])
     return VH_OK;
 }
 
+extern "C" int vh_dist_loopback_id(char id[VH_DIST_ID_BYTES])
+{
+    if (!id) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lk(g_loop_mutex);
+    auto g = std::make_shared<LoopGroup>();
+    g->serial = ++g_loop_serial;
+    g_loops[g->serial] = g;
+    std::memset(id, 0, VH_DIST_ID_BYTES);
+    std::memcpy(id, kLoopMagic, sizeof kLoopMagic);
+    std::memcpy(id + sizeof kLoopMagic, &g->serial, sizeof g->serial);
+    return VH_OK;
+}
+
+extern "C" int vh_dist_probe(void)
+{
+    return rccl_load();
+}
+
+extern "C" const char *vh_dist_transport_name(vh_dist *d) { return d && d->transport ? d->transport->name : ""; }
+
 extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_ID_BYTES], void *nccl_comm, vh_dist **out)
 {
     if (!cfg || !out || (!id && !nccl_comm)) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
@@ -161,7 +361,8 @@ extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_I
         return fail(VH_ERR_INVALID_ARGUMENT, "bad packet format");
     const size_t npix = (size_t)cfg->table.width * cfg->table.height;
     if (cfg->packet_format == VH_PACKET_U16 && npix % 2) return fail(VH_ERR_INVALID_ARGUMENT, "sensor-depth packets need an even number of pixels");
-    int rc = rccl_load();
+    const bool loopback = !nccl_comm && std::memcmp(id, kLoopMagic, sizeof kLoopMagic) == 0;
+    int rc = loopback ? VH_OK : rccl_load();
     if (rc != VH_OK) return rc;
     // bucket range of this rank: owner(h) = h / ceil(numBuckets / world)  (dist.py: ShardPlan)
     const uint32_t nb = cfg->table.params.numBuckets, R = (uint32_t)cfg->world;
@@ -195,6 +396,7 @@ extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_I
         }                                                                                            \
     } while (0)
     for (hipStream_t *s : {&d->sGen, &d->sComm, &d->sTable}) VH_DIST_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&d->userEvent, &d->outEvent}) VH_DIST_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < vh_dist::kSets; ++i) {
         for (hipEvent_t *e : {&d->generated[i], &d->ready[i], &d->first[i]}) VH_DIST_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
         VH_DIST_TRY(hipMalloc((void **)&d->set[i].binsSend, binBytes));
@@ -206,14 +408,19 @@ extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_I
     }
     VH_DIST_TRY(hipDeviceSynchronize());
 #undef VH_DIST_TRY
-    if (nccl_comm) {
+    if (loopback) {
+        if ((rc = loop_join(d, id)) != VH_OK) { dist_free(d); return rc; }
+        d->transport = &kLoopTransport;
+    } else if (nccl_comm) {
         d->comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+        d->transport = &kRcclTransport;
     } else {
         ncclUniqueId u;
         std::memcpy(&u, id, sizeof u);
         const ncclResult_t r = g_rccl.commInitRank(&d->comm, cfg->world, u, cfg->rank);
         if (r != ncclSuccess) { dist_free(d); return rccl_fail("ncclCommInitRank", r); }
         d->ownComm = true;
+        d->transport = &kRcclTransport;
     }
     d->shard->stream = d->sTable;
     d->shard->pipelineShards = 2;          // a batch's last frame rides in the first launch of the next batch
@@ -228,6 +435,14 @@ extern "C" int vh_dist_destroy(vh_dist *d)
 }
 
 extern "C" vh_context *vh_dist_shard(vh_dist *d) { return d ? d->shard : nullptr; }
+
+extern "C" int vh_dist_set_user_stream(vh_dist *d, void *stream, int32_t enable)
+{
+    if (!d) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    d->userStream = (hipStream_t)stream;
+    d->haveUser = enable != 0;
+    return VH_OK;
+}
 
 static int dist_apply(vh_dist *d, int s)
 {
@@ -250,7 +465,11 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     vh_dist::Set &set = d->set[s];
     int rc;
     // generate: keys binned by owner + this camera's packets.  The set's send buffers were last read by the collectives
-    // of exchange count-3.
+    // of exchange count-3.  The frames are read behind whatever the caller's stream has queued (vh_dist_set_user_stream).
+    if (d->haveUser) {
+        VH_HIP(hipEventRecord(d->userEvent, d->userStream));
+        VH_HIP(hipStreamWaitEvent(d->sGen, d->userEvent, 0));
+    }
     if (d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sGen, d->ready[s], 0));
     d->shard->stream = d->sGen;
     if (d->cfg.packet_format == VH_PACKET_U16)
@@ -262,12 +481,14 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     d->shard->stream = d->sTable;
     if (rc != VH_OK) return rc;
     VH_HIP(hipEventRecord(d->generated[s], d->sGen));
+    // (the frames have been consumed once `generated` fires: the caller's stream may overwrite them behind it)
+    if (d->haveUser) VH_HIP(hipStreamWaitEvent(d->userStream, d->generated[s], 0));
     // exchange: the receive buffers of this set were last read by the frames of exchange count-3, the last of which rode in
     // the first launch of exchange count-2's frames (queued by the previous call)
     VH_HIP(hipStreamWaitEvent(d->sComm, d->generated[s], 0));
     if (d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sComm, d->first[(s + 1) % vh_dist::kSets], 0));
-    VH_RCCL(g_rccl.allToAll(set.binsSend, set.binsRecv, (size_t)d->capacity * 4, ncclInt32, d->comm, d->sComm));
-    VH_RCCL(g_rccl.allGather(set.packet, set.packets, (size_t)B * d->packetUnits, ncclFloat32, d->comm, d->sComm));
+    if ((rc = d->transport->all_to_all(d, set.binsSend, set.binsRecv, (size_t)d->capacity * 4 * sizeof(int32_t), d->sComm)) != VH_OK) return rc;
+    if ((rc = d->transport->all_gather(d, set.packet, set.packets, (size_t)B * d->packetUnits * sizeof(float), d->sComm)) != VH_OK) return rc;
     VH_HIP(hipEventRecord(d->ready[s], d->sComm));
     // apply the previous exchange while this one travels
     if (d->pending >= 0 && (rc = dist_apply(d, d->pending)) != VH_OK) return rc;
@@ -278,16 +499,23 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     return VH_OK;
 }
 
-extern "C" int vh_dist_flush(vh_dist *d)
+// applies the exchange in flight and the last frame's deferred half: everything fed is queued on the table stream
+static int dist_drain(vh_dist *d)
 {
-    if (!d) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
-    DeviceGuard guard(d->device);
     if (d->pending >= 0) {
         const int rc = dist_apply(d, d->pending);
         if (rc != VH_OK) return rc;
         d->pending = -1;
     }
-    { const int rc = flush_pending(d->shard); if (rc != VH_OK) return rc; }      // the last frame's deferred half
+    return flush_pending(d->shard);
+}
+
+extern "C" int vh_dist_flush(vh_dist *d)
+{
+    if (!d) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(d->device);
+    const int rc = dist_drain(d);
+    if (rc != VH_OK) return rc;
     VH_HIP(hipStreamSynchronize(d->sTable));
     VH_HIP(hipStreamSynchronize(d->sComm));
     VH_HIP(hipStreamSynchronize(d->sGen));
@@ -298,24 +526,30 @@ extern "C" int vh_dist_raycast(vh_dist *d, const float pose[16], float t_min, fl
                                int32_t *d_lost)
 {
     if (!d || !pose || !d_depth_out || capacity < 1) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    const int R = d->cfg.world;
+    if (R > 16) return fail(VH_ERR_INVALID_ARGUMENT, "the fixed-slot raycast round serves at most 16 views");
     DeviceGuard guard(d->device);
     int rc = vh_dist_flush(d);                      // the model as of every fed exchange
     if (rc != VH_OK) return rc;
-    const int R = d->cfg.world;
-    if (R > 16) return fail(VH_ERR_INVALID_ARGUMENT, "the fixed-slot raycast round serves at most 16 views");
     if (!d->view) {
         vh_config vc = d->cfg.table;
         vc.params.numVoxelBlocks = 1;               // the voxels of a view table stay in the received records
         vc.device = d->device;
         if ((rc = vh_create(&vc, &d->view)) != VH_OK) return rc;
         d->view->stream = d->sTable;
-        d->view->rc_fx = d->shard->rc_fx; d->view->rc_fy = d->shard->rc_fy; d->view->rc_cx = d->shard->rc_cx; d->view->rc_cy = d->shard->rc_cy;
-        d->view->raycastMode = d->shard->raycastMode;
-        if (d->shard->fp.flags & kFlagOverflow) { d->view->fp.flags |= kFlagOverflow; d->view->fp.listSize = d->shard->fp.listSize; }
         VH_HIP(hipMalloc((void **)&d->poseMine, 16 * sizeof(float)));
         VH_HIP(hipMalloc((void **)&d->poseAll, (size_t)R * 16 * sizeof(float)));
         VH_HIP(hipMalloc((void **)&d->viewCounts, (size_t)R * sizeof(int32_t)));
     }
+    // the view table renders with the shard's raycast settings as they are NOW (vh_set_option / vh_set_raycast_intrinsics
+    // on vh_dist_shard() between rounds take effect)
+    d->view->rc_fx = d->shard->rc_fx; d->view->rc_fy = d->shard->rc_fy; d->view->rc_cx = d->shard->rc_cx; d->view->rc_cy = d->shard->rc_cy;
+    d->view->raycastMode = d->shard->raycastMode;
+    d->view->raycastBeam = d->shard->raycastBeam;
+    d->view->raycastPatch = d->shard->raycastPatch;
+    d->view->raycastXcd = d->shard->raycastXcd;
+    d->view->fp.flags = (d->view->fp.flags & ~kFlagOverflow) | (d->shard->fp.flags & kFlagOverflow);
+    d->view->fp.listSize = d->shard->fp.listSize;
     if (d->viewCapacity < capacity) {
         VH_HIP(hipStreamSynchronize(d->sTable));
         if (d->viewSend) (void)hipFree(d->viewSend);
@@ -329,17 +563,43 @@ extern "C" int vh_dist_raycast(vh_dist *d, const float pose[16], float t_min, fl
         VH_HIP(hipMemsetAsync(d->viewRecv, 0, bytes, d->sTable));
         d->viewCapacity = capacity;
     }
+    // the image (and d_lost) are written behind whatever the caller's stream has queued, and the caller's stream reads them
+    // behind the raycast (vh_dist_set_user_stream)
+    if (d->haveUser) {
+        VH_HIP(hipEventRecord(d->userEvent, d->userStream));
+        VH_HIP(hipStreamWaitEvent(d->sTable, d->userEvent, 0));
+    }
     Pose16 p;
     std::memcpy(p.m, pose, sizeof p.m);
     dist_store_pose_kernel<<<1, 64, 0, d->sTable>>>(p, d->poseMine);
-    VH_RCCL(g_rccl.allGather(d->poseMine, d->poseAll, 16, ncclFloat32, d->comm, d->sTable));
+    if ((rc = d->transport->all_gather(d, d->poseMine, d->poseAll, 16 * sizeof(float), d->sTable)) != VH_OK) return rc;
     d->shard->stream = d->sTable;
     if ((rc = vh_export_views_fixed(d->shard, d->poseAll, R, t_min, t_max, d->viewSend, capacity, d->viewCounts)) != VH_OK) return rc;
-    VH_RCCL(g_rccl.allToAll(d->viewSend, d->viewRecv, (size_t)capacity * sizeof(vh_view_record), ncclUint8, d->comm, d->sTable));
+    if ((rc = d->transport->all_to_all(d, d->viewSend, d->viewRecv, (size_t)capacity * sizeof(vh_view_record), d->sTable)) != VH_OK) return rc;
     if ((rc = vh_import_views(d->view, d->viewRecv, R, capacity, nullptr)) != VH_OK) return rc;
     if ((rc = vh_raycast(d->view, pose, t_min, t_max, d_depth_out)) != VH_OK) return rc;
     if (d_lost) dist_lost_kernel<<<1, 64, 0, d->sTable>>>(reinterpret_cast<const uint8_t *>(d->viewRecv), R, capacity, d_lost);
     VH_HIP(hipGetLastError());
+    if (d->haveUser) {
+        VH_HIP(hipEventRecord(d->outEvent, d->sTable));
+        VH_HIP(hipStreamWaitEvent(d->userStream, d->outEvent, 0));
+    }
+    return VH_OK;
+}
+
+extern "C" int vh_dist_comm_info(vh_dist *d, int32_t *rank, int32_t *world)
+{
+    if (!d) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    int r = d->cfg.rank, n = d->cfg.world;
+    if (d->transport == &kRcclTransport) {           // what the communicator itself says
+        VH_RCCL(g_rccl.commCount(d->comm, &n));
+        VH_RCCL(g_rccl.commUserRank(d->comm, &r));
+    } else if (d->loop) {
+        std::lock_guard<std::mutex> lk(d->loop->m);
+        n = d->loop->joined;
+    }
+    if (rank) *rank = r;
+    if (world) *world = n;
     return VH_OK;
 }
 

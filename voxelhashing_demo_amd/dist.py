@@ -289,6 +289,18 @@ def unique_id(rank: int = 0, broadcast=None) -> bytes:
     return broadcast(buf) if broadcast is not None else buf
 
 
+def loopback_id() -> bytes:
+    """The id of a fresh loop-back group (include/voxelhash_dist.h: vh_dist_loopback_id): `world` NativeDist instances of
+    THIS process created with it exchange through hipMemcpyAsync instead of RCCL; their collective calls must be made
+    from one host thread per rank (NativeGroup does)."""
+    import ctypes as C
+
+    from . import _lib as L
+    raw = C.create_string_buffer(128)
+    L.check(L.load().vh_dist_loopback_id(raw), "vh_dist_loopback_id")
+    return raw.raw
+
+
 def torch_broadcast_bytes(group=None):
     """A `broadcast` for unique_id over torch.distributed (any backend)."""
     def bc(buf):
@@ -326,6 +338,19 @@ class NativeDist:
         self._h, self.rank, self.world, self.batch = h, rank, world, batch
         plan = ShardPlan(params.numBuckets, world)
         self.table = SDFHashtable.borrowed(self._lib.vh_dist_shard(h), params, width, height, semantics, plan.bucket_range(rank))
+        self.transport = self._lib.vh_dist_transport_name(h).decode()
+
+    def order_against(self, stream=None):
+        """Orders step() / raycast() against a torch stream (default: the current one) like ordinary stream work: frames are
+        read behind what the stream has queued and may be overwritten by what it queues afterwards; the raycast image is
+        ready for work queued on the stream after the call (include/voxelhash_dist.h, STREAM CONTRACT).  None of it costs a
+        host synchronisation.  `stream=False` returns to the caller-synchronises contract."""
+        import torch
+        if stream is False:
+            self._L.check(self._lib.vh_dist_set_user_stream(self._h, None, 0), "vh_dist_set_user_stream")
+            return
+        st = torch.cuda.current_stream() if stream is None else stream
+        self._L.check(self._lib.vh_dist_set_user_stream(self._h, st.cuda_stream, 1), "vh_dist_set_user_stream")
 
     def step(self, poses, frames):
         """One exchange: `batch` poses and device tensors (uint16 sensor images, or float4 vertex maps) of THIS rank's camera."""
@@ -349,6 +374,13 @@ class NativeDist:
                                                 out.data_ptr(), None if lost is None else lost.data_ptr()), "vh_dist_raycast")
         return out
 
+    def comm_info(self):
+        """(rank, size) as the transport reports them (ncclCommUserRank / ncclCommCount over RCCL)."""
+        import ctypes as C
+        r, n = C.c_int32(), C.c_int32()
+        self._L.check(self._lib.vh_dist_comm_info(self._h, C.byref(r), C.byref(n)), "vh_dist_comm_info")
+        return r.value, n.value
+
     def host_stats(self):
         import ctypes as C
         s, n = C.c_double(), C.c_uint64()
@@ -366,6 +398,64 @@ class NativeDist:
             self.close()
         except Exception:
             pass
+
+
+class NativeGroup:
+    """All `world` ranks of the native exchange in ONE process on ONE GPU, joined by the library's loop-back transport
+    (vh_dist_loopback_id) and driven by one host thread per rank -- the stand-in for `world` processes on `world` GPUs that
+    lets vh_dist_step_batch / vh_dist_raycast (the code bench.py --gpus N runs) execute with R > 1 on a single-GPU box.
+    ctypes releases the GIL inside the C calls, so the R calls of a collective really are concurrent."""
+
+    def __init__(self, params, width, height, semantics, world: int, batch: int, sensor_k_inv=None, key_capacity: int = 0,
+                 device: int = -1, options=None, band: float = 0.0):
+        from concurrent.futures import ThreadPoolExecutor
+        uid = loopback_id()
+        self.world, self.batch = world, batch
+        self.ranks = [NativeDist(params, width, height, semantics, r, world, batch, uid, sensor_k_inv=sensor_k_inv,
+                                 key_capacity=key_capacity, device=device) for r in range(world)]
+        for nd in self.ranks:
+            assert nd.transport == "loopback"
+            for k, v in (options or {}).items():
+                nd.table.set_option(k, v)
+            if band > 0.0:
+                nd.table.set_alloc_band(band)
+        self._pool = ThreadPoolExecutor(max_workers=world)
+
+    def _all(self, fn):
+        futures = [self._pool.submit(fn, r, nd) for r, nd in enumerate(self.ranks)]
+        errors, out = [], []
+        for f in futures:
+            try:
+                out.append(f.result())
+            except Exception as e:          # noqa: BLE001 -- every rank's call is awaited before the first error is raised
+                errors.append(e)
+        if errors:
+            raise errors[0]
+        return out
+
+    def step(self, poses, frames):
+        """One exchange: poses[r][b], frames[r][b] for every rank r and frame b of the batch."""
+        self._all(lambda r, nd: nd.step(poses[r], frames[r]))
+
+    def raycast(self, poses, outs, capacity: int, t_min: float = 0.1, t_max: float = 5.0, losts=None):
+        """One raycast round: rank r renders poses[r] into outs[r]."""
+        self._all(lambda r, nd: nd.raycast(poses[r], outs[r], capacity, t_min, t_max, None if losts is None else losts[r]))
+        return outs
+
+    def flush(self):
+        for nd in self.ranks:
+            nd.flush()
+
+    @property
+    def tables(self):
+        return [nd.table for nd in self.ranks]
+
+    def close(self):
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        for nd in self.ranks:
+            nd.close()
 
 
 # ----------------------------------------------------------------------------
@@ -722,22 +812,24 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     native_error = None
     nd = None
     if native:
-        # every rank must take the same path: a rank whose library cannot bind RCCL (or whose communicator fails) sends all
-        # of them to the Python host instead of leaving the others waiting in a collective
-        try:
+        # Every rank must take the same path, and must agree on it BEFORE any native collective: each rank first finds out
+        # locally whether its library can bind RCCL (vh_dist_probe: no collective, nothing created), the outcomes are
+        # reduced, and only then does rank 0 draw the id -- it always takes part in the broadcast -- and every rank call
+        # ncclCommInitRank.  A failure after the agreement (out of memory while the shard is created, say) is fatal for
+        # that rank: it exits and the launcher ends the others, instead of walking into a mismatched collective.
+        from . import _lib as L
+        probe = L.load().vh_dist_probe()
+        if probe != 0:
+            native_error = f"vh_dist_probe: {L.load().vh_last_error().decode()}"
+        ok = torch.tensor([1 if probe == 0 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            native = False
+            native_error = native_error or "another rank's library could not bind RCCL"
+        else:
             uid = unique_id(rank, torch_broadcast_bytes())
             nd = NativeDist(params, Wd, Ht, SEM_PINHOLE, rank, world, batch, uid, sensor_k_inv=k_inv if sensor else None,
                             key_capacity=0, device=local_rank)
-        except Exception as e:          # noqa: BLE001 -- reported in the line
-            native_error = repr(e)
-        ok = torch.tensor([0 if nd is None else 1], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            if nd is not None:
-                nd.close()
-                nd = None
-            native = False
-            native_error = native_error or "another rank could not create its vh_dist"
     with torch.cuda.stream(stream):
         if native:
             # (key bins: the library's default -- ONE bin per (owner, batch) of 1.5 x batch x W*H/16 / world records)
@@ -895,6 +987,7 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     stats = torch.tensor([c["occupied"], c["allocated_total"], c["bin_overflow"]], dtype=torch.int64, device=cdev)
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     out = None
+    comm_ranks = nd.comm_info()[1] if native else None
     if rank == 0:
         frames = args.steps * world * batch
         launches = max(1, kt["launches"])
@@ -943,6 +1036,7 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             vs_baseline=None, dtype="f32", data="synthetic",
             windows=len(windows), timed_s=round(sum(windows), 4),
             host_enqueue_ms_per_step=round(1e3 * statistics.median(host_enqueue) / args.steps, 5),
+            exchange_ranks=dict(transport=nd.transport, ranks=comm_ranks) if native else dict(transport="torch.distributed " + dist.get_backend(), ranks=dist.get_world_size()),
             exchange_host="libvoxelhash_hip.so: vh_dist_step_batch on RCCL directly (include/voxelhash_dist.h)" if native
             else "Python: dist.ShardedPipeline over torch.distributed collectives (--python-exchange / --no-pipeline)"
                  + (f"; the native exchange was not available: {native_error}" if native_error else ""),
