@@ -103,6 +103,13 @@ int vh_dist_flush(vh_dist *d);
 int vh_dist_raycast(vh_dist *d, const float pose[16], float t_min, float t_max, int32_t capacity, float *d_depth_out,
                     int32_t *d_lost);
 
+/* The same round with the slot capacity chosen by the library and no holes: renders, gathers every rank's lost count, and
+ * repeats the round for all ranks with more room while any view lost records (the slots are one size everywhere, so the
+ * ranks decide together).  Synchronises the host.  d_normals_out (nullable): camera-frame normals of the hits, as
+ * vh_raycast_normals.  capacity_used (nullable): the capacity that rendered every view whole.  Collective. */
+int vh_dist_raycast_auto(vh_dist *d, const float pose[16], float t_min, float t_max, float *d_depth_out,
+                         vh_float4 *d_normals_out, int32_t *capacity_used);
+
 /* host seconds spent inside vh_dist_step_batch since creation / the number of calls (diagnostics for bench.py) */
 int vh_dist_host_stats(vh_dist *d, double *seconds, uint64_t *calls);
 

@@ -404,3 +404,36 @@ def test_one_launch_multi_camera_frames_across_the_epoch_wrap(oracle, vh, torch_
     assert sh.table.counters()["epoch"] == 1040 and sh.table.counters()["heap_exhausted"] == 0
     assert check_shard_against_full(sh.table, full, 0, kw["numBuckets"], 5) > 20
     sh.table.close()
+
+
+def test_single_camera_pipelined_frames_between_deferred_multi_camera_halves(oracle, vh, torch_cuda):
+    """a context that holds a multi-camera frame's deferred half (pipeline_shards 2, what vh_dist's shard is set
+    to) is handed pipelined single-camera frames (vh_integrate, option "pipeline"): the deferred half must be served first --
+    the two pipelines share buffer parity and counter sets -- and the other way round at the next multi-camera batch."""
+    torch = torch_cuda
+    plan = vdist.ShardPlan(KW["numBuckets"], 1)
+    sh = vdist.HipShard(vh.default_params(**KW), W, H, 1, plan, 0, W * H // 4, batch=2)
+    sh.table.set_option("pipeline_shards", 2)
+    sh.table.set_option("pipeline", 1)
+    full = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+    keep, step = [], 0
+    for round_ in range(3):
+        frames = [cameras(1, step + b) for b in range(2)]
+        dv = [[torch.from_numpy(frames[b][0][1]).cuda() for b in range(2)]]
+        keep.append(dv)
+        vdist.loopback_step([sh], [[frames[b][0][0] for b in range(2)]], dv)           # leaves the last frame's half pending
+        for cams in frames:
+            full.integrate(cams[0][0], cams[0][1])
+        step += 2
+        for _ in range(1 + round_):                                                    # 1, 2, 3 pipelined single-camera frames
+            (pose, verts), = cameras(1, step)
+            d = torch.from_numpy(verts).cuda()
+            keep.append(d)
+            sh.table.integrate(pose, d)
+            full.integrate(pose, verts)
+            step += 1
+    sh.table.synchronize()
+    assert check_shard_against_full(sh.table, full, 0, KW["numBuckets"], 5) > 100
+    assert sh.table.counters()["occupied"] == len(full.compact())
+    sh.table.close()
+    full.close()

@@ -183,6 +183,7 @@ DIST_SIGNATURES = {
     "vh_dist_raycast": (C.c_int, [_vp, _fp, _f, _f, C.c_int32, _vp, _vp]),
     "vh_dist_host_stats": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "vh_dist_probe": (C.c_int, []),
+    "vh_dist_raycast_auto": (C.c_int, [_vp, _fp, _f, _f, _vp, _vp, C.POINTER(C.c_int32)]),
     "vh_dist_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vh_dist_loopback_id": (C.c_int, [C.c_char_p]),
     "vh_dist_transport_name": (C.c_char_p, [_vp]),

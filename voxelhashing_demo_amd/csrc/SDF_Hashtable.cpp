@@ -88,19 +88,23 @@ void SDF_Hashtable::integrate(const float4x4 &viewMat, const uint16_t *d_depth, 
 
 void SDF_Hashtable::raycast(const float4x4 &pose, float *d_depth_out, float zNear, float zFar)
 {
-    if (dist_) check(vh_dist_raycast(dist_, pose.entries, zNear, zFar, 4096, d_depth_out, nullptr), "raycast");   // through all shards
+    // sharded: through all shards, the record slots sized by the library until no view has holes (collective)
+    if (dist_) check(vh_dist_raycast_auto(dist_, pose.entries, zNear, zFar, d_depth_out, nullptr, nullptr), "raycast");
     else check(vh_raycast(ctx_, pose.entries, zNear, zFar, d_depth_out), "raycast");
 }
 
 void SDF_Hashtable::raycast(const float4x4 &pose, float *d_depth_out, vh_float4 *d_normal_out, float zNear, float zFar)
 {
-    check(vh_raycast_normals(ctx_, pose.entries, zNear, zFar, d_depth_out, d_normal_out), "raycast");
+    if (dist_) check(vh_dist_raycast_auto(dist_, pose.entries, zNear, zFar, d_depth_out, d_normal_out, nullptr), "raycast");
+    else check(vh_raycast_normals(ctx_, pose.entries, zNear, zFar, d_depth_out, d_normal_out), "raycast");
 }
 
 void SDF_Hashtable::raycast(const float4x4 &pose, float *d_depth_out, vh_float4 *d_vertices_out, vh_float4 *d_normals_out,
                             float zNear, float zFar)
 {
-    check(vh_raycast_maps(ctx_, pose.entries, zNear, zFar, d_depth_out, d_vertices_out, d_normals_out), "raycast");
+    // (a sharded table has no vertex-map form: the local shard alone would render a view full of holes)
+    check(dist_ ? VH_ERR_INVALID_ARGUMENT : vh_raycast_maps(ctx_, pose.entries, zNear, zFar, d_depth_out, d_vertices_out, d_normals_out),
+          dist_ ? "raycast with vertex maps is not available on a sharded table: use raycast(pose, depth, normals)" : "raycast");
 }
 
 void SDF_Hashtable::renderBlocks(const float4x4 &pose, float *d_front, float *d_back, float zNear, float zFar)

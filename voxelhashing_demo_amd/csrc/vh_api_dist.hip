@@ -193,6 +193,8 @@ struct vh_dist {
     vh_view_record *viewSend = nullptr, *viewRecv = nullptr;
     int32_t *viewCounts = nullptr;
     int32_t viewCapacity = 0;
+    int32_t *lostDev = nullptr;            // vh_dist_raycast_auto: [0] this view's lost records, [1..R] every rank's
+    int32_t autoCapacity = 0;              // ... and the slot capacity that last rendered every view whole
     double hostSeconds = 0.0;
     uint64_t hostCalls = 0;
 };
@@ -306,7 +308,7 @@ static void dist_free(vh_dist *d)
         if (s.packet) (void)hipFree(s.packet);
         if (s.packets) (void)hipFree(s.packets);
     }
-    for (void *p : {(void *)d->poseMine, (void *)d->poseAll, (void *)d->viewSend, (void *)d->viewRecv, (void *)d->viewCounts})
+    for (void *p : {(void *)d->poseMine, (void *)d->poseAll, (void *)d->viewSend, (void *)d->viewRecv, (void *)d->viewCounts, (void *)d->lostDev})
         if (p) (void)hipFree(p);
     for (int i = 0; i < vh_dist::kSets; ++i)
         for (hipEvent_t e : {d->generated[i], d->ready[i], d->first[i]})
@@ -522,8 +524,8 @@ extern "C" int vh_dist_flush(vh_dist *d)
     return VH_OK;
 }
 
-extern "C" int vh_dist_raycast(vh_dist *d, const float pose[16], float t_min, float t_max, int32_t capacity, float *d_depth_out,
-                               int32_t *d_lost)
+static int dist_raycast_impl(vh_dist *d, const float pose[16], float t_min, float t_max, int32_t capacity, float *d_depth_out,
+                             vh_float4 *d_normals_out, int32_t *d_lost)
 {
     if (!d || !pose || !d_depth_out || capacity < 1) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     const int R = d->cfg.world;
@@ -577,7 +579,9 @@ extern "C" int vh_dist_raycast(vh_dist *d, const float pose[16], float t_min, fl
     if ((rc = vh_export_views_fixed(d->shard, d->poseAll, R, t_min, t_max, d->viewSend, capacity, d->viewCounts)) != VH_OK) return rc;
     if ((rc = d->transport->all_to_all(d, d->viewSend, d->viewRecv, (size_t)capacity * sizeof(vh_view_record), d->sTable)) != VH_OK) return rc;
     if ((rc = vh_import_views(d->view, d->viewRecv, R, capacity, nullptr)) != VH_OK) return rc;
-    if ((rc = vh_raycast(d->view, pose, t_min, t_max, d_depth_out)) != VH_OK) return rc;
+    rc = d_normals_out ? vh_raycast_normals(d->view, pose, t_min, t_max, d_depth_out, d_normals_out)
+                       : vh_raycast(d->view, pose, t_min, t_max, d_depth_out);
+    if (rc != VH_OK) return rc;
     if (d_lost) dist_lost_kernel<<<1, 64, 0, d->sTable>>>(reinterpret_cast<const uint8_t *>(d->viewRecv), R, capacity, d_lost);
     VH_HIP(hipGetLastError());
     if (d->haveUser) {
@@ -585,6 +589,48 @@ extern "C" int vh_dist_raycast(vh_dist *d, const float pose[16], float t_min, fl
         VH_HIP(hipStreamWaitEvent(d->userStream, d->outEvent, 0));
     }
     return VH_OK;
+}
+
+extern "C" int vh_dist_raycast(vh_dist *d, const float pose[16], float t_min, float t_max, int32_t capacity, float *d_depth_out,
+                               int32_t *d_lost)
+{
+    return dist_raycast_impl(d, pose, t_min, t_max, capacity, d_depth_out, nullptr, d_lost);
+}
+
+// The round with the slot capacity found by the library: rendered, the ranks' lost counts gathered (a view with holes on any
+// rank repeats the round for all, since the slots are one size everywhere), repeated with room for what was lost.
+extern "C" int vh_dist_raycast_auto(vh_dist *d, const float pose[16], float t_min, float t_max, float *d_depth_out,
+                                    vh_float4 *d_normals_out, int32_t *capacity_used)
+{
+    if (!d) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(d->device);
+    const int R = d->cfg.world;
+    if (!d->lostDev) {
+        VH_HIP(hipMalloc((void **)&d->lostDev, sizeof(int32_t) * (size_t)(R + 1)));
+        VH_HIP(hipMemset(d->lostDev, 0, sizeof(int32_t) * (size_t)(R + 1)));
+    }
+    // a shard cannot select more blocks than its pool holds, and the view table lists one imported record per entry
+    const int64_t most = std::max<int64_t>(1, std::min<int64_t>((int64_t)d->cfg.table.params.numVoxelBlocks,
+        (int64_t)d->cfg.table.params.numBuckets * d->cfg.table.params.bucketSize / R));
+    int32_t cap = (int32_t)std::min<int64_t>(most, std::max<int32_t>(d->autoCapacity, 4096));
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        int rc = dist_raycast_impl(d, pose, t_min, t_max, cap, d_depth_out, d_normals_out, d->lostDev);
+        if (rc != VH_OK) return rc;
+        if ((rc = d->transport->all_gather(d, d->lostDev, d->lostDev + 1, sizeof(int32_t), d->sTable)) != VH_OK) return rc;
+        int32_t lost[VH_MAX_CAMERAS];
+        VH_HIP(hipMemcpyAsync(lost, d->lostDev + 1, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost, d->sTable));
+        VH_HIP(hipStreamSynchronize(d->sTable));
+        int32_t worst = 0;
+        for (int r = 0; r < R; ++r) worst = std::max(worst, lost[r]);
+        if (worst == 0) {
+            d->autoCapacity = cap;
+            if (capacity_used) *capacity_used = cap;
+            return VH_OK;
+        }
+        if ((int64_t)cap >= most) break;
+        cap = (int32_t)std::min<int64_t>(most, std::max<int64_t>((int64_t)cap + worst, (int64_t)cap * 2));
+    }
+    return fail(VH_ERR_INVALID_ARGUMENT, "vh_dist_raycast_auto: a view selects more blocks of a shard than the shard's pool holds");
 }
 
 extern "C" int vh_dist_comm_info(vh_dist *d, int32_t *rank, int32_t *world)

@@ -334,7 +334,8 @@ static int flush_single_pending(vh_context *c)
     return VH_OK;
 }
 
-// (at most one of the two is pending: every entry point that starts a frame of one kind flushes the other)
+// (at most one of the two is pending: every entry point that starts a frame of one kind flushes the other --
+// vh_integrate / vh_integrate_depth the multi-camera half, vh_apply_frames_batch the single-camera one)
 static int flush_pending(vh_context *c)
 {
     const int rc = flush_single_pending(c);
@@ -458,7 +459,10 @@ extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4
 {
     if (!c || !pose || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(c->device);
-    int rc = vh_set_pose(c, pose);
+    // a single-camera frame on a context that still holds a multi-camera frame's deferred half (pipeline_shards 2, e.g. the
+    // shard of a vh_dist): that half is served first -- the two pipelines share buffer parity and counter sets
+    int rc = flush_multi_pending(c);
+    if (rc == VH_OK) rc = vh_set_pose(c, pose);
     if (rc == VH_OK) rc = vh_reset_mutexes(c);
     if (rc != VH_OK) return rc;
     c->allocEpoch = c->epochTotal;
@@ -472,7 +476,8 @@ extern "C" int vh_integrate_depth(vh_context *c, const float pose[16], const uin
 {
     if (!c || !pose || !d_depth || !k_inv) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(c->device);
-    int rc = vh_set_pose(c, pose);
+    int rc = flush_multi_pending(c);                      // (see vh_integrate)
+    if (rc == VH_OK) rc = vh_set_pose(c, pose);
     if (rc == VH_OK) rc = vh_reset_mutexes(c);
     if (rc != VH_OK) return rc;
     SensorImage in;
