@@ -4,7 +4,8 @@ bench.py times, on C2 (BASELINE.json configs[1]: 640x480, 2^20 buckets x 5, 2^18
   value / roofline        vh_integrate_batch(8) over consecutive frames of the 500-pose loop
   loaded_integrate        the same with vh_set_alloc_band(0.1)
   sensor_depth_input      vh_integrate_depth_batch / vh_integrate_depth on uint16 sensor images
-  sharded_world1          the bucket-range-sharded step (key bins + sensor packets) with one rank over RCCL
+  sharded_world1          vh_dist_step_batch (key bins + sensor packets) with one rank over RCCL, and with two ranks over the
+                          loop-back transport (the N > 1 lines)
   raycast                 vh_raycast on the model those frames built
 Here each of them runs from a FRESH table (so the frames that insert blocks are inside) over 96 frames of that loop in
 batches of 8, next to the oracle (vho_integrate_mt: identical results on several host threads), and is compared slot for
@@ -120,49 +121,75 @@ def test_c2_sensor_depth_frames_from_a_fresh_table(oracle, vh, torch_cuda, loop_
     ot.close()
 
 
-def test_c2_sharded_world1_over_rccl(oracle, vh, torch_cuda, loop_frames):
-    """`sharded_world1`: the code path of the N > 1 lines with one rank -- key generation from the sensor images, the
-    all-to-all of the key bins and the all-gather of the sensor packets over RCCL, vh_apply_frames_batch -- through the
-    three-stream pipeline bench.py uses, at C2's table size, batches of 8."""
-    import os
-    import socket
-
-    import torch.distributed as dist
-
+@pytest.mark.parametrize("world", [1, 2])
+def test_c2_sharded_native_exchange(oracle, vh, torch_cuda, loop_frames, world):
+    """`sharded_world1` and the N > 1 lines: the bucket-range-sharded path as bench.py runs it -- vh_dist_step_batch inside the
+    library (key generation from the sensor images into ONE bin per (owner, batch), all-to-all of the bins, all-gather of the
+    sensor packets, vh_apply_frames_batch with the batch's last frame deferred into the next exchange) at C2's table size,
+    batches of 8, the library's default bin size.  world 1: over RCCL (ncclCommInitRank with one rank, as the bench leg);
+    world 2: two ranks of this process over the loop-back transport, each camera feeding its own 48 frames of the loop."""
+    from test_gpu_configs import assert_slice_equals, compare_blocks
     from voxelhashing_demo_amd import dist as vdist
     torch = torch_cuda
     poses, verts = loop_frames
     kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
     n = 48
-    d16 = [np.round(v[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for v in verts[:n]]
-    pre = [oracle.preprocess(d, kinv)[0] for d in d16]
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        plan = vdist.ShardPlan(KW["numBuckets"], 1)
-        transport = vdist.TorchDistTransport()
-        table_stream, front = torch.cuda.Stream(), torch.cuda.Stream()
-        capacity = max(2048, -(-W * H // 16))                  # bench_sharded's bin size
-        sh = vdist.HipShard(vh.default_params(**KW), W, H, 1, plan, 0, capacity, batch=BATCH, stream=table_stream, sets=2,
-                            sensor_k_inv=kinv)
-        pipe = vdist.ShardedPipeline(sh, transport, table_stream, front)
-        dv = [torch.from_numpy(v).cuda() for v in pre]
-        dd = [torch.from_numpy(d).cuda() for d in d16]
-        torch.cuda.synchronize()
-        ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
-        for k in range(0, n, BATCH):
-            pipe.feed(poses[k:k + BATCH], dv[k:k + BATCH], dd[k:k + BATCH])
-            for j in range(k, k + BATCH):
-                ot.integrate_mt(poses[j], pre[j], THREADS)     # one camera: the multi-camera frame is integrate()
-        pipe.flush()
-        torch.cuda.synchronize()
-        assert sh.table.counters()["bin_overflow"] == 0
-        _compare_light(ot, sh.table)
-        sh.table.close()
-        ot.close()
-    finally:
-        dist.destroy_process_group()
+    # camera r walks frames r*n .. r*n+n-1 of the loop (world 1: the bench's single camera)
+    d16 = [[np.round(v[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for v in verts[r * n:(r + 1) * n]] for r in range(world)]
+    pre = [[oracle.preprocess(d, kinv)[0] for d in d16[r]] for r in range(world)]
+    cam_poses = [poses[r * n:(r + 1) * n] for r in range(world)]
+    dd = [[torch.from_numpy(d).cuda() for d in d16[r]] for r in range(world)]
+    torch.cuda.synchronize()
+    ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+    if world == 1:
+        ranks = [vdist.NativeDist(vh.default_params(**KW), W, H, 1, 0, 1, BATCH, vdist.unique_id(), sensor_k_inv=kinv)]
+        assert ranks[0].transport == "rccl" and ranks[0].comm_info() == (0, 1)
+        group = None
+    else:
+        group = vdist.NativeGroup(vh.default_params(**KW), W, H, 1, world, BATCH, sensor_k_inv=kinv)
+        ranks = group.ranks
+    for k in range(0, n, BATCH):
+        if group:
+            group.step([cam_poses[r][k:k + BATCH] for r in range(world)], [dd[r][k:k + BATCH] for r in range(world)])
+        else:
+            ranks[0].step(cam_poses[0][k:k + BATCH], dd[0][k:k + BATCH])
+        for j in range(k, k + BATCH):
+            if world == 1:
+                ot.integrate_mt(cam_poses[0][j], pre[0][j], THREADS)       # one camera: the multi-camera frame is integrate()
+            else:
+                vdist.reference_multi_camera_frame(ot, [cam_poses[r][j] for r in range(world)], [pre[r][j] for r in range(world)])
+    for nd in ranks:
+        nd.flush()
+    torch.cuda.synchronize()
+    if world == 1:
+        assert ranks[0].table.counters()["bin_overflow"] == 0
+        _compare_light(ot, ranks[0].table)
+    else:
+        plan = vdist.ShardPlan(KW["numBuckets"], world)
+        otab, total = ot.hash_table(), 0
+        for r, nd in enumerate(ranks):
+            lo, hi = plan.bucket_range(r)
+            gtab = nd.table.hash_table()
+            assert_slice_equals(gtab, otab, lo, hi, 5, f"shard {r}")
+            total += compare_blocks(nd.table, gtab, ot, otab[lo * 5:hi * 5], every=7)
+            c = nd.table.counters()
+            assert c["bin_overflow"] == 0 and c["heap_exhausted"] == 0 and c["epoch"] == n
+        assert total > 100
+    # the raycast round through the shards
+    outs = [torch.empty((H, W), dtype=torch.float32, device="cuda") for _ in range(world)]
+    view_poses = [cam_poses[r][20] for r in range(world)]
+    if group:
+        group.raycast(view_poses, outs, 8192)
+    else:
+        ranks[0].raycast(view_poses[0], outs[0], 8192)
+    for nd in ranks:
+        nd.flush()
+    torch.cuda.synchronize()
+    for r in range(world):
+        want = ot.raycast(view_poses[r])
+        assert np.array_equal(outs[r].cpu().numpy().view(np.uint32), want.view(np.uint32)) and (want > 0).mean() > 0.5
+    if group:
+        group.close()
+    else:
+        ranks[0].close()
+    ot.close()

@@ -1,33 +1,31 @@
 #!/usr/bin/env python3
-"""R bucket-range shards on ONE GPU with the in-process exchange: what a rank's kernels cost per
-multi-camera frame when the table is cut R ways (the collectives are not part of this).
-   tools/emulate_ranks.py [R=8] [batch=8] [pipeline_shards=1] [per_batch_bins=0]"""
-import os, sys, time
+"""R ranks of the NATIVE exchange (vh_dist_step_batch -- the code bench.py --gpus N runs) on ONE GPU, joined by the library's
+loop-back transport, one host thread per rank: what a rank's launches cost per multi-camera frame when the table is cut R
+ways, how full the key bins get, and what the whole rig sustains.  The bytes cross by hipMemcpyAsync instead of xGMI, and
+the R ranks share one GPU, so the frames/s figure is a rig number, not a scaling point.
+   tools/emulate_ranks.py [R=8] [batch=8] [workload=C2|C5] [steps=12]"""
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-import voxelhashing_demo_amd as V
-from voxelhashing_demo_amd import dist as vdist, synth
 
-W, H = 640, 480
+import voxelhashing_demo_amd as V
+from voxelhashing_demo_amd import dist as vdist
+from voxelhashing_demo_amd import synth
+
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-K = synth.K_matrix(W, H)
-kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+WL = sys.argv[3] if len(sys.argv) > 3 else "C2"
+STEPS = int(sys.argv[4]) if len(sys.argv) > 4 else 12
+W, H, NB, VOX, BLOCKS = (640, 480, 1 << 20, 0.02, 1 << 16) if WL == "C2" else (1920, 1080, 1 << 24, 0.01, 1 << 16)
+kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
 prims = synth.room_primitives()
-plan = vdist.ShardPlan(1 << 20, R)
-PER_BATCH = len(sys.argv) > 4 and int(sys.argv[4]) != 0
-# per-frame bins: one record per 16 pixels whatever the number of owners (bench.py's size); per-batch bins: vh_dist's default
-cap = max(2048, (-(-W * H // 16) * B * 3 // 2 + R - 1) // R + 1) if PER_BATCH else max(2048, -(-W * H // 16))
-shards = [vdist.HipShard(V.default_params(numBuckets=1 << 20, numVoxelBlocks=1 << 16), W, H, 1, plan, r, cap, batch=B,
-                         sensor_k_inv=kinv, per_batch_bins=PER_BATCH) for r in range(R)]
-if len(sys.argv) > 3:
-    for sh in shards:
-        sh.table.set_option("pipeline_shards", int(sys.argv[3]))      # 0: two launches per multi-camera frame
-if os.environ.get("VH_LEAN") is not None:
-    for sh in shards:
-        sh.table.set_option("lean_kernels", int(os.environ["VH_LEAN"]))
-nf = 64
+params = V.default_params(numBuckets=NB, numVoxelBlocks=BLOCKS, voxelSize=VOX)
+g = vdist.NativeGroup(params, W, H, 1, R, B, sensor_k_inv=kinv)
+nf = 32 if WL == "C2" else 8
 poses = [synth.camera_loop(500, phase=vdist.camera_phase(r, R))[:nf] for r in range(R)]
 depth = [[(synth.render_room_verts(p, W, H, prims, device="cuda")[..., 2] * 5000).round().clamp(0, 65535).to(torch.uint16)
           for p in poses[r]] for r in range(R)]
@@ -36,35 +34,38 @@ torch.cuda.synchronize()
 
 def exchange(i):
     ks = [(i * B + b) % nf for b in range(B)]
-    vdist.loopback_step(shards, [[poses[r][k] for k in ks] for r in range(R)], [[None] * B for _ in range(R)],
-                        [[depth[r][k] for k in ks] for r in range(R)])
+    g.step([[poses[r][k] for k in ks] for r in range(R)], [[depth[r][k] for k in ks] for r in range(R)])
 
 
 for i in range(4):
     exchange(i)
+g.flush()
 torch.cuda.synchronize()
-shards[0].table.set_profiling(True)
-n = 6
-for i in range(n):
+t0 = time.perf_counter()
+for i in range(STEPS):
     exchange(4 + i)
+g.flush()
 torch.cuda.synchronize()
-kt = shards[0].table.kernel_times(reset=True)
-frames = n * B
-print(f"R={R} batch={B}: rank 0 per multi-camera frame ({R} cameras): one-launch frames {1e3*kt['frame_pipelined_ms']/frames:.2f} us "
-      f"(B + 1 launches per batch; two-launch form: scan+claim {1e3*kt['frame_scan_claim_ms']/frames:.2f} us, "
-      f"commit+integrate {1e3*kt['frame_commit_integrate_ms']/frames:.2f} us); shard {shards[0].table.num_entries*20/1e6:.1f} MB, "
-      f"occupied {shards[0].table.counters()['occupied']}, bins {cap*16*R*(1 if PER_BATCH else B)/1e6:.2f} MB "
-      f"({'one per (owner, batch)' if PER_BATCH else 'one per (owner, frame)'}, {cap} records) and packets {shards[0].packet_floats*4*R*B/1e6:.1f} MB received per exchange")
-fill = max(int(sh.bins_recv[:, :, 0, 0].max().item()) for sh in shards)
-print(f"fullest bin of the last exchange: {fill} of {cap - 1} records; bin overflows over the run: {sum(sh.table.counters()['bin_overflow'] for sh in shards)}")
-# key generation of a batch, timed on the device
-sh = shards[0]
-ks = list(range(B))
-for _ in range(3):
-    sh.generate_all([poses[0][k] for k in ks], [None] * B, [depth[0][k] for k in ks])
+wall = time.perf_counter() - t0
+for t in g.tables:
+    t.set_profiling(True)
+for i in range(3):
+    exchange(4 + STEPS + i)
+g.flush()
 torch.cuda.synchronize()
-t = time.perf_counter()
-for _ in range(50):
-    sh.generate_all([poses[0][k] for k in ks], [None] * B, [depth[0][k] for k in ks])
-torch.cuda.synchronize()
-print(f"key generation + packets of a batch of {B}: {1e6*(time.perf_counter()-t)/50:.1f} us")
+frames = 3 * B
+cap = max(2048, (-(-W * H // 16) * B * 3 // 2 + R - 1) // R + 1)
+per_rank = []
+for r, t in enumerate(g.tables):
+    kt = t.kernel_times(reset=True)
+    per_rank.append(1e3 * kt["frame_pipelined_ms"] / frames)
+    t.set_profiling(False)
+c0 = g.tables[0].counters()
+print(f"{WL} R={R} batch={B} transport={g.ranks[0].transport}: frame_multi_pipelined_kernel per multi-camera frame ({R} cameras), per rank: "
+      + " ".join(f"{x:.2f}" for x in per_rank) + f" us; shard {g.tables[0].num_entries * 20 / 1e6:.1f} MB, rank 0 occupied {c0['occupied']}")
+print(f"key bins: {cap} records per (owner, batch) = {cap * 16 * R / 1e6:.2f} MB per rank and exchange; bin overflows over the run: "
+      f"{sum(t.counters()['bin_overflow'] for t in g.tables)}; host time in vh_dist_step_batch per exchange (rank 0): "
+      f"{1e6 * g.ranks[0].host_stats()[0] / g.ranks[0].host_stats()[1]:.0f} us")
+print(f"rig throughput (all {R} ranks on this one GPU, loop-back copies): {STEPS * B * R / wall:.0f} frames/s "
+      f"= {1e6 * wall / (STEPS * B):.1f} us per multi-camera frame for the {R} shards together")
+g.close()
