@@ -50,12 +50,17 @@ WORKLOADS = {
                desc="C3: synthetic room, 1280x960, 2^22 buckets x 5 (419 MB of VoxelEntry: beyond the 256 MiB "
                     "Infinity Cache), 2^21 voxel blocks, voxel 0.005 m, PINHOLE semantics (the first 200 poses of "
                     "the 2000-pose path resident)"),
+    # C3's frames into a table of C5's size on ONE GPU (2^24 buckets x 5 = 1.68 GB of VoxelEntry, 6.5 x the Infinity Cache): the
+    # walk with no residency left to argue about ("prove the HBM figure")
+    "C5table": dict(width=1280, height=960, frames=64, buckets=1 << 24, blocks=1 << 21, voxel=0.005, loop=2000,
+                    desc="C5table: C3's 1280x960 frames into an unsharded table of C5's size, 2^24 buckets x 5 (1.68 GB of "
+                         "VoxelEntry = 6.5 x the 256 MiB Infinity Cache), 2^21 voxel blocks, voxel 0.005 m, PINHOLE semantics"),
     # BASELINE.json configs[4], per-rank share when launched with --gpus 8 (one stream per GPU)
     "C5": dict(width=1920, height=1080, frames=64, buckets=1 << 24, blocks=1 << 21, voxel=0.01, loop=500,
                desc="C5: synthetic room, 1920x1080 streams, 2^24 buckets x 5 in all, 2^21 voxel blocks per rank, "
                     "voxel 0.01 m, PINHOLE semantics"),
 }
-ALL_LEGS = ("two_launch", "first_lap", "index", "sensor", "raycast", "next", "loaded", "c3", "sharded", "cpu")
+ALL_LEGS = ("two_launch", "first_lap", "index", "sensor", "raycast", "next", "loaded", "c3", "c5table", "sharded", "cpu")
 
 
 def parse_args():
@@ -83,6 +88,8 @@ def parse_args():
                     help="sharded path: float vertex maps and float camera-z packets instead of uint16 sensor depth")
     ap.add_argument("--sharded-raycast", action="store_true",
                     help="sharded path: also time the raycast over the shards (always on with one rank)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="vh_set_option on the measured table (A/B switches: walk_entries=8, lean_kernels=0, claim_span=60 ...); repeatable")
     ap.add_argument("--sharded", action="store_true",
                     help="force the bucket-range-sharded path (torch.distributed) even with one rank")
     a = ap.parse_args()
@@ -180,6 +187,9 @@ class Integrator:
         self.table = V.SDFHashtable(params, wl["width"], wl["height"], V.SEM_PINHOLE, device=local_rank, stream=stream)
         if wl.get("band"):
             self.table.set_alloc_band(wl["band"])
+        for kv in wl.get("options", []):
+            k, v = kv.split("=")
+            self.table.set_option(k, int(v))
         # pipelined frames: one launch per frame (the commit + TSDF update of frame i ride in the launch of
         # frame i+1); every synchronisation flushes, so a timed window contains all of its frames' work
         self.table.set_option("pipeline", 1 if pipeline else 0)
@@ -283,7 +293,7 @@ class Integrator:
 def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, want_profile=True, frames=None,
                      pipeline=True):
     """Timed windows + dominant-kernel roofline of one single-GPU workload.  Returns (record, Integrator, poses, verts)."""
-    wl = WORKLOADS[name]
+    wl = dict(WORKLOADS[name], options=list(getattr(args, "option", [])))
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.Stream(device=dev)
     nframes = args.frames or wl["frames"]
@@ -658,6 +668,15 @@ def main():
             del d3
         extra["configs"] = {"C3": c3_rec}
         c3_it.close()
+        if "c5table" in legs:
+            # the same frames into a 1.68 GB table: 64 of them, short windows (a frame takes ~ 0.25 ms)
+            n5 = min(len(c3_poses), WORKLOADS["C5table"]["frames"])
+            c5_rec, c5_it, _, _ = measure_workload(args, V, L, synth, torch, "C5table", local_rank, 25, 5,
+                                                   frames=(c3_poses[:n5], c3_verts[:n5]))
+            c5_rec["workload"] = WORKLOADS["C5table"]["desc"]
+            c5_rec["unit"] = "frames/s"
+            extra["configs"]["C5table"] = c5_rec
+            c5_it.close()
         del c3_verts
         torch.cuda.empty_cache()
         poses, verts = render_frames(synth, wl, min(nframes, 64), dev, torch)     # for the CPU sample below
