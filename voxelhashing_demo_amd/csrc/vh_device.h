@@ -229,6 +229,10 @@ __device__ __forceinline__ float4 mat4_mul(const float *m, float x, float y, flo
 }
 
 // project, VoxelUtils.cu:770-777: M*p, true divides by .z, implicit float->int
+// (The two divisions share their divisor, and div_fixed with one refined reciprocal gives the same bits in 13 instead of 26
+// instructions where its range conditions hold -- measured in round 4, same box (profiles/r04_ab_frame_project.txt): the
+// range tests and the branch to the plain division cost more than the divisions saved: C2 launch 17.65 -> 18.20 us, C3
+// 67.7 -> 68.5, the TSDF-update launch of C3 11.6 -> 12.4.  Not adopted.)
 __device__ __forceinline__ void project(const float *m, float x, float y, float z, int &sx, int &sy)
 {
     const float qx = m[0] * x + m[1] * y + m[2] * z;
