@@ -207,11 +207,18 @@ int vh_set_alloc_band(vh_context *ctx, float band_metres);
  *                       d_normals argument of vh_alloc_blocks / vh_integrate (preProcess's normal map, camera
  *                       frame), pixels without a normal demand their surface block only.  Not offered by
  *                       vh_integrate_depth and the key-generation calls (they carry no normal map).
+ *                       VH_BAND_RAY_DDA: the same block DDA along the pixel's VIEWING RAY -- every block the segment
+ *                       from the ray's point at camera depth z - band to its point at z + band crosses (a band that
+ *                       would begin behind the camera begins at the surface point): the exact set the samples of
+ *                       VH_BAND_RAY approximate, at one transform per segment end and the DDA's divisions per pixel
+ *                       instead of a transform and four divisions per sample; needs no normals, offered by every
+ *                       entry point.
  *   "depth_truncation" 1   truncation + truncScale * depth in the TSDF update (VoxelUtils.cu:815, getTruncation)
  *   "weight_sample" 1      sample weight max(integrationWeightSample * 1.5 * (1 - (depth - 0.5) / 4.5), 1) instead of
  *                          0.1 (VoxelUtils.cu:808-811, :827) */
 #define VH_BAND_RAY        0
 #define VH_BAND_NORMAL_DDA 1
+#define VH_BAND_RAY_DDA    2
 
 /* SDF_Hashtable.cpp:15-21: stores the pose and its cofactor inverse
  * (cuda_SimpleMatrixUtil.h:944-1069, same summation order, fp32, on the host) */

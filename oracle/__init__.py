@@ -18,7 +18,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "libvh_oracle.so")
 SEM_REFERENCE = 0
 SEM_PINHOLE = 1
 FREE_BLOCK = -1
-BAND_RAY, BAND_NORMAL_DDA = 0, 1
+BAND_RAY, BAND_NORMAL_DDA, BAND_RAY_DDA = 0, 1, 2
 INT_DEPTH_TRUNCATION, INT_WEIGHT_SAMPLE = 1, 2
 RAYCAST_FIXED_STEP, RAYCAST_DDA = 0, 1
 POS_SENTINEL = 0x7FFFFFFF

@@ -27,7 +27,7 @@ struct vho_table {
     float rc_fx, rc_fy, rc_cx, rc_cy;
     uint32_t bucket_lo, bucket_hi;  /* this table owns buckets [lo, hi) of the logical table */
     float alloc_band;               /* 0: surface block only (reference); > 0: truncation-band allocation */
-    int   band_mode;                /* VHO_BAND_RAY / VHO_BAND_NORMAL_DDA */
+    int   band_mode;                /* VHO_BAND_RAY / VHO_BAND_NORMAL_DDA / VHO_BAND_RAY_DDA */
     const float *normals;           /* normal map of the running allocBlocks (NORMAL_DDA), camera frame */
     int   overflow;                 /* overflow linked list on (VoxelUtils.cu:384-411,458-539,578-602 done right) */
     uint32_t overflow_seg;          /* chains wrap inside segments of this many buckets (0: the owned range) */
@@ -588,23 +588,12 @@ static int band_key(const vho_table *t, const float *v, int k, int nS, float ste
 void vho_set_band_mode(vho_table *t, int mode) { t->band_mode = mode; }
 void vho_set_normals(vho_table *t, const float *normals) { t->normals = normals; }
 
-static int dda_keys(const vho_table *t, const float *v, const float *nrm, int32_t keys[][3])
+/* the block DDA of both DDA band modes: every block the segment start -> end crosses, from start's block on */
+static int dda_walk(const vho_table *t, const float start[3], const float end[3], int32_t keys[][3])
 {
-    float g[4];
-    vho_mat4_mul_vec4(t->p.global_transform, v, g);                   /* :622, w as stored */
-    vho_world2block(g, t->p.voxelSize, t->p.voxelBlockSize, keys[0]);
-    if (!nrm || (nrm[0] == 0.0f && nrm[1] == 0.0f && nrm[2] == 0.0f) || nrm[0] != nrm[0] || nrm[1] != nrm[1] ||
-        nrm[2] != nrm[2])
-        return 1;
-    const float *T = t->p.global_transform;
-    const float b = t->alloc_band, vs = t->p.voxelSize;
-    float start[3], end[3], dir[3];
-    for (int a = 0; a < 3; ++a) {
-        const float nw = T[4*a+0]*nrm[0] + T[4*a+1]*nrm[1] + T[4*a+2]*nrm[2];
-        start[a] = g[a] - (b * nw);                                   /* :632 */
-        end[a] = g[a] + (b * nw);                                     /* :633 */
-        dir[a] = end[a] - start[a];
-    }
+    const float vs = t->p.voxelSize;
+    float dir[3];
+    for (int a = 0; a < 3; ++a) dir[a] = end[a] - start[a];
     int32_t cur[3], last[3];
     vho_world2block(start, vs, t->p.voxelBlockSize, cur);
     vho_world2block(end, vs, t->p.voxelBlockSize, last);
@@ -634,6 +623,45 @@ static int dda_keys(const vho_table *t, const float *v, const float *nrm, int32_
     return n;
 }
 
+static int dda_keys(const vho_table *t, const float *v, const float *nrm, int32_t keys[][3])
+{
+    float g[4];
+    vho_mat4_mul_vec4(t->p.global_transform, v, g);                   /* :622, w as stored */
+    vho_world2block(g, t->p.voxelSize, t->p.voxelBlockSize, keys[0]);
+    if (!nrm || (nrm[0] == 0.0f && nrm[1] == 0.0f && nrm[2] == 0.0f) || nrm[0] != nrm[0] || nrm[1] != nrm[1] ||
+        nrm[2] != nrm[2])
+        return 1;
+    const float *T = t->p.global_transform;
+    const float b = t->alloc_band;
+    float start[3], end[3];
+    for (int a = 0; a < 3; ++a) {
+        const float nw = T[4*a+0]*nrm[0] + T[4*a+1]*nrm[1] + T[4*a+2]*nrm[2];
+        start[a] = g[a] - (b * nw);                                   /* :632 */
+        end[a] = g[a] + (b * nw);                                     /* :633 */
+    }
+    return dda_walk(t, start, end, keys);
+}
+
+/* Third band mode, VHO_BAND_RAY_DDA (round 4): the same block DDA along the pixel's VIEWING RAY instead of its normal --
+ * every block the world-space segment from the ray's point at camera depth z - b to its point at depth z + b crosses
+ * (z = the vertex's depth, b = alloc_band; a band that would begin at or behind the camera begins at the surface point
+ * instead).  What the ray samples of VHO_BAND_RAY approximate with 2*ceil(b / half a block)+1 points: here the blocks
+ * are exactly those the segment crosses, one transform per segment end and the DDA's divisions per PIXEL, nothing per
+ * sample.  The two ends: the vertex scaled to the end's depth, (x*s/z, y*s/z, s, w), through global_transform as :622. */
+static int ray_dda_keys(const vho_table *t, const float *v, int32_t keys[][3])
+{
+    const float z = v[2], b = t->alloc_band;
+    float s0 = z - b;
+    if (!(s0 > 0.0f)) s0 = z;
+    const float s1 = z + b;
+    const float c0 = s0 / z, c1 = s1 / z;
+    const float p0[4] = { v[0] * c0, v[1] * c0, s0, v[3] }, p1[4] = { v[0] * c1, v[1] * c1, s1, v[3] };
+    float g0[4], g1[4];
+    vho_mat4_mul_vec4(t->p.global_transform, p0, g0);
+    vho_mat4_mul_vec4(t->p.global_transform, p1, g1);
+    return dda_walk(t, g0, g1, keys);
+}
+
 /* the block keys pixel (x,y) demands, in rank order; valid[k] = 0 where a ray sample has no key */
 static int pixel_keys(const vho_table *t, const float *verts, int x, int y, int nS, float step, int32_t keys[][3],
                       uint8_t *valid)
@@ -641,6 +669,11 @@ static int pixel_keys(const vho_table *t, const float *verts, int x, int y, int 
     const float *v = verts + 4 * ((size_t)y * t->width + x);
     if (t->band_mode == VHO_BAND_NORMAL_DDA && t->alloc_band > 0.0f) {
         const int n = dda_keys(t, v, t->normals ? t->normals + 4 * ((size_t)y * t->width + x) : NULL, keys);
+        for (int k = 0; k < n; ++k) valid[k] = 1;
+        return n;
+    }
+    if (t->band_mode == VHO_BAND_RAY_DDA && t->alloc_band > 0.0f) {
+        const int n = ray_dda_keys(t, v, keys);
         for (int k = 0; k < n; ++k) valid[k] = 1;
         return n;
     }
@@ -797,7 +830,7 @@ int vho_integrate_mt(vho_table *t, const float pose[16], const float *verts, int
     float step;
     const int nS = band_samples(t, &step);
     /* ---- allocBlocks: keys in parallel, insertions in launch order ---- */
-    const int maxK = (t->band_mode == VHO_BAND_NORMAL_DDA && t->alloc_band > 0.0f) ? VHO_MAX_BAND_SAMPLES : nS;
+    const int maxK = (t->band_mode != VHO_BAND_RAY && t->alloc_band > 0.0f) ? VHO_MAX_BAND_SAMPLES : nS;
     int32_t *keys = (int32_t *)malloc((size_t)W * H * maxK * 4 * sizeof(int32_t));   /* {x,y,z,wanted} */
     if (!keys) return -1;
     #pragma omp parallel for num_threads(threads) schedule(static)

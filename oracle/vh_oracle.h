@@ -86,6 +86,7 @@ void       vho_set_raycast_intrinsics(vho_table *t, float fx, float fy, float cx
 void       vho_set_alloc_band(vho_table *t, float band_metres);
 #define VHO_BAND_RAY        0   /* samples on the viewing ray, half-block steps (round 1) */
 #define VHO_BAND_NORMAL_DDA 1   /* block DDA from p - b*n to p + b*n (VoxelUtils.cu:632-703, commented out there) */
+#define VHO_BAND_RAY_DDA    2   /* the same block DDA along the viewing ray, from depth z - b to z + b (round 4) */
 void       vho_set_band_mode(vho_table *t, int mode);
 void       vho_set_normals(vho_table *t, const float *normals);   /* W*H float4, camera frame; borrowed; NULL = none */
 /* opt-in overflow linked list (VoxelUtils.cu:384-411, 458-539, 578-602: dead code there); chains wrap

@@ -290,3 +290,57 @@ def test_tsdf_update_variants(oracle, vh, torch_cuda):
         _compare(ot, gt)
         w = gt.sdf_blocks()["weight"]
         assert (w.max() > 25.0) == bool(flags & 2)
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_ray_dda_band(oracle, vh, torch_cuda, variant):
+    """VH_BAND_RAY_DDA: band allocation by the block DDA along the viewing ray (no normals), every frame form, vertex maps
+    and -- the DDA needs no normal map -- the sensor-depth entry point; the room with a moving camera, slot-exact."""
+    torch = torch_cuda
+    W, H = 320, 240
+    ot, gt = pair(oracle, vh, variant, W, H, 1, overflow=False, numBuckets=1 << 15, numVoxelBlocks=1 << 15)
+    ot.set_alloc_band(0.1, oracle.BAND_RAY_DDA)
+    gt.set_alloc_band(0.1)
+    gt.set_option("band_mode", vh.BAND_RAY_DDA)
+    kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+    poses = synth.camera_loop(60)
+    prims = synth.room_primitives()
+    for n, i in enumerate((0, 2, 4, 9, 11, 30)):
+        v = synth.render_room_verts(poses[i], W, H, prims).numpy()
+        if n % 2:
+            d16 = np.round(v[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16)
+            ot.integrate(poses[i], oracle.preprocess(d16, kinv)[0])
+            gt.integrate_depth(poses[i], torch.from_numpy(d16).cuda(), kinv)
+        else:
+            ot.integrate(poses[i], v)
+            gt.integrate(poses[i], torch.from_numpy(v).cuda())
+        gt.synchronize()
+        _compare(ot, gt)
+    assert len(gt.allocated()) > 1500
+    ot.close()
+    gt.close()
+
+
+def test_ray_dda_band_on_native_ranks(oracle, vh, torch_cuda):
+    """... and through the native exchange: the key generation of vh_dist walks the same DDA (records carry frame | launch
+    rank | step)."""
+    torch = torch_cuda
+    from test_gpu_dist_loopback import _camera_frames, _feed
+    from test_sharding_cpu import check_shard_against_full
+    W, H, world, batch, band = 320, 240, 2, 2, 0.1
+    kw = dict(numBuckets=1 << 14, numVoxelBlocks=1 << 14)
+    frames, kinv = _camera_frames(oracle, torch, world, 4, W, H, True)
+    full = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    full.set_alloc_band(band, oracle.BAND_RAY_DDA)
+    g = vdist.NativeGroup(vh.default_params(**kw), W, H, 1, world, batch, sensor_k_inv=kinv, key_capacity=W * H * batch,
+                          band=band, options={"band_mode": vh.BAND_RAY_DDA})
+    _feed(g, full, frames, batch)
+    g.flush()
+    plan = vdist.ShardPlan(kw["numBuckets"], world)
+    total = 0
+    for r, t in enumerate(g.tables):
+        total += check_shard_against_full(t, full, *plan.bucket_range(r), 5)
+        assert t.counters()["bin_overflow"] == 0
+    assert total == len(full.allocated()) > 500
+    g.close()
+    full.close()

@@ -292,3 +292,48 @@ def test_depth_truncation_and_sample_weight(oracle):
     assert len(one) > 10000 and one.max() < 11.5
     depth = 0.5 + 4.5 * (1.0 - one.astype(np.float64) / 15.0)                     # invert the weight formula
     assert 1.4 < depth.min() and depth.max() < 2.7
+
+
+def test_ray_dda_band_geometry(oracle):
+    """BAND_RAY_DDA (round 4): every block the segment of the viewing ray between depths z - b and z + b crosses.  A superset
+    of what dense sampling of those segments finds (up to the frustum test), nothing farther from the surface along the ray
+    than the band plus a block, the surface blocks included; tighter than the five ray samples of BAND_RAY, which reach +-16 cm."""
+    W, H, band = 160, 120, 0.1
+    verts, _, n = _plane_scene(W, H)
+    kw = dict(numBuckets=1 << 14, numVoxelBlocks=1 << 14)
+    surf = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    ray = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    dda = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    ray.set_alloc_band(band, oracle.BAND_RAY)
+    dda.set_alloc_band(band, oracle.BAND_RAY_DDA)
+    for _ in range(12):
+        surf.integrate(I4, verts)
+        ray.integrate(I4, verts)
+        dda.integrate(I4, verts)
+    s_keys = set(map(tuple, surf.allocated()["pos"].tolist()))
+    r_keys = set(map(tuple, ray.allocated()["pos"].tolist()))
+    d_keys = set(map(tuple, dda.allocated()["pos"].tolist()))
+    assert s_keys <= d_keys and len(d_keys) > 1.5 * len(s_keys)
+    # (BAND_RAY's outermost samples sit at +-2 half-block steps = +-16 cm for a 10 cm band: the DDA's set is the tighter one)
+    assert len(d_keys) < len(r_keys) and len(d_keys - r_keys) <= len(d_keys) // 10
+    vs = np.float32(0.02)
+    want = set()
+    for y in range(1, H, 7):
+        for x in range(0, W, 5):
+            p = verts[y, x, :3].astype(np.float64)
+            for s in np.linspace(p[2] - band, p[2] + band, 41):
+                q = (p * (s / p[2])).astype(np.float32)
+                want.add(tuple(int(c) for c in oracle.world2block(q, float(vs))))
+    visible = {k for k in want if dda.block_in_frustum(k)}
+    missing = visible - d_keys
+    assert len(missing) <= len(visible) // 200, f"{len(missing)} of {len(visible)} sampled band blocks are missing"
+    centres = (np.array(sorted(d_keys), np.float64) * 8 + 3.5) * 0.02
+    dist = np.abs((centres - np.array([0, 0, 1.3])) @ n)
+    assert dist.max() <= band + 0.16 * np.sqrt(3) / 2 + 0.02       # (the ray leans at most ~35 degrees off the plane normal here: closer than along the ray)
+    # a surface closer to the camera than the band: the band begins at the surface point
+    near = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    near.set_alloc_band(0.5, oracle.BAND_RAY_DDA)
+    v2 = verts.copy()
+    v2[..., :3] *= np.float32(0.3 / 1.3)
+    near.integrate(I4, v2)
+    assert len(near.allocated()) > 0

@@ -19,6 +19,9 @@ verts = [synth.render_room_verts(p, Wd, Ht, prims, device="cuda") for p in poses
 t = V.SDFHashtable(V.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"]), Wd, Ht, V.SEM_PINHOLE)
 if wl.get("band"):
     t.set_alloc_band(wl["band"])
+for kv in sys.argv[2:]:            # name=value options (band_mode=2 ...)
+    k, v = kv.split("=")
+    t.set_option(k, int(v))
 for i in range(60):
     t.integrate(poses[i], verts[i])
 t.synchronize()

@@ -8,3 +8,4 @@ from ._lib import (SEM_PINHOLE, SEM_REFERENCE, HashTableParams, VoxelHashError, 
 from .hashtable import ENTRY_DTYPE, VOXEL_DTYPE, SDFHashtable, default_params, preprocess  # noqa: F401
 
 RAYCAST_FIXED_STEP, RAYCAST_DDA = 0, 1      # vh_set_option(ctx, "raycast_mode", ...), include/voxelhash.h
+BAND_RAY, BAND_NORMAL_DDA, BAND_RAY_DDA = 0, 1, 2      # vh_set_option(ctx, "band_mode", ...)

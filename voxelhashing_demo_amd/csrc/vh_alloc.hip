@@ -258,9 +258,30 @@ struct BandWalk {
             vsR1 = refined_rcp(fp.voxelSize); vsOk = fast_range(fp.voxelSize, 0x1p-40f, 0x1p40f);
             zR1 = refined_rcp(p.v.z); zOk = fast_range(p.v.z, 0x1p-40f, 0x1p40f);
         }
-        dda = (fp.flags & kFlagBandDda) && fp.allocBand > 0.0f;
+        const bool rayDda = (fp.flags & kFlagBandRayDda) && fp.allocBand > 0.0f;      // (wave-uniform)
+        dda = ((fp.flags & kFlagBandDda) && fp.allocBand > 0.0f) || rayDda;
         more = false;
         if (!dda || !p.valid) return;
+        float start[3], dir[3];
+        if (rayDda) {
+            // VH_BAND_RAY_DDA: the segment of the viewing ray between camera depths z - b and z + b (oracle: ray_dda_keys);
+            // its two ends are the vertex scaled to those depths, through the pose as :622
+            const float z = p.v.z, b = fp.allocBand;
+            float s0 = z - b;
+            if (!(s0 > 0.0f)) s0 = z;
+            const float s1 = z + b;
+            const float c0 = s0 / z, c1 = s1 / z;
+            const float4 g0 = mat4_mul(fp.T, p.v.x * c0, p.v.y * c0, s0, p.v.w);
+            const float4 g1 = mat4_mul(fp.T, p.v.x * c1, p.v.y * c1, s1, p.v.w);
+            const float a0[3] = {g0.x, g0.y, g0.z}, a1[3] = {g1.x, g1.y, g1.z};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                start[a] = a0[a];
+                dir[a] = a1[a] - a0[a];
+                cur[a] = voxel2block1(world2voxel1(a0[a], fp.voxelSize));
+                end[a] = voxel2block1(world2voxel1(a1[a], fp.voxelSize));
+            }
+        } else {
         const float4 g = mat4_mul(fp.T, p.v.x, p.v.y, p.v.z, p.v.w);                 // :622, w as stored
         const int3_ sb = world2block(g.x, g.y, g.z, fp.voxelSize);
         cur[0] = sb.x; cur[1] = sb.y; cur[2] = sb.z;
@@ -268,7 +289,6 @@ struct BandWalk {
         const float nx = p.n.x, ny = p.n.y, nz = p.n.z;
         if ((nx == 0.0f && ny == 0.0f && nz == 0.0f) || nx != nx || ny != ny || nz != nz) return;   // surface block only
         const float gw[3] = {g.x, g.y, g.z};
-        float start[3], dir[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float nw = fp.T[4 * a + 0] * nx + fp.T[4 * a + 1] * ny + fp.T[4 * a + 2] * nz;
@@ -277,6 +297,7 @@ struct BandWalk {
             dir[a] = e - start[a];
             cur[a] = voxel2block1(world2voxel1(start[a], fp.voxelSize));
             end[a] = voxel2block1(world2voxel1(e, fp.voxelSize));
+        }
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -453,6 +474,9 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
         }
     };
     int count = 0;                                                       // (wave-uniform)
+    // (Measured in round 4 and not kept: for the DDA bands, every lane first taking 8 DDA steps on its own, then the dedup of
+    // all 8 samples, then the queueing -- no cross-lane round trip between the steps.  Sample loop 6.16 -> 6.52 us per tile,
+    // launch 22.2 -> 23.0 us: the loop is not a chain of cross-lane waits.)
     for (int k = 0; !walk.wave_done(k); ++k) {
         const SampleKey s = sample_key<false>(fp, p, walk, k, ox, oy, oz, oh);
         bool take = s.leader;
@@ -515,9 +539,10 @@ __device__ __forceinline__ void generate_keys_tile(const FrameParams &fp, const 
     const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
     int ox = 0, oy = 0, oz = 0;
     bool oh = false;
-    // (the ray band's sample count is the same for every lane of the workgroup; the DDA band is not
-    // offered on this path: vh_generate_keys* carry no normal map)
-    for (int k = 0; k < walk.nS; ++k) {
+    // (the ray band's sample count is the same for every lane of the workgroup; the ray DDA runs until no lane of the
+    // workgroup has a step left; the normal DDA is not offered on this path: vh_generate_keys* carry no normal map)
+    for (int k = 0; k < kMaxBandSamples - 1; ++k) {
+        if (walk.dda ? (k > 0 && !__syncthreads_or(walk.more ? 1 : 0)) : k >= walk.nS) break;
         if (threadIdx.x < VH_MAX_CAMERAS) ldsCount[threadIdx.x] = 0;
         __syncthreads();
         const SampleKey s = sample_key(fp, p, walk, k, ox, oy, oz, oh);

@@ -287,12 +287,16 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
         const uint32_t fo = hasOld ? c->pipeFp.flags : c->fp.flags;
         if (c->fp.flags == kFlagWalkShort && fo == kFlagWalkShort) lean = 1;
         else if (c->fp.flags == (kFlagWalkShort | kFlagWalkNt) && fo == (kFlagWalkShort | kFlagWalkNt)) lean = 2;
+        else if (band && c->fp.flags == (kFlagWalkShort | kFlagBandRayDda) && fo == c->fp.flags) lean = 3;
+        else if (band && c->fp.flags == (kFlagWalkShort | kFlagWalkNt | kFlagBandRayDda) && fo == c->fp.flags) lean = 4;
     }
 #define VH_LAUNCH_PIPELINED(DEPTH, BAND, SERIAL, LEAN) \
     launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DEPTH, BAND, SERIAL, LEAN>, grid, dim3(256), c->fp, dpNew, inNew, c->pipeFp, dpOld, d, a)
 #define VH_LAUNCH_PIPELINED_ANY(DEPTH) \
     (lean == 1 ? (band ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 1) : VH_LAUNCH_PIPELINED(DEPTH, false, false, 1)) \
      : lean == 2 ? (band ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 2) : VH_LAUNCH_PIPELINED(DEPTH, false, false, 2)) \
+     : lean == 3 ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 3) \
+     : lean == 4 ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 4) \
      : serial ? (band ? VH_LAUNCH_PIPELINED(DEPTH, true, true, 0) : VH_LAUNCH_PIPELINED(DEPTH, false, true, 0)) \
               : (band ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 0) : VH_LAUNCH_PIPELINED(DEPTH, false, false, 0)))
     if (hasOld && c->pipeSensor) {

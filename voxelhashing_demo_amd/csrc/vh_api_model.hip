@@ -418,8 +418,10 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
         c->fp.flags = value ? (c->fp.flags | kFlagOverflow) : (c->fp.flags & ~kFlagOverflow);
         return VH_OK;
     }
-    if (std::strcmp(name, "band_mode") == 0 && (value == VH_BAND_RAY || value == VH_BAND_NORMAL_DDA)) {
-        c->fp.flags = value == VH_BAND_NORMAL_DDA ? (c->fp.flags | kFlagBandDda) : (c->fp.flags & ~kFlagBandDda);
+    if (std::strcmp(name, "band_mode") == 0 && (value == VH_BAND_RAY || value == VH_BAND_NORMAL_DDA || value == VH_BAND_RAY_DDA)) {
+        c->fp.flags &= ~(kFlagBandDda | kFlagBandRayDda);
+        if (value == VH_BAND_NORMAL_DDA) c->fp.flags |= kFlagBandDda;
+        if (value == VH_BAND_RAY_DDA) c->fp.flags |= kFlagBandRayDda;
         return VH_OK;
     }
     if (std::strcmp(name, "depth_truncation") == 0) {

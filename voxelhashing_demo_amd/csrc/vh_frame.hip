@@ -316,7 +316,9 @@ __global__ __launch_bounds__(256) void frame_pipelined_kernel(FrameParams fpNew,
                                                               const Depth depthOld, PipeArgs a)
 {
     if (kLean != 0) {
-        constexpr uint32_t flags = kLean == 2 ? (kFlagWalkShort | kFlagWalkNt) : kFlagWalkShort;
+        // (3 / 4: the same two with the ray-DDA band, VH_BAND_RAY_DDA -- builds that exist with kBand only)
+        constexpr uint32_t flags = (kLean == 2 || kLean == 4 ? (kFlagWalkShort | kFlagWalkNt) : kFlagWalkShort) |
+                                   (kLean >= 3 ? kFlagBandRayDda : 0u);
         fpNew.flags = flags;
         fpOld.flags = flags;
         a.walkIndexed = 0u;
