@@ -41,10 +41,14 @@ WORKLOADS = {
     "C2": dict(width=640, height=480, frames=500, buckets=1 << 20, blocks=1 << 18, voxel=0.02, loop=500,
                desc="C2: synthetic 6x3x5 m room, 640x480 x 500-pose camera loop, 2^20 buckets x 5, "
                     "2^18 voxel blocks, voxel 0.02 m, PINHOLE semantics"),
-    # C2 with truncation-band allocation (+-10 cm along the viewing ray): thousands of blocks updated per frame
+    # C2 with truncation-band allocation (+-10 cm along the viewing ray): hundreds of blocks updated per frame
     "C2band": dict(width=640, height=480, frames=500, buckets=1 << 20, blocks=1 << 18, voxel=0.02, loop=500, band=0.1,
-                   desc="C2 with vh_set_alloc_band(0.1): every pixel demands the blocks within +-10 cm of its surface "
-                        "point, launch 2 (commit + integrateDepthMap) under load"),
+                   options=["band_mode=2"],
+                   desc="C2 with vh_set_alloc_band(0.1), band_mode VH_BAND_RAY_DDA: every pixel demands the blocks its viewing "
+                        "ray crosses within +-10 cm of its surface point (block DDA), commit + integrateDepthMap under load"),
+    # ... the same band as rounds 1-3 specified it: five samples on the ray at half-block steps (reach +-16 cm)
+    "C2bandSamples": dict(width=640, height=480, frames=500, buckets=1 << 20, blocks=1 << 18, voxel=0.02, loop=500, band=0.1,
+                          desc="C2 with vh_set_alloc_band(0.1), band_mode VH_BAND_RAY: five samples per pixel on the viewing ray"),
     # BASELINE.json configs[2] (HBM-bound stress)
     "C3": dict(width=1280, height=960, frames=200, buckets=1 << 22, blocks=1 << 21, voxel=0.005, loop=2000,
                desc="C3: synthetic room, 1280x960, 2^22 buckets x 5 (419 MB of VoxelEntry: beyond the 256 MiB "
@@ -293,7 +297,7 @@ class Integrator:
 def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, want_profile=True, frames=None,
                      pipeline=True):
     """Timed windows + dominant-kernel roofline of one single-GPU workload.  Returns (record, Integrator, poses, verts)."""
-    wl = dict(WORKLOADS[name], options=list(getattr(args, "option", [])))
+    wl = dict(WORKLOADS[name], options=list(WORKLOADS[name].get("options", [])) + list(getattr(args, "option", [])))
     dev = torch.device("cuda", local_rank)
     stream = torch.cuda.Stream(device=dev)
     nframes = args.frames or wl["frames"]
@@ -625,6 +629,12 @@ def main():
         l_it.dominant_roofline("C2band", kt_l2, l_it.table.counters()["occupied"])
         l_rec["roofline_commit_integrate_two_launch"] = l_it.commit_roofline
         l_it.close()
+        # the band as rounds 1-3 specified it (five ray samples per pixel), for comparison
+        s_rec, s_it, _, _ = measure_workload(args, V, L, synth, torch, "C2bandSamples", local_rank, max(50, args.steps // 4),
+                                             min(args.warmup, 20), frames=(poses, verts))
+        l_rec["ray_samples_variant"] = dict(value=s_rec["value"], unit="frames/s", occupied_blocks=s_rec["occupied_blocks"],
+                                            roofline=s_rec.get("roofline"), workload=WORKLOADS["C2bandSamples"]["desc"])
+        s_it.close()
 
     # ---- next rows ----
     if "next" in legs:

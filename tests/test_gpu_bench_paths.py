@@ -2,7 +2,7 @@
 
 bench.py times, on C2 (BASELINE.json configs[1]: 640x480, 2^20 buckets x 5, 2^18 voxel blocks, 2 cm voxels, PINHOLE),
   value / roofline        vh_integrate_batch(8) over consecutive frames of the 500-pose loop
-  loaded_integrate        the same with vh_set_alloc_band(0.1)
+  loaded_integrate        the same with vh_set_alloc_band(0.1), band_mode VH_BAND_RAY_DDA (and VH_BAND_RAY, its variant)
   sensor_depth_input      vh_integrate_depth_batch / vh_integrate_depth on uint16 sensor images
   sharded_world1          vh_dist_step_batch (key bins + sensor packets) with one rank over RCCL, and with two ranks over the
                           loop-back transport (the N > 1 lines)
@@ -67,17 +67,19 @@ def _raycast_equal(ot, gt, torch, pose):
     assert (od > 0).mean() > 0.5
 
 
-@pytest.mark.parametrize("band", [0.0, 0.1])
-def test_c2_integrate_batch_from_a_fresh_table(oracle, vh, torch_cuda, loop_frames, band):
-    """`value` (band 0) and `loaded_integrate` (band 0.1): vh_integrate_batch(8), pipelined frames, fresh table."""
+@pytest.mark.parametrize("band,mode", [(0.0, 0), (0.1, 2), (0.1, 0)])
+def test_c2_integrate_batch_from_a_fresh_table(oracle, vh, torch_cuda, loop_frames, band, mode):
+    """`value` (band 0), `loaded_integrate` (band 0.1 by the block DDA along the viewing ray, VH_BAND_RAY_DDA) and its
+    `ray_samples_variant` (VH_BAND_RAY): vh_integrate_batch(8), pipelined frames, fresh table."""
     torch = torch_cuda
     poses, verts = loop_frames
     ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
     gt = vh.SDFHashtable(vh.default_params(**KW), W, H, 1)
     gt.set_option("pipeline", 1)                       # as bench.py's Integrator does
     if band:
-        ot.set_alloc_band(band)
+        ot.set_alloc_band(band, mode)
         gt.set_alloc_band(band)
+        gt.set_option("band_mode", mode)
     d_verts = [torch.from_numpy(v).cuda() for v in verts]
     torch.cuda.synchronize()
     for k in range(0, FRAMES, BATCH):
@@ -85,7 +87,7 @@ def test_c2_integrate_batch_from_a_fresh_table(oracle, vh, torch_cuda, loop_fram
         for j in range(k, k + BATCH):
             ot.integrate_mt(poses[j], verts[j], THREADS)
     gt.synchronize()
-    blocks = _compare_light(ot, gt, min_blocks=2000 if band else 500)
+    blocks = _compare_light(ot, gt, min_blocks=(2000 if mode == 0 else 1500) if band else 500)
     assert gt.counters()["epoch"] == FRAMES
     _raycast_equal(ot, gt, torch, poses[40])
     print(f"band {band}: {blocks} blocks after {FRAMES} frames")
