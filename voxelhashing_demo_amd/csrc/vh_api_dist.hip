@@ -397,6 +397,9 @@ extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_I
             return fail(e_ == hipErrorOutOfMemory ? VH_ERR_OUT_OF_MEMORY : VH_ERR_HIP, #call, e_);   \
         }                                                                                            \
     } while (0)
+    // (Round 4: the key-generation stream restricted to every 2nd / 4th / 8th CU with hipExtStreamCreateWithCUMask, so that the
+    // generation of exchange n+1 would not slow the frame launch it runs beside (28 instead of 20 us): 43.9 / 43.4 / 43.2 k
+    // frames/s against 43.8 k without a mask, the launch as slow as before -- what the two kernels contend for is not CUs.)
     for (hipStream_t *s : {&d->sGen, &d->sComm, &d->sTable}) VH_DIST_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
     for (hipEvent_t *e : {&d->userEvent, &d->outEvent}) VH_DIST_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < vh_dist::kSets; ++i) {
@@ -451,8 +454,9 @@ static int dist_apply(vh_dist *d, int s)
     VH_HIP(hipStreamWaitEvent(d->sTable, d->ready[s], 0));
     d->shard->stream = d->sTable;
     d->shard->multiFirstEvent = d->first[s];
-    const int rc = vh_apply_frames_batch(d->shard, d->cfg.batch, d->set[s].binsRecv, d->cfg.world, d->capacity, 0, VH_BIN_PER_BATCH,
-                                         d->cfg.world, d->set[s].packets, 0, 0);
+    const bool alone = d->cfg.world == 1;
+    const int rc = vh_apply_frames_batch(d->shard, d->cfg.batch, alone ? d->set[s].binsSend : d->set[s].binsRecv, d->cfg.world, d->capacity, 0,
+                                         VH_BIN_PER_BATCH, d->cfg.world, alone ? d->set[s].packet : d->set[s].packets, 0, 0);
     d->shard->multiFirstEvent = nullptr;
     return rc;
 }
@@ -473,6 +477,9 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
         VH_HIP(hipStreamWaitEvent(d->sGen, d->userEvent, 0));
     }
     if (d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sGen, d->ready[s], 0));
+    // (one rank: the frames are applied straight from the send buffers, so those are free only when the frames of exchange
+    // count-3 are done, the last of which rode in the first launch of exchange count-2's frames)
+    if (R == 1 && d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sGen, d->first[(s + 1) % vh_dist::kSets], 0));
     d->shard->stream = d->sGen;
     if (d->cfg.packet_format == VH_PACKET_U16)
         rc = vh_generate_keys_depth_batch(d->shard, B, poses, reinterpret_cast<const uint16_t *const *>(d_frames), d->cfg.k_inv,
@@ -489,8 +496,12 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     // the first launch of exchange count-2's frames (queued by the previous call)
     VH_HIP(hipStreamWaitEvent(d->sComm, d->generated[s], 0));
     if (d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sComm, d->first[(s + 1) % vh_dist::kSets], 0));
-    if ((rc = d->transport->all_to_all(d, set.binsSend, set.binsRecv, (size_t)d->capacity * 4 * sizeof(int32_t), d->sComm)) != VH_OK) return rc;
-    if ((rc = d->transport->all_gather(d, set.packet, set.packets, (size_t)B * d->packetUnits * sizeof(float), d->sComm)) != VH_OK) return rc;
+    if (R > 1) {
+        if ((rc = d->transport->all_to_all(d, set.binsSend, set.binsRecv, (size_t)d->capacity * 4 * sizeof(int32_t), d->sComm)) != VH_OK) return rc;
+        if ((rc = d->transport->all_gather(d, set.packet, set.packets, (size_t)B * d->packetUnits * sizeof(float), d->sComm)) != VH_OK) return rc;
+    }
+    // (one rank: the only bin and the only packet are this rank's own -- the frames are applied straight from the send
+    // buffers, no collective and no copy; the events order the hand-offs as with peers)
     VH_HIP(hipEventRecord(d->ready[s], d->sComm));
     // apply the previous exchange while this one travels
     if (d->pending >= 0 && (rc = dist_apply(d, d->pending)) != VH_OK) return rc;
