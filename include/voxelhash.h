@@ -133,6 +133,11 @@ typedef struct vh_counters {
     uint32_t last_freed;        /* ... by the last vh_delete_blocks / vh_garbage_collect */
     uint32_t cand_overflow;     /* contenders dropped since creation because the candidate list of their
                                    frame was full (their keys retry next frame; see "cand_capacity") */
+    uint32_t spin_timeouts;     /* ERROR REPORT: workgroups of a serialised one-launch frame (option "overflow_list" with
+                                   "pipeline" / vh_integrate_batch / vh_apply_frames_batch) that gave up waiting for the
+                                   pending frame's commit phase after "spin_limit" polls (default 2^20, ~1.5 s): that frame
+                                   is incomplete; once this is seen here the context runs its overflow-list frames as two
+                                   launches each.  0 in every run so far. */
 } vh_counters;
 
 /* per-kernel device time, accumulated while profiling is on (HIP events on
@@ -327,6 +332,8 @@ int vh_debug_eval(vh_context *ctx, const vh_float4 *d_points, int32_t n, int32_t
 /* diagnostics hook: the DDA raycast records per wave {start, end (100 MHz clock), voxel steps + jumps of lane 0,
  * pixel patch x | y << 16} in d_stamps (4 uint64 per wave, workgroups in launch order); NULL = off */
 int vh_debug_set_raycast_stamps(vh_context *ctx, void *d_stamps);
+/* test hook: `workgroups` x 256 lanes that stay resident for `microseconds` on `stream` (a device busy with another kernel) */
+int vh_debug_occupy(vh_context *ctx, void *stream, int32_t workgroups, int32_t microseconds);
 
 /* Options.  Tuning knobs for A/B measurements, results never change: "fused_frame" (1: two launches
  * per frame, 0: the four step kernels), "flatten_variant" (3 = the walk over every VoxelEntry, default;

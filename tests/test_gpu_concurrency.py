@@ -90,3 +90,68 @@ def test_contexts_driven_from_concurrent_host_threads(oracle, vh, torch_cuda):
     for k, t in enumerate(tables):
         frames = [(pose if k % 2 else np.eye(4, dtype=np.float32), v) for pose, v in seqs[k]]
         same(oracle_table(oracle, frames, k % 2), t)
+
+
+def _collision_frames(n):
+    """The room through a table small enough for chains: 512 buckets of 2 slots."""
+    prims = synth.room_primitives()
+    loop = synth.camera_loop(40)
+    return [(loop[(3 * i) % 40], synth.render_room_verts(loop[(3 * i) % 40], 160, 120, prims).numpy()) for i in range(n)]
+
+
+def test_serialised_launches_while_another_kernel_holds_the_chip(oracle, vh, torch_cuda):
+    """Overflow-list frames are one launch each, serialised INSIDE the launch: the claim / walk workgroups of frame i+1 poll a
+    word that a commit workgroup of the same grid publishes (forward progress rests on dispatch
+    order).  Here the chip is held by a long kernel of another stream while those launches run -- 1 792 resident workgroups (seven of the eight a CU holds) for
+    30 ms, then again -- so that the launch's workgroups trickle in as slots come free: the frames must still be the oracle's,
+    slot for slot and link for link, and no workgroup may have given up (vh_counters.spin_timeouts)."""
+    torch = torch_cuda
+    kw = dict(numBuckets=512, bucketSize=2, numVoxelBlocks=4096, attachedLinkedListSize=8)
+    frames = _collision_frames(24)
+    ot = oracle.OracleTable(oracle.default_params(**kw), 160, 120, 1)
+    ot.set_overflow(True)
+    st, hog = torch.cuda.Stream(), torch.cuda.Stream()
+    gt = vh.SDFHashtable(vh.default_params(**kw), 160, 120, 1, stream=st)
+    gt.set_option("overflow_list", 1)
+    gt.set_option("pipeline", 1)
+    dv = [torch.from_numpy(v).cuda() for _, v in frames]
+    torch.cuda.synchronize()
+    L = vh.load()
+    for k in range(0, 24, 8):
+        assert L.vh_debug_occupy(gt._h, hog.cuda_stream, 1792, 30000) == 0       # the chip is somebody else's for 30 ms
+        gt.integrate_batch([p for p, _ in frames[k:k + 8]], dv[k:k + 8])
+        for p, v in frames[k:k + 8]:
+            ot.integrate(p, v)
+    gt.synchronize()
+    torch.cuda.synchronize()
+    c = gt.counters()
+    assert c["spin_timeouts"] == 0 and c["epoch"] == 24
+    a, b = ot.hash_table(), gt.hash_table()
+    assert np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["offset"], b["offset"]) and np.array_equal(a["ptr"] != -1, b["ptr"] != -1)
+    assert (a["offset"] != 0).sum() > 10
+    same(ot, gt)
+    gt.close()
+    ot.close()
+
+
+def test_a_serialised_launch_that_times_out_is_reported_and_bounded(oracle, vh, torch_cuda):
+    """With "spin_limit" 1 every waiting workgroup gives up at its first look: the launch returns (no hang), the counter says
+    so, and from the moment the host has seen it the context's overflow-list frames take two launches each -- which are exact
+    again from a fresh table."""
+    torch = torch_cuda
+    kw = dict(numBuckets=512, bucketSize=2, numVoxelBlocks=4096, attachedLinkedListSize=8)
+    frames = _collision_frames(8)
+    gt = vh.SDFHashtable(vh.default_params(**kw), 160, 120, 1)
+    gt.set_option("overflow_list", 1)
+    gt.set_option("pipeline", 1)
+    gt.set_option("spin_limit", 1)
+    dv = [torch.from_numpy(v).cuda() for _, v in frames]
+    gt.integrate_batch([p for p, _ in frames], dv)
+    gt.synchronize()
+    assert gt.counters()["spin_timeouts"] > 0                     # (seen by the host: the context falls back)
+    gt.set_profiling(True)
+    gt.integrate_batch([p for p, _ in frames[:4]], dv[:4])
+    gt.synchronize()
+    kt = gt.kernel_times(reset=True)
+    assert kt["frame_pipelined_ms"] == 0 and kt["frame_scan_claim_ms"] > 0 and kt["frame_commit_integrate_ms"] > 0
+    gt.close()

@@ -49,7 +49,7 @@ class Counters(C.Structure):
     _fields_ = [("occupied", C.c_int32), ("heap_counter", C.c_int32), ("allocated_total", C.c_uint32),
                 ("heap_exhausted", C.c_uint32), ("candidates", C.c_uint32), ("epoch", C.c_uint32),
                 ("bin_overflow", C.c_uint32), ("freed_total", C.c_uint32), ("last_freed", C.c_uint32),
-                ("cand_overflow", C.c_uint32)]
+                ("cand_overflow", C.c_uint32), ("spin_timeouts", C.c_uint32)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -103,6 +103,7 @@ SIGNATURES = {
     "vh_raycast": (C.c_int, [_vp, _fp, _f, _f, _vp]),
     "vh_raycast_normals": (C.c_int, [_vp, _fp, _f, _f, _vp, _vp]),
     "vh_debug_set_raycast_stamps": (C.c_int, [_vp, _vp]),
+    "vh_debug_occupy": (C.c_int, [_vp, _vp, _i32, _i32]),
     "vh_render_blocks": (C.c_int, [_vp, _fp, _f, _f, _vp, _vp]),
     "vh_icp_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "vh_icp_destroy": (C.c_int, [_vp]),

@@ -243,7 +243,7 @@ static DevPtrs pipe_view(const vh_context *c, int parity)
 static bool pipeline_applies(const vh_context *c)
 {
     return c->pipeline && c->fusedFrame && (c->flattenVariant == kWalkStridedBallot || c->flattenVariant == kWalkIndexed) &&
-           c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks;
+           c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks && !(c->serialFallback && (c->fp.flags & kFlagOverflow));
 }
 
 // One launch: {claim || walk} of the new frame (in != nullptr) and {commit + integrate} of the pending one.
@@ -272,6 +272,7 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     a.planeNew = (hasNew && !newSensor) ? c->planeBuf[newParity] : nullptr;
     a.rawNew = (hasNew && newSensor) ? c->rawBuf[newParity] : nullptr;
     a.doneTag = c->pipeDoneTag;
+    a.spinLimit = c->spinLimit ? c->spinLimit : kSpinLimitDefault;
 #ifdef VH_DEBUG_SKIP_ROLES
     a.skipRoles = (uint32_t)c->debugSkipRoles;
 #endif

@@ -88,6 +88,8 @@ extern "C" int vh_get_counters(vh_context *c, vh_counters *out)
     out->freed_total = (uint32_t)h[kFreedTotal];
     out->last_freed = (uint32_t)h[kLastFreed];
     out->cand_overflow = (uint32_t)h[kCandOverflow];
+    out->spin_timeouts = (uint32_t)h[kSpinTimeouts];
+    if (out->spin_timeouts) c->serialFallback = true;       // (overflow-list frames: two launches each from now on)
     c->params.numOccupiedBlocks = (uint32_t)h[c->occupiedCounter];
     return VH_OK;
 }
@@ -400,6 +402,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (std::strcmp(name, "debug_skip_roles") == 0 && value >= 0 && value < 16) { c->debugSkipRoles = value; return VH_OK; }
 #endif
     if (std::strcmp(name, "lean_kernels") == 0) { c->leanKernels = value != 0; return VH_OK; }
+    if (std::strcmp(name, "spin_limit") == 0 && value >= 0) { c->spinLimit = (uint32_t)value; return VH_OK; }
     if (std::strcmp(name, "pipeline_shards") == 0) {
         if (value < 0 || value > 2) return fail(VH_ERR_INVALID_ARGUMENT, "pipeline_shards: 0, 1 or 2");
         if (value < 2) { DeviceGuard g(c->device); const int frc = flush_multi_pending(c); if (frc != VH_OK) return frc; }
@@ -515,6 +518,22 @@ extern "C" int vh_debug_set_claim_stamps(void *d_stamps)
     return hipMemcpyToSymbol(HIP_SYMBOL(vh::g_claimStamps), &d_stamps, sizeof d_stamps) == hipSuccess ? VH_OK : VH_ERR_HIP;
 }
 #endif
+
+// test hook (tests/test_gpu_concurrency.py): `workgroups` workgroups of 256 lanes that do nothing but stay resident for
+// `microseconds` -- a chip that is busy with somebody else's long kernel -- on `stream` (any stream of the context's device)
+__global__ __launch_bounds__(256) void debug_occupy_kernel(unsigned long long ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int vh_debug_occupy(vh_context *c, void *stream, int32_t workgroups, int32_t microseconds)
+{
+    if (!c || workgroups < 1 || microseconds < 0) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
+    DeviceGuard guard(c->device);
+    debug_occupy_kernel<<<dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream>>>((unsigned long long)microseconds * 100ull);
+    VH_HIP(hipGetLastError());
+    return VH_OK;
+}
 
 // diagnostics hook (tools/raycast_stamps.py): the DDA raycast writes {start, end (s_memrealtime, 100 MHz), steps, patch}
 // per wave into d_stamps (4 uint64 per wave, waves in workgroup order); NULL switches it off

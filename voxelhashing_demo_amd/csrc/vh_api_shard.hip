@@ -406,6 +406,7 @@ static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b)
     a.claimRatio = claim_ratio(a.claimBlocks, a.claimSpan);
     a.epochOld = mp.epochOld;
     a.doneTag = mp.doneTag;
+    a.spinLimit = c->spinLimit ? c->spinLimit : kSpinLimitDefault;
     a.packetsOld = mp.packetsOld;
     DevPtrs dpNew = pipe_view(c, newParity);
     dpNew.compactMask = maskOf[newParity];
@@ -488,7 +489,7 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
     // the next batch -- B launches -- or in the flush any observer does first.
     // Same conditions as the single-camera pipeline (bucketSize <= 16, not a view table; with the overflow list the frames are
     // serialised inside the launch).
-    if (c->pipelineShards && c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks) {
+    if (c->pipelineShards && c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks && !(c->serialFallback && (c->fp.flags & kFlagOverflow))) {
         int rc = ensure_pipeline_buffers(c);
         if (rc != VH_OK) return rc;
         if (!c->maskBuf2) VH_HIP(hipMalloc((void **)&c->maskBuf2, sizeof(uint32_t) * c->numEntries));
@@ -518,6 +519,7 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
         VH_HIP(hipGetLastError());
         return VH_OK;
     }
+    { const int frc = flush_multi_pending(c); if (frc != VH_OK) return frc; }
     for (int b = 0; b < batch; ++b) {
         int rc = vh_reset_mutexes(c);
         if (rc != VH_OK) return rc;

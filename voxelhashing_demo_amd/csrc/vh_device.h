@@ -42,6 +42,7 @@ enum Counter : int {
     kFreedTotal = 16,      // blocks returned to the heap since creation
     kLastFreed = 17,       // ... by the last vh_delete_blocks / vh_garbage_collect
     kCandOverflow = 18,    // contenders dropped because the candidate list was full (never cleared)
+    kSpinTimeouts = 19,    // workgroups of a serialised pipelined launch that gave up waiting for the pending frame's commit phase (never cleared)
     // pipelined frames (vh_integrate_batch): three rotating sets -- the launch of frame i+1 fills set
     // (i+1)%3 (claim / walk), consumes set i%3 (commit / integrate of frame i) and clears set (i+2)%3
     // Each set has a 128-byte line of its own (kPipeSetStride ints apart; the host hands the kernel set * stride):

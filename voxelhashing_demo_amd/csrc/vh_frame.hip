@@ -154,11 +154,36 @@ struct PipeArgs {
     float *planeNew;                       // private depth copies written by claim(new) ...
     uint16_t *rawNew;
     int32_t doneTag;                       // overflow list: the pending frame's tag (lock epochs since creation), published when its commit phase ends
+    uint32_t spinLimit;                    // ... and how many polls a workgroup waits for it (wait_commit_done)
 #ifdef VH_DEBUG_SKIP_ROLES
     uint32_t skipRoles;                    // diagnostics build (option "debug_skip_roles"): bit r set = workgroups of role r return at once
 #endif
                                            // (0 commit, 1 integrate, 2 claim, 3 walk): what the launch costs without them
 };
+
+// Serialised pipelined launches (overflow list): the claim and walk workgroups of frame i+1 wait here until the commit phase
+// of frame i -- workgroups of the SAME grid, with the lowest indices, hence dispatched first -- has published its tag.
+// "Dispatched first" is how the hardware dispatches today, not a guarantee, so the wait is bounded: after `limit` polls
+// (~1.5 us each) the workgroup counts itself in kSpinTimeouts and gives up; the host sees the counter in vh_get_counters and
+// runs that context's overflow-list frames as two launches from then on (the frame that timed out has lost the work of the
+// workgroups that gave up: vh_counters.spin_timeouts > 0 is an error report, not a mode).
+constexpr uint32_t kSpinLimitDefault = 1u << 20;
+__device__ __forceinline__ bool wait_commit_done(int32_t *counters, int32_t tag, uint32_t limit)
+{
+    __shared__ int reached;
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        for (uint32_t it = 0; it < limit; ++it) {
+            if (__hip_atomic_load(counters + kPipeCommitDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (!ok) atomicAdd(counters + kSpinTimeouts, 1);
+        reached = ok;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return reached != 0;
+}
 
 template <class In, class Depth, bool kBand, bool kSerial>
 __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const DevPtrs &dpNew, const In &inNew,
@@ -216,11 +241,7 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
         if (!a.hasNew) return;
         if (serial && a.hasOld) {
             // (the commit and integrate workgroups have the lowest indices of the grid: they are running or done when this one starts)
-            if (threadIdx.x == 0)
-                while (__hip_atomic_load(counters + kPipeCommitDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.doneTag)
-                    __builtin_amdgcn_s_sleep(8);
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (!wait_commit_done(counters, a.doneTag, a.spinLimit)) return;
         }
         const Pending pend{a.hasOld && !serial ? dpOld.claim : nullptr, dpOld.candidates, fpOld.epoch, live,
                            serial ? -1 : kPipeWinners + a.setNew};

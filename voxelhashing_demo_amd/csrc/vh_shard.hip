@@ -243,6 +243,7 @@ struct MultiPipeArgs {
     int32_t capacity, binStride, numCams;
     int32_t binFrame;            // >= 0: the bins hold the whole batch, this launch claims the records of that frame
     int32_t doneTag;             // overflow list: the pending frame's tag, published when its commit phase ends (vh_frame.hip)
+    uint32_t spinLimit;          // ... and how many polls a workgroup waits for it
     int32_t setNew, setOld, setClear;
     uint32_t hasNew, hasOld;
     uint32_t claimSpan, claimRatio;
@@ -274,11 +275,7 @@ __global__ __launch_bounds__(256) void frame_multi_pipelined_kernel(const FrameP
         // ---- frame i+1: claim its bins || walk the shard for its cameras ----
         if (!a.hasNew) return;
         if (serial && a.hasOld) {
-            if (threadIdx.x == 0)
-                while (__hip_atomic_load(counters + kPipeCommitDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.doneTag)
-                    __builtin_amdgcn_s_sleep(8);
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (!wait_commit_done(counters, a.doneTag, a.spinLimit)) return;
         }
         const Pending pend{a.hasOld && !serial ? a.claimOld : nullptr, a.candOld, a.epochOld, live, serial ? -1 : kPipeWinners + a.setNew};
         const uint32_t r = b - a.commitBlocks - a.integrateBlocks;
