@@ -18,6 +18,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $T/pmc_$C -- python3 bench.py --legs none --workload $WL --steps 100 --warmup 10 --profile-steps 0 > /dev/null 2>&1
   python3 tools/prof_summary.py pmc $T/pmc_$C $OUT/pmc_${C}_$WL.json 10 > /dev/null
 done
+# DRAM-side read requests beside all L2->fabric read requests: what share of the launch's reads the
+# Infinity Cache answered.  TCC_EA0_RDREQ_DRAM counts requests "destined for DRAM (MC)"
+rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum --output-format csv -d $T/pmc_dram -- python3 bench.py --legs none --workload $WL --steps 100 --warmup 10 --profile-steps 0 > /dev/null 2>&1
+python3 tools/prof_summary.py pmc $T/pmc_dram $OUT/pmc_RDREQ_DRAM_$WL.json 10 > /dev/null
 if [ "$WL" = "C2" ]; then
   # raycast: VALU instructions per wave (the kernel is VALU-issue bound)
   rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --output-format csv -d $T/pmc_valu -- python3 bench.py --legs raycast --workload C2 --steps 20 --warmup 5 --profile-steps 0 > /dev/null 2>&1

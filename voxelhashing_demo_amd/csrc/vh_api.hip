@@ -116,6 +116,7 @@ struct vh_context {
     int4 *candBuf[2] = {nullptr, nullptr};
     VoxelEntry *compactBuf[2] = {nullptr, nullptr};
     uint32_t *maskBuf2 = nullptr;          // pipelined multi-camera frames: the camera masks of the second compact buffer
+    int multiWalkEntries = 0;              // option "multi_walk_entries": entries per lane of the multi-camera pipelined walk (0: by shard size)
     uint32_t spinLimit = 0;                // option "spin_limit": polls a workgroup of a serialised pipelined launch waits for the pending commit phase (0: kSpinLimitDefault)
     bool serialFallback = false;           // a serialised launch has timed out (vh_counters.spin_timeouts): overflow-list frames take two launches from now on
     int leanKernels = 1;                   // option "lean_kernels": builds of the pipelined launch with the option flags folded in (A/B switch)

@@ -391,7 +391,10 @@ static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b)
         uint32_t parts = (uint32_t)grid_for((size_t)mb->capacity, 256 * 4);
         if (parts < 1) parts = 1;
         a.claimBlocks = (uint32_t)mb->numBins * parts;
-        a.walkBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane);
+        // option "multi_walk_entries": 4 | 8 | 0 = by the shard's size (4 from 32 MB of entries on)
+        a.walkShort = c->multiWalkEntries ? (c->multiWalkEntries == kEntriesPerLaneShort ? 1u : 0u)
+                                          : (c->numEntries * sizeof(VoxelEntry) >= ((size_t)32 << 20) ? 1u : 0u);
+        a.walkBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * (a.walkShort ? kEntriesPerLaneShort : kEntriesPerLane));
         a.partsPerBin = parts; a.numBins = (uint32_t)mb->numBins;
         a.capacity = mb->capacity; a.binStride = mb->binStride;
         a.binsNew = mb->bins + (size_t)mb->frameStride * b;

@@ -59,18 +59,19 @@ __device__ __forceinline__ uint32_t camera_mask(const FrameParams &fp, const int
 // One walk over the shard's entries for ALL cameras of the step: a live entry is
 // tested against every camera's frustum and appended once, with the mask of the
 // cameras that see it.
+template <int kN = kEntriesPerLane>
 __device__ __forceinline__ void flatten_multi_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
                                                    uint32_t tileIndex, int32_t numCams,
                                                    const float *__restrict__ packets, size_t packetStride,
                                                    int counter, const Pending &pend = kNoPending)
 {
-    const uint32_t tile = tileIndex * (kFlattenThreads * kEntriesPerLane);
-    int32_t ptrs[kEntriesPerLane];
+    const uint32_t tile = tileIndex * (kFlattenThreads * kN);
+    int32_t ptrs[kN];
     walk_load_tile(fp, dp, numEntries, tileIndex, ptrs);
-    uint32_t seen[kEntriesPerLane];         // cameras whose frustum holds entry j
+    uint32_t seen[kN];                      // cameras whose frustum holds entry j
     int myCount = 0;
 #pragma unroll
-    for (int j = 0; j < kEntriesPerLane; ++j) {
+    for (int j = 0; j < kN; ++j) {
         seen[j] = 0;
         if (ptrs[j] == VH_FREE_BLOCK) continue;
         const uint32_t e = tile + j * kFlattenThreads + threadIdx.x;
@@ -88,7 +89,7 @@ __device__ __forceinline__ void flatten_multi_tile(const FrameParams &fp, const 
     int slot = reserve_compact_slots(dp, counter, myCount);
     if (slot < 0) return;
 #pragma unroll
-    for (int j = 0; j < kEntriesPerLane; ++j) {
+    for (int j = 0; j < kN; ++j) {
         if (seen[j] == 0u) continue;
         dp.compact[slot] = dp.table[tile + j * kFlattenThreads + threadIdx.x];
         dp.compactMask[slot] = seen[j];
@@ -246,6 +247,7 @@ struct MultiPipeArgs {
     uint32_t spinLimit;          // ... and how many polls a workgroup waits for it
     int32_t setNew, setOld, setClear;
     uint32_t hasNew, hasOld;
+    uint32_t walkShort;          // the walk takes 4 instead of 8 entries per lane
     uint32_t claimSpan, claimRatio;
     uint32_t epochOld;
     const int4 *binsNew;
@@ -286,7 +288,9 @@ __global__ __launch_bounds__(256) void frame_multi_pipelined_kernel(const FrameP
             claim_bin_slice(fp, dp, a.binsNew, a.capacity, a.binStride, before / a.partsPerBin, before % a.partsPerBin, a.partsPerBin,
                             kPipeCand + a.setNew, pend, a.binFrame);
         } else {
-            flatten_multi_tile(fp, dp, a.numEntries, r - before, a.numCams, a.packetsNew, a.packetStride, kPipeScan + a.setNew, pend);
+            // (4 entries per lane for a large shard, as the single-camera frame walks; 8 for the shards of many ranks)
+            if (a.walkShort) flatten_multi_tile<kEntriesPerLaneShort>(fp, dp, a.numEntries, r - before, a.numCams, a.packetsNew, a.packetStride, kPipeScan + a.setNew, pend);
+            else flatten_multi_tile(fp, dp, a.numEntries, r - before, a.numCams, a.packetsNew, a.packetStride, kPipeScan + a.setNew, pend);
         }
         return;
     }

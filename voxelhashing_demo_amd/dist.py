@@ -835,6 +835,10 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             # (key bins: the library's default -- ONE bin per (owner, batch) of 1.5 x batch x W*H/16 / world records)
             native_capacity = max(2048, (-(-Wd * Ht // 16) * batch * 3 // 2 + world - 1) // world + 1)
 
+            for kv in getattr(args, "option", []) or []:          # A/B switches (bench.py --option name=value)
+                k_, v_ = kv.split("=")
+                nd.table.set_option(k_, int(v_))
+
             class _Shard:          # what the rest of this function reads of a HipShard
                 table, packet_floats = nd.table, (36 + Wd * Ht // 2) if sensor else (32 + Wd * Ht)
             shard, pipe = _Shard, None
