@@ -331,6 +331,9 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
 // 5 in as well: C2 17.2 but C3 70.2; one at a time: the semantics C2 17.9 / C3 68.4, the bucket size 17.8 / 75.2, the shard's
 // bucket range 17.45 / 69.0 against 17.6 / 68.5 -- not done: what the compiler makes of a smaller kernel is not monotone.
 // The same builds of the two-launch kernels: no difference (C2 16.27 + 4.45 us either way, C3 63.0 + 11.7 / 63.4 + 11.4).)
+// (Eight waves per SIMD instead of the seven the 106 SGPRs allow -- __launch_bounds__(256, 8): 78 SGPRs, 129 instead of 100 of
+// them spilled to VGPR lanes -- measured in round 4, same box: C2 17.69 -> 18.37 us, C3 69.0 -> 69.4, C2 with the band 22.9 ->
+// 25.4.  The launch does not lack wave slots; the spill traffic lengthens the claim tiles.  profiles/r04_ab_pipe_waves.txt)
 template <class In, class Depth, bool kBand, bool kSerial, int kLean>
 __global__ __launch_bounds__(256) void frame_pipelined_kernel(FrameParams fpNew, const DevPtrs dpNew, const In inNew,
                                                               FrameParams fpOld, const DevPtrs dpOld,
