@@ -702,7 +702,8 @@ def main():
             from voxelhashing_demo_amd import dist as vdist
             init_dist(dist, torch, local_rank)
             sargs = argparse.Namespace(**vars(args))
-            sargs.steps, sargs.warmup = max(20, min(args.steps, 200) // max(1, args.batch)), 5
+            # (windows of ~20 ms: with the 4 ms windows of earlier rounds the flush at each window's end cost the leg 3-4 %)
+            sargs.steps, sargs.warmup = max(20, min(args.steps, 1000) // max(1, args.batch)), 5
             sargs.metric_name = baseline_metric(Wd, Ht)
             extra["sharded_world1"] = vdist.bench_sharded(sargs, wl, name, 0, 1, local_rank)
             dist.destroy_process_group()
