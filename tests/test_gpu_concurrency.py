@@ -114,6 +114,7 @@ def test_serialised_launches_while_another_kernel_holds_the_chip(oracle, vh, tor
     gt = vh.SDFHashtable(vh.default_params(**kw), 160, 120, 1, stream=st)
     gt.set_option("overflow_list", 1)
     gt.set_option("pipeline", 1)
+    gt.set_option("pipeline_overflow", 2)
     dv = [torch.from_numpy(v).cuda() for _, v in frames]
     torch.cuda.synchronize()
     L = vh.load()
@@ -144,6 +145,7 @@ def test_a_serialised_launch_that_times_out_is_reported_and_bounded(oracle, vh, 
     gt = vh.SDFHashtable(vh.default_params(**kw), 160, 120, 1)
     gt.set_option("overflow_list", 1)
     gt.set_option("pipeline", 1)
+    gt.set_option("pipeline_overflow", 2)
     gt.set_option("spin_limit", 1)
     dv = [torch.from_numpy(v).cuda() for _, v in frames]
     gt.integrate_batch([p for p, _ in frames], dv)

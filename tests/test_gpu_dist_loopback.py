@@ -188,7 +188,7 @@ def test_native_ranks_overflow_list(oracle, vh, torch_cuda, world, batch):
     full = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
     full.set_overflow(True, plan.per_shard)
     g = vdist.NativeGroup(vh.default_params(**kw), W, H, 1, world, batch, key_capacity=W * H * batch,
-                          options={"overflow_list": 1})
+                          options={"overflow_list": 1, "pipeline_overflow": 2})
     _feed(g, full, frames, batch)
     g.flush()
     ftab, fvol = full.hash_table(), full.sdf_blocks()

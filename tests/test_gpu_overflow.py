@@ -23,9 +23,11 @@ def pair(oracle, vh, variant, W=640, H=480, sem=0, overflow=True, **kw):
     gt.set_option("flatten_variant", walk)
     if len(VARIANTS[variant]) > 2:           # one launch per frame: with the overflow list, serialised inside the launch
         gt.set_option("pipeline", 1)
+        gt.set_option("pipeline_overflow", 2)    # (... whatever the launch's size: by default only small launches take that form)
     if overflow:
         ot.set_overflow(True)
         gt.set_option("overflow_list", 1)
+    gt.set_option("pipeline_overflow", 2)
     return ot, gt
 
 
@@ -66,6 +68,7 @@ def test_overflow_list_pipelined_batches(oracle, vh, torch_cuda, walk, nb, bs, L
     gt = vh.SDFHashtable(vh.default_params(**kw), 640, 480, 1)
     ot.set_overflow(True)
     gt.set_option("overflow_list", 1)
+    gt.set_option("pipeline_overflow", 2)                 # (1 200 claim tiles: beyond what the default takes as one launch)
     gt.set_option("flatten_variant", walk)
     gt.set_profiling(True)
     sphere = synth.sphere_inside_scene()
@@ -193,6 +196,7 @@ def test_overflow_on_shards(oracle, vh, torch_cuda, world, calls, batch):
     full.set_overflow(True, plan.per_shard)
     for sh in shards:
         sh.table.set_option("overflow_list", 1)
+        sh.table.set_option("pipeline_overflow", 2)
     prims = synth.room_primitives()
     poses = None
     for step in range(0, 6, batch):
@@ -344,3 +348,24 @@ def test_ray_dda_band_on_native_ranks(oracle, vh, torch_cuda):
     assert total == len(full.allocated()) > 500
     g.close()
     full.close()
+
+
+def test_overflow_frames_choose_their_form_by_size(oracle, vh, torch_cuda):
+    """Option "pipeline_overflow" 1 (the default): with the list on, a frame is one serialised launch only while few
+    workgroups would have to wait and acquire (160x120: 80 claim tiles); a 640x480 frame (1 200) runs as two launches, which
+    is ~9 times faster at C2's size.  0 = never, 2 = always.  The bits are the same in every form (the tests above)."""
+    torch = torch_cuda
+    kw = dict(numBuckets=512, bucketSize=2, numVoxelBlocks=4096, attachedLinkedListSize=8)
+    for (W, H, mode, pipelined) in ((160, 120, 1, True), (640, 480, 1, False), (640, 480, 2, True), (160, 120, 0, False)):
+        gt = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
+        gt.set_option("overflow_list", 1)
+        gt.set_option("pipeline", 1)
+        gt.set_option("pipeline_overflow", mode)
+        v = torch.from_numpy(synth.render_room_verts(synth.camera_loop(40)[3], W, H, synth.room_primitives()).numpy()).cuda()
+        gt.set_profiling(True)
+        for _ in range(3):
+            gt.integrate(synth.camera_loop(40)[3], v)
+        gt.synchronize()
+        kt = gt.kernel_times(reset=True)
+        assert (kt["frame_pipelined_ms"] > 0) == pipelined and (kt["frame_scan_claim_ms"] > 0) == (not pipelined), (W, H, mode, kt)
+        gt.close()

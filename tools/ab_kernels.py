@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0, help="frames per vh_integrate_batch call (0: vh_integrate)")
     ap.add_argument("--set", nargs="*", default=[], help="name=value options set once")
+    ap.add_argument("--preset", nargs="*", default=[], help="name=value options set before the first frame (overflow_list=1 ...)")
     a = ap.parse_args()
     import torch
 
@@ -40,6 +41,9 @@ def main():
                        Wd, Ht, V.SEM_PINHOLE, stream=stream)
     if wl.get("band"):
         t.set_alloc_band(wl["band"])
+    for kv in a.preset:
+        k, v = kv.split("=")
+        t.set_option(k, int(v))
     for i in range(a.frames):
         t.integrate(poses[i], verts[i])
     t.synchronize()

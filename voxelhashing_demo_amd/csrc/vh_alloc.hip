@@ -20,6 +20,12 @@ namespace vh {
 // which heads that bucket's own chain) and then needs BOTH buckets: it stakes its claim on both and
 // commits only if it holds both (the reference locks the parent bucket, then the new one,
 // VoxelUtils.cu:472-482; both stay locked for the frame).
+// (Round 4 built the wave's version of this probe -- eight lanes per key: the bucket's slots read side by side and judged by
+// a ballot, the chain followed in step, the nine look-ahead slots read together, the group's first lane staking the claim;
+// slot- and link-exact on the whole overflow suite -- and measured it against this one, same box: the two-launch frame of C2
+// with the list on 16.5 -> 17.0 us, with a 10 cm band 19.9 -> 22.5 us (profiles/r04_ab_overflow_coop.txt; branch
+// wip/overflow-probe-wave).  The keys of a wave are probed side by side already, one per lane; serving them eight at a time
+// shortens a key's chain of reads but makes eight rounds of it.  Not adopted.)
 __device__ __forceinline__ void probe_and_claim_overflow(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz,
                                                          uint32_t h, uint32_t rank, int candCounter)
 {

@@ -118,6 +118,7 @@ struct vh_context {
     uint32_t *maskBuf2 = nullptr;          // pipelined multi-camera frames: the camera masks of the second compact buffer
     int multiWalkEntries = 0;              // option "multi_walk_entries": entries per lane of the multi-camera pipelined walk (0: by shard size)
     uint32_t spinLimit = 0;                // option "spin_limit": polls a workgroup of a serialised pipelined launch waits for the pending commit phase (0: kSpinLimitDefault)
+    int pipelineOverflow = 1;              // option "pipeline_overflow": one-launch (serialised) frames with the overflow list: 0 never, 1 by the launch's size (default), 2 always
     bool serialFallback = false;           // a serialised launch has timed out (vh_counters.spin_timeouts): overflow-list frames take two launches from now on
     int leanKernels = 1;                   // option "lean_kernels": builds of the pipelined launch with the option flags folded in (A/B switch)
     int debugSkipRoles = 0;                // diagnostics: roles of the pipelined launch that return at once (timing only; the model is wrong)

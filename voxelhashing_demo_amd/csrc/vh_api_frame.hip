@@ -239,11 +239,24 @@ static DevPtrs pipe_view(const vh_context *c, int parity)
     return d;
 }
 
+// With the overflow list a one-launch frame is serialised inside the launch: every claim / walk workgroup of frame i+1 waits
+// for commit(i) and then ACQUIRES -- on this chip an L2 invalidate per workgroup.  Measured in round 4 on C2 (6 320 such
+// workgroups per launch, profiles/r04_ab_overflow_coop.txt): 186 us per launch against 16.5 + 4.5 us for the two-launch
+// frame, i.e. ~26 ns per waiting workgroup against ~3 us for a second launch.  So the serialised form is taken only where it
+// is the cheaper one: up to kSerialMaxWaiters waiting workgroups (option "pipeline_overflow" 1, the default; 0 never, 2 always).
+constexpr uint32_t kSerialMaxWaiters = 128;
+static bool serial_launch_pays(const vh_context *c, uint32_t waiters)
+{
+    if (!(c->fp.flags & kFlagOverflow)) return true;
+    if (c->serialFallback || c->pipelineOverflow == 0) return false;
+    return c->pipelineOverflow == 2 || waiters <= kSerialMaxWaiters;
+}
+
 // can this context run its frames pipelined right now?
 static bool pipeline_applies(const vh_context *c)
 {
     return c->pipeline && c->fusedFrame && (c->flattenVariant == kWalkStridedBallot || c->flattenVariant == kWalkIndexed) &&
-           c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks && !(c->serialFallback && (c->fp.flags & kFlagOverflow));
+           c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks && serial_launch_pays(c, host_num_tiles(c) + walk_blocks(c));
 }
 
 // One launch: {claim || walk} of the new frame (in != nullptr) and {commit + integrate} of the pending one.

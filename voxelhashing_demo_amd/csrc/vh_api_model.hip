@@ -403,6 +403,13 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
 #endif
     if (std::strcmp(name, "lean_kernels") == 0) { c->leanKernels = value != 0; return VH_OK; }
     if (std::strcmp(name, "spin_limit") == 0 && value >= 0) { c->spinLimit = (uint32_t)value; return VH_OK; }
+    if (std::strcmp(name, "pipeline_overflow") == 0 && value >= 0 && value <= 2) {
+        DeviceGuard g(c->device);
+        const int frc = flush_pending(c);               // (the form of the next frame may change)
+        if (frc != VH_OK) return frc;
+        c->pipelineOverflow = value;
+        return VH_OK;
+    }
     if (std::strcmp(name, "multi_walk_entries") == 0 && (value == 0 || value == kEntriesPerLaneShort || value == kEntriesPerLane)) { c->multiWalkEntries = value; return VH_OK; }
     if (std::strcmp(name, "pipeline_shards") == 0) {
         if (value < 0 || value > 2) return fail(VH_ERR_INVALID_ARGUMENT, "pipeline_shards: 0, 1 or 2");

@@ -492,7 +492,8 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
     // the next batch -- B launches -- or in the flush any observer does first.
     // Same conditions as the single-camera pipeline (bucketSize <= 16, not a view table; with the overflow list the frames are
     // serialised inside the launch).
-    if (c->pipelineShards && c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks && !(c->serialFallback && (c->fp.flags & kFlagOverflow))) {
+    if (c->pipelineShards && c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks &&
+        serial_launch_pays(c, (uint32_t)num_bins * parts + (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLaneShort))) {
         int rc = ensure_pipeline_buffers(c);
         if (rc != VH_OK) return rc;
         if (!c->maskBuf2) VH_HIP(hipMalloc((void **)&c->maskBuf2, sizeof(uint32_t) * c->numEntries));
