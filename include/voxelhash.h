@@ -208,8 +208,8 @@ int vh_set_alloc_band(vh_context *ctx, float band_metres);
  *                       once per lock epoch (several cameras per epoch: vh_insert_bins / vh_apply_frames_batch).
  *   "pipeline_overflow" one-launch frames ("pipeline", vh_integrate_batch, vh_apply_frames_batch) with the overflow list on are
  *                       serialised inside the launch, and every waiting workgroup pays a cache invalidate: 1 (default) =
- *                       taken only for small launches (up to 128 claim + walk workgroups), larger ones run as two launches
- *                       (C2: 21 us against 186 us); 0 = never; 2 = always.  Results are the same bits either way.
+ *                       taken only for small launches (up to 512 claim + walk workgroups), larger ones run as two launches
+ *                       (C2: 21 us against 53 us); 0 = never; 2 = always.  Results are the same bits either way.
  *   "band_mode"         VH_BAND_RAY (default: vh_set_alloc_band's samples along the viewing ray) or
  *                       VH_BAND_NORMAL_DDA: every block the segment from p - band*n to p + band*n crosses, by a
  *                       block DDA (commented out in the reference, VoxelUtils.cu:632-703); n comes from the

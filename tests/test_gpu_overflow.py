@@ -353,7 +353,7 @@ def test_ray_dda_band_on_native_ranks(oracle, vh, torch_cuda):
 def test_overflow_frames_choose_their_form_by_size(oracle, vh, torch_cuda):
     """Option "pipeline_overflow" 1 (the default): with the list on, a frame is one serialised launch only while few
     workgroups would have to wait and acquire (160x120: 80 claim tiles); a 640x480 frame (1 200) runs as two launches, which
-    is ~9 times faster at C2's size.  0 = never, 2 = always.  The bits are the same in every form (the tests above)."""
+    is 2.5 times faster at C2's size.  0 = never, 2 = always.  The bits are the same in every form (the tests above)."""
     torch = torch_cuda
     kw = dict(numBuckets=512, bucketSize=2, numVoxelBlocks=4096, attachedLinkedListSize=8)
     for (W, H, mode, pipelined) in ((160, 120, 1, True), (640, 480, 1, False), (640, 480, 2, True), (160, 120, 0, False)):

@@ -240,11 +240,12 @@ static DevPtrs pipe_view(const vh_context *c, int parity)
 }
 
 // With the overflow list a one-launch frame is serialised inside the launch: every claim / walk workgroup of frame i+1 waits
-// for commit(i) and then ACQUIRES -- on this chip an L2 invalidate per workgroup.  Measured in round 4 on C2 (6 320 such
-// workgroups per launch, profiles/r04_ab_overflow_coop.txt): 186 us per launch against 16.5 + 4.5 us for the two-launch
-// frame, i.e. ~26 ns per waiting workgroup against ~3 us for a second launch.  So the serialised form is taken only where it
-// is the cheaper one: up to kSerialMaxWaiters waiting workgroups (option "pipeline_overflow" 1, the default; 0 never, 2 always).
-constexpr uint32_t kSerialMaxWaiters = 128;
+// for commit(i) and then ACQUIRES -- a cache invalidate (buffer_inv sc1), which this chip serves one at a time.  Measured in
+// round 4 on C2 (6 320 such workgroups per launch, profiles/r04_ab_overflow_serial.txt): 185 us per launch with the
+// invalidate in every wave, 53 us with one per workgroup (wait_commit_done), against 16.4 + 4.6 us for the two-launch frame
+// -- ~5.5 ns per waiting workgroup against ~3 us for a second launch.  So the serialised form is taken only where it is the
+// cheaper one: up to kSerialMaxWaiters waiting workgroups (option "pipeline_overflow" 1, the default; 0 never, 2 always).
+constexpr uint32_t kSerialMaxWaiters = 512;
 static bool serial_launch_pays(const vh_context *c, uint32_t waiters)
 {
     if (!(c->fp.flags & kFlagOverflow)) return true;

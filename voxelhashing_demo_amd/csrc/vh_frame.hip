@@ -179,9 +179,11 @@ __device__ __forceinline__ bool wait_commit_done(int32_t *counters, int32_t tag,
         }
         if (!ok) atomicAdd(counters + kSpinTimeouts, 1);
         reached = ok;
+        // the acquire: ONE cache invalidate per workgroup (its CU's vector cache, the XCD's non-coherent L2 lines), by the
+        // wave that saw the tag; the other waves' loads come behind the barrier
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return reached != 0;
 }
 
