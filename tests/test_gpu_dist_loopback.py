@@ -117,6 +117,31 @@ def test_native_ranks_keep_feeding_after_a_raycast(oracle, vh, torch_cuda):
     full.close()
 
 
+def test_raycast_round_that_finds_its_own_slot_capacity(oracle, vh, torch_cuda, monkeypatch):
+    """vh_dist_raycast_auto (what the C++ facade's sharded raycast calls): the first try with far too few record slots (16),
+    every rank's lost count gathered, the round repeated for ALL ranks with room for what was lost, until every view is whole;
+    depth and normals equal the oracle's raycast of the one table."""
+    torch = torch_cuda
+    W, H, world, batch = 320, 240, 2, 2
+    kw = dict(numBuckets=1 << 14, numVoxelBlocks=1 << 13)
+    frames, kinv = _camera_frames(oracle, torch, world, 6, W, H, True)
+    full = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    g = vdist.NativeGroup(vh.default_params(**kw), W, H, 1, world, batch, sensor_k_inv=kinv)
+    _feed(g, full, frames, batch)
+    monkeypatch.setenv("VOXELHASH_RAYCAST_AUTO_START", "16")
+    poses = [c[0] for c in frames[-1]]
+    outs = [torch.empty((H, W), dtype=torch.float32, device="cuda") for _ in range(world)]
+    nrm = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(world)]
+    caps = g._all(lambda r, nd: nd.raycast_auto(poses[r], outs[r], nrm[r]))
+    assert caps[0] == caps[1] > 16                               # (the ranks agree; 16 slots were not enough)
+    for r in range(world):
+        od, on = full.raycast(poses[r], normals=True)
+        assert np.array_equal(outs[r].cpu().numpy().view(np.uint32), od.view(np.uint32))
+        assert np.array_equal(nrm[r].cpu().numpy().view(np.uint32), on.view(np.uint32))
+    g.close()
+    full.close()
+
+
 def test_native_ranks_with_a_user_stream(oracle, vh, torch_cuda):
     """vh_dist_set_user_stream: the frames are produced on a torch stream right before the call and overwritten right after
     it, the raycast image is consumed on that stream right after the call -- no host synchronisation anywhere."""

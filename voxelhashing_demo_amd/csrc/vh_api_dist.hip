@@ -623,7 +623,9 @@ extern "C" int vh_dist_raycast_auto(vh_dist *d, const float pose[16], float t_mi
     // a shard cannot select more blocks than its pool holds, and the view table lists one imported record per entry
     const int64_t most = std::max<int64_t>(1, std::min<int64_t>((int64_t)d->cfg.table.params.numVoxelBlocks,
         (int64_t)d->cfg.table.params.numBuckets * d->cfg.table.params.bucketSize / R));
-    int32_t cap = (int32_t)std::min<int64_t>(most, std::max<int32_t>(d->autoCapacity, 4096));
+    int32_t first = 4096;                               // (VOXELHASH_RAYCAST_AUTO_START: a smaller first try, for the test of the retry)
+    if (const char *e = std::getenv("VOXELHASH_RAYCAST_AUTO_START")) first = std::max(1, std::atoi(e));
+    int32_t cap = (int32_t)std::min<int64_t>(most, std::max<int32_t>(d->autoCapacity, first));
     for (int attempt = 0; attempt < 8; ++attempt) {
         int rc = dist_raycast_impl(d, pose, t_min, t_max, cap, d_depth_out, d_normals_out, d->lostDev);
         if (rc != VH_OK) return rc;

@@ -374,6 +374,16 @@ class NativeDist:
                                                 out.data_ptr(), None if lost is None else lost.data_ptr()), "vh_dist_raycast")
         return out
 
+    def raycast_auto(self, pose, out, normals=None, t_min: float = 0.1, t_max: float = 5.0):
+        """The raycast round with the slot capacity agreed by the ranks (vh_dist_raycast_auto): repeated with more room while
+        any rank's view lost records; returns the capacity that rendered every view whole.  Synchronises.  Collective."""
+        import ctypes as C
+        p = np.ascontiguousarray(np.asarray(pose, np.float32).reshape(16))
+        cap = C.c_int32()
+        self._L.check(self._lib.vh_dist_raycast_auto(self._h, p.ctypes.data_as(C.POINTER(C.c_float)), t_min, t_max, out.data_ptr(),
+                                                     None if normals is None else normals.data_ptr(), C.byref(cap)), "vh_dist_raycast_auto")
+        return cap.value
+
     def comm_info(self):
         """(rank, size) as the transport reports them (ncclCommUserRank / ncclCommCount over RCCL)."""
         import ctypes as C
