@@ -47,6 +47,9 @@ public:
     SDF_Hashtable(const HashTableParams &params, int width, int height, int semantics, int rank, int world, int batch,
                   const char uniqueId[VH_DIST_ID_BYTES], const float kInv[9], int device = -1);
     static void uniqueId(char id[VH_DIST_ID_BYTES]);
+    /* the id of an in-process loop-back group (vh_dist_loopback_id): `world` SDF_Hashtable ranks of ONE process, one host
+     * thread per rank, exchange by device copies instead of RCCL -- the N > 1 host on a single-GPU box */
+    static void loopbackId(char id[VH_DIST_ID_BYTES]);
     /* `batch` frames of this rank's camera (poses: batch*16 row-major floats; d_depth: batch device pointers): queues
      * this exchange and applies the previous one; flush() completes what is in flight.  Collective over the ranks. */
     void integrateExchange(const float *poses, const uint16_t *const *d_depth);

@@ -147,3 +147,47 @@ def test_cpp_sharded_program(oracle, vh, torch_cuda, tmp_path):
     depth = np.fromfile(tmp_path / "depth_out.bin", dtype=np.float32).reshape(H, W)
     assert np.array_equal(depth.view(np.uint32), ot.raycast(poses[5]).view(np.uint32))
     ot.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cpp_threads_program_with_several_ranks(oracle, vh, torch_cuda, tmp_path, world):
+    """tests/cpp/sharded_threads_demo.cpp: a C++ host (no Python, no torch in that process) with R ranks of SDF_Hashtable's
+    multi-GPU constructor on the one GPU, one std::thread per rank, joined by the loop-back transport: every shard equals its
+    slice of ONE oracle table, every rank's raycast through all shards equals the oracle's."""
+    from voxelhashing_demo_amd import dist as vdist
+    lib = os.path.join(ROOT, "voxelhashing_demo_amd", "lib")
+    exe = tmp_path / "sharded_threads_demo"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "sharded_threads_demo.cpp"), "-o", str(exe),
+                    "-L", lib, "-lsdf_hashtable", "-lvoxelhash_hip", f"-Wl,-rpath,{lib}"], check=True)
+    batch, steps = 2, 3
+    n = batch * steps
+    prims = synth.room_primitives()
+    kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+    cam_poses = [synth.camera_loop(60, phase=vdist.camera_phase(r, world))[:3 * n:3] for r in range(world)]
+    d16 = [[np.round(synth.render_room_verts(p, W, H, prims).numpy()[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for p in cam_poses[r]]
+           for r in range(world)]
+    np.asarray(cam_poses, np.float32).tofile(tmp_path / "poses.bin")
+    np.stack([np.stack(d) for d in d16]).tofile(tmp_path / "depth.bin")
+    kinv.tofile(tmp_path / "kinv.bin")
+    import torch
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    env = dict(os.environ, LD_LIBRARY_PATH=tlib + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([str(exe), str(world), str(tmp_path / "poses.bin"), str(tmp_path / "depth.bin"), str(tmp_path / "kinv.bin"),
+                          str(W), str(H), str(batch), str(steps), str(KW["numBuckets"]), str(KW["numVoxelBlocks"]), str(tmp_path) + "/"],
+                         check=True, capture_output=True, text=True, env=env, timeout=600).stdout
+    got = dict((k, int(v)) for k, v in re.findall(r"(\w+)=(\d+)", out))
+    ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+    for j in range(n):
+        vdist.reference_multi_camera_frame(ot, [cam_poses[r][j] for r in range(world)],
+                                           [oracle.preprocess(d16[r][j], kinv)[0] for r in range(world)])
+    otab = ot.hash_table()
+    assert got["ranks"] == world and got["allocated"] == int((otab["ptr"] != -1).sum()) > 100 and got["bin_overflow"] == 0
+    plan = vdist.ShardPlan(KW["numBuckets"], world)
+    for r in range(world):
+        lo, hi = plan.bucket_range(r)
+        tab = np.fromfile(tmp_path / f"table{r}.bin", dtype=vh.ENTRY_DTYPE)
+        assert np.array_equal(tab["pos"], otab["pos"][lo * 5:hi * 5]) and np.array_equal(tab["ptr"] != -1, otab["ptr"][lo * 5:hi * 5] != -1)
+        depth = np.fromfile(tmp_path / f"depth{r}.bin", dtype=np.float32).reshape(H, W)
+        assert np.array_equal(depth.view(np.uint32), ot.raycast(cam_poses[r][-1]).view(np.uint32)), r
+    ot.close()

@@ -61,6 +61,7 @@ SDF_Hashtable::SDF_Hashtable(const HashTableParams &params, int width, int heigh
 }
 
 void SDF_Hashtable::uniqueId(char id[VH_DIST_ID_BYTES]) { check(vh_dist_unique_id(id), "vh_dist_unique_id"); }
+void SDF_Hashtable::loopbackId(char id[VH_DIST_ID_BYTES]) { check(vh_dist_loopback_id(id), "vh_dist_loopback_id"); }
 
 void SDF_Hashtable::integrateExchange(const float *poses, const uint16_t *const *d_depth)
 {
