@@ -742,12 +742,14 @@ def main():
 
 
 def init_dist(dist, torch, local_rank):
-    if "MASTER_ADDR" not in os.environ:
+    if "RANK" not in os.environ or "WORLD_SIZE" not in os.environ:
+        # direct (not torchrun) launch: one rank, any free port -- whatever MASTER_* a parent process may have left in the
+        # environment (a test session that ran a process group of its own did)
         import socket
-        with socket.socket() as sk:              # direct (not torchrun) launch: any free port
+        with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     # one node by contract: keep RCCL's bootstrap and the c10d store on the loop-back interface
     # (the container's hostname may not resolve), and surface a stuck collective in minutes
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")

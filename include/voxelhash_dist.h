@@ -40,7 +40,7 @@ typedef struct vh_dist_config {
     int32_t rank, world;      /* this rank's index and the number of ranks = cameras = shards (<= VH_MAX_CAMERAS) */
     int32_t batch;            /* frames per camera and exchange (>= 1) */
     int32_t key_capacity;     /* records per (camera, owner) key bin -- one bin for the whole batch (VH_BIN_PER_BATCH);
-                                 0 = max(2048, 1.5 * batch * W*H/16 / world) */
+                                 0 = max(8192, 1.5 * batch * W*H/16 / world) */
     int32_t packet_format;    /* VH_PACKET_U16: frames are uint16 sensor images (k_inv used), packets carry the image;
                                  VH_PACKET_F32: frames are float4 vertex maps, packets carry a float camera-z plane */
     float   k_inv[9];         /* row-major K^-1 of the cameras (VH_PACKET_U16) */

@@ -61,11 +61,8 @@ def test_native_ranks_equal_one_oracle_table(oracle, vh, torch_cuda, world, batc
     steps = 5 * batch
     frames, kinv = _camera_frames(oracle, torch, world, steps, W, H, sensor)
     full = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
-    # (the library's default bin size for 2 and 4 ranks; at this small image size the fullest bin of the ragged three-way and
-    # of the eight-way split exceeds 1.5 x the even share by a few records -- counted in bin_overflow, the dropped keys are
-    # demanded again by the next frame -- so those get room; C4 / C5 below run the default at their sizes)
-    g = vdist.NativeGroup(vh.default_params(**kw), W, H, 1, world, batch, sensor_k_inv=kinv if sensor else None,
-                          key_capacity=W * H // 8 * batch if world in (3, 8) else 0)
+    # (the library's default bin size for every split, the ragged three-way one included)
+    g = vdist.NativeGroup(vh.default_params(**kw), W, H, 1, world, batch, sensor_k_inv=kinv if sensor else None)
     assert all(nd.transport == "loopback" and nd.comm_info() == (r, world) for r, nd in enumerate(g.ranks))
     _feed(g, full, frames, batch)
     g.flush()

@@ -54,7 +54,7 @@ for i in range(3):
 g.flush()
 torch.cuda.synchronize()
 frames = 3 * B
-cap = max(2048, (-(-W * H // 16) * B * 3 // 2 + R - 1) // R + 1)
+cap = max(8192, (-(-W * H // 16) * B * 3 // 2 + R - 1) // R + 1)
 per_rank = []
 for r, t in enumerate(g.tables):
     kt = t.kernel_times(reset=True)

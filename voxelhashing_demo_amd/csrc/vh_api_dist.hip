@@ -384,7 +384,9 @@ extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_I
     // 2-D wave dedup leaves of a room frame) and the owners share them evenly; bucket-range ownership is skewed by up to
     // ~2.5 x the even share on walls (the 8-rank rig), hence the factor on top.  Overflows are counted, never silent.
     const size_t perOwner = ((npix + 15) / 16 * (size_t)cfg->batch * 3 / 2 + (size_t)cfg->world - 1) / (size_t)cfg->world;
-    d->capacity = cfg->key_capacity > 0 ? cfg->key_capacity : (int)std::max<size_t>(2048, perOwner + 1);
+    // (the floor: small images split many ways have bins whose fullest exceeds 1.5 x the even share -- 320x240 over 3 or 8
+    // ranks overflowed 4 801- and 2 048-record bins by 2 and 6 records in round 4's tests; 128 KB per bin costs nothing there)
+    d->capacity = cfg->key_capacity > 0 ? cfg->key_capacity : (int)std::max<size_t>(8192, perOwner + 1);
     d->packetUnits = cfg->packet_format == VH_PACKET_U16 ? (size_t)kPacketHeaderU16 + npix / 2 : (size_t)kPacketHeader + npix;
     const size_t B = (size_t)cfg->batch;
     const size_t binBytes = (size_t)R * (size_t)d->capacity * 4 * sizeof(int32_t);      // [peer][capacity] records of 16 bytes

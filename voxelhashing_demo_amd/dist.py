@@ -843,7 +843,7 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     with torch.cuda.stream(stream):
         if native:
             # (key bins: the library's default -- ONE bin per (owner, batch) of 1.5 x batch x W*H/16 / world records)
-            native_capacity = max(2048, (-(-Wd * Ht // 16) * batch * 3 // 2 + world - 1) // world + 1)
+            native_capacity = max(8192, (-(-Wd * Ht // 16) * batch * 3 // 2 + world - 1) // world + 1)
 
             for kv in getattr(args, "option", []) or []:          # A/B switches (bench.py --option name=value)
                 k_, v_ = kv.split("=")
