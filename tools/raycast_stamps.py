@@ -27,6 +27,9 @@ for k in (0, 35, 77):
     t.synchronize()
     L.vh_debug_set_raycast_stamps(t._h, None)
     s = st.cpu().numpy()
+    # (a library built with -DVH_RAYCAST_DIAG keeps three more figures in the upper halves of words 4-6)
+    dEntry, dWalk, dRounds = (s[:, 4] >> 32) / 100.0, (s[:, 5] >> 32) / 100.0, (s[:, 6] >> 32)
+    s[:, 4] &= 0xffffffff; s[:, 5] &= 0xffffffff; s[:, 6] &= 0xffffffff
     t0 = s[:, 0].min()
     start, end = (s[:, 0] - t0) / 100.0, (s[:, 1] - t0) / 100.0          # microseconds
     life = end - start
@@ -56,6 +59,12 @@ for k in (0, 35, 77):
               f"mean {shared.mean():.1f} max {shared.max():.1f} us; the ten slowest tiles now {np.sort(t4.max(axis=1))[-10:].round(1).tolist()} shared {np.sort(shared)[-10:].round(1).tolist()}")
         slow = np.argsort(-life)[:6]
         print("   slowest waves: (life, list, walked)", [(round(float(life[i]), 1), int(s[i, 6]), int(s[i, 7])) for i in slow])
+        if dRounds.max() > 0:
+            print("   diagnostics build, slowest waves: (life, list resolved at, entry tests us, voxel loops us, loop rounds, ns per round)",
+                  [(round(float(life[i]), 1), round(float(tB[i]), 1), round(float(dEntry[i]), 1), round(float(dWalk[i]), 1), int(dRounds[i]),
+                    round(1000.0 * float(dWalk[i]) / max(1, int(dRounds[i])))) for i in slow])
+            print(f"   all waves: entry tests {dEntry.mean():.2f} us, voxel loops {dWalk.mean():.2f} us, rounds {dRounds.mean():.1f}, "
+                  f"rounds per walked block {dRounds.sum() / max(1, s[:, 7].sum()):.1f}, ns per round {1000.0 * dWalk.sum() / max(1, dRounds.sum()):.0f}")
     ok = rounds > 0
     if not ok.any():
         continue

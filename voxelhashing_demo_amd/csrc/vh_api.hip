@@ -117,6 +117,7 @@ struct vh_context {
     VoxelEntry *compactBuf[2] = {nullptr, nullptr};
     uint32_t *maskBuf2 = nullptr;          // pipelined multi-camera frames: the camera masks of the second compact buffer
     int multiWalkEntries = 0;              // option "multi_walk_entries": entries per lane of the multi-camera pipelined walk (0: by shard size)
+    int genFramesPerLaunch = 4;            // option "gen_frames_per_launch": frames of a batch one key-generation launch takes (1..8)
     uint32_t spinLimit = 0;                // option "spin_limit": polls a workgroup of a serialised pipelined launch waits for the pending commit phase (0: kSpinLimitDefault)
     int pipelineOverflow = 1;              // option "pipeline_overflow": one-launch (serialised) frames with the overflow list: 0 never, 1 by the launch's size (default), 2 always
     bool serialFallback = false;           // a serialised launch has timed out (vh_counters.spin_timeouts): overflow-list frames take two launches from now on

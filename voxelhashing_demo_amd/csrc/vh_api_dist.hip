@@ -405,7 +405,16 @@ extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_I
     for (hipStream_t *s : {&d->sGen, &d->sComm, &d->sTable}) VH_DIST_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
     for (hipEvent_t *e : {&d->userEvent, &d->outEvent}) VH_DIST_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < vh_dist::kSets; ++i) {
-        for (hipEvent_t *e : {&d->generated[i], &d->ready[i], &d->first[i]}) VH_DIST_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+#ifndef VH_DIST_EVENT_FLAGS_FIRST
+#define VH_DIST_EVENT_FLAGS_FIRST (hipEventDisableTiming | hipEventDisableSystemFence)
+#endif
+#ifndef VH_DIST_EVENT_FLAGS
+#define VH_DIST_EVENT_FLAGS hipEventDisableTiming
+#endif
+        for (hipEvent_t *e : {&d->generated[i], &d->ready[i]}) VH_DIST_TRY(hipEventCreateWithFlags(e, VH_DIST_EVENT_FLAGS));
+        // `first` only says that the frames are done READING a buffer set (it orders the next writer on this device behind them),
+        // and it is recorded between two frame launches: no system-scope fence, whose cache write-back the next launch would pay
+        VH_DIST_TRY(hipEventCreateWithFlags(&d->first[i], VH_DIST_EVENT_FLAGS_FIRST));
         VH_DIST_TRY(hipMalloc((void **)&d->set[i].binsSend, binBytes));
         VH_DIST_TRY(hipMalloc((void **)&d->set[i].binsRecv, binBytes));
         VH_DIST_TRY(hipMalloc((void **)&d->set[i].packet, pkBytes));
@@ -453,9 +462,13 @@ extern "C" int vh_dist_set_user_stream(vh_dist *d, void *stream, int32_t enable)
 
 static int dist_apply(vh_dist *d, int s)
 {
+#ifndef VH_DEBUG_DIST_NO_READY_WAIT          // (diagnostics builds: what the two event operations at a batch's boundary cost)
     VH_HIP(hipStreamWaitEvent(d->sTable, d->ready[s], 0));
+#endif
     d->shard->stream = d->sTable;
+#ifndef VH_DEBUG_DIST_NO_FIRST
     d->shard->multiFirstEvent = d->first[s];
+#endif
     const bool alone = d->cfg.world == 1;
     const int rc = vh_apply_frames_batch(d->shard, d->cfg.batch, alone ? d->set[s].binsSend : d->set[s].binsRecv, d->cfg.world, d->capacity, 0,
                                          VH_BIN_PER_BATCH, d->cfg.world, alone ? d->set[s].packet : d->set[s].packets, 0, 0);
@@ -483,6 +496,12 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     // count-3 are done, the last of which rode in the first launch of exchange count-2's frames)
     if (R == 1 && d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sGen, d->first[(s + 1) % vh_dist::kSets], 0));
     d->shard->stream = d->sGen;
+#ifdef VH_DEBUG_DIST_SKIP_GEN
+    // diagnostics build (tools/ab_variants.sh): from the 7th exchange on nothing is generated -- the frames re-apply what the
+    // buffer set holds -- so that the frame launches can be timed without a key generation beside them
+    if (d->count >= 6) rc = VH_OK;
+    else
+#endif
     if (d->cfg.packet_format == VH_PACKET_U16)
         rc = vh_generate_keys_depth_batch(d->shard, B, poses, reinterpret_cast<const uint16_t *const *>(d_frames), d->cfg.k_inv,
                                           (uint32_t)d->cfg.rank, R, set.binsSend, d->capacity, 0, VH_BIN_PER_BATCH, set.packet, 0);

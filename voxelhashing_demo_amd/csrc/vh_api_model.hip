@@ -410,6 +410,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
         c->pipelineOverflow = value;
         return VH_OK;
     }
+    if (std::strcmp(name, "gen_frames_per_launch") == 0 && value >= 1 && value <= kGenBatch) { c->genFramesPerLaunch = value; return VH_OK; }
     if (std::strcmp(name, "multi_walk_entries") == 0 && (value == 0 || value == kEntriesPerLaneShort || value == kEntriesPerLane)) { c->multiWalkEntries = value; return VH_OK; }
     if (std::strcmp(name, "pipeline_shards") == 0) {
         if (value < 0 || value > 2) return fail(VH_ERR_INVALID_ARGUMENT, "pipeline_shards: 0, 1 or 2");

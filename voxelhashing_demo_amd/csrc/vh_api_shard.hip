@@ -224,8 +224,8 @@ extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float 
     else
         prepare_bins_kernel<<<grid_for((size_t)num_shards * batch, 256), 256, 0, c->stream>>>(
             reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, batch, frame_stride);
-    for (int b0 = 0; b0 < batch; b0 += kGenBatch) {
-        const int n = std::min<int>(kGenBatch, batch - b0);
+    for (int b0 = 0; b0 < batch; b0 += c->genFramesPerLaunch) {
+        const int n = std::min<int>(c->genFramesPerLaunch, batch - b0);
         GenFrames fr;
         std::memset(&fr, 0, sizeof fr);
         for (int j = 0; j < n; ++j) {
@@ -297,8 +297,8 @@ extern "C" int vh_generate_keys_depth_batch(vh_context *c, int32_t batch, const 
     else
         prepare_bins_kernel<<<grid_for((size_t)num_shards * batch, 256), 256, 0, c->stream>>>(
             reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride, batch, frame_stride);
-    for (int b0 = 0; b0 < batch; b0 += kGenBatch) {
-        const int n = std::min<int>(kGenBatch, batch - b0);
+    for (int b0 = 0; b0 < batch; b0 += c->genFramesPerLaunch) {
+        const int n = std::min<int>(c->genFramesPerLaunch, batch - b0);
         GenSensorFrames fr;
         std::memset(&fr, 0, sizeof fr);
         std::memcpy(fr.k, k_inv, sizeof fr.k);

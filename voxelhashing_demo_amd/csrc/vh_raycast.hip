@@ -349,6 +349,9 @@ constexpr int kCoopSubs = VH_COOP_SUBS;        // slabs per lane and window of t
 #ifndef VH_COOP_PRIO
 #define VH_COOP_PRIO 1
 #endif
+#ifndef VH_COOP_PREFETCH
+#define VH_COOP_PREFETCH 0   // 1: the walked blocks' lines are requested one block ahead (below; measured: 31.8-32.2 us against 31.1-31.2 without)
+#endif
 #ifndef VH_COOP_RESOLVE
 #define VH_COOP_RESOLVE 1    // 1: the set's cells are looked up eight lanes per bucket (0: one lane per cell, slot after slot)
 #endif
@@ -505,6 +508,10 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
     unsigned long long stampP1 = 0ull;                        // diagnostics: the ray set-up is done
     unsigned long long stampA = stamp0, stampB = stamp0;      // diagnostics: the set is built / the list is resolved
     int coopList = 0, coopWalks = 0;
+#ifdef VH_RAYCAST_DIAG
+    unsigned long long diagEntry = 0ull, diagWalk = 0ull;     // diagnostics build: time in the entry tests / in the voxel loops, and the loops' rounds
+    int diagRounds = 0;
+#endif
     if (ra.beam == 2) {
         __shared__ CoopShared sh_;
         uint32_t *tags = sh_.tag[wave], *ptrs = sh_.ptr[wave];
@@ -535,6 +542,8 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
         bool fail = false;
         float bestT = __builtin_inff();                            // arrival event of the best candidate's hit voxel
         int bestP = 3;
+        int recW = -1;                                             // where the best candidate's pair sits (-1: none yet)
+        float recPs = 0.0f, recSdf = 0.0f;                         // its two samples
         int nList = 0;
         bool final_ = !inImage;
         __builtin_amdgcn_wave_barrier();
@@ -740,12 +749,35 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
             // its OWN blocks, one per round -- the busiest ray of a wave enters as many blocks as the wave walks, 2.1 vs 2.2
             // rounds, and the per-lane block pointer made it 44.7 us against 40.2)
             {
+#if VH_COOP_PREFETCH
+                // The voxel loop below is a chain of dependent gathers, and a block's lines are met for the first time by its
+                // first rounds (the pool is far larger than an L2; diagnostics build: ~690 cycles per round for 55 instructions).
+                // So every lane touches one 64-byte piece of the NEXT block of the list -- the block's whole 4 KiB, one request per
+                // lane -- while this block's entry arithmetic and walk run; the value is never used, only waited for a block later.
+                uint32_t pf = 0u;
+                if (listBegin < nList) {
+                    const int s0_ = __builtin_amdgcn_readfirstlane((int)(list[listBegin] & 0xffffu));
+                    const int p0_ = __builtin_amdgcn_readfirstlane((int)ptrs[s0_]);
+                    pf = reinterpret_cast<const uint32_t *>(dp.blocks + (size_t)p0_)[lane * 16];
+                }
+#endif
                 for (int i = listBegin; i < nList; ++i) {
                     if (__ballot(!final_) == 0ull) break;
+#if VH_COOP_PREFETCH
+                    asm volatile("" ::"v"(pf));
+                    if (i + 1 < nList) {
+                        const int sN = __builtin_amdgcn_readfirstlane((int)(list[i + 1] & 0xffffu));
+                        const int pN = __builtin_amdgcn_readfirstlane((int)ptrs[sN]);
+                        pf = reinterpret_cast<const uint32_t *>(dp.blocks + (size_t)pN)[lane * 16];
+                    }
+#endif
                     const int slot = __builtin_amdgcn_readfirstlane((int)(list[i] & 0xffffu));
                     const uint32_t tg = (uint32_t)__builtin_amdgcn_readfirstlane((int)tags[slot]) - 1u;
                     const int bptr = __builtin_amdgcn_readfirstlane((int)ptrs[slot]);
                     const int kk[3] = {base0 + (int)(tg & 1023u), base1 + (int)((tg >> 10) & 1023u), base2 + (int)(tg >> 20)};
+#ifdef VH_RAYCAST_DIAG
+                    const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
+#endif
                     const CoopEntry e = coop_entry(ax, c, kk, ra.tMax);
                     const float tE = e.tE;
                     const int pE = e.pE, xe = e.xe;
@@ -794,13 +826,23 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                     int pArr = pE;
                     bool pv = false, firstVoxel = !inside, walking = true;
                     float ps = 0.0f;
-                    int prevLin = -1, p0 = 0, p1 = 0, p2 = 0;     // the previous sample: a voxel of this block (prevLin) or the neighbour (p0..2)
+                    int prevLin = -1;                             // the previous sample: a voxel of this block, or (-1) the neighbour behind the entry face
 #if VH_COOP_LDS
                     const Voxel *blk = sh_.block[wave];
 #else
                     const Voxel *blk = dp.blocks + (size_t)bptr;
 #endif
+#ifdef VH_RAYCAST_DIAG
+                    const unsigned long long dg1 = __builtin_amdgcn_s_memrealtime();
+                    diagEntry += dg1 - dg0;
+#endif
+#ifdef VH_RAYCAST_DIAG
+                    while (__ballot(walking) != 0ull) {
+                        ++diagRounds;
+                        if (!walking) continue;
+#else
                     while (walking) {
+#endif
                         int pls[kCoopK], vp[kCoopK];
                         float vt[kCoopK];
                         Voxel vv[kCoopK];
@@ -831,8 +873,8 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                                 const bool valid = vv[j].weight > 0.0f;
                                 const int lin = (int)((uint32_t)pls[j] >> 16);
                                 if (valid && vv[j].sdf <= 0.0f) {
-                                    const int vx = bx0 + (lin & 7), vy = by0 + ((lin >> 3) & 7), vz = bz0 + (lin >> 6);
                                     if (firstVoxel) {
+                                        const int vx = bx0 + (lin & 7), vy = by0 + ((lin >> 3) & 7), vz = bz0 + (lin >> 6);
                                         // the voxel the ray was in before the entry event: one step back on the entry axis, in the
                                         // neighbouring block -- allocated iff it is in the wave's set
                                         const int n0 = vx - (xe == 0 ? ax[0].s : 0), n1 = vy - (xe == 1 ? ax[1].s : 0), n2 = vz - (xe == 2 ? ax[2].s : 0);
@@ -842,20 +884,19 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                                             const uint32_t np = ptrs[fs];
                                             if (np != (uint32_t)VH_FREE_BLOCK && np != kCoopUnresolved) {
                                                 const Voxel nb = dp.blocks[(size_t)np + (size_t)(((n2 & 7) << 6) | ((n1 & 7) << 3) | (n0 & 7))];
-                                                pv = nb.weight > 0.0f; ps = nb.sdf; p0 = n0; p1 = n1; p2 = n2; prevLin = -1;
+                                                pv = nb.weight > 0.0f; ps = nb.sdf; prevLin = -1;
                                             }
                                         }
                                     }
                                     if (pv && ps > 0.0f) {
                                         if (dda_before(vt[j], vp[j], bestT, bestP)) {
+                                            // Only WHERE the pair sits is kept here (the set's slot, the voxel, the previous sample, the entry
+                                            // axis) with its two values; the depth is worked out once, behind the last block (below).  On a
+                                            // grazing patch some ray finds its pair at nearly every step of the wave, and the dot products and
+                                            // the division under this branch then doubled the step's instructions.
                                             bestT = vt[j]; bestP = vp[j];
-                                            if (prevLin >= 0) { p0 = bx0 + (prevLin & 7); p1 = by0 + ((prevLin >> 3) & 7); p2 = bz0 + (prevLin >> 6); }
-                                            // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
-                                            const float tc = ((ra.zrow[0] * (float)vx + ra.zrow[1] * (float)vy) + ra.zrow[2] * (float)vz) + ra.zrow[3];
-                                            const float tp = ((ra.zrow[0] * (float)p0 + ra.zrow[1] * (float)p1) + ra.zrow[2] * (float)p2) + ra.zrow[3];
-                                            hit = tp + ((tc - tp) * ps) / (ps - vv[j].sdf);
-                                            found = true;
-                                            hx = vx; hy = vy; hz = vz; hptr = bptr;
+                                            recPs = ps; recSdf = vv[j].sdf;
+                                            recW = slot | (lin << 8) | ((prevLin & 1023) << 17) | (xe << 27);
                                         }
                                         walking = false;                   // (the block's first pair: nothing earlier behind it)
                                         n = j;                             // (stops the judging)
@@ -866,13 +907,35 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                             }
                         }
                     }
+#ifdef VH_RAYCAST_DIAG
+                    diagWalk += __builtin_amdgcn_s_memrealtime() - dg1;
+#endif
                 }
             }
             // a candidate that arrived before this window's end cannot be beaten by a block found later
             final_ = final_ || bestT < tw + window;
             if (__ballot(!final_) == 0ull) break;
         }
-        if (!fail) { coopDone = true; live = false; }
+        if (!fail) {
+            coopDone = true; live = false;
+            if (recW != -1) {
+                // the best candidate: its voxel and the previous sample's, from the set's slot
+                const int slot = recW & 255, lin = (recW >> 8) & 511, pl = (recW >> 17) & 1023, xe = (recW >> 27) & 3;
+                const uint32_t tg = tags[slot] - 1u;
+                const int b0 = (base0 + (int)(tg & 1023u)) << 3, b1 = (base1 + (int)((tg >> 10) & 1023u)) << 3, b2 = (base2 + (int)(tg >> 20)) << 3;
+                const int vx = b0 + (lin & 7), vy = b1 + ((lin >> 3) & 7), vz = b2 + (lin >> 6);
+                const bool nb = pl == 1023;            // the voxel the ray was in before the block's entry event
+                const int p0 = nb ? vx - (xe == 0 ? ax[0].s : 0) : b0 + (pl & 7);
+                const int p1 = nb ? vy - (xe == 1 ? ax[1].s : 0) : b1 + ((pl >> 3) & 7);
+                const int p2 = nb ? vz - (xe == 2 ? ax[2].s : 0) : b2 + (pl >> 6);
+                // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
+                const float tc = ((ra.zrow[0] * (float)vx + ra.zrow[1] * (float)vy) + ra.zrow[2] * (float)vz) + ra.zrow[3];
+                const float tp = ((ra.zrow[0] * (float)p0 + ra.zrow[1] * (float)p1) + ra.zrow[2] * (float)p2) + ra.zrow[3];
+                hit = tp + ((tc - tp) * recPs) / (recPs - recSdf);
+                found = true;
+                hx = vx; hy = vy; hz = vz; hptr = (int)ptrs[slot];
+            }
+        }
     }
     // ---- beam front end: the depth before which no ray of this wave can meet an allocated block ----
     if (ra.beam && !coopDone) {
@@ -1093,6 +1156,10 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
         ra.stamps[w] = stamp0; ra.stamps[w + 1] = __builtin_amdgcn_s_memrealtime();
         ra.stamps[w + 2] = coopDone ? (stampP1 - stamp0) : (unsigned long long)(ra.budget - budget) | ((unsigned long long)round << 32); ra.stamps[w + 3] = (unsigned long long)(pu | (pv << 16)) | ((stamp1 - stamp0) << 32);
         ra.stamps[w + 4] = stampA - stamp0; ra.stamps[w + 5] = stampB - stamp0; ra.stamps[w + 6] = (unsigned long long)coopList; ra.stamps[w + 7] = (unsigned long long)coopWalks;
+#ifdef VH_RAYCAST_DIAG
+        ra.stamps[w + 6] |= (unsigned long long)diagRounds << 32;
+        ra.stamps[w + 4] |= diagEntry << 32; ra.stamps[w + 5] |= diagWalk << 32;
+#endif
     }
     if (!inImage) return;
     depthOut[(size_t)v * fp.width + u] = hit;
