@@ -759,6 +759,12 @@ def init_dist(dist, torch, local_rank):
     # code path on a one-GPU box -- RCCL refuses two ranks on one device; device buffers are then staged
     # through the host by the transport.  The driver's runs use the default: nccl = RCCL.
     backend = os.environ.get("VH_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and os.environ.get("VH_BENCH_SHARE_GPU") == "1":
+        # the same rig on RCCL itself: RCCL only refuses two ranks of one HOST on one device, so every rank calls itself a
+        # host of its own and the ranks meet over RCCL's socket transport on the loop-back interface -- a functional run of
+        # the N > 1 path (tests/test_gpu_dist_rccl.py), never a measurement
+        os.environ.setdefault("NCCL_HOSTID", f"voxelhash-bench-host-{os.environ['RANK']}")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
     if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
                                 timeout=datetime.timedelta(seconds=300))

@@ -93,3 +93,20 @@ def test_sharded_line_names_its_transport(torch_cuda):
     assert p.returncode == 0, p.stderr[-3000:]
     rec = _line(p.stdout)
     assert rec["exchange_ranks"] == {"transport": "rccl", "ranks": 1}
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_gpus_n_on_rccl_itself_with_every_rank_a_host_of_its_own(torch_cuda, ranks):
+    """`python bench.py --gpus N` as the driver types it, on the DEFAULT backend (nccl = RCCL) and the native host
+    (vh_dist_step_batch): RCCL only refuses two ranks of one host on one device, so with VH_BENCH_SHARE_GPU=1 every rank
+    names a host of its own (NCCL_HOSTID) and the N ranks of this one-GPU box meet over RCCL's socket transport.  The line
+    must say that RCCL carried the exchange between N ranks; its rate means nothing (shared GPU, sockets)."""
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VH_BENCH_BACKEND")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--legs", "none"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(base, VH_BENCH_SHARE_GPU="1"))
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-5000:])
+    rec = _line(p.stdout)
+    _check(rec, ranks, 3, 1)
+    assert rec["exchange_ranks"] == {"transport": "rccl", "ranks": ranks, "shared_gpu": True}
+    assert "vh_dist_step_batch" in rec["exchange_host"]
+    assert rec["config"]["key_bin_overflows"] == 0 and rec["config"]["occupied_blocks_all_ranks"] > 0

@@ -21,6 +21,7 @@ loop-back that plays all ranks in one process).  torch is transport and buffer o
 from __future__ import annotations
 
 import math
+import os
 import time
 
 import numpy as np
@@ -1050,7 +1051,8 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             vs_baseline=None, dtype="f32", data="synthetic",
             windows=len(windows), timed_s=round(sum(windows), 4),
             host_enqueue_ms_per_step=round(1e3 * statistics.median(host_enqueue) / args.steps, 5),
-            exchange_ranks=dict(transport=nd.transport, ranks=comm_ranks) if native else dict(transport="torch.distributed " + dist.get_backend(), ranks=dist.get_world_size()),
+            exchange_ranks=dict(dict(transport=nd.transport, ranks=comm_ranks) if native else dict(transport="torch.distributed " + dist.get_backend(), ranks=dist.get_world_size()),
+                                **({"shared_gpu": True} if os.environ.get("VH_BENCH_SHARE_GPU") == "1" and world > 1 else {})),
             exchange_host="libvoxelhash_hip.so: vh_dist_step_batch on RCCL directly (include/voxelhash_dist.h)" if native
             else "Python: dist.ShardedPipeline over torch.distributed collectives (--python-exchange / --no-pipeline)"
                  + (f"; the native exchange was not available: {native_error}" if native_error else ""),
