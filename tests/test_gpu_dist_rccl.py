@@ -7,15 +7,20 @@ calls a node with R GPUs would make.  (The loop-back transport of tests/test_gpu
 with hipMemcpyAsync in their place and can afford C4 / C5 at size; this file is about the RCCL calls.)  Every rank checks
 its shard against its bucket slice of ONE oracle table and its raycast against the oracle's."""
 import os
+import re
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from test_sharding_cpu import _free_port
+from voxelhashing_demo_amd import dist as vdist
+from voxelhashing_demo_amd import synth
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 
 
 def rank_env(rank):
@@ -64,3 +69,60 @@ def test_rccl_c4_at_size(torch_cuda):
 def test_rccl_eight_ranks(torch_cuda):
     """Eight ranks (C5's split) at a small image size: seven peers per grouped send / receive, an 8-way all-gather."""
     run_ranks(8, 1, True, "buckets=16", "blocks=12", "exchanges=4", timeout=900)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cpp_rank_processes_over_rccl(oracle, vh, torch_cuda, tmp_path, world):
+    """tests/cpp/sharded_ranks_demo.cpp: one C++ process per rank (no Python, no torch in them), the communicator's id
+    handed over in a file, SDF_Hashtable's multi-GPU constructor on RCCL: every shard equals its slice of ONE oracle table,
+    every rank's raycast through all shards (vh_dist_raycast_auto inside the facade) equals the oracle's."""
+    W, H = 320, 240
+    kw = dict(numBuckets=1 << 14, numVoxelBlocks=1 << 13)
+    lib = os.path.join(ROOT, "voxelhashing_demo_amd", "lib")
+    exe = tmp_path / "sharded_ranks_demo"
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "sharded_ranks_demo.cpp"), "-o", str(exe),
+                    "-L", lib, "-lsdf_hashtable", "-lvoxelhash_hip", f"-Wl,-rpath,{lib}"], check=True)
+    batch, steps = 2, 3
+    n = batch * steps
+    prims = synth.room_primitives()
+    kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+    cam_poses = [synth.camera_loop(60, phase=vdist.camera_phase(r, world))[:3 * n:3] for r in range(world)]
+    d16 = [[np.round(synth.render_room_verts(p, W, H, prims).numpy()[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for p in cam_poses[r]]
+           for r in range(world)]
+    np.asarray(cam_poses, np.float32).tofile(tmp_path / "poses.bin")
+    np.stack([np.stack(d) for d in d16]).tofile(tmp_path / "depth.bin")
+    kinv.tofile(tmp_path / "kinv.bin")
+    # (the programs take their HIP runtime and RCCL from the files this test session has already mapped -- torch's copies)
+    import torch
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    procs = []
+    for r in range(world):
+        env = dict(rank_env(r), LD_LIBRARY_PATH=tlib + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+        procs.append(subprocess.Popen([str(exe), str(r), str(world), str(tmp_path / "comm.id"), str(tmp_path / "poses.bin"), str(tmp_path / "depth.bin"),
+                                       str(tmp_path / "kinv.bin"), str(W), str(H), str(batch), str(steps), str(kw["numBuckets"]), str(kw["numVoxelBlocks"]),
+                                       str(tmp_path) + "/"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    got = []
+    try:
+        for r, p in enumerate(procs):
+            out, err = p.communicate(timeout=600)
+            assert p.returncode == 0, f"rank {r} exit {p.returncode}\n{out[-1000:]}\n{err[-4000:]}"
+            got.append(dict((k, int(v)) for k, v in re.findall(r"(\w+)=(\d+)", out)))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    ot = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    for j in range(n):
+        vdist.reference_multi_camera_frame(ot, [cam_poses[r][j] for r in range(world)],
+                                           [oracle.preprocess(d16[r][j], kinv)[0] for r in range(world)])
+    otab = ot.hash_table()
+    assert sum(g["allocated"] for g in got) == int((otab["ptr"] != -1).sum()) > 100 and all(g["bin_overflow"] == 0 and g["epoch"] == n for g in got)
+    plan = vdist.ShardPlan(kw["numBuckets"], world)
+    for r in range(world):
+        lo, hi = plan.bucket_range(r)
+        tab = np.fromfile(tmp_path / f"table{r}.bin", dtype=vh.ENTRY_DTYPE)
+        assert np.array_equal(tab["pos"], otab["pos"][lo * 5:hi * 5]) and np.array_equal(tab["ptr"] != -1, otab["ptr"][lo * 5:hi * 5] != -1)
+        depth = np.fromfile(tmp_path / f"depth{r}.bin", dtype=np.float32).reshape(H, W)
+        assert np.array_equal(depth.view(np.uint32), ot.raycast(cam_poses[r][-1]).view(np.uint32)), r
+    ot.close()
