@@ -1,8 +1,8 @@
 """The multi-GPU host inside the library (include/voxelhash_dist.h: vh_dist_* on RCCL directly), with one rank on the GPU
 box: the pipelined exchange (generate -> ncclAllToAll + ncclAllGather -> apply, three streams) must leave the oracle's
 table, in both packet formats; vh_dist_raycast must render the oracle's image; and a plain C++ program drives it without
-Python or torch (tests/cpp/sharded_demo.cpp).  The N > 1 exchange logic is covered by the gloo tests
-(tests/test_sharding_cpu.py) and by the loop-back shards on one GPU (tests/test_gpu_sharding.py)."""
+Python or torch (tests/cpp/sharded_demo.cpp).  N > 1: tests/test_gpu_dist_loopback.py (the same host code, ranks of one
+process joined by the loop-back transport) and tests/test_gpu_dist_rccl.py (RCCL itself, one process per rank on the one GPU)."""
 import os
 import re
 import subprocess
