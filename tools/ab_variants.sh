@@ -18,7 +18,7 @@ elif [ "${1:-}" = run ]; then
   for lib in "$ALT"/v_*.so "$ROOT/voxelhashing_demo_amd/lib/libvoxelhash_hip.so"; do
     [ -f "$lib" ] || continue
     echo "== $(basename "$lib")"
-    VOXELHASH_LIB=$lib timeout 600 python3 "$@" 2>&1 | grep -v amdgpu.ids | tail -3
+    VOXELHASH_LIB=$lib timeout 600 python3 "$@" 2>&1 | grep -v amdgpu.ids | tail -8
   done
 else
   echo "usage: $0 build name flags ... | run script args"; exit 2
