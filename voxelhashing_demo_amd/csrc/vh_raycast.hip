@@ -336,16 +336,11 @@ __device__ __forceinline__ bool beam_slab_occupied(const FrameParams &fp, const 
 // is in the list.  Whenever the preconditions fail -- a box spans more than two blocks on an axis, the set
 // overflows, a block lies more than 511 blocks from the wave's first -- the wave falls back to the per-lane walk.
 #ifndef VH_COOP_K
-#define VH_COOP_K 1             // voxels fetched per round trip in the block walk (with 5 waves per SIMD: 1: 35.3 us, 2: 38.1; with 4: 38.9 / 40.6)
+#define VH_COOP_K 1             // voxels fetched per round trip in the block walk (with 5 waves per SIMD: 1: 35.3 us, 2: 38.1; with 4: 38.9 / 40.6;
+                                // round 4: 2 only for waves whose list has 3 / 4 / 5 / 6 blocks or more, the loop built twice: 34.9 / 35.1 / 34.8 / 34.7 us
+                                // against 30.4 -- 16 registers spilled instead of 2, whichever loop a wave runs)
 #endif
 constexpr int kCoopK = VH_COOP_K;
-#ifndef VH_COOP_K_LONG
-#define VH_COOP_K_LONG 2        // ... for a wave whose list has VH_COOP_LONG_LIST blocks or more
-#endif
-#ifndef VH_COOP_LONG_LIST
-#define VH_COOP_LONG_LIST 5
-#endif
-template <int N> struct CoopK { static constexpr int value = N; };
 #ifndef VH_COOP_SUBS
 #define VH_COOP_SUBS 4
 #endif
@@ -768,7 +763,6 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                     pf = reinterpret_cast<const uint32_t *>(dp.blocks + (size_t)p0_)[lane * 16];
                 }
 #endif
-                const bool longList = nList - listBegin >= VH_COOP_LONG_LIST;        // (wave-uniform)
                 for (int i = listBegin; i < nList; ++i) {
                     if (__ballot(!final_) == 0ull) break;
 #if VH_COOP_PREFETCH
@@ -844,11 +838,6 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                     const unsigned long long dg1 = __builtin_amdgcn_s_memrealtime();
                     diagEntry += dg1 - dg0;
 #endif
-                    // (K voxels fetched per round trip: 1 for most waves -- with five waves per SIMD the rounds of one wave hide behind
-                    // the others' -- and VH_COOP_K_LONG for the waves with long lists, which run their last blocks alone on their SIMD
-                    // and wait ~470 of a round's ~690 cycles for its gather)
-                    auto walkLoop = [&](auto kc) {
-                    constexpr int K = decltype(kc)::value;
 #ifdef VH_RAYCAST_DIAG
                     while (__ballot(walking) != 0ull) {
                         ++diagRounds;
@@ -856,13 +845,13 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
 #else
                     while (walking) {
 #endif
-                        int pls[K], vp[K];
-                        float vt[K];
-                        Voxel vv[K];
+                        int pls[kCoopK], vp[kCoopK];
+                        float vt[kCoopK];
+                        Voxel vv[kCoopK];
                         int n = 0;
                         bool more = true;
 #pragma unroll
-                        for (int j = 0; j < K; ++j) {
+                        for (int j = 0; j < kCoopK; ++j) {
                             if (more) {
                                 pls[j] = pl; vt[j] = tArr; vp[j] = pArr;
                                 vv[j] = blk[(uint32_t)pl >> 16];
@@ -881,7 +870,7 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                         }
                         walking = more;
 #pragma unroll
-                        for (int j = 0; j < K; ++j) {
+                        for (int j = 0; j < kCoopK; ++j) {
                             if (j < n) {
                                 const bool valid = vv[j].weight > 0.0f;
                                 const int lin = (int)((uint32_t)pls[j] >> 16);
@@ -920,9 +909,6 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                             }
                         }
                     }
-                    };
-                    if (VH_COOP_K_LONG != kCoopK && longList) walkLoop(CoopK<VH_COOP_K_LONG>{});
-                    else walkLoop(CoopK<kCoopK>{});
 #ifdef VH_RAYCAST_DIAG
                     diagWalk += __builtin_amdgcn_s_memrealtime() - dg1;
 #endif
