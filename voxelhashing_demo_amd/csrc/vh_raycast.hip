@@ -773,6 +773,8 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                         pf = reinterpret_cast<const uint32_t *>(dp.blocks + (size_t)pN)[lane * 16];
                     }
 #endif
+                    // (measured in round 4: {tag, pointer} kept in walking order beside the list, one LDS round trip here instead of three
+                    // dependent ones: 31.5 against 31.0 us -- 5 registers spilled instead of 2)
                     const int slot = __builtin_amdgcn_readfirstlane((int)(list[i] & 0xffffu));
                     const uint32_t tg = (uint32_t)__builtin_amdgcn_readfirstlane((int)tags[slot]) - 1u;
                     const int bptr = __builtin_amdgcn_readfirstlane((int)ptrs[slot]);
