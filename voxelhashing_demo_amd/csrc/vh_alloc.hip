@@ -81,6 +81,11 @@ struct Pending {
 };
 __device__ constexpr Pending kNoPending{nullptr, nullptr, 0u, false, -1};
 
+// kEagerSlot: the bucket's first slot is requested together with the pending frame's claim word -- two independent addresses,
+// one round trip instead of two; what it returns is not looked at when that slot is the one being written.  It pays where the
+// probes answer from HBM or the claim tiles are long (same box, launch us without / with: C3 68.3 / 67.6, C5table 278.5 / 275.5,
+// C2 with the band 22.75 / 22.2) and costs the cache-resident reference frame a little (C2 17.68 / 17.78): the callers choose.
+template <bool kEagerSlot = false>
 __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz,
                                                 uint32_t h, uint32_t rank, int candCounter = kCandCount,
                                                 const Pending &pend = kNoPending)
@@ -91,6 +96,8 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
     }
     const uint32_t local = h - fp.bucketLo;
     const VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
+    VoxelEntry e0{};
+    if (kEagerSlot) e0 = bucket[0];
     // the insertion in flight into this bucket, if any: it takes the bucket's first free slot (pf)
     uint32_t pf = ~0u;
     int4 pk = make_int4(0, 0, 0, 0);
@@ -107,7 +114,7 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
             if (pk.x == kx && pk.y == ky && pk.z == kz) return;
             continue;
         }
-        const VoxelEntry e = bucket[i];
+        const VoxelEntry e = (kEagerSlot && i == 0u) ? e0 : bucket[i];
         if (e.ptr == VH_FREE_BLOCK) {
             firstFree = i;
             break;                       // prefix property: nothing allocated behind a free slot
@@ -443,7 +450,9 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
         if (!p.valid || dupLeft || dupUp || !block_in_frustum(fp, s.kx, s.ky, s.kz)) return;
         const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
         if (h < fp.bucketLo || h >= fp.bucketHi) return;                // not this shard's bucket
-        probe_and_claim(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, 0), candCounter, pend);
+        // (a table beyond the Infinity Cache -- the walk's loads are non-temporal then -- answers the probes from HBM)
+        if (fp.flags & kFlagWalkNt) probe_and_claim<true>(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, 0), candCounter, pend);
+        else probe_and_claim<false>(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, 0), candCounter, pend);
         return;
     }
     BandWalk walk;
@@ -475,7 +484,7 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
                 // the frustum test (:673) of the queued keys, one per lane: in the sample loop it ran for the one or two
                 // leaders of a wave at a time
                 if (block_in_frustum(fp, kx, ky, kz))
-                    probe_and_claim(fp, dp, kx, ky, kz, hash_block(kx, ky, kz, fp.numBuckets), rank, candCounter, pend);
+                    probe_and_claim<true>(fp, dp, kx, ky, kz, hash_block(kx, ky, kz, fp.numBuckets), rank, candCounter, pend);
             }
         }
     };
