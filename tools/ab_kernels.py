@@ -41,6 +41,9 @@ def main():
                        Wd, Ht, V.SEM_PINHOLE, stream=stream)
     if wl.get("band"):
         t.set_alloc_band(wl["band"])
+    for kv in wl.get("options", []):            # (the workload's own options: C2band's band_mode ...)
+        k, v = kv.split("=")
+        t.set_option(k, int(v))
     for kv in a.preset:
         k, v = kv.split("=")
         t.set_option(k, int(v))
