@@ -40,6 +40,25 @@ def torch_cuda():
     return torch
 
 
+@pytest.fixture(scope="session")
+def rccl_rig(torch_cuda):
+    """The rig of tests/test_gpu_dist_rccl.py -- R rank processes on ONE GPU, each a host of its own to RCCL (NCCL_HOSTID), meeting
+    over RCCL's socket transport on the loop-back interface -- checked once with torch's own collectives
+    (tools/micro/rccl_one_gpu_probe.py).  Where the rig itself cannot run (no loop-back sockets for RCCL, an RCCL that compares
+    devices differently) the tests that need it are skipped with that reason; where it runs, a failure in them is the library's."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "micro", "rccl_one_gpu_probe.py")], env=env,
+                           capture_output=True, text=True, timeout=400)
+        ok, why = p.returncode == 0 and "all_reduce -> 3.0" in p.stdout, (p.stdout + p.stderr)[-800:]
+    except subprocess.TimeoutExpired:
+        ok, why = False, "the probe timed out"
+    if not ok:
+        pytest.skip("RCCL cannot run two ranks on this box's one GPU even with a host id per rank: " + why)
+    return True
+
+
 def entries_as_set(entries):
     """{(x,y,z)} of a VoxelEntry array."""
     return set(map(tuple, np.asarray(entries["pos"]).reshape(-1, 3).tolist()))

@@ -96,7 +96,7 @@ def test_sharded_line_names_its_transport(torch_cuda):
 
 
 @pytest.mark.parametrize("ranks", [2, 4])
-def test_gpus_n_on_rccl_itself_with_every_rank_a_host_of_its_own(torch_cuda, ranks):
+def test_gpus_n_on_rccl_itself_with_every_rank_a_host_of_its_own(rccl_rig, ranks):
     """`python bench.py --gpus N` as the driver types it, on the DEFAULT backend (nccl = RCCL) and the native host
     (vh_dist_step_batch): RCCL only refuses two ranks of one host on one device, so with VH_BENCH_SHARE_GPU=1 every rank
     names a host of its own (NCCL_HOSTID) and the N ranks of this one-GPU box meet over RCCL's socket transport.  The line

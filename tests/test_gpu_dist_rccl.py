@@ -52,27 +52,27 @@ def run_ranks(world, batch, sensor, *extra, timeout=600):
 
 
 @pytest.mark.parametrize("world,batch,sensor", [(2, 2, True), (2, 1, False), (4, 2, True)])
-def test_rccl_ranks_equal_one_oracle_table(torch_cuda, world, batch, sensor):
+def test_rccl_ranks_equal_one_oracle_table(rccl_rig, world, batch, sensor):
     run_ranks(world, batch, sensor)
 
 
-def test_rccl_raycast_round_that_agrees_on_its_capacity(torch_cuda):
+def test_rccl_raycast_round_that_agrees_on_its_capacity(rccl_rig):
     """vh_dist_raycast_auto: the lost counts travel by ncclAllGather, every rank repeats the round with the same capacity."""
     run_ranks(2, 2, True, "raycast_auto")
 
 
-def test_rccl_c4_at_size(torch_cuda):
+def test_rccl_c4_at_size(rccl_rig):
     """C4 (BASELINE.json configs): four 640x480 cameras, 2^20 buckets over four ranks, sensor-depth packets, batches of 2."""
     run_ranks(4, 2, True, "size=640x480", "buckets=20", "blocks=15", "exchanges=3", timeout=900)
 
 
-def test_rccl_eight_ranks(torch_cuda):
+def test_rccl_eight_ranks(rccl_rig):
     """Eight ranks (C5's split) at a small image size: seven peers per grouped send / receive, an 8-way all-gather."""
     run_ranks(8, 1, True, "buckets=16", "blocks=12", "exchanges=4", timeout=900)
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_cpp_rank_processes_over_rccl(oracle, vh, torch_cuda, tmp_path, world):
+def test_cpp_rank_processes_over_rccl(oracle, vh, rccl_rig, tmp_path, world):
     """tests/cpp/sharded_ranks_demo.cpp: one C++ process per rank (no Python, no torch in them), the communicator's id
     handed over in a file, SDF_Hashtable's multi-GPU constructor on RCCL: every shard equals its slice of ONE oracle table,
     every rank's raycast through all shards (vh_dist_raycast_auto inside the facade) equals the oracle's."""

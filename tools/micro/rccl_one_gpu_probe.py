@@ -6,11 +6,11 @@ import subprocess
 import sys
 
 if len(sys.argv) > 1:
-    rank, world = int(sys.argv[1]), int(sys.argv[2])
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=rank, world_size=world, init_method="tcp://127.0.0.1:29617")
+    dist.init_process_group("nccl", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
     x = torch.full((1024,), float(rank + 1), device="cuda")
     dist.all_reduce(x)
     a = torch.arange(world * 4, dtype=torch.int32, device="cuda") + 100 * rank
@@ -22,11 +22,15 @@ if len(sys.argv) > 1:
     sys.exit(0)
 
 world = 2
+import socket
+with socket.socket() as sk:
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
 procs = []
 for r in range(world):
     env = dict(os.environ, NCCL_HOSTID=f"probe-host-{r}", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1", NCCL_DEBUG="WARN",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs.append(subprocess.Popen([sys.executable, __file__, str(r), str(world)], env=env))
+    procs.append(subprocess.Popen([sys.executable, __file__, str(r), str(world), str(port)], env=env))
 rc = 0
 for p in procs:
     try:
