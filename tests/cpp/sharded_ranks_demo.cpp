@@ -57,7 +57,7 @@ int main(int argc, char **argv)
     float *d_out = nullptr;
     if (hipMalloc((void **)&d_depth, depth.size() * sizeof(uint16_t)) != hipSuccess) return 4;
     if (hipMalloc((void **)&d_out, npix * sizeof(float)) != hipSuccess) return 4;
-    hipMemcpy(d_depth, depth.data(), depth.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (hipMemcpy(d_depth, depth.data(), depth.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess) return 4;
 
     HashTableParams p;
     vh_default_params(&p);
@@ -86,12 +86,12 @@ int main(int argc, char **argv)
     table.raycast(view, d_out);                          // this rank's view through every shard (collective)
     table.flush();
     std::vector<float> out(npix);
-    hipMemcpy(out.data(), d_out, npix * sizeof(float), hipMemcpyDeviceToHost);
+    if (hipMemcpy(out.data(), d_out, npix * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 4;
     f = std::fopen((prefix + "depth" + std::to_string(rank) + ".bin").c_str(), "wb");
     if (!f || std::fwrite(out.data(), sizeof(float), npix, f) != npix) return 6;
     std::fclose(f);
     std::printf("rank=%d allocated=%d occupied=%d epoch=%u bin_overflow=%u\n", rank, allocated, c.occupied, c.epoch, c.bin_overflow);
-    hipFree(d_depth);
-    hipFree(d_out);
+    (void)hipFree(d_depth);
+    (void)hipFree(d_out);
     return 0;
 }

@@ -108,3 +108,18 @@ def test_headers_compile_as_c99_and_cxx11(tmp_path):
     cpp.write_text('#include "voxelhash.h"\n#include "SDF_Hashtable.h"\n#include "CameraTracking.h"\nint main() { return 0; }\n')
     subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(cpp)],
                    check=True)
+
+
+def test_cpp_hosts_compile_against_the_headers():
+    """The C++ programs the GPU tests build and run (tests/cpp/: one rank, threads over the loop-back transport, one process
+    per rank over RCCL) still match include/SDF_Hashtable.h and include/voxelhash*.h -- checked here without a GPU."""
+    import glob
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc in this image")
+    srcs = sorted(glob.glob(os.path.join(ROOT, "tests", "cpp", "*.cpp")))
+    assert len(srcs) >= 3
+    for src in srcs:
+        subprocess.run([hipcc, "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), src], check=True,
+                       capture_output=True, timeout=300)
