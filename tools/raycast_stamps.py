@@ -15,6 +15,7 @@ t = V.SDFHashtable(V.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl[
 for p in poses:
     t.integrate(p, synth.render_room_verts(p, 640, 480, prims, device="cuda"))
 depth = torch.empty((480, 640), dtype=torch.float32, device="cuda")
+t.set_option("raycast_split", 0)          # (the one-launch cooperative form; the split form: tools/raycast_split_stamps.py)
 nw = 40 * 30 * 4
 st = torch.zeros((nw, 8), dtype=torch.int64, device="cuda")
 for i in range(5):

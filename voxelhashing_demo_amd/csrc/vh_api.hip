@@ -88,6 +88,10 @@ struct vh_context {
     int raycastBeam = 3;           // DDA: 2 = cooperative form (one block list per wave), 1 = per-lane walk behind the beam front end, 0 = per-lane walk,
                                    // 3 = by the view: cooperative when 64 half-block slabs span [t_min, t_max], else 1 (option "raycast_beam")
     int raycastMode = VH_RAYCAST_DDA;   // option "raycast_mode": voxel DDA (raycastSDF.frag:121-177) or the fixed-step march
+    int raycastSplit = 0;          // option "raycast_split": the cooperative form as three launches (list / walk one (patch, block) item per wave / resolve); measured slower, off
+    int raycastItemsGrid = 0;      // option "raycast_items_grid": workgroups of the item launch (0: by the image)
+    RaycastSplit rcSplit{};        // the split form's buffers, allocated at the first such raycast
+    uint32_t rcSplitPatches = 0;   // patches they were sized for
     int packetFormat = VH_PACKET_F32;   // what vh_integrate_packets / vh_apply_frames_batch read
     int fusedFrame = 1;            // vh_integrate as two launches (0: the four step kernels)
     int commitBlocks = 128;        // workgroups serving candidates in the fused second launch
@@ -299,6 +303,12 @@ static int free_buffers(vh_context *c)
     if (c->viewLists) (void)hipFree(c->viewLists);
     if (c->blockList) (void)hipFree(c->blockList);
     c->blockList = nullptr;
+    if (c->rcSplit.state) (void)hipFree(c->rcSplit.state);
+    if (c->rcSplit.best) (void)hipFree(c->rcSplit.best);
+    if (c->rcSplit.items) (void)hipFree(c->rcSplit.items);
+    if (c->rcSplit.counts) (void)hipFree(c->rcSplit.counts);
+    c->rcSplit = RaycastSplit{};
+    c->rcSplitPatches = 0;
     c->viewLists = nullptr;
     c->viewListsSize = 0;
     c->dp = DevPtrs{};

@@ -71,6 +71,39 @@ static int launch(vh_context *c, int phase, K kernel, dim3 grid, dim3 block, Arg
     return VH_OK;
 }
 
+// Several launches timed as ONE span (the split raycast): the start event rides on the first launch, the stop event on the
+// last, so the span includes the gaps between them -- what a caller of the entry point waits for.  pos: 0 first, 1 middle, 2 last.
+template <typename K, typename... Args>
+static int launch_span(vh_context *c, int phase, int pos, TimedLaunch &span, K kernel, dim3 grid, dim3 block, Args... args)
+{
+    if (!c->profiling) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, args...);
+        return VH_OK;
+    }
+    if (pos == 0) {
+        if (c->timed.size() >= kMaxTimedLaunches) {
+            const int rc = accumulate_times(c);
+            if (rc != VH_OK) return rc;
+        }
+        span = TimedLaunch{phase, nullptr, nullptr};
+        if (!c->eventPool.empty()) {
+            span.start = c->eventPool.back().first;
+            span.stop = c->eventPool.back().second;
+            c->eventPool.pop_back();
+        } else {
+            VH_HIP(hipEventCreate(&span.start));
+            const hipError_t e = hipEventCreate(&span.stop);
+            if (e != hipSuccess) {
+                (void)hipEventDestroy(span.start);
+                return fail(VH_ERR_HIP, "hipEventCreate", e);
+            }
+        }
+    }
+    hipExtLaunchKernelGGL(kernel, grid, block, 0, c->stream, pos == 0 ? span.start : nullptr, pos == 2 ? span.stop : nullptr, 0, args...);
+    if (pos == 2) c->timed.push_back(span);
+    return VH_OK;
+}
+
 template <class In>
 static int launch_alloc(vh_context *c, const In &in)
 {
@@ -569,6 +602,8 @@ static int raycast_impl(vh_context *c, const float pose[16], float t_min, float 
                           c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out, c->raycastXcd);
     } else {
         RaycastArgs ra;
+        ra.sp = RaycastSplit{};
+        ra.stampsItemBase = 0;
         ra.fx = c->rc_fx; ra.fy = c->rc_fy; ra.cx = c->rc_cx; ra.cy = c->rc_cy;
         ra.tMin = t_min; ra.tMax = t_max;
         float inv[16];
@@ -612,7 +647,52 @@ static int raycast_impl(vh_context *c, const float pose[16], float t_min, float 
         const dim3 block(64 * kDdaBlockWaves);
         if (kDdaBlockWaves == 1)
             grid = c->raycastPatch ? dim3((fp.width + 7) / 8, (fp.height + 7) / 8) : dim3((fp.width + 15) / 16, (fp.height + 3) / 4);
-        if (nrm)
+        // The split form (option "raycast_split", the default where the cooperative form runs): list / items / resolve.
+        const uint32_t nTiles = grid.x * grid.y, nPatches = nTiles * 4u;
+        const uint32_t segCap = 4u * ((nTiles + kRcShards - 1) / kRcShards);
+        const bool split = ra.beam == 2 && c->raycastSplit && kDdaBlockWaves == 4 &&
+                           (uint64_t)kRcSegs * segCap <= (1u << 21);
+        if (split) {
+            if (c->rcSplitPatches < nPatches) {          // first use (or a larger image): allocate, counters zero
+                VH_HIP(hipStreamSynchronize(c->stream));
+                if (c->rcSplit.state) (void)hipFree(c->rcSplit.state);
+                if (c->rcSplit.best) (void)hipFree(c->rcSplit.best);
+                if (c->rcSplit.items) (void)hipFree(c->rcSplit.items);
+                if (c->rcSplit.counts) (void)hipFree(c->rcSplit.counts);
+                c->rcSplit = RaycastSplit{};
+                c->rcSplitPatches = 0;
+                VH_HIP(hipMalloc((void **)&c->rcSplit.state, sizeof(float) * 9 * 64 * (size_t)nPatches));
+                VH_HIP(hipMalloc((void **)&c->rcSplit.best, sizeof(unsigned long long) * 64 * (size_t)nPatches));
+                VH_HIP(hipMalloc((void **)&c->rcSplit.items, sizeof(RcItem) * (size_t)kRcSegs * segCap));
+                VH_HIP(hipMalloc((void **)&c->rcSplit.counts, sizeof(uint32_t) * kRcSegs));
+                VH_HIP(hipMemsetAsync(c->rcSplit.counts, 0, sizeof(uint32_t) * kRcSegs, c->stream));
+                c->rcSplitPatches = nPatches;
+            }
+            ra.sp = c->rcSplit;
+            ra.sp.segCap = segCap;
+            ra.sp.patchesX = c->raycastPatch ? grid.x * 2u : grid.x;
+            // the item launch: a grid-stride loop over the items, so its size is a tuning parameter (any size is exact)
+            const uint32_t itemGrid = c->raycastItemsGrid > 0 ? (uint32_t)c->raycastItemsGrid : std::max<uint32_t>(nPatches * 3u / kItemWaves, 256u);
+            ra.stampsItemBase = nPatches;
+            TimedLaunch span{};
+            if (nrm)
+                rc = c->raycastPatch ? launch_span(c, kPhaseRaycast, 0, span, raycast_dda_kernel<1, true, true>, grid, block, fp, dp, ra, d_depth_out, nrm)
+                                     : launch_span(c, kPhaseRaycast, 0, span, raycast_dda_kernel<0, true, true>, grid, block, fp, dp, ra, d_depth_out, nrm);
+            else
+                rc = c->raycastPatch ? launch_span(c, kPhaseRaycast, 0, span, raycast_dda_kernel<1, false, true>, grid, block, fp, dp, ra, d_depth_out, nrm)
+                                     : launch_span(c, kPhaseRaycast, 0, span, raycast_dda_kernel<0, false, true>, grid, block, fp, dp, ra, d_depth_out, nrm);
+            if (rc == VH_OK)
+                rc = c->raycastPatch ? launch_span(c, kPhaseRaycast, 1, span, raycast_items_kernel<1>, dim3(itemGrid), dim3(64 * kItemWaves), fp, dp, ra)
+                                     : launch_span(c, kPhaseRaycast, 1, span, raycast_items_kernel<0>, dim3(itemGrid), dim3(64 * kItemWaves), fp, dp, ra);
+            if (rc == VH_OK) {
+                if (nrm)
+                    rc = c->raycastPatch ? launch_span(c, kPhaseRaycast, 2, span, raycast_resolve_kernel<1, true>, grid, block, fp, dp, ra, d_depth_out, nrm)
+                                         : launch_span(c, kPhaseRaycast, 2, span, raycast_resolve_kernel<0, true>, grid, block, fp, dp, ra, d_depth_out, nrm);
+                else
+                    rc = c->raycastPatch ? launch_span(c, kPhaseRaycast, 2, span, raycast_resolve_kernel<1, false>, grid, block, fp, dp, ra, d_depth_out, nrm)
+                                         : launch_span(c, kPhaseRaycast, 2, span, raycast_resolve_kernel<0, false>, grid, block, fp, dp, ra, d_depth_out, nrm);
+            }
+        } else if (nrm)
             rc = c->raycastPatch ? launch(c, kPhaseRaycast, raycast_dda_kernel<1, true>, grid, block, fp, dp, ra, d_depth_out, nrm)
                                  : launch(c, kPhaseRaycast, raycast_dda_kernel<0, true>, grid, block, fp, dp, ra, d_depth_out, nrm);
         else

@@ -453,6 +453,8 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (std::strcmp(name, "raycast_patch") == 0) { c->raycastPatch = value; return VH_OK; }
     if (std::strcmp(name, "raycast_xcd") == 0) { c->raycastXcd = value; return VH_OK; }
     if (std::strcmp(name, "raycast_beam") == 0 && value >= 0 && value <= 3) { c->raycastBeam = value; return VH_OK; }
+    if (std::strcmp(name, "raycast_split") == 0 && (value == 0 || value == 1)) { c->raycastSplit = value; return VH_OK; }
+    if (std::strcmp(name, "raycast_items_grid") == 0 && value >= 0) { c->raycastItemsGrid = value; return VH_OK; }
     if (std::strcmp(name, "raycast_mode") == 0 && (value == VH_RAYCAST_DDA || value == VH_RAYCAST_FIXED_STEP)) {
         c->raycastMode = value;
         return VH_OK;
@@ -493,7 +495,7 @@ static int accumulate_times(vh_context *c)
             case kPhaseCommit: c->times.alloc_commit_ms += ms; break;
             case kPhaseFlatten: c->times.flatten_ms += ms; break;
             case kPhaseIntegrate: c->times.integrate_ms += ms; break;
-            case kPhaseRaycast: c->times.raycast_ms += ms; c->times.raycast_launches += 1; break;
+            case kPhaseRaycast: c->times.raycast_ms += ms; c->times.raycast_launches += 1; break;     // (the split form: one pair around its three launches)
             case kPhaseFrameScanClaim: c->times.frame_scan_claim_ms += ms; break;
             case kPhaseFrameCommitIntegrate: c->times.frame_commit_integrate_ms += ms; break;
             case kPhaseViewExport: c->times.view_export_ms += ms; break;

@@ -208,6 +208,48 @@ __device__ __forceinline__ int dda_start(const DdaAxis &ax, int cur, float tau)
     return e;
 }
 
+// ---- the split form (option "raycast_split"): the cooperative raycast as three launches ----
+// The fused cooperative kernel below is as long as its heaviest wave: a silhouette or grazing patch lists 8-13 blocks and
+// walks them one after the other, ~3.5 us each, while the mean wave lists 2.7-4.2 (profiles/r04_raycast_stamps.txt).  The
+// split form keeps steps 1 and 2 (beam, resolve: uniform work) in a launch of their own, which PUBLISHES every patch's
+// listed blocks as items {block key, voxel pointer, patch}; a second launch walks one (patch, block) item per wave, whatever
+// patch it came from, and merges the candidates of a ray with ONE 64-bit atomicMin on the ray's word -- a candidate is
+// {arrival event of the hit voxel (t, axis priority), item, voxel}, the events of a ray are totally ordered, so the minimum
+// IS the hit the sequential walk finds first; a third launch turns the winning word into depth (+ normal) with the fused
+// kernel's arithmetic.  Queues: one per (list position, shard of 8 by workgroup index) so that no counter is hot -- a
+// workgroup takes one returning atomic per list position for its four patches -- and so that the items of list position 0
+// (the blocks nearest the camera) are walked first: by the time a patch's later blocks are taken, most of its rays already
+// hold a candidate that precedes the block's entry event and skip it, as in the fused kernel's front-to-back order.
+constexpr int kRcRanks = 32;                      // list positions with a queue of their own (a longer list: the per-lane walk)
+constexpr int kRcShards = 8;
+constexpr int kRcSegs = kRcRanks * kRcShards;     // 256: one uint4 of counts per lane in the item launch
+constexpr unsigned long long kRcNone = ~0ull;                    // a ray's word: no candidate
+constexpr uint32_t kRcDoneKey = 0xfffffffeu;                     // ... top half: the first launch has written the pixel itself (fall-back walk)
+struct RcItem {
+    int kx, ky, kz, ptr;          // block key, first voxel of the block
+    uint32_t patch;               // linear index of the 8x8 (16x4) pixel patch
+    uint32_t pad[3];
+};
+struct RaycastSplit {
+    float *state;                 // [patch][9][64]: E[3], invE[3] (0: the axis never steps), c[3] (int bits) of every ray
+    unsigned long long *best;     // [patch][64]: the ray's best candidate {ordered t : 32 | priority : 2 | item : 21 | voxel : 9}
+    RcItem *items;                // [kRcSegs][segCap]
+    uint32_t *counts;             // [kRcSegs]; zero between calls (the last launch clears them)
+    uint32_t segCap;              // >= the patches one shard can hold
+    uint32_t patchesX;            // patches per image row
+};
+
+// candidate word of a ray: events compare as (t, priority); t as a sign-ordered 32-bit key (-0 is written as +0)
+__device__ __forceinline__ uint32_t rc_time_key(float t)
+{
+    const uint32_t b = __float_as_uint(t + 0.0f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float rc_key_time(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
 struct RaycastArgs {
     float fx, fy, cx, cy;
     float tMin, tMax;
@@ -219,6 +261,8 @@ struct RaycastArgs {
     int beam;                 // 2: the cooperative form (one block list per wave); 1: per-lane walk behind a beam front end; 0: per-lane walk
                               // from t_min (A/B; views with t_min <= 0)
     unsigned long long *stamps;   // diagnostics (tools/raycast_stamps.py): per wave {start, end} of s_memrealtime (100 MHz), or null
+    uint32_t stampsItemBase;      // diagnostics: first 8-word record of the item launch's waves in `stamps` (behind the list launch's)
+    RaycastSplit sp;              // the split form's buffers (raycast_dda_kernel<.., kSplit>, raycast_items_kernel, raycast_resolve_kernel)
 };
 
 // voxel (vx,vy,vz) if its block is allocated and its weight > 0 (normals: the neighbours of the hit voxel)
@@ -232,6 +276,36 @@ __device__ __forceinline__ bool dda_voxel(const FrameParams &fp, const DevPtrs &
     const Voxel s = dp.blocks[(size_t)ptr + (size_t)(((vz & 7) << 6) | ((vy & 7) << 3) | (vx & 7))];
     sdf = s.sdf;
     return s.weight > 0.0f;
+}
+
+// normal of a hit: the TSDF gradient at the hit voxel (central difference where both neighbours are samples, else one-sided,
+// else no normal), normalised, rotated into the camera frame (R^T w), w = 0
+__device__ __forceinline__ float4 dda_normal(const FrameParams &fp, const DevPtrs &dp, int hx, int hy, int hz, int hptr)
+{
+    float4 n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int kx = hx >> 3, ky = hy >> 3, kz = hz >> 3;
+    float here = 0.0f, g[3] = {0.0f, 0.0f, 0.0f};
+    bool ok = dda_voxel(fp, dp, hx, hy, hz, kx, ky, kz, hptr, here);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float sp = 0.0f, sm = 0.0f;
+        const bool hp = dda_voxel(fp, dp, hx + (a == 0), hy + (a == 1), hz + (a == 2), kx, ky, kz, hptr, sp);
+        const bool hm = dda_voxel(fp, dp, hx - (a == 0), hy - (a == 1), hz - (a == 2), kx, ky, kz, hptr, sm);
+        if (hp && hm) g[a] = (sp - sm) * 0.5f;
+        else if (hp) g[a] = sp - here;
+        else if (hm) g[a] = here - sm;
+        else ok = false;
+    }
+    if (ok) {
+        const float len = __builtin_sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+        if (len > 0.0f) {
+            const float w0 = g[0] / len, w1 = g[1] / len, w2 = g[2] / len;
+            n.x = fp.T[0] * w0 + fp.T[4] * w1 + fp.T[8] * w2;          // R^T * w: world -> camera
+            n.y = fp.T[1] * w0 + fp.T[5] * w1 + fp.T[9] * w2;
+            n.z = fp.T[2] * w0 + fp.T[6] * w1 + fp.T[10] * w2;
+        }
+    }
+    return n;
 }
 
 // Beam front end.  The 64 rays of a wave (an 8x8 or 16x4 pixel patch) are nearly parallel and a few voxels apart,
@@ -369,6 +443,8 @@ struct CoopShared {
     uint32_t list[kDdaBlockWaves][kCoopSlots];     // allocated cells: slot | depth key << 16 (the list is walked front to back)
     uint16_t cells[kDdaBlockWaves][kCoopSlots];    // the set's occupied slots in order of insertion (what step 2 resolves)
     uint32_t count[kDdaBlockWaves];
+    uint32_t nItems[kDdaBlockWaves];               // split form: the patches' list lengths, and where each list position's items go
+    uint32_t segBase[kRcRanks];
 #if VH_COOP_LDS
     Voxel block[kDdaBlockWaves][kBlockVoxels];     // the block the wave is walking (4 KiB per wave)
 #endif
@@ -464,7 +540,7 @@ constexpr int kDdaK = VH_DDA_K;
                             // once the front end had been slimmed) all start at once: 40.6 -> 35.3 us.  6 (80 registers, 30-60 spilled): slower.
 #endif
 
-template <int kPatch, bool kNormals>
+template <int kPatch, bool kNormals, bool kSplit = false>
 __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda_kernel(const FrameParams fp, const DevPtrs dp, const RaycastArgs ra,
                                                           float *__restrict__ depthOut, float4 *__restrict__ normalOut)
 {
@@ -738,6 +814,7 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                 }
             }
             if (ra.stamps) { stampB = __builtin_amdgcn_s_memrealtime(); coopList = nList; }
+            if constexpr (kSplit) continue;             // (the walk is the item launch's; every window is listed)
 #if VH_COOP_PRIO
             // The launch is as long as its slowest wave, and the slowest waves are the ones with the longest lists: they get the
             // issue slots first (s_setprio; 35.6 -> 32.6 us; thresholds 6/4/3, 7/5/3 and 10/7/5 measured the same).
@@ -782,6 +859,22 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
 #ifdef VH_RAYCAST_DIAG
                     const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#if VH_COOP_LDS == 2
+                    // LDS-DMA of the block's 4 KiB (four global_load_lds_dwordx4, no registers), issued BEFORE the entry test: its
+                    // round trip runs under the ~0.8 us of entry arithmetic, and every step of the walk then reads at LDS latency
+                    // instead of waiting ~690 cycles for a gather.  One buffer per wave: the previous block's walk is over (the
+                    // lanes have met again), a DMA that was never waited for (no lane entered its block) is waited for here.
+                    {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        const char *src = reinterpret_cast<const char *>(dp.blocks + (size_t)bptr) + lane * 16;
+                        char *dst = reinterpret_cast<char *>(sh_.block[wave]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j * 1024),
+                                                             (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+                    }
+#endif
                     const CoopEntry e = coop_entry(ax, c, kk, ra.tMax);
                     const float tE = e.tE;
                     const int pE = e.pE, xe = e.xe;
@@ -789,7 +882,10 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
                     const bool enters = e.enters && !final_ && dda_before(tE, pE, bestT, bestP);      // (not behind the best candidate so far)
                     if (__ballot(enters) == 0ull) continue;
                     ++coopWalks;
-#if VH_COOP_LDS
+#if VH_COOP_LDS == 2
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the block is in LDS
+                    __builtin_amdgcn_wave_barrier();
+#elif VH_COOP_LDS
                     // the block's 4 KiB into LDS, 64 bytes per lane: one coalesced round trip, after which every step of every
                     // ray reads at LDS latency instead of waiting for a gather
                     {
@@ -919,6 +1015,54 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
             // a candidate that arrived before this window's end cannot be beaten by a block found later
             final_ = final_ || bestT < tw + window;
             if (__ballot(!final_) == 0ull) break;
+        }
+        if constexpr (kSplit) {
+            // ---- publication: the patch's listed blocks become items of the queues, its rays' set-up goes to memory ----
+            // One returning atomic per list position and WORKGROUP (lane r of wave 0 adds the number of the workgroup's patches
+            // that have an r-th block to the counter of queue (r, shard)); every wave then writes its own items, lane r the r-th.
+            const bool publish = !fail && nList <= kRcRanks && __ballot(inImage) != 0ull;     // (a patch outside the image: nothing to walk)
+            if (lane == 0) sh_.nItems[wave] = publish ? (uint32_t)nList : 0u;
+            __syncthreads();
+            uint32_t cnt = 0u, before = 0u;
+#pragma unroll
+            for (int w = 0; w < kDdaBlockWaves; ++w) {
+                const uint32_t has = sh_.nItems[w] > (uint32_t)lane ? 1u : 0u;
+                cnt += has;
+                before += w < wave ? has : 0u;
+            }
+            const uint32_t shard = (uint32_t)(blockIdx.y * gridDim.x + blockIdx.x) & (kRcShards - 1);
+            if (wave == 0 && lane < kRcRanks && cnt) sh_.segBase[lane] = atomicAdd(&ra.sp.counts[lane * kRcShards + shard], cnt);
+            __syncthreads();
+            if (publish) {
+                const uint32_t patch = (uint32_t)(pv / (kPatch == 0 ? 4 : 8)) * ra.sp.patchesX + (uint32_t)(pu / (kPatch == 0 ? 16 : 8));
+                if (lane < nList) {
+                    const int slot = (int)(list[lane] & 0xffffu);
+                    const uint32_t tg = tags[slot] - 1u;
+                    RcItem item;
+                    item.kx = base0 + (int)(tg & 1023u); item.ky = base1 + (int)((tg >> 10) & 1023u); item.kz = base2 + (int)(tg >> 20);
+                    item.ptr = (int)ptrs[slot];
+                    item.patch = patch;
+                    item.pad[0] = item.pad[1] = item.pad[2] = 0u;
+                    const uint32_t at = sh_.segBase[lane] + before;        // (< segCap: a shard's queue has room for every patch of the shard)
+                    ra.sp.items[(size_t)(lane * kRcShards + (int)shard) * ra.sp.segCap + at] = item;
+                }
+                float *st = ra.sp.state + (size_t)patch * (9 * 64) + lane;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    st[64 * a] = ax[a].E;
+                    st[64 * (3 + a)] = ax[a].invE;
+                    st[64 * (6 + a)] = __int_as_float(c[a]);
+                }
+                ra.sp.best[(size_t)patch * 64 + lane] = kRcNone;
+                if (ra.stamps && lane == 0) {
+                    const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kDdaBlockWaves + wave) * 8;
+                    ra.stamps[w] = stamp0; ra.stamps[w + 1] = __builtin_amdgcn_s_memrealtime();
+                    ra.stamps[w + 2] = stampP1 - stamp0; ra.stamps[w + 3] = (unsigned long long)(pu | (pv << 16));
+                    ra.stamps[w + 4] = stampA - stamp0; ra.stamps[w + 5] = stampB - stamp0; ra.stamps[w + 6] = (unsigned long long)nList; ra.stamps[w + 7] = 0ull;
+                }
+                return;                                  // (the item launch walks, the resolve launch writes the pixels)
+            }
+            fail = true;                                 // the per-lane walk below, pixels written here
         }
         if (!fail) {
             coopDone = true; live = false;
@@ -1166,35 +1310,233 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_dda
 #endif
     }
     if (!inImage) return;
+    if constexpr (kSplit) {                      // a patch that took the per-lane walk: its pixels are final, the resolve launch leaves them alone
+        const uint32_t patch = (uint32_t)(pv / (kPatch == 0 ? 4 : 8)) * ra.sp.patchesX + (uint32_t)(pu / (kPatch == 0 ? 16 : 8));
+        ra.sp.best[(size_t)patch * 64 + lane] = (unsigned long long)kRcDoneKey << 32;
+    }
     depthOut[(size_t)v * fp.width + u] = hit;
     if (!kNormals) return;
     // ---- normal of the hit: TSDF gradient at the hit voxel, normalised, camera frame, w = 0 ----
     float4 n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (found) {
-        const int kx = hx >> 3, ky = hy >> 3, kz = hz >> 3;
-        float here = 0.0f, g[3] = {0.0f, 0.0f, 0.0f};
-        bool ok = dda_voxel(fp, dp, hx, hy, hz, kx, ky, kz, hptr, here);
+    if (found) n = dda_normal(fp, dp, hx, hy, hz, hptr);
+    normalOut[(size_t)v * fp.width + u] = n;
+}
+
+// ---------------------------------------------------------------------------
+// The split form, second launch: one (patch, block) item per wave
+// ---------------------------------------------------------------------------
+// Step 3 of the cooperative form for ONE listed block: whether and where each ray of the item's patch enters the block, the
+// voxel walk inside it, the block's first + -> - pair as the ray's candidate.  Nothing here knows what the other blocks of
+// the patch yield: the candidate is merged into the ray's word with a 64-bit atomicMin (64 lanes x 8 contiguous bytes), and
+// the word read beforehand only serves to skip a block the ray enters behind a candidate it already holds.  The grid is a
+// tuning parameter (a grid-stride loop over the items, queue after queue: list position 0 of every shard, then 1, ...); the
+// number of items is read from the queues' counters, 256 of them = one uint4 per lane + one wave scan.
+#ifndef VH_ITEM_WAVES
+#define VH_ITEM_WAVES 4         // items (waves) per workgroup of the item launch
+#endif
+#ifndef VH_ITEM_OCC
+#define VH_ITEM_OCC 6           // waves per SIMD the item launch is compiled for
+#endif
+constexpr int kItemWaves = VH_ITEM_WAVES;
+
+template <int kPatch>
+__global__ __launch_bounds__(64 * kItemWaves, VH_ITEM_OCC) void raycast_items_kernel(const FrameParams fp, const DevPtrs dp, const RaycastArgs ra)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const RaycastSplit &sp = ra.sp;
+    const unsigned long long stamp0 = ra.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long stampS = 0ull, stampW = 0ull;       // diagnostics: the queues are known; time spent in entered blocks
+    int nDone = 0, nEntered = 0;
+    const uint4 cn = reinterpret_cast<const uint4 *>(sp.counts)[lane];
+    const uint32_t mine = cn.x + cn.y + cn.z + cn.w;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        incl += lane >= d ? t : 0u;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t excl = incl - mine;
+    const uint32_t nWaves = gridDim.x * kItemWaves;
+    const int prio[3] = {2, 0, 1};
+    if (ra.stamps) stampS = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t it = blockIdx.x * kItemWaves + wave; it < total; it += nWaves) {
+        ++nDone;
+        // which queue: the first lane whose inclusive count exceeds the item's index, then one of its four
+        const int l = __ffsll((long long)__ballot(it < incl)) - 1;
+        uint32_t off = it - (uint32_t)__builtin_amdgcn_readlane((int)excl, l);
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cn.x, l), c1 = (uint32_t)__builtin_amdgcn_readlane((int)cn.y, l),
+                       c2 = (uint32_t)__builtin_amdgcn_readlane((int)cn.z, l);
+        uint32_t seg = (uint32_t)l * 4u;
+        if (off >= c0) { off -= c0; ++seg; if (off >= c1) { off -= c1; ++seg; if (off >= c2) { off -= c2; ++seg; } } }
+        const uint32_t itemIndex = seg * sp.segCap + off;
+        const RcItem item = sp.items[itemIndex];
+        const int kk[3] = {__builtin_amdgcn_readfirstlane(item.kx), __builtin_amdgcn_readfirstlane(item.ky), __builtin_amdgcn_readfirstlane(item.kz)};
+        const int bptr = __builtin_amdgcn_readfirstlane(item.ptr);
+        const uint32_t patch = (uint32_t)__builtin_amdgcn_readfirstlane((int)item.patch);
+        const int py = (int)(patch / sp.patchesX), px = (int)(patch - (uint32_t)py * sp.patchesX);
+        const int u = px * (kPatch == 0 ? 16 : 8) + (kPatch == 0 ? (lane & 15) : (lane & 7));
+        const int v = py * (kPatch == 0 ? 4 : 8) + (kPatch == 0 ? (lane >> 4) : (lane >> 3));
+        const bool inImage = u < fp.width && v < fp.height;
+        // the ray's set-up, as the first launch left it
+        const float *st = sp.state + (size_t)patch * (9 * 64) + lane;
+        DdaAxis ax[3];
+        int c[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            float sp = 0.0f, sm = 0.0f;
-            const bool hp = dda_voxel(fp, dp, hx + (a == 0), hy + (a == 1), hz + (a == 2), kx, ky, kz, hptr, sp);
-            const bool hm = dda_voxel(fp, dp, hx - (a == 0), hy - (a == 1), hz - (a == 2), kx, ky, kz, hptr, sm);
-            if (hp && hm) g[a] = (sp - sm) * 0.5f;
-            else if (hp) g[a] = sp - here;
-            else if (hm) g[a] = here - sm;
-            else ok = false;
+            ax[a].G = ra.G[a];
+            ax[a].E = st[64 * a];
+            ax[a].invE = st[64 * (3 + a)];
+            c[a] = __float_as_int(st[64 * (6 + a)]);
+            ax[a].s = ax[a].E > 0.0f ? 1 : -1;
+            ax[a].Gs = ax[a].E > 0.0f ? ax[a].G - 1.0f : ax[a].G;
         }
-        if (ok) {
-            const float len = __builtin_sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
-            if (len > 0.0f) {
-                const float w0 = g[0] / len, w1 = g[1] / len, w2 = g[2] / len;
-                n.x = fp.T[0] * w0 + fp.T[4] * w1 + fp.T[8] * w2;          // R^T * w: world -> camera
-                n.y = fp.T[1] * w0 + fp.T[5] * w1 + fp.T[9] * w2;
-                n.z = fp.T[2] * w0 + fp.T[6] * w1 + fp.T[10] * w2;
+        unsigned long long *word = sp.best + (size_t)patch * 64 + lane;
+        const unsigned long long cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool none = cur == kRcNone;
+        const float bestT = none ? __builtin_inff() : rc_key_time((uint32_t)(cur >> 32));
+        const int bestP = none ? 3 : (int)((cur >> 30) & 3ull);
+        const CoopEntry e = coop_entry(ax, c, kk, ra.tMax);
+        const float tE = e.tE;
+        const int pE = e.pE, xe = e.xe;
+        const bool inside = e.inside;
+        const bool enters = inImage && e.enters && dda_before(tE, pE, bestT, bestP);      // (not behind the candidate the ray holds)
+        const unsigned long long stampE = ra.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        if (__ballot(enters) != 0ull) ++nEntered;
+        if (enters) {      // (structured: the lanes meet again behind the block, before the next item's wave-level operations)
+            const float f0 = (float)ax[0].s, f1 = (float)ax[1].s, f2 = (float)ax[2].s;
+            const float ie0 = ax[0].invE != 0.0f ? ax[0].invE : __builtin_inff(), gs0 = ax[0].invE != 0.0f ? ax[0].Gs : -1.0e30f;
+            const float ie1 = ax[1].invE != 0.0f ? ax[1].invE : __builtin_inff(), gs1 = ax[1].invE != 0.0f ? ax[1].Gs : -1.0e30f;
+            const float ie2 = ax[2].invE != 0.0f ? ax[2].invE : __builtin_inff(), gs2 = ax[2].invE != 0.0f ? ax[2].Gs : -1.0e30f;
+            const int d0 = ax[0].s * ((1 << 16) + 1), d1 = ax[1].s * ((8 << 16) + (1 << 5)), d2 = ax[2].s * ((64 << 16) + (1 << 10));
+            // the voxel the ray enters at
+            int q[3];
+    #pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int lo = kk[a] << 3, hi = lo + 7;
+                const int nearC = ax[a].s > 0 ? lo : hi, farC = ax[a].s > 0 ? hi : lo;
+                if (inside || ax[a].invE == 0.0f) q[a] = c[a];
+                else if (a == xe) q[a] = nearC;
+                else q[a] = dda_advance(ax[a], prio[a], e.startIn[a] ? c[a] : nearC, farC, tE, pE);
+            }
+            const int bx0 = kk[0] << 3, by0 = kk[1] << 3, bz0 = kk[2] << 3;
+            int pl;
+            {
+                const int lx = q[0] & 7, ly = q[1] & 7, lz = q[2] & 7;
+                pl = ((lx | (ly << 3) | (lz << 6)) << 16) | (lx + 8) | ((ly + 8) << 5) | ((lz + 8) << 10);
+            }
+            float fc0 = (float)q[0], fc1 = (float)q[1], fc2 = (float)q[2];
+            float tn0 = (fc0 - gs0) * ie0, tn1 = (fc1 - gs1) * ie1, tn2 = (fc2 - gs2) * ie2;
+            float tArr = tE;
+            int pArr = pE;
+            bool pvd = false, firstVoxel = !inside, walking = true, have = false;
+            float ps = 0.0f, candT = 0.0f;
+            int candP = 0, candLin = 0;
+            const Voxel *blk = dp.blocks + (size_t)bptr;
+            while (walking) {
+                const int lin = (int)((uint32_t)pl >> 16);
+                const float vt = tArr;
+                const int vp = pArr;
+                const Voxel vv = blk[lin];
+                // the crossing that ends this voxel (raycastSDF.frag:156-170)
+                const bool m0 = tn0 < tn1 && tn0 < tn2;
+                const bool m2 = !m0 && tn2 < tn1;
+                const bool m1 = !m0 && !m2;
+                tArr = m0 ? tn0 : m2 ? tn2 : tn1;
+                pArr = m0 ? 2 : m2 ? 1 : 0;
+                pl += m0 ? d0 : m2 ? d2 : d1;
+                fc0 += m0 ? f0 : 0.0f; fc1 += m1 ? f1 : 0.0f; fc2 += m2 ? f2 : 0.0f;
+                tn0 = (fc0 - gs0) * ie0; tn1 = (fc1 - gs1) * ie1; tn2 = (fc2 - gs2) * ie2;
+                walking = tArr < ra.tMax && (pl & 0x6318) == 0x2108;     // (a voxel is visited iff the ray arrives before t_max)
+                const bool valid = vv.weight > 0.0f;
+                if (valid && vv.sdf <= 0.0f) {
+                    if (firstVoxel) {
+                        // the voxel the ray was in before the entry event: one step back on the entry axis, in the neighbouring block
+                        const int vx = bx0 + (lin & 7), vy = by0 + ((lin >> 3) & 7), vz = bz0 + (lin >> 6);
+                        const int n0 = vx - (xe == 0 ? ax[0].s : 0), n1 = vy - (xe == 1 ? ax[1].s : 0), n2 = vz - (xe == 2 ? ax[2].s : 0);
+                        const int np = lookup_block(fp, dp, n0 >> 3, n1 >> 3, n2 >> 3);
+                        pvd = false;
+                        if (np != VH_FREE_BLOCK) {
+                            const Voxel nb = dp.blocks[(size_t)np + (size_t)(((n2 & 7) << 6) | ((n1 & 7) << 3) | (n0 & 7))];
+                            pvd = nb.weight > 0.0f; ps = nb.sdf;
+                        }
+                    }
+                    if (pvd && ps > 0.0f) {                    // the block's first pair: nothing earlier behind it
+                        have = dda_before(vt, vp, bestT, bestP);
+                        candT = vt; candP = vp; candLin = lin;
+                        walking = false;
+                    }
+                }
+                pvd = valid; ps = vv.sdf;
+                firstVoxel = false;
+            }
+            if (have) {
+                const unsigned long long cand = ((unsigned long long)rc_time_key(candT) << 32) | ((unsigned long long)candP << 30) |
+                                                ((unsigned long long)itemIndex << 9) | (unsigned long long)candLin;
+                (void)__hip_atomic_fetch_min(word, cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        if (ra.stamps) stampW += __builtin_amdgcn_s_memrealtime() - stampE;
     }
-    normalOut[(size_t)v * fp.width + u] = n;
+    if (ra.stamps && lane == 0) {
+        unsigned long long *o = ra.stamps + ((size_t)sp.patchesX * 0 + (size_t)ra.stampsItemBase + (size_t)(blockIdx.x * kItemWaves + wave)) * 8;
+        o[0] = stamp0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = (unsigned long long)nDone | ((unsigned long long)nEntered << 32);
+        o[3] = stampS - stamp0; o[4] = stampW; o[5] = total; o[6] = 0ull; o[7] = 0ull;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The split form, third launch: the rays' words become pixels
+// ---------------------------------------------------------------------------
+// A word names the hit voxel (item -> block, voxel) and the event the ray arrived in it by; the pair's first sample is the
+// voxel one step back on that event's axis (consecutive visited voxels).  Depth and normal with the fused kernel's
+// arithmetic, in its order.  Workgroup 0 also clears the queues' counters for the next call.
+template <int kPatch, bool kNormals>
+__global__ __launch_bounds__(64 * kDdaBlockWaves) void raycast_resolve_kernel(const FrameParams fp, const DevPtrs dp, const RaycastArgs ra,
+                                                                             float *__restrict__ depthOut, float4 *__restrict__ normalOut)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const RaycastSplit &sp = ra.sp;
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < kRcSegs; i += 64 * kDdaBlockWaves) sp.counts[i] = 0u;
+    int tx = blockIdx.x, ty = blockIdx.y;
+    if (ra.xcdAware) {
+        const int n = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+        if ((n & 7) == 0) {
+            const int r = (b & 7) * (n >> 3) + (b >> 3);
+            ty = r / (int)gridDim.x;
+            tx = r - ty * (int)gridDim.x;
+        }
+    }
+    const int pu = tx * 16 + (kPatch == 0 ? 0 : (wave & 1) * 8);
+    const int pv = ty * 16 + (kPatch == 0 ? wave * 4 : (wave >> 1) * 8);
+    const int u = pu + (kPatch == 0 ? (lane & 15) : (lane & 7));
+    const int v = pv + (kPatch == 0 ? (lane >> 4) : (lane >> 3));
+    if (u >= fp.width || v >= fp.height) return;
+    const uint32_t patch = (uint32_t)(pv / (kPatch == 0 ? 4 : 8)) * sp.patchesX + (uint32_t)(pu / (kPatch == 0 ? 16 : 8));
+    const unsigned long long w = sp.best[(size_t)patch * 64 + lane];
+    if ((uint32_t)(w >> 32) == kRcDoneKey) return;                 // written by the first launch (per-lane walk)
+    float hit = 0.0f;
+    float4 n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (w != kRcNone) {
+        const RcItem item = sp.items[(uint32_t)(w >> 9) & 0x1fffffu];
+        const int lin = (int)(w & 511ull), p = (int)((w >> 30) & 3ull);
+        const int axis = p == 2 ? 0 : p == 0 ? 1 : 2;
+        const int s = sp.state[(size_t)patch * (9 * 64) + 64 * axis + lane] > 0.0f ? 1 : -1;
+        const int vx = (item.kx << 3) + (lin & 7), vy = (item.ky << 3) + ((lin >> 3) & 7), vz = (item.kz << 3) + (lin >> 6);
+        const int p0 = vx - (axis == 0 ? s : 0), p1 = vy - (axis == 1 ? s : 0), p2 = vz - (axis == 2 ? s : 0);
+        const float sdf = dp.blocks[(size_t)item.ptr + (size_t)lin].sdf;
+        int pptr = item.ptr;
+        if ((p0 >> 3) != item.kx || (p1 >> 3) != item.ky || (p2 >> 3) != item.kz) pptr = lookup_block(fp, dp, p0 >> 3, p1 >> 3, p2 >> 3);
+        const float ps = dp.blocks[(size_t)pptr + (size_t)(((p2 & 7) << 6) | ((p1 & 7) << 3) | (p0 & 7))].sdf;
+        // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
+        const float tc = ((ra.zrow[0] * (float)vx + ra.zrow[1] * (float)vy) + ra.zrow[2] * (float)vz) + ra.zrow[3];
+        const float tp = ((ra.zrow[0] * (float)p0 + ra.zrow[1] * (float)p1) + ra.zrow[2] * (float)p2) + ra.zrow[3];
+        hit = tp + ((tc - tp) * ps) / (ps - sdf);
+        if (kNormals) n = dda_normal(fp, dp, vx, vy, vz, item.ptr);
+    }
+    depthOut[(size_t)v * fp.width + u] = hit;
+    if (kNormals) normalOut[(size_t)v * fp.width + u] = n;
 }
 
 }  // namespace vh
