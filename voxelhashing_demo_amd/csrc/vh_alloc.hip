@@ -78,8 +78,23 @@ struct Pending {
     uint32_t epoch;
     bool live;
     int winnersCounter;                               // of the frame being claimed: counts its distinct buckets (-1: not counted)
+    const uint32_t *__restrict__ filter;              // the pending frame's claim filter (below), or nullptr: every claim word is read
+    uint32_t *filterNew;                              // the filter the frame being claimed fills, or nullptr
 };
-__device__ constexpr Pending kNoPending{nullptr, nullptr, 0u, false, -1};
+__device__ constexpr Pending kNoPending{nullptr, nullptr, 0u, false, -1, nullptr, nullptr};
+
+// Claim filter (round 5).  "Is an insertion in flight into this bucket?" is asked by every probe of the claim phase and
+// for every allocated entry the walk meets, and the answer sits in the pending frame's claim word: 8 bytes out of an array
+// of 8 bytes per bucket (134 MB at 2^24 buckets) -- a round trip to HBM to learn, 99.9 % of the time, "nothing".  The
+// buckets with an insertion in flight are the pending frame's winners: a few hundred at most.  So the claim phase also sets
+// one bit per staked bucket in a filter of 2^17 bits (16 KB: L2-resident; indexed by the bucket's low bits, three of them
+// rotating with the per-frame counter sets: filled by frame i, read by the launch of frame i+1, cleared by that of i+2);
+// readers touch the claim word only behind a set bit.  A false positive reads the word as before: exactness is untouched.
+constexpr uint32_t kPendFilterWords = 4096;
+__device__ __forceinline__ bool pend_maybe(const Pending &pend, uint32_t local)
+{
+    return pend.filter == nullptr || ((pend.filter[(local >> 5) & (kPendFilterWords - 1u)] >> (local & 31u)) & 1u) != 0u;
+}
 
 // kEagerSlot: the bucket's first slot is requested together with the pending frame's claim word -- two independent addresses,
 // one round trip instead of two; what it returns is not looked at when that slot is the one being written.  It pays where the
@@ -101,7 +116,7 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
     // the insertion in flight into this bucket, if any: it takes the bucket's first free slot (pf)
     uint32_t pf = ~0u;
     int4 pk = make_int4(0, 0, 0, 0);
-    if (pend.claim && pend.live) {
+    if (pend.claim && pend.live && pend_maybe(pend, local)) {
         const unsigned long long w = pend.claim[local];
         if (claim_epoch(w) == pend.epoch) {
             pf = claim_f(w);
@@ -131,6 +146,7 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
     }
     dp.candidates[slot] = make_int4(kx, ky, kz, (int)rank);
     const unsigned long long before = atomicMax(dp.claim + local, claim_word(fp.epoch, rank, firstFree, slot));
+    if (pend.filterNew) atomicOr(pend.filterNew + ((local >> 5) & (kPendFilterWords - 1u)), 1u << (local & 31u));
     // first claim on this bucket in this epoch: one more entry the commit phase will insert
     if (pend.winnersCounter >= 0 && claim_epoch(before) != fp.epoch) atomicAdd(dp.counters + pend.winnersCounter, 1);
 }

@@ -119,6 +119,8 @@ struct vh_context {
     unsigned long long *claimBuf[2] = {nullptr, nullptr};
     int4 *candBuf[2] = {nullptr, nullptr};
     VoxelEntry *compactBuf[2] = {nullptr, nullptr};
+    uint32_t *claimFilter = nullptr;       // pipelined frames: three claim filters of kPendFilterWords words (vh_alloc.hip: pend_maybe)
+    int claimFilterOn = 1;                 // option "claim_filter": readers of the pending frame's claim words test the filter first
     uint32_t *maskBuf2 = nullptr;          // pipelined multi-camera frames: the camera masks of the second compact buffer
     int multiWalkEntries = 0;              // option "multi_walk_entries": entries per lane of the multi-camera pipelined walk (0: by shard size)
     int genFramesPerLaunch = 4;            // option "gen_frames_per_launch": frames of a batch one key-generation launch takes (1..8)
@@ -298,6 +300,8 @@ static int free_buffers(vh_context *c)
     c->fusedPlane = nullptr;
     if (c->maskBuf2) (void)hipFree(c->maskBuf2);
     c->maskBuf2 = nullptr;
+    if (c->claimFilter) (void)hipFree(c->claimFilter);
+    c->claimFilter = nullptr;
     if (c->viewSet) (void)hipFree(c->viewSet);
     c->viewSet = nullptr;
     if (c->viewLists) (void)hipFree(c->viewLists);

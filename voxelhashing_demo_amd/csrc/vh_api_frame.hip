@@ -118,7 +118,7 @@ static int launch_alloc(vh_context *c, const In &in)
 static uint32_t walk_blocks(const vh_context *c)
 {
     if (c->flattenVariant == kWalkIndexed)       // one lane per 32-bucket word of the occupancy bitmap
-        return (uint32_t)grid_for(((size_t)c->ownedBuckets + 31) / 32, kFlattenThreads);
+        return (uint32_t)grid_for(((size_t)c->ownedBuckets + 31) / 32, kFlattenThreads * kIndexWords);
     if (c->flattenVariant == kWalkPersistent)    // resident workgroups striding over the tiles
         return std::min<uint32_t>((uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane),
                                   (uint32_t)c->persistentBlocks);
@@ -238,6 +238,7 @@ static int ensure_pipeline_buffers(vh_context *c)
     unsigned long long *claim2 = nullptr;
     int4 *cand2 = nullptr;
     VoxelEntry *compact2 = nullptr;
+    uint32_t *filter = nullptr;
     float *plane[2] = {nullptr, nullptr};
     uint16_t *raw[2] = {nullptr, nullptr};
     hipError_t e = hipMalloc((void **)&claim2, claimBytes);
@@ -248,7 +249,10 @@ static int ensure_pipeline_buffers(vh_context *c)
         if (e == hipSuccess) e = hipMalloc((void **)&raw[i], sizeof(uint16_t) * npix);
     }
     if (e == hipSuccess) e = hipMemsetAsync(claim2, 0, claimBytes, c->stream);
+    if (e == hipSuccess) e = hipMalloc((void **)&filter, sizeof(uint32_t) * 3 * kPendFilterWords);
+    if (e == hipSuccess) e = hipMemsetAsync(filter, 0, sizeof(uint32_t) * 3 * kPendFilterWords, c->stream);
     if (e != hipSuccess) {
+        if (filter) (void)hipFree(filter);
         if (claim2) (void)hipFree(claim2);
         if (cand2) (void)hipFree(cand2);
         if (compact2) (void)hipFree(compact2);
@@ -259,6 +263,7 @@ static int ensure_pipeline_buffers(vh_context *c)
     c->candBuf[0] = c->dp.candidates;      c->candBuf[1] = cand2;
     c->compactBuf[0] = c->dp.compact;      c->compactBuf[1] = compact2;
     for (int i = 0; i < 2; ++i) { c->planeBuf[i] = plane[i]; c->rawBuf[i] = raw[i]; }
+    c->claimFilter = filter;
     c->pipeParity = 0;                     // dp.* currently alias set 0
     return VH_OK;
 }
@@ -318,6 +323,11 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     a.claimRatio = claim_ratio(a.claimBlocks, a.claimSpan);
     a.planeNew = (hasNew && !newSensor) ? c->planeBuf[newParity] : nullptr;
     a.rawNew = (hasNew && newSensor) ? c->rawBuf[newParity] : nullptr;
+    // (the filters rotate with the counter sets whether they are read or not, so that the option can change between frames)
+    a.filter = c->claimFilter;
+    a.filterRead = c->claimFilterOn ? 1u : 0u;
+    a.filtNew = kPendFilterWords * (uint32_t)setNew; a.filtOld = kPendFilterWords * (uint32_t)setOld;
+    a.filtClear = kPendFilterWords * (uint32_t)((setNew + 1) % 3);
     a.doneTag = c->pipeDoneTag;
     a.spinLimit = c->spinLimit ? c->spinLimit : kSpinLimitDefault;
 #ifdef VH_DEBUG_SKIP_ROLES
@@ -331,9 +341,13 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     const bool serial = (c->fp.flags & kFlagOverflow) != 0u;
     // the lean builds (vh_frame.hip): no band, no list, the reference's walk, and both frames' option flags exactly the walk's
     int lean = 0;
-    if (!serial && !a.walkIndexed && c->leanKernels) {      // (with a band: the ray band only -- kFlagBandDda is a flag like the others)
+    if (!serial && c->leanKernels) {      // (with a band: the ray band only -- kFlagBandDda is a flag like the others)
         const uint32_t fo = hasOld ? c->pipeFp.flags : c->fp.flags;
-        if (c->fp.flags == kFlagWalkShort && fo == kFlagWalkShort) lean = 1;
+        if (a.walkIndexed) {                // the walk-free frame (flatten_variant 4): builds of its own, without a band
+            if (!band && c->fp.flags == kFlagWalkShort && fo == kFlagWalkShort) lean = 5;
+            else if (!band && c->fp.flags == (kFlagWalkShort | kFlagWalkNt) && fo == (kFlagWalkShort | kFlagWalkNt)) lean = 6;
+        }
+        else if (c->fp.flags == kFlagWalkShort && fo == kFlagWalkShort) lean = 1;
         else if (c->fp.flags == (kFlagWalkShort | kFlagWalkNt) && fo == (kFlagWalkShort | kFlagWalkNt)) lean = 2;
         else if (band && c->fp.flags == (kFlagWalkShort | kFlagBandRayDda) && fo == c->fp.flags) lean = 3;
         else if (band && c->fp.flags == (kFlagWalkShort | kFlagWalkNt | kFlagBandRayDda) && fo == c->fp.flags) lean = 4;
@@ -345,6 +359,8 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
      : lean == 2 ? (band ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 2) : VH_LAUNCH_PIPELINED(DEPTH, false, false, 2)) \
      : lean == 3 ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 3) \
      : lean == 4 ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 4) \
+     : lean == 5 ? VH_LAUNCH_PIPELINED(DEPTH, false, false, 5) \
+     : lean == 6 ? VH_LAUNCH_PIPELINED(DEPTH, false, false, 6) \
      : serial ? (band ? VH_LAUNCH_PIPELINED(DEPTH, true, true, 0) : VH_LAUNCH_PIPELINED(DEPTH, false, true, 0)) \
               : (band ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 0) : VH_LAUNCH_PIPELINED(DEPTH, false, false, 0)))
     if (hasOld && c->pipeSensor) {

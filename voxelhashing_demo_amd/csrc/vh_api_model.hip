@@ -453,6 +453,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (std::strcmp(name, "raycast_patch") == 0) { c->raycastPatch = value; return VH_OK; }
     if (std::strcmp(name, "raycast_xcd") == 0) { c->raycastXcd = value; return VH_OK; }
     if (std::strcmp(name, "raycast_beam") == 0 && value >= 0 && value <= 3) { c->raycastBeam = value; return VH_OK; }
+    if (std::strcmp(name, "claim_filter") == 0 && (value == 0 || value == 1)) { c->claimFilterOn = value; return VH_OK; }
     if (std::strcmp(name, "raycast_split") == 0 && (value == 0 || value == 1)) { c->raycastSplit = value; return VH_OK; }
     if (std::strcmp(name, "raycast_items_grid") == 0 && value >= 0) { c->raycastItemsGrid = value; return VH_OK; }
     if (std::strcmp(name, "raycast_mode") == 0 && (value == VH_RAYCAST_DDA || value == VH_RAYCAST_FIXED_STEP)) {

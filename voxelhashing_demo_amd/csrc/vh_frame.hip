@@ -153,6 +153,9 @@ struct PipeArgs {
     uint32_t claimSpan, claimRatio;        // claim tiles are interleaved with the first claimSpan - claimBlocks walk tiles
     float *planeNew;                       // private depth copies written by claim(new) ...
     uint16_t *rawNew;
+    uint32_t *filter;                      // claim filters (vh_alloc.hip: pend_maybe), three of kPendFilterWords words, or nullptr (option "claim_filter" 0)
+    uint32_t filtNew, filtOld, filtClear;  // word offsets of the filter the new frame fills / the pending frame filled / this launch clears
+    uint32_t filterRead;                   // option "claim_filter": the readers consult it (it is filled and cleared either way)
     int32_t doneTag;                       // overflow list: the pending frame's tag (lock epochs since creation), published when its commit phase ends
     uint32_t spinLimit;                    // ... and how many polls a workgroup waits for it (wait_commit_done)
 #ifdef VH_DEBUG_SKIP_ROLES
@@ -220,6 +223,17 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
     const uint32_t b = blockIdx.x;
     uint32_t role, index;                          // 0 commit, 1 integrate, 2 claim, 3 walk
     if (b < a.commitBlocks) { role = 0; index = b; }
+    else if (a.walkIndexed) {
+        // The walk-free frame streams nothing: every role is a chain of dependent reads plus arithmetic, and a chain that starts
+        // late is the launch's tail.  The index walk's workgroups are few and their chain is the longest (bitmap -> buckets ->
+        // frustum test -> list), so they come first, then the TSDF update, then the claim tiles; spread among the claim tiles
+        // like the streaming walk they cost C2 10.8-11.2 us against 9.0-9.2, C3 28.1 against 27.6 (same box, generic build,
+        // profiles/r05_index_walk_shapes.txt); their issue priority makes no difference.
+        const uint32_t r = b - a.commitBlocks;
+        if (r < a.walkBlocks) { role = 3; index = r; }
+        else if (r < a.walkBlocks + a.integrateBlocks) { role = 1; index = r - a.walkBlocks; }
+        else { role = 2; index = r - a.walkBlocks - a.integrateBlocks; }
+    }
     else if (b < a.commitBlocks + a.integrateBlocks) { role = 1; index = b - a.commitBlocks; }
     else {
         // the claim tiles are spread over the first a.claimSpan of the claim + walk workgroups (multiply-high
@@ -246,7 +260,9 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
             if (!wait_commit_done(counters, a.doneTag, a.spinLimit)) return;
         }
         const Pending pend{a.hasOld && !serial ? dpOld.claim : nullptr, dpOld.candidates, fpOld.epoch, live,
-                           serial ? -1 : kPipeWinners + a.setNew};
+                           serial ? -1 : kPipeWinners + a.setNew,
+                           a.filter && a.filterRead && a.hasOld && !serial ? a.filter + a.filtOld : nullptr,
+                           a.filter && !serial ? a.filter + a.filtNew : nullptr};
         if (role == 2u) {
             __builtin_amdgcn_s_setprio(3);
             claim_tile<In, kBand>(fpNew, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
@@ -260,6 +276,15 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
         return;
     }
     if (!a.hasOld) return;
+    // the filter frame i+2 will fill: cleared here (nobody reads or writes it during this launch); a flush launch clears
+    // the one a new frame would have filled as well, so that a run always starts on an empty one
+    if (role == 0u && a.filter) {
+        const uint32_t t = index * 256u + threadIdx.x;
+        if (t < kPendFilterWords) {
+            a.filter[a.filtClear + t] = 0u;
+            if (!a.hasNew) a.filter[a.filtNew + t] = 0u;
+        }
+    }
     const int scanOld = counters[kPipeScan + a.setOld];
     if (role == 1u) {
         // ---- frame i: TSDF update of the blocks its walk (and commit(i-1)) listed ----
@@ -343,11 +368,12 @@ __global__ __launch_bounds__(256) void frame_pipelined_kernel(FrameParams fpNew,
 {
     if (kLean != 0) {
         // (3 / 4: the same two with the ray-DDA band, VH_BAND_RAY_DDA -- builds that exist with kBand only)
-        constexpr uint32_t flags = (kLean == 2 || kLean == 4 ? (kFlagWalkShort | kFlagWalkNt) : kFlagWalkShort) |
-                                   (kLean >= 3 ? kFlagBandRayDda : 0u);
+        // (5 / 6: the first two with the occupancy-index walk in place of the reference's -- the walk-free frame, no band)
+        constexpr uint32_t flags = (kLean == 2 || kLean == 4 || kLean == 6 ? (kFlagWalkShort | kFlagWalkNt) : kFlagWalkShort) |
+                                   (kLean == 3 || kLean == 4 ? kFlagBandRayDda : 0u);
         fpNew.flags = flags;
         fpOld.flags = flags;
-        a.walkIndexed = 0u;
+        a.walkIndexed = kLean >= 5 ? 1u : 0u;
     }
     frame_pipelined<In, Depth, kBand, kSerial>(fpNew, dpNew, inNew, fpOld, dpOld, depthOld, a);
 }

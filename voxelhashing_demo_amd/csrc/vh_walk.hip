@@ -124,8 +124,10 @@ __device__ __forceinline__ void walk_process_tile(const FrameParams &fp, const D
             bool inFlight = false;
             if (pend.claim && pend.live) {
                 const uint32_t b = e / fp.bucketSize;
-                const unsigned long long w = pend.claim[b];
-                inFlight = claim_epoch(w) == pend.epoch && claim_f(w) == e - b * fp.bucketSize;
+                if (pend_maybe(pend, b)) {
+                    const unsigned long long w = pend.claim[b];
+                    inFlight = claim_epoch(w) == pend.epoch && claim_f(w) == e - b * fp.bucketSize;
+                }
             }
             if (!inFlight) hit = block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);   // VoxelUtils.cu:732
         }
@@ -190,12 +192,26 @@ __device__ __forceinline__ void flatten_tiles_persistent(const FrameParams &fp, 
 // (nothing is allocated behind it: it is the bucket's first free slot) -- that entry is appended by the
 // commit phase itself; whether this walk already sees the bucket's occupancy bit or not makes no difference
 // (a bucket whose bit is still clear held nothing before).
-__device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
-                                                   const CompactOut &out, const Pending &pend = kNoPending)
+//
+// This form (round 1) follows one bucket per lane and loop round, slot after slot: a chain of dependent reads per set bit
+// and one returning atomic per slot that has a hit; a wave is as long as its fullest word.  Kept for tables with the
+// overflow list (holes in the buckets, chains behind them).
+#ifndef VH_INDEX_WORDS
+#define VH_INDEX_WORDS 4       // (same box, walk-free launch of C2 / C3 / C5table, generic build, index tiles first: 1 word per lane with a
+                               //  reservation per wave 10.2 / 35.7 / 43.0 us; 2 words 9.3 / 31.8 / 39.8; 2 words, a reservation per workgroup 9.2 / 28.3 /
+                               //  32.7; 4 words 9.2 / 27.6 / 29.5; 8 words 10.2 / 29.0 / 29.7 -- profiles/r05_index_walk_shapes.txt)
+#endif
+#ifndef VH_INDEX_WG_RESERVE
+#define VH_INDEX_WG_RESERVE 1        // 1: one list reservation per workgroup and round; 0: one per wave
+#endif
+constexpr int kIndexWords = VH_INDEX_WORDS;       // bitmap words per lane of an index tile: a workgroup covers 256 * 4 * 32 = 32 768 buckets
+__device__ __forceinline__ void flatten_index_tile_chain(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
+                                                         const CompactOut &out, const Pending &pend = kNoPending)
 {
     const uint32_t owned = fp.bucketHi - fp.bucketLo;
     const uint32_t numWords = (owned + 31u) / 32u;
-    const uint32_t w = tileIndex * kFlattenThreads + threadIdx.x;
+    for (int k = 0; k < kIndexWords; ++k) {
+    const uint32_t w = (tileIndex * kIndexWords + (uint32_t)k) * kFlattenThreads + threadIdx.x;
     uint32_t bits = (w < numWords) ? dp.bucketBits[w] : 0u;
     while (__ballot(bits != 0u) != 0ull) {
         const bool have = bits != 0u;
@@ -204,7 +220,7 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
         bool more = have;                   // entries form a prefix of the bucket (not with the overflow list: holes)
         const bool holes = (fp.flags & kFlagOverflow) != 0u;
         uint32_t inFlight = ~0u;            // slot of this bucket the concurrent commit phase writes
-        if (have && pend.claim && pend.live) {
+        if (have && pend.claim && pend.live && pend_maybe(pend, bucket)) {
             const unsigned long long cw = pend.claim[bucket];
             if (claim_epoch(cw) == pend.epoch) inFlight = claim_f(cw);
         }
@@ -223,6 +239,163 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
             if (mask == 0ull) continue;
             compact_append(dp, out, tileIndex, mask, hit, ent);
         }
+    }
+    }
+}
+
+// The same walk with the work dealt out evenly, every read in flight at once, and ONE list reservation per workgroup and
+// round (round 5).  Measured first: the round-1 form cost the C2 launch 3.6 of its 10.9 us (a wave is as long as the fullest
+// of its 64 words, a dependent read per slot); with that fixed the C3 launch stood at 29 us against 15 without the walk --
+// 2 048 waves x one returning atomic each on the list's two counters, which take ~90 per microsecond each
+// (profiles/r05_index_roles.txt).  So: a lane reads kIndexWords bitmap words (32 contiguous bytes), the wave's non-empty
+// buckets go to a list in LDS (a prefix sum of the popcounts says where), the list is dealt to the lanes -- two buckets per
+// lane and round, their first two slots and (behind the claim filter) the pending frame's claim word requested together --
+// the four waves' hit counts meet in LDS and one lane reserves the list slots of all of them: C5table 512 workgroups = 256
+// atomics per counter and frame.  Slots 2 and beyond are read only behind a live slot 1 (a bucket holding three entries:
+// rare at any load the reference's 5-slot buckets work at) and appended per wave.
+constexpr int kIndexQueue = 512;
+__device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
+                                                   const CompactOut &out, const Pending &pend = kNoPending)
+{
+    if (fp.flags & kFlagOverflow) { flatten_index_tile_chain(fp, dp, tileIndex, out, pend); return; }
+    constexpr int kWaves = kFlattenThreads / kWave;
+    __shared__ uint32_t queue_[kWaves][kIndexQueue];
+    __shared__ int rounds_[kWaves], hits_[kWaves], base_;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    uint32_t *q = queue_[wave];
+    const uint32_t owned = fp.bucketHi - fp.bucketLo;
+    const uint32_t numWords = (owned + 31u) / 32u;
+    // words w0 .. w0 + kIndexWords - 1 of this lane: contiguous (two 16-byte loads; the bitmap has a word of padding, but a
+    // whole tile beyond the end does not: tested word by word)
+    const uint32_t w0 = (tileIndex * kFlattenThreads + threadIdx.x) * kIndexWords;
+    uint32_t bits[kIndexWords];
+#pragma unroll
+    for (int k = 0; k < kIndexWords; ++k) bits[k] = (w0 + (uint32_t)k < numWords) ? dp.bucketBits[w0 + k] : 0u;
+    const bool toB = out.counterB >= 0 && (tileIndex & 1u);
+    const bool pending = pend.claim != nullptr && pend.live;
+    for (;;) {
+        // ---- the pass's buckets: a lane contributes its set bits while the wave's list has room ----
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < kIndexWords; ++k) cnt += __popc(bits[k]);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int n = __shfl_up(incl, d);
+            if (lane >= d) incl += n;
+        }
+        const int excl = incl - cnt;
+        const int m = min(__builtin_amdgcn_readlane(incl, kWave - 1), kIndexQueue);
+        int room = max(0, min(cnt, kIndexQueue - excl)), at = excl;
+#pragma unroll
+        for (int k = 0; k < kIndexWords; ++k) {
+            while (room > 0 && bits[k] != 0u) {
+                q[at++] = (w0 + (uint32_t)k) * 32u + (uint32_t)__ffs((int)bits[k]) - 1u;
+                bits[k] &= bits[k] - 1u;
+                --room;
+            }
+        }
+        if (lane == 0) rounds_[wave] = (m + 2 * kWave - 1) / (2 * kWave);
+        __syncthreads();
+        int rounds = 0;
+#pragma unroll
+        for (int i = 0; i < kWaves; ++i) rounds = max(rounds, rounds_[i]);
+        // ---- two buckets per lane and round; the same number of rounds for the four waves (one, normally) ----
+        for (int r = 0; r < rounds; ++r) {
+            const int base = r * 2 * kWave;
+            VoxelEntry e[2][2];
+            unsigned long long cw[2] = {0ull, 0ull};
+            uint32_t bk[2];
+            bool hv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int idx = base + kWave * j + lane;
+                hv[j] = idx < m;
+                bk[j] = hv[j] ? q[idx] : 0u;
+                const VoxelEntry *slot = dp.table + (size_t)bk[j] * fp.bucketSize;
+                e[j][0].ptr = VH_FREE_BLOCK; e[j][1].ptr = VH_FREE_BLOCK;
+                if (hv[j]) {
+                    e[j][0] = slot[0];
+                    if (fp.bucketSize > 1u) e[j][1] = slot[1];
+                    if (pending && pend_maybe(pend, bk[j])) cw[j] = pend.claim[bk[j]];
+                }
+            }
+            bool hit[2][2], deeper[2];
+            uint32_t inFlight[2];
+            int nh = 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                inFlight[j] = (pending && claim_epoch(cw[j]) == pend.epoch) ? claim_f(cw[j]) : ~0u;
+                const bool live0 = hv[j] && inFlight[j] != 0u && e[j][0].ptr != VH_FREE_BLOCK;
+                const bool live1 = live0 && inFlight[j] != 1u && e[j][1].ptr != VH_FREE_BLOCK;
+                hit[j][0] = live0 && block_in_frustum(fp, e[j][0].pos[0], e[j][0].pos[1], e[j][0].pos[2]);
+                hit[j][1] = live1 && block_in_frustum(fp, e[j][1].pos[0], e[j][1].pos[1], e[j][1].pos[2]);
+                deeper[j] = live1 && fp.bucketSize > 2u && inFlight[j] != 2u;
+                nh += (hit[j][0] ? 1 : 0) + (hit[j][1] ? 1 : 0);
+            }
+            // one reservation for the workgroup's hits of this round
+            int hincl = nh;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const int n = __shfl_up(hincl, d);
+                if (lane >= d) hincl += n;
+            }
+#if VH_INDEX_WG_RESERVE
+            if (lane == kWave - 1) hits_[wave] = hincl;
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int i = 0; i < kWaves; ++i) {
+                const int h = hits_[i];
+                before += i < wave ? h : 0;
+                total += h;
+            }
+#else
+            const int before = 0, total = __builtin_amdgcn_readlane(hincl, kWave - 1);
+#endif
+            if (total != 0) {          // (the same for every wave)
+#if VH_INDEX_WG_RESERVE
+                if (threadIdx.x == 0) base_ = atomicAdd(dp.counters + (toB ? out.counterB : out.counterA), total);
+                __syncthreads();
+                const int start = base_;
+#else
+                int start = 0;
+                if (lane == kWave - 1) start = atomicAdd(dp.counters + (toB ? out.counterB : out.counterA), total);
+                start = __shfl(start, kWave - 1);
+#endif
+                uint32_t pos = (uint32_t)(start + before + hincl - nh);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        if (hit[j][k]) { dp.compact[toB ? out.numEntries - 1u - pos : pos] = e[j][k]; ++pos; }
+            }
+            // slots 2 ..: only behind a live slot 1 (per wave)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bool more = deeper[j];
+                if (__ballot(more) == 0ull) continue;
+                for (uint32_t s = 2; s < fp.bucketSize; ++s) {
+                    VoxelEntry ent;
+                    bool h = false;
+                    if (s == inFlight[j]) more = false;
+                    if (more) {
+                        ent = dp.table[(size_t)bk[j] * fp.bucketSize + s];
+                        more = ent.ptr != VH_FREE_BLOCK;
+                        h = more && block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);
+                    }
+                    const unsigned long long mask = __ballot(h);
+                    if (__ballot(more) == 0ull && mask == 0ull) break;
+                    if (mask == 0ull) continue;
+                    compact_append(dp, out, tileIndex, mask, h, ent);
+                }
+            }
+            __syncthreads();           // (hits_ and base_ are rewritten by the next round)
+        }
+        bool left = false;
+#pragma unroll
+        for (int k = 0; k < kIndexWords; ++k) left |= bits[k] != 0u;
+        if (!__syncthreads_or(left ? 1 : 0)) break;       // (also: the lists are refilled by the next pass)
     }
 }
 
