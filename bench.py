@@ -314,6 +314,8 @@ def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, 
                                min_time=1.0)
     rec = window_stats(times, steps, B)
     counters = it.table.counters()
+    if counters["spin_timeouts"]:          # (a serialised launch gave up waiting: the frames timed are not the frames fused)
+        raise SystemExit(f"bench.py: {counters['spin_timeouts']} workgroups of serialised launches timed out (vh_counters.spin_timeouts)")
     occ = counters["occupied"]
     rec["occupied_blocks"], rec["allocated_blocks"], rec["resident_frames"] = occ, counters["allocated_total"], nframes
     if want_profile and args.profile_steps > 0:
@@ -350,6 +352,43 @@ def two_launch_record(args, it, name, occ, steps, warmup, sync):
     it.table.set_option("pipeline", 1)
     it.pipeline = True
     return rec2
+
+
+def index_variant_record(args, it, name, steps, warmup, sync):
+    """The walk-free frame (vh_set_option flatten_variant = 4) on the same resident frames, pipelined like the headline
+    path: the walk role reads the bucket-occupancy bitmap and the non-empty buckets instead of every VoxelEntry.  NOT the
+    reference's flattenKernel (SURVEY.md 8(d) allows it if the smaller byte count is reported), hence never `value`.  Its
+    roofline is on that smaller byte count; the launch streams next to nothing, so what bounds it is named as measured:
+    chains of dependent reads and VALU issue of the claim tiles and the TSDF update (profiles/r05_index_roles.txt)."""
+    wl = it.wl
+    Wd, Ht = wl["width"], wl["height"]
+    it.table.set_option("flatten_variant", 4)
+    t_idx, nxt = timed_windows(it.step, sync, steps, warmup)
+    rec = dict(window_stats(t_idx, steps, it.batch), unit="frames/s")
+    counters = it.table.counters()
+    occ, alloc = counters["occupied"], counters["allocated_total"] - counters.get("freed_total", 0)
+    flatten_bytes = wl["buckets"] // 8 + 100 * alloc
+    nbytes = 16 * Wd * Ht + 4 * Wd * Ht + flatten_bytes + 20 * occ + occ * (20 + 4096 + 4096) + 100 * occ
+    rec["flatten_bytes"] = flatten_bytes
+    if args.profile_steps > 0:
+        kt = it.kernel_profile(min(args.profile_steps, 200), nxt)
+        us = 1e3 * kt["frame_pipelined_ms"] / max(1, kt["launches"])
+        ach = nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        rec["roofline"] = dict(
+            bound="latency + VALU issue (chains of dependent reads of the claim tiles, the index walk and the TSDF update; "
+                  "no stream: the HBM fraction below says how far from a byte bound the launch is, not how good it is)",
+            kernel="frame_pipelined_kernel (walk role = flatten_index_tile)", achieved=round(ach, 1), peak=HBM_PEAK_GBS,
+            unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4), traffic=pmc_traffic(name + "index", "frame_pipelined_kernel"),
+            bytes_per_launch=nbytes, us_per_launch=round(us, 2),
+            bytes_formula="16*W*H + 4*W*H + numBuckets/8 + 100*allocated + 20*occ + occ*(20+4096+4096) + 100*occ "
+                          "(SURVEY.md 8(d) with numBuckets/8 + 100*allocated in place of 20*N)",
+            roles="profiles/r05_index_roles.txt (diagnostics build: each role switched off)")
+    it.table.set_option("flatten_variant", 3)
+    rec["note"] = ("vh_set_option(flatten_variant=4), pipelined like the headline path: walk over the bucket-occupancy "
+                   "bitmap (numBuckets/8 bytes) + the non-empty buckets instead of the 20*N-byte table walk; NOT the "
+                   "reference's flattenKernel, hence not `value`; bit-equal tables, voxels and compact set "
+                   "(tests/test_gpu_bench_paths.py, test_gpu_full_size.py)")
+    return rec
 
 
 def cpu_baseline_leg(args, name, poses, verts):
@@ -404,29 +443,54 @@ def cpu_baseline_leg(args, name, poses, verts):
 
 def launcher_command(argv, gpus, port):
     """What `python bench.py --gpus N` starts when it was not itself started by a launcher: the driver's own command line,
-    one rank per GPU of this node (argv = this process's arguments, passed through unchanged)."""
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
-            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    one rank per GPU of this node (argv = this process's arguments, passed through unchanged).  port 0: the launcher picks a
+    free rendezvous port itself (c10d rendezvous on 127.0.0.1:0) instead of one this process found free a moment earlier."""
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}"]
+    if port:
+        head += ["--master-addr", "127.0.0.1", "--master-port", str(port)]
+    else:
+        head += ["--rdzv-backend=c10d", "--rdzv-endpoint=127.0.0.1:0", "--local-addr", "127.0.0.1"]
+    return head + [os.path.abspath(__file__)] + list(argv)
 
 
 def self_launch(args, argv):
     """--gpus N > 1 without WORLD_SIZE: start the N ranks as a CHILD process (never exec: this process must not be replaced,
     and it never touches the GPU itself -- no torch import here), relay their output and rank 0's JSON line, return the
-    child's exit code."""
-    import socket
+    child's exit code.  The child leads a process group of its own; whatever ends this process in an orderly way (SIGTERM
+    from a driver's or pytest's timeout, SIGHUP, Ctrl-C) ends the launcher AND its ranks -- terminate, ten seconds of grace,
+    kill -- so that no orphaned rank keeps a GPU busy."""
+    import signal
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = launcher_command(argv, args.gpus, port)
+    cmd = launcher_command(argv, args.gpus, 0)
     print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC (without it RCCL's P2P set-up between
+    # processes fails with hipIpcGetMemHandle: invalid argument); the image exports it, a caller's own value wins
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
-    child = subprocess.Popen(cmd, env=env)
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+
+    def end_children(signum=None, frame=None):
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+            try:
+                os.killpg(child.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                break
+            try:
+                child.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        if signum is not None:
+            raise SystemExit(128 + signum)
+
+    old = {sig: signal.signal(sig, end_children) for sig in (signal.SIGTERM, signal.SIGHUP)}
     try:
         return child.wait()
     except KeyboardInterrupt:
-        child.terminate()
+        end_children()
         return child.wait()
+    finally:
+        for sig, h in old.items():
+            signal.signal(sig, h)
 
 
 def main():
@@ -447,6 +511,8 @@ def main():
         local_rank = 0
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)")
+    if os.environ.get("VH_BENCH_TEST_HOLD_S"):      # test hook (tests/test_bench_launch.py): ranks that stay around to be terminated
+        time.sleep(float(os.environ["VH_BENCH_TEST_HOLD_S"]))
     # (device_count() does not initialise the GPU: a rank that cannot have a device of its own says so before any HIP call)
     visible = torch.cuda.device_count()
     if os.environ.get("VH_BENCH_SHARE_GPU") != "1" and visible < world:
@@ -519,15 +585,7 @@ def main():
     # flatten step reads the 1-bit-per-bucket index and only the non-empty buckets instead of
     # every VoxelEntry; reported separately, never as `value`) ----
     if "index" in legs:
-        table.set_option("flatten_variant", 4)
-        t_idx, _ = timed_windows(it.step, sync, args.steps, args.warmup)
-        table.set_option("flatten_variant", 3)
-        extra["occupancy_index_variant"] = dict(
-            window_stats(t_idx, args.steps, it.batch), unit="frames/s",
-            flatten_bytes=wl["buckets"] // 8 + 100 * main_rec["allocated_blocks"],
-            note="vh_set_option(flatten_variant=4), pipelined like the headline path: walk over the bucket-occupancy "
-                 "bitmap (numBuckets/8 bytes) + the non-empty buckets instead of the 20*N-byte table walk; NOT the "
-                 "reference's flattenKernel, hence not `value`")
+        extra["occupancy_index_variant"] = index_variant_record(args, it, name, args.steps, args.warmup, sync)
 
     # ---- the same frames straight from uint16 sensor depth (vh_integrate_depth: preProcess's vertex
     # computation inside the claim phase, no vertex map in memory), against the two-call form
@@ -654,6 +712,10 @@ def main():
             c3_rec["two_launch_frame"] = two_launch_record(
                 args, c3_it, "C3", c3_rec["occupied_blocks"], max(50, min(args.steps, 200)), min(args.warmup, 20),
                 lambda: (c3_it.sync(), torch.cuda.synchronize()))
+        if "index" in legs:
+            c3_rec["occupancy_index_variant"] = index_variant_record(
+                args, c3_it, "C3", max(50, min(args.steps, 200)), min(args.warmup, 20),
+                lambda: (c3_it.sync(), torch.cuda.synchronize()))
         if "raycast" in legs:
             # the raycast of the C3 model (1280x960, 5 mm voxels: the per-lane walk behind the beam front end, chosen by the view)
             W3, H3 = WORKLOADS["C3"]["width"], WORKLOADS["C3"]["height"]
@@ -685,6 +747,9 @@ def main():
                                                    frames=(c3_poses[:n5], c3_verts[:n5]))
             c5_rec["workload"] = WORKLOADS["C5table"]["desc"]
             c5_rec["unit"] = "frames/s"
+            if "index" in legs:
+                c5_rec["occupancy_index_variant"] = index_variant_record(
+                    args, c5_it, "C5table", 50, 10, lambda: (c5_it.sync(), torch.cuda.synchronize()))
             extra["configs"]["C5table"] = c5_rec
             c5_it.close()
         del c3_verts
@@ -706,6 +771,15 @@ def main():
             sargs.steps, sargs.warmup = max(20, min(args.steps, 1000) // max(1, args.batch)), 5
             sargs.metric_name = baseline_metric(Wd, Ht)
             extra["sharded_world1"] = vdist.bench_sharded(sargs, wl, name, 0, 1, local_rank)
+            if "index" in legs:
+                # the same leg on the walk-free multi-camera frame (flatten_variant 4 on the shard: IndexSinkMulti)
+                iargs = argparse.Namespace(**vars(sargs))
+                iargs.option = list(getattr(sargs, "option", []) or []) + ["flatten_variant=4"]
+                irec = vdist.bench_sharded(iargs, wl, name, 0, 1, local_rank)
+                extra["sharded_world1"]["occupancy_index_variant"] = dict(
+                    value=irec["value"], unit="frames/s", ms_per_step=irec["ms_per_step"], roofline=irec["roofline"],
+                    note="vh_set_option(flatten_variant=4) on the shard: the multi-camera frame's walk over the bucket-occupancy "
+                         "bitmap; not the reference's walk, hence not the leg's value")
             dist.destroy_process_group()
         except Exception as e:       # the main line must not be lost to a transport problem
             extra["sharded_world1"] = dict(error=repr(e))
@@ -750,8 +824,11 @@ def init_dist(dist, torch, local_rank):
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    # one node by contract: keep RCCL's bootstrap and the c10d store on the loop-back interface
-    # (the container's hostname may not resolve), and surface a stuck collective in minutes
+    # One node by contract.  NCCL_SOCKET_IFNAME names the interface of RCCL's BOOTSTRAP (and of its socket transport, which
+    # GPUs of one node do not use: they talk over xGMI P2P / shared memory, chosen from the topology, not from this
+    # variable).  The bootstrap of a one-node job is safest on the loop-back interface -- these containers have no network,
+    # and their hostname may not resolve -- so it is the default here; a caller's own setting wins (setdefault), and the
+    # shared-GPU rig below needs it (its ranks are "hosts" that can only meet over sockets on lo).
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     import datetime

@@ -99,7 +99,12 @@ enum {
     VH_ERR_OUT_OF_MEMORY = 3,
     VH_ERR_HIP = 4,              /* any other HIP runtime failure; see vh_last_error() */
     VH_ERR_NOT_INITIALISED = 5,  /* drop-in call before deviceAllocate() */
-    VH_ERR_SINGULAR = 6          /* vh_icp_solve: J^T J is not positive definite */
+    VH_ERR_SINGULAR = 6,         /* vh_icp_solve: J^T J is not positive definite */
+    VH_ERR_TIMEOUT = 7           /* workgroups of a serialised one-launch frame (overflow list, option "pipeline_overflow") gave up waiting
+                                  * for the pending frame's commit phase (option "spin_limit"): frames queued since the last successful
+                                  * synchronisation have lost work.  Returned ONCE, by the first call that synchronises with the host and
+                                  * sees the counter (vh_synchronize, vh_download*, vh_dist_flush); vh_get_counters reports the count
+                                  * (spin_timeouts) without failing.  From then on the context runs such frames as two launches. */
 };
 
 /* projection / transform semantics */
@@ -330,6 +335,15 @@ int vh_download(vh_context *ctx, int which, void *host_dst, size_t bytes);  /* s
  * multi-gigabyte volume: offset = 8 * entry.ptr) */
 int vh_download_range(vh_context *ctx, int which, size_t offset_bytes, void *host_dst, size_t bytes);
 
+/* DIAGNOSTICS AND TEST FACILITIES.  They are part of the library a deployment loads -- the tests and the profiles run on the
+ * product, not on a build of their own -- and are supported as documented here; none of them changes a result:
+ *   vh_debug_eval, vh_debug_set_raycast_stamps, vh_debug_occupy (below); the loop-back transport of voxelhash_dist.h
+ *   (vh_dist_loopback_id: the N-rank exchange inside one process); vh_set_profiling / vh_get_kernel_times; the options
+ *   "spin_limit", "lean_kernels", "claim_filter", "raycast_split", "raycast_items_grid"; environment: VOXELHASH_LEAN_KERNELS
+ *   (the option's default), VOXELHASH_LOOPBACK_TIMEOUT_S (how long a loop-back rank waits for its peers), VH_ICP_BLOCKS
+ *   (workgroups of an ICP round), VOXELHASH_SEMANTICS (the drop-in names' semantics).
+ * Code that exists only in diagnostics BUILDS (make EXTRA=-D...) and in no shipped library: VH_DEBUG_SKIP_ROLES (roles of the
+ * pipelined launch return at once), VH_RAYCAST_DIAG, VH_CLAIM_STAMPS, VH_DEBUG_DIST_* (per-phase time stamps and switch-offs). */
 /* test hook: evaluates the device scalar helpers on n points; writes 8 int32 per
  * point: block x,y,z, hash, blockInFrustum, project() x,y, float->int of .w */
 int vh_debug_eval(vh_context *ctx, const vh_float4 *d_points, int32_t n, int32_t *d_out);

@@ -74,6 +74,9 @@ int vh_dist_comm_info(vh_dist *d, int32_t *rank, int32_t *world);
  * adopts `nccl_comm`, an ncclComm_t the caller owns, when it is not NULL), streams, events and the exchange buffers.
  * Collective: every rank calls it. */
 int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_ID_BYTES], void *nccl_comm, vh_dist **out);
+/* Synchronises this rank's device first.  Ranks of a loop-back group share the events of their collectives: destroy them
+ * only after every rank of the group has returned from vh_dist_flush (NativeGroup.close does), as the ranks of an RCCL
+ * group must not be destroyed inside a collective their peers are still in. */
 int vh_dist_destroy(vh_dist *d);
 
 /* this rank's shard: counters, download, snapshot, options (set before the first step) ... go through voxelhash.h */
@@ -105,13 +108,45 @@ int vh_dist_raycast(vh_dist *d, const float pose[16], float t_min, float t_max, 
 
 /* The same round with the slot capacity chosen by the library and no holes: renders, gathers every rank's lost count, and
  * repeats the round for all ranks with more room while any view lost records (the slots are one size everywhere, so the
- * ranks decide together).  Synchronises the host.  d_normals_out (nullable): camera-frame normals of the hits, as
+ * ranks decide together -- the first capacity too: the largest any rank proposes, gathered before the first round).  Synchronises the host.  d_normals_out (nullable): camera-frame normals of the hits, as
  * vh_raycast_normals.  capacity_used (nullable): the capacity that rendered every view whole.  Collective. */
 int vh_dist_raycast_auto(vh_dist *d, const float pose[16], float t_min, float t_max, float *d_depth_out,
                          vh_float4 *d_normals_out, int32_t *capacity_used);
 
 /* host seconds spent inside vh_dist_step_batch since creation / the number of calls (diagnostics for bench.py) */
 int vh_dist_host_stats(vh_dist *d, double *seconds, uint64_t *calls);
+
+/* Options of the exchange:
+ *   "force_collectives" 0 | 1   with ONE rank nothing is exchanged -- the frames are applied straight from the send buffers, no
+ *                               collective, no copy (vh_dist_transport_name still names the transport that WOULD carry them).
+ *                               1 makes a one-rank group run ncclAllToAll / ncclAllGather all the same: the call sequence of an
+ *                               R-GPU node, exercised where only one GPU is at hand.  Set before the first exchange or behind
+ *                               vh_dist_flush.
+ *   "phase_timing" 0 | 1        timing events around the three phases of every exchange (vh_dist_phase_times).  Off by default.
+ *   "raycast_auto_start" n      this rank's proposal for the slot capacity of vh_dist_raycast_auto's first round (default 4096;
+ *                               the ranks take the largest proposal, so they need not agree on it) */
+int vh_dist_set_option(vh_dist *d, const char *name, int32_t value);
+
+/* Sums over the exchanges completed since the last reset (option "phase_timing"), microseconds on the device's clock:
+ *   generate_us        the key-generation launch(es) of an exchange (its stream may share the GPU with frame launches)
+ *   collectives_us     from the moment the exchange's collectives may start (generation done, receive buffers free) to their
+ *                      completion: ncclAllToAll of the key bins + ncclAllGather of the packets (world 1: ~0, nothing is sent)
+ *   apply_us           the frame launches of the exchange on the owner, first to last
+ *   first_to_last_us   from the start of the generation to the end of the frame launches: the latency of one exchange (three
+ *                      of them overlap)
+ *   host_enqueue_us    host time inside vh_dist_step_batch for as many calls
+ * A measured scaling curve is read against these: the period of an exchange is max(generate, collectives, apply) when the
+ * three streams overlap as designed, their sum when they do not. */
+typedef struct vh_dist_phases {
+    double generate_us, collectives_us, apply_us, first_to_last_us, host_enqueue_us;
+    uint64_t exchanges;
+} vh_dist_phases;
+int vh_dist_phase_times(vh_dist *d, vh_dist_phases *out, int32_t reset);
+
+/* Start-up check of the transport: a known pattern through the two collectives an exchange uses (all-to-all of one 64 KB
+ * slice per peer, all-gather of 64 KB), compared on the device; fails loudly (VH_ERR_HIP, the count of wrong words in
+ * vh_last_error) before anything is fused or timed.  Flushes first; leaves the exchange buffers empty.  Collective. */
+int vh_dist_self_check(vh_dist *d);
 
 #ifdef __cplusplus
 }

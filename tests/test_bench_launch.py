@@ -17,6 +17,33 @@ def test_launcher_command_is_the_drivers():
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2", "--workload", "C5"]     # arguments pass through unchanged
+    # port 0 (what bench.py itself uses): the launcher picks the rendezvous port -- no port found free here and taken by another run since
+    own = bench.launcher_command(["--gpus", "2"], 2, 0)
+    assert "--master-port" not in own and "--rdzv-endpoint=127.0.0.1:0" in own and own[own.index("--local-addr") + 1] == "127.0.0.1"
+
+
+def test_a_terminated_parent_takes_its_ranks_along(tmp_path):
+    """SIGTERM to `python bench.py --gpus 2` (a driver's timeout): the launcher and its ranks end with it -- no orphan keeps a GPU busy."""
+    import signal
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["VH_BENCH_TEST_HOLD_S"] = "60"             # the ranks wait here before they look for a GPU (test hook in bench.py)
+    p = subprocess.Popen([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    deadline = time.time() + 120
+    def ranks():
+        out = subprocess.run(["pgrep", "-f", "bench.py --gpus 2 --steps 3 --warmup 1"], capture_output=True, text=True).stdout.split()
+        return [int(x) for x in out if int(x) != p.pid]
+    while time.time() < deadline and len(ranks()) < 3:      # launcher + 2 ranks
+        time.sleep(0.5)
+    assert len(ranks()) >= 3, "the ranks did not start"
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) == 128 + signal.SIGTERM
+    end = time.time() + 20                           # (the ranks got the same SIGTERM: they are gone within moments)
+    while time.time() < end and ranks():
+        time.sleep(0.5)
+    assert ranks() == [], "ranks outlived their parent"
 
 
 def test_gpus_2_without_a_launcher_starts_its_own_ranks():

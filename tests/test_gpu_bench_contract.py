@@ -87,12 +87,17 @@ def test_gpus_2_as_typed_on_a_one_gpu_box(torch_cuda):
 
 
 def test_sharded_line_names_its_transport(torch_cuda):
-    """One rank over RCCL: the line says which transport carried the exchange and how many ranks the communicator has."""
+    """One rank: the line says that NOTHING carried the exchange (a lone rank applies its frames straight from the send buffers,
+    ADVICE round 4) and which transport would; it carries the per-exchange phase times and the prediction written beforehand."""
     p = subprocess.run([sys.executable, "bench.py", "--sharded", "--steps", "3", "--warmup", "1", "--legs", "none"],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     rec = _line(p.stdout)
-    assert rec["exchange_ranks"] == {"transport": "rccl", "ranks": 1}
+    er = rec["exchange_ranks"]
+    assert er["ranks"] == 1 and er["transport"].startswith("none (one rank") and "rccl" in er["transport"] and "not run" in er["self_check"]
+    ph = rec["exchange_phases_us"]
+    assert ph["exchanges"] == 9 and ph["generate"] > 0 and ph["apply"] > ph["generate"] * 0.5 and ph["collectives"] < 15.0
+    assert rec["predicted"]["reference_walk"]["nominal"]["frames_per_s"] > 0 and "before" in rec["predicted"]["note"]
 
 
 @pytest.mark.parametrize("ranks", [2, 4])
@@ -107,6 +112,8 @@ def test_gpus_n_on_rccl_itself_with_every_rank_a_host_of_its_own(rccl_rig, ranks
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-5000:])
     rec = _line(p.stdout)
     _check(rec, ranks, 3, 1)
-    assert rec["exchange_ranks"] == {"transport": "rccl", "ranks": ranks, "shared_gpu": True}
+    assert rec["exchange_ranks"] == {"transport": "rccl", "ranks": ranks, "shared_gpu": True, "self_check": "passed (vh_dist_self_check)"}
+    assert rec["exchange_phases_us"]["exchanges"] == 9 and rec["exchange_phases_us"]["collectives"] > 0
+    assert rec["predicted"]["reference_walk"]["nominal"]["frames_per_s"] > 0
     assert "vh_dist_step_batch" in rec["exchange_host"]
     assert rec["config"]["key_bin_overflows"] == 0 and rec["config"]["occupied_blocks_all_ranks"] > 0

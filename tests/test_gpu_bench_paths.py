@@ -67,15 +67,18 @@ def _raycast_equal(ot, gt, torch, pose):
     assert (od > 0).mean() > 0.5
 
 
-@pytest.mark.parametrize("band,mode", [(0.0, 0), (0.1, 2), (0.1, 0)])
-def test_c2_integrate_batch_from_a_fresh_table(oracle, vh, torch_cuda, loop_frames, band, mode):
+@pytest.mark.parametrize("band,mode,walk", [(0.0, 0, 3), (0.1, 2, 3), (0.1, 0, 3), (0.0, 0, 4), (0.1, 2, 4)])
+def test_c2_integrate_batch_from_a_fresh_table(oracle, vh, torch_cuda, loop_frames, band, mode, walk):
     """`value` (band 0), `loaded_integrate` (band 0.1 by the block DDA along the viewing ray, VH_BAND_RAY_DDA) and its
-    `ray_samples_variant` (VH_BAND_RAY): vh_integrate_batch(8), pipelined frames, fresh table."""
+    `ray_samples_variant` (VH_BAND_RAY): vh_integrate_batch(8), pipelined frames, fresh table.  walk 4: the same as
+    `occupancy_index_variant` runs them -- the walk-free frame (flatten_variant 4: its lean build without a band, the generic
+    build with one)."""
     torch = torch_cuda
     poses, verts = loop_frames
     ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
     gt = vh.SDFHashtable(vh.default_params(**KW), W, H, 1)
     gt.set_option("pipeline", 1)                       # as bench.py's Integrator does
+    gt.set_option("flatten_variant", walk)
     if band:
         ot.set_alloc_band(band, mode)
         gt.set_alloc_band(band)
@@ -123,13 +126,15 @@ def test_c2_sensor_depth_frames_from_a_fresh_table(oracle, vh, torch_cuda, loop_
     ot.close()
 
 
-@pytest.mark.parametrize("world", [1, 2])
-def test_c2_sharded_native_exchange(oracle, vh, torch_cuda, loop_frames, world):
+@pytest.mark.parametrize("world,walk", [(1, 3), (2, 3), (1, 4), (2, 4)])
+def test_c2_sharded_native_exchange(oracle, vh, torch_cuda, loop_frames, world, walk):
     """`sharded_world1` and the N > 1 lines: the bucket-range-sharded path as bench.py runs it -- vh_dist_step_batch inside the
     library (key generation from the sensor images into ONE bin per (owner, batch), all-to-all of the bins, all-gather of the
     sensor packets, vh_apply_frames_batch with the batch's last frame deferred into the next exchange) at C2's table size,
     batches of 8, the library's default bin size.  world 1: over RCCL (ncclCommInitRank with one rank, as the bench leg);
-    world 2: two ranks of this process over the loop-back transport, each camera feeding its own 48 frames of the loop."""
+    world 2: two ranks of this process over the loop-back transport, each camera feeding its own 48 frames of the loop.
+    walk 4: the shards run the walk-free multi-camera frame (flatten_variant 4: the occupancy-index walk for all cameras), as
+    `sharded_world1.occupancy_index_variant` does."""
     from test_gpu_configs import assert_slice_equals, compare_blocks
     from voxelhashing_demo_amd import dist as vdist
     torch = torch_cuda
@@ -150,6 +155,8 @@ def test_c2_sharded_native_exchange(oracle, vh, torch_cuda, loop_frames, world):
     else:
         group = vdist.NativeGroup(vh.default_params(**KW), W, H, 1, world, BATCH, sensor_k_inv=kinv)
         ranks = group.ranks
+    for nd in ranks:
+        nd.table.set_option("flatten_variant", walk)
     for k in range(0, n, BATCH):
         if group:
             group.step([cam_poses[r][k:k + BATCH] for r in range(world)], [dd[r][k:k + BATCH] for r in range(world)])

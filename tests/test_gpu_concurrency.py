@@ -136,9 +136,10 @@ def test_serialised_launches_while_another_kernel_holds_the_chip(oracle, vh, tor
 
 
 def test_a_serialised_launch_that_times_out_is_reported_and_bounded(oracle, vh, torch_cuda):
-    """With "spin_limit" 1 every waiting workgroup gives up at its first look: the launch returns (no hang), the counter says
-    so, and from the moment the host has seen it the context's overflow-list frames take two launches each -- which are exact
-    again from a fresh table."""
+    """With "spin_limit" 1 every waiting workgroup gives up at its first look: the launch returns (no hang), the FIRST call that
+    synchronises with the host fails with VH_ERR_TIMEOUT (a host that never polls the counters must not keep
+    fusing into a model that has lost work) -- once --, the counter says how many gave up, and from that moment the context's
+    overflow-list frames take two launches each."""
     torch = torch_cuda
     kw = dict(numBuckets=512, bucketSize=2, numVoxelBlocks=4096, attachedLinkedListSize=8)
     frames = _collision_frames(8)
@@ -149,11 +150,21 @@ def test_a_serialised_launch_that_times_out_is_reported_and_bounded(oracle, vh, 
     gt.set_option("spin_limit", 1)
     dv = [torch.from_numpy(v).cuda() for _, v in frames]
     gt.integrate_batch([p for p, _ in frames], dv)
-    gt.synchronize()
-    assert gt.counters()["spin_timeouts"] > 0                     # (seen by the host: the context falls back)
+    with pytest.raises(vh.VoxelHashError, match="gave up waiting"):
+        gt.synchronize()                                          # VH_ERR_TIMEOUT, latched at this synchronisation
+    gt.synchronize()                                              # (reported once)
+    assert gt.counters()["spin_timeouts"] > 0
     gt.set_profiling(True)
     gt.integrate_batch([p for p, _ in frames[:4]], dv[:4])
     gt.synchronize()
     kt = gt.kernel_times(reset=True)
     assert kt["frame_pipelined_ms"] == 0 and kt["frame_scan_claim_ms"] > 0 and kt["frame_commit_integrate_ms"] > 0
     gt.close()
+    # ... and a host that downloads the table instead of synchronising hears of it there
+    g2 = vh.SDFHashtable(vh.default_params(**kw), 160, 120, 1)
+    for k, v in (("overflow_list", 1), ("pipeline", 1), ("pipeline_overflow", 2), ("spin_limit", 1)):
+        g2.set_option(k, v)
+    g2.integrate_batch([p for p, _ in frames], dv)
+    with pytest.raises(vh.VoxelHashError, match="gave up waiting"):
+        g2.hash_table()
+    g2.close()

@@ -64,8 +64,15 @@ def test_native_ranks_equal_one_oracle_table(oracle, vh, torch_cuda, world, batc
     # (the library's default bin size for every split, the ragged three-way one included)
     g = vdist.NativeGroup(vh.default_params(**kw), W, H, 1, world, batch, sensor_k_inv=kinv if sensor else None)
     assert all(nd.transport == "loopback" and nd.comm_info() == (r, world) for r, nd in enumerate(g.ranks))
+    g.self_check()                      # the start-up check bench.py runs at N > 1: a pattern through both collectives
+    for nd in g.ranks:
+        nd.set_option("phase_timing", 1)
     _feed(g, full, frames, batch)
     g.flush()
+    for nd in g.ranks:                  # per-exchange phase times (bench.py: exchange_phases_us): every exchange accounted for
+        ph = nd.phase_times()
+        assert ph["exchanges"] == steps // batch and ph["generate"] > 0 and ph["collectives"] > 0 and ph["apply"] > 0, ph
+        nd.set_option("phase_timing", 0)
     plan = vdist.ShardPlan(kw["numBuckets"], world)
     total = 0
     for r, t in enumerate(g.tables):
@@ -125,12 +132,13 @@ def test_raycast_round_that_finds_its_own_slot_capacity(oracle, vh, torch_cuda, 
     full = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
     g = vdist.NativeGroup(vh.default_params(**kw), W, H, 1, world, batch, sensor_k_inv=kinv)
     _feed(g, full, frames, batch)
-    monkeypatch.setenv("VOXELHASH_RAYCAST_AUTO_START", "16")
+    g.ranks[0].set_option("raycast_auto_start", 16)              # (rank 1 proposes the default 4096 ... which is capped by the
+    g.ranks[1].set_option("raycast_auto_start", 24)              #  shard's pool; the ranks start from the LARGEST proposal: 24)
     poses = [c[0] for c in frames[-1]]
     outs = [torch.empty((H, W), dtype=torch.float32, device="cuda") for _ in range(world)]
     nrm = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(world)]
     caps = g._all(lambda r, nd: nd.raycast_auto(poses[r], outs[r], nrm[r]))
-    assert caps[0] == caps[1] > 16                               # (the ranks agree; 16 slots were not enough)
+    assert caps[0] == caps[1] > 24                               # (the ranks agree; 24 slots were not enough)
     for r in range(world):
         od, on = full.raycast(poses[r], normals=True)
         assert np.array_equal(outs[r].cpu().numpy().view(np.uint32), od.view(np.uint32))

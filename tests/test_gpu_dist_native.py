@@ -26,8 +26,12 @@ def _frames(n):
     return poses, [synth.render_room_verts(p, W, H, prims).numpy() for p in poses]
 
 
-@pytest.mark.parametrize("sensor", [True, False])
-def test_native_exchange_with_one_rank_equals_the_oracle(oracle, vh, torch_cuda, sensor):
+@pytest.mark.parametrize("sensor,forced", [(True, False), (False, False), (True, True), (False, True)])
+def test_native_exchange_with_one_rank_equals_the_oracle(oracle, vh, torch_cuda, sensor, forced):
+    """forced: vh_dist_set_option "force_collectives" -- a one-rank group applies its frames straight from the send buffers (no
+    collective); forced, it runs ncclAllToAll + ncclAllGather all the same, through the receive buffers: the
+    call sequence of an R-GPU node driven through vh_dist_step_batch without the NCCL_HOSTID rig.  Both: the start-up self-check
+    of the transport, and the per-exchange phase times."""
     torch = torch_cuda
     batch, steps = 3, 5
     poses, verts = _frames(batch * steps)
@@ -41,12 +45,20 @@ def test_native_exchange_with_one_rank_equals_the_oracle(oracle, vh, torch_cuda,
         frames = [torch.from_numpy(v).cuda() for v in verts]
     torch.cuda.synchronize()
     nd = vdist.NativeDist(vh.default_params(**KW), W, H, 1, 0, 1, batch, vdist.unique_id(), sensor_k_inv=kinv if sensor else None)
+    nd.self_check()                                     # a pattern through ncclAllToAll / ncclAllGather, compared on the device
+    nd.set_option("force_collectives", 1 if forced else 0)
+    nd.set_option("phase_timing", 1)
     for s in range(steps):
         k = s * batch
         nd.step(poses[k:k + batch], frames[k:k + batch])
         for j in range(k, k + batch):
             ot.integrate(poses[j], verts[j])            # one camera: the multi-camera frame is integrate()
     nd.flush()
+    ph = nd.phase_times()
+    assert ph["exchanges"] == steps and ph["generate"] > 0 and ph["apply"] > 0 and ph["first_to_last"] >= ph["apply"]
+    # nothing is sent by a lone rank unless forced: the two timing events back to back (~6 us) against two RCCL kernels
+    assert (ph["collectives"] > 15.0) == forced, ph
+    nd.set_option("phase_timing", 0)
     assert check_shard_against_full(nd.table, ot, 0, KW["numBuckets"], 5) > 100
     c = nd.table.counters()
     assert c["bin_overflow"] == 0 and c["epoch"] == batch * steps

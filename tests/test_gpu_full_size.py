@@ -32,20 +32,39 @@ def test_c2_full_size_against_oracle(oracle, vh, torch_cuda):
     assert len(gt.allocated()) > 500
 
 
-def test_c3_full_size_properties(oracle, vh, torch_cuda):
+@pytest.mark.parametrize("walk", [3, 4])
+def test_c3_full_size_properties(oracle, vh, torch_cuda, walk):
+    """walk 3: the reference's walk, two-launch frames.  walk 4: the walk-free frame PIPELINED at C3's size (flatten_variant 4
+    through vh_integrate_batch: the build bench.py's configs.C3.occupancy_index_variant times; 2^22 buckets: 128 index tiles,
+    a table beyond the Infinity Cache: the non-temporal build), exact for the first frames, properties after."""
     torch = torch_cuda
     W, H = 1280, 960
     kw = dict(numBuckets=1 << 22, numVoxelBlocks=1 << 16, voxelSize=0.005)
     ot = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
     gt = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
-    frames = _frames(W, H, (0, 1))
-    for pose, verts in frames:
-        ot.integrate(pose, verts)
-        gt.integrate(pose, torch.from_numpy(verts).cuda())
+    gt.set_option("flatten_variant", walk)
+    frames = _frames(W, H, (0, 1) if walk == 3 else (0, 1, 2, 3))
+    if walk == 4:
+        gt.set_option("pipeline", 1)
+        d_frames = [torch.from_numpy(v).cuda() for _, v in frames]         # (alive until the synchronisation below)
+        gt.integrate_batch([p for p, _ in frames], d_frames)
+        for pose, verts in frames:
+            ot.integrate_mt(pose, verts, 16)
+    else:
+        for pose, verts in frames:
+            ot.integrate(pose, verts)
+            gt.integrate(pose, torch.from_numpy(verts).cuda())
     gt.synchronize()
     otab, gtab = ot.hash_table(), gt.hash_table()
     assert np.array_equal(otab["pos"], gtab["pos"])                       # exact, 21 M entries
     assert gt.counters()["occupied"] == len(ot.compact())
+    if walk == 4:            # the voxels of every 5th block, bit for bit (the pipelined TSDF update read the index walk's list)
+        ovol, live = ot.sdf_blocks(), np.nonzero(gtab["ptr"] != -1)[0]
+        for i in live[::5]:
+            g = gt.block_voxels(int(gtab["ptr"][i]))
+            o = ovol[int(otab["ptr"][i]):int(otab["ptr"][i]) + 512]
+            assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+        assert entries_as_set(gt.compact()) == entries_as_set(ot.compact())
     # -- properties from here on (no oracle) --
     pose, verts = frames[1]
     d_verts = torch.from_numpy(verts).cuda()

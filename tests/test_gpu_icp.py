@@ -117,6 +117,33 @@ def test_drop_in_compute_correspondences(oracle, vh, torch_cuda):
     assert abs(err - oerr) <= SUM_RTOL * max(abs(oerr), 0.08 * np.sqrt(ocnt))
 
 
+def test_partial_sums_hand_off_while_another_kernel_holds_the_chip(oracle, vh, torch_cuda):
+    """The last workgroup of an ICP round adds what all the others stored (records written as agent-scope stores, drained, then
+    a ticket -- no cache write-back, vh_icp.hip).  Here a long kernel of another stream holds most workgroup
+    slots of every XCD while 60 rounds run, so that a round's workgroups trickle in on whatever compute unit comes free: every
+    round must still give the sums it gives on an idle chip, bit for bit (fixed summation order), and the oracle's within the
+    fp32 tolerance."""
+    from voxelhashing_demo_amd import tracking
+    torch = torch_cuda
+    K, v0, v1, true = frame_pair(100, 101, 250)
+    kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    p0, n0, g0, gn0 = maps_on_both(oracle, torch, v0[..., 2], kinv)
+    p1, _, g1, _ = maps_on_both(oracle, torch, v1[..., 2], kinv)
+    trk = tracking.CameraTracking(W, H, K, flags=0)
+    d32 = true.astype(np.float32)
+    idle = trk.build_system(g1, g0, gn0, d32)
+    close_sums(idle, oracle.icp_build_system(p1, p0, n0, d32, K, 0.08, 0))
+    gt = vh.SDFHashtable(vh.default_params(numBuckets=1 << 10, numVoxelBlocks=64), 64, 48, 1)      # (only for vh_debug_occupy)
+    hog, L = torch.cuda.Stream(), vh.load()
+    for burst in range(6):
+        assert L.vh_debug_occupy(gt._h, hog.cuda_stream, 1792, 20000) == 0                          # 20 ms of a nearly full chip
+        for _ in range(10):
+            got = trk.build_system(g1, g0, gn0, d32)
+            assert np.array_equal(got[0], idle[0]) and np.array_equal(got[1], idle[1]) and got[2] == idle[2] and got[3] == idle[3]
+    torch.cuda.synchronize()
+    gt.close()
+
+
 @pytest.mark.parametrize("flags", [0, 3])
 def test_align_matches_oracle_and_truth(oracle, vh, torch_cuda, flags):
     from voxelhashing_demo_amd import tracking

@@ -64,6 +64,6 @@ for name, t, rays in (("fused", a, ra), ("four-kernel", b, rb), ("fused-indexed"
     for k, (x, y) in enumerate(zip(rays, ro)):
         assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (name, "raycast", k)
     cnt = t.counters()
-    assert cnt["heap_exhausted"] == 0 and cnt["heap_counter"] == ot.heap_counter(), name
+    assert cnt["heap_exhausted"] == 0 and cnt["heap_counter"] == ot.heap_counter() and cnt["spin_timeouts"] == 0, name
     print(name, "ok: blocks", len(live), "freed", cnt["freed_total"], "raycasts", len(rays))
 print("SOAK OK")

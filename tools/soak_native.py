@@ -63,6 +63,7 @@ g.flush()
 from test_sharding_cpu import check_shard_against_full
 tot = sum(check_shard_against_full(t, full, *plan.bucket_range(r), 5) for r, t in enumerate(g.tables))
 ov = sum(t.counters()["bin_overflow"] for t in g.tables)
+assert all(t.counters()["spin_timeouts"] == 0 for t in g.tables), "a serialised launch gave up waiting"
 print(f"done: {N} exchanges x {B} frames x {R} cameras, {tot} blocks bit-equal, bin overflows {ov}, mismatches {bad}")
 g.close()
 sys.exit(1 if bad else 0)

@@ -55,7 +55,7 @@ for step in range(steps):
             sh.table.synchronize()
             total += check_shard_against_full(sh.table, full, *plan.bucket_range(r), 5)
             c = sh.table.counters()
-            assert c["bin_overflow"] == 0 and c["heap_exhausted"] == 0
+            assert c["bin_overflow"] == 0 and c["heap_exhausted"] == 0 and c["spin_timeouts"] == 0
         assert total == len(full.allocated())
         print(f"exchange {step}: {total} blocks, {freed} freed, raycasts bit-equal, {time.time() - t0:.0f} s", flush=True)
 print("SHARDED SOAK OK")

@@ -167,6 +167,12 @@ SIGNATURES = {
 
 
 
+class DistPhases(C.Structure):
+    """vh_dist_phases (include/voxelhash_dist.h): sums over the exchanges completed since the last reset."""
+    _fields_ = [("generate_us", C.c_double), ("collectives_us", C.c_double), ("apply_us", C.c_double),
+                ("first_to_last_us", C.c_double), ("host_enqueue_us", C.c_double), ("exchanges", C.c_uint64)]
+
+
 class DistConfig(C.Structure):
     """vh_dist_config of include/voxelhash_dist.h."""
     _fields_ = [("table", Config), ("rank", C.c_int32), ("world", C.c_int32), ("batch", C.c_int32),
@@ -183,6 +189,9 @@ DIST_SIGNATURES = {
     "vh_dist_flush": (C.c_int, [_vp]),
     "vh_dist_raycast": (C.c_int, [_vp, _fp, _f, _f, C.c_int32, _vp, _vp]),
     "vh_dist_host_stats": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "vh_dist_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int32]),
+    "vh_dist_phase_times": (C.c_int, [_vp, C.POINTER(DistPhases), C.c_int32]),
+    "vh_dist_self_check": (C.c_int, [_vp]),
     "vh_dist_probe": (C.c_int, []),
     "vh_dist_raycast_auto": (C.c_int, [_vp, _fp, _f, _f, _vp, _vp, C.POINTER(C.c_int32)]),
     "vh_dist_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

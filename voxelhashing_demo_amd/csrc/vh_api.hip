@@ -126,6 +126,8 @@ struct vh_context {
     int genFramesPerLaunch = 4;            // option "gen_frames_per_launch": frames of a batch one key-generation launch takes (1..8)
     uint32_t spinLimit = 0;                // option "spin_limit": polls a workgroup of a serialised pipelined launch waits for the pending commit phase (0: kSpinLimitDefault)
     int pipelineOverflow = 1;              // option "pipeline_overflow": one-launch (serialised) frames with the overflow list: 0 never, 1 by the launch's size (default), 2 always
+    bool serialQueued = false;             // a serialised launch has been queued since the host last looked at kSpinTimeouts (check_spin_timeouts)
+    uint32_t spinSeen = 0;                 // ... and what the counter read then
     bool serialFallback = false;           // a serialised launch has timed out (vh_counters.spin_timeouts): overflow-list frames take two launches from now on
     int leanKernels = 1;                   // option "lean_kernels": builds of the pipelined launch with the option flags folded in (A/B switch)
     int debugSkipRoles = 0;                // diagnostics: roles of the pipelined launch that return at once (timing only; the model is wrong)
@@ -238,6 +240,7 @@ extern "C" const char *vh_error_string(int code)
         case VH_ERR_HIP: return "HIP runtime error";
         case VH_ERR_NOT_INITIALISED: return "deviceAllocate() has not been called";
         case VH_ERR_SINGULAR: return "singular linear system";
+        case VH_ERR_TIMEOUT: return "a serialised launch gave up waiting (spin_limit): frames have lost work";
         default: return "unknown error";
     }
 }
@@ -267,6 +270,7 @@ static void default_projection(vh_context *c)
     c->rc_fx = fx; c->rc_fy = fy; c->rc_cx = cx; c->rc_cy = cy;
 }
 
+static int check_spin_timeouts(vh_context *c);  // vh_api_model.hip: behind a host synchronisation, VH_ERR_TIMEOUT if a serialised launch gave up
 static int flush_pending(vh_context *c);       // vh_api_frame.hip: launches a pipelined frame's deferred half
 static int flush_single_pending(vh_context *c);
 static int flush_multi_pending(vh_context *c);     // vh_api_shard.hip: the same for a multi-camera frame (pipeline_shards 2)

@@ -195,8 +195,14 @@ struct vh_dist {
     int32_t viewCapacity = 0;
     int32_t *lostDev = nullptr;            // vh_dist_raycast_auto: [0] this view's lost records, [1..R] every rank's
     int32_t autoCapacity = 0;              // ... and the slot capacity that last rendered every view whole
+    int32_t autoStart = 4096;              // option "raycast_auto_start": this rank's proposal for the first round (the ranks take the largest)
     double hostSeconds = 0.0;
     uint64_t hostCalls = 0;
+    bool forceCollectives = false;         // option "force_collectives": world 1 runs ncclAllToAll / ncclAllGather anyway (tests; the bench's first rounds)
+    // option "phase_timing": per-exchange phase times from timing events of the library's own (vh_dist_phase_times)
+    bool phaseTiming = false;
+    struct PhaseEvents { hipEvent_t gen0 = nullptr, gen1 = nullptr, comm0 = nullptr, comm1 = nullptr, app0 = nullptr, app1 = nullptr; bool armed = false, applied = false; } phaseEv[kSets];
+    vh_dist_phases phases{};
 };
 
 // ---------------------------------------------------------------------------
@@ -315,6 +321,9 @@ static void dist_free(vh_dist *d)
             if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {d->userEvent, d->outEvent})
         if (e) (void)hipEventDestroy(e);
+    for (auto &pe : d->phaseEv)
+        for (hipEvent_t e : {pe.gen0, pe.gen1, pe.comm0, pe.comm1, pe.app0, pe.app1})
+            if (e) (void)hipEventDestroy(e);
     if (d->transport) d->transport->leave(d);
     for (hipStream_t s : {d->sGen, d->sComm, d->sTable})
         if (s) (void)hipStreamDestroy(s);
@@ -460,6 +469,114 @@ extern "C" int vh_dist_set_user_stream(vh_dist *d, void *stream, int32_t enable)
     return VH_OK;
 }
 
+// Phase timing (option "phase_timing"): six timing events per buffer set -- generation launch(es), the collectives, the frame
+// launches of the set's exchange -- harvested when the set comes round again or at a flush.  Off by default: a timing event
+// is a timestamp write behind a cache write-back, which the timed windows of bench.py do not pay.
+static void phases_harvest(vh_dist *d, int s)
+{
+    vh_dist::PhaseEvents &e = d->phaseEv[s];
+    if (!e.armed || !e.applied) return;
+    // (the set comes round again three exchanges later: its frames are normally done; if not, this diagnostics mode waits)
+    if (hipEventSynchronize(e.app1) != hipSuccess) return;
+    float gen = 0, comm = 0, app = 0, lag = 0;
+    if (hipEventElapsedTime(&gen, e.gen0, e.gen1) == hipSuccess && hipEventElapsedTime(&comm, e.comm0, e.comm1) == hipSuccess &&
+        hipEventElapsedTime(&app, e.app0, e.app1) == hipSuccess && hipEventElapsedTime(&lag, e.gen0, e.app1) == hipSuccess) {
+        d->phases.generate_us += 1e3 * gen; d->phases.collectives_us += 1e3 * comm; d->phases.apply_us += 1e3 * app;
+        d->phases.first_to_last_us += 1e3 * lag;
+        d->phases.exchanges += 1;
+    }
+    e.armed = false; e.applied = false;
+}
+
+extern "C" int vh_dist_set_option(vh_dist *d, const char *name, int32_t value)
+{
+    if (!d || !name) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(d->device);
+    if (std::strcmp(name, "force_collectives") == 0) {
+        if (d->count != 0 && d->pending >= 0) return fail(VH_ERR_INVALID_ARGUMENT, "force_collectives: set it before the first exchange or behind vh_dist_flush");
+        d->forceCollectives = value != 0;
+        return VH_OK;
+    }
+    if (std::strcmp(name, "raycast_auto_start") == 0 && value >= 1) { d->autoStart = value; return VH_OK; }
+    if (std::strcmp(name, "phase_timing") == 0) {
+        if (value && !d->phaseEv[0].gen0)
+            for (auto &e : d->phaseEv)
+                for (hipEvent_t *ev : {&e.gen0, &e.gen1, &e.comm0, &e.comm1, &e.app0, &e.app1}) VH_HIP(hipEventCreate(ev));
+        for (auto &e : d->phaseEv) { e.armed = false; e.applied = false; }
+        d->phaseTiming = value != 0;
+        return VH_OK;
+    }
+    return fail(VH_ERR_INVALID_ARGUMENT, "unknown option");
+}
+
+extern "C" int vh_dist_phase_times(vh_dist *d, vh_dist_phases *out, int32_t reset)
+{
+    if (!d || !out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(d->device);
+    for (int s = 0; s < vh_dist::kSets; ++s) phases_harvest(d, s);
+    *out = d->phases;
+    out->host_enqueue_us = d->hostCalls ? 1e6 * d->hostSeconds / (double)d->hostCalls * (double)d->phases.exchanges : 0.0;
+    if (reset) d->phases = vh_dist_phases{};
+    return VH_OK;
+}
+
+// Start-up self-check of the transport (VERDICT round 4, next #4c): a known pattern through the same two collectives an exchange
+// uses -- all-to-all of one 64 KB slice per peer, all-gather of 64 KB -- compared on the device, before anything is timed or fused.
+__global__ void dist_pattern_kernel(uint32_t *a2a, uint32_t *gather, int32_t rank, int32_t world, uint32_t words)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words) return;
+    for (int p = 0; p < world; ++p) a2a[(size_t)p * words + i] = 0x9e3779b9u * (uint32_t)(rank * 64 + p + 1) + i;     // what `rank` sends to p
+    gather[i] = 0x85ebca6bu * (uint32_t)(rank + 1) ^ i;
+}
+__global__ void dist_pattern_check_kernel(const uint32_t *a2a, const uint32_t *gather, int32_t rank, int32_t world, uint32_t words, int32_t *bad)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= words) return;
+    int n = 0;
+    for (int p = 0; p < world; ++p) {
+        n += a2a[(size_t)p * words + i] != 0x9e3779b9u * (uint32_t)(p * 64 + rank + 1) + i;      // what p sent to `rank`
+        n += gather[(size_t)p * words + i] != (0x85ebca6bu * (uint32_t)(p + 1) ^ i);
+    }
+    if (n) atomicAdd(bad, n);
+}
+extern "C" int vh_dist_self_check(vh_dist *d)
+{
+    if (!d) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(d->device);
+    int rc = vh_dist_flush(d);
+    if (rc != VH_OK) return rc;
+    const int R = d->cfg.world;
+    // up to 64 KB per peer, what the smaller of a key bin and this rank's packets holds (in whole 1 KB pieces)
+    const uint32_t words = (uint32_t)std::min<size_t>(16384, std::min<size_t>((size_t)d->capacity * 4, (size_t)d->cfg.batch * d->packetUnits)) & ~255u;
+    if (words == 0) return fail(VH_ERR_INVALID_ARGUMENT, "vh_dist_self_check: exchange buffers smaller than 1 KB");
+    vh_dist::Set &set = d->set[0];
+    int32_t *bad = nullptr;
+    VH_HIP(hipMalloc((void **)&bad, sizeof(int32_t)));
+    VH_HIP(hipMemsetAsync(bad, 0, sizeof(int32_t), d->sComm));
+    dist_pattern_kernel<<<dim3(words / 256), dim3(256), 0, d->sComm>>>(reinterpret_cast<uint32_t *>(set.binsSend), reinterpret_cast<uint32_t *>(set.packet), d->cfg.rank, R, words);
+    rc = d->transport->all_to_all(d, set.binsSend, set.binsRecv, (size_t)words * 4, d->sComm);
+    if (rc == VH_OK) rc = d->transport->all_gather(d, set.packet, set.packets, (size_t)words * 4, d->sComm);
+    if (rc != VH_OK) { (void)hipFree(bad); return rc; }
+    dist_pattern_check_kernel<<<dim3(words / 256), dim3(256), 0, d->sComm>>>(reinterpret_cast<const uint32_t *>(set.binsRecv), reinterpret_cast<const uint32_t *>(set.packets), d->cfg.rank, R, words, bad);
+    int32_t n = -1;
+    hipError_t e = hipMemcpyAsync(&n, bad, sizeof n, hipMemcpyDeviceToHost, d->sComm);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->sComm);
+    // the buffers go back to what vh_dist_create left: empty bins (a header record of zero keys)
+    const size_t binBytes = (size_t)R * (size_t)d->capacity * 4 * sizeof(int32_t);
+    if (e == hipSuccess) e = hipMemsetAsync(set.binsSend, 0, binBytes, d->sComm);
+    if (e == hipSuccess) e = hipMemsetAsync(set.binsRecv, 0, binBytes, d->sComm);
+    if (e == hipSuccess) e = hipStreamSynchronize(d->sComm);
+    (void)hipFree(bad);
+    if (e != hipSuccess) return fail(VH_ERR_HIP, "vh_dist_self_check", e);
+    if (n != 0) {
+        char msg[160];
+        std::snprintf(msg, sizeof msg, "vh_dist_self_check: rank %d of %d received %d wrong words through the %s transport", d->cfg.rank, R, n, d->transport->name);
+        return fail(VH_ERR_HIP, msg);
+    }
+    return VH_OK;
+}
+
 static int dist_apply(vh_dist *d, int s)
 {
 #ifndef VH_DEBUG_DIST_NO_READY_WAIT          // (diagnostics builds: what the two event operations at a batch's boundary cost)
@@ -469,10 +586,15 @@ static int dist_apply(vh_dist *d, int s)
 #ifndef VH_DEBUG_DIST_NO_FIRST
     d->shard->multiFirstEvent = d->first[s];
 #endif
-    const bool alone = d->cfg.world == 1;
+    const bool alone = d->cfg.world == 1 && !d->forceCollectives;
+    if (d->phaseTiming && d->phaseEv[s].armed) VH_HIP(hipEventRecord(d->phaseEv[s].app0, d->sTable));
     const int rc = vh_apply_frames_batch(d->shard, d->cfg.batch, alone ? d->set[s].binsSend : d->set[s].binsRecv, d->cfg.world, d->capacity, 0,
                                          VH_BIN_PER_BATCH, d->cfg.world, alone ? d->set[s].packet : d->set[s].packets, 0, 0);
     d->shard->multiFirstEvent = nullptr;
+    if (rc == VH_OK && d->phaseTiming && d->phaseEv[s].armed) {
+        VH_HIP(hipEventRecord(d->phaseEv[s].app1, d->sTable));
+        d->phaseEv[s].applied = true;
+    }
     return rc;
 }
 
@@ -494,7 +616,13 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     if (d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sGen, d->ready[s], 0));
     // (one rank: the frames are applied straight from the send buffers, so those are free only when the frames of exchange
     // count-3 are done, the last of which rode in the first launch of exchange count-2's frames)
-    if (R == 1 && d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sGen, d->first[(s + 1) % vh_dist::kSets], 0));
+    const bool alone = R == 1 && !d->forceCollectives;
+    if (alone && d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sGen, d->first[(s + 1) % vh_dist::kSets], 0));
+    if (d->phaseTiming) {
+        phases_harvest(d, s);
+        d->phaseEv[s].armed = hipEventRecord(d->phaseEv[s].gen0, d->sGen) == hipSuccess;
+        d->phaseEv[s].applied = false;
+    }
     d->shard->stream = d->sGen;
 #ifdef VH_DEBUG_DIST_SKIP_GEN
     // diagnostics build (tools/ab_variants.sh): from the 7th exchange on nothing is generated -- the frames re-apply what the
@@ -510,6 +638,7 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
                                     set.binsSend, d->capacity, 0, VH_BIN_PER_BATCH, set.packet, 0);
     d->shard->stream = d->sTable;
     if (rc != VH_OK) return rc;
+    if (d->phaseTiming && d->phaseEv[s].armed) VH_HIP(hipEventRecord(d->phaseEv[s].gen1, d->sGen));
     VH_HIP(hipEventRecord(d->generated[s], d->sGen));
     // (the frames have been consumed once `generated` fires: the caller's stream may overwrite them behind it)
     if (d->haveUser) VH_HIP(hipStreamWaitEvent(d->userStream, d->generated[s], 0));
@@ -517,10 +646,12 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     // the first launch of exchange count-2's frames (queued by the previous call)
     VH_HIP(hipStreamWaitEvent(d->sComm, d->generated[s], 0));
     if (d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sComm, d->first[(s + 1) % vh_dist::kSets], 0));
-    if (R > 1) {
+    if (d->phaseTiming && d->phaseEv[s].armed) VH_HIP(hipEventRecord(d->phaseEv[s].comm0, d->sComm));      // (behind the waits: when the collectives may start)
+    if (!alone) {
         if ((rc = d->transport->all_to_all(d, set.binsSend, set.binsRecv, (size_t)d->capacity * 4 * sizeof(int32_t), d->sComm)) != VH_OK) return rc;
         if ((rc = d->transport->all_gather(d, set.packet, set.packets, (size_t)B * d->packetUnits * sizeof(float), d->sComm)) != VH_OK) return rc;
     }
+    if (d->phaseTiming && d->phaseEv[s].armed) VH_HIP(hipEventRecord(d->phaseEv[s].comm1, d->sComm));
     // (one rank: the only bin and the only packet are this rank's own -- the frames are applied straight from the send
     // buffers, no collective and no copy; the events order the hand-offs as with peers)
     VH_HIP(hipEventRecord(d->ready[s], d->sComm));
@@ -553,7 +684,7 @@ extern "C" int vh_dist_flush(vh_dist *d)
     VH_HIP(hipStreamSynchronize(d->sTable));
     VH_HIP(hipStreamSynchronize(d->sComm));
     VH_HIP(hipStreamSynchronize(d->sGen));
-    return VH_OK;
+    return check_spin_timeouts(d->shard);      // (VH_ERR_TIMEOUT: a serialised multi-camera launch gave up waiting, voxelhash.h)
 }
 
 static int dist_raycast_impl(vh_dist *d, const float pose[16], float t_min, float t_max, int32_t capacity, float *d_depth_out,
@@ -644,10 +775,24 @@ extern "C" int vh_dist_raycast_auto(vh_dist *d, const float pose[16], float t_mi
     // a shard cannot select more blocks than its pool holds, and the view table lists one imported record per entry
     const int64_t most = std::max<int64_t>(1, std::min<int64_t>((int64_t)d->cfg.table.params.numVoxelBlocks,
         (int64_t)d->cfg.table.params.numBuckets * d->cfg.table.params.bucketSize / R));
-    int32_t first = 4096;                               // (VOXELHASH_RAYCAST_AUTO_START: a smaller first try, for the test of the retry)
-    if (const char *e = std::getenv("VOXELHASH_RAYCAST_AUTO_START")) first = std::max(1, std::atoi(e));
+    const int32_t first = d->autoStart;                 // (option "raycast_auto_start": 4096 unless a caller -- the test of the retry -- asks otherwise)
     int32_t cap = (int32_t)std::min<int64_t>(most, std::max<int32_t>(d->autoCapacity, first));
-    for (int attempt = 0; attempt < 8; ++attempt) {
+    {
+        // The slots are one size everywhere and every rank issues an all-to-all of that size: the ranks AGREE on the first
+        // capacity (the largest any of them proposes) instead of trusting that their local state -- the capacity of their last
+        // call, an environment variable -- is identical; ranks that disagreed would hang in mismatched collectives.
+        int rc = vh_dist_flush(d);
+        if (rc != VH_OK) return rc;
+        VH_HIP(hipMemcpyAsync(d->lostDev, &cap, sizeof cap, hipMemcpyHostToDevice, d->sTable));
+        if ((rc = d->transport->all_gather(d, d->lostDev, d->lostDev + 1, sizeof(int32_t), d->sTable)) != VH_OK) return rc;
+        int32_t proposed[VH_MAX_CAMERAS];
+        VH_HIP(hipMemcpyAsync(proposed, d->lostDev + 1, sizeof(int32_t) * (size_t)R, hipMemcpyDeviceToHost, d->sTable));
+        VH_HIP(hipStreamSynchronize(d->sTable));
+        for (int r = 0; r < R; ++r) cap = std::max(cap, proposed[r]);
+        cap = (int32_t)std::min<int64_t>(most, cap);
+    }
+    const int kAttempts = 8;
+    for (int attempt = 0; attempt < kAttempts; ++attempt) {
         int rc = dist_raycast_impl(d, pose, t_min, t_max, cap, d_depth_out, d_normals_out, d->lostDev);
         if (rc != VH_OK) return rc;
         if ((rc = d->transport->all_gather(d, d->lostDev, d->lostDev + 1, sizeof(int32_t), d->sTable)) != VH_OK) return rc;
@@ -661,10 +806,12 @@ extern "C" int vh_dist_raycast_auto(vh_dist *d, const float pose[16], float t_mi
             if (capacity_used) *capacity_used = cap;
             return VH_OK;
         }
-        if ((int64_t)cap >= most) break;
+        if ((int64_t)cap >= most)
+            return fail(VH_ERR_INVALID_ARGUMENT, "vh_dist_raycast_auto: a view selects more blocks of a shard than the shard's pool holds");
         cap = (int32_t)std::min<int64_t>(most, std::max<int64_t>((int64_t)cap + worst, (int64_t)cap * 2));
     }
-    return fail(VH_ERR_INVALID_ARGUMENT, "vh_dist_raycast_auto: a view selects more blocks of a shard than the shard's pool holds");
+    return fail(VH_ERR_INVALID_ARGUMENT, "vh_dist_raycast_auto: views still lost records after 8 rounds of growing the slots (the capacity at least doubles "
+                                         "every round): start larger (a previous call's capacity_used) or use vh_dist_raycast with a capacity of your own");
 }
 
 extern "C" int vh_dist_comm_info(vh_dist *d, int32_t *rank, int32_t *world)

@@ -373,6 +373,7 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
 #undef VH_LAUNCH_PIPELINED_ANY
 #undef VH_LAUNCH_PIPELINED
     if (rc != VH_OK) return rc;
+    if (serial && hasNew && hasOld) c->serialQueued = true;       // (its claim / walk workgroups wait: check_spin_timeouts)
     if (hasOld) { c->foldA = kPipeScan + a.setOld; c->foldB = kPipeScanB + a.setOld; c->foldNew = kPipeNew + a.setOld; }
     if (hasNew) {
         c->pipePending = true;

@@ -61,13 +61,31 @@ extern "C" int vh_garbage_collect(vh_context *c, float sdf_threshold)
 // ---------------------------------------------------------------------------
 // queries
 // ---------------------------------------------------------------------------
+// A workgroup of a serialised launch that gives up waiting (wait_commit_done, vh_frame.hip) drops its claim / walk work of that
+// frame: the model is then wrong, and every call has returned VH_OK.  So wherever the library synchronises with the host
+// anyway, and a serialised launch has been queued since the last look, the counter is read (4 bytes) and a new timeout is an
+// ERROR there -- once; the context falls back to two launches per overflow-list frame at the same moment.
+static int check_spin_timeouts(vh_context *c)
+{
+    if (!c->serialQueued) return VH_OK;
+    int32_t n = 0;
+    VH_HIP(hipMemcpyAsync(&n, c->dp.counters + kSpinTimeouts, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    VH_HIP(hipStreamSynchronize(c->stream));
+    c->serialQueued = false;
+    if ((uint32_t)n == c->spinSeen) return VH_OK;
+    c->spinSeen = (uint32_t)n;
+    c->serialFallback = true;
+    return fail(VH_ERR_TIMEOUT, "workgroups of a serialised one-launch frame gave up waiting for the pending frame's commit phase "
+                                "(vh_counters.spin_timeouts): frames queued since the last synchronisation have lost work");
+}
+
 extern "C" int vh_synchronize(vh_context *c)
 {
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     DeviceGuard guard(c->device);
     { const int frc = settle(c); if (frc != VH_OK) return frc; }
     VH_HIP(hipStreamSynchronize(c->stream));
-    return VH_OK;
+    return check_spin_timeouts(c);
 }
 
 extern "C" int vh_get_counters(vh_context *c, vh_counters *out)
@@ -90,6 +108,8 @@ extern "C" int vh_get_counters(vh_context *c, vh_counters *out)
     out->cand_overflow = (uint32_t)h[kCandOverflow];
     out->spin_timeouts = (uint32_t)h[kSpinTimeouts];
     if (out->spin_timeouts) c->serialFallback = true;       // (overflow-list frames: two launches each from now on)
+    c->spinSeen = out->spin_timeouts;                       // (reported here: the next synchronisation does not fail for it again)
+    c->serialQueued = false;
     c->params.numOccupiedBlocks = (uint32_t)h[c->occupiedCounter];
     return VH_OK;
 }
@@ -139,7 +159,7 @@ static int download_range(vh_context *c, int which, size_t offset, void *dst, si
     { const int frc = settle(c); if (frc != VH_OK) return frc; }
     VH_HIP(hipMemcpyAsync(dst, src + offset, bytes, hipMemcpyDeviceToHost, c->stream));
     VH_HIP(hipStreamSynchronize(c->stream));
-    return VH_OK;
+    return check_spin_timeouts(c);         // (what was downloaded is the model of frames that may have lost work: say so)
 }
 
 extern "C" int vh_download(vh_context *c, int which, void *dst, size_t bytes)

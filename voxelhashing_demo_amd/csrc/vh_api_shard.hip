@@ -395,6 +395,9 @@ static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b)
         a.walkShort = c->multiWalkEntries ? (c->multiWalkEntries == kEntriesPerLaneShort ? 1u : 0u)
                                           : (c->numEntries * sizeof(VoxelEntry) >= ((size_t)32 << 20) ? 1u : 0u);
         a.walkBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * (a.walkShort ? kEntriesPerLaneShort : kEntriesPerLane));
+        // the walk-free multi-camera frame (flatten_variant 4; not with the overflow list: holes and chains take the reference's walk)
+        a.walkIndexed = (c->flattenVariant == kWalkIndexed && !(c->fp.flags & kFlagOverflow)) ? 1u : 0u;
+        if (a.walkIndexed) a.walkBlocks = (uint32_t)grid_for(((size_t)c->ownedBuckets + 31) / 32, kFlattenThreads * kIndexWords);
         a.partsPerBin = parts; a.numBins = (uint32_t)mb->numBins;
         a.capacity = mb->capacity; a.binStride = mb->binStride;
         a.binsNew = mb->bins + (size_t)mb->frameStride * b;
@@ -419,12 +422,17 @@ static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b)
     const dim3 grid(a.commitBlocks + a.integrateBlocks + a.claimBlocks + a.walkBlocks);
     const int format = doNew ? c->packetFormat : mp.packetFormat;
     const bool serial = (c->fp.flags & kFlagOverflow) != 0u;
+    if (a.walkIndexed)         // (never with the overflow list, hence never serialised)
+        rc = format == VH_PACKET_U16 ? launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<true, false, true>, grid, dim3(256), c->fp, dpNew, a)
+                                     : launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<false, false, true>, grid, dim3(256), c->fp, dpNew, a);
+    else
     rc = format == VH_PACKET_U16
              ? (serial ? launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<true, true>, grid, dim3(256), c->fp, dpNew, a)
                        : launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<true, false>, grid, dim3(256), c->fp, dpNew, a))
              : (serial ? launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<false, true>, grid, dim3(256), c->fp, dpNew, a)
                        : launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<false, false>, grid, dim3(256), c->fp, dpNew, a));
     if (rc != VH_OK) return rc;
+    if (serial && doNew && hasOld) c->serialQueued = true;         // (its claim / walk workgroups wait: check_spin_timeouts)
     if (doNew) {
         mp.active = true;
         mp.epochOld = c->fp.epoch;

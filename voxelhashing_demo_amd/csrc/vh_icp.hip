@@ -346,6 +346,15 @@ __global__ __launch_bounds__(kIcpThreads) void icp_round_kernel(IcpParams ip, co
         // the record is complete before the ticket is drawn: the wave's stores have been acknowledged (s_waitcnt), no cache
         // write-back -- round 4: an agent-scope release here is an L2 write-back per workgroup, which the chip serves one at
         // a time (vh_icp_align of 20 rounds, same box: 350 us with __threadfence() here, 312 us with this)
+        // This hand-off is NOT a release / acquire pair of the HIP memory model: it rests on gfx942 / gfx950 behaviour -- an
+        // agent-scope relaxed atomic store is a write-through (sc1) store, complete for every XCD once s_waitcnt has seen it
+        // acknowledged, and the reader's agent-scope atomic loads (sc1) never hit a stale line of their own L2
+        // (MI355X_MICROARCH.md, valid forms: "every store of the handed-off bytes sc1 and drained before the counter, every
+        // load of them an sc1 load").  RULE: every store a workgroup makes before its ticket must be such an atomic store; a
+        // plain store added here, or another architecture (a separate store counter), needs __threadfence() back.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "vh_icp.hip: the ticket hand-off without a cache write-back is only valid on gfx942 / gfx950 (see the comment above)"
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_waitcnt(0);
         if (threadIdx.x == 0) isLast = atomicAdd(&state->ticket, 1) == (int)gridDim.x - 1;

@@ -97,6 +97,23 @@ __device__ __forceinline__ void flatten_multi_tile(const FrameParams &fp, const 
     }
 }
 
+// The occupancy-index walk (vh_walk.hip: flatten_index_tile_to) for all cameras of the step: the walk-free multi-camera frame
+// (flatten_variant 4; NOT the reference's walk).  An entry goes to the dense list once, with the mask of the cameras that see it.
+struct IndexSinkMulti {
+    const FrameParams &fp;
+    int32_t numCams;
+    const float *__restrict__ packets;
+    size_t packetStride;
+    int counterIndex;
+    __device__ __forceinline__ uint32_t judge(const VoxelEntry &e) const { return camera_mask(fp, e.pos, numCams, packets, packetStride); }
+    __device__ __forceinline__ int counter() const { return counterIndex; }
+    __device__ __forceinline__ void emit(const DevPtrs &dp, uint32_t pos, const VoxelEntry &e, uint32_t seen) const
+    {
+        dp.compact[pos] = e;
+        dp.compactMask[pos] = seen;
+    }
+};
+
 __global__ __launch_bounds__(kFlattenThreads) void flatten_multi_kernel(const FrameParams fp, const DevPtrs dp,
                                                                         uint32_t numEntries, int32_t numCams,
                                                                         const float *__restrict__ packets,
@@ -248,6 +265,7 @@ struct MultiPipeArgs {
     int32_t setNew, setOld, setClear;
     uint32_t hasNew, hasOld;
     uint32_t walkShort;          // the walk takes 4 instead of 8 entries per lane
+    uint32_t walkIndexed;        // flatten_variant 4: the walk runs over the bucket-occupancy bitmap, its tiles ahead of the claim slices
     uint32_t claimSpan, claimRatio;
     uint32_t epochOld;
     const int4 *binsNew;
@@ -262,7 +280,10 @@ struct MultiPipeArgs {
 
 // (builds with the option flags folded in, as frame_pipelined_kernel has them, were measured here too: 4.2 k instead of 5.3 k
 // instructions, but the launch 19.2-19.4 us against 19.1 on the world-1 sharded leg: not kept)
-template <bool kSensor, bool kSerial>
+// kIndexed: the walk-free multi-camera frame (a.walkIndexed), a build of its own -- with the index walk as a run-time branch of the
+// one build the default launch went from 18.7 to 20.8 us on the world-1 sharded leg (the code of these launches is weighed by the
+// microsecond, vh_frame.hip).
+template <bool kSensor, bool kSerial, bool kIndexed = false>
 __global__ __launch_bounds__(256) void frame_multi_pipelined_kernel(const FrameParams fp, const DevPtrs dp, const MultiPipeArgs a)
 {
     int32_t *counters = dp.counters;
@@ -282,7 +303,15 @@ __global__ __launch_bounds__(256) void frame_multi_pipelined_kernel(const FrameP
         const Pending pend{a.hasOld && !serial ? a.claimOld : nullptr, a.candOld, a.epochOld, live, serial ? -1 : kPipeWinners + a.setNew};
         const uint32_t r = b - a.commitBlocks - a.integrateBlocks;
         uint32_t before = a.claimBlocks, after = a.claimBlocks;
-        if (r < a.claimSpan) { before = __umulhi(r, a.claimRatio); after = __umulhi(r + 1u, a.claimRatio); }
+        if constexpr (kIndexed) {
+            // (the walk-free frame: the index tiles first, as in frame_pipelined)
+            if (r < a.walkBlocks) {
+                flatten_index_tile_to(fp, dp, r, IndexSinkMulti{fp, a.numCams, a.packetsNew, a.packetStride, kPipeScan + a.setNew}, pend);
+                return;
+            }
+            before = r - a.walkBlocks; after = before + 1u;
+        }
+        else { if (r < a.claimSpan) { before = __umulhi(r, a.claimRatio); after = __umulhi(r + 1u, a.claimRatio); } }
         if (after != before) {
             __builtin_amdgcn_s_setprio(3);
             claim_bin_slice(fp, dp, a.binsNew, a.capacity, a.binStride, before / a.partsPerBin, before % a.partsPerBin, a.partsPerBin,

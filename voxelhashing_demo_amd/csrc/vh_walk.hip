@@ -254,10 +254,24 @@ __device__ __forceinline__ void flatten_index_tile_chain(const FrameParams &fp, 
 // atomics per counter and frame.  Slots 2 and beyond are read only behind a live slot 1 (a bucket holding three entries:
 // rare at any load the reference's 5-slot buckets work at) and appended per wave.
 constexpr int kIndexQueue = 512;
-__device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
-                                                   const CompactOut &out, const Pending &pend = kNoPending)
+// Where the index walk's hits go.  The single-camera frame: an entry inside the frame's frustum, onto one of the two ends
+// of the frame's list.  (vh_shard.hip has the multi-camera one: the mask of the cameras that see the block, one dense list.)
+struct IndexSinkFrame {
+    const FrameParams &fp;
+    CompactOut out;
+    bool toB;
+    __device__ __forceinline__ uint32_t judge(const VoxelEntry &e) const { return block_in_frustum(fp, e.pos[0], e.pos[1], e.pos[2]) ? 1u : 0u; }
+    __device__ __forceinline__ int counter() const { return toB ? out.counterB : out.counterA; }
+    __device__ __forceinline__ void emit(const DevPtrs &dp, uint32_t pos, const VoxelEntry &e, uint32_t) const
+    {
+        dp.compact[toB ? out.numEntries - 1u - pos : pos] = e;
+    }
+};
+
+template <class Sink>
+__device__ __forceinline__ void flatten_index_tile_to(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
+                                                      const Sink &sink, const Pending &pend)
 {
-    if (fp.flags & kFlagOverflow) { flatten_index_tile_chain(fp, dp, tileIndex, out, pend); return; }
     constexpr int kWaves = kFlattenThreads / kWave;
     __shared__ uint32_t queue_[kWaves][kIndexQueue];
     __shared__ int rounds_[kWaves], hits_[kWaves], base_;
@@ -271,7 +285,6 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
     uint32_t bits[kIndexWords];
 #pragma unroll
     for (int k = 0; k < kIndexWords; ++k) bits[k] = (w0 + (uint32_t)k < numWords) ? dp.bucketBits[w0 + k] : 0u;
-    const bool toB = out.counterB >= 0 && (tileIndex & 1u);
     const bool pending = pend.claim != nullptr && pend.live;
     for (;;) {
         // ---- the pass's buckets: a lane contributes its set bits while the wave's list has room ----
@@ -320,7 +333,8 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
                     if (pending && pend_maybe(pend, bk[j])) cw[j] = pend.claim[bk[j]];
                 }
             }
-            bool hit[2][2], deeper[2];
+            uint32_t hit[2][2];                    // what the sink sees in the entry (0: nothing)
+            bool deeper[2];
             uint32_t inFlight[2];
             int nh = 0;
 #pragma unroll
@@ -328,8 +342,8 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
                 inFlight[j] = (pending && claim_epoch(cw[j]) == pend.epoch) ? claim_f(cw[j]) : ~0u;
                 const bool live0 = hv[j] && inFlight[j] != 0u && e[j][0].ptr != VH_FREE_BLOCK;
                 const bool live1 = live0 && inFlight[j] != 1u && e[j][1].ptr != VH_FREE_BLOCK;
-                hit[j][0] = live0 && block_in_frustum(fp, e[j][0].pos[0], e[j][0].pos[1], e[j][0].pos[2]);
-                hit[j][1] = live1 && block_in_frustum(fp, e[j][1].pos[0], e[j][1].pos[1], e[j][1].pos[2]);
+                hit[j][0] = live0 ? sink.judge(e[j][0]) : 0u;
+                hit[j][1] = live1 ? sink.judge(e[j][1]) : 0u;
                 deeper[j] = live1 && fp.bucketSize > 2u && inFlight[j] != 2u;
                 nh += (hit[j][0] ? 1 : 0) + (hit[j][1] ? 1 : 0);
             }
@@ -355,12 +369,12 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
 #endif
             if (total != 0) {          // (the same for every wave)
 #if VH_INDEX_WG_RESERVE
-                if (threadIdx.x == 0) base_ = atomicAdd(dp.counters + (toB ? out.counterB : out.counterA), total);
+                if (threadIdx.x == 0) base_ = atomicAdd(dp.counters + sink.counter(), total);
                 __syncthreads();
                 const int start = base_;
 #else
                 int start = 0;
-                if (lane == kWave - 1) start = atomicAdd(dp.counters + (toB ? out.counterB : out.counterA), total);
+                if (lane == kWave - 1) start = atomicAdd(dp.counters + sink.counter(), total);
                 start = __shfl(start, kWave - 1);
 #endif
                 uint32_t pos = (uint32_t)(start + before + hincl - nh);
@@ -368,7 +382,7 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
-                        if (hit[j][k]) { dp.compact[toB ? out.numEntries - 1u - pos : pos] = e[j][k]; ++pos; }
+                        if (hit[j][k]) { sink.emit(dp, pos, e[j][k], hit[j][k]); ++pos; }
             }
             // slots 2 ..: only behind a live slot 1 (per wave)
 #pragma unroll
@@ -377,17 +391,21 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
                 if (__ballot(more) == 0ull) continue;
                 for (uint32_t s = 2; s < fp.bucketSize; ++s) {
                     VoxelEntry ent;
-                    bool h = false;
+                    uint32_t h = 0u;
                     if (s == inFlight[j]) more = false;
                     if (more) {
                         ent = dp.table[(size_t)bk[j] * fp.bucketSize + s];
                         more = ent.ptr != VH_FREE_BLOCK;
-                        h = more && block_in_frustum(fp, ent.pos[0], ent.pos[1], ent.pos[2]);
+                        h = more ? sink.judge(ent) : 0u;
                     }
-                    const unsigned long long mask = __ballot(h);
+                    const unsigned long long mask = __ballot(h != 0u);
                     if (__ballot(more) == 0ull && mask == 0ull) break;
                     if (mask == 0ull) continue;
-                    compact_append(dp, out, tileIndex, mask, h, ent);
+                    int start = 0;
+                    const int leader = __ffsll((long long)mask) - 1;
+                    if (lane == leader) start = atomicAdd(dp.counters + sink.counter(), __popcll(mask));
+                    start = __shfl(start, leader);
+                    if (h != 0u) sink.emit(dp, (uint32_t)start + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)), ent, h);
                 }
             }
             __syncthreads();           // (hits_ and base_ are rewritten by the next round)
@@ -397,6 +415,13 @@ __device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const 
         for (int k = 0; k < kIndexWords; ++k) left |= bits[k] != 0u;
         if (!__syncthreads_or(left ? 1 : 0)) break;       // (also: the lists are refilled by the next pass)
     }
+}
+
+__device__ __forceinline__ void flatten_index_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
+                                                   const CompactOut &out, const Pending &pend = kNoPending)
+{
+    if (fp.flags & kFlagOverflow) { flatten_index_tile_chain(fp, dp, tileIndex, out, pend); return; }
+    flatten_index_tile_to(fp, dp, tileIndex, IndexSinkFrame{fp, out, out.counterB >= 0 && (tileIndex & 1u)}, pend);
 }
 
 // tileIndex: index of this workgroup among the `walkBlocks` workgroups doing the walk

@@ -385,6 +385,22 @@ class NativeDist:
                                                      None if normals is None else normals.data_ptr(), C.byref(cap)), "vh_dist_raycast_auto")
         return cap.value
 
+    def set_option(self, name: str, value: int):
+        """vh_dist_set_option: "force_collectives" (a one-rank group runs the collectives anyway), "phase_timing"."""
+        self._L.check(self._lib.vh_dist_set_option(self._h, name.encode(), int(value)), "vh_dist_set_option")
+
+    def phase_times(self, reset: bool = True):
+        """Per-exchange phase times in microseconds (option "phase_timing"): means over the exchanges completed since the last reset."""
+        ph = self._L.DistPhases()
+        self._L.check(self._lib.vh_dist_phase_times(self._h, ph, 1 if reset else 0), "vh_dist_phase_times")
+        n = max(1, ph.exchanges)
+        return dict(exchanges=int(ph.exchanges), generate=ph.generate_us / n, collectives=ph.collectives_us / n, apply=ph.apply_us / n,
+                    first_to_last=ph.first_to_last_us / n, host_enqueue=ph.host_enqueue_us / n)
+
+    def self_check(self):
+        """vh_dist_self_check: a known pattern through the transport's all-to-all and all-gather, compared on the device.  Collective."""
+        self._L.check(self._lib.vh_dist_self_check(self._h), "vh_dist_self_check")
+
     def comm_info(self):
         """(rank, size) as the transport reports them (ncclCommUserRank / ncclCommCount over RCCL)."""
         import ctypes as C
@@ -457,6 +473,10 @@ class NativeGroup:
         for nd in self.ranks:
             nd.flush()
 
+    def self_check(self):
+        """vh_dist_self_check on every rank (collective): the transport carries a known pattern to the right places."""
+        self._all(lambda r, nd: nd.self_check())
+
     @property
     def tables(self):
         return [nd.table for nd in self.ranks]
@@ -465,6 +485,11 @@ class NativeGroup:
         if getattr(self, "_pool", None) is not None:
             self._pool.shutdown(wait=True)
             self._pool = None
+        for nd in self.ranks:          # (every rank idle before any is destroyed: the loop-back events are shared, voxelhash_dist.h)
+            try:
+                nd.flush()
+            except Exception:          # noqa: BLE001 -- a rank that already failed is destroyed all the same
+                pass
         for nd in self.ranks:
             nd.close()
 
@@ -764,6 +789,21 @@ def camera_phase(rank: int, world: int) -> float:
 # ----------------------------------------------------------------------------
 # bench (called by bench.py when WORLD_SIZE > 1)
 # ----------------------------------------------------------------------------
+def scaling_prediction(wl_name, world, batch):
+    """The prediction written down BEFORE any multi-GPU run (profiles/r05_scaling_model.json, tools/scaling_model.py): frames/s at
+    this world size from one-rank-at-a-time kernel times and bytes on the wire / a stated xGMI rate -- so that a measured curve
+    is held against a number that was not fitted to it.  None where the model has no entry."""
+    import json
+    import os
+    try:
+        m = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_scaling_model.json")))
+        e = m["workloads"][wl_name if wl_name in m["workloads"] else "C2"]["predicted"][str(world)]
+        return dict(e, model="profiles/r05_scaling_model.json", batch_of_model=m["batch"],
+                    note="written before any multi-GPU measurement; see the file for inputs and assumptions")
+    except Exception:
+        return None
+
+
 def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     """Timed windows of K exchanges on the bucket-range-sharded path (the process group is the caller's).
     Returns the result record on rank 0 and None elsewhere."""
@@ -841,6 +881,10 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             uid = unique_id(rank, torch_broadcast_bytes())
             nd = NativeDist(params, Wd, Ht, SEM_PINHOLE, rank, world, batch, uid, sensor_k_inv=k_inv if sensor else None,
                             key_capacity=0, device=local_rank)
+            if world > 1:
+                # before anything is fused or timed: a known pattern through ncclAllToAll / ncclAllGather, compared on the
+                # device -- a transport that delivers to the wrong place fails here, loudly, on every rank that sees it
+                nd.self_check()
     with torch.cuda.stream(stream):
         if native:
             # (key bins: the library's default -- ONE bin per (owner, batch) of 1.5 x batch x W*H/16 / world records)
@@ -925,6 +969,27 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
         drain()
         kt = shard.table.kernel_times(reset=True)
         shard.table.set_profiling(False)
+        # per-exchange phase times from timing events of the library's own (separate, untimed pass): what a measured
+        # scaling curve is read against -- the exchange's period is max(generate, collectives, apply) when the three streams
+        # overlap as designed
+        phases = None
+        if native:
+            nd.set_option("phase_timing", 1)
+            for i in range(9):
+                step(nxt + 3 + i)
+            drain()
+            ph = nd.phase_times()
+            nd.set_option("phase_timing", 0)
+            pt = torch.tensor([ph["generate"], ph["collectives"], ph["apply"], ph["first_to_last"], ph["host_enqueue"]],
+                              dtype=torch.float64, device=cdev)
+            dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+            phases = dict(zip(("generate", "collectives", "apply", "first_to_last", "host_enqueue"), [round(float(x), 2) for x in pt.tolist()]),
+                          exchanges=ph["exchanges"], frames_per_camera_per_exchange=batch,
+                          note="microseconds per exchange, the slowest rank's mean of each phase over 9 exchanges in a separate pass "
+                               "with timing events (vh_dist_phase_times): key-generation launches / from the moment the collectives "
+                               "may start to their completion (ncclAllToAll of the key bins + ncclAllGather of the packets; one rank: "
+                               "nothing is sent) / the frame launches first to last / generation start to last frame launch / host "
+                               "time inside vh_dist_step_batch")
 
         # raycast over the shards (extra, after the timed region).  With more than one rank it runs
         # only on request: the default multi-GPU run is the integration benchmark alone.
@@ -1015,7 +1080,13 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             # 4 KiB written (cameras applied in registers)
             kname = "frame_multi_pipelined_kernel (rank 0)"
             walk_us = 1e3 * kt["frame_pipelined_ms"] / launches
-            walk_bytes = 20 * shard.table.num_entries + 24 * occ + occ * (20 + 4096 + 4096)
+            indexed = any(kv.replace(" ", "") == "flatten_variant=4" for kv in (getattr(args, "option", []) or []))
+            if indexed:      # the walk-free multi-camera frame: bitmap + non-empty buckets in place of the 20*N walk
+                kname = "frame_multi_pipelined_kernel (rank 0; walk role = flatten_index_tile_to<IndexSinkMulti>)"
+                owned = shard.table.num_entries // 5
+                walk_bytes = owned // 8 + 100 * (c["allocated_total"] - c.get("freed_total", 0)) + 24 * occ + occ * (20 + 4096 + 4096)
+            else:
+                walk_bytes = 20 * shard.table.num_entries + 24 * occ + occ * (20 + 4096 + 4096)
             pmc_key = "frame_multi_pipelined_kernel"
         else:
             # two launches per multi-camera frame: the dominant one = claim the bins || walk the shard for all cameras
@@ -1038,7 +1109,7 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
                                   f"one-rank PMC ratio {m / a:.3f} x this rank's algorithmic bytes")
         except Exception:
             pass
-        roofline = dict(bound="hbm", kernel=kname, achieved=round(achieved, 1),
+        roofline = dict(bound="hbm" if not (one_launch and indexed) else "latency + VALU issue (no stream; the fraction is not a quality figure)", kernel=kname, achieved=round(achieved, 1),
                         peak=8000.0, unit="GB/s", frac=round(achieved / 8000.0, 4), traffic=traffic,
                         traffic_source=traffic_source,
                         bytes_per_launch=walk_bytes, us_per_launch=round(walk_us, 2),
@@ -1051,9 +1122,14 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             vs_baseline=None, dtype="f32", data="synthetic",
             windows=len(windows), timed_s=round(sum(windows), 4),
             host_enqueue_ms_per_step=round(1e3 * statistics.median(host_enqueue) / args.steps, 5),
-            exchange_ranks=dict(dict(transport=nd.transport, ranks=comm_ranks) if native else dict(transport="torch.distributed " + dist.get_backend(), ranks=dist.get_world_size()),
+            exchange_ranks=dict(dict(transport=(nd.transport if world > 1 else f"none (one rank: the frames are applied straight from the send buffers; "
+                                                                                            f"{nd.transport} would carry them)"),
+                                     ranks=comm_ranks, self_check="passed (vh_dist_self_check)" if world > 1 else "not run (one rank)")
+                                if native else dict(transport="torch.distributed " + dist.get_backend(), ranks=dist.get_world_size()),
                                 **({"shared_gpu": True} if os.environ.get("VH_BENCH_SHARE_GPU") == "1" and world > 1 else {})),
-            exchange_host="libvoxelhash_hip.so: vh_dist_step_batch on RCCL directly (include/voxelhash_dist.h)" if native
+            exchange_phases_us=phases, predicted=scaling_prediction(wl_name, world, batch),
+            exchange_host=("libvoxelhash_hip.so: vh_dist_step_batch (include/voxelhash_dist.h)"
+                           + (" on RCCL directly" if world > 1 else ", one rank: no collective")) if native
             else "Python: dist.ShardedPipeline over torch.distributed collectives (--python-exchange / --no-pipeline)"
                  + (f"; the native exchange was not available: {native_error}" if native_error else ""),
             config=dict(workload=f"{'C5' if wl_name == 'C5' else 'C4-style'}: {world} virtual {Wd}x{Ht} cameras (one per GPU) into one scene, "
