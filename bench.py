@@ -50,13 +50,13 @@ WORKLOADS = {
     "C2bandSamples": dict(width=640, height=480, frames=500, buckets=1 << 20, blocks=1 << 18, voxel=0.02, loop=500, band=0.1,
                           desc="C2 with vh_set_alloc_band(0.1), band_mode VH_BAND_RAY: five samples per pixel on the viewing ray"),
     # BASELINE.json configs[2] (HBM-bound stress)
-    "C3": dict(width=1280, height=960, frames=200, buckets=1 << 22, blocks=1 << 21, voxel=0.005, loop=2000,
-               desc="C3: synthetic room, 1280x960, 2^22 buckets x 5 (419 MB of VoxelEntry: beyond the 256 MiB "
-                    "Infinity Cache), 2^21 voxel blocks, voxel 0.005 m, PINHOLE semantics (the first 200 poses of "
-                    "the 2000-pose path resident)"),
+    "C3": dict(width=1280, height=960, frames=2000, buckets=1 << 22, blocks=1 << 21, voxel=0.005, loop=2000, sensor=True,
+               desc="C3: synthetic room, 1280x960 x the whole 2000-pose path, 2^22 buckets x 5 (419 MB of VoxelEntry: beyond the "
+                    "256 MiB Infinity Cache), 2^21 voxel blocks, voxel 0.005 m, PINHOLE semantics; the 2000 frames resident as "
+                    "uint16 sensor images (4.9 GB), fused by vh_integrate_depth_batch"),
     # C3's frames into a table of C5's size on ONE GPU (2^24 buckets x 5 = 1.68 GB of VoxelEntry, 6.5 x the Infinity Cache): the
     # walk with no residency left to argue about ("prove the HBM figure")
-    "C5table": dict(width=1280, height=960, frames=64, buckets=1 << 24, blocks=1 << 21, voxel=0.005, loop=2000,
+    "C5table": dict(width=1280, height=960, frames=64, buckets=1 << 24, blocks=1 << 21, voxel=0.005, loop=2000, sensor=True,
                     desc="C5table: C3's 1280x960 frames into an unsharded table of C5's size, 2^24 buckets x 5 (1.68 GB of "
                          "VoxelEntry = 6.5 x the 256 MiB Infinity Cache), 2^21 voxel blocks, voxel 0.005 m, PINHOLE semantics"),
     # BASELINE.json configs[4], per-rank share when launched with --gpus 8 (one stream per GPU)
@@ -171,14 +171,24 @@ def rocprof_mean_us(workload, kernel):
     return None
 
 
-def render_frames(synth, wl, nframes, dev, torch):
+def render_frames(synth, wl, nframes, dev, torch, sensor=None):
+    """Resident frames: float4 vertex maps [n, H, W, 4], or (sensor: the workload's "sensor" flag) uint16 depth images
+    [n, H, W] as a sensor delivers them (5000 units = 1 m, Application.cpp:38-42) -- 2 instead of 16 bytes per pixel, so that
+    C3's whole 2000-pose path is resident (4.9 GB) instead of its first 200 poses."""
+    sensor = wl.get("sensor", False) if sensor is None else sensor
     poses = synth.camera_loop(wl["loop"])[:nframes]
     prims = synth.room_primitives()
-    verts = torch.empty((nframes, wl["height"], wl["width"], 4), dtype=torch.float32, device=dev)
-    for i in range(nframes):
-        verts[i] = synth.render_room_verts(poses[i], wl["width"], wl["height"], prims, device=dev)
+    if sensor:
+        frames = torch.empty((nframes, wl["height"], wl["width"]), dtype=torch.uint16, device=dev)
+        for i in range(nframes):
+            v = synth.render_room_verts(poses[i], wl["width"], wl["height"], prims, device=dev)
+            frames[i] = (v[:, :, 2] * 5000.0).round().clamp(0, 65535).to(torch.uint16)
+    else:
+        frames = torch.empty((nframes, wl["height"], wl["width"], 4), dtype=torch.float32, device=dev)
+        for i in range(nframes):
+            frames[i] = synth.render_room_verts(poses[i], wl["width"], wl["height"], prims, device=dev)
     torch.cuda.synchronize()
-    return poses, verts
+    return poses, frames
 
 
 class Integrator:
@@ -201,6 +211,13 @@ class Integrator:
         self.pose_keep = [np.ascontiguousarray(p.reshape(16)) for p in poses]
         self.pose_ptrs = [p.ctypes.data_as(C.POINTER(C.c_float)) for p in self.pose_keep]
         self.vert_ptrs = [verts[i].data_ptr() for i in range(self.nframes)]
+        # uint16 sensor images instead of vertex maps: vh_integrate_depth(_batch), the vertices computed inside the claim phase
+        self.sensor = str(verts.dtype) == "torch.uint16"
+        if self.sensor:
+            from voxelhashing_demo_amd import synth as _synth
+            k_inv = np.linalg.inv(_synth.K_matrix(wl["width"], wl["height"]).astype(np.float64)).astype(np.float32)
+            self._kin = np.ascontiguousarray(k_inv.reshape(9))
+            self.kin_p = self._kin.ctypes.data_as(C.POINTER(C.c_float))
         # a step = one batch of `batch` consecutive frames handed to vh_integrate_batch (as the sharded path's
         # step is one exchange of `batch` frames per camera): argument blocks prepared once per start frame
         B, n = self.batch, self.nframes
@@ -214,14 +231,20 @@ class Integrator:
             for j in range(self.batch):
                 self.frame(k + j)
             return
-        rc = self.lib.vh_integrate_batch(self.h, self.batch, self._batch_pose_ptrs[k], self._batch_verts[k], None)
+        if self.sensor:
+            rc = self.lib.vh_integrate_depth_batch(self.h, self.batch, self._batch_pose_ptrs[k], self._batch_verts[k], self.kin_p)
+        else:
+            rc = self.lib.vh_integrate_batch(self.h, self.batch, self._batch_pose_ptrs[k], self._batch_verts[k], None)
         if rc != 0:
             self.L.check(rc, "vh_integrate_batch")
 
     def frame(self, i):
         """one frame (the legs that are not batch-shaped)"""
         k = i % self.nframes
-        rc = self.lib.vh_integrate(self.h, self.pose_ptrs[k], self.vert_ptrs[k], None)
+        if self.sensor:
+            rc = self.lib.vh_integrate_depth(self.h, self.pose_ptrs[k], self.vert_ptrs[k], self.kin_p)
+        else:
+            rc = self.lib.vh_integrate(self.h, self.pose_ptrs[k], self.vert_ptrs[k], None)
         if rc != 0:
             self.L.check(rc, "vh_integrate")
 
@@ -257,18 +280,18 @@ class Integrator:
             # per distinct block key (keys ~ occ).
             kname = "frame_pipelined_kernel"
             us = 1e3 * kt["frame_pipelined_ms"] / launches
-            nbytes = 16 * Wd * Ht + 4 * Wd * Ht + 20 * n_entries + 20 * occ + occ * (20 + 4096 + 4096) + 100 * occ
+            nbytes = self.input_bytes() + 20 * n_entries + 20 * occ + occ * (20 + 4096 + 4096) + 100 * occ
         else:
             # dominant kernel of the two-launch frame: per-pixel claim phase || walk over the VoxelEntry array:
             # the vertex map read once by the claim half (16*W*H), one pass over the table (20*N), the compact
             # entries written (20*occ) and one 100-byte bucket probe per distinct block key (keys ~ occ).
             kname = "frame_scan_claim_kernel"
             us = 1e3 * kt["frame_scan_claim_ms"] / launches
-            nbytes = 16 * Wd * Ht + 20 * n_entries + 20 * occ + 100 * occ
+            nbytes = (2 if self.sensor else 16) * Wd * Ht + 20 * n_entries + 20 * occ + 100 * occ
             # launch 2: per occupied block the 20-byte entry, 4 KiB of voxels read and 4 KiB written, plus the
             # depth plane the update gathers from (counted once)
             us2 = 1e3 * kt["frame_commit_integrate_ms"] / launches
-            bytes2 = occ * (20 + 4096 + 4096) + 4 * Wd * Ht
+            bytes2 = occ * (20 + 4096 + 4096) + (2 if self.sensor else 4) * Wd * Ht
             ach2 = bytes2 / (us2 * 1e-6) / 1e9 if us2 > 0 else 0.0
             self.commit_roofline = dict(bound="hbm", kernel="frame_commit_integrate_kernel", achieved=round(ach2, 1),
                                         peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach2 / HBM_PEAK_GBS, 4),
@@ -289,6 +312,12 @@ class Integrator:
             out["rocprofv3_us_per_launch"] = rp
             out["frac_at_rocprofv3_mean"] = round(nbytes / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         return out
+
+    def input_bytes(self):
+        """The frame's input terms of SURVEY.md 8(d): the vertex map read once (16*W*H) + the depth the TSDF update gathers
+        (4*W*H) -- or, fed by the sensor image: the image read once (2*W*H) + the depth gathered from its copy (2*W*H)."""
+        Wd, Ht = self.wl["width"], self.wl["height"]
+        return (2 + 2) * Wd * Ht if self.sensor else (16 + 4) * Wd * Ht
 
     def close(self):
         self.table.close()
@@ -328,8 +357,10 @@ def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, 
     Wd, Ht, n_entries = wl["width"], wl["height"], it.table.num_entries
     # algorithmic bytes of the whole frame (SURVEY.md 8(d) B_frame; no mutex memset in this build);
     # distinct in-frustum block keys of a frame ~ occupied blocks (not counted on the device)
-    b_frame = 16 * Wd * Ht + 4 * Wd * Ht + 20 * n_entries + 20 * occ + occ * (20 + 4096 + 4096) + 100 * occ
+    b_frame = it.input_bytes() + 20 * n_entries + 20 * occ + occ * (20 + 4096 + 4096) + 100 * occ
     rec["frame_algorithmic_bytes"] = b_frame
+    rec["input"] = ("uint16 sensor images (vh_integrate_depth_batch): input terms 2*W*H + 2*W*H in place of 16*W*H + 4*W*H"
+                    if it.sensor else "float4 vertex maps (vh_integrate_batch)")
     rec["ms_per_frame"] = round(rec["ms_per_step"] / B, 5)
     rec["frame_algorithmic_gbs"] = round(b_frame * rec["value"] / 1e9, 1)
     rec["frame_frac_of_hbm_peak"] = round(b_frame * rec["value"] / 1e9 / HBM_PEAK_GBS, 4)
@@ -368,7 +399,7 @@ def index_variant_record(args, it, name, steps, warmup, sync):
     counters = it.table.counters()
     occ, alloc = counters["occupied"], counters["allocated_total"] - counters.get("freed_total", 0)
     flatten_bytes = wl["buckets"] // 8 + 100 * alloc
-    nbytes = 16 * Wd * Ht + 4 * Wd * Ht + flatten_bytes + 20 * occ + occ * (20 + 4096 + 4096) + 100 * occ
+    nbytes = it.input_bytes() + flatten_bytes + 20 * occ + occ * (20 + 4096 + 4096) + 100 * occ
     rec["flatten_bytes"] = flatten_bytes
     if args.profile_steps > 0:
         kt = it.kernel_profile(min(args.profile_steps, 200), nxt)

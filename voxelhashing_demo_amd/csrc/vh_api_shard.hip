@@ -200,6 +200,16 @@ extern "C" int vh_generate_keys(vh_context *c, const vh_float4 *verts, uint32_t 
     return VH_OK;
 }
 
+// Per-batch bins: behind every generation launch but the last, the count so far is written into the bin headers as a mark, so
+// that the launch of a frame reads only the records of its own generation launch (claim_bin_slice).  At most two marks fit the
+// header: batches of more than three generation launches go without (their frames scan the whole bin, as before).
+static void mark_bins(vh_context *c, bool perBatch, int batch, int b0, int4 *bins, int32_t numShards, int32_t binStride)
+{
+    const int per = c->genFramesPerLaunch, launches = (batch + per - 1) / per, g = b0 / per;
+    if (!perBatch || launches < 2 || launches > 3 || g >= launches - 1 || per > 255) return;
+    bin_mark_kernel<<<1, 64, 0, c->stream>>>(bins, numShards, binStride, g, per, launches - 1);
+}
+
 // `batch` frames of one camera in one call: one launch zeroes all bin headers, then one launch per
 // kGenBatch frames (blockIdx.y = frame, poses and vertex-map pointers in the kernel arguments).
 extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float *poses,
@@ -246,6 +256,7 @@ extern "C" int vh_generate_keys_batch(vh_context *c, int32_t batch, const float 
             c->fp, fr, num_shards, perBatch ? reinterpret_cast<int4 *>(d_bins) : reinterpret_cast<int4 *>(d_bins) + (size_t)frame_stride * b0, capacity, bin_stride,
             perBatch ? -1 : frame_stride, d_packets ? d_packets + packet_frame_stride * (size_t)b0 : nullptr, packet_frame_stride,
             perBatch ? (uint32_t)b0 << kRankCameraShift : camera_id << kRankCameraShift);
+        mark_bins(c, perBatch, batch, b0, reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride);
     }
     VH_HIP(hipGetLastError());
     return VH_OK;
@@ -321,6 +332,7 @@ extern "C" int vh_generate_keys_depth_batch(vh_context *c, int32_t batch, const 
         else if (band) launch_gen_sensor<kGenThreads, 0>(c, n, fr, num_shards, bins0, capacity, bin_stride, fs, pk0, packet_frame_stride, rank0);
         else if (many) launch_gen_sensor<kGenThreads / 2, VH_GEN_GROUPS_MANY>(c, n, fr, num_shards, bins0, capacity, bin_stride, fs, pk0, packet_frame_stride, rank0);
         else launch_gen_sensor<VH_GEN_THREADS_ONE, VH_GEN_GROUPS_ONE>(c, n, fr, num_shards, bins0, capacity, bin_stride, fs, pk0, packet_frame_stride, rank0);
+        mark_bins(c, perBatch, batch, b0, reinterpret_cast<int4 *>(d_bins), num_shards, bin_stride);
     }
     VH_HIP(hipGetLastError());
     return VH_OK;

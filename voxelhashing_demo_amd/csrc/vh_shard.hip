@@ -19,12 +19,26 @@ __device__ __forceinline__ void claim_bin_slice(const FrameParams &fp, const Dev
     // frame >= 0: ONE bin per (source, batch) -- the records of all frames of the batch, each with its frame index where a
     // per-frame bin's record has the camera id (the camera IS the source: bin index); this launch serves `frame` only
     const int4 *bin = bins + (size_t)binIndex * binStride;
-    int n = bin[0].x;
+    const int4 head = bin[0];
+    int n = head.x;
     if (n > capacity - 1) {
         if (part == 0 && threadIdx.x == 0) atomicAdd(dp.counters + kBinOverflow, 1);
         n = capacity - 1;
     }
-    for (int i = (int)part * 256 + (int)threadIdx.x; i < n; i += (int)parts * 256) {
+    // A per-batch bin is filled by one generation launch per group of frames, one after the other, and the generator leaves a
+    // mark behind each of them (bin_mark_kernel: header .y, .z = the count after the first and the second launch, .w = frames per
+    // launch | marks << 8): the records of `frame` lie between two marks, and its launch reads only those (round 5: every launch
+    // of a batch scanned the whole bin for its own frame's records, 0.8 us per launch at C2 size -- profiles/r04_sharded_*.txt).
+    // No marks (.w == 0: bins not made by this generator, or more than three launches per batch): the whole bin.
+    int lo = 0;
+    if (frame >= 0 && head.w != 0) {
+        const int per = head.w & 0xff, marks = (head.w >> 8) & 0xff, g = frame / per;
+        const int m0 = min(head.y, n), m1 = min(head.z, n);
+        lo = g == 0 ? 0 : g == 1 ? m0 : m1;
+        n = g < marks ? (g == 0 ? m0 : m1) : n;
+        if (g > 2) lo = n;                                   // (cannot be: the generator writes no marks then)
+    }
+    for (int i = lo + (int)part * 256 + (int)threadIdx.x; i < n; i += (int)parts * 256) {
         const int4 k = bin[1 + i];
         uint32_t rank = (uint32_t)k.w;
         if (frame >= 0) {
@@ -424,6 +438,17 @@ __global__ __launch_bounds__(256) void write_packets_u16_kernel(const SensorFram
     uint32_t *dst = reinterpret_cast<uint32_t *>(pk + kPacketHeaderU16);
     const int words = numPixels / 2;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < words; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+// Behind generation launch `g` (0, 1) of a per-batch bin: the count so far becomes mark g of the header (claim_bin_slice above).
+__global__ void bin_mark_kernel(int4 *bins, int32_t numShards, int32_t binStride, int32_t g, int32_t framesPerLaunch, int32_t marks)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numShards) return;
+    int4 *head = bins + (size_t)i * binStride;
+    const int count = head->x;
+    if (g == 0) head->y = count; else head->z = count;
+    head->w = framesPerLaunch | (marks << 8);
 }
 
 // Zeroes the header record of the bins of `batch` frames x numShards shards before
