@@ -292,6 +292,9 @@ struct BandWalk {
         more = false;
         if (!dda || !p.valid) return;
         float start[3], dir[3];
+        // (round 5, measured and not kept: the fourteen divisions of this set-up -- two by z, six by voxelSize, two per axis by the
+        // segment's component -- as div_fixed with shared refined reciprocals, the same bits: C2band's launch 22.3 -> 23.0 us, the
+        // sample band 24.3 -> 24.3 -- each FixedDivisor::divide carries its plain-division fall-back; profiles/r05_band_div_fixed_ab.txt)
         if (rayDda) {
             // VH_BAND_RAY_DDA: the segment of the viewing ray between camera depths z - b and z + b (oracle: ray_dda_keys);
             // its two ends are the vertex scaled to those depths, through the pose as :622
