@@ -59,6 +59,10 @@ WORKLOADS = {
     "C5table": dict(width=1280, height=960, frames=64, buckets=1 << 24, blocks=1 << 21, voxel=0.005, loop=2000, sensor=True,
                     desc="C5table: C3's 1280x960 frames into an unsharded table of C5's size, 2^24 buckets x 5 (1.68 GB of "
                          "VoxelEntry = 6.5 x the 256 MiB Infinity Cache), 2^21 voxel blocks, voxel 0.005 m, PINHOLE semantics"),
+    # ... and into one of half that size (839 MB): where the claim tiles' placement rule changes over (vh_api_frame.hip: claim_span)
+    "C4table": dict(width=1280, height=960, frames=64, buckets=1 << 23, blocks=1 << 21, voxel=0.005, loop=2000, sensor=True,
+                    desc="C4table: C3's 1280x960 frames into an unsharded table of 2^23 buckets x 5 (839 MB of VoxelEntry), 2^21 voxel "
+                         "blocks, voxel 0.005 m, PINHOLE semantics"),
     # BASELINE.json configs[4], per-rank share when launched with --gpus 8 (one stream per GPU)
     "C5": dict(width=1920, height=1080, frames=64, buckets=1 << 24, blocks=1 << 21, voxel=0.01, loop=500,
                desc="C5: synthetic room, 1920x1080 streams, 2^24 buckets x 5 in all, 2^21 voxel blocks per rank, "
