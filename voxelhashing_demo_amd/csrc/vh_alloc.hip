@@ -469,6 +469,9 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
         if (!p.valid || dupLeft || dupUp || !block_in_frustum(fp, s.kx, s.ky, s.kz)) return;
         const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
         if (h < fp.bucketLo || h >= fp.bucketHi) return;                // not this shard's bucket
+#ifdef VH_DEBUG_SKIP_ROLES
+        if (fp.flags & kFlagDebugNoProbe) return;
+#endif
         // (a table beyond the Infinity Cache -- the walk's loads are non-temporal then -- answers the probes from HBM)
         if (fp.flags & kFlagWalkNt) probe_and_claim<true>(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, 0), candCounter, pend);
         else probe_and_claim<false>(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, 0), candCounter, pend);

@@ -94,6 +94,7 @@ constexpr uint32_t kFlagDepthTruncation = 4u;   // truncation + truncScale * dep
 constexpr uint32_t kFlagWalkShort = 32u;        // the table walk takes 4 entries per lane instead of 8 (option "walk_entries")
 constexpr uint32_t kFlagWalkNt = 16u;           // the table walk's ptr loads are non-temporal (option "walk_nt")
 constexpr uint32_t kFlagBandRayDda = 64u;       // band allocation by the block DDA along the viewing ray (VH_BAND_RAY_DDA)
+constexpr uint32_t kFlagDebugNoProbe = 1u << 30;   // diagnostics builds only (VH_DEBUG_SKIP_ROLES): claim tiles return before probing
 constexpr uint32_t kFlagWeightSample = 8u;      // weight = max(integrationWeightSample * 1.5 * (1 - depth01), 1) (:808-811, :827)
 constexpr int kLookAhead = 10;                  // free-slot search behind a full bucket: j < 10 (:475-478)
 

@@ -265,6 +265,14 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
                            a.filter && !serial ? a.filter + a.filtNew : nullptr};
         if (role == 2u) {
             __builtin_amdgcn_s_setprio(3);
+#ifdef VH_DEBUG_SKIP_ROLES
+            if (a.skipRoles & 16u) {           // diagnostics: the claim tiles end before their probes (what the probes' wait costs the launch)
+                FrameParams fpN = fpNew;
+                fpN.flags |= kFlagDebugNoProbe;
+                claim_tile<In, kBand>(fpN, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
+                return;
+            }
+#endif
             claim_tile<In, kBand>(fpNew, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
         } else if (a.walkIndexed) {
             flatten_index_tile(fpNew, dpNew, index, CompactOut{kPipeScan + a.setNew, kPipeScanB + a.setNew, a.numEntries},
