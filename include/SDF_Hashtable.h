@@ -89,7 +89,8 @@ public:
     void garbageCollect(float sdfThreshold);
     /* Opt-in extensions (voxelhash.h, vh_set_option): "pipeline" (one launch per frame, the commit and
      * TSDF update of a frame ride in the launch of the next; flush() launches the pending half),
-     * "overflow_list", "band_mode", "depth_truncation", "weight_sample", ... */
+     * "overflow_list", "band_mode", "depth_truncation", "weight_sample", "flatten_variant" (4: the walk-free frame -- the
+     * occupancy-index walk in place of flattenKernel's scan of every entry: same results, 2-10x the frame rate on large tables), ... */
     void setOption(const char *name, int value);
     void setAllocBand(float bandMetres);
     void flush();

@@ -68,7 +68,26 @@ int main(int argc, char **argv)
         for (float z : depth) covered += z > 0.0f;
         hipFree(d_back);
     }
-    std::printf("occupied=%d allocated=%d hits=%d allocated2=%d covered=%d\n", occupied, allocated, hits, allocated2, covered);
+    // a third table on the walk-free frame (option "flatten_variant" 4: the occupancy-index walk in place of flattenKernel's scan;
+    // the same table and compact list by construction), three frames pipelined
+    int allocated3 = 0, occupied3 = 0;
+    {
+        SDF_Hashtable t3;
+        t3.setOption("flatten_variant", 4);
+        float poses[48];
+        for (int k = 0; k < 3; ++k)
+            for (int i = 0; i < 16; ++i) poses[16 * k + i] = (i % 5 == 0) ? 1.0f : 0.0f;
+        const vh_float4 *ptrs[3] = {d_verts, d_verts, d_verts};
+        t3.integrateBatch(3, poses, ptrs, nullptr);
+        if (vh_download(t3.context(), VH_BUF_HASH_TABLE, entries.data(), entries.size() * sizeof(VoxelEntry)) != VH_OK)
+            return 7;
+        for (const VoxelEntry &e : entries) allocated3 += e.ptr != VH_FREE_BLOCK;
+        vh_counters c3;
+        if (vh_get_counters(t3.context(), &c3) != VH_OK) return 8;
+        occupied3 = c3.occupied;
+    }
+    std::printf("occupied=%d allocated=%d hits=%d allocated2=%d covered=%d allocated3=%d occupied3=%d\n", occupied, allocated, hits, allocated2,
+                covered, allocated3, occupied3);
     hipFree(d_verts);
     hipFree(d_depth);
     return 0;

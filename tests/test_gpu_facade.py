@@ -35,6 +35,8 @@ def test_cpp_facade_program(oracle, vh, torch_cuda, tmp_path):
     ot.integrate(I4, verts)
     assert got["allocated2"] == len(ot.allocated())
     assert got["covered"] == int((ot.render_blocks(I4)[0] > 0).sum()) > 1000
+    # the third table: the walk-free frame through the facade (three frames = the oracle's table after its third)
+    assert got["allocated3"] == len(ot.allocated()) and got["occupied3"] == len(ot.compact())
 
 
 def test_cpp_tracking_program(oracle, vh, torch_cuda, tmp_path):

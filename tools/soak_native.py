@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Long run of the native exchange with R ranks on one GPU (loop-back transport) against ONE oracle table: many exchanges,
 a raycast round every few of them, a garbage collection now and then -- the buffer-set rotation, the deferred frames and the
-event reuse of the transport over thousands of collectives.   tools/soak_native.py [R=4] [exchanges=200] [batch=4]"""
+event reuse of the transport over thousands of collectives.   tools/soak_native.py [R=4] [exchanges=200] [batch=4] [flatten_variant=3]
+(flatten_variant 4: the shards run the walk-free multi-camera frame)"""
 import os
 import sys
 import time
@@ -19,6 +20,7 @@ from voxelhashing_demo_amd import synth
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+WALK = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 W, H = 320, 240
 kw = dict(numBuckets=1 << 14, numVoxelBlocks=1 << 13)
 kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
@@ -31,6 +33,9 @@ dd = [[torch.from_numpy(d).cuda() for d in d16[r]] for r in range(R)]
 torch.cuda.synchronize()
 full = O.OracleTable(O.default_params(**kw), W, H, 1)
 g = vdist.NativeGroup(V.default_params(**kw), W, H, 1, R, B, sensor_k_inv=kinv, key_capacity=W * H // 8 * B)
+for t_ in g.tables:
+    t_.set_option("flatten_variant", WALK)
+g.self_check()
 plan = vdist.ShardPlan(kw["numBuckets"], R)
 outs = [torch.empty((H, W), dtype=torch.float32, device="cuda") for _ in range(R)]
 t0 = time.time()
