@@ -17,6 +17,9 @@
  * the third), as the Python host of round 2 did it with two (voxelhashing_demo_amd/dist.py: ShardedPipeline) -- but one C
  * call per exchange instead of a dozen Python calls and four torch collectives.  The table sees its
  * operations in the order of the plain step sequence, so results do not depend on the pipelining.
+ * By default (option "fused_generation") the generate step has no launches of its own: it runs as a role of the frame launches
+ * that apply the exchange fed two calls earlier, over four buffer sets -- the table stream then carries generation and table
+ * work, the collectives of exchange n overlap the frame launches of exchange n-1.
  *
  * RCCL is bound at run time (dlopen of librccl.so.1, or whatever copy the process has loaded already -- torch's): the
  * library has no link-time dependency on it, and single-GPU users never load it.  No torch types anywhere.
@@ -122,18 +125,27 @@ int vh_dist_host_stats(vh_dist *d, double *seconds, uint64_t *calls);
  *                               1 makes a one-rank group run ncclAllToAll / ncclAllGather all the same: the call sequence of an
  *                               R-GPU node, exercised where only one GPU is at hand.  Set before the first exchange or behind
  *                               vh_dist_flush.
+ *   "fused_generation" 0 | 1    1 (the default): the key generation of an exchange runs as a role of the frame launches that apply
+ *                               the exchange two calls earlier -- no launches of its own, no second stream; with one rank and
+ *                               no caller stream a steady-state vh_dist_step_batch is `batch` kernel launches and no event
+ *                               operation.  An exchange is then applied by the SECOND call after the one that fed it (0: by
+ *                               the next call); vh_dist_flush applies whatever is in flight either way.  The library falls
+ *                               back to separate generation launches by itself where the role does not apply (the first two
+ *                               calls behind a flush, float packets, an allocation band, batch > 8).  Same results bit for
+ *                               bit.  Set before the first exchange or behind vh_dist_flush.
  *   "phase_timing" 0 | 1        timing events around the three phases of every exchange (vh_dist_phase_times).  Off by default.
  *   "raycast_auto_start" n      this rank's proposal for the slot capacity of vh_dist_raycast_auto's first round (default 4096;
  *                               the ranks take the largest proposal, so they need not agree on it) */
 int vh_dist_set_option(vh_dist *d, const char *name, int32_t value);
 
 /* Sums over the exchanges completed since the last reset (option "phase_timing"), microseconds on the device's clock:
- *   generate_us        the key-generation launch(es) of an exchange (its stream may share the GPU with frame launches)
+ *   generate_us        the key-generation launch(es) of an exchange (its stream may share the GPU with frame launches); with
+ *                      "fused_generation" the span of the frame launches that carried it -- the same launches apply_us times
  *   collectives_us     from the moment the exchange's collectives may start (generation done, receive buffers free) to their
  *                      completion: ncclAllToAll of the key bins + ncclAllGather of the packets (world 1: ~0, nothing is sent)
  *   apply_us           the frame launches of the exchange on the owner, first to last
  *   first_to_last_us   from the start of the generation to the end of the frame launches: the latency of one exchange (three
- *                      of them overlap)
+ *                      of them overlap; four with "fused_generation")
  *   host_enqueue_us    host time inside vh_dist_step_batch for as many calls
  * A measured scaling curve is read against these: the period of an exchange is max(generate, collectives, apply) when the
  * three streams overlap as designed, their sum when they do not. */

@@ -56,8 +56,8 @@ def test_native_exchange_with_one_rank_equals_the_oracle(oracle, vh, torch_cuda,
     nd.flush()
     ph = nd.phase_times()
     assert ph["exchanges"] == steps and ph["generate"] > 0 and ph["apply"] > 0 and ph["first_to_last"] >= ph["apply"]
-    # nothing is sent by a lone rank unless forced: the two timing events back to back (~6 us) against two RCCL kernels
-    assert (ph["collectives"] > 15.0) == forced, ph
+    # nothing is sent by a lone rank unless forced: the two timing events back to back (~5.5 us) against two RCCL kernels (15 us and more)
+    assert (ph["collectives"] > 10.0) == forced, ph
     nd.set_option("phase_timing", 0)
     assert check_shard_against_full(nd.table, ot, 0, KW["numBuckets"], 5) > 100
     c = nd.table.counters()
@@ -78,6 +78,41 @@ def test_native_exchange_with_one_rank_equals_the_oracle(oracle, vh, torch_cuda,
     torch.cuda.synchronize()
     assert int(lost.item()) > 0
     nd.close()
+    ot.close()
+
+
+@pytest.mark.parametrize("batch", [1, 4, 8])
+def test_fused_and_separate_generation_agree(oracle, vh, torch_cuda, batch):
+    """Option "fused_generation" (the default): the key generation of exchange n rides in the frame launches that apply exchange
+    n-2 (GenJob role, per-frame counters in the bins, no event operation with one rank).  The same frames through the fused form,
+    through the separate launches, and through a run that switches between the two behind a flush must leave one table: the
+    oracle's.  No timing events here, so the one-rank fused calls run in their quiet form."""
+    torch = torch_cuda
+    steps = 9
+    poses, verts = _frames(min(120, batch * steps))
+    steps = len(poses) // batch
+    kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+    d16 = [np.round(v[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for v in verts]
+    frames = [torch.from_numpy(d).cuda() for d in d16]
+    torch.cuda.synchronize()
+    ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+    for j in range(steps * batch):
+        ot.integrate(poses[j], oracle.preprocess(d16[j], kinv)[0])
+    for plan in ("fused", "separate", "switching"):
+        nd = vdist.NativeDist(vh.default_params(**KW), W, H, 1, 0, 1, batch, vdist.unique_id(), sensor_k_inv=kinv)
+        if plan == "separate":
+            nd.set_option("fused_generation", 0)
+        for s in range(steps):
+            if plan == "switching" and s in (4, 6):     # (behind a flush; the first two calls after it generate separately)
+                nd.flush()
+                nd.set_option("fused_generation", 0 if s == 4 else 1)
+            k = s * batch
+            nd.step(poses[k:k + batch], frames[k:k + batch])
+        nd.flush()
+        assert check_shard_against_full(nd.table, ot, 0, KW["numBuckets"], 5) > 100, plan
+        c = nd.table.counters()
+        assert c["bin_overflow"] == 0 and c["epoch"] == batch * steps and c["spin_timeouts"] == 0, (plan, c)
+        nd.close()
     ot.close()
 
 

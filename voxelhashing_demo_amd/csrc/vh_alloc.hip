@@ -605,14 +605,23 @@ __device__ __forceinline__ void generate_keys_tile(const FrameParams &fp, const 
 // The reference's frame (one key per pixel, fp.allocBand == 0) with kGroups pixel groups per workgroup: the keys of all groups
 // are counted in LDS first and the workgroup takes ONE global atomicAdd per owner for all of them -- the returning atomics on
 // the bin headers are what bounds the launch (above), and this divides their number by kGroups.
+// frameSlot >= 0 (fused generation, vh_shard.hip): the frames of a batch are generated by one launch after the other, and each
+// counts its records in a counter of its OWN -- int frameSlot of the bin's last two records (outCapacity excludes them) -- and writes
+// them behind the records of the frames before it, whose counters are final: a frame's records are contiguous, the consumer finds
+// them by a prefix sum of the eight counters, and nobody has to mark the end of a frame.
 template <class In, int kThreads, int kGroups>
 __device__ __forceinline__ void generate_keys_groups(const FrameParams &fp, const In &verts, int32_t numShards,
                                                      int4 *__restrict__ outBins, int32_t outCapacity, int32_t outBinStride,
-                                                     float *__restrict__ outDepth, uint32_t rankBase, uint32_t firstGroup)
+                                                     float *__restrict__ outDepth, uint32_t rankBase, uint32_t firstGroup, int frameSlot = -1)
 {
     __shared__ int ldsCount[VH_MAX_CAMERAS];
     __shared__ int ldsBase[VH_MAX_CAMERAS];
     if (threadIdx.x < VH_MAX_CAMERAS) ldsCount[threadIdx.x] = 0;
+    int frameStart = 0;                       // (lane = owner) records of the frames before this one
+    if (frameSlot >= 0 && (int)threadIdx.x < numShards) {
+        const int *cnt = reinterpret_cast<const int *>(outBins + (size_t)threadIdx.x * outBinStride + outCapacity);
+        for (int f = 0; f < frameSlot; ++f) frameStart += cnt[f];
+    }
     __syncthreads();
     const uint32_t perShard = (fp.numBuckets + (uint32_t)numShards - 1u) / (uint32_t)numShards;
     const int ln = threadIdx.x & (kWave - 1);
@@ -640,8 +649,13 @@ __device__ __forceinline__ void generate_keys_groups(const FrameParams &fp, cons
         }
     }
     __syncthreads();
-    if ((int)threadIdx.x < numShards && ldsCount[threadIdx.x] > 0)
-        ldsBase[threadIdx.x] = atomicAdd(&outBins[(size_t)threadIdx.x * outBinStride].x, ldsCount[threadIdx.x]);
+    if ((int)threadIdx.x < numShards && ldsCount[threadIdx.x] > 0) {
+        if (frameSlot >= 0)
+            ldsBase[threadIdx.x] = frameStart + atomicAdd(reinterpret_cast<int *>(outBins + (size_t)threadIdx.x * outBinStride + outCapacity) + frameSlot,
+                                                          ldsCount[threadIdx.x]);
+        else
+            ldsBase[threadIdx.x] = atomicAdd(&outBins[(size_t)threadIdx.x * outBinStride].x, ldsCount[threadIdx.x]);
+    }
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < kGroups; ++g) {

@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <deque>
 #include <condition_variable>
 #include <map>
 #include <memory>
@@ -12,6 +13,9 @@
 #include <rccl/rccl.h>          // types and prototypes only: the library is bound at run time (rccl_load)
 
 #include "../../include/voxelhash_dist.h"
+#ifndef VH_DIST_FUSED_DEFAULT
+#define VH_DIST_FUSED_DEFAULT 1      // option "fused_generation" of a new vh_dist
+#endif
 
 // ---------------------------------------------------------------------------
 // RCCL, bound at run time
@@ -180,7 +184,10 @@ struct vh_dist {
     // Three buffer sets: while exchange n travels into one, the frames of exchange n-1 are applied from the second, and the
     // last frame of exchange n-2 -- whose commit + TSDF update ride in the first launch of n-1's frames (pipeline_shards 2) --
     // still reads its packets in the third.
-    static constexpr int kSets = 3;
+    // (fused generation, below: FOUR sets -- the generation of exchange n rides in the frame launches of exchange n-2, its collectives
+    // travel beside the launches of n-1, it is applied with n+2's generation aboard, and its last frame's deferred half still reads
+    // its packets in the first launch after that.  The separate-generation path keeps rotating over the first three.)
+    static constexpr int kSets = 4, kSetsSeparate = 3;
     hipEvent_t generated[kSets] = {}, ready[kSets] = {}, first[kSets] = {};     // first: behind the first launch of the set's frames
     struct Set {
         int32_t *binsSend = nullptr, *binsRecv = nullptr;      // [world][batch][capacity][4]
@@ -198,6 +205,12 @@ struct vh_dist {
     int32_t autoStart = 4096;              // option "raycast_auto_start": this rank's proposal for the first round (the ranks take the largest)
     double hostSeconds = 0.0;
     uint64_t hostCalls = 0;
+    // option "fused_generation": the key generation as a role of the frame launches (vh_shard.hip: GenJob)
+    bool fused = VH_DIST_FUSED_DEFAULT != 0;
+    std::deque<int> inflight;              // fused path: the sets of the exchanges generated (and travelling / landed) but not applied yet: at most two
+    bool genOnTable[kSets] = {};           // ... whose generation ran on the table stream (no event needed to apply it with one rank)
+    bool headersClean[kSets] = {};         // ... whose send-bin headers the previous exchange's last job has zeroed
+    hipEvent_t tableMark = nullptr;        // "everything queued on the table stream so far" (separate generation inside the fused path)
     bool forceCollectives = false;         // option "force_collectives": world 1 runs ncclAllToAll / ncclAllGather anyway (tests; the bench's first rounds)
     // option "phase_timing": per-exchange phase times from timing events of the library's own (vh_dist_phase_times)
     bool phaseTiming = false;
@@ -319,7 +332,7 @@ static void dist_free(vh_dist *d)
     for (int i = 0; i < vh_dist::kSets; ++i)
         for (hipEvent_t e : {d->generated[i], d->ready[i], d->first[i]})
             if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {d->userEvent, d->outEvent})
+    for (hipEvent_t e : {d->userEvent, d->outEvent, d->tableMark})
         if (e) (void)hipEventDestroy(e);
     for (auto &pe : d->phaseEv)
         for (hipEvent_t e : {pe.gen0, pe.gen1, pe.comm0, pe.comm1, pe.app0, pe.app1})
@@ -412,7 +425,7 @@ extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_I
     // generation of exchange n+1 would not slow the frame launch it runs beside (28 instead of 20 us): 43.9 / 43.4 / 43.2 k
     // frames/s against 43.8 k without a mask, the launch as slow as before -- what the two kernels contend for is not CUs.)
     for (hipStream_t *s : {&d->sGen, &d->sComm, &d->sTable}) VH_DIST_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking));
-    for (hipEvent_t *e : {&d->userEvent, &d->outEvent}) VH_DIST_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t *e : {&d->userEvent, &d->outEvent, &d->tableMark}) VH_DIST_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
     for (int i = 0; i < vh_dist::kSets; ++i) {
 #ifndef VH_DIST_EVENT_FLAGS_FIRST
 #define VH_DIST_EVENT_FLAGS_FIRST (hipEventDisableTiming | hipEventDisableSystemFence)
@@ -493,11 +506,18 @@ extern "C" int vh_dist_set_option(vh_dist *d, const char *name, int32_t value)
     if (!d || !name) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(d->device);
     if (std::strcmp(name, "force_collectives") == 0) {
-        if (d->count != 0 && d->pending >= 0) return fail(VH_ERR_INVALID_ARGUMENT, "force_collectives: set it before the first exchange or behind vh_dist_flush");
+        if (d->pending >= 0 || !d->inflight.empty()) return fail(VH_ERR_INVALID_ARGUMENT, "force_collectives: set it before the first exchange or behind vh_dist_flush");
         d->forceCollectives = value != 0;
         return VH_OK;
     }
     if (std::strcmp(name, "raycast_auto_start") == 0 && value >= 1) { d->autoStart = value; return VH_OK; }
+    if (std::strcmp(name, "fused_generation") == 0) {
+        if (d->pending >= 0 || !d->inflight.empty()) return fail(VH_ERR_INVALID_ARGUMENT, "fused_generation: set it before the first exchange or behind vh_dist_flush");
+        d->fused = value != 0;
+        d->count = 0;                         // (the set rotation restarts: nothing is in flight)
+        for (bool &b : d->headersClean) b = false;
+        return VH_OK;
+    }
     if (std::strcmp(name, "phase_timing") == 0) {
         if (value && !d->phaseEv[0].gen0)
             for (auto &e : d->phaseEv)
@@ -577,19 +597,21 @@ extern "C" int vh_dist_self_check(vh_dist *d)
     return VH_OK;
 }
 
-static int dist_apply(vh_dist *d, int s)
+// jobs (fused path, nullable): the generation jobs that ride in this exchange's frame launches
+static int dist_apply(vh_dist *d, int s, const GenJob *jobs = nullptr)
 {
+    const bool alone = d->cfg.world == 1 && !d->forceCollectives;
 #ifndef VH_DEBUG_DIST_NO_READY_WAIT          // (diagnostics builds: what the two event operations at a batch's boundary cost)
-    VH_HIP(hipStreamWaitEvent(d->sTable, d->ready[s], 0));
+    // (fused path, one rank: the exchange was generated on this very stream and nothing travelled: stream order is the hand-off)
+    if (!(d->fused && alone && d->genOnTable[s])) VH_HIP(hipStreamWaitEvent(d->sTable, d->ready[s], 0));
 #endif
     d->shard->stream = d->sTable;
 #ifndef VH_DEBUG_DIST_NO_FIRST
-    d->shard->multiFirstEvent = d->first[s];
+    if (!d->fused) d->shard->multiFirstEvent = d->first[s];
 #endif
-    const bool alone = d->cfg.world == 1 && !d->forceCollectives;
     if (d->phaseTiming && d->phaseEv[s].armed) VH_HIP(hipEventRecord(d->phaseEv[s].app0, d->sTable));
-    const int rc = vh_apply_frames_batch(d->shard, d->cfg.batch, alone ? d->set[s].binsSend : d->set[s].binsRecv, d->cfg.world, d->capacity, 0,
-                                         VH_BIN_PER_BATCH, d->cfg.world, alone ? d->set[s].packet : d->set[s].packets, 0, 0);
+    const int rc = vh_apply_frames_batch_gen(d->shard, d->cfg.batch, alone ? d->set[s].binsSend : d->set[s].binsRecv, d->cfg.world, d->capacity, 0,
+                                             VH_BIN_PER_BATCH, d->cfg.world, alone ? d->set[s].packet : d->set[s].packets, 0, 0, jobs);
     d->shard->multiFirstEvent = nullptr;
     if (rc == VH_OK && d->phaseTiming && d->phaseEv[s].armed) {
         VH_HIP(hipEventRecord(d->phaseEv[s].app1, d->sTable));
@@ -598,12 +620,120 @@ static int dist_apply(vh_dist *d, int s)
     return rc;
 }
 
+// The fused path (option "fused_generation", the default): exchange n is GENERATED inside the frame launches that apply exchange
+// n-2 (GenJob: a role of frame_multi_pipelined_kernel), its collectives travel beside the launches of exchange n-1, and it is applied
+// in call n+2 with the generation of n+2 aboard.  One stream carries table work and generation, so nothing of the library runs
+// beside the frame launches: with one rank a steady-state call is B launches and NO event operation.  Whenever a call cannot fuse
+// -- the first two calls (nothing to ride in), a band, float packets, the overflow list -- it generates with the kernels of the
+// separate path on sGen, ordered behind "everything queued on the table stream so far".
+static int dist_step_fused(vh_dist *d, const float *poses, const void *const *d_frames)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    DeviceGuard guard(d->device);
+    const int s = (int)(d->count % vh_dist::kSets), sNext = (s + 1) % vh_dist::kSets;
+    const int B = d->cfg.batch, R = d->cfg.world;
+    vh_dist::Set &set = d->set[s];
+    const bool alone = R == 1 && !d->forceCollectives;
+    int rc;
+    const bool canFuse = d->inflight.size() == 2 && d->cfg.packet_format == VH_PACKET_U16 && B <= 8 && d->capacity >= 8 &&
+                         multi_can_fuse_generation(d->shard, R, d->capacity);
+    if (d->haveUser) VH_HIP(hipEventRecord(d->userEvent, d->userStream));
+    if (d->phaseTiming) {
+        phases_harvest(d, s);
+        d->phaseEv[s].armed = hipEventRecord(d->phaseEv[s].gen0, canFuse ? d->sTable : d->sGen) == hipSuccess;
+        d->phaseEv[s].applied = false;
+    }
+    GenJob jobs[VH_MAX_CAMERAS];
+    if (canFuse) {
+        const uint32_t tiles = host_num_tiles(d->shard);
+        for (int b = 0; b < B; ++b) {
+            GenJob &j = jobs[b];
+            std::memset(&j, 0, sizeof j);
+            if ((rc = vh_set_pose(d->shard, poses + 16 * (size_t)b)) != VH_OK) return rc;          // pose + cofactor inverse
+            if (!d_frames[b]) return fail(VH_ERR_INVALID_ARGUMENT, "null depth image");
+            std::memcpy(j.T, d->shard->fp.T, sizeof j.T);
+            std::memcpy(j.Tinv, d->shard->fp.Tinv, sizeof j.Tinv);
+            std::memcpy(j.k, d->cfg.k_inv, sizeof j.k);
+            j.unit = 5000.0f;                                                                       // CameraTrackingUtils.cu:64
+            j.blocks = (tiles + kFusedGenGroups - 1) / kFusedGenGroups;
+            j.numShards = R; j.capacity = d->capacity; j.binStride = d->capacity;
+            j.bins = reinterpret_cast<int4 *>(set.binsSend);
+            j.packet = set.packet + (size_t)b * d->packetUnits;
+            j.depth = reinterpret_cast<const uint16_t *>(d_frames[b]);
+            j.rankBase = (uint32_t)b << kRankCameraShift;
+            if (b == B - 1) { j.clearBins = reinterpret_cast<int4 *>(d->set[sNext].binsSend); j.clearStride = d->capacity; }
+            j.frame = b; j.batch = B;
+        }
+    } else {
+        // separate generation: this set's buffers were last read by table work queued in earlier calls
+        VH_HIP(hipEventRecord(d->tableMark, d->sTable));
+        VH_HIP(hipStreamWaitEvent(d->sGen, d->tableMark, 0));
+        if (d->haveUser) VH_HIP(hipStreamWaitEvent(d->sGen, d->userEvent, 0));
+        d->shard->stream = d->sGen;
+        if (d->cfg.packet_format == VH_PACKET_U16)
+            rc = vh_generate_keys_depth_batch(d->shard, B, poses, reinterpret_cast<const uint16_t *const *>(d_frames), d->cfg.k_inv,
+                                              (uint32_t)d->cfg.rank, R, set.binsSend, d->capacity, 0, VH_BIN_PER_BATCH, set.packet, 0);
+        else
+            rc = vh_generate_keys_batch(d->shard, B, poses, reinterpret_cast<const vh_float4 *const *>(d_frames), (uint32_t)d->cfg.rank, R,
+                                        set.binsSend, d->capacity, 0, VH_BIN_PER_BATCH, set.packet, 0);
+        d->shard->stream = d->sTable;
+        if (rc != VH_OK) return rc;
+        if (d->phaseTiming && d->phaseEv[s].armed) VH_HIP(hipEventRecord(d->phaseEv[s].gen1, d->sGen));
+        VH_HIP(hipEventRecord(d->generated[s], d->sGen));
+        d->genOnTable[s] = false;
+    }
+    // apply exchange n-2 (with this exchange's generation aboard when it can ride)
+    bool quiet = false;                     // one rank, fused, nobody else to tell: no event operation at all
+    if (d->inflight.size() == 2) {
+        const int old = d->inflight.front();
+        d->inflight.pop_front();
+        if (canFuse) {
+            if (d->haveUser) VH_HIP(hipStreamWaitEvent(d->sTable, d->userEvent, 0));
+            if (!d->headersClean[s]) {      // (the first fused call behind a separate one: nobody has emptied this set's send bins)
+                prepare_bins_fused_kernel<<<1, 64, 0, d->sTable>>>(reinterpret_cast<int4 *>(set.binsSend), R, d->capacity, d->capacity, B);
+            }
+        }
+        if ((rc = dist_apply(d, old, canFuse ? jobs : nullptr)) != VH_OK) return rc;
+        if (canFuse) {
+            d->genOnTable[s] = true;
+            d->headersClean[sNext] = true;
+            quiet = alone && !d->haveUser && !d->phaseTiming;
+            if (!quiet) {
+                if (d->phaseTiming && d->phaseEv[s].armed) VH_HIP(hipEventRecord(d->phaseEv[s].gen1, d->sTable));
+                VH_HIP(hipEventRecord(d->generated[s], d->sTable));
+            }
+        }
+    }
+    d->headersClean[s] = false;
+    if (!quiet) {
+        // (the frames have been consumed once `generated` fires: the caller's stream may overwrite them behind it)
+        if (d->haveUser) VH_HIP(hipStreamWaitEvent(d->userStream, d->generated[s], 0));
+        // exchange: the receive buffers of this set were last read by table work of earlier calls -- behind which `generated` lies when
+        // it was recorded on the table stream, and behind tableMark otherwise
+        VH_HIP(hipStreamWaitEvent(d->sComm, d->generated[s], 0));
+        if (!canFuse) VH_HIP(hipStreamWaitEvent(d->sComm, d->tableMark, 0));
+        if (d->phaseTiming && d->phaseEv[s].armed) VH_HIP(hipEventRecord(d->phaseEv[s].comm0, d->sComm));
+        if (!alone) {
+            if ((rc = d->transport->all_to_all(d, set.binsSend, set.binsRecv, (size_t)d->capacity * 4 * sizeof(int32_t), d->sComm)) != VH_OK) return rc;
+            if ((rc = d->transport->all_gather(d, set.packet, set.packets, (size_t)B * d->packetUnits * sizeof(float), d->sComm)) != VH_OK) return rc;
+        }
+        if (d->phaseTiming && d->phaseEv[s].armed) VH_HIP(hipEventRecord(d->phaseEv[s].comm1, d->sComm));
+        VH_HIP(hipEventRecord(d->ready[s], d->sComm));
+    }
+    d->inflight.push_back(s);
+    d->count += 1;
+    d->hostSeconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    d->hostCalls += 1;
+    return VH_OK;
+}
+
 extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *const *d_frames)
 {
     if (!d || !poses || !d_frames) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     const auto t0 = std::chrono::steady_clock::now();
     DeviceGuard guard(d->device);
-    const int s = (int)(d->count % vh_dist::kSets);
+    if (d->fused) return dist_step_fused(d, poses, d_frames);
+    const int s = (int)(d->count % vh_dist::kSetsSeparate);
     const int B = d->cfg.batch, R = d->cfg.world;
     vh_dist::Set &set = d->set[s];
     int rc;
@@ -613,11 +743,11 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
         VH_HIP(hipEventRecord(d->userEvent, d->userStream));
         VH_HIP(hipStreamWaitEvent(d->sGen, d->userEvent, 0));
     }
-    if (d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sGen, d->ready[s], 0));
+    if (d->count >= vh_dist::kSetsSeparate) VH_HIP(hipStreamWaitEvent(d->sGen, d->ready[s], 0));
     // (one rank: the frames are applied straight from the send buffers, so those are free only when the frames of exchange
     // count-3 are done, the last of which rode in the first launch of exchange count-2's frames)
     const bool alone = R == 1 && !d->forceCollectives;
-    if (alone && d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sGen, d->first[(s + 1) % vh_dist::kSets], 0));
+    if (alone && d->count >= vh_dist::kSetsSeparate) VH_HIP(hipStreamWaitEvent(d->sGen, d->first[(s + 1) % vh_dist::kSetsSeparate], 0));
     if (d->phaseTiming) {
         phases_harvest(d, s);
         d->phaseEv[s].armed = hipEventRecord(d->phaseEv[s].gen0, d->sGen) == hipSuccess;
@@ -645,7 +775,7 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     // exchange: the receive buffers of this set were last read by the frames of exchange count-3, the last of which rode in
     // the first launch of exchange count-2's frames (queued by the previous call)
     VH_HIP(hipStreamWaitEvent(d->sComm, d->generated[s], 0));
-    if (d->count >= vh_dist::kSets) VH_HIP(hipStreamWaitEvent(d->sComm, d->first[(s + 1) % vh_dist::kSets], 0));
+    if (d->count >= vh_dist::kSetsSeparate) VH_HIP(hipStreamWaitEvent(d->sComm, d->first[(s + 1) % vh_dist::kSetsSeparate], 0));
     if (d->phaseTiming && d->phaseEv[s].armed) VH_HIP(hipEventRecord(d->phaseEv[s].comm0, d->sComm));      // (behind the waits: when the collectives may start)
     if (!alone) {
         if ((rc = d->transport->all_to_all(d, set.binsSend, set.binsRecv, (size_t)d->capacity * 4 * sizeof(int32_t), d->sComm)) != VH_OK) return rc;
@@ -667,6 +797,12 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
 // applies the exchange in flight and the last frame's deferred half: everything fed is queued on the table stream
 static int dist_drain(vh_dist *d)
 {
+    while (!d->inflight.empty()) {          // fused path: up to two exchanges generated, not applied
+        const int s = d->inflight.front();
+        d->inflight.pop_front();
+        const int rc = dist_apply(d, s);
+        if (rc != VH_OK) return rc;
+    }
     if (d->pending >= 0) {
         const int rc = dist_apply(d, d->pending);
         if (rc != VH_OK) return rc;

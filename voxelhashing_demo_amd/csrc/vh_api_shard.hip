@@ -384,7 +384,7 @@ struct MultiBatch {
     bool perBatch;           // the bins hold the whole batch (frameStride 0): a launch claims the records of its frame
 };
 
-static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b)
+static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b, const GenJob *job = nullptr)
 {
     MultiPending &mp = c->multiPend;
     const bool doNew = mb != nullptr, hasOld = mp.active;
@@ -431,10 +431,16 @@ static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b)
     const DevPtrs dpOld = pipe_view(c, oldParity);
     a.claimOld = dpOld.claim; a.candOld = dpOld.candidates; a.compactOld = dpOld.compact; a.maskOld = maskOf[oldParity];
     a.candCapacityOld = dpOld.candCapacity;
-    const dim3 grid(a.commitBlocks + a.integrateBlocks + a.claimBlocks + a.walkBlocks);
     const int format = doNew ? c->packetFormat : mp.packetFormat;
     const bool serial = (c->fp.flags & kFlagOverflow) != 0u;
-    if (a.walkIndexed)         // (never with the overflow list, hence never serialised)
+    // the fused generation role (vh_dist): sensor frames, no overflow list (its launches may be serialised inside), no band
+    const bool gen = job && job->blocks && doNew && format == VH_PACKET_U16 && !serial;
+    if (gen) a.gen = *job;
+    const dim3 grid(a.commitBlocks + a.integrateBlocks + (gen ? a.gen.blocks : 0u) + a.claimBlocks + a.walkBlocks);
+    if (gen)
+        rc = a.walkIndexed ? launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<true, false, true, true>, grid, dim3(256), c->fp, dpNew, a)
+                           : launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<true, false, false, true>, grid, dim3(256), c->fp, dpNew, a);
+    else if (a.walkIndexed)         // (never with the overflow list, hence never serialised)
         rc = format == VH_PACKET_U16 ? launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<true, false, true>, grid, dim3(256), c->fp, dpNew, a)
                                      : launch(c, kPhaseFramePipelined, frame_multi_pipelined_kernel<false, false, true>, grid, dim3(256), c->fp, dpNew, a);
     else
@@ -479,9 +485,33 @@ static int flush_multi_pending(vh_context *c)
 
 // `batch` multi-camera frames applied one after the other, each as the fused pair of launches
 // (new lock epoch; {claim bins || walk}; {commit + integrate}).
+// Can the multi-camera frames of this context carry a fused generation role (launch_multi_pipelined: gen)?  What vh_dist asks
+// before it hands vh_apply_frames_batch_gen the jobs instead of launching the generation itself.
+static bool multi_can_fuse_generation(const vh_context *c, int32_t num_bins, int32_t capacity)
+{
+    uint32_t parts = (uint32_t)grid_for((size_t)capacity, 256 * 4);
+    if (parts < 1) parts = 1;
+    return c->pipelineShards && c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks && !(c->fp.flags & kFlagOverflow) &&
+           c->packetFormat == VH_PACKET_U16 && !(c->fp.allocBand > 0.0f) &&
+           serial_launch_pays(c, (uint32_t)num_bins * parts + (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLaneShort));
+}
+
+static int vh_apply_frames_batch_gen(vh_context *c, int32_t batch, const int32_t *d_bins, int32_t num_bins,
+                                     int32_t capacity, int32_t bin_stride, int32_t frame_stride, int32_t num_cams,
+                                     const float *d_packets, size_t packet_stride, size_t packet_frame_stride, const GenJob *jobs);
+
 extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t *d_bins, int32_t num_bins,
                                      int32_t capacity, int32_t bin_stride, int32_t frame_stride, int32_t num_cams,
                                      const float *d_packets, size_t packet_stride, size_t packet_frame_stride)
+{
+    return vh_apply_frames_batch_gen(c, batch, d_bins, num_bins, capacity, bin_stride, frame_stride, num_cams, d_packets, packet_stride,
+                                     packet_frame_stride, nullptr);
+}
+
+// jobs (nullable): one fused generation job per frame of the batch (GenJob, vh_shard.hip), riding in the launch of that frame
+static int vh_apply_frames_batch_gen(vh_context *c, int32_t batch, const int32_t *d_bins, int32_t num_bins,
+                                     int32_t capacity, int32_t bin_stride, int32_t frame_stride, int32_t num_cams,
+                                     const float *d_packets, size_t packet_stride, size_t packet_frame_stride, const GenJob *jobs)
 {
     if (!c || !d_bins || !d_packets || batch <= 0 || num_bins <= 0 || capacity < 2 || num_cams <= 0 ||
         num_cams > VH_MAX_CAMERAS)
@@ -533,7 +563,7 @@ extern "C" int vh_apply_frames_batch(vh_context *c, int32_t batch, const int32_t
             // at the epoch wrap vh_reset_mutexes clears the claim words, which the pending frame still needs: it is
             // served by a launch of its own first
             if (mp.active && c->fp.epoch >= kMaxClaimEpoch) doNew = false;
-            if ((rc = launch_multi_pipelined(c, doNew ? &mb : nullptr, b)) != VH_OK) return rc;
+            if ((rc = launch_multi_pipelined(c, doNew ? &mb : nullptr, b, doNew && jobs ? jobs + b : nullptr)) != VH_OK) return rc;
             if (doNew) {
                 if (b == 0 && c->multiFirstEvent) VH_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(c->multiFirstEvent), c->stream));
                 ++b;

@@ -4,6 +4,11 @@
 
 namespace vh {
 
+// A fused-generation bin: the frames of a batch are generated one launch after the other, each counting its records in a counter
+// of its own (eight ints in the bin's last two records; batches of up to 8 frames), so the records of frame b lie between two prefix
+// sums of the counters; header .w = kBinFrameMarks | batch says so, .x is unused, and the records stay out of the last two (capacity - 2).
+constexpr int kBinFrameMarks = 0x40000000;
+
 // ---------------------------------------------------------------------------
 // multi-camera frame on a bucket-range shard
 // ---------------------------------------------------------------------------
@@ -21,17 +26,33 @@ __device__ __forceinline__ void claim_bin_slice(const FrameParams &fp, const Dev
     const int4 *bin = bins + (size_t)binIndex * binStride;
     const int4 head = bin[0];
     int n = head.x;
-    if (n > capacity - 1) {
+    const bool frameMarks = frame >= 0 && (head.w & kBinFrameMarks) != 0;      // (fused generation: per-frame counters in the last two records)
+    const int room = frameMarks ? capacity - 3 : capacity - 1;
+    int lo = 0, hiMark = 0;
+    if (frameMarks) {
+        const int4 c0 = bin[capacity - 2], c1 = bin[capacity - 1];
+        const int cnt[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        n = 0;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            if (f == frame) lo = n;
+            n += cnt[f];
+            if (f == frame) hiMark = n;
+        }
+    }
+    if (n > room) {
         if (part == 0 && threadIdx.x == 0) atomicAdd(dp.counters + kBinOverflow, 1);
-        n = capacity - 1;
+        n = room;
     }
     // A per-batch bin is filled by one generation launch per group of frames, one after the other, and the generator leaves a
     // mark behind each of them (bin_mark_kernel: header .y, .z = the count after the first and the second launch, .w = frames per
     // launch | marks << 8): the records of `frame` lie between two marks, and its launch reads only those (round 5: every launch
     // of a batch scanned the whole bin for its own frame's records, 0.8 us per launch at C2 size -- profiles/r04_sharded_*.txt).
     // No marks (.w == 0: bins not made by this generator, or more than three launches per batch): the whole bin.
-    int lo = 0;
-    if (frame >= 0 && head.w != 0) {
+    if (frameMarks) {
+        lo = min(lo, n);
+        n = min(hiMark, n);
+    } else if (frame >= 0 && head.w != 0) {
         const int per = head.w & 0xff, marks = (head.w >> 8) & 0xff, g = frame / per;
         const int m0 = min(head.y, n), m1 = min(head.z, n);
         lo = g == 0 ? 0 : g == 1 ? m0 : m1;
@@ -269,8 +290,35 @@ __global__ __launch_bounds__(256) void frame_multi_commit_integrate_kernel(const
 // The two frames differ in their lock epoch, their bins and packets (both lie in the batch's receive buffers, which
 // stay valid until the batch has been applied) and in the three buffers that alternate (claim words, candidate list,
 // compact list with its camera masks); the poses travel inside the packets.  A batch of B frames is B + 1 launches.
+// Fused key generation (round 5; vh_dist option "fused_generation"): the launch that applies frame b of one exchange also turns
+// frame b of THIS rank's camera for a LATER exchange into keys binned by owner + its packet -- the work of
+// generate_keys_sensor_batch_kernel (vh_alloc.hip: generate_keys_groups), as a role of 256-lane workgroups of this grid instead of
+// a kernel of its own on a second stream, which cost the frame launches ~6 % by running beside them and ~3 % in the gaps two
+// queues leave (profiles/r05_timeline_C2sharded.txt).  No band, sensor frames (the host checks).
+#ifndef VH_FUSED_GEN_GROUPS
+#define VH_FUSED_GEN_GROUPS 8        // (same box, sharded leg with one rank, frames/s: 2 groups 40.4 k, 4: 47.1 k, 8: 47.8-47.9 k, 12: 37.6 k, 16: 33.6 k;
+                                     //  the separate generation 45.5-45.7 k -- profiles/r05_fused_generation_ab.txt)
+#endif
+#ifndef VH_FUSED_GEN_PRIO
+#define VH_FUSED_GEN_PRIO 0
+#endif
+constexpr int kFusedGenGroups = VH_FUSED_GEN_GROUPS;            // 16x16 pixel tiles per generation workgroup (one returning atomic per owner for all of them)
+struct GenJob {
+    uint32_t blocks;                           // workgroups of the role (0: none in this launch)
+    int32_t numShards, capacity, binStride;
+    int4 *bins;                                // this rank's send bins of the later exchange: [owner][capacity]
+    float *packet;                             // ... and its packet of this frame
+    const uint16_t *depth;
+    uint32_t rankBase;                         // frame index << kRankCameraShift (per-batch bins)
+    float T[16], Tinv[16], k[9], unit;
+    int4 *clearBins;                           // the send bins whose headers the LAST frame's job zeroes for the exchange after (or null)
+    int32_t clearStride;
+    int32_t frame, batch;                      // this frame's index in its batch: the role's last workgroup marks the frame's end in the bins
+};
+
+
 struct MultiPipeArgs {
-    uint32_t claimBlocks, walkBlocks, commitBlocks, integrateBlocks;     // roles by workgroup index, in this order: commit, integrate, claim/walk interleaved
+    uint32_t claimBlocks, walkBlocks, commitBlocks, integrateBlocks;     // roles by workgroup index, in this order: commit, integrate, [generation,] claim/walk interleaved
     uint32_t partsPerBin, numBins, numEntries;
     int32_t capacity, binStride, numCams;
     int32_t binFrame;            // >= 0: the bins hold the whole batch, this launch claims the records of that frame
@@ -290,6 +338,7 @@ struct MultiPipeArgs {
     VoxelEntry *compactOld;
     uint32_t *maskOld;
     uint32_t candCapacityOld;
+    GenJob gen;
 };
 
 // (builds with the option flags folded in, as frame_pipelined_kernel has them, were measured here too: 4.2 k instead of 5.3 k
@@ -297,9 +346,48 @@ struct MultiPipeArgs {
 // kIndexed: the walk-free multi-camera frame (a.walkIndexed), a build of its own -- with the index walk as a run-time branch of the
 // one build the default launch went from 18.7 to 20.8 us on the world-1 sharded leg (the code of these launches is weighed by the
 // microsecond, vh_frame.hip).
-template <bool kSensor, bool kSerial, bool kIndexed = false>
+template <bool kSensor, bool kSerial, bool kIndexed = false, bool kGen = false>
 __global__ __launch_bounds__(256) void frame_multi_pipelined_kernel(const FrameParams fp, const DevPtrs dp, const MultiPipeArgs a)
 {
+    // (first launch of a run: workgroup 0 -- whatever its role -- leaves the free-block count the next launch tests frame i+1's insertions against)
+    if (!a.hasOld && blockIdx.x == 0u && threadIdx.x == 0) dp.counters[kPipeHeapFree + a.setNew] = dp.counters[kHeapCounter] + 1;
+    if constexpr (kGen) {
+        // ---- generation role: the first a.gen.blocks workgroups behind commit + TSDF update ----
+        const uint32_t g0 = a.commitBlocks + a.integrateBlocks;
+        if (blockIdx.x >= g0 && blockIdx.x < g0 + a.gen.blocks) {
+            const uint32_t g = blockIdx.x - g0;
+            if (VH_FUSED_GEN_PRIO) __builtin_amdgcn_s_setprio(VH_FUSED_GEN_PRIO);
+            FrameParams fg = fp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { fg.T[i] = a.gen.T[i]; fg.Tinv[i] = a.gen.Tinv[i]; }
+            SensorImage in;
+            in.depth = a.gen.depth;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) in.k[i] = a.gen.k[i];
+            in.unit = a.gen.unit;
+            float *pk = a.gen.packet;
+            if (g == 0 && threadIdx.x < kPacketHeaderU16) {
+                const int t = threadIdx.x;
+                pk[t] = t < 16 ? a.gen.T[t] : t < 32 ? a.gen.Tinv[t - 16] : t == 32 ? a.gen.k[6] : t == 33 ? a.gen.k[7] : t == 34 ? a.gen.k[8] : a.gen.unit;
+            }
+            if (g == 0 && a.gen.clearBins && (int)threadIdx.x < a.gen.numShards) {    // (the exchange after this one starts from empty bins)
+                int4 *nb = a.gen.clearBins + (size_t)threadIdx.x * a.gen.clearStride;
+                nb[0] = make_int4(0, 0, 0, kBinFrameMarks | a.gen.batch);
+                nb[a.gen.capacity - 2] = make_int4(0, 0, 0, 0);
+                nb[a.gen.capacity - 1] = make_int4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < kFusedGenGroups; ++j) {            // the image itself, one pixel per lane
+                const int idx = ((int)g * kFusedGenGroups + j) * 256 + (int)threadIdx.x;
+                if (idx < fp.width * fp.height) reinterpret_cast<uint16_t *>(pk + kPacketHeaderU16)[idx] = in.depth[idx];
+            }
+            // (batches of up to 8 frames: per-frame counters in the bins' last two records, generate_keys_groups; the host checks)
+            generate_keys_groups<SensorImage, 256, kFusedGenGroups>(fg, in, a.gen.numShards, a.gen.bins, a.gen.capacity - 2, a.gen.binStride, nullptr,
+                                                                    a.gen.rankBase, g * (uint32_t)kFusedGenGroups, a.gen.frame);
+            return;
+        }
+    }
+    const uint32_t genBlocks = kGen ? a.gen.blocks : 0u;
     int32_t *counters = dp.counters;
     const int demandedOld = a.hasOld ? counters[kPipeCand + a.setOld] : 0;
     const int candOld = min(demandedOld, (int)a.candCapacityOld);
@@ -307,15 +395,14 @@ __global__ __launch_bounds__(256) void frame_multi_pipelined_kernel(const FrameP
     constexpr bool serial = kSerial;
     const bool live = serial ? a.hasOld != 0u : a.hasOld && counters[kPipeHeapFree + a.setOld] >= counters[kPipeWinners + a.setOld];
     const uint32_t b = blockIdx.x;
-    if (!a.hasOld && b == 0u && threadIdx.x == 0) counters[kPipeHeapFree + a.setNew] = counters[kHeapCounter] + 1;
-    if (b >= a.commitBlocks + a.integrateBlocks) {
+    if (b >= a.commitBlocks + a.integrateBlocks + genBlocks) {
         // ---- frame i+1: claim its bins || walk the shard for its cameras ----
         if (!a.hasNew) return;
         if (serial && a.hasOld) {
             if (!wait_commit_done(counters, a.doneTag, a.spinLimit)) return;
         }
         const Pending pend{a.hasOld && !serial ? a.claimOld : nullptr, a.candOld, a.epochOld, live, serial ? -1 : kPipeWinners + a.setNew};
-        const uint32_t r = b - a.commitBlocks - a.integrateBlocks;
+        const uint32_t r = b - a.commitBlocks - a.integrateBlocks - genBlocks;
         uint32_t before = a.claimBlocks, after = a.claimBlocks;
         if constexpr (kIndexed) {
             // (the walk-free frame: the index tiles first, as in frame_pipelined)
@@ -449,6 +536,17 @@ __global__ void bin_mark_kernel(int4 *bins, int32_t numShards, int32_t binStride
     const int count = head->x;
     if (g == 0) head->y = count; else head->z = count;
     head->w = framesPerLaunch | (marks << 8);
+}
+
+// ... of a fused-generation bin: header {0, 0, 0, kBinFrameMarks | batch}, the eight frame counters zero
+__global__ void prepare_bins_fused_kernel(int4 *bins, int32_t numShards, int32_t binStride, int32_t capacity, int32_t batch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numShards) return;
+    int4 *nb = bins + (size_t)i * binStride;
+    nb[0] = make_int4(0, 0, 0, kBinFrameMarks | batch);
+    nb[capacity - 2] = make_int4(0, 0, 0, 0);
+    nb[capacity - 1] = make_int4(0, 0, 0, 0);
 }
 
 // Zeroes the header record of the bins of `batch` frames x numShards shards before

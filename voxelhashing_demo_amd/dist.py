@@ -892,7 +892,10 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
 
             for kv in getattr(args, "option", []) or []:          # A/B switches (bench.py --option name=value)
                 k_, v_ = kv.split("=")
-                nd.table.set_option(k_, int(v_))
+                if k_ in ("fused_generation", "force_collectives", "raycast_auto_start"):      # options of the exchange itself
+                    nd.set_option(k_, int(v_))
+                else:
+                    nd.table.set_option(k_, int(v_))
 
             class _Shard:          # what the rest of this function reads of a HipShard
                 table, packet_floats = nd.table, (36 + Wd * Ht // 2) if sensor else (32 + Wd * Ht)
@@ -986,7 +989,8 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             phases = dict(zip(("generate", "collectives", "apply", "first_to_last", "host_enqueue"), [round(float(x), 2) for x in pt.tolist()]),
                           exchanges=ph["exchanges"], frames_per_camera_per_exchange=batch,
                           note="microseconds per exchange, the slowest rank's mean of each phase over 9 exchanges in a separate pass "
-                               "with timing events (vh_dist_phase_times): key-generation launches / from the moment the collectives "
+                               "with timing events (vh_dist_phase_times): key-generation launches (fused generation, the default: the frame launches "
+                               "that carried it, i.e. the apply phase of an earlier exchange) / from the moment the collectives "
                                "may start to their completion (ncclAllToAll of the key bins + ncclAllGather of the packets; one rank: "
                                "nothing is sent) / the frame launches first to last / generation start to last frame launch / host "
                                "time inside vh_dist_step_batch")
