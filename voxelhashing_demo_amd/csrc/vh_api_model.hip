@@ -419,7 +419,12 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     }
     if (std::strcmp(name, "pipe_integrate_grid") == 0 && value > 0) { c->pipeIntegrateGrid = value; return VH_OK; }
 #ifdef VH_DEBUG_SKIP_ROLES      // diagnostics builds only (make EXTRA=-DVH_DEBUG_SKIP_ROLES): the check costs the product launch a scalar load per workgroup
-    if (std::strcmp(name, "debug_skip_roles") == 0 && value >= 0 && value < 32) { c->debugSkipRoles = value; return VH_OK; }
+    if (std::strcmp(name, "debug_skip_roles") == 0 && value >= 0 && value < 32) {
+        c->debugSkipRoles = value;
+        // (a shard's multi-camera launch: bit 16 = the claim role finds its bins empty -- what the probes of received keys cost it)
+        if (value & 16) c->fp.flags |= kFlagDebugNoProbe; else c->fp.flags &= ~kFlagDebugNoProbe;
+        return VH_OK;
+    }
 #endif
     if (std::strcmp(name, "lean_kernels") == 0) { c->leanKernels = value != 0; return VH_OK; }
     if (std::strcmp(name, "spin_limit") == 0 && value >= 0) { c->spinLimit = (uint32_t)value; return VH_OK; }

@@ -59,6 +59,9 @@ __device__ __forceinline__ void claim_bin_slice(const FrameParams &fp, const Dev
         n = g < marks ? (g == 0 ? m0 : m1) : n;
         if (g > 2) lo = n;                                   // (cannot be: the generator writes no marks then)
     }
+#ifdef VH_DEBUG_SKIP_ROLES
+    if (fp.flags & kFlagDebugNoProbe) n = min(n, lo + ((n - lo) >> 5));      // diagnostics: 1/32 of the frame's records (what an acknowledgement channel would leave)
+#endif
     for (int i = lo + (int)part * 256 + (int)threadIdx.x; i < n; i += (int)parts * 256) {
         const int4 k = bin[1 + i];
         uint32_t rank = (uint32_t)k.w;
