@@ -51,7 +51,8 @@ public:
      * thread per rank, exchange by device copies instead of RCCL -- the N > 1 host on a single-GPU box */
     static void loopbackId(char id[VH_DIST_ID_BYTES]);
     /* `batch` frames of this rank's camera (poses: batch*16 row-major floats; d_depth: batch device pointers): queues
-     * this exchange and applies the previous one; flush() completes what is in flight.  Collective over the ranks. */
+     * this exchange and applies an earlier one (vh_dist_step_batch: the one before the previous by default); flush() completes
+     * what is in flight.  Collective over the ranks. */
     void integrateExchange(const float *poses, const uint16_t *const *d_depth);
     bool sharded() const { return dist_ != nullptr; }
     ~SDF_Hashtable();

@@ -97,9 +97,11 @@ int vh_dist_set_user_stream(vh_dist *d, void *stream, int32_t enable);
 
 /* One exchange: `batch` frames of THIS rank's camera (poses: batch*16 host floats; d_frames: host array of `batch`
  * device pointers -- uint16 sensor images or float4 vertex maps by packet_format).  Enqueues the generation and the
- * collectives of this exchange and the application of the PREVIOUS one; returns without waiting.  Collective. */
+ * collectives of this exchange and the application of an EARLIER one -- the previous one, or with option "fused_generation"
+ * (the default) the one before it, in whose frame launches this exchange's generation rides; returns without waiting.
+ * Collective. */
 int vh_dist_step_batch(vh_dist *d, const float *poses, const void *const *d_frames);
-/* applies the exchange in flight and waits for the three streams */
+/* applies the exchange(s) in flight -- one, or two with "fused_generation" -- and waits for the three streams */
 int vh_dist_flush(vh_dist *d);
 
 /* Raycast of this rank's view through the WHOLE sharded table (voxelhash.h: vh_export_views_fixed / vh_import_views):

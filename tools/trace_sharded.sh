@@ -16,6 +16,28 @@ rows.sort()
 # one exchange batch from the middle of the run: from one key-generation launch to the next
 gen = [i for i, r in enumerate(rows) if "generate_keys" in r[2]]
 out = open(sys.argv[2], "w")
+import statistics
+fr = [r for r in rows if "frame_multi_pipelined" in r[2]]
+if len(gen) < len(fr) // 64:
+    # fused generation (vh_dist option "fused_generation", the default): in steady state there is no generation launch -- an
+    # exchange is 8 frame launches on one stream.  The separate launches left are the first two exchanges behind each flush.
+    print(f"fused generation: {len(gen)} key-generation launches beside {len(fr)} frame launches (the first two exchanges behind each flush)", file=out)
+    m = len(fr) // 2
+    t0 = fr[m][0]
+    print("sixteen consecutive frame launches from the middle of the run (two exchanges):", file=out)
+    for s, e, n, st in fr[m:m + 16]:
+        print(f"  {(s - t0) / 1e3:8.1f} .. {(e - t0) / 1e3:8.1f} us  ({(e - s) / 1e3:6.1f})  stream {st:>3}  {n}", file=out)
+    gaps = [(fr[i + 1][0] - fr[i][1]) / 1e3 for i in range(len(fr) - 1)]
+    small = [g for g in gaps if g <= 2.0]
+    big = [g for g in gaps if g > 2.0]
+    dur = [(r[1] - r[0]) / 1e3 for r in fr]
+    print(f"frame launches: {len(fr)}, mean {statistics.mean(dur):.2f} median {statistics.median(dur):.2f} us; gaps between consecutive ones inside a timed window: "
+          f"mean {statistics.mean(small):.2f} us ({len(small)}); {len(big)} gaps > 2 us (window boundaries, flushes) totalling {sum(big):.0f} us", file=out)
+    per = statistics.mean(dur) + statistics.mean(small)
+    print(f"period per frame launch under the trace: {per:.2f} us = {1e6 / per:.0f} frames/s", file=out)
+    out.close()
+    print(open(sys.argv[2]).read())
+    sys.exit(0)
 if len(gen) > 12:
     a, b = gen[len(gen) // 2], gen[len(gen) // 2 + 1]
     t0 = rows[a][0]
@@ -23,9 +45,7 @@ if len(gen) > 12:
     for s, e, n, st in rows[a:b]:
         print(f"  {(s - t0) / 1e3:8.1f} .. {(e - t0) / 1e3:8.1f} us  ({(e - s) / 1e3:6.1f})  stream {st:>3}  {n}", file=out)
 # where the time between key generations goes, over the whole run: frame launches, gaps between them on their stream
-import statistics
 iv = [(rows[gen[i + 1]][0] - rows[gen[i]][0]) / 1e3 for i in range(len(gen) - 1)]
-fr = [r for r in rows if "frame_multi_pipelined" in r[2]]
 gaps = [(fr[i + 1][0] - fr[i][1]) / 1e3 for i in range(len(fr) - 1)]
 big = [g for g in gaps if g > 2.0]
 print(f"batches: {len(iv)}; interval median {statistics.median(iv):.1f} mean {statistics.mean(iv):.1f} p90 {sorted(iv)[int(0.9 * len(iv))]:.1f} max {max(iv):.1f} us", file=out)
