@@ -299,11 +299,13 @@ __global__ __launch_bounds__(256) void frame_multi_commit_integrate_kernel(const
 // a kernel of its own on a second stream, which cost the frame launches ~6 % by running beside them and ~3 % in the gaps two
 // queues leave (profiles/r05_timeline_C2sharded.txt).  No band, sensor frames (the host checks).
 #ifndef VH_FUSED_GEN_GROUPS
-#define VH_FUSED_GEN_GROUPS 8        // (same box, sharded leg with one rank, frames/s: 2 groups 40.4 k, 4: 47.1 k, 8: 47.8-47.9 k, 12: 37.6 k, 16: 33.6 k;
-                                     //  the separate generation 45.5-45.7 k -- profiles/r05_fused_generation_ab.txt)
+#define VH_FUSED_GEN_GROUPS 6        // (same box, sharded leg with one rank, frames/s: first form 2 groups 40.4 k, 4: 47.1 k, 8: 47.9 k, 12: 37.6 k,
+                                     //  16: 33.6 k; with the owner computed without a division and the role's priority raised 6: 49.2-49.5 k,
+                                     //  8: 49.2-49.3 k, 10: 43.6 k -- six keeps its distance from the cliff; the separate generation 45.5-45.7 k;
+                                     //  profiles/r05_fused_generation_ab.txt)
 #endif
 #ifndef VH_FUSED_GEN_PRIO
-#define VH_FUSED_GEN_PRIO 0
+#define VH_FUSED_GEN_PRIO 3        // (s_setprio of the generating workgroups: 49.0 -> 49.3 k frames/s, three runs each)
 #endif
 constexpr int kFusedGenGroups = VH_FUSED_GEN_GROUPS;            // 16x16 pixel tiles per generation workgroup (one returning atomic per owner for all of them)
 struct GenJob {
