@@ -8,8 +8,8 @@ Model of one exchange (B frames per camera; three streams overlap):
   apply   = B * (frame_us + gap_us)                       frame launches on the owner, back to back
   comm    = (bin_bytes + packet_bytes) / link_rate        every peer pair has a link of its own (8 GPUs fully connected: 7 links
                                                           per GPU), RCCL's all-to-all / all-gather drive them in parallel
-  gen     = gen_us                                        key generation, its own stream
-  period  = max(apply * (1 + contention), comm, gen)      contention: what the co-running generation costs the frame launches
+  gen     = rides in the frame launches (vh_dist option "fused_generation", the default): no term of its own, a factor on apply
+  period  = max(apply * (1 + contention), comm)           contention: what the generating role aboard costs the frame launches
   frames/s = N * B / period
    tools/scaling_model.py gpurun_out/r05/scaling_inputs_C2.json [gpurun_out/r05/scaling_inputs_C5.json] > profiles/r05_scaling_model.json"""
 import json
@@ -17,7 +17,8 @@ import sys
 
 LINK_GBS = dict(conservative=45.0, nominal=64.0)      # achieved GB/s per direction of ONE xGMI link (peak ~76.8 of 153.6 bidirectional)
 GAP_US = 1.0            # between two frame launches of a batch (profiles/r04_timeline_C2sharded.txt: 8.1 us per batch of 8)
-CONTENTION = 0.08       # frame launches beside a key generation (profiles/r04_sharded_skipgen.txt: 47.3 k against 45.3 k, + event operations)
+CONTENTION = 0.03       # the generating role aboard a frame launch: 19.2-19.3 us against 18.9 without it (profiles/r05_fused_generation_ab.txt);
+                        # (0.08 for the generation as launches of its own on a second stream, the model's first version: 47.7 k at N = 1, measured 45.6 k)
 out = dict(
     note="written before any multi-GPU run; inputs measured one rank at a time on one MI355X (tools/scaling_inputs.py)",
     assumptions=dict(link_gbs_per_direction=LINK_GBS, gap_us_per_launch=GAP_US, contention=CONTENTION,
@@ -35,12 +36,12 @@ for path in sys.argv[1:]:
         e = {}
         for walk, key in (("reference_walk", "frame_us"), ("walk_free", "frame_index_us")):
             apply_us = B * (r[key] + GAP_US) * (1.0 + CONTENTION)
-            row = dict(apply_us=round(apply_us, 1), gen_us=r["gen_us"])
+            row = dict(apply_us=round(apply_us, 1), gen_us_if_launched_separately=r["gen_us"])
             for name, gbs in LINK_GBS.items():
                 comm_us = 0.0 if n == 1 else (r["bin_bytes_per_peer"] + r["packet_bytes_per_peer"]) / (gbs * 1e3)
-                period = max(apply_us, comm_us, r["gen_us"])
+                period = max(apply_us, comm_us)
                 row[name] = dict(comm_us=round(comm_us, 1), period_us=round(period, 1), frames_per_s=round(n * B / period * 1e6),
-                                 bound="apply" if period == apply_us else "collectives" if period == comm_us else "generation")
+                                 bound="apply" if period == apply_us else "collectives")
             e[walk] = row
         e["inputs"] = r
         pred[N] = e
