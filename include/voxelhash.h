@@ -364,7 +364,8 @@ int vh_debug_occupy(vh_context *ctx, void *stream, int32_t workgroups, int32_t m
  * build; environment VOXELHASH_LEAN_KERNELS overrides the default at vh_create), "multi_walk_entries" (the same
  * for the multi-camera launch; 0 = by the shard's size), "gen_frames_per_launch" (1..8, default 4: frames of a batch one
  * key-generation launch of vh_generate_keys*_batch takes -- fewer per launch leave more of the chip to the frame launches
- * the generation runs beside).  They apply to vh_integrate and
+ * the generation runs beside), "claim_wave_tiles" (0 | 1 | 2: the walk-free frame's claim role takes a launch tile per wave
+ * instead of per workgroup -- never, always, or for images of more than 2400 tiles, the default; same results).  They apply to vh_integrate and
  * vh_integrate_depth alike.  "cand_capacity" shrinks the candidate list (test hook for
  * vh_counters.cand_overflow).  Format switch: "packet_format" (VH_PACKET_F32 / VH_PACKET_U16, below). */
 int vh_set_option(vh_context *ctx, const char *name, int value);

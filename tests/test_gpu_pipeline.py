@@ -36,7 +36,15 @@ def test_batches_with_the_occupancy_index_walk(oracle, vh, torch_cuda, chunk):
     _batches_equal_oracle_frames(oracle, vh, torch_cuda, 1, chunk, 0, walk=4)
 
 
-def _batches_equal_oracle_frames(oracle, vh, torch_cuda, sem, chunk, walk_nt, walk=3):
+@pytest.mark.parametrize("walk_nt", [0, 1])
+def test_walk_free_frame_with_a_launch_tile_per_wave(oracle, vh, torch_cuda, walk_nt):
+    """Option "claim_wave_tiles" 1: the walk-free frame's claim role with a launch tile per WAVE (claim_tile_wave; lean builds
+    7 / 8, what images of more than 2400 tiles get by themselves) on a 640x480 image, whose 1200 tiles would not select it:
+    the same keys with the same ranks must reach the probes, so the table is the oracle's slot for slot."""
+    _batches_equal_oracle_frames(oracle, vh, torch_cuda, 1, 3, walk_nt, walk=4, wave_tiles=1)
+
+
+def _batches_equal_oracle_frames(oracle, vh, torch_cuda, sem, chunk, walk_nt, walk=3, wave_tiles=None):
     """The sphere scene twice (frame 1 demands keys frame 0 is still inserting), then a moving camera:
     checked after every batch, whatever the batch length."""
     torch = torch_cuda
@@ -45,6 +53,8 @@ def _batches_equal_oracle_frames(oracle, vh, torch_cuda, sem, chunk, walk_nt, wa
     gt = vh.SDFHashtable(vh.default_params(**kw), 640, 480, sem)
     gt.set_option("walk_nt", walk_nt)
     gt.set_option("flatten_variant", walk)
+    if wave_tiles is not None:
+        gt.set_option("claim_wave_tiles", wave_tiles)
     sphere = synth.sphere_inside_scene()
     frames = [(I4, sphere)] * 3 + room_frames(torch, 640, 480, (0, 1, 2, 3, 8, 9, 10))
     for s in range(0, len(frames), chunk):

@@ -254,7 +254,7 @@ __device__ __forceinline__ PixelVertex load_pixel(const FrameParams &fp, const I
 // the same with the tile's position in the grid of tiles known (a caller that visits consecutive tiles divides once)
 template <class In>
 __device__ __forceinline__ PixelVertex load_pixel_at(const FrameParams &fp, const In &in, uint32_t tile, uint32_t bx, uint32_t by, uint32_t t,
-                                                     float *__restrict__ outDepth)
+                                                     float *__restrict__ outDepth, uint16_t *__restrict__ outRaw = nullptr)
 {
     PixelVertex p{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), 0, 0, (tile << 8) + t, false};
     p.px = (int)(bx * 16u + (t & 15u));
@@ -264,6 +264,7 @@ __device__ __forceinline__ PixelVertex load_pixel_at(const FrameParams &fp, cons
         p.v = in.vertex(idx, p.px, p.py);
         if ((fp.flags & kFlagBandDda) && fp.allocBand > 0.0f) p.n = in.normal(idx);
         if (outDepth) outDepth[idx] = p.v.z;
+        if (outRaw) outRaw[idx] = in.raw(idx);
         p.valid = p.v.z != 0.0f;                                         // VoxelUtils.cu:621
     }
     return p;
@@ -556,6 +557,74 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
     drain(count);
     __builtin_amdgcn_s_waitcnt(0);
     VH_CLAIM_STAMP(3);
+}
+
+// The reference's frame (one key per pixel, no band) with a launch tile per WAVE instead of per workgroup: lane l takes pixels
+// l, l + 64, l + 128, l + 192 of the tile -- the four 16x4 patches the four waves of claim_tile take -- keeps the same dedup per
+// patch (so the same keys survive, with the same ranks), queues the survivors in LDS and probes them in one pass, one per lane.
+// A quarter of the waves, each with four times the arithmetic behind the same round trips (vertex, bucket, claim word): the
+// walk-free frame of a large image, whose launch is vector issue of thousands of claim tiles, gains (C3 28.4 -> 26.7 us); where
+// the claim tile's chain is the launch's tail it loses -- C2 walk-free 8.9 -> 11.1 us, and under the reference's walk C2 18.9 ->
+// 19.9 us at best (any claim_span) -- so the host selects it per frame (vh_api_frame.hip: claimPerWave).
+constexpr int kWaveQueue = 64;            // survivors a wave queues before it probes them (a tile has ~9; a full queue is probed and refilled)
+template <class In>
+__device__ __forceinline__ void claim_tile_wave(const FrameParams &fp, const DevPtrs &dp, const In &in, uint32_t tile, int candCounter,
+                                                const Pending &pend, float *__restrict__ outDepth, uint16_t *__restrict__ outRaw)
+{
+    __shared__ int4 waveKeys[256 / kWave][kWaveQueue];
+    volatile int4 *queue = waveKeys[threadIdx.x / kWave];
+    const int ln = threadIdx.x & (kWave - 1);
+    const uint32_t tilesX = (uint32_t)(fp.width + 15) >> 4;
+    const uint32_t by = tile / tilesX, bx = tile - by * tilesX;              // (wave-uniform)
+    auto drain = [&](int n) {
+        if (ln < n) {
+            const int kx = queue[ln].x, ky = queue[ln].y, kz = queue[ln].z;
+            const uint32_t rank = (uint32_t)queue[ln].w;
+            if (block_in_frustum(fp, kx, ky, kz)) {                          // :673
+                const uint32_t h = hash_block(kx, ky, kz, fp.numBuckets);
+                bool mine = h >= fp.bucketLo && h < fp.bucketHi;             // this shard's bucket
+#ifdef VH_DEBUG_SKIP_ROLES
+                if (fp.flags & kFlagDebugNoProbe) mine = false;
+#endif
+                if (mine) {
+                    if (fp.flags & kFlagWalkNt) probe_and_claim<true>(fp, dp, kx, ky, kz, h, rank, candCounter, pend);
+                    else probe_and_claim<false>(fp, dp, kx, ky, kz, h, rank, candCounter, pend);
+                }
+            }
+        }
+    };
+    PixelVertex p[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = load_pixel_at(fp, in, tile, bx, by, (uint32_t)ln + 64u * (uint32_t)j, outDepth, outRaw);
+    int count = 0;                                                           // (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int kx = 0, ky = 0, kz = 0;
+        if (p[j].valid) {
+            const float4 g = mat4_mul(fp.T, p[j].v.x, p[j].v.y, p[j].v.z, p[j].v.w);       // :622
+            const int3_ b = world2block(g.x, g.y, g.z, fp.voxelSize);                       // :636
+            kx = b.x; ky = b.y; kz = b.z;
+        }
+        const unsigned long long wants = __ballot(p[j].valid);
+        const int lx = __shfl_up(kx, 1), ly = __shfl_up(ky, 1), lz = __shfl_up(kz, 1);
+        const int ux = __shfl_up(kx, 16), uy = __shfl_up(ky, 16), uz = __shfl_up(kz, 16);
+        const bool dupLeft = (ln & 15) != 0 && ((wants >> (ln - 1)) & 1ull) && lx == kx && ly == ky && lz == kz;
+        const bool dupUp = ln >= 16 && ((wants >> (ln - 16)) & 1ull) && ux == kx && uy == ky && uz == kz;
+        const bool leader = p[j].valid && !dupLeft && !dupUp;
+        const unsigned long long mask = __ballot(leader);
+        if (mask == 0ull) continue;
+        const int n = __popcll(mask);
+        if (count + n > kWaveQueue) {
+            drain(count);
+            count = 0;
+        }
+        if (leader) {
+            const int at = count + __popcll(mask & ((1ull << ln) - 1ull));
+            queue[at].x = kx; queue[at].y = ky; queue[at].z = kz; queue[at].w = (int)sample_rank(p[j], 0);
+        }
+        count += n;
+    }
+    drain(count);
 }
 
 template <class In>

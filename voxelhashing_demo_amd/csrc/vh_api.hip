@@ -129,6 +129,7 @@ struct vh_context {
     bool serialQueued = false;             // a serialised launch has been queued since the host last looked at kSpinTimeouts (check_spin_timeouts)
     uint32_t spinSeen = 0;                 // ... and what the counter read then
     bool serialFallback = false;           // a serialised launch has timed out (vh_counters.spin_timeouts): overflow-list frames take two launches from now on
+    int claimWaveTiles = 2;                // option "claim_wave_tiles": 0 never, 1 always, 2 by image size (walk-free lean builds; vh_api_frame.hip)
     int leanKernels = 1;                   // option "lean_kernels": builds of the pipelined launch with the option flags folded in (A/B switch)
     int debugSkipRoles = 0;                // diagnostics: roles of the pipelined launch that return at once (timing only; the model is wrong)
     int pipelineShards = 1;                // option "pipeline_shards": vh_apply_frames_batch runs a batch of B multi-camera frames as B + 1 launches (1) or B (2: the last frame's half stays pending across calls)

@@ -311,9 +311,32 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     const int oldParity = c->pipeParity, newParity = oldParity ^ 1;
     const int setOld = c->pipeSet, setNew = (setOld + 1) % 3;
     PipeArgs a;
-    a.claimBlocks = hasNew ? host_num_tiles(c) : 0u;
+    const bool band = c->fp.allocBand > 0.0f;       // (the new frame's; the pending frame's claims are done)
+    // (without a band a claim workgroup takes four launch tiles, one per wave: claim_tile_wave, vh_alloc.hip)
     a.walkBlocks = hasNew ? walk_blocks(c) : 0u;
     a.walkIndexed = c->flattenVariant == kWalkIndexed ? 1u : 0u;
+    const bool serial = (c->fp.flags & kFlagOverflow) != 0u;
+    // the lean builds (vh_frame.hip): no band, no list, the reference's walk, and both frames' option flags exactly the walk's
+    int lean = 0;
+    if (!serial && c->leanKernels) {      // (with a band: the ray band only -- kFlagBandDda is a flag like the others)
+        const uint32_t fo = hasOld ? c->pipeFp.flags : c->fp.flags;
+        if (a.walkIndexed) {                // the walk-free frame (flatten_variant 4): builds of its own, without a band
+            if (!band && c->fp.flags == kFlagWalkShort && fo == kFlagWalkShort) lean = 5;
+            else if (!band && c->fp.flags == (kFlagWalkShort | kFlagWalkNt) && fo == (kFlagWalkShort | kFlagWalkNt)) lean = 6;
+        }
+        else if (c->fp.flags == kFlagWalkShort && fo == kFlagWalkShort) lean = 1;
+        else if (c->fp.flags == (kFlagWalkShort | kFlagWalkNt) && fo == (kFlagWalkShort | kFlagWalkNt)) lean = 2;
+        else if (band && c->fp.flags == (kFlagWalkShort | kFlagBandRayDda) && fo == c->fp.flags) lean = 3;
+        else if (band && c->fp.flags == (kFlagWalkShort | kFlagWalkNt | kFlagBandRayDda) && fo == c->fp.flags) lean = 4;
+    }
+    // The walk-free frame of a large image: a claim workgroup takes four launch tiles, one per wave (claim_tile_wave, vh_alloc.hip:
+    // a quarter of the waves, each with four pixels per lane).  C3 28.4 -> 26.7 us same box; a 640x480 frame prefers the tile per
+    // workgroup (8.9 against 11.1 us: the longer chain per wave is its tail), and so does every frame under the reference's walk
+    // (C2 18.9 -> 19.9-22.7 us, C3 72.0 -> 71.5): profiles/r05_claim_wave_tile_ab.txt.  Option "claim_wave_tiles" 0 | 1 | 2 (auto).
+    a.claimPerWave = (hasNew && (lean == 5 || lean == 6) &&
+                      (c->claimWaveTiles == 1 || (c->claimWaveTiles == 2 && host_num_tiles(c) > 2400u))) ? 1u : 0u;
+    if (a.claimPerWave) lean += 2;                                // builds 7 / 8
+    a.claimBlocks = !hasNew ? 0u : a.claimPerWave ? (host_num_tiles(c) + 3u) / 4u : host_num_tiles(c);
     a.commitBlocks = hasOld ? (uint32_t)c->commitBlocks : 0u;
     a.integrateBlocks = hasOld ? (uint32_t)c->pipeIntegrateGrid : 0u;
     // (the walk-free frame of a large image: its TSDF update is on the critical path, not under a walk -- twice the workgroups:
@@ -340,21 +363,6 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     const dim3 grid(a.commitBlocks + a.integrateBlocks + a.claimBlocks + a.walkBlocks);
     In inNew{};
     if (hasNew) inNew = *in;
-    const bool band = c->fp.allocBand > 0.0f;       // (the new frame's; the pending frame's claims are done)
-    const bool serial = (c->fp.flags & kFlagOverflow) != 0u;
-    // the lean builds (vh_frame.hip): no band, no list, the reference's walk, and both frames' option flags exactly the walk's
-    int lean = 0;
-    if (!serial && c->leanKernels) {      // (with a band: the ray band only -- kFlagBandDda is a flag like the others)
-        const uint32_t fo = hasOld ? c->pipeFp.flags : c->fp.flags;
-        if (a.walkIndexed) {                // the walk-free frame (flatten_variant 4): builds of its own, without a band
-            if (!band && c->fp.flags == kFlagWalkShort && fo == kFlagWalkShort) lean = 5;
-            else if (!band && c->fp.flags == (kFlagWalkShort | kFlagWalkNt) && fo == (kFlagWalkShort | kFlagWalkNt)) lean = 6;
-        }
-        else if (c->fp.flags == kFlagWalkShort && fo == kFlagWalkShort) lean = 1;
-        else if (c->fp.flags == (kFlagWalkShort | kFlagWalkNt) && fo == (kFlagWalkShort | kFlagWalkNt)) lean = 2;
-        else if (band && c->fp.flags == (kFlagWalkShort | kFlagBandRayDda) && fo == c->fp.flags) lean = 3;
-        else if (band && c->fp.flags == (kFlagWalkShort | kFlagWalkNt | kFlagBandRayDda) && fo == c->fp.flags) lean = 4;
-    }
 #define VH_LAUNCH_PIPELINED(DEPTH, BAND, SERIAL, LEAN) \
     launch(c, kPhaseFramePipelined, frame_pipelined_kernel<In, DEPTH, BAND, SERIAL, LEAN>, grid, dim3(256), c->fp, dpNew, inNew, c->pipeFp, dpOld, d, a)
 #define VH_LAUNCH_PIPELINED_ANY(DEPTH) \
@@ -364,6 +372,8 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
      : lean == 4 ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 4) \
      : lean == 5 ? VH_LAUNCH_PIPELINED(DEPTH, false, false, 5) \
      : lean == 6 ? VH_LAUNCH_PIPELINED(DEPTH, false, false, 6) \
+     : lean == 7 ? VH_LAUNCH_PIPELINED(DEPTH, false, false, 7) \
+     : lean == 8 ? VH_LAUNCH_PIPELINED(DEPTH, false, false, 8) \
      : serial ? (band ? VH_LAUNCH_PIPELINED(DEPTH, true, true, 0) : VH_LAUNCH_PIPELINED(DEPTH, false, true, 0)) \
               : (band ? VH_LAUNCH_PIPELINED(DEPTH, true, false, 0) : VH_LAUNCH_PIPELINED(DEPTH, false, false, 0)))
     if (hasOld && c->pipeSensor) {

@@ -427,6 +427,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     }
 #endif
     if (std::strcmp(name, "lean_kernels") == 0) { c->leanKernels = value != 0; return VH_OK; }
+    if (std::strcmp(name, "claim_wave_tiles") == 0 && value >= 0 && value <= 2) { c->claimWaveTiles = value; return VH_OK; }
     if (std::strcmp(name, "spin_limit") == 0 && value >= 0) { c->spinLimit = (uint32_t)value; return VH_OK; }
     if (std::strcmp(name, "pipeline_overflow") == 0 && value >= 0 && value <= 2) {
         DeviceGuard g(c->device);

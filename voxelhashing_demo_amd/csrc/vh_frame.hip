@@ -150,6 +150,7 @@ struct PipeArgs {
     int32_t setNew, setOld, setClear;      // counter sets: filled, consumed, cleared by this launch
     uint32_t hasNew, hasOld;               // first launch of a run: no old frame; flush launch: no new frame
     uint32_t walkIndexed;                  // flatten_variant 4: the walk role runs over the bucket-occupancy bitmap
+    uint32_t claimPerWave;                 // the claim role takes a launch tile per WAVE (claim_tile_wave; the walk-free builds only)
     uint32_t claimSpan, claimRatio;        // claim tiles are interleaved with the first claimSpan - claimBlocks walk tiles
     float *planeNew;                       // private depth copies written by claim(new) ...
     uint16_t *rawNew;
@@ -269,11 +270,22 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
             if (a.skipRoles & 16u) {           // diagnostics: the claim tiles end before their probes (what the probes' wait costs the launch)
                 FrameParams fpN = fpNew;
                 fpN.flags |= kFlagDebugNoProbe;
-                claim_tile<In, kBand>(fpN, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
+                if (!kBand && a.claimPerWave) {
+                    const uint32_t tile = index * (256u / kWave) + threadIdx.x / kWave;
+                    if (tile < num_tiles(fpN)) claim_tile_wave<In>(fpN, dpNew, inNew, tile, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
+                } else {
+                    claim_tile<In, kBand>(fpN, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
+                }
                 return;
             }
 #endif
-            claim_tile<In, kBand>(fpNew, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
+            if (!kBand && a.claimPerWave) {
+                // (a launch tile per wave: the host sized the role at a quarter of the tiles, vh_api_frame.hip)
+                const uint32_t tile = index * (256u / kWave) + threadIdx.x / kWave;
+                if (tile < num_tiles(fpNew)) claim_tile_wave<In>(fpNew, dpNew, inNew, tile, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
+            } else {
+                claim_tile<In, kBand>(fpNew, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
+            }
         } else if (a.walkIndexed) {
             flatten_index_tile(fpNew, dpNew, index, CompactOut{kPipeScan + a.setNew, kPipeScanB + a.setNew, a.numEntries},
                                pend);                                              // (opt-in: not the reference's walk)
@@ -377,12 +389,15 @@ __global__ __launch_bounds__(256) void frame_pipelined_kernel(FrameParams fpNew,
     if (kLean != 0) {
         // (3 / 4: the same two with the ray-DDA band, VH_BAND_RAY_DDA -- builds that exist with kBand only)
         // (5 / 6: the first two with the occupancy-index walk in place of the reference's -- the walk-free frame, no band)
-        constexpr uint32_t flags = (kLean == 2 || kLean == 4 || kLean == 6 ? (kFlagWalkShort | kFlagWalkNt) : kFlagWalkShort) |
+        // (7 / 8: 5 / 6 with a launch tile per wave in the claim role, claim_tile_wave -- the walk-free frame of a large image)
+        constexpr uint32_t flags = (kLean == 2 || kLean == 4 || kLean == 6 || kLean == 8 ? (kFlagWalkShort | kFlagWalkNt) : kFlagWalkShort) |
                                    (kLean == 3 || kLean == 4 ? kFlagBandRayDda : 0u);
         fpNew.flags = flags;
         fpOld.flags = flags;
         a.walkIndexed = kLean >= 5 ? 1u : 0u;
     }
+    a.claimPerWave = (kLean == 7 || kLean == 8) ? 1u : 0u;      // (builds of their own: carried as a run-time switch by builds 5 / 6 it
+                                                                //  cost the 640x480 walk-free frame 8.9 -> 9.45 us)
     frame_pipelined<In, Depth, kBand, kSerial>(fpNew, dpNew, inNew, fpOld, dpOld, depthOld, a);
 }
 
