@@ -133,8 +133,11 @@ int vh_dist_host_stats(vh_dist *d, double *seconds, uint64_t *calls);
  *                               operation.  An exchange is then applied by the SECOND call after the one that fed it (0: by
  *                               the next call); vh_dist_flush applies whatever is in flight either way.  The library falls
  *                               back to separate generation launches by itself where the role does not apply (the first two
- *                               calls behind a flush, float packets, an allocation band, batch > 8).  Same results bit for
- *                               bit.  Set before the first exchange or behind vh_dist_flush.
+ *                               calls behind a flush, batch > 8) and to the separate host path -- application by the next
+ *                               call -- for a shard whose frame launch cannot carry it (float packets, an allocation band,
+ *                               the overflow list, the walk-free launch of "flatten_variant" 4; looked at in the first
+ *                               exchange and behind every vh_dist_flush).  Same results bit for bit.  Set before the first
+ *                               exchange or behind vh_dist_flush.
  *   "phase_timing" 0 | 1        timing events around the three phases of every exchange (vh_dist_phase_times).  Off by default.
  *   "raycast_auto_start" n      this rank's proposal for the slot capacity of vh_dist_raycast_auto's first round (default 4096;
  *                               the ranks take the largest proposal, so they need not agree on it) */

@@ -207,6 +207,10 @@ struct vh_dist {
     uint64_t hostCalls = 0;
     // option "fused_generation": the key generation as a role of the frame launches (vh_shard.hip: GenJob)
     bool fused = VH_DIST_FUSED_DEFAULT != 0;
+    // ... and the form in effect: the fused host path when the shard's frames can carry the role at all (multi_can_fuse_generation:
+    // not the walk-free launch, a band, float packets), else the separate path with its three streams overlapping as before.  Decided
+    // where nothing is in flight and the streams are idle: at the first exchange and behind every vh_dist_flush.
+    bool fusedActive = false, modeDirty = true;
     std::deque<int> inflight;              // fused path: the sets of the exchanges generated (and travelling / landed) but not applied yet: at most two
     bool genOnTable[kSets] = {};           // ... whose generation ran on the table stream (no event needed to apply it with one rank)
     bool headersClean[kSets] = {};         // ... whose send-bin headers the previous exchange's last job has zeroed
@@ -514,8 +518,7 @@ extern "C" int vh_dist_set_option(vh_dist *d, const char *name, int32_t value)
     if (std::strcmp(name, "fused_generation") == 0) {
         if (d->pending >= 0 || !d->inflight.empty()) return fail(VH_ERR_INVALID_ARGUMENT, "fused_generation: set it before the first exchange or behind vh_dist_flush");
         d->fused = value != 0;
-        d->count = 0;                         // (the set rotation restarts: nothing is in flight)
-        for (bool &b : d->headersClean) b = false;
+        d->modeDirty = true;                  // (vh_dist_step_batch decides the form in effect; nothing is in flight)
         return VH_OK;
     }
     if (std::strcmp(name, "phase_timing") == 0) {
@@ -603,11 +606,11 @@ static int dist_apply(vh_dist *d, int s, const GenJob *jobs = nullptr)
     const bool alone = d->cfg.world == 1 && !d->forceCollectives;
 #ifndef VH_DEBUG_DIST_NO_READY_WAIT          // (diagnostics builds: what the two event operations at a batch's boundary cost)
     // (fused path, one rank: the exchange was generated on this very stream and nothing travelled: stream order is the hand-off)
-    if (!(d->fused && alone && d->genOnTable[s])) VH_HIP(hipStreamWaitEvent(d->sTable, d->ready[s], 0));
+    if (!(d->fusedActive && alone && d->genOnTable[s])) VH_HIP(hipStreamWaitEvent(d->sTable, d->ready[s], 0));
 #endif
     d->shard->stream = d->sTable;
 #ifndef VH_DEBUG_DIST_NO_FIRST
-    if (!d->fused) d->shard->multiFirstEvent = d->first[s];
+    if (!d->fusedActive) d->shard->multiFirstEvent = d->first[s];
 #endif
     if (d->phaseTiming && d->phaseEv[s].armed) VH_HIP(hipEventRecord(d->phaseEv[s].app0, d->sTable));
     const int rc = vh_apply_frames_batch_gen(d->shard, d->cfg.batch, alone ? d->set[s].binsSend : d->set[s].binsRecv, d->cfg.world, d->capacity, 0,
@@ -732,7 +735,17 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     if (!d || !poses || !d_frames) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     const auto t0 = std::chrono::steady_clock::now();
     DeviceGuard guard(d->device);
-    if (d->fused) return dist_step_fused(d, poses, d_frames);
+    if (d->modeDirty) {
+        const bool want = d->fused && d->cfg.packet_format == VH_PACKET_U16 && d->cfg.batch <= 8 && d->capacity >= 8 &&
+                          multi_can_fuse_generation(d->shard, d->cfg.world, d->capacity);
+        if (want != d->fusedActive) {
+            d->fusedActive = want;
+            d->count = 0;                     // (the set rotation restarts: nothing is in flight, the streams are idle)
+            for (bool &b : d->headersClean) b = false;
+        }
+        d->modeDirty = false;
+    }
+    if (d->fusedActive) return dist_step_fused(d, poses, d_frames);
     const int s = (int)(d->count % vh_dist::kSetsSeparate);
     const int B = d->cfg.batch, R = d->cfg.world;
     vh_dist::Set &set = d->set[s];
@@ -820,6 +833,7 @@ extern "C" int vh_dist_flush(vh_dist *d)
     VH_HIP(hipStreamSynchronize(d->sTable));
     VH_HIP(hipStreamSynchronize(d->sComm));
     VH_HIP(hipStreamSynchronize(d->sGen));
+    d->modeDirty = true;
     return check_spin_timeouts(d->shard);      // (VH_ERR_TIMEOUT: a serialised multi-camera launch gave up waiting, voxelhash.h)
 }
 

@@ -491,8 +491,11 @@ static bool multi_can_fuse_generation(const vh_context *c, int32_t num_bins, int
 {
     uint32_t parts = (uint32_t)grid_for((size_t)capacity, 256 * 4);
     if (parts < 1) parts = 1;
+    // (not the walk-free launch, flatten_variant 4: it has no 17 us walk for the generating workgroups' chain to end inside, and it
+    // leaves most of the chip to a generation launched beside it -- one rank, frames/s: separate launches 96.0 k, fused with 3 / 4 / 6 / 2
+    // groups per workgroup 90.2 / 87.6 / 82.3 / 72.6 k, 1 group 39.7 k; profiles/r05_fused_generation_ab.txt, box 9)
     return c->pipelineShards && c->fp.bucketSize <= kMaxPipelinedBucket && !c->viewBlocks && !(c->fp.flags & kFlagOverflow) &&
-           c->packetFormat == VH_PACKET_U16 && !(c->fp.allocBand > 0.0f) &&
+           c->packetFormat == VH_PACKET_U16 && !(c->fp.allocBand > 0.0f) && c->flattenVariant != kWalkIndexed &&
            serial_launch_pays(c, (uint32_t)num_bins * parts + (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLaneShort));
 }
 
