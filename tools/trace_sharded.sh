@@ -31,8 +31,8 @@ if len(gen) < len(fr) // 64:
     small = [g for g in gaps if g <= 2.0]
     big = [g for g in gaps if g > 2.0]
     dur = [(r[1] - r[0]) / 1e3 for r in fr]
-    print(f"frame launches: {len(fr)}, mean {statistics.mean(dur):.2f} median {statistics.median(dur):.2f} us; gaps between consecutive ones inside a timed window: "
-          f"mean {statistics.mean(small):.2f} us ({len(small)}); {len(big)} gaps > 2 us (window boundaries, flushes) totalling {sum(big):.0f} us", file=out)
+    print(f"frame launches: {len(fr)}, mean {statistics.mean(dur):.2f} median {statistics.median(dur):.2f} us; gaps between consecutive ones inside a timed window (consecutive launches abut in the "
+          f"trace: a launch's start stamp is its predecessor's end, so the durations carry the hand-over): mean {statistics.mean(small):.2f} us ({len(small)}); {len(big)} gaps > 2 us (window boundaries, flushes) totalling {sum(big):.0f} us", file=out)
     per = statistics.mean(dur) + statistics.mean(small)
     print(f"period per frame launch under the trace: {per:.2f} us = {1e6 / per:.0f} frames/s", file=out)
     out.close()
