@@ -100,10 +100,12 @@ __device__ __forceinline__ bool pend_maybe(const Pending &pend, uint32_t local)
 // one round trip instead of two; what it returns is not looked at when that slot is the one being written.  It pays where the
 // probes answer from HBM or the claim tiles are long (same box, launch us without / with: C3 68.3 / 67.6, C5table 278.5 / 275.5,
 // C2 with the band 22.75 / 22.2) and costs the cache-resident reference frame a little (C2 17.68 / 17.78): the callers choose.
+// slot0 (nullable): the bucket's first slot as the caller has requested it already (claim_tile: before the frustum test, whose
+// ~100 instructions then run under that round trip); implies what kEagerSlot does with it.
 template <bool kEagerSlot = false>
 __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const DevPtrs &dp, int kx, int ky, int kz,
                                                 uint32_t h, uint32_t rank, int candCounter = kCandCount,
-                                                const Pending &pend = kNoPending)
+                                                const Pending &pend = kNoPending, const VoxelEntry *slot0 = nullptr)
 {
     if (fp.flags & kFlagOverflow) {
         probe_and_claim_overflow(fp, dp, kx, ky, kz, h, rank, candCounter);
@@ -112,7 +114,8 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
     const uint32_t local = h - fp.bucketLo;
     const VoxelEntry *bucket = dp.table + (size_t)local * fp.bucketSize;
     VoxelEntry e0{};
-    if (kEagerSlot) e0 = bucket[0];
+    if (slot0) e0 = *slot0;
+    else if (kEagerSlot) e0 = bucket[0];
     // the insertion in flight into this bucket, if any: it takes the bucket's first free slot (pf)
     uint32_t pf = ~0u;
     int4 pk = make_int4(0, 0, 0, 0);
@@ -129,7 +132,7 @@ __device__ __forceinline__ void probe_and_claim(const FrameParams &fp, const Dev
             if (pk.x == kx && pk.y == ky && pk.z == kz) return;
             continue;
         }
-        const VoxelEntry e = (kEagerSlot && i == 0u) ? e0 : bucket[i];
+        const VoxelEntry e = ((kEagerSlot || slot0) && i == 0u) ? e0 : bucket[i];
         if (e.ptr == VH_FREE_BLOCK) {
             firstFree = i;
             break;                       // prefix property: nothing allocated behind a free slot
@@ -485,15 +488,30 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
         const int ux = __shfl_up(s.kx, 16), uy = __shfl_up(s.ky, 16), uz = __shfl_up(s.kz, 16);
         const bool dupLeft = (ln & 15) != 0 && ((wants >> (ln - 1)) & 1ull) && lx == s.kx && ly == s.ky && lz == s.kz;
         const bool dupUp = ln >= 16 && ((wants >> (ln - 16)) & 1ull) && ux == s.kx && uy == s.ky && uz == s.kz;
-        if (!p.valid || dupLeft || dupUp || !block_in_frustum(fp, s.kx, s.ky, s.kz)) return;
+        if (!p.valid || dupLeft || dupUp) return;
+        if (fp.flags & kFlagWalkNt) {
+            // A table beyond the Infinity Cache (the walk's loads are non-temporal then) answers the probes from HBM: the bucket's
+            // first slot is requested BEFORE the frustum test (:673), which is a function of the key alone -- a key that fails it
+            // has cost a read, every other key's chain is shorter by the test.  Same box, three rounds (profiles/r05_claim_early_slot_ab.txt):
+            // C5table 3 468 -> 3 567 frames/s on average (noisy: +6 / -2 / +5 %), C3 +0.1 ... +1 %; the cache-resident C2 loses 0.7 %
+            // (51.3 -> 50.95 k) and keeps the test first.
+            const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
+            if (h < fp.bucketLo || h >= fp.bucketHi) return;            // not this shard's bucket
+            const VoxelEntry first = dp.table[(size_t)(h - fp.bucketLo) * fp.bucketSize];
+            if (!block_in_frustum(fp, s.kx, s.ky, s.kz)) return;
+#ifdef VH_DEBUG_SKIP_ROLES
+            if (fp.flags & kFlagDebugNoProbe) return;
+#endif
+            probe_and_claim<true>(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, 0), candCounter, pend, (fp.flags & kFlagOverflow) ? nullptr : &first);
+            return;
+        }
+        if (!block_in_frustum(fp, s.kx, s.ky, s.kz)) return;
         const uint32_t h = hash_block(s.kx, s.ky, s.kz, fp.numBuckets);
         if (h < fp.bucketLo || h >= fp.bucketHi) return;                // not this shard's bucket
 #ifdef VH_DEBUG_SKIP_ROLES
         if (fp.flags & kFlagDebugNoProbe) return;
 #endif
-        // (a table beyond the Infinity Cache -- the walk's loads are non-temporal then -- answers the probes from HBM)
-        if (fp.flags & kFlagWalkNt) probe_and_claim<true>(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, 0), candCounter, pend);
-        else probe_and_claim<false>(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, 0), candCounter, pend);
+        probe_and_claim<false>(fp, dp, s.kx, s.ky, s.kz, h, sample_rank(p, 0), candCounter, pend);
         return;
     }
     BandWalk walk;
@@ -580,16 +598,17 @@ __device__ __forceinline__ void claim_tile_wave(const FrameParams &fp, const Dev
         if (ln < n) {
             const int kx = queue[ln].x, ky = queue[ln].y, kz = queue[ln].z;
             const uint32_t rank = (uint32_t)queue[ln].w;
-            if (block_in_frustum(fp, kx, ky, kz)) {                          // :673
-                const uint32_t h = hash_block(kx, ky, kz, fp.numBuckets);
-                bool mine = h >= fp.bucketLo && h < fp.bucketHi;             // this shard's bucket
+            const uint32_t h = hash_block(kx, ky, kz, fp.numBuckets);
+            bool mine = h >= fp.bucketLo && h < fp.bucketHi;                 // this shard's bucket
 #ifdef VH_DEBUG_SKIP_ROLES
-                if (fp.flags & kFlagDebugNoProbe) mine = false;
+            if (fp.flags & kFlagDebugNoProbe) mine = false;
 #endif
-                if (mine) {
-                    if (fp.flags & kFlagWalkNt) probe_and_claim<true>(fp, dp, kx, ky, kz, h, rank, candCounter, pend);
-                    else probe_and_claim<false>(fp, dp, kx, ky, kz, h, rank, candCounter, pend);
-                }
+            if (mine && (fp.flags & kFlagWalkNt)) {                          // (the first slot ahead of the frustum test, claim_tile: C3 walk-free 34.8 -> 35.5 k, C5table 36.5 -> 37.4 k)
+                const VoxelEntry first = dp.table[(size_t)(h - fp.bucketLo) * fp.bucketSize];
+                if (block_in_frustum(fp, kx, ky, kz))                        // :673
+                    probe_and_claim<true>(fp, dp, kx, ky, kz, h, rank, candCounter, pend, (fp.flags & kFlagOverflow) ? nullptr : &first);
+            } else if (mine && block_in_frustum(fp, kx, ky, kz)) {
+                probe_and_claim<false>(fp, dp, kx, ky, kz, h, rank, candCounter, pend);
             }
         }
     };
