@@ -466,7 +466,8 @@ __device__ unsigned long long *g_claimStamps = nullptr;
 template <class In, bool kBand = true>
 __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs &dp, const In &in, uint32_t tile,
                                            int candCounter, const Pending &pend = kNoPending,
-                                           float *__restrict__ outDepth = nullptr, uint16_t *__restrict__ outRaw = nullptr)
+                                           float *__restrict__ outDepth = nullptr, uint16_t *__restrict__ outRaw = nullptr,
+                                           bool slotFirst = false)
 {
     VH_CLAIM_STAMP(0);
     const PixelVertex p = load_pixel(fp, in, tile, threadIdx.x, outDepth, outRaw);
@@ -489,7 +490,8 @@ __device__ __forceinline__ void claim_tile(const FrameParams &fp, const DevPtrs 
         const bool dupLeft = (ln & 15) != 0 && ((wants >> (ln - 1)) & 1ull) && lx == s.kx && ly == s.ky && lz == s.kz;
         const bool dupUp = ln >= 16 && ((wants >> (ln - 16)) & 1ull) && ux == s.kx && uy == s.ky && uz == s.kz;
         if (!p.valid || dupLeft || dupUp) return;
-        if (fp.flags & kFlagWalkNt) {
+        if ((fp.flags & kFlagWalkNt) || slotFirst) {
+            // (slotFirst: the walk-free frame, where the claim tile's chain is the launch -- C2 walk-free 8.93 -> 8.83 us.)
             // A table beyond the Infinity Cache (the walk's loads are non-temporal then) answers the probes from HBM: the bucket's
             // first slot is requested BEFORE the frustum test (:673), which is a function of the key alone -- a key that fails it
             // has cost a read, every other key's chain is shorter by the test.  Same box, three rounds (profiles/r05_claim_early_slot_ab.txt):

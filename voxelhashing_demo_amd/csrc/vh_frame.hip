@@ -274,7 +274,7 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
                     const uint32_t tile = index * (256u / kWave) + threadIdx.x / kWave;
                     if (tile < num_tiles(fpN)) claim_tile_wave<In>(fpN, dpNew, inNew, tile, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
                 } else {
-                    claim_tile<In, kBand>(fpN, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
+                    claim_tile<In, kBand>(fpN, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew, a.walkIndexed != 0u);
                 }
                 return;
             }
@@ -284,7 +284,7 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
                 const uint32_t tile = index * (256u / kWave) + threadIdx.x / kWave;
                 if (tile < num_tiles(fpNew)) claim_tile_wave<In>(fpNew, dpNew, inNew, tile, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
             } else {
-                claim_tile<In, kBand>(fpNew, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew);
+                claim_tile<In, kBand>(fpNew, dpNew, inNew, index, kPipeCand + a.setNew, pend, a.planeNew, a.rawNew, a.walkIndexed != 0u);
             }
         } else if (a.walkIndexed) {
             flatten_index_tile(fpNew, dpNew, index, CompactOut{kPipeScan + a.setNew, kPipeScanB + a.setNew, a.numEntries},
