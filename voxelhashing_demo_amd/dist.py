@@ -1087,6 +1087,7 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
         launches = max(1, kt["launches"])
         occ = c["occupied"]
         one_launch = kt.get("frame_pipelined_ms", 0) > 0
+        indexed = False
         if one_launch:
             # the ONE launch of a multi-camera frame (frame_multi_pipelined_kernel: commit + TSDF update of frame b with the
             # claim + walk of frame b+1): one pass over rank 0's shard of the VoxelEntry array for all cameras (20 B per
@@ -1117,6 +1118,8 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             pmc = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
                                               "pmc_latest.json"))).get(wl_name + "sharded", {})
             m, a = pmc.get(pmc_key + "_hbm_bytes_per_launch"), pmc.get("algorithmic_bytes_per_launch")
+            if one_launch and indexed:
+                m = None             # (no counter pass of the walk-free multi-camera launch exists: the reference walk's figure is not its)
             if m and a:
                 traffic = int(round(walk_bytes * m / a)) if world > 1 else int(m)
                 traffic_source = ("rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of the one-rank run" if world == 1 else
