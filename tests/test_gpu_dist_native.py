@@ -119,6 +119,37 @@ def test_fused_and_separate_generation_agree(oracle, vh, torch_cuda, batch):
     ot.close()
 
 
+@pytest.mark.parametrize("fused", [1, 0])
+def test_key_bins_too_small_are_counted_not_overrun(oracle, vh, torch_cuda, fused):
+    """A bin that cannot hold a batch's keys: the generator (the separate launches and the role of the frame launches alike, with its
+    per-frame counters in the bin's last two records) drops what does not fit, the owner's launch counts the overflow and applies
+    what arrived; nothing is written past a bin -- every allocated block is one the oracle has -- and the exchange goes on."""
+    from conftest import entries_as_set
+    torch = torch_cuda
+    batch, steps = 4, 6
+    poses, verts = _frames(batch * steps)
+    kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
+    d16 = [np.round(v[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for v in verts]
+    frames = [torch.from_numpy(d).cuda() for d in d16]
+    torch.cuda.synchronize()
+    ot = oracle.OracleTable(oracle.default_params(**KW), W, H, 1)
+    for j in range(batch * steps):
+        ot.integrate(poses[j], oracle.preprocess(d16[j], kinv)[0])
+    want = entries_as_set(ot.allocated())
+    nd = vdist.NativeDist(vh.default_params(**KW), W, H, 1, 0, 1, batch, vdist.unique_id(), sensor_k_inv=kinv, key_capacity=96)
+    nd.set_option("fused_generation", fused)
+    for s in range(steps):
+        k = s * batch
+        nd.step(poses[k:k + batch], frames[k:k + batch])
+    nd.flush()
+    c = nd.table.counters()
+    assert c["bin_overflow"] > 0 and c["spin_timeouts"] == 0 and c["epoch"] == batch * steps, c
+    got = entries_as_set(nd.table.allocated())
+    assert 0 < len(got) < len(want) and got <= want
+    nd.close()
+    ot.close()
+
+
 def test_native_exchange_equals_the_python_pipeline(oracle, vh, torch_cuda):
     """Same frames through dist.ShardedPipeline (Python host, torch collectives) and through vh_dist_*: the same table."""
     import socket
