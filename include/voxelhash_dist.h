@@ -17,9 +17,9 @@
  * the third), as the Python host of round 2 did it with two (voxelhashing_demo_amd/dist.py: ShardedPipeline) -- but one C
  * call per exchange instead of a dozen Python calls and four torch collectives.  The table sees its
  * operations in the order of the plain step sequence, so results do not depend on the pipelining.
- * By default (option "fused_generation") the generate step has no launches of its own: it runs as a role of the frame launches
- * that apply the exchange fed two calls earlier, over four buffer sets -- the table stream then carries generation and table
- * work, the collectives of exchange n overlap the frame launches of exchange n-1.
+ * On shards large enough for it to pay (option "fused_generation") the generate step has no launches of its own: it runs as a role
+ * of the frame launches that apply the exchange fed two calls earlier, over four buffer sets -- the table stream then carries
+ * generation and table work, the collectives of exchange n overlap the frame launches of exchange n-1.
  *
  * RCCL is bound at run time (dlopen of librccl.so.1, or whatever copy the process has loaded already -- torch's): the
  * library has no link-time dependency on it, and single-GPU users never load it.  No torch types anywhere.
@@ -127,17 +127,18 @@ int vh_dist_host_stats(vh_dist *d, double *seconds, uint64_t *calls);
  *                               1 makes a one-rank group run ncclAllToAll / ncclAllGather all the same: the call sequence of an
  *                               R-GPU node, exercised where only one GPU is at hand.  Set before the first exchange or behind
  *                               vh_dist_flush.
- *   "fused_generation" 0 | 1    1 (the default): the key generation of an exchange runs as a role of the frame launches that apply
- *                               the exchange two calls earlier -- no launches of its own, no second stream; with one rank and
- *                               no caller stream a steady-state vh_dist_step_batch is `batch` kernel launches and no event
- *                               operation.  An exchange is then applied by the SECOND call after the one that fed it (0: by
- *                               the next call); vh_dist_flush applies whatever is in flight either way.  The library falls
- *                               back to separate generation launches by itself where the role does not apply (the first two
- *                               calls behind a flush, batch > 8) and to the separate host path -- application by the next
- *                               call -- for a shard whose frame launch cannot carry it (float packets, an allocation band,
- *                               the overflow list, the walk-free launch of "flatten_variant" 4; looked at in the first
- *                               exchange and behind every vh_dist_flush).  Same results bit for bit.  Set before the first
- *                               exchange or behind vh_dist_flush.
+ *   "fused_generation" 0|1|2    The key generation of an exchange as a role of the frame launches that apply the exchange two
+ *                               calls earlier -- no launches of its own, no second stream; with one rank and no caller stream a
+ *                               steady-state vh_dist_step_batch is `batch` kernel launches and no event operation.  0: never;
+ *                               2: wherever the shard's frame launch can carry it; 1 (the default): where it also pays -- a
+ *                               shard of more than 60 MB of table, whose walk is long enough to hide the role (C2's 2^20
+ *                               buckets on one rank: 49 k against 46 k frames/s; cut 4 or 8 ways: separate launches win).
+ *                               Fused, an exchange is applied by the SECOND call after the one that fed it (else by the next
+ *                               call); vh_dist_flush applies whatever is in flight either way.  The launch cannot carry the
+ *                               role with float packets, an allocation band, the overflow list or the walk-free launch of
+ *                               "flatten_variant" 4 (looked at in the first exchange and behind every vh_dist_flush), nor in
+ *                               the first two calls behind a flush or with batch > 8.  Same results bit for bit.  Set before
+ *                               the first exchange or behind vh_dist_flush.  Environment VOXELHASH_DIST_FUSED: the default.
  *   "phase_timing" 0 | 1        timing events around the three phases of every exchange (vh_dist_phase_times).  Off by default.
  *   "raycast_auto_start" n      this rank's proposal for the slot capacity of vh_dist_raycast_auto's first round (default 4096;
  *                               the ranks take the largest proposal, so they need not agree on it) */

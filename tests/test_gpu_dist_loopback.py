@@ -19,6 +19,18 @@ from voxelhashing_demo_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["by size rule", "fused"])
+def generation_form(request, monkeypatch):
+    """Every test of this file twice: with vh_dist's default -- option "fused_generation" 1, whose size rule keeps tables as small as
+    these on the separate generation launches -- and with the key generation forced into the frame launches wherever they can carry it
+    (VOXELHASH_DIST_FUSED=2, read by vh_dist_create)."""
+    if request.param == "fused":
+        monkeypatch.setenv("VOXELHASH_DIST_FUSED", "2")
+    else:
+        monkeypatch.delenv("VOXELHASH_DIST_FUSED", raising=False)
+    return request.param
+
+
 def _camera_frames(oracle, torch, world, steps, W, H, sensor, loop=40, stride=3):
     """frames[s][r] = (pose, verts as the oracle sees them (numpy), device tensor the rank feeds)."""
     prims = synth.room_primitives()

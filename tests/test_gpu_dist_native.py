@@ -100,12 +100,13 @@ def test_fused_and_separate_generation_agree(oracle, vh, torch_cuda, batch):
         ot.integrate(poses[j], oracle.preprocess(d16[j], kinv)[0])
     for plan in ("fused", "separate", "switching", "walks"):
         nd = vdist.NativeDist(vh.default_params(**KW), W, H, 1, 0, 1, batch, vdist.unique_id(), sensor_k_inv=kinv)
-        if plan == "separate":
-            nd.set_option("fused_generation", 0)
+        # (2 = wherever the launch can carry the role; the default, 1, adds a size rule that keeps tables as small as this test's on
+        # the separate path: multi_fusing_pays)
+        nd.set_option("fused_generation", 0 if plan == "separate" else 2)
         for s in range(steps):
             if plan == "switching" and s in (4, 6):     # (behind a flush; the first two calls after it generate separately)
                 nd.flush()
-                nd.set_option("fused_generation", 0 if s == 4 else 1)
+                nd.set_option("fused_generation", 0 if s == 4 else 2)
             if plan == "walks" and s in (3, 6):         # (the walk-free launch cannot carry the role: the library changes its host
                 nd.flush()                              #  path behind a flush, and back)
                 nd.table.set_option("flatten_variant", 4 if s == 3 else 3)
@@ -119,7 +120,7 @@ def test_fused_and_separate_generation_agree(oracle, vh, torch_cuda, batch):
     ot.close()
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [2, 0])
 def test_key_bins_too_small_are_counted_not_overrun(oracle, vh, torch_cuda, fused):
     """A bin that cannot hold a batch's keys: the generator (the separate launches and the role of the frame launches alike, with its
     per-frame counters in the bin's last two records) drops what does not fit, the owner's launch counts the overflow and applies

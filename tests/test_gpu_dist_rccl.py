@@ -51,8 +51,14 @@ def run_ranks(world, batch, sensor, *extra, timeout=600):
     return outs
 
 
-@pytest.mark.parametrize("world,batch,sensor", [(2, 2, True), (2, 1, False), (4, 2, True)])
-def test_rccl_ranks_equal_one_oracle_table(rccl_rig, world, batch, sensor):
+@pytest.mark.parametrize("world,batch,sensor,fused", [(2, 2, True, False), (2, 1, False, False), (4, 2, True, False), (2, 2, True, True), (4, 2, True, True)])
+def test_rccl_ranks_equal_one_oracle_table(rccl_rig, monkeypatch, world, batch, sensor, fused):
+    """fused: the key generation forced into the frame launches (VOXELHASH_DIST_FUSED=2, inherited by the rank processes); otherwise
+    vh_dist's default, whose size rule keeps tables as small as these on the separate generation launches."""
+    if fused:
+        monkeypatch.setenv("VOXELHASH_DIST_FUSED", "2")
+    else:
+        monkeypatch.delenv("VOXELHASH_DIST_FUSED", raising=False)
     run_ranks(world, batch, sensor)
 
 

@@ -3,7 +3,7 @@
 loop-back transport, one host thread per rank: what a rank's launches cost per multi-camera frame when the table is cut R
 ways, how full the key bins get, and what the whole rig sustains.  The bytes cross by hipMemcpyAsync instead of xGMI, and
 the R ranks share one GPU, so the frames/s figure is a rig number, not a scaling point.
-   tools/emulate_ranks.py [R=8] [batch=8] [workload=C2|C5] [steps=12]"""
+   tools/emulate_ranks.py [R=8] [batch=8] [workload=C2|C5] [steps=12] [fused_generation=default|0|1]"""
 import os
 import sys
 import time
@@ -20,11 +20,15 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 WL = sys.argv[3] if len(sys.argv) > 3 else "C2"
 STEPS = int(sys.argv[4]) if len(sys.argv) > 4 else 12
+FUSED = int(sys.argv[5]) if len(sys.argv) > 5 else None
 W, H, NB, VOX, BLOCKS = (640, 480, 1 << 20, 0.02, 1 << 16) if WL == "C2" else (1920, 1080, 1 << 24, 0.01, 1 << 16)
 kinv = np.linalg.inv(synth.K_matrix(W, H).astype(np.float64)).astype(np.float32)
 prims = synth.room_primitives()
 params = V.default_params(numBuckets=NB, numVoxelBlocks=BLOCKS, voxelSize=VOX)
 g = vdist.NativeGroup(params, W, H, 1, R, B, sensor_k_inv=kinv)
+if FUSED is not None:
+    for nd in g.ranks:
+        nd.set_option("fused_generation", FUSED)
 nf = 32 if WL == "C2" else 8
 poses = [synth.camera_loop(500, phase=vdist.camera_phase(r, R))[:nf] for r in range(R)]
 depth = [[(synth.render_room_verts(p, W, H, prims, device="cuda")[..., 2] * 5000).round().clamp(0, 65535).to(torch.uint16)
@@ -49,11 +53,12 @@ torch.cuda.synchronize()
 wall = time.perf_counter() - t0
 for t in g.tables:
     t.set_profiling(True)
-for i in range(3):
+PROF = 10            # (behind a flush the first two exchanges generate with launches of their own: 8 of 10 carry the role)
+for i in range(PROF):
     exchange(4 + STEPS + i)
 g.flush()
 torch.cuda.synchronize()
-frames = 3 * B
+frames = PROF * B
 cap = max(8192, (-(-W * H // 16) * B * 3 // 2 + R - 1) // R + 1)
 per_rank = []
 for r, t in enumerate(g.tables):

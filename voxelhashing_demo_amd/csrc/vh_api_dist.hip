@@ -206,7 +206,7 @@ struct vh_dist {
     double hostSeconds = 0.0;
     uint64_t hostCalls = 0;
     // option "fused_generation": the key generation as a role of the frame launches (vh_shard.hip: GenJob)
-    bool fused = VH_DIST_FUSED_DEFAULT != 0;
+    int fused = VH_DIST_FUSED_DEFAULT;     // 0 never, 1 where it pays (multi_fusing_pays: by the shard's size), 2 wherever the launch can carry it
     // ... and the form in effect: the fused host path when the shard's frames can carry the role at all (multi_can_fuse_generation:
     // not the walk-free launch, a band, float packets), else the separate path with its three streams overlapping as before.  Decided
     // where nothing is in flight and the streams are idle: at the first exchange and behind every vh_dist_flush.
@@ -401,6 +401,10 @@ extern "C" int vh_dist_create(const vh_dist_config *cfg, const char id[VH_DIST_I
 
     vh_dist *d = new vh_dist();
     d->cfg = *cfg;
+    if (const char *e = std::getenv("VOXELHASH_DIST_FUSED")) {           // the option's default (A/B and test switch, like VOXELHASH_LEAN_KERNELS)
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= 2) d->fused = v;
+    }
     rc = vh_create_shard(&cfg->table, lo, hi, &d->shard);
     if (rc != VH_OK) { dist_free(d); return rc; }
     d->device = d->shard->device;
@@ -517,7 +521,8 @@ extern "C" int vh_dist_set_option(vh_dist *d, const char *name, int32_t value)
     if (std::strcmp(name, "raycast_auto_start") == 0 && value >= 1) { d->autoStart = value; return VH_OK; }
     if (std::strcmp(name, "fused_generation") == 0) {
         if (d->pending >= 0 || !d->inflight.empty()) return fail(VH_ERR_INVALID_ARGUMENT, "fused_generation: set it before the first exchange or behind vh_dist_flush");
-        d->fused = value != 0;
+        if (value < 0 || value > 2) return fail(VH_ERR_INVALID_ARGUMENT, "fused_generation: 0, 1 or 2");
+        d->fused = value;
         d->modeDirty = true;                  // (vh_dist_step_batch decides the form in effect; nothing is in flight)
         return VH_OK;
     }
@@ -736,8 +741,8 @@ extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *co
     const auto t0 = std::chrono::steady_clock::now();
     DeviceGuard guard(d->device);
     if (d->modeDirty) {
-        const bool want = d->fused && d->cfg.packet_format == VH_PACKET_U16 && d->cfg.batch <= 8 && d->capacity >= 8 &&
-                          multi_can_fuse_generation(d->shard, d->cfg.world, d->capacity);
+        const bool want = d->fused != 0 && d->cfg.packet_format == VH_PACKET_U16 && d->cfg.batch <= 8 && d->capacity >= 8 &&
+                          multi_can_fuse_generation(d->shard, d->cfg.world, d->capacity) && (d->fused == 2 || multi_fusing_pays(d->shard));
         if (want != d->fusedActive) {
             d->fusedActive = want;
             d->count = 0;                     // (the set rotation restarts: nothing is in flight, the streams are idle)

@@ -499,6 +499,16 @@ static bool multi_can_fuse_generation(const vh_context *c, int32_t num_bins, int
            serial_launch_pays(c, (uint32_t)num_bins * parts + (uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLaneShort));
 }
 
+// ... and does it pay?  A generating workgroup's chain (6 tiles, ~11 us beside a walk) has to end inside the launch: it does where the
+// shard's walk is long enough to hide it.  One rank, one camera, 640x480, frames/s fused against separate launches
+// (tools/r05_small_shard.py, profiles/r05_fused_by_table_size.txt): 2^21 buckets of 5 entries 30.5 / 29.2 k, 2^20 50.2 / 47.0 k, 2^19
+// 67.0 / 66.7 k, 2^18 74.9 / 89.2 k, 2^17 77.1 / 93.0 k (4 tiles per workgroup: 84.7 / 90.4 k and 85.4 / 93.7 k) -- so above 2^19 buckets,
+// i.e. a walk of more than 60 MB (~10 us).  C2 cut 2, 4 or 8 ways generates with launches of its own; C5's 2^21 buckets per rank fuse.
+static bool multi_fusing_pays(const vh_context *c)
+{
+    return (size_t)c->numEntries * sizeof(VoxelEntry) > ((size_t)60 << 20);
+}
+
 static int vh_apply_frames_batch_gen(vh_context *c, int32_t batch, const int32_t *d_bins, int32_t num_bins,
                                      int32_t capacity, int32_t bin_stride, int32_t frame_stride, int32_t num_cams,
                                      const float *d_packets, size_t packet_stride, size_t packet_frame_stride, const GenJob *jobs);
