@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+OUT=gpurun_out/r05_check; mkdir -p $OUT; rm -f $OUT/ilds.txt
+q() { python3 -c "
+import json,sys; p=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('value', p['value'], 'us/launch', p['roofline'].get('us_per_launch'))"; }
+for i in 1 2; do
+for args in "--workload C3 --option flatten_variant=4" "--workload C5table --option flatten_variant=4" "--workload C2 --option flatten_variant=4"; do
+  echo -n "$args LDS-DMA prefetch in the TSDF update: " | tee -a $OUT/ilds.txt; VOXELHASH_LIB=voxelhashing_demo_amd/lib/alt/v_ilds.so python3 bench.py --legs none --no-cpu-baseline $args 2>/dev/null | q | tee -a $OUT/ilds.txt
+  echo -n "$args in-tree: " | tee -a $OUT/ilds.txt; python3 bench.py --legs none --no-cpu-baseline $args 2>/dev/null | q | tee -a $OUT/ilds.txt
+done; done

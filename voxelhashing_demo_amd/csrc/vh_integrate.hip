@@ -104,7 +104,8 @@ __device__ __forceinline__ void integrate_block(const FrameParams &fp, const Dev
 #ifndef VH_INTEGRATE_LDS
 #define VH_INTEGRATE_LDS 0      // 1: block k+1's 4 KiB prefetched into LDS by LDS-DMA while block k is updated.  Measured (round 3,
                                 // same box, parity-green): C3 launch 2 13.4 vs 11.6 us without, pipelined C3 71.4 vs 70.3,
-                                // loaded C2 26.2 vs 25.6, C2 19.6 vs 19.3 -- off
+                                // loaded C2 26.2 vs 25.6, C2 19.6 vs 19.3; round 5, the walk-free frames: C3 29.4 vs 27.3 us, C5table 27.5 vs 25.8,
+                                // C2 9.1 vs 8.9 (profiles/r05_index_integrate_grid.txt) -- off
 #endif
 template <class Depth>
 // countB > 0: the list has two ends (CompactOut, vh_walk.hip): entries 0 .. count-1 from the front, countB more
