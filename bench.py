@@ -68,7 +68,7 @@ WORKLOADS = {
                desc="C5: synthetic room, 1920x1080 streams, 2^24 buckets x 5 in all, 2^21 voxel blocks per rank, "
                     "voxel 0.01 m, PINHOLE semantics"),
 }
-ALL_LEGS = ("two_launch", "first_lap", "index", "sensor", "raycast", "next", "loaded", "c3", "c5table", "sharded", "cpu")
+ALL_LEGS = ("two_launch", "first_lap", "index", "sensor", "raycast", "next", "loop", "loaded", "c3", "c5table", "sharded", "cpu")
 
 
 def parse_args():
@@ -441,19 +441,25 @@ def index_variant_record(args, it, name, steps, warmup, sync):
     return rec
 
 
-def cpu_baseline_leg(args, name, poses, verts):
+def cpu_baseline_leg(args, name, poses, verts, budget_s=15.0, one_thread_s=3.0, prefix=0):
     """The oracle (kind "port") on this box's host cores over a bounded sample of the same frame
-    sequence: a few seconds on one thread, then the rest of ~15 s on the fastest thread count."""
+    sequence: `one_thread_s` seconds on one thread, then the rest of `budget_s` on the fastest thread count.
+    prefix > 0: the sample is the first `prefix` frames of the sequence, each leg once ("C2/C3 on a 20-frame
+    prefix"), whatever that takes up to the budget."""
     import oracle as O
     wl = WORKLOADS[name]
     Wd, Ht, nframes = wl["width"], wl["height"], len(poses)
+    if prefix:
+        nframes = min(nframes, prefix)
+    host = [np.ascontiguousarray(verts[k].cpu().numpy()) for k in range(nframes)] if nframes <= 64 else None
+    frame = (lambda k: host[k]) if host is not None else (lambda k: verts[k].cpu().numpy())
     op = O.default_params(numBuckets=wl["buckets"], numVoxelBlocks=min(wl["blocks"], 1 << 18), voxelSize=wl["voxel"])
     ot = O.OracleTable(op, Wd, Ht, O.SEM_PINHOLE)
-    budget_s, nmax = 15.0, args.cpu_frames or 10 ** 9
+    nmax = args.cpu_frames or (prefix if prefix else 10 ** 9)
     done, spent, one_done, one_spent = 0, 0.0, 0, 0.0
-    while one_done < nmax and one_spent < 3.0 and one_done < 5000:
+    while one_done < nmax and one_spent < one_thread_s and one_done < 5000:
         k = one_done % nframes
-        v = verts[k].cpu().numpy()
+        v = frame(k)
         c0 = time.perf_counter()
         ot.integrate(poses[k], v)
         one_spent += time.perf_counter() - c0
@@ -462,21 +468,22 @@ def cpu_baseline_leg(args, name, poses, verts):
     # peaks at 16 threads and falls off beyond; the container's CPU share is not the 256 logical
     # cores it sees)
     threads, best, cal = 1, one_done / one_spent, []
+    per_frame = one_spent / one_done
     for th in (4, 8, 16, 32, 64):
         if th > (os.cpu_count() or 1):
             break
         c0, n = time.perf_counter(), 0
-        while time.perf_counter() - c0 < 0.4:
+        while time.perf_counter() - c0 < max(0.4, 1.5 * per_frame / th):
             k = (one_done + n) % nframes
-            ot.integrate_mt(poses[k], verts[k].cpu().numpy(), th)
+            ot.integrate_mt(poses[k], frame(k), th)
             n += 1
-        rate = n / (time.perf_counter() - c0)         # includes the device->host copy: only a ranking
+        rate = n / (time.perf_counter() - c0)         # includes the host copy where frames are not staged: only a ranking
         cal.append((th, round(rate, 1)))
         if rate > best:
             threads, best = th, rate
     while threads > 1 and done < nmax and (args.cpu_frames or spent < budget_s - one_spent) and done < 20000:
         k = (one_done + done) % nframes
-        v = verts[k].cpu().numpy()
+        v = frame(k)
         c0 = time.perf_counter()
         ot.integrate_mt(poses[k], v, threads)
         spent += time.perf_counter() - c0
@@ -486,9 +493,41 @@ def cpu_baseline_leg(args, name, poses, verts):
     ot.close()
     return dict(value=round(done / spent, 3), unit="frames/s", cores=threads, kind="port",
                 one_thread_frames_per_s=round(one_done / one_spent, 3), thread_calibration=cal,
+                sample_short=f"{one_done} fr x1 thread + {done} fr x{threads} threads, {name}"
+                             + (f" {nframes}-frame prefix" if prefix else "") + f", {os.cpu_count()} logical cores",
                 sample=f"{one_done} frames on 1 thread, then {done} frames on {threads} threads (fastest of the "
-                       f"calibration) of the same {name} sequence, oracle/vh_oracle.c "
+                       f"calibration) of the same {name} sequence" + (f" (its first {nframes} frames, cycled)" if prefix else "")
+                       + ", oracle/vh_oracle.c "
                        f"(gcc -O2 -ffp-contract=off -fopenmp), {os.cpu_count()} logical host cores")
+
+
+def cpu_baseline_c1(synth):
+    """BASELINE.json configs[0], literally: ONE 640x480 synthetic sphere depth frame, 8^3 blocks, 2^17 buckets, scalar CPU
+    integrate -- the oracle on one thread, both sphere scenes of SURVEY.md 8(c) G2/G3 (inside-out R = 2 m, from outside
+    r = 0.5 m at 1.5 m), REFERENCE semantics (what the anchors pin) and PINHOLE; a fresh table per repetition, the
+    table's allocation outside the clock; median of the repetitions that fit ~0.5 s per case."""
+    import oracle as O
+    I4 = np.eye(4, dtype=np.float32)
+    out = {}
+    for scene, verts in (("sphere_inside", synth.sphere_inside_scene()), ("sphere_outside", synth.sphere_outside_scene())):
+        for sem, sname in ((O.SEM_REFERENCE, "reference"), (O.SEM_PINHOLE, "pinhole")):
+            times, blocks = [], 0
+            while sum(times) < 0.5 and len(times) < 50:
+                ot = O.OracleTable(O.default_params(numBuckets=1 << 17, numVoxelBlocks=4096), 640, 480, sem)
+                c0 = time.perf_counter()
+                ot.integrate(I4, verts)
+                times.append(time.perf_counter() - c0)
+                blocks = ot.compact_count()
+                ot.close()
+            med = statistics.median(times)
+            out[f"{scene}_{sname}"] = dict(ms_per_frame=round(1e3 * med, 3), frames_per_s=round(1.0 / med, 2),
+                                           occupied_blocks=blocks, repetitions=len(times))
+    head = out["sphere_inside_pinhole"]
+    return dict(value=head["frames_per_s"], unit="frames/s", cores=1, kind="port",
+                sample_short="C1: 1 sphere frame (inside-out, pinhole), fresh 2^17-bucket table, 1 thread",
+                sample="C1 (BASELINE.json configs[0]): one 640x480 sphere frame into a fresh 2^17-bucket table, oracle/vh_oracle.c "
+                       "on one thread; value = the inside-out sphere in PINHOLE semantics, `cases` holds both scenes x both semantics",
+                cases=out)
 
 
 def launcher_command(argv, gpus, port):
@@ -580,11 +619,12 @@ def main():
         out = vdist.bench_sharded(args, wl, args.workload, rank, world, local_rank)
         if rank == 0:
             if "cpu" in legs:       # the reported CPU baseline: one camera's frames of the same workload, rank 0's host
-                poses, verts = render_frames(synth, wl, min(32, wl["frames"]), torch.device("cuda", local_rank), torch)
+                poses, verts = render_frames(synth, wl, min(32, wl["frames"]), torch.device("cuda", local_rank), torch, sensor=False)
                 out["cpu_baseline"] = cpu_baseline_leg(args, args.workload, poses, verts)
-            print(json.dumps(out), flush=True)
         dist.barrier()
         dist.destroy_process_group()
+        if rank == 0:
+            emit(out, compact_sharded_line(out))
         return
 
     # A full collection of the Python garbage collector walks every object torch has created (~10^6):
@@ -643,7 +683,7 @@ def main():
     k_inv = np.linalg.inv(synth.K_matrix(Wd, Ht).astype(np.float64)).astype(np.float32)
     kin = np.ascontiguousarray(k_inv.reshape(9))
     kin_p = kin.ctypes.data_as(C.POINTER(C.c_float))
-    if "sensor" in legs:
+    if "sensor" in legs and not it.sensor:      # (a sensor-fed workload IS this leg's fused form already)
         nd = min(nframes, 250)
         depth16 = torch.empty((nd, Ht, Wd), dtype=torch.uint16, device=dev)
         for i in range(nd):
@@ -745,8 +785,13 @@ def main():
         s_it.close()
 
     # ---- next rows ----
+    # (the legs below hand float4 vertex maps to vh_preprocess / ICP / the oracle: a sensor-fed workload renders a few)
+    fposes, fverts = (poses, verts) if not it.sensor else render_frames(synth, wl, min(nframes, 24), dev, torch, sensor=False)
     if "next" in legs:
-        extra["next_rows"] = next_rows_leg(V, synth, torch, it, verts, k_inv, stream, Wd, Ht)
+        extra["next_rows"] = next_rows_leg(V, synth, torch, it, fverts, k_inv, stream, Wd, Ht)
+    # ---- closed loop: track each frame against the model, integrate at the tracked pose, raycast ----
+    if "loop" in legs:
+        extra["closed_loop"] = closed_loop_leg(V, synth, torch, wl, fposes, fverts, local_rank, stream)
 
     # ---- C3 sub-record: the table that does NOT fit the Infinity Cache (true HBM streaming) ----
     if "c3" in legs and name == "C2":
@@ -790,6 +835,11 @@ def main():
             del d3
         extra["configs"] = {"C3": c3_rec}
         c3_it.close()
+        if "cpu" in legs:
+            # C3 on a 20-frame prefix, one thread and the fastest thread count
+            p20, v20 = render_frames(synth, WORKLOADS["C3"], 20, dev, torch, sensor=False)
+            c3_rec["cpu_baseline"] = cpu_baseline_leg(args, "C3", p20, v20, budget_s=10.0, one_thread_s=3.0, prefix=20)
+            del v20
         if "c5table" in legs:
             # the same frames into a 1.68 GB table: 64 of them, short windows (a frame takes ~ 0.25 ms)
             n5 = min(len(c3_poses), WORKLOADS["C5table"]["frames"])
@@ -804,8 +854,7 @@ def main():
             c5_it.close()
         del c3_verts
         torch.cuda.empty_cache()
-        poses, verts = render_frames(synth, wl, min(nframes, 64), dev, torch)     # for the CPU sample below
-        nframes = len(poses)
+        fposes, fverts = render_frames(synth, wl, min(nframes, 64), dev, torch, sensor=False)     # for the CPU sample below
 
     # ---- the sharded path with ONE rank over RCCL: the code path the N > 1 lines run, so that the
     # scaling curve's anchor and its points share a code path ----
@@ -835,7 +884,11 @@ def main():
             extra["sharded_world1"] = dict(error=repr(e))
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample ----
-    cpu = cpu_baseline_leg(args, name, poses, verts) if "cpu" in legs else None
+    cpu = cpu_baseline_leg(args, name, fposes, fverts) if "cpu" in legs else None
+    if "cpu" in legs:
+        extra.setdefault("configs", {})["C1"] = dict(cpu_baseline=cpu_baseline_c1(synth), workload="C1: BASELINE.json configs[0] "
+                                                     "(CPU-only plumbing case: no GPU leg; the GPU parity of the same scenes is "
+                                                     "tests/test_gpu_parity.py and __graft_entry__.smoke)")
 
     out = dict(
         metric=baseline_metric(Wd, Ht),
@@ -859,10 +912,153 @@ def main():
         frame_frac_of_hbm_peak=main_rec["frame_frac_of_hbm_peak"],
     )
     out.update(extra)
-    print(json.dumps(out), flush=True)
     if it is not None:
         it.close()
     torch.cuda.synchronize()
+    emit(out, compact_line(out))
+
+
+COMPACT_LIMIT = 4096         # the driver keeps the last 8 KB of stdout: the line it parses must fit with room to spare
+
+
+def _pick(d, *keys):
+    """The named keys of a record that are present and not None (numbers and short strings only reach the line)."""
+    return {k: d[k] for k in keys if isinstance(d, dict) and d.get(k) is not None}
+
+
+def _roofline_numbers(rf):
+    return _pick(rf, "bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "us_per_launch",
+                 "rocprofv3_us_per_launch", "frac_at_rocprofv3_mean") if rf else None
+
+
+def _cpu_numbers(cb):
+    if not cb:
+        return None
+    out = _pick(cb, "value", "unit", "cores", "kind", "one_thread_frames_per_s")
+    out["sample"] = cb.get("sample_short") or str(cb.get("sample", ""))[:120]
+    return out
+
+
+def _walk_free_numbers(rec):
+    """The walk-free frame in the line: frames/s, the launch, and the latency/issue model it is held against (not an HBM fraction)."""
+    if not rec:
+        return None
+    out = _pick(rec, "value", "ms_per_step")
+    rf = rec.get("roofline") or {}
+    out.update(_pick(rf, "us_per_launch", "traffic", "bytes_per_launch"))
+    out["bound"] = "latency+issue"
+    if rec.get("latency_model"):
+        out["model_us"] = rec["latency_model"].get("model_us")
+    return out
+
+
+def compact_line(out):
+    """The ONE stdout line of a one-GPU run: the contract's keys, the roofline and CPU baseline as numbers, and per comparison
+    leg {value, ms_per_step, frac}.  Everything else (notes, formulas, per-kernel tables) is in bench_detail.json."""
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = _pick(out["config"], "workload", "resident_frames", "occupied_blocks", "allocated_blocks", "pipelined")
+    line["config"]["frames_per_step"] = out.get("frames_per_step")
+    line["roofline"] = _roofline_numbers(out.get("roofline"))
+    if line["roofline"] is not None:
+        line["roofline"].setdefault("traffic", None)
+    line["cpu_baseline"] = _cpu_numbers(out.get("cpu_baseline"))
+    line["raycast_mpix_per_s"] = out.get("raycast_mpix_per_s")
+    line["windows"], line["timed_s"] = out.get("windows"), out.get("timed_s")
+    rc = out.get("raycast")
+    if rc:
+        line["raycast"] = dict(_pick(rc, "kernel_us", "kernel_mpix_per_s", "poses"),
+                               **({"valu_issue_frac": rc["roofline"].get("frac")} if rc.get("roofline") else {}))
+    legs = {}
+    for key, short in (("two_launch_frame", "two_launch"), ("first_lap", "first_lap")):
+        if out.get(key):
+            legs[short] = _pick(out[key], "value", "ms_per_step")
+    if out.get("occupancy_index_variant"):
+        legs["walk_free"] = _walk_free_numbers(out["occupancy_index_variant"])
+    if out.get("loaded_integrate"):
+        lr = out["loaded_integrate"]
+        legs["loaded"] = dict(_pick(lr, "value", "ms_per_step", "occupied_blocks"),
+                              **_pick(lr.get("roofline") or {}, "frac", "us_per_launch", "traffic", "frac_at_rocprofv3_mean"))
+    for cname, crec in (out.get("configs") or {}).items():
+        c = dict(_pick(crec, "value", "ms_per_step", "occupied_blocks"),
+                 **_pick(crec.get("roofline") or {}, "frac", "us_per_launch", "traffic", "frac_at_rocprofv3_mean"))
+        if crec.get("cpu_baseline"):
+            c["cpu_baseline"] = _cpu_numbers(crec["cpu_baseline"])
+        if crec.get("occupancy_index_variant"):
+            c["walk_free"] = _walk_free_numbers(crec["occupancy_index_variant"])
+        if crec.get("raycast"):
+            c["raycast_us"] = dict(dda=crec["raycast"].get("kernel_us"), **(crec["raycast"].get("variants_kernel_us") or {}))
+        legs[cname] = c
+    sw = out.get("sharded_world1")
+    if sw:
+        legs["sharded_world1"] = (dict(error=str(sw["error"])[:160]) if "error" in sw else
+                                  dict(_pick(sw, "value", "ms_per_step"), **_pick(sw.get("roofline") or {}, "frac", "us_per_launch")))
+    if out.get("closed_loop"):
+        legs["closed_loop"] = _pick(out["closed_loop"], "value", "unit", "integrate_us", "raycast_us", "align_us", "frames")
+    line["legs"] = legs
+    line["detail"] = "bench_detail.json"
+    return line
+
+
+def compact_sharded_line(out):
+    """The ONE stdout line of an N-rank run (same rule: numbers and short names; the prose stays in bench_detail.json)."""
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data", "windows", "timed_s", "host_enqueue_ms_per_step")}
+    cfg = out["config"]
+    line["config"] = dict(workload=str(cfg["workload"])[:200],
+                          **_pick(cfg, "frames_per_step", "frames_per_camera_per_exchange", "resident_frames", "pipelined",
+                                  "key_bin_overflows", "occupied_blocks_all_ranks", "allocated_blocks_all_ranks", "packet_bytes",
+                                  "key_bin_bytes_per_rank_and_exchange"))
+    rf = out.get("roofline") or {}
+    line["roofline"] = dict(_pick(rf, "bound", "kernel", "achieved", "peak", "unit", "frac", "bytes_per_launch", "us_per_launch",
+                                  "launches_per_frame"), traffic=rf.get("traffic"))
+    line["cpu_baseline"] = _cpu_numbers(out.get("cpu_baseline"))
+    er = out.get("exchange_ranks") or {}
+    line["exchange_ranks"] = dict(er, transport=str(er.get("transport", ""))[:120])
+    ph = out.get("exchange_phases_us")
+    line["exchange_phases_us"] = _pick(ph, "generate", "collectives", "apply", "first_to_last", "host_enqueue", "exchanges") if ph else None
+    pr = out.get("predicted")
+    if pr:
+        line["predicted"] = {k: (_pick(v.get("nominal", v), "frames_per_s") if isinstance(v, dict) else v)
+                             for k, v in pr.items() if k in ("reference_walk", "walk_free", "model")}
+    line["exchange_host"] = str(out.get("exchange_host", ""))[:100]
+    if out.get("generation_form"):
+        line["generation_form"] = out["generation_form"]
+    sr = out.get("sharded_raycast")
+    if sr:
+        line["sharded_raycast"] = _pick(sr, "mpix_per_s", "views_per_round", "ms_per_round", "lost_records")
+    line["detail"] = "bench_detail.json"
+    return line
+
+
+def emit(detail, line):
+    """Full record -> bench_detail.json (next to this file, and gpurun_out/ where that exists) and stderr; the compact line ->
+    stdout, LAST: C stdio is flushed first (RCCL prints its version banner through it and would otherwise flush it at exit,
+    behind the line), and nothing is printed after."""
+    text = json.dumps(detail)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(json.dumps(detail, indent=1) + "\n")
+            except OSError:
+                pass
+    print("bench.py detail: " + text, file=sys.stderr, flush=True)
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) >= COMPACT_LIMIT:                 # never silently: a line the driver cannot parse is a lost round
+        for k in ("legs", "predicted", "exchange_phases_us", "raycast"):
+            line.pop(k, None)
+            s = json.dumps(line, separators=(",", ":"))
+            if len(s) < COMPACT_LIMIT:
+                break
+        print(f"bench.py: compact line trimmed to {len(s)} bytes", file=sys.stderr, flush=True)
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stderr.flush()
+    sys.stdout.write(s + "\n")
+    sys.stdout.flush()
 
 
 def init_dist(dist, torch, local_rank):
@@ -919,6 +1115,70 @@ def raycast_roofline(workload, kernel_us, Wd, Ht):
     return dict(bound="valu-issue", kernel=kernel, achieved=round(achieved, 1), peak=round(peak, 1),
                 unit="G wave-instr/s", frac=round(achieved / peak, 4), traffic=None, valu_per_wave=valu_per_wave, waves=waves,
                 us_per_launch=round(kernel_us, 2))
+
+
+def closed_loop_leg(V, synth, torch, wl, poses, verts, local_rank, stream, nloop=60):
+    """The KinectFusion loop of SURVEY.md 8(f)4 on this workload's first `nloop` frames, a FRESH table: per frame
+    vh_preprocess -> vh_icp_align against the model's raycast maps -> vh_integrate_depth at the tracked pose ->
+    vh_raycast_maps (tracking.FusionLoop; frame order of Application.cpp:73-90).  frames/s = tracked frames / wall time of
+    the loop (one stream; the only host synchronisation of a frame is vh_icp_align handing back the pose).  The per-stage
+    microseconds come from a second pass over the same frames with a stream synchronisation after each stage."""
+    from voxelhashing_demo_amd import tracking
+    Wd, Ht = wl["width"], wl["height"]
+    n = min(nloop, len(poses))
+    K = synth.K_matrix(Wd, Ht)
+    k_inv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    depth16 = torch.empty((n, Ht, Wd), dtype=torch.uint16, device=verts.device)
+    for i in range(n):
+        depth16[i] = (verts[i, :, :, 2] * 5000.0).round().clamp(0, 65535).to(torch.uint16)
+    torch.cuda.synchronize()
+    params = V.default_params(numBuckets=wl["buckets"], numVoxelBlocks=wl["blocks"], voxelSize=wl["voxel"])
+    out = {}
+    for timed_stages in (False, True):
+        table = V.SDFHashtable(params, Wd, Ht, V.SEM_PINHOLE, device=local_rank, stream=stream)
+        loop = tracking.FusionLoop(table, K, k_inv, stream=stream)
+        with torch.cuda.stream(stream):
+            loop.start(depth16[0], poses[0])
+            table.synchronize()
+            stage = dict(align=0.0, integrate=0.0, raycast=0.0)
+            errs, rounds = [], 0
+            t0 = time.perf_counter()
+            for k in range(1, n):
+                if not timed_stages:
+                    loop.step(depth16[k])
+                else:
+                    c0 = time.perf_counter()
+                    loop.track(depth16[k])                       # (synchronises by itself)
+                    c1 = time.perf_counter()
+                    p32 = loop.pose.astype(np.float32)
+                    table.integrate_depth(p32, depth16[k], loop.k_inv)
+                    table.synchronize()
+                    c2 = time.perf_counter()
+                    table.raycast_maps(p32, loop.depth, loop.model_v, loop.model_n)
+                    table.synchronize()
+                    c3 = time.perf_counter()
+                    stage["align"] += c1 - c0
+                    stage["integrate"] += c2 - c1
+                    stage["raycast"] += c3 - c2
+                rounds += loop.trk.iterations
+                truth = np.asarray(poses[k], np.float64).reshape(4, 4)
+                errs.append(float(np.abs(loop.pose[:3, 3] - truth[:3, 3]).max()))
+            table.synchronize()
+            wall = time.perf_counter() - t0
+        if not timed_stages:
+            out.update(value=round((n - 1) / wall, 1), unit="frames/s", frames=n - 1, ms_per_frame=round(1e3 * wall / (n - 1), 4),
+                       icp_rounds_per_frame=round(rounds / (n - 1), 1), max_drift_mm=round(1e3 * max(errs), 2),
+                       blocks=table.counters()["allocated_total"])
+        else:
+            out.update(align_us=round(1e6 * stage["align"] / (n - 1), 1), integrate_us=round(1e6 * stage["integrate"] / (n - 1), 1),
+                       raycast_us=round(1e6 * stage["raycast"] / (n - 1), 1))
+        loop.close()
+        table.close()
+    out["note"] = ("tracking.FusionLoop on a fresh table: vh_preprocess -> vh_icp_align (up to 20 rounds, device-side solve, one "
+                   "copy + synchronisation) -> vh_integrate_depth (two-launch frame: the model is read right after) -> vh_raycast_maps; "
+                   "align_us includes vh_preprocess; the stage times are host-timed with a synchronisation per stage (second pass), "
+                   "value is the unsynchronised loop; drift = max |translation error| against the synthetic truth")
+    return out
 
 
 def next_rows_leg(V, synth, torch, it, verts, k_inv, stream, Wd, Ht):

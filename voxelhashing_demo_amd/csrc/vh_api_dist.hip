@@ -568,11 +568,18 @@ __global__ void dist_pattern_check_kernel(const uint32_t *a2a, const uint32_t *g
     }
     if (n) atomicAdd(bad, n);
 }
+// Drain + synchronise.  late != nullptr: the caller is about to enter collectives -- a rank-local, non-fatal condition
+// (VH_ERR_TIMEOUT: a serialised launch of THIS shard gave up waiting) must not make this rank leave the round while its peers
+// enter ncclAllGather without it: it is latched into *late, VH_OK is returned, and the caller returns *late
+// after the round's last collective.
+static int dist_flush_sync(vh_dist *d, int *late);
+
 extern "C" int vh_dist_self_check(vh_dist *d)
 {
     if (!d) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(d->device);
-    int rc = vh_dist_flush(d);
+    int late = VH_OK;
+    int rc = dist_flush_sync(d, &late);
     if (rc != VH_OK) return rc;
     const int R = d->cfg.world;
     // up to 64 KB per peer, what the smaller of a key bin and this rank's packets holds (in whole 1 KB pieces)
@@ -597,6 +604,7 @@ extern "C" int vh_dist_self_check(vh_dist *d)
     if (e == hipSuccess) e = hipStreamSynchronize(d->sComm);
     (void)hipFree(bad);
     if (e != hipSuccess) return fail(VH_ERR_HIP, "vh_dist_self_check", e);
+    if (n == 0 && late != VH_OK) return late;
     if (n != 0) {
         char msg[160];
         std::snprintf(msg, sizeof msg, "vh_dist_self_check: rank %d of %d received %d wrong words through the %s transport", d->cfg.rank, R, n, d->transport->name);
@@ -829,17 +837,27 @@ static int dist_drain(vh_dist *d)
     return flush_pending(d->shard);
 }
 
-extern "C" int vh_dist_flush(vh_dist *d)
+static int dist_flush_sync(vh_dist *d, int *late)
 {
-    if (!d) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
-    DeviceGuard guard(d->device);
     const int rc = dist_drain(d);
     if (rc != VH_OK) return rc;
     VH_HIP(hipStreamSynchronize(d->sTable));
     VH_HIP(hipStreamSynchronize(d->sComm));
     VH_HIP(hipStreamSynchronize(d->sGen));
     d->modeDirty = true;
-    return check_spin_timeouts(d->shard);      // (VH_ERR_TIMEOUT: a serialised multi-camera launch gave up waiting, voxelhash.h)
+    const int t = check_spin_timeouts(d->shard);      // (VH_ERR_TIMEOUT: a serialised multi-camera launch gave up waiting, voxelhash.h)
+    if (t == VH_ERR_TIMEOUT && late) {
+        *late = t;
+        return VH_OK;
+    }
+    return t;
+}
+
+extern "C" int vh_dist_flush(vh_dist *d)
+{
+    if (!d) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    DeviceGuard guard(d->device);
+    return dist_flush_sync(d, nullptr);
 }
 
 static int dist_raycast_impl(vh_dist *d, const float pose[16], float t_min, float t_max, int32_t capacity, float *d_depth_out,
@@ -849,7 +867,8 @@ static int dist_raycast_impl(vh_dist *d, const float pose[16], float t_min, floa
     const int R = d->cfg.world;
     if (R > 16) return fail(VH_ERR_INVALID_ARGUMENT, "the fixed-slot raycast round serves at most 16 views");
     DeviceGuard guard(d->device);
-    int rc = vh_dist_flush(d);                      // the model as of every fed exchange
+    int late = VH_OK;                               // (a spin timeout of this shard: reported after the round's collectives)
+    int rc = dist_flush_sync(d, &late);             // the model as of every fed exchange
     if (rc != VH_OK) return rc;
     if (!d->view) {
         vh_config vc = d->cfg.table;
@@ -906,7 +925,7 @@ static int dist_raycast_impl(vh_dist *d, const float pose[16], float t_min, floa
         VH_HIP(hipEventRecord(d->outEvent, d->sTable));
         VH_HIP(hipStreamWaitEvent(d->userStream, d->outEvent, 0));
     }
-    return VH_OK;
+    return late;
 }
 
 extern "C" int vh_dist_raycast(vh_dist *d, const float pose[16], float t_min, float t_max, int32_t capacity, float *d_depth_out,
@@ -930,13 +949,14 @@ extern "C" int vh_dist_raycast_auto(vh_dist *d, const float pose[16], float t_mi
     // a shard cannot select more blocks than its pool holds, and the view table lists one imported record per entry
     const int64_t most = std::max<int64_t>(1, std::min<int64_t>((int64_t)d->cfg.table.params.numVoxelBlocks,
         (int64_t)d->cfg.table.params.numBuckets * d->cfg.table.params.bucketSize / R));
+    int late = VH_OK;                                   // a rank-local spin timeout: every collective of the call still runs, then it is returned
     const int32_t first = d->autoStart;                 // (option "raycast_auto_start": 4096 unless a caller -- the test of the retry -- asks otherwise)
     int32_t cap = (int32_t)std::min<int64_t>(most, std::max<int32_t>(d->autoCapacity, first));
     {
         // The slots are one size everywhere and every rank issues an all-to-all of that size: the ranks AGREE on the first
         // capacity (the largest any of them proposes) instead of trusting that their local state -- the capacity of their last
         // call, an environment variable -- is identical; ranks that disagreed would hang in mismatched collectives.
-        int rc = vh_dist_flush(d);
+        int rc = dist_flush_sync(d, &late);
         if (rc != VH_OK) return rc;
         VH_HIP(hipMemcpyAsync(d->lostDev, &cap, sizeof cap, hipMemcpyHostToDevice, d->sTable));
         if ((rc = d->transport->all_gather(d, d->lostDev, d->lostDev + 1, sizeof(int32_t), d->sTable)) != VH_OK) return rc;
@@ -949,6 +969,7 @@ extern "C" int vh_dist_raycast_auto(vh_dist *d, const float pose[16], float t_mi
     const int kAttempts = 8;
     for (int attempt = 0; attempt < kAttempts; ++attempt) {
         int rc = dist_raycast_impl(d, pose, t_min, t_max, cap, d_depth_out, d_normals_out, d->lostDev);
+        if (rc == VH_ERR_TIMEOUT) { late = rc; rc = VH_OK; }
         if (rc != VH_OK) return rc;
         if ((rc = d->transport->all_gather(d, d->lostDev, d->lostDev + 1, sizeof(int32_t), d->sTable)) != VH_OK) return rc;
         int32_t lost[VH_MAX_CAMERAS];
@@ -959,7 +980,7 @@ extern "C" int vh_dist_raycast_auto(vh_dist *d, const float pose[16], float t_mi
         if (worst == 0) {
             d->autoCapacity = cap;
             if (capacity_used) *capacity_used = cap;
-            return VH_OK;
+            return late;
         }
         if ((int64_t)cap >= most)
             return fail(VH_ERR_INVALID_ARGUMENT, "vh_dist_raycast_auto: a view selects more blocks of a shard than the shard's pool holds");

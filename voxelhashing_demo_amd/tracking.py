@@ -122,3 +122,61 @@ class CameraTracking:
 
     def getTransform(self) -> np.ndarray:
         return self.delta
+
+
+class FusionLoop:
+    """The demo's frame order as a closed loop (Application.cpp:73-90: preProcess -> Align -> integrate, then the
+    renderer reads the model; CameraTracking.cpp:26-69): per uint16 sensor frame
+
+        vh_preprocess(depth)            -> input vertex map             (CameraTrackingUtils.cu:115-120)
+        vh_icp_align(input, model maps) -> delta, pose = pose . delta   (frame-to-model: the target is the raycast)
+        vh_integrate_depth(pose, depth) -> the model takes the frame    (SDF_Hashtable.cpp:11-40)
+        vh_raycast_maps(pose)           -> depth + vertex + normal maps of the model for the next frame's Align
+
+    all queued on ONE stream (the table's; the tracker is bound to it).  The only host synchronisation of a frame is the
+    one inside vh_icp_align, which hands the 4x4 delta to the host -- the pose is a host value in the reference's
+    interface (integrate(const float4x4&, ...)), so the next frame's calls cannot be queued before it is known.
+    The first frame is integrated at `start_pose`."""
+
+    def __init__(self, table, K, k_inv, stream=None, flags: int = ICP_ABS_DISTANCE | ICP_NEED_TARGET, max_iters: int = MAX_ITERS):
+        import torch
+        self.table, self.W, self.H = table, table.width, table.height
+        self.k_inv = np.ascontiguousarray(np.asarray(k_inv, np.float32).reshape(9))
+        self.trk = CameraTracking(self.W, self.H, K, stream=stream, flags=flags, max_iters=max_iters)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.depth = torch.zeros((self.H, self.W), dtype=torch.float32, device=dev)
+        self.model_v, self.model_n, self.in_v, self.in_n = (torch.empty((self.H, self.W, 4), dtype=torch.float32, device=dev)
+                                                            for _ in range(4))
+        self.stream = stream
+        self.pose = None
+        self.frames = 0
+
+    def start(self, depth_u16, start_pose):
+        self.pose = np.asarray(start_pose, np.float64).reshape(4, 4).copy()
+        self.table.integrate_depth(self.pose.astype(np.float32), depth_u16, self.k_inv)
+        self.table.raycast_maps(self.pose.astype(np.float32), self.depth, self.model_v, self.model_n)
+        self.frames = 1
+        return self.pose
+
+    def track(self, depth_u16):
+        """pre-process + Align only: the new pose (not yet integrated)."""
+        from .hashtable import preprocess
+        preprocess(depth_u16, self.k_inv, self.in_v, self.in_n, stream=self.stream)
+        delta = self.trk.Align(self.in_v, self.model_v, self.model_n).astype(np.float64)
+        self.pose = self.pose @ delta
+        return self.pose
+
+    def fuse(self, depth_u16):
+        """integrate at the current pose + the model's maps for the next Align."""
+        p32 = self.pose.astype(np.float32)
+        self.table.integrate_depth(p32, depth_u16, self.k_inv)
+        self.table.raycast_maps(p32, self.depth, self.model_v, self.model_n)
+        self.frames += 1
+
+    def step(self, depth_u16):
+        self.track(depth_u16)
+        self.fuse(depth_u16)
+        return self.pose
+
+    def close(self):
+        self.trk.close()
