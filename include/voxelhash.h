@@ -274,7 +274,7 @@ int vh_integrate_depth(vh_context *ctx, const float pose[16], const uint16_t *d_
  * (they count as heap_exhausted and retry), where vh_integrate serves as many as there are blocks.
  * With "overflow_list" the frames are still one launch each, but serialised inside it: the claim and walk workgroups of
  * the new frame start when the commit phase of the pending one has finished (and that phase serves as many winners as the
- * heap has blocks, like the unpipelined frame).  bucketSize > 16 and the persistent walk (flatten_variant 5) run unpipelined.  vh_integrate_batch / vh_integrate_depth_batch: `count` frames (poses: count*16 host
+ * heap has blocks, like the unpipelined frame).  bucketSize > 16 runs unpipelined.  vh_integrate_batch / vh_integrate_depth_batch: `count` frames (poses: count*16 host
  * floats; d_verts / d_normals / d_depth: host arrays of `count` device pointers, d_normals may be NULL)
  * in count + 1 launches -- the pipeline switched on for the call and flushed at its end. */
 int vh_flush(vh_context *ctx);
@@ -339,11 +339,10 @@ int vh_download_range(vh_context *ctx, int which, size_t offset_bytes, void *hos
  * product, not on a build of their own -- and are supported as documented here; none of them changes a result:
  *   vh_debug_eval, vh_debug_set_raycast_stamps, vh_debug_occupy (below); the loop-back transport of voxelhash_dist.h
  *   (vh_dist_loopback_id: the N-rank exchange inside one process); vh_set_profiling / vh_get_kernel_times; the options
- *   "spin_limit", "lean_kernels", "claim_filter", "raycast_split", "raycast_items_grid"; environment: VOXELHASH_LEAN_KERNELS
- *   (the option's default), VOXELHASH_LOOPBACK_TIMEOUT_S (how long a loop-back rank waits for its peers), VH_ICP_BLOCKS
+ *   "spin_limit"; environment: VOXELHASH_LOOPBACK_TIMEOUT_S (how long a loop-back rank waits for its peers), VH_ICP_BLOCKS
  *   (workgroups of an ICP round), VOXELHASH_SEMANTICS (the drop-in names' semantics).
  * Code that exists only in diagnostics BUILDS (make EXTRA=-D...) and in no shipped library: VH_DEBUG_SKIP_ROLES (roles of the
- * pipelined launch return at once), VH_RAYCAST_DIAG, VH_CLAIM_STAMPS, VH_DEBUG_DIST_* (per-phase time stamps and switch-offs). */
+ * pipelined launch return at once), VH_CLAIM_STAMPS, VH_DEBUG_DIST_* (per-phase time stamps and switch-offs). */
 /* test hook: evaluates the device scalar helpers on n points; writes 8 int32 per
  * point: block x,y,z, hash, blockInFrustum, project() x,y, float->int of .w */
 int vh_debug_eval(vh_context *ctx, const vh_float4 *d_points, int32_t n, int32_t *d_out);
@@ -353,21 +352,27 @@ int vh_debug_set_raycast_stamps(vh_context *ctx, void *d_stamps);
 /* test hook: `workgroups` x 256 lanes that stay resident for `microseconds` on `stream` (a device busy with another kernel) */
 int vh_debug_occupy(vh_context *ctx, void *stream, int32_t workgroups, int32_t microseconds);
 
-/* Options.  Tuning knobs for A/B measurements, results never change: "fused_frame" (1: two launches
- * per frame, 0: the four step kernels), "flatten_variant" (3 = the walk over every VoxelEntry, default;
- * 4 = occupancy index; 5 = persistent prefetching walk; anything else is rejected), "integrate_grid",
- * "commit_blocks", "persistent_blocks", "raycast_patch", "raycast_xcd", "walk_nt" (non-temporal loads in
- * the table walk; on by default when the table exceeds the 256 MiB Infinity Cache), "claim_span" (percent
- * of a launch's claim + walk workgroups the claim tiles are spread over; 0 = by the size rule), "walk_entries"
- * (4 or 8 table entries per lane of the frame's walk; default 4), "lean_kernels" (1, default: the pipelined launch
- * runs the build that has the context's option flags folded in when such a build exists; 0: always the generic
- * build; environment VOXELHASH_LEAN_KERNELS overrides the default at vh_create), "multi_walk_entries" (the same
- * for the multi-camera launch; 0 = by the shard's size), "gen_frames_per_launch" (1..8, default 4: frames of a batch one
- * key-generation launch of vh_generate_keys*_batch takes -- fewer per launch leave more of the chip to the frame launches
- * the generation runs beside), "claim_wave_tiles" (0 | 1 | 2: the walk-free frame's claim role takes a launch tile per wave
- * instead of per workgroup -- never, always, or for images of more than 2400 tiles, the default; same results).  They apply to vh_integrate and
- * vh_integrate_depth alike.  "cand_capacity" shrinks the candidate list (test hook for
- * vh_counters.cand_overflow).  Format switch: "packet_format" (VH_PACKET_F32 / VH_PACKET_U16, below). */
+/* Options (18 names; anything else is rejected with VH_ERR_INVALID_ARGUMENT).  Results never depend on the tuning ones.
+ *   semantics of the model (extensions of the reference, each with its oracle counterpart):
+ *     "overflow_list" (0 | 1, before the first frame), "band_mode" (VH_BAND_*), "depth_truncation", "weight_sample" (0 | 1)
+ *   the frame:
+ *     "flatten_variant"  3 = the reference's walk over every VoxelEntry (flattenKernel, VoxelUtils.cu:719-749), 4 = the walk
+ *                        over the bucket-occupancy bitmap and the non-empty buckets (same compact set); default: see vh_create
+ *     "pipeline"         1: one launch per frame (a frame's commit + TSDF update ride in the next frame's launch)
+ *     "pipeline_overflow" 0 | 1 | 2: one-launch frames with the overflow list never / by the launch's size / always
+ *     "pipeline_shards"  0 | 1 | 2: the same for a shard's multi-camera frames (vh_apply_frames_batch)
+ *     "fused_frame"      1 (default): vh_integrate as two launches; 0: the four step kernels of the step-level entry points
+ *     "walk_nt"          non-temporal loads in the reference walk (default: on when the table exceeds the 256 MiB Infinity Cache)
+ *     "integrate_grid", "commit_blocks"   workgroups of the TSDF update / of the commit phase in the two-launch frame
+ *     "gen_frames_per_launch"  1..8 (default 4): frames of a batch one key-generation launch of vh_generate_keys*_batch takes
+ *     "spin_limit"       polls a workgroup of a serialised one-launch frame waits for the pending commit phase (0: default)
+ *   the raycast:
+ *     "raycast_mode" (VH_RAYCAST_DDA | VH_RAYCAST_FIXED_STEP), "raycast_beam" (0 | 1 | 2 | 3 = by the view, default)
+ *   formats / test hooks:
+ *     "packet_format" (VH_PACKET_F32 / VH_PACKET_U16, below), "cand_capacity" (a smaller candidate list: vh_counters.cand_overflow)
+ * Variants that were measured and lost (the persistent walk, 8 entries per lane in the frame's walk, the generic build where a
+ * lean one exists, the raycast as three launches, 16x4 ray patches, LDS staging of the TSDF update and of the raycast's
+ * blocks ...) are not in the library: DESIGN_LOG.md names the commit that last held each. */
 int vh_set_option(vh_context *ctx, const char *name, int value);
 int vh_set_profiling(vh_context *ctx, int enabled);
 int vh_get_kernel_times(vh_context *ctx, vh_kernel_times *out, int reset);  /* synchronises */

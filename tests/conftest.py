@@ -59,6 +59,42 @@ def rccl_rig(torch_cuda):
     return True
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _room_frames_rendered_once():
+    """The synthetic room frames of the tests (synth.render_room_verts) cost ~1 s each at 640x480 on the host, and the same few
+    dozen (pose, size) pairs are rendered by test after test: on a GPU box they are ray-cast on the GPU (both sides of a
+    parity test are handed the same array, so where it was computed is immaterial) and every frame is kept for the session.
+    Without a GPU (the `-m "not gpu"` run) only the memo applies."""
+    from collections import OrderedDict
+
+    import torch
+
+    from voxelhashing_demo_amd import synth
+    plain = synth.render_room_verts
+    on_gpu = torch.cuda.is_available()
+    memo, limit = OrderedDict(), 1 << 30            # bytes of frames kept
+
+    def render(pose, width=640, height=480, prims=None, device="cpu"):
+        if str(device) != "cpu":
+            return plain(pose, width, height, prims, device)
+        prims = synth.room_primitives() if prims is None else prims
+        key = (np.asarray(pose, np.float32).tobytes(), int(width), int(height),
+               tuple((k, np.asarray(c, np.float64).tobytes(), np.asarray(sz, np.float64).tobytes()) for k, c, sz in prims))
+        hit = memo.get(key)
+        if hit is None:
+            hit = plain(pose, width, height, prims, "cuda").cpu() if on_gpu else plain(pose, width, height, prims, "cpu")
+            memo[key] = hit
+            while sum(t.numel() * 4 for t in memo.values()) > limit and len(memo) > 1:
+                memo.popitem(last=False)
+        else:
+            memo.move_to_end(key)
+        return hit.clone()
+
+    synth.render_room_verts = render
+    yield
+    synth.render_room_verts = plain
+
+
 def entries_as_set(entries):
     """{(x,y,z)} of a VoxelEntry array."""
     return set(map(tuple, np.asarray(entries["pos"]).reshape(-1, 3).tolist()))

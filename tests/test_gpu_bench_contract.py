@@ -78,7 +78,7 @@ def test_sensor_fed_workload_runs_its_legs(torch_cuda):
     """C3 / C4table / C5table keep uint16 sensor images resident; the legs that hand vertex maps to
     vh_preprocess, ICP or the oracle must render their own instead of indexing the sensor tensor."""
     p = subprocess.run([sys.executable, "bench.py", "--workload", "C3", "--frames", "6", "--steps", "2", "--warmup", "1",
-                        "--legs", "sensor,raycast,next,loop,cpu", "--cpu-frames", "2", "--raycast-steps", "3"],
+                        "--legs", "sensor,raycast,next,cpu", "--cpu-frames", "2", "--raycast-steps", "3"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     rec = _line(p.stdout)

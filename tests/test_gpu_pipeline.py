@@ -38,25 +38,24 @@ def test_batches_with_the_occupancy_index_walk(oracle, vh, torch_cuda, chunk):
 
 @pytest.mark.parametrize("walk_nt", [0, 1])
 def test_walk_free_frame_with_a_launch_tile_per_wave(oracle, vh, torch_cuda, walk_nt):
-    """Option "claim_wave_tiles" 1: the walk-free frame's claim role with a launch tile per WAVE (claim_tile_wave; lean builds
-    7 / 8, what images of more than 2400 tiles get by themselves) on a 640x480 image, whose 1200 tiles would not select it:
-    the same keys with the same ranks must reach the probes, so the table is the oracle's slot for slot."""
-    _batches_equal_oracle_frames(oracle, vh, torch_cuda, 1, 3, walk_nt, walk=4, wave_tiles=1)
+    """The walk-free frame's claim role with a launch tile per WAVE (claim_tile_wave; lean builds 7 / 8): what images of more
+    than 2400 launch tiles get -- here 1024x640 = 2560 tiles.  The same keys with the same ranks must reach the probes, so the
+    table is the oracle's slot for slot."""
+    _batches_equal_oracle_frames(oracle, vh, torch_cuda, 1, 3, walk_nt, walk=4, size=(1024, 640))
 
 
-def _batches_equal_oracle_frames(oracle, vh, torch_cuda, sem, chunk, walk_nt, walk=3, wave_tiles=None):
+def _batches_equal_oracle_frames(oracle, vh, torch_cuda, sem, chunk, walk_nt, walk=3, size=(640, 480)):
     """The sphere scene twice (frame 1 demands keys frame 0 is still inserting), then a moving camera:
     checked after every batch, whatever the batch length."""
     torch = torch_cuda
+    W, H = size
     kw = dict(numBuckets=1 << 15, numVoxelBlocks=1 << 13)
-    ot = oracle.OracleTable(oracle.default_params(**kw), 640, 480, sem)
-    gt = vh.SDFHashtable(vh.default_params(**kw), 640, 480, sem)
+    ot = oracle.OracleTable(oracle.default_params(**kw), W, H, sem)
+    gt = vh.SDFHashtable(vh.default_params(**kw), W, H, sem)
     gt.set_option("walk_nt", walk_nt)
     gt.set_option("flatten_variant", walk)
-    if wave_tiles is not None:
-        gt.set_option("claim_wave_tiles", wave_tiles)
-    sphere = synth.sphere_inside_scene()
-    frames = [(I4, sphere)] * 3 + room_frames(torch, 640, 480, (0, 1, 2, 3, 8, 9, 10))
+    sphere = synth.sphere_inside_scene(W, H)
+    frames = [(I4, sphere)] * 3 + room_frames(torch, W, H, (0, 1, 2, 3, 8, 9, 10))
     for s in range(0, len(frames), chunk):
         part = frames[s:s + chunk]
         d = [torch.from_numpy(np.ascontiguousarray(v)).cuda() for _, v in part]
@@ -174,9 +173,10 @@ def test_band_allocation_pipelined(oracle, vh, torch_cuda):
 
 
 @pytest.mark.parametrize("band", [0.0, 0.15])
-def test_generic_and_lean_builds_of_the_pipelined_launch(oracle, vh, torch_cuda, band):
-    """The pipelined launch has builds with the context's option flags folded in (the default when such a build exists)
-    and the generic one (option lean_kernels 0): the same frames through both, switched in the middle of a run."""
+def test_lean_builds_of_the_pipelined_launch_switched_in_a_run(oracle, vh, torch_cuda, band):
+    """The pipelined launch has builds with the context's option flags folded in (one per flag set that has such a build; every
+    other flag set -- overflow list, TSDF-update variants, the other bands: tests/test_gpu_overflow.py -- runs the generic
+    build): the same frames through the build without and the build with non-temporal walk loads, switched in the middle of a run."""
     torch = torch_cuda
     W, H = 320, 240
     kw = dict(numBuckets=1 << 14, numVoxelBlocks=1 << 14)
@@ -186,7 +186,7 @@ def test_generic_and_lean_builds_of_the_pipelined_launch(oracle, vh, torch_cuda,
     ot.set_alloc_band(band)
     gt.set_alloc_band(band)
     for i, (p, v) in enumerate(room_frames(torch, W, H, (0, 1, 2, 3, 4, 5, 6, 7))):
-        gt.set_option("lean_kernels", 0 if i in (2, 3, 6) else 1)        # (no flush: the pending half rides in the other build's launch)
+        gt.set_option("walk_nt", 1 if i in (2, 3, 6) else 0)             # (a change of option flushes the pending half first)
         gt.integrate(p, torch.from_numpy(v).cuda())
         ot.integrate(p, v)
         if i in (3, 7):

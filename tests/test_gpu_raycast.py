@@ -2,9 +2,7 @@
 the cooperative form (one block list per wave), the per-lane walk behind the beam front end, the per-lane walk from t_min --
 must give the oracle's bits (oracle/vh_oracle.c: vho_raycast_dda, which walks voxel by voxel and leaves absent blocks only
 through exact look-ups), depth and normals, also where the cooperative form falls back (boxes wider than two blocks, views
-with t_min = 0, several depth windows) -- and the cooperative form both as ONE launch and split into three (option
-"raycast_split": list / one (patch, block) item per wave merged by a 64-bit atomicMin per ray / resolve), whatever the size
-of the item launch's grid."""
+with t_min = 0, several depth windows)."""
 import numpy as np
 import pytest
 
@@ -31,13 +29,12 @@ def _room(oracle, vh, torch, W, H, voxel, buckets, blocks, frames):
     return ot, gt, poses
 
 
-@pytest.mark.parametrize("beam,split", [(2, 1), (2, 0), (1, 1), (0, 1), (3, 1), (3, 0)])    # (3 = chosen by the view, the default; split 1 = the default)
-def test_every_form_of_the_kernel_equals_the_oracle(oracle, vh, torch_cuda, beam, split):
+@pytest.mark.parametrize("beam", [2, 1, 0, 3])    # (3 = chosen by the view, the default)
+def test_every_form_of_the_kernel_equals_the_oracle(oracle, vh, torch_cuda, beam):
     torch = torch_cuda
     W, H = 640, 480
     ot, gt, poses = _room(oracle, vh, torch, W, H, 0.02, 1 << 18, 1 << 14, (0, 3, 6, 9, 30, 33))
     gt.set_option("raycast_beam", beam)
-    gt.set_option("raycast_split", split)
     d = torch.empty((H, W), dtype=torch.float32, device="cuda")
     n = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
     views = [(poses[3], 0.1, 5.0), (poses[20], 0.1, 5.0), (synth.yaw_pose(200.0, (0.3, 0.1, -0.4)), 0.1, 5.0),
@@ -52,15 +49,6 @@ def test_every_form_of_the_kernel_equals_the_oracle(oracle, vh, torch_cuda, beam
         gt.raycast(pose, d, t0, t1)                   # (the kernel without the normal output)
         gt.synchronize()
         assert np.array_equal(_bits(d.cpu().numpy()), _bits(od))
-        if split and beam == 2:
-            # the item launch is a grid-stride loop over the queues: one workgroup or far too many, the image is the same
-            for g in (1, 7, 65536):
-                gt.set_option("raycast_items_grid", g)
-                d.zero_()
-                gt.raycast(pose, d, t0, t1)
-                gt.synchronize()
-                assert np.array_equal(_bits(d.cpu().numpy()), _bits(od)), (g, t0, t1)
-            gt.set_option("raycast_items_grid", 0)
     assert (od > 0).mean() > 0.3
     gt.close()
     ot.close()
@@ -79,14 +67,13 @@ def test_small_voxels_wide_beams_and_odd_image_sizes(oracle, vh, torch_cuda):
         n = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
         for pose in (poses[4], poses[15]):
             od, on = ot.raycast(pose, 0.1, 5.0, normals=True)
-            for beam, split in ((3, 1), (2, 1), (2, 0)):      # (forced cooperative form: the fall-back inside the list launch)
+            for beam in (3, 2):      # (forced cooperative form: the fall-back inside the launch)
                 gt.set_option("raycast_beam", beam)
-                gt.set_option("raycast_split", split)
                 d.fill_(-1.0)
                 n.fill_(-1.0)
                 gt.raycast_normals(pose, d, n, 0.1, 5.0)
                 gt.synchronize()
-                assert np.array_equal(_bits(d.cpu().numpy()), _bits(od)) and np.array_equal(_bits(n.cpu().numpy()), _bits(on)), (W, beam, split)
+                assert np.array_equal(_bits(d.cpu().numpy()), _bits(od)) and np.array_equal(_bits(n.cpu().numpy()), _bits(on)), (W, beam)
         assert (od > 0).mean() > 0.2
         gt.close()
         ot.close()

@@ -88,10 +88,8 @@ def test_random_call_sequences(oracle, vh, torch_cuda, tmp_path, seed, sem):
             ot.delete_blocks([])                                        # a loaded model has no compact list yet
         elif op == "option":
             gt.set_option("fused_frame", int(rng.randint(2)))
-            gt.set_option("flatten_variant", int(rng.choice([3, 4, 5])))
+            gt.set_option("flatten_variant", int(rng.choice([3, 4])))
             gt.set_option("walk_nt", int(rng.randint(2)))              # (on by default only beyond 256 MiB of table)
-            gt.set_option("claim_span", int(rng.choice([0, 1, 37, 100])))   # where the claim tiles sit in the grid
-            gt.set_option("walk_entries", int(rng.choice([4, 8])))     # (4 by default only beyond 256 MiB of table)
         elif op == "band":
             b = float(rng.choice([0.0, 0.1]))
             ot.set_alloc_band(b)

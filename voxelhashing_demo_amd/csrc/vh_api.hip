@@ -81,25 +81,17 @@ struct vh_context {
     uint64_t profiledFrames = 0;
     vh_kernel_times times{};
     int integrateGrid = 2048;
-    int persistentBlocks = 2048;   // workgroups of the persistent walk (flatten_variant 5)
-    int raycastPatch = 1;          // pixels of a raycast wave: 1 = 8x8 square, 0 = 16x4 rows
-    int raycastXcd = 1;            // tiles renumbered so that each XCD (own L2) renders a contiguous part of the image
     void *raycastStamps = nullptr; // diagnostics: device buffer of 4 uint64 per wave (vh_debug_set_raycast_stamps)
     int raycastBeam = 3;           // DDA: 2 = cooperative form (one block list per wave), 1 = per-lane walk behind the beam front end, 0 = per-lane walk,
                                    // 3 = by the view: cooperative when 64 half-block slabs span [t_min, t_max], else 1 (option "raycast_beam")
     int raycastMode = VH_RAYCAST_DDA;   // option "raycast_mode": voxel DDA (raycastSDF.frag:121-177) or the fixed-step march
-    int raycastSplit = 0;          // option "raycast_split": the cooperative form as three launches (list / walk one (patch, block) item per wave / resolve); measured slower, off
-    int raycastItemsGrid = 0;      // option "raycast_items_grid": workgroups of the item launch (0: by the image)
-    RaycastSplit rcSplit{};        // the split form's buffers, allocated at the first such raycast
-    uint32_t rcSplitPatches = 0;   // patches they were sized for
     int packetFormat = VH_PACKET_F32;   // what vh_integrate_packets / vh_apply_frames_batch read
     int fusedFrame = 1;            // vh_integrate as two launches (0: the four step kernels)
     int commitBlocks = 128;        // workgroups serving candidates in the fused second launch
     int fusedParity = 0;           // which of the two per-frame counter sets the next fused frame uses
     bool compactArmed = false;     // alloc_commit has zeroed the compact counter and no flatten ran since
-    // WalkKind: 3 = strided ballot walk (default), 4 = occupancy index (not the reference walk),
-    // 5 = persistent prefetching walk.  Round-1 A/B of the fused frame (launch 1 + launch 2, us):
-    // C2  3: 17.2 + 5.1, 5: 17.7, 4: 6.4 + 5.3; C3  3: 88 + 22, 4: 43 + 19.
+    // WalkKind (option "flatten_variant"): 3 = the reference's walk over every VoxelEntry (flattenKernel, VoxelUtils.cu:719-749),
+    // 4 = the walk over the bucket-occupancy bitmap and the non-empty buckets (same compact set, 2-11 x the frames/s)
     int flattenVariant = 3;
     uint32_t candAllocated = 0;    // records the candidate buffer holds (dp.candCapacity <= this)
     uint32_t allocEpoch = 0;       // lock epoch (epochTotal) of the last allocBlocks (overflow list: one per epoch)
@@ -107,30 +99,25 @@ struct vh_context {
     // pipelined frames (option "pipeline", vh_integrate_batch; vh_frame.hip)
     float *fusedPlane = nullptr;   // packed camera-z plane launch 1 of the two-launch frame leaves for launch 2 (large images)
     int pipeline = 0;
-    int pipeIntegrateGrid = 512;   // workgroups of the deferred TSDF update inside a pipelined launch (4 blocks each per pass)
+    int pipeIntegrateGrid = 512;   // workgroups of the deferred TSDF update inside a pipelined launch
     bool pipePending = false;      // the commit + TSDF update of the last frame are still to be launched
     FrameParams pipeFp;            // that frame's parameters
     int32_t pipeDoneTag = 0;       // ... and its tag (lock epochs since creation): what its commit phase publishes (overflow list)
     int pipeSet = 0;               // counter set its claim / walk filled
     int pipeParity = 0;            // which of the two buffer sets it used
-    int claimSpanPct = 0;         // option "claim_span": share of the stream workgroups the claim tiles are spread over
     int pipeSensor = 0;            // its private depth copy: 0 = float camera-z plane, 1 = uint16 sensor image
     float pipeK[4] = {0, 0, 0, 0}; // K_inv row 2 and the depth unit of a sensor frame
     unsigned long long *claimBuf[2] = {nullptr, nullptr};
     int4 *candBuf[2] = {nullptr, nullptr};
     VoxelEntry *compactBuf[2] = {nullptr, nullptr};
     uint32_t *claimFilter = nullptr;       // pipelined frames: three claim filters of kPendFilterWords words (vh_alloc.hip: pend_maybe)
-    int claimFilterOn = 1;                 // option "claim_filter": readers of the pending frame's claim words test the filter first
     uint32_t *maskBuf2 = nullptr;          // pipelined multi-camera frames: the camera masks of the second compact buffer
-    int multiWalkEntries = 0;              // option "multi_walk_entries": entries per lane of the multi-camera pipelined walk (0: by shard size)
     int genFramesPerLaunch = 4;            // option "gen_frames_per_launch": frames of a batch one key-generation launch takes (1..8)
     uint32_t spinLimit = 0;                // option "spin_limit": polls a workgroup of a serialised pipelined launch waits for the pending commit phase (0: kSpinLimitDefault)
     int pipelineOverflow = 1;              // option "pipeline_overflow": one-launch (serialised) frames with the overflow list: 0 never, 1 by the launch's size (default), 2 always
     bool serialQueued = false;             // a serialised launch has been queued since the host last looked at kSpinTimeouts (check_spin_timeouts)
     uint32_t spinSeen = 0;                 // ... and what the counter read then
     bool serialFallback = false;           // a serialised launch has timed out (vh_counters.spin_timeouts): overflow-list frames take two launches from now on
-    int claimWaveTiles = 2;                // option "claim_wave_tiles": 0 never, 1 always, 2 by image size (walk-free lean builds; vh_api_frame.hip)
-    int leanKernels = 1;                   // option "lean_kernels": builds of the pipelined launch with the option flags folded in (A/B switch)
     int debugSkipRoles = 0;                // diagnostics: roles of the pipelined launch that return at once (timing only; the model is wrong)
     int pipelineShards = 1;                // option "pipeline_shards": vh_apply_frames_batch runs a batch of B multi-camera frames as B + 1 launches (1) or B (2: the last frame's half stays pending across calls)
     MultiPending multiPend;                // the multi-camera frame whose commit + TSDF update have not been launched yet
@@ -312,12 +299,6 @@ static int free_buffers(vh_context *c)
     if (c->viewLists) (void)hipFree(c->viewLists);
     if (c->blockList) (void)hipFree(c->blockList);
     c->blockList = nullptr;
-    if (c->rcSplit.state) (void)hipFree(c->rcSplit.state);
-    if (c->rcSplit.best) (void)hipFree(c->rcSplit.best);
-    if (c->rcSplit.items) (void)hipFree(c->rcSplit.items);
-    if (c->rcSplit.counts) (void)hipFree(c->rcSplit.counts);
-    c->rcSplit = RaycastSplit{};
-    c->rcSplitPatches = 0;
     c->viewLists = nullptr;
     c->viewListsSize = 0;
     c->dp = DevPtrs{};
@@ -348,7 +329,6 @@ static int create_impl(const vh_config *cfg, uint32_t lo, uint32_t hi, vh_contex
     if (dev >= ndev) return fail(VH_ERR_INVALID_ARGUMENT, "device ordinal out of range");
 
     vh_context *c = new vh_context();
-    if (const char *e = std::getenv("VOXELHASH_LEAN_KERNELS")) c->leanKernels = std::atoi(e) != 0;      // A/B switch (also option "lean_kernels")
     c->device = dev;
     DeviceGuard guard(dev);
     if (!guard.ok) { delete c; return fail(VH_ERR_NO_DEVICE, "hipSetDevice"); }

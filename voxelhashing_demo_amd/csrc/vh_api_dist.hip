@@ -885,8 +885,6 @@ static int dist_raycast_impl(vh_dist *d, const float pose[16], float t_min, floa
     d->view->rc_fx = d->shard->rc_fx; d->view->rc_fy = d->shard->rc_fy; d->view->rc_cx = d->shard->rc_cx; d->view->rc_cy = d->shard->rc_cy;
     d->view->raycastMode = d->shard->raycastMode;
     d->view->raycastBeam = d->shard->raycastBeam;
-    d->view->raycastPatch = d->shard->raycastPatch;
-    d->view->raycastXcd = d->shard->raycastXcd;
     d->view->fp.flags = (d->view->fp.flags & ~kFlagOverflow) | (d->shard->fp.flags & kFlagOverflow);
     d->view->fp.listSize = d->shard->fp.listSize;
     if (d->viewCapacity < capacity) {

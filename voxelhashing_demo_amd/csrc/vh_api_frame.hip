@@ -71,39 +71,6 @@ static int launch(vh_context *c, int phase, K kernel, dim3 grid, dim3 block, Arg
     return VH_OK;
 }
 
-// Several launches timed as ONE span (the split raycast): the start event rides on the first launch, the stop event on the
-// last, so the span includes the gaps between them -- what a caller of the entry point waits for.  pos: 0 first, 1 middle, 2 last.
-template <typename K, typename... Args>
-static int launch_span(vh_context *c, int phase, int pos, TimedLaunch &span, K kernel, dim3 grid, dim3 block, Args... args)
-{
-    if (!c->profiling) {
-        hipLaunchKernelGGL(kernel, grid, block, 0, c->stream, args...);
-        return VH_OK;
-    }
-    if (pos == 0) {
-        if (c->timed.size() >= kMaxTimedLaunches) {
-            const int rc = accumulate_times(c);
-            if (rc != VH_OK) return rc;
-        }
-        span = TimedLaunch{phase, nullptr, nullptr};
-        if (!c->eventPool.empty()) {
-            span.start = c->eventPool.back().first;
-            span.stop = c->eventPool.back().second;
-            c->eventPool.pop_back();
-        } else {
-            VH_HIP(hipEventCreate(&span.start));
-            const hipError_t e = hipEventCreate(&span.stop);
-            if (e != hipSuccess) {
-                (void)hipEventDestroy(span.start);
-                return fail(VH_ERR_HIP, "hipEventCreate", e);
-            }
-        }
-    }
-    hipExtLaunchKernelGGL(kernel, grid, block, 0, c->stream, pos == 0 ? span.start : nullptr, pos == 2 ? span.stop : nullptr, 0, args...);
-    if (pos == 2) c->timed.push_back(span);
-    return VH_OK;
-}
-
 template <class In>
 static int launch_alloc(vh_context *c, const In &in)
 {
@@ -119,9 +86,6 @@ static uint32_t walk_blocks(const vh_context *c)
 {
     if (c->flattenVariant == kWalkIndexed)       // one lane per 32-bucket word of the occupancy bitmap
         return (uint32_t)grid_for(((size_t)c->ownedBuckets + 31) / 32, kFlattenThreads * kIndexWords);
-    if (c->flattenVariant == kWalkPersistent)    // resident workgroups striding over the tiles
-        return std::min<uint32_t>((uint32_t)grid_for(c->numEntries, kFlattenThreads * kEntriesPerLane),
-                                  (uint32_t)c->persistentBlocks);
     return (uint32_t)grid_for(c->numEntries, kFlattenThreads * ((c->fp.flags & kFlagWalkShort) ? kEntriesPerLaneShort : kEntriesPerLane));
 }
 
@@ -130,9 +94,6 @@ static int launch_flatten(vh_context *c)
     const dim3 grid(walk_blocks(c));
     if (c->flattenVariant == kWalkIndexed)
         return launch(c, kPhaseFlatten, flatten_kernel<kWalkIndexed>, grid, dim3(kFlattenThreads), c->fp, c->dp,
-                      (uint32_t)c->numEntries);
-    if (c->flattenVariant == kWalkPersistent)
-        return launch(c, kPhaseFlatten, flatten_kernel<kWalkPersistent>, grid, dim3(kFlattenThreads), c->fp, c->dp,
                       (uint32_t)c->numEntries);
     return launch(c, kPhaseFlatten, flatten_kernel<kWalkStridedBallot>, grid, dim3(kFlattenThreads), c->fp, c->dp,
                   (uint32_t)c->numEntries);
@@ -202,19 +163,16 @@ extern "C" int vh_integrate_depth_map(vh_context *c, const vh_float4 *verts)
 // squeezing them further starves the stream.  In-process A/B of the pipelined launch (4 entries per lane in
 // the walk): C2 19.5 us uniform, 18.6 by this rule (77 %), 18.9 at 65 % or 85 %; C2 with band allocation (a
 // claim tile then runs ~12 us) 29.0 uniform, 26.2 at 70 %, 24.3 at 50 %, 24.6 at 40 %, 26.6 at 30 %; C3, a
-// 72 us launch: 72.5 uniform, 72.2 by the rule (94 %).  Option "claim_span": percent, 0 = this rule.
+// 72 us launch: 72.5 uniform, 72.2 by the rule (94 %).
 static uint32_t claim_span(const vh_context *c, uint32_t claimBlocks, uint32_t walkBlocks)
 {
     const uint32_t total = claimBlocks + walkBlocks;
-    double share = c->claimSpanPct / 100.0;
-    if (c->claimSpanPct == 0) {
-        const double walk_us = (double)c->numEntries * sizeof(VoxelEntry) / 6.0e6;     // bytes / (6 TB/s) in us
-        // with band allocation a pixel demands several keys: ~2 us more per sample
-        double chain_us = 4.0;
-        if (c->fp.allocBand > 0.0f)
-            chain_us += 2.0 * std::min(8.0, 2.0 * std::ceil((double)c->fp.allocBand / (4.0 * c->fp.voxelSize)));
-        share = std::min(1.0, std::max(0.5, 1.0 - chain_us / std::max(walk_us, 1.0)));
-    }
+    const double walk_us = (double)c->numEntries * sizeof(VoxelEntry) / 6.0e6;     // bytes / (6 TB/s) in us
+    // with band allocation a pixel demands several keys: ~2 us more per sample
+    double chain_us = 4.0;
+    if (c->fp.allocBand > 0.0f)
+        chain_us += 2.0 * std::min(8.0, 2.0 * std::ceil((double)c->fp.allocBand / (4.0 * c->fp.voxelSize)));
+    const double share = std::min(1.0, std::max(0.5, 1.0 - chain_us / std::max(walk_us, 1.0)));
     // (strictly more workgroups than claim tiles whenever there is a walk: claim_ratio below must stay < 2^32)
     return std::min(total, std::max<uint32_t>(claimBlocks + (walkBlocks ? 1u : 0u), (uint32_t)(share * total)));
 }
@@ -318,7 +276,7 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     const bool serial = (c->fp.flags & kFlagOverflow) != 0u;
     // the lean builds (vh_frame.hip): no band, no list, the reference's walk, and both frames' option flags exactly the walk's
     int lean = 0;
-    if (!serial && c->leanKernels) {      // (with a band: the ray band only -- kFlagBandDda is a flag like the others)
+    if (!serial) {                        // (with a band: the ray band only -- kFlagBandDda is a flag like the others)
         const uint32_t fo = hasOld ? c->pipeFp.flags : c->fp.flags;
         if (a.walkIndexed) {                // the walk-free frame (flatten_variant 4): builds of its own, without a band
             if (!band && c->fp.flags == kFlagWalkShort && fo == kFlagWalkShort) lean = 5;
@@ -332,9 +290,8 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     // The walk-free frame of a large image: a claim workgroup takes four launch tiles, one per wave (claim_tile_wave, vh_alloc.hip:
     // a quarter of the waves, each with four pixels per lane).  C3 28.4 -> 26.7 us same box; a 640x480 frame prefers the tile per
     // workgroup (8.9 against 11.1 us: the longer chain per wave is its tail), and so does every frame under the reference's walk
-    // (C2 18.9 -> 19.9-22.7 us, C3 72.0 -> 71.5): profiles/r05_claim_wave_tile_ab.txt.  Option "claim_wave_tiles" 0 | 1 | 2 (auto).
-    a.claimPerWave = (hasNew && (lean == 5 || lean == 6) &&
-                      (c->claimWaveTiles == 1 || (c->claimWaveTiles == 2 && host_num_tiles(c) > 2400u))) ? 1u : 0u;
+    // (C2 18.9 -> 19.9-22.7 us, C3 72.0 -> 71.5): profiles/r05_claim_wave_tile_ab.txt.  Hence the size rule.
+    a.claimPerWave = (hasNew && (lean == 5 || lean == 6) && host_num_tiles(c) > 2400u) ? 1u : 0u;
     if (a.claimPerWave) lean += 2;                                // builds 7 / 8
     a.claimBlocks = !hasNew ? 0u : a.claimPerWave ? (host_num_tiles(c) + 3u) / 4u : host_num_tiles(c);
     a.commitBlocks = hasOld ? (uint32_t)c->commitBlocks : 0u;
@@ -349,9 +306,7 @@ static int launch_pipelined(vh_context *c, const In *in, int newSensor, const fl
     a.claimRatio = claim_ratio(a.claimBlocks, a.claimSpan);
     a.planeNew = (hasNew && !newSensor) ? c->planeBuf[newParity] : nullptr;
     a.rawNew = (hasNew && newSensor) ? c->rawBuf[newParity] : nullptr;
-    // (the filters rotate with the counter sets whether they are read or not, so that the option can change between frames)
     a.filter = c->claimFilter;
-    a.filterRead = c->claimFilterOn ? 1u : 0u;
     a.filtNew = kPendFilterWords * (uint32_t)setNew; a.filtOld = kPendFilterWords * (uint32_t)setOld;
     a.filtClear = kPendFilterWords * (uint32_t)((setNew + 1) % 3);
     a.doneTag = c->pipeDoneTag;
@@ -511,8 +466,6 @@ static int run_frame(vh_context *c, const In &in, const Depth &depth)
         float *plane = (size_t)c->fp.width * c->fp.height >= ((size_t)1 << 20) ? fused_plane(c, in) : nullptr;
         if (c->flattenVariant == kWalkIndexed)
             rc = launch_scan_claim<kWalkIndexed>(c, in, claimBlocks, scanBlocks, plane);
-        else if (c->flattenVariant == kWalkPersistent)
-            rc = launch_scan_claim<kWalkPersistent>(c, in, claimBlocks, scanBlocks, plane);
         else
             rc = launch_scan_claim<kWalkStridedBallot>(c, in, claimBlocks, scanBlocks, plane);
         if (rc != VH_OK) return rc;
@@ -625,15 +578,10 @@ static int raycast_impl(vh_context *c, const float pose[16], float t_min, float 
         const float q = (t_max - t_min) / fp.voxelSize;
         int nsteps = (q >= 2147483648.0f) ? 0x7fffffff : (int)q;
         nsteps += 1;
-        rc = c->raycastPatch
-                 ? launch(c, kPhaseRaycast, raycast_kernel<1>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy,
-                          c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out, c->raycastXcd)
-                 : launch(c, kPhaseRaycast, raycast_kernel<0>, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy,
-                          c->rc_cx, c->rc_cy, t_min, nsteps, d_depth_out, c->raycastXcd);
+        rc = launch(c, kPhaseRaycast, raycast_kernel, grid, dim3(256), fp, dp, c->rc_fx, c->rc_fy, c->rc_cx, c->rc_cy, t_min, nsteps,
+                    d_depth_out);
     } else {
         RaycastArgs ra;
-        ra.sp = RaycastSplit{};
-        ra.stampsItemBase = 0;
         ra.fx = c->rc_fx; ra.fy = c->rc_fy; ra.cx = c->rc_cx; ra.cy = c->rc_cy;
         ra.tMin = t_min; ra.tMax = t_max;
         float inv[16];
@@ -652,7 +600,6 @@ static int raycast_impl(vh_context *c, const float pose[16], float t_min, float 
                      (double)fp.voxelSize + 2.0;
         if (!(steps < 4194304.0)) return fail(VH_ERR_INVALID_ARGUMENT, "view too deep for the voxel size (more than 2^22 voxel steps per ray) or not finite");
         ra.budget = (int)steps;
-        ra.xcdAware = c->raycastXcd;
         // The camera centre in voxel-grid units, and the domain: inside an allocated block the kernel steps the voxel
         // coordinate as a float (exact below 2^24), so a view that can reach |coordinate| >= 2^23 is refused.
         double reach = 0.0;
@@ -675,59 +622,15 @@ static int raycast_impl(vh_context *c, const float pose[16], float t_min, float 
         ra.beam = t_min > 0.0f ? beam : 0;
         float4 *nrm = reinterpret_cast<float4 *>(d_normals_out);
         const dim3 block(64 * kDdaBlockWaves);
-        if (kDdaBlockWaves == 1)
-            grid = c->raycastPatch ? dim3((fp.width + 7) / 8, (fp.height + 7) / 8) : dim3((fp.width + 15) / 16, (fp.height + 3) / 4);
-        // The split form (option "raycast_split", the default where the cooperative form runs): list / items / resolve.
-        const uint32_t nTiles = grid.x * grid.y, nPatches = nTiles * 4u;
-        const uint32_t segCap = 4u * ((nTiles + kRcShards - 1) / kRcShards);
-        const bool split = ra.beam == 2 && c->raycastSplit && kDdaBlockWaves == 4 &&
-                           (uint64_t)kRcSegs * segCap <= (1u << 21);
-        if (split) {
-            if (c->rcSplitPatches < nPatches) {          // first use (or a larger image): allocate, counters zero
-                VH_HIP(hipStreamSynchronize(c->stream));
-                if (c->rcSplit.state) (void)hipFree(c->rcSplit.state);
-                if (c->rcSplit.best) (void)hipFree(c->rcSplit.best);
-                if (c->rcSplit.items) (void)hipFree(c->rcSplit.items);
-                if (c->rcSplit.counts) (void)hipFree(c->rcSplit.counts);
-                c->rcSplit = RaycastSplit{};
-                c->rcSplitPatches = 0;
-                VH_HIP(hipMalloc((void **)&c->rcSplit.state, sizeof(float) * 9 * 64 * (size_t)nPatches));
-                VH_HIP(hipMalloc((void **)&c->rcSplit.best, sizeof(unsigned long long) * 64 * (size_t)nPatches));
-                VH_HIP(hipMalloc((void **)&c->rcSplit.items, sizeof(RcItem) * (size_t)kRcSegs * segCap));
-                VH_HIP(hipMalloc((void **)&c->rcSplit.counts, sizeof(uint32_t) * kRcSegs));
-                VH_HIP(hipMemsetAsync(c->rcSplit.counts, 0, sizeof(uint32_t) * kRcSegs, c->stream));
-                c->rcSplitPatches = nPatches;
-            }
-            ra.sp = c->rcSplit;
-            ra.sp.segCap = segCap;
-            ra.sp.patchesX = c->raycastPatch ? grid.x * 2u : grid.x;
-            // the item launch: a grid-stride loop over the items, so its size is a tuning parameter (any size is exact)
-            const uint32_t itemGrid = c->raycastItemsGrid > 0 ? (uint32_t)c->raycastItemsGrid : std::max<uint32_t>(nPatches * 3u / kItemWaves, 256u);
-            ra.stampsItemBase = nPatches;
-            TimedLaunch span{};
-            if (nrm)
-                rc = c->raycastPatch ? launch_span(c, kPhaseRaycast, 0, span, raycast_dda_kernel<1, true, true>, grid, block, fp, dp, ra, d_depth_out, nrm)
-                                     : launch_span(c, kPhaseRaycast, 0, span, raycast_dda_kernel<0, true, true>, grid, block, fp, dp, ra, d_depth_out, nrm);
-            else
-                rc = c->raycastPatch ? launch_span(c, kPhaseRaycast, 0, span, raycast_dda_kernel<1, false, true>, grid, block, fp, dp, ra, d_depth_out, nrm)
-                                     : launch_span(c, kPhaseRaycast, 0, span, raycast_dda_kernel<0, false, true>, grid, block, fp, dp, ra, d_depth_out, nrm);
-            if (rc == VH_OK)
-                rc = c->raycastPatch ? launch_span(c, kPhaseRaycast, 1, span, raycast_items_kernel<1>, dim3(itemGrid), dim3(64 * kItemWaves), fp, dp, ra)
-                                     : launch_span(c, kPhaseRaycast, 1, span, raycast_items_kernel<0>, dim3(itemGrid), dim3(64 * kItemWaves), fp, dp, ra);
-            if (rc == VH_OK) {
-                if (nrm)
-                    rc = c->raycastPatch ? launch_span(c, kPhaseRaycast, 2, span, raycast_resolve_kernel<1, true>, grid, block, fp, dp, ra, d_depth_out, nrm)
-                                         : launch_span(c, kPhaseRaycast, 2, span, raycast_resolve_kernel<0, true>, grid, block, fp, dp, ra, d_depth_out, nrm);
-                else
-                    rc = c->raycastPatch ? launch_span(c, kPhaseRaycast, 2, span, raycast_resolve_kernel<1, false>, grid, block, fp, dp, ra, d_depth_out, nrm)
-                                         : launch_span(c, kPhaseRaycast, 2, span, raycast_resolve_kernel<0, false>, grid, block, fp, dp, ra, d_depth_out, nrm);
-            }
-        } else if (nrm)
-            rc = c->raycastPatch ? launch(c, kPhaseRaycast, raycast_dda_kernel<1, true>, grid, block, fp, dp, ra, d_depth_out, nrm)
-                                 : launch(c, kPhaseRaycast, raycast_dda_kernel<0, true>, grid, block, fp, dp, ra, d_depth_out, nrm);
+        ra.patchesX = (fp.width + 7) / 8;
+        ra.numPatches = ra.patchesX * ((fp.height + 7) / 8);
+        ra.groups = (ra.numPatches + kDdaBlockWaves - 1) / kDdaBlockWaves;
+        if (ra.beam == 2)       // the cooperative form: a workgroup per group of four far-apart patches (vh_raycast_coop.hip)
+            rc = nrm ? launch(c, kPhaseRaycast, raycast_coop_kernel<true>, dim3((unsigned)ra.groups), block, fp, dp, ra, d_depth_out, nrm)
+                     : launch(c, kPhaseRaycast, raycast_coop_kernel<false>, dim3((unsigned)ra.groups), block, fp, dp, ra, d_depth_out, nrm);
         else
-            rc = c->raycastPatch ? launch(c, kPhaseRaycast, raycast_dda_kernel<1, false>, grid, block, fp, dp, ra, d_depth_out, nrm)
-                                 : launch(c, kPhaseRaycast, raycast_dda_kernel<0, false>, grid, block, fp, dp, ra, d_depth_out, nrm);
+            rc = nrm ? launch(c, kPhaseRaycast, raycast_dda_kernel<true>, grid, block, fp, dp, ra, d_depth_out, nrm)
+                     : launch(c, kPhaseRaycast, raycast_dda_kernel<false>, grid, block, fp, dp, ra, d_depth_out, nrm);
     }
     if (rc != VH_OK) return rc;
     VH_HIP(hipGetLastError());

@@ -403,8 +403,8 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     if (c) { DeviceGuard fguard(c->device); const int frc = flush_pending(c); if (frc != VH_OK) return frc; }
     if (!c || !name) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     if (std::strcmp(name, "flatten_variant") == 0) {
-        if (value != kWalkStridedBallot && value != kWalkIndexed && value != kWalkPersistent)
-            return fail(VH_ERR_INVALID_ARGUMENT, "flatten_variant: 3 (walk), 4 (occupancy index) or 5 (persistent walk)");
+        if (value != kWalkStridedBallot && value != kWalkIndexed)
+            return fail(VH_ERR_INVALID_ARGUMENT, "flatten_variant: 3 (the reference's walk) or 4 (occupancy index)");
         c->flattenVariant = value;
         return VH_OK;
     }
@@ -412,12 +412,6 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
         c->fp.flags = value ? (c->fp.flags | kFlagWalkNt) : (c->fp.flags & ~kFlagWalkNt);
         return VH_OK;
     }
-    if (std::strcmp(name, "claim_span") == 0 && value >= 0 && value <= 100) { c->claimSpanPct = value; return VH_OK; }
-    if (std::strcmp(name, "walk_entries") == 0 && (value == kEntriesPerLaneShort || value == kEntriesPerLane)) {
-        c->fp.flags = value == kEntriesPerLaneShort ? (c->fp.flags | kFlagWalkShort) : (c->fp.flags & ~kFlagWalkShort);
-        return VH_OK;
-    }
-    if (std::strcmp(name, "pipe_integrate_grid") == 0 && value > 0) { c->pipeIntegrateGrid = value; return VH_OK; }
 #ifdef VH_DEBUG_SKIP_ROLES      // diagnostics builds only (make EXTRA=-DVH_DEBUG_SKIP_ROLES): the check costs the product launch a scalar load per workgroup
     if (std::strcmp(name, "debug_skip_roles") == 0 && value >= 0 && value < 32) {
         c->debugSkipRoles = value;
@@ -426,8 +420,6 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
         return VH_OK;
     }
 #endif
-    if (std::strcmp(name, "lean_kernels") == 0) { c->leanKernels = value != 0; return VH_OK; }
-    if (std::strcmp(name, "claim_wave_tiles") == 0 && value >= 0 && value <= 2) { c->claimWaveTiles = value; return VH_OK; }
     if (std::strcmp(name, "spin_limit") == 0 && value >= 0) { c->spinLimit = (uint32_t)value; return VH_OK; }
     if (std::strcmp(name, "pipeline_overflow") == 0 && value >= 0 && value <= 2) {
         DeviceGuard g(c->device);
@@ -437,7 +429,6 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
         return VH_OK;
     }
     if (std::strcmp(name, "gen_frames_per_launch") == 0 && value >= 1 && value <= kGenBatch) { c->genFramesPerLaunch = value; return VH_OK; }
-    if (std::strcmp(name, "multi_walk_entries") == 0 && (value == 0 || value == kEntriesPerLaneShort || value == kEntriesPerLane)) { c->multiWalkEntries = value; return VH_OK; }
     if (std::strcmp(name, "pipeline_shards") == 0) {
         if (value < 0 || value > 2) return fail(VH_ERR_INVALID_ARGUMENT, "pipeline_shards: 0, 1 or 2");
         if (value < 2) { DeviceGuard g(c->device); const int frc = flush_multi_pending(c); if (frc != VH_OK) return frc; }
@@ -476,12 +467,7 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
     }
     if (std::strcmp(name, "integrate_grid") == 0 && value > 0) { c->integrateGrid = value; return VH_OK; }
     if (std::strcmp(name, "fused_frame") == 0) { c->fusedFrame = value; return VH_OK; }
-    if (std::strcmp(name, "raycast_patch") == 0) { c->raycastPatch = value; return VH_OK; }
-    if (std::strcmp(name, "raycast_xcd") == 0) { c->raycastXcd = value; return VH_OK; }
     if (std::strcmp(name, "raycast_beam") == 0 && value >= 0 && value <= 3) { c->raycastBeam = value; return VH_OK; }
-    if (std::strcmp(name, "claim_filter") == 0 && (value == 0 || value == 1)) { c->claimFilterOn = value; return VH_OK; }
-    if (std::strcmp(name, "raycast_split") == 0 && (value == 0 || value == 1)) { c->raycastSplit = value; return VH_OK; }
-    if (std::strcmp(name, "raycast_items_grid") == 0 && value >= 0) { c->raycastItemsGrid = value; return VH_OK; }
     if (std::strcmp(name, "raycast_mode") == 0 && (value == VH_RAYCAST_DDA || value == VH_RAYCAST_FIXED_STEP)) {
         c->raycastMode = value;
         return VH_OK;
@@ -490,7 +476,6 @@ extern "C" int vh_set_option(vh_context *c, const char *name, int value)
         c->packetFormat = value;
         return VH_OK;
     }
-    if (std::strcmp(name, "persistent_blocks") == 0 && value > 0) { c->persistentBlocks = value; return VH_OK; }
     if (std::strcmp(name, "commit_blocks") == 0 && value > 0) { c->commitBlocks = value; return VH_OK; }
     return fail(VH_ERR_INVALID_ARGUMENT, "unknown option");
 }

@@ -403,9 +403,8 @@ static int launch_multi_pipelined(vh_context *c, const MultiBatch *mb, int b, co
         uint32_t parts = (uint32_t)grid_for((size_t)mb->capacity, 256 * 4);
         if (parts < 1) parts = 1;
         a.claimBlocks = (uint32_t)mb->numBins * parts;
-        // option "multi_walk_entries": 4 | 8 | 0 = by the shard's size (4 from 32 MB of entries on)
-        a.walkShort = c->multiWalkEntries ? (c->multiWalkEntries == kEntriesPerLaneShort ? 1u : 0u)
-                                          : (c->numEntries * sizeof(VoxelEntry) >= ((size_t)32 << 20) ? 1u : 0u);
+        // entries per lane of the multi-camera walk by the shard's size: 4 from 32 MB of entries on, else 8
+        a.walkShort = c->numEntries * sizeof(VoxelEntry) >= ((size_t)32 << 20) ? 1u : 0u;
         a.walkBlocks = (uint32_t)grid_for(c->numEntries, kFlattenThreads * (a.walkShort ? kEntriesPerLaneShort : kEntriesPerLane));
         // the walk-free multi-camera frame (flatten_variant 4; not with the overflow list: holes and chains take the reference's walk)
         a.walkIndexed = (c->flattenVariant == kWalkIndexed && !(c->fp.flags & kFlagOverflow)) ? 1u : 0u;

@@ -154,9 +154,8 @@ struct PipeArgs {
     uint32_t claimSpan, claimRatio;        // claim tiles are interleaved with the first claimSpan - claimBlocks walk tiles
     float *planeNew;                       // private depth copies written by claim(new) ...
     uint16_t *rawNew;
-    uint32_t *filter;                      // claim filters (vh_alloc.hip: pend_maybe), three of kPendFilterWords words, or nullptr (option "claim_filter" 0)
+    uint32_t *filter;                      // claim filters (vh_alloc.hip: pend_maybe), three of kPendFilterWords words
     uint32_t filtNew, filtOld, filtClear;  // word offsets of the filter the new frame fills / the pending frame filled / this launch clears
-    uint32_t filterRead;                   // option "claim_filter": the readers consult it (it is filled and cleared either way)
     int32_t doneTag;                       // overflow list: the pending frame's tag (lock epochs since creation), published when its commit phase ends
     uint32_t spinLimit;                    // ... and how many polls a workgroup waits for it (wait_commit_done)
 #ifdef VH_DEBUG_SKIP_ROLES
@@ -262,7 +261,7 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
         }
         const Pending pend{a.hasOld && !serial ? dpOld.claim : nullptr, dpOld.candidates, fpOld.epoch, live,
                            serial ? -1 : kPipeWinners + a.setNew,
-                           a.filter && a.filterRead && a.hasOld && !serial ? a.filter + a.filtOld : nullptr,
+                           a.filter && a.hasOld && !serial ? a.filter + a.filtOld : nullptr,
                            a.filter && !serial ? a.filter + a.filtNew : nullptr};
         if (role == 2u) {
             __builtin_amdgcn_s_setprio(3);
@@ -299,8 +298,7 @@ __device__ __forceinline__ void frame_pipelined(const FrameParams &fpNew, const 
     // the filter frame i+2 will fill: cleared here (nobody reads or writes it during this launch); a flush launch clears
     // the one a new frame would have filled as well, so that a run always starts on an empty one
     if (role == 0u && a.filter) {
-        const uint32_t t = index * 256u + threadIdx.x;
-        if (t < kPendFilterWords) {
+        for (uint32_t t = index * 256u + threadIdx.x; t < kPendFilterWords; t += a.commitBlocks * 256u) {
             a.filter[a.filtClear + t] = 0u;
             if (!a.hasNew) a.filter[a.filtNew + t] = 0u;
         }

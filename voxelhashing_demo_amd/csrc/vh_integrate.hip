@@ -99,14 +99,11 @@ __device__ __forceinline__ void integrate_block(const FrameParams &fp, const Dev
 // voxels per lane in a row make the dependent chain longer than the extra loads in flight shorten it);
 // software pipelining over the list, voxels of block k+1 and entry of block k+2 in flight while block k
 // is updated (14.2 us against 13.6 without it: the workgroups of a 2048-4096 grid already overlap each
-// other's chains); staging the 4 KiB through LDS as a prefetch buffer (LDS-DMA, round 3: VH_INTEGRATE_LDS below)
-// was slower in every frame form: every voxel is read once and written once by the same lane.
-#ifndef VH_INTEGRATE_LDS
-#define VH_INTEGRATE_LDS 0      // 1: block k+1's 4 KiB prefetched into LDS by LDS-DMA while block k is updated.  Measured (round 3,
-                                // same box, parity-green): C3 launch 2 13.4 vs 11.6 us without, pipelined C3 71.4 vs 70.3,
-                                // loaded C2 26.2 vs 25.6, C2 19.6 vs 19.3; round 5, the walk-free frames: C3 29.4 vs 27.3 us, C5table 27.5 vs 25.8,
-                                // C2 9.1 vs 8.9 (profiles/r05_index_integrate_grid.txt) -- off
-#endif
+// other's chains); staging the 4 KiB through LDS as a prefetch buffer (global_load_lds_dwordx4, block k+1 into a double
+// buffer while block k is updated; rounds 3 and 5) was slower in every frame form -- C3 launch 2 13.4 vs 11.6 us, pipelined C3
+// 71.4 vs 70.3, loaded C2 26.2 vs 25.6, walk-free C3 29.4 vs 27.3: every voxel is read once and written once by the same
+// lane, so there is no reuse for LDS to serve (north_star's "one 8^3 block staged into LDS per workgroup" is therefore an
+// accepted, measured deviation: README.md; the code is in git history, DESIGN_LOG.md names the commit).
 template <class Depth>
 // countB > 0: the list has two ends (CompactOut, vh_walk.hip): entries 0 .. count-1 from the front, countB more
 // from the back of the numEntries-entry buffer
@@ -114,46 +111,8 @@ __device__ __forceinline__ void integrate_list(const FrameParams &fp, const DevP
                                                int count, int first, int stride, const Depth &src, int countB = 0,
                                                uint32_t numEntries = 0)
 {
-#if VH_INTEGRATE_LDS
-    // The north star's "8^3 block staged into LDS", in the one form that can pay without intra-block reuse: as a prefetch
-    // buffer.  global_load_lds_dwordx4 moves the NEXT block of this workgroup (16 bytes per lane, each wave its own KiB)
-    // into the other half of a double buffer while the current block is updated from the first; the entry after next is
-    // in flight too, so the DMA's address never waits.  Each lane reads back what its own wave's DMA wrote: no barrier.
-    __shared__ float4 stage[2][256];
-    const int total = count + countB;
-    if (first >= total) return;
-    const int wave = threadIdx.x >> 6;
-    auto entry_at = [&](int k) { return k < count ? list[k] : list[numEntries - 1u - (uint32_t)(k - count)]; };
-    auto issue = [&](const VoxelEntry &en, int b) {
-        const float4 *g = reinterpret_cast<const float4 *>(dp.blocks + (size_t)en.ptr) + threadIdx.x;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                         (__attribute__((address_space(3))) void *)&stage[b][wave * 64], 16, 0, 0);
-    };
-    VoxelEntry e = entry_at(first), en = e;
-    issue(e, 0);
-    if (first + stride < total) en = entry_at(first + stride);
-    int b = 0;
-    for (int k = first; k < total; k += stride) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this block's DMA has landed, the next entry is here
-        float4 v = stage[b][threadIdx.x];
-        const VoxelEntry cur = e;
-        e = en;
-        if (k + stride < total) {
-            issue(e, b ^ 1);
-            if (k + 2 * stride < total) en = entry_at(k + 2 * stride);
-        }
-        const int lin = 2 * (int)threadIdx.x;
-        const int tx = lin & 7, ty = (lin >> 3) & 7, tz = lin >> 6;
-        const int bx = (int)((uint32_t)cur.pos[0] * 8u) + tx, by = (int)((uint32_t)cur.pos[1] * 8u) + ty, bz = (int)((uint32_t)cur.pos[2] * 8u) + tz;
-        const bool u0 = tsdf_update(fp, fp.Tinv, src, bx, by, bz, v.x, v.y);
-        const bool u1 = tsdf_update(fp, fp.Tinv, src, bx + 1, by, bz, v.z, v.w);
-        if (u0 || u1) *reinterpret_cast<float4 *>(dp.blocks + (size_t)cur.ptr + lin) = v;
-        b ^= 1;
-    }
-#else
     for (int k = first; k < count + countB; k += stride)
         integrate_block(fp, dp, k < count ? list[k] : list[numEntries - 1u - (uint32_t)(k - count)], src);
-#endif
 }
 
 // The dense list of the boundary: end B of a two-ended list moved behind end A and what the commit phase appended

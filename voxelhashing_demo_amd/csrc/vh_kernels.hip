@@ -33,6 +33,7 @@
 #include "vh_frame.hip"
 #include "vh_shard.hip"
 #include "vh_raycast.hip"
+#include "vh_raycast_coop.hip"
 #include "vh_view.hip"
 #include "vh_gc.hip"
 #include "vh_blocks.hip"

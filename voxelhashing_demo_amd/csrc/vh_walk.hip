@@ -31,7 +31,7 @@ constexpr int kFlattenThreads = 256;
 #endif
 constexpr int kEntriesPerLane = VH_ENTRIES_PER_LANE;   // tuning knob (make EXTRA=-DVH_ENTRIES_PER_LANE=n)
 // option "flatten_variant" (values kept from round 1)
-enum WalkKind : int { kWalkStridedBallot = 3, kWalkIndexed = 4, kWalkPersistent = 5 };
+enum WalkKind : int { kWalkStridedBallot = 3, kWalkIndexed = 4 };      // (5, a persistent prefetching walk, lost in round 1 and is gone)
 
 // First compact slot for this lane's `myCount` hits (one atomicAdd per wave that has any).
 __device__ __forceinline__ int reserve_compact_slots(const DevPtrs &dp, int counter, int myCount)
@@ -159,31 +159,6 @@ __device__ __forceinline__ void flatten_tile_ballot(const FrameParams &fp, const
     else flatten_tile_ballot_n<kEntriesPerLane>(fp, dp, numEntries, tileIndex, out, pend);
 }
 
-// Persistent form of the same walk for tables far larger than the Infinity Cache: a workgroup
-// strides over tiles and issues the ptr loads of its NEXT tile before it works through the live
-// entries of the current one (re-read, frustum test, returning atomic, store: microseconds of
-// latency during which the one-shot form has no streaming loads in flight).
-__device__ __forceinline__ void flatten_tiles_persistent(const FrameParams &fp, const DevPtrs &dp,
-                                                         uint32_t numEntries, uint32_t firstTile, uint32_t stride,
-                                                         const CompactOut &out)
-{
-    const uint32_t numTiles = (numEntries + kFlattenThreads * kEntriesPerLane - 1) / (kFlattenThreads * kEntriesPerLane);
-    uint32_t t = firstTile;
-    if (t >= numTiles) return;
-    int32_t cur[kEntriesPerLane], nxt[kEntriesPerLane];
-    walk_load_tile(fp, dp, numEntries, t, cur);
-    for (;;) {
-        const uint32_t n = t + stride;
-        const bool more = n < numTiles;
-        if (more) walk_load_tile(fp, dp, numEntries, n, nxt);
-        walk_process_tile(fp, dp, t, cur, out);
-        if (!more) break;
-#pragma unroll
-        for (int j = 0; j < kEntriesPerLane; ++j) cur[j] = nxt[j];
-        t = n;
-    }
-}
-
 // NOT the reference algorithm (opt-in, "walk_index"): instead of visiting every VoxelEntry,
 // walk the bucket-occupancy bitmap (1 bit per bucket, maintained by the commit phase) and read
 // only the buckets that hold entries.  One lane per 32-bucket word; the compact SET is the
@@ -200,9 +175,6 @@ __device__ __forceinline__ void flatten_tiles_persistent(const FrameParams &fp, 
 #define VH_INDEX_WORDS 4       // (same box, walk-free launch of C2 / C3 / C5table, generic build, index tiles first: 1 word per lane with a
                                //  reservation per wave 10.2 / 35.7 / 43.0 us; 2 words 9.3 / 31.8 / 39.8; 2 words, a reservation per workgroup 9.2 / 28.3 /
                                //  32.7; 4 words 9.2 / 27.6 / 29.5; 8 words 10.2 / 29.0 / 29.7 -- profiles/r05_index_walk_shapes.txt)
-#endif
-#ifndef VH_INDEX_WG_RESERVE
-#define VH_INDEX_WG_RESERVE 1        // 1: one list reservation per workgroup and round; 0: one per wave
 #endif
 constexpr int kIndexWords = VH_INDEX_WORDS;       // bitmap words per lane of an index tile: a workgroup covers 256 * 4 * 32 = 32 768 buckets
 __device__ __forceinline__ void flatten_index_tile_chain(const FrameParams &fp, const DevPtrs &dp, uint32_t tileIndex,
@@ -354,7 +326,6 @@ __device__ __forceinline__ void flatten_index_tile_to(const FrameParams &fp, con
                 const int n = __shfl_up(hincl, d);
                 if (lane >= d) hincl += n;
             }
-#if VH_INDEX_WG_RESERVE
             if (lane == kWave - 1) hits_[wave] = hincl;
             __syncthreads();
             int before = 0, total = 0;
@@ -364,19 +335,10 @@ __device__ __forceinline__ void flatten_index_tile_to(const FrameParams &fp, con
                 before += i < wave ? h : 0;
                 total += h;
             }
-#else
-            const int before = 0, total = __builtin_amdgcn_readlane(hincl, kWave - 1);
-#endif
             if (total != 0) {          // (the same for every wave)
-#if VH_INDEX_WG_RESERVE
                 if (threadIdx.x == 0) base_ = atomicAdd(dp.counters + sink.counter(), total);
                 __syncthreads();
                 const int start = base_;
-#else
-                int start = 0;
-                if (lane == kWave - 1) start = atomicAdd(dp.counters + sink.counter(), total);
-                start = __shfl(start, kWave - 1);
-#endif
                 uint32_t pos = (uint32_t)(start + before + hincl - nh);
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -429,9 +391,7 @@ template <int kKind>
 __device__ __forceinline__ void flatten_tile(const FrameParams &fp, const DevPtrs &dp, uint32_t numEntries,
                                              uint32_t tileIndex, const CompactOut &out, uint32_t walkBlocks)
 {
-    if constexpr (kKind == kWalkPersistent)
-        flatten_tiles_persistent(fp, dp, numEntries, tileIndex, walkBlocks, out);
-    else if constexpr (kKind == kWalkIndexed)
+    if constexpr (kKind == kWalkIndexed)
         flatten_index_tile(fp, dp, tileIndex, out);
     else
         flatten_tile_ballot(fp, dp, numEntries, tileIndex, out);
