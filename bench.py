@@ -216,6 +216,9 @@ class Integrator:
         self.table = V.SDFHashtable(params, wl["width"], wl["height"], V.SEM_PINHOLE, device=local_rank, stream=stream)
         if wl.get("band"):
             self.table.set_alloc_band(wl["band"])
+        # `value` is the reference's frame: flattenKernel's walk over every VoxelEntry (20*N bytes), which the
+        # library no longer runs by default (flatten_variant 4, the walk-free frame: the `walk_free` leg); --option overrides
+        self.table.set_option("flatten_variant", 3)
         for kv in wl.get("options", []):
             k, v = kv.split("=")
             self.table.set_option(k, int(v))
@@ -265,6 +268,16 @@ class Integrator:
 
     def sync(self):
         self.table.synchronize()
+
+    def mean_occupied(self, samples=125):
+        """Mean visible-block count (vh_counters.occupied) over `samples` evenly spaced resident frames, each fused once more and
+        its counter read behind a synchronisation (untimed)."""
+        n = min(samples, self.nframes)
+        total = 0
+        for i in range(n):
+            self.frame((i * self.nframes) // n)
+            total += self.table.counters()["occupied"]
+        return int(round(total / max(1, n)))
 
     def kernel_profile(self, n, first):
         """Per-dispatch HIP events on the path's own stream (untimed pass)."""
@@ -360,8 +373,11 @@ def measure_workload(args, V, L, synth, torch, name, local_rank, steps, warmup, 
     counters = it.table.counters()
     if counters["spin_timeouts"]:          # (a serialised launch gave up waiting: the frames timed are not the frames fused)
         raise SystemExit(f"bench.py: {counters['spin_timeouts']} workgroups of serialised launches timed out (vh_counters.spin_timeouts)")
-    occ = counters["occupied"]
-    rec["occupied_blocks"], rec["allocated_blocks"], rec["resident_frames"] = occ, counters["allocated_total"], nframes
+    rec["occupied_blocks_last_frame"], rec["allocated_blocks"], rec["resident_frames"] = counters["occupied"], counters["allocated_total"], nframes
+    # the visible-block count the byte formulas use is the MEAN over the resident frames (the counter passes and the per-dispatch
+    # times are means over all of them too; the last frame's count alone made the walk-free frame's traffic look 1.4 x its bytes)
+    occ = it.mean_occupied()
+    rec["occupied_blocks"] = occ
     if want_profile and args.profile_steps > 0:
         kt = it.kernel_profile(args.profile_steps, nxt)
         rec["roofline"] = it.dominant_roofline(name, kt, occ)
@@ -412,7 +428,7 @@ def index_variant_record(args, it, name, steps, warmup, sync):
     t_idx, nxt = timed_windows(it.step, sync, steps, warmup)
     rec = dict(window_stats(t_idx, steps, it.batch), unit="frames/s")
     counters = it.table.counters()
-    occ, alloc = counters["occupied"], counters["allocated_total"] - counters.get("freed_total", 0)
+    occ, alloc = it.mean_occupied(), counters["allocated_total"] - counters.get("freed_total", 0)
     flatten_bytes = wl["buckets"] // 8 + 100 * alloc
     nbytes = it.input_bytes() + flatten_bytes + 20 * occ + occ * (20 + 4096 + 4096) + 100 * occ
     rec["flatten_bytes"] = flatten_bytes
@@ -774,7 +790,7 @@ def main():
         for i in range(20):
             l_it.step(i)
         kt_l2 = l_it.kernel_profile(min(200, max(20, args.profile_steps)), 20)
-        l_it.dominant_roofline("C2band", kt_l2, l_it.table.counters()["occupied"])
+        l_it.dominant_roofline("C2band", kt_l2, l_it.mean_occupied())
         l_rec["roofline_commit_integrate_two_launch"] = l_it.commit_roofline
         l_it.close()
         # the band as rounds 1-3 specified it (five ray samples per pixel), for comparison
@@ -906,7 +922,8 @@ def main():
         windows=main_rec["windows"], timed_s=main_rec["timed_s"],
         window_min_ms=main_rec["window_min_ms"], window_max_ms=main_rec["window_max_ms"],
         config=dict(workload=wl["desc"], resident_frames=main_rec["resident_frames"], semantics="pinhole", pipelined=True,
-                    occupied_blocks=occ, allocated_blocks=main_rec["allocated_blocks"], keys_last_frame=occ),
+                    occupied_blocks=occ, occupied_blocks_last_frame=main_rec["occupied_blocks_last_frame"],
+                    allocated_blocks=main_rec["allocated_blocks"]),
         roofline=main_rec.get("roofline"), cpu_baseline=cpu,
         raycast_mpix_per_s=round(raycast_mpix, 1) if raycast_mpix else None,
         kernels=main_rec.get("kernels"),

@@ -339,7 +339,10 @@ int vh_download_range(vh_context *ctx, int which, size_t offset_bytes, void *hos
  * product, not on a build of their own -- and are supported as documented here; none of them changes a result:
  *   vh_debug_eval, vh_debug_set_raycast_stamps, vh_debug_occupy (below); the loop-back transport of voxelhash_dist.h
  *   (vh_dist_loopback_id: the N-rank exchange inside one process); vh_set_profiling / vh_get_kernel_times; the options
- *   "spin_limit"; environment: VOXELHASH_LOOPBACK_TIMEOUT_S (how long a loop-back rank waits for its peers), VH_ICP_BLOCKS
+ *   "spin_limit"; environment: VOXELHASH_ROCTX=1 (roctx ranges named after the entry points -- vh_integrate, vh_integrate_depth,
+ *   vh_flush, vh_raycast, vh_render_blocks, vh_icp_align, vh_garbage_collect, vh_preprocess, vh_dist_step_batch, vh_dist_raycast --
+ *   for `rocprofv3 --marker-trace`; libroctx64 is loaded at run time, nothing is linked), VOXELHASH_LOOPBACK_TIMEOUT_S (how long a
+ *   loop-back rank waits for its peers), VH_ICP_BLOCKS
  *   (workgroups of an ICP round), VOXELHASH_SEMANTICS (the drop-in names' semantics).
  * Code that exists only in diagnostics BUILDS (make EXTRA=-D...) and in no shipped library: VH_DEBUG_SKIP_ROLES (roles of the
  * pipelined launch return at once), VH_CLAIM_STAMPS, VH_DEBUG_DIST_* (per-phase time stamps and switch-offs). */
@@ -357,7 +360,9 @@ int vh_debug_occupy(vh_context *ctx, void *stream, int32_t workgroups, int32_t m
  *     "overflow_list" (0 | 1, before the first frame), "band_mode" (VH_BAND_*), "depth_truncation", "weight_sample" (0 | 1)
  *   the frame:
  *     "flatten_variant"  3 = the reference's walk over every VoxelEntry (flattenKernel, VoxelUtils.cu:719-749), 4 = the walk
- *                        over the bucket-occupancy bitmap and the non-empty buckets (same compact set); default: see vh_create
+ *                        over the bucket-occupancy bitmap and the non-empty buckets (same compact SET, the list's order is free
+ *                        in the reference too: an atomic race, VoxelUtils.cu:737-746) -- the default: 2-11 x the frames/s of the
+ *                        reference's walk at every table size measured
  *     "pipeline"         1: one launch per frame (a frame's commit + TSDF update ride in the next frame's launch)
  *     "pipeline_overflow" 0 | 1 | 2: one-launch frames with the overflow list never / by the launch's size / always
  *     "pipeline_shards"  0 | 1 | 2: the same for a shard's multi-camera frames (vh_apply_frames_batch)

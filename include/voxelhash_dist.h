@@ -72,6 +72,11 @@ int vh_dist_loopback_id(char id[VH_DIST_ID_BYTES]);
 const char *vh_dist_transport_name(vh_dist *d);
 /* rank and size as the transport itself reports them (ncclCommUserRank / ncclCommCount; loop-back: ranks that have joined) */
 int vh_dist_comm_info(vh_dist *d, int32_t *rank, int32_t *world);
+/* The form of the key generation THIS rank's exchanges run in (decided per rank at the first exchange and behind every
+ * vh_dist_flush, option "fused_generation"): 1 = a role of the frame launches, 0 = launches of its own on a second stream.
+ * Ranks may differ (the size rule looks at the rank's own shard); every form issues the same collectives in the same call.
+ * Negative: an error code. */
+int vh_dist_generation_form(vh_dist *d);
 
 /* Creates this rank's shard (vh_create_shard over its bucket range), the communicator (ncclCommInitRank with `id`; or
  * adopts `nccl_comm`, an ncclComm_t the caller owns, when it is not NULL), streams, events and the exchange buffers.

@@ -53,6 +53,8 @@ def main():
     uid = vdist.unique_id(rank, vdist.torch_broadcast_bytes())
     nd = vdist.NativeDist(vh.default_params(**kw), W, H, 1, rank, world, batch, uid, sensor_k_inv=kinv if sensor else None)
     assert nd.transport == "rccl" and nd.comm_info() == (rank, world), (nd.transport, nd.comm_info())
+    if os.environ.get("VOXELHASH_DIST_FUSED") == "2":     # the key generation inside the frame launches: only the reference's walk carries it
+        nd.table.set_option("flatten_variant", 3)
     mine = [torch.from_numpy(np.ascontiguousarray(frames[s][rank][2])).cuda() for s in range(steps)]
     torch.cuda.synchronize()
     for s0 in range(0, steps, batch):

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(vh):
     assert sorted(_lib.SIGNATURES) == declared_functions()
     # the multi-GPU host (include/voxelhash_dist.h): exported, bound, and RCCL is NOT a link-time dependency
     dist = declared_functions(DIST_HEADER)
-    assert "vh_dist_step_batch" in dist and "vh_dist_loopback_id" in dist and len(dist) == 17
+    assert "vh_dist_step_batch" in dist and "vh_dist_loopback_id" in dist and len(dist) == 18
     assert not [n for n in dist if not hasattr(L, n)]
     assert sorted(_lib.DIST_SIGNATURES) == dist
     import subprocess

@@ -21,11 +21,18 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=["by size rule", "fused"])
 def generation_form(request, monkeypatch):
-    """Every test of this file twice: with vh_dist's default -- option "fused_generation" 1, whose size rule keeps tables as small as
-    these on the separate generation launches -- and with the key generation forced into the frame launches wherever they can carry it
-    (VOXELHASH_DIST_FUSED=2, read by vh_dist_create)."""
+    """Every test of this file twice: with the library's defaults -- the walk-free multi-camera frame (flatten_variant 4), whose key
+    generation always runs in launches of its own -- and as bench.py's N-rank `value` runs at C5's shard sizes: the reference's walk
+    (flatten_variant 3) with the key generation forced into the frame launches wherever they can carry it (VOXELHASH_DIST_FUSED=2,
+    read by vh_dist_create; the size rule of option "fused_generation" 1 would keep tables as small as these on separate launches)."""
     if request.param == "fused":
         monkeypatch.setenv("VOXELHASH_DIST_FUSED", "2")
+        plain = vdist.NativeDist.__init__
+
+        def with_reference_walk(self, *a, **k):
+            plain(self, *a, **k)
+            self.table.set_option("flatten_variant", 3)
+        monkeypatch.setattr(vdist.NativeDist, "__init__", with_reference_walk)
     else:
         monkeypatch.delenv("VOXELHASH_DIST_FUSED", raising=False)
     return request.param
@@ -129,6 +136,41 @@ def test_native_ranks_keep_feeding_after_a_raycast(oracle, vh, torch_cuda):
     plan = vdist.ShardPlan(kw["numBuckets"], world)
     for r, t in enumerate(g.tables):
         check_shard_against_full(t, full, *plan.bucket_range(r), 5)
+    g.close()
+    full.close()
+
+
+def test_ranks_in_different_generation_forms(oracle, vh, torch_cuda, generation_form):
+    """The form of the key generation is each rank's own decision (the size rule reads the rank's own shard, and a ragged bucket
+    split can straddle it): ranks 0 and 2 forced to carry it in their frame launches, ranks 1 and 3 to launch it separately.  Both
+    forms issue the same collectives in the same call, so the exchange neither hangs nor mixes frames: every shard equals its
+    slice of the one oracle table, and a raycast round between such ranks equals the oracle's."""
+    if generation_form != "by size rule":
+        pytest.skip("the forms are set rank by rank here")
+    torch = torch_cuda
+    W, H, world, batch = 320, 240, 4, 2
+    kw = dict(numBuckets=1 << 14, numVoxelBlocks=1 << 13)
+    frames, kinv = _camera_frames(oracle, torch, world, 10, W, H, True)
+    full = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    g = vdist.NativeGroup(vh.default_params(**kw), W, H, 1, world, batch, sensor_k_inv=kinv)
+    for r, nd in enumerate(g.ranks):
+        nd.table.set_option("flatten_variant", 3)                 # (the walk-free multi-camera frame never carries the generation)
+        nd.set_option("fused_generation", 2 if r % 2 == 0 else 0)
+    _feed(g, full, frames[:6], batch)
+    assert [nd.generation_form() for nd in g.ranks] == ["fused", "separate", "fused", "separate"]
+    outs = [torch.empty((H, W), dtype=torch.float32, device="cuda") for _ in range(world)]
+    g.raycast([c[0] for c in frames[5]], outs, 2048)
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert np.array_equal(outs[r].cpu().numpy().view(np.uint32), full.raycast(frames[5][r][0]).view(np.uint32))
+    _feed(g, full, frames[6:], batch)
+    g.flush()
+    plan = vdist.ShardPlan(kw["numBuckets"], world)
+    total = 0
+    for r, t in enumerate(g.tables):
+        total += check_shard_against_full(t, full, *plan.bucket_range(r), 5)
+        assert t.counters()["bin_overflow"] == 0
+    assert total == len(full.allocated()) > 150
     g.close()
     full.close()
 

@@ -102,6 +102,7 @@ def test_fused_and_separate_generation_agree(oracle, vh, torch_cuda, batch):
         nd = vdist.NativeDist(vh.default_params(**KW), W, H, 1, 0, 1, batch, vdist.unique_id(), sensor_k_inv=kinv)
         # (2 = wherever the launch can carry the role; the default, 1, adds a size rule that keeps tables as small as this test's on
         # the separate path: multi_fusing_pays)
+        nd.table.set_option("flatten_variant", 3)     # (the reference's walk: the library's default, the walk-free launch, never carries the role)
         nd.set_option("fused_generation", 0 if plan == "separate" else 2)
         for s in range(steps):
             if plan == "switching" and s in (4, 6):     # (behind a flush; the first two calls after it generate separately)
@@ -138,11 +139,13 @@ def test_key_bins_too_small_are_counted_not_overrun(oracle, vh, torch_cuda, fuse
         ot.integrate(poses[j], oracle.preprocess(d16[j], kinv)[0])
     want = entries_as_set(ot.allocated())
     nd = vdist.NativeDist(vh.default_params(**KW), W, H, 1, 0, 1, batch, vdist.unique_id(), sensor_k_inv=kinv, key_capacity=96)
+    nd.table.set_option("flatten_variant", 3)         # (so that fused = 2 does ride in the frame launches)
     nd.set_option("fused_generation", fused)
     for s in range(steps):
         k = s * batch
         nd.step(poses[k:k + batch], frames[k:k + batch])
     nd.flush()
+    assert nd.generation_form() == ("fused" if fused else "separate")
     c = nd.table.counters()
     assert c["bin_overflow"] > 0 and c["spin_timeouts"] == 0 and c["epoch"] == batch * steps, c
     got = entries_as_set(nd.table.allocated())

@@ -11,7 +11,7 @@ from voxelhashing_demo_amd import synth
 pytestmark = pytest.mark.gpu
 
 W, H = 320, 240
-VARIANTS = {"fused-ballot-walk": (1, 3), "four-kernel-persistent-walk": (0, 5), "fused-indexed-walk": (1, 4)}
+VARIANTS = {"fused-ballot-walk": (1, 3), "four-kernel-reference-walk": (0, 3), "fused-indexed-walk": (1, 4)}
 
 
 def frames(n, step=5):

@@ -217,6 +217,52 @@ def test_frame_to_model_tracking_loop(oracle, vh, torch_cuda, normals):
     assert max(errs) < 0.012, errs         # drift about 1 cm over 14 cm of travel (round 2's fixed-step march: 9.9 mm)
 
 
+def test_fusion_loop_poses_equal_the_oracle_loop(oracle, vh, torch_cuda):
+    """The closed loop bench.py times (tracking.FusionLoop; frame order of Application.cpp:73-90): per uint16 sensor frame
+    vh_preprocess -> vh_icp_align against the model's raycast maps -> vh_integrate_depth at the tracked pose -> vh_raycast_maps.
+    The same loop on the oracle (preprocess, icp_align, integrate, raycast + depth_to_maps) must track the same poses: the
+    per-pixel work is bit-equal, the ICP sums are fp32 tree sums here and double sums there (2e-4 per Align, test above), and
+    both stay on the synthetic truth."""
+    from voxelhashing_demo_amd import tracking
+    torch = torch_cuda
+    prims = synth.room_primitives()
+    gt_poses = synth.camera_loop(500)[200:207]
+    K = synth.K_matrix(W, H)
+    kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    d16 = [np.round(synth.render_room_verts(p, W, H, prims).numpy()[..., 2] * 5000.0).clip(0, 65535).astype(np.uint16) for p in gt_poses]
+    kw = dict(numBuckets=1 << 16, numVoxelBlocks=1 << 14)
+    flags = tracking.ICP_ABS_DISTANCE | tracking.ICP_NEED_TARGET
+    # the library
+    table = vh.SDFHashtable(vh.default_params(**kw), W, H, 1)
+    loop = tracking.FusionLoop(table, K, kinv, flags=flags)
+    dev = [torch.from_numpy(d).cuda() for d in d16]
+    got = [loop.start(dev[0], gt_poses[0]).copy()]
+    for k in range(1, len(gt_poses)):
+        got.append(loop.step(dev[k]).copy())
+        assert loop.trk.last[3] > 0.5 * W * H
+    # the oracle, the same order of operations
+    ot = oracle.OracleTable(oracle.default_params(**kw), W, H, 1)
+    pose = np.asarray(gt_poses[0], np.float64).reshape(4, 4).copy()
+    want = [pose.copy()]
+    ot.integrate(pose.astype(np.float32), oracle.preprocess(d16[0], kinv)[0])
+    mv, mn = oracle.depth_to_maps(ot.raycast(pose.astype(np.float32)), kinv)
+    for k in range(1, len(gt_poses)):
+        iv = oracle.preprocess(d16[k], kinv)[0]
+        delta = oracle.icp_align(iv, mv, mn, K, 0.08, 20, flags)[0]
+        pose = pose @ np.asarray(delta, np.float64).reshape(4, 4)
+        want.append(pose.copy())
+        ot.integrate(pose.astype(np.float32), iv)
+        mv, mn = oracle.depth_to_maps(ot.raycast(pose.astype(np.float32)), kinv)
+    for k in range(len(gt_poses)):
+        truth = np.asarray(gt_poses[k], np.float64).reshape(4, 4)
+        assert np.abs(got[k] - want[k]).max() < 1.5e-3, (k, np.abs(got[k] - want[k]).max())
+        assert np.abs(got[k][:3, 3] - truth[:3, 3]).max() < 0.012 and np.abs(want[k][:3, 3] - truth[:3, 3]).max() < 0.012
+    assert np.abs(np.asarray(gt_poses[-1])[:3, 3] - np.asarray(gt_poses[0])[:3, 3]).max() > 0.05
+    loop.close()
+    table.close()
+    ot.close()
+
+
 def test_raycast_maps_is_raycast_plus_depth_to_maps(oracle, vh, torch_cuda):
     torch = torch_cuda
     prims = synth.room_primitives()

@@ -20,15 +20,14 @@ I4 = np.eye(4, dtype=np.float32)
 _FUSED = {"on": 1, "walk": 3}
 
 
-@pytest.fixture(autouse=True, params=["fused-ballot-walk", "fused-indexed-walk", "four-kernel-persistent-walk"])
+@pytest.fixture(autouse=True, params=["fused-reference-walk", "fused-indexed-walk", "four-kernel-reference-walk"])
 def frame_variant(request):
-    """Every test runs in each variant of vh_integrate: the fused two-launch frame with the in-walk
-    compaction (the default), the same with the opt-in walk over the bucket-occupancy bitmap, and
-    the four step kernels (alloc claim / commit / flatten / integrate) with the persistent
-    prefetching walk."""
+    """Every test runs in each variant of vh_integrate: the fused two-launch frame with the reference's walk over every
+    VoxelEntry, the same with the walk over the bucket-occupancy bitmap (the library's default), and the four step kernels
+    (alloc claim / commit / flatten / integrate) with the reference's walk (the steps with the bitmap walk: test_gpu_sequences.py)."""
     p = request.param
     _FUSED["on"] = 0 if p.startswith("four-kernel") else 1
-    _FUSED["walk"] = 4 if "indexed" in p else 5 if "persistent" in p else 3
+    _FUSED["walk"] = 4 if "indexed" in p else 3
     yield p
 
 

@@ -9,8 +9,8 @@ if [ "${2:-}" != "skip-tests" ]; then
   echo "pytest exit $?" >> $OUT/gputest.log
   tail -40 $OUT/gputest.log
 fi
-timeout 900 python bench.py > $OUT/bench_default.log 2>&1; echo "bench exit $?"
-grep '"metric"' $OUT/bench_default.log > $OUT/bench_default.json; tail -c 3000 $OUT/bench_default.log
+timeout 900 python bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err; echo "bench exit $?"
+tail -n 1 $OUT/bench_default.log > $OUT/bench_default.json; cp bench_detail.json $OUT/bench_default_detail.json; tail -c 3000 $OUT/bench_default.log
 timeout 900 bash tools/profile_round.sh $TAG C2 > $OUT/profile_C2.log 2>&1; tail -25 $OUT/profile_C2.log
 timeout 900 bash tools/profile_round.sh $TAG C3 > $OUT/profile_C3.log 2>&1; tail -12 $OUT/profile_C3.log
 timeout 900 bash tools/profile_round.sh $TAG C2band > $OUT/profile_C2band.log 2>&1; tail -6 $OUT/profile_C2band.log

@@ -50,8 +50,8 @@ for wl in sys.argv[2:]:
     if os.path.exists(valu):
         v = json.load(open(valu))
         # (the raycast leg also times the fixed-step march on the same poses: the DDA kernel, the default, is the one reported)
-        for k, cs in sorted(v.items(), key=lambda kv: 0 if kv[0].startswith("raycast_dda_kernel<1, false>") else 1 if kv[0].startswith("raycast_dda") else 2):
-            if k.startswith(("raycast_dda_kernel", "raycast_kernel")) and "SQ_INSTS_VALU" in cs and "SQ_WAVES" in cs:
+        for k, cs in sorted(v.items(), key=lambda kv: 0 if kv[0].startswith("raycast_coop_kernel<false>") else 1 if kv[0].startswith(("raycast_coop", "raycast_dda")) else 2):
+            if k.startswith(("raycast_coop_kernel", "raycast_dda_kernel", "raycast_kernel")) and "SQ_INSTS_VALU" in cs and "SQ_WAVES" in cs:
                 out[wl + "_raycast"] = {
                     "source": f"{src}: rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES, bench.py --legs raycast --workload {wl}",
                     "kernel": k.split("(")[0],

@@ -13,9 +13,9 @@ WL=$WL0$SUFFIX
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 T=/tmp/prof_${TAG}_${WL}; rm -rf $T
-rocprofv3 --kernel-trace --stats --output-format csv -d $T/trace -- python3 bench.py --legs none --workload $WL0 $EXTRA > $OUT/bench_under_rocprof_$WL.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/trace -- python3 bench.py --legs none --workload $WL0 $EXTRA > $OUT/bench_under_rocprof_$WL.log 2> $OUT/bench_under_rocprof_$WL.err
 python3 tools/prof_summary.py stats $T/trace $OUT/kernel_stats_$WL.csv > $OUT/kernel_stats_$WL.txt
-grep '"metric"' $OUT/bench_under_rocprof_$WL.log > $OUT/bench_under_rocprof_$WL.json
+grep '^{"metric"' $OUT/bench_under_rocprof_$WL.log | tail -n 1 > $OUT/bench_under_rocprof_$WL.json       # (the compact line: stdout's last)
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $T/pmc_$C -- python3 bench.py --legs none --workload $WL0 $EXTRA --steps 100 --warmup 10 --profile-steps 0 > /dev/null 2>&1
   python3 tools/prof_summary.py pmc $T/pmc_$C $OUT/pmc_${C}_$WL.json 10 > /dev/null
@@ -31,7 +31,7 @@ if [ "$WL" = "C2" ] && [ -z "$SUFFIX" ]; then
 fi
 if [ "$WL" = "C2" ] && [ -z "$SUFFIX" ]; then
   # the sharded path with one rank (the code path of the N > 1 lines): bench line + PMC of its table launches
-  python3 bench.py --sharded --legs none --workload C2 > $OUT/bench_sharded_world1_C2.log 2>&1; grep '"metric"' $OUT/bench_sharded_world1_C2.log > $OUT/bench_sharded_world1_C2.json
+  python3 bench.py --sharded --legs none --workload C2 > $OUT/bench_sharded_world1_C2.log 2> $OUT/bench_sharded_world1_C2.err; grep '^{"metric"' $OUT/bench_sharded_world1_C2.log | tail -n 1 > $OUT/bench_sharded_world1_C2.json
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --output-format csv -d $T/pmcs_$C -- python3 bench.py --sharded --legs none --workload C2 --steps 10 --warmup 2 > /dev/null 2>&1
     python3 tools/prof_summary.py pmc $T/pmcs_$C $OUT/pmc_${C}_C2sharded.json 10 > /dev/null

@@ -197,6 +197,7 @@ DIST_SIGNATURES = {
     "vh_dist_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "vh_dist_loopback_id": (C.c_int, [C.c_char_p]),
     "vh_dist_transport_name": (C.c_char_p, [_vp]),
+    "vh_dist_generation_form": (C.c_int, [_vp]),
     "vh_dist_set_user_stream": (C.c_int, [_vp, _vp, C.c_int32]),
 }
 

@@ -745,6 +745,7 @@ static int dist_step_fused(vh_dist *d, const float *poses, const void *const *d_
 
 extern "C" int vh_dist_step_batch(vh_dist *d, const float *poses, const void *const *d_frames)
 {
+    VH_TRACE("vh_dist_step_batch");
     if (!d || !poses || !d_frames) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     const auto t0 = std::chrono::steady_clock::now();
     DeviceGuard guard(d->device);
@@ -863,6 +864,7 @@ extern "C" int vh_dist_flush(vh_dist *d)
 static int dist_raycast_impl(vh_dist *d, const float pose[16], float t_min, float t_max, int32_t capacity, float *d_depth_out,
                              vh_float4 *d_normals_out, int32_t *d_lost)
 {
+    VH_TRACE("vh_dist_raycast");
     if (!d || !pose || !d_depth_out || capacity < 1) return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     const int R = d->cfg.world;
     if (R > 16) return fail(VH_ERR_INVALID_ARGUMENT, "the fixed-slot raycast round serves at most 16 views");
@@ -1002,6 +1004,17 @@ extern "C" int vh_dist_comm_info(vh_dist *d, int32_t *rank, int32_t *world)
     if (rank) *rank = r;
     if (world) *world = n;
     return VH_OK;
+}
+
+extern "C" int vh_dist_generation_form(vh_dist *d)
+{
+    if (!d) return -fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (d->modeDirty) {                  // (no exchange since creation / the last flush: what the next one will decide)
+        const bool want = d->fused != 0 && d->cfg.packet_format == VH_PACKET_U16 && d->cfg.batch <= 8 && d->capacity >= 8 &&
+                          multi_can_fuse_generation(d->shard, d->cfg.world, d->capacity) && (d->fused == 2 || multi_fusing_pays(d->shard));
+        return want ? 1 : 0;
+    }
+    return d->fusedActive ? 1 : 0;
 }
 
 extern "C" int vh_dist_host_stats(vh_dist *d, double *seconds, uint64_t *calls)

@@ -7,6 +7,7 @@
 extern "C" int vh_preprocess(const uint16_t *d_depth, const float k_inv[9], int32_t width, int32_t height,
                              vh_float4 *d_positions, vh_float4 *d_normals, void *hip_stream)
 {
+    VH_TRACE("vh_preprocess");
     if (!d_depth || !k_inv || !d_positions || !d_normals || width <= 0 || height <= 0 ||
         (uint64_t)width * height > (1u << 24))
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");

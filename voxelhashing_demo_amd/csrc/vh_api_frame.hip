@@ -410,6 +410,7 @@ static int settle(vh_context *c)
 
 extern "C" int vh_flush(vh_context *c)
 {
+    VH_TRACE("vh_flush");
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     DeviceGuard guard(c->device);
     return settle(c);
@@ -492,6 +493,7 @@ static int run_frame(vh_context *c, const In &in, const Depth &depth)
 
 extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4 *verts, const vh_float4 *normals)
 {
+    VH_TRACE("vh_integrate");
     if (!c || !pose || !verts) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(c->device);
     // a single-camera frame on a context that still holds a multi-camera frame's deferred half (pipeline_shards 2, e.g. the
@@ -509,6 +511,7 @@ extern "C" int vh_integrate(vh_context *c, const float pose[16], const vh_float4
 // the claim half, the TSDF update reads the image.  Equals vh_preprocess + vh_integrate.
 extern "C" int vh_integrate_depth(vh_context *c, const float pose[16], const uint16_t *d_depth, const float k_inv[9])
 {
+    VH_TRACE("vh_integrate_depth");
     if (!c || !pose || !d_depth || !k_inv) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     DeviceGuard guard(c->device);
     int rc = flush_multi_pending(c);                      // (see vh_integrate)
@@ -562,6 +565,7 @@ extern "C" int vh_integrate_depth_batch(vh_context *c, int32_t count, const floa
 static int raycast_impl(vh_context *c, const float pose[16], float t_min, float t_max, float *d_depth_out,
                         vh_float4 *d_normals_out)
 {
+    VH_TRACE("vh_raycast");
     if (!c || !pose || !d_depth_out) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     if (!(t_max > t_min)) return fail(VH_ERR_INVALID_ARGUMENT, "t_max must exceed t_min");
     if (c->raycastMode == VH_RAYCAST_FIXED_STEP && d_normals_out)
@@ -622,12 +626,9 @@ static int raycast_impl(vh_context *c, const float pose[16], float t_min, float 
         ra.beam = t_min > 0.0f ? beam : 0;
         float4 *nrm = reinterpret_cast<float4 *>(d_normals_out);
         const dim3 block(64 * kDdaBlockWaves);
-        ra.patchesX = (fp.width + 7) / 8;
-        ra.numPatches = ra.patchesX * ((fp.height + 7) / 8);
-        ra.groups = (ra.numPatches + kDdaBlockWaves - 1) / kDdaBlockWaves;
-        if (ra.beam == 2)       // the cooperative form: a workgroup per group of four far-apart patches (vh_raycast_coop.hip)
-            rc = nrm ? launch(c, kPhaseRaycast, raycast_coop_kernel<true>, dim3((unsigned)ra.groups), block, fp, dp, ra, d_depth_out, nrm)
-                     : launch(c, kPhaseRaycast, raycast_coop_kernel<false>, dim3((unsigned)ra.groups), block, fp, dp, ra, d_depth_out, nrm);
+        if (ra.beam == 2)       // the cooperative form: one block list per wave (vh_raycast_coop.hip)
+            rc = nrm ? launch(c, kPhaseRaycast, raycast_coop_kernel<true>, grid, block, fp, dp, ra, d_depth_out, nrm)
+                     : launch(c, kPhaseRaycast, raycast_coop_kernel<false>, grid, block, fp, dp, ra, d_depth_out, nrm);
         else
             rc = nrm ? launch(c, kPhaseRaycast, raycast_dda_kernel<true>, grid, block, fp, dp, ra, d_depth_out, nrm)
                      : launch(c, kPhaseRaycast, raycast_dda_kernel<false>, grid, block, fp, dp, ra, d_depth_out, nrm);
@@ -653,6 +654,7 @@ extern "C" int vh_raycast_normals(vh_context *c, const float pose[16], float t_m
 extern "C" int vh_render_blocks(vh_context *c, const float pose[16], float t_min, float t_max, float *d_front,
                                 float *d_back)
 {
+    VH_TRACE("vh_render_blocks");
     if (!c || !pose || !d_front || !d_back) return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
     if (!(t_max > t_min) || !(t_min >= 0.0f)) return fail(VH_ERR_INVALID_ARGUMENT, "need 0 <= t_min < t_max");
     DeviceGuard guard(c->device);

@@ -148,6 +148,7 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
                             const vh_float4 *d_target_normals, const float K[9], float dist_thres, int32_t max_iters,
                             int32_t flags, float delta[16], vh_icp_system *last, int32_t *iterations)
 {
+    VH_TRACE("vh_icp_align");
     if (!p || !d_input || !d_target || !d_target_normals || !K || !delta || max_iters < 0)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     DeviceGuard guard(p->device);

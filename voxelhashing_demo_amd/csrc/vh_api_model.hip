@@ -44,6 +44,7 @@ extern "C" int vh_delete_blocks(vh_context *c, const int32_t *d_keys, int32_t n)
 
 extern "C" int vh_garbage_collect(vh_context *c, float sdf_threshold)
 {
+    VH_TRACE("vh_garbage_collect");
     if (!c) return fail(VH_ERR_INVALID_ARGUMENT, "null context");
     if (c->viewBlocks) return fail(VH_ERR_INVALID_ARGUMENT, "a view table owns no blocks");
     DeviceGuard guard(c->device);

@@ -408,6 +408,13 @@ class NativeDist:
         self._L.check(self._lib.vh_dist_comm_info(self._h, C.byref(r), C.byref(n)), "vh_dist_comm_info")
         return r.value, n.value
 
+    def generation_form(self) -> str:
+        """"fused" (the key generation rides in the frame launches) or "separate" (launches of its own): this rank's choice."""
+        f = self._lib.vh_dist_generation_form(self._h)
+        if f < 0:
+            self._L.check(-f, "vh_dist_generation_form")
+        return "fused" if f else "separate"
+
     def host_stats(self):
         import ctypes as C
         s, n = C.c_double(), C.c_uint64()
@@ -890,6 +897,7 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
             # (key bins: the library's default -- ONE bin per (owner, batch) of 1.5 x batch x W*H/16 / world records)
             native_capacity = max(8192, (-(-Wd * Ht // 16) * batch * 3 // 2 + world - 1) // world + 1)
 
+            nd.table.set_option("flatten_variant", 3)             # the line's value is the reference's walk (bench.py: Integrator); --option overrides
             for kv in getattr(args, "option", []) or []:          # A/B switches (bench.py --option name=value)
                 k_, v_ = kv.split("=")
                 if k_ in ("fused_generation", "force_collectives", "raycast_auto_start"):      # options of the exchange itself
@@ -909,6 +917,11 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
         else:
             shard = HipShard(params, Wd, Ht, SEM_PINHOLE, plan, rank, capacity, batch=batch, device=dev, stream=stream,
                              sets=2 if pipelined else 1, sensor_k_inv=k_inv if sensor else None)
+            shard.table.set_option("flatten_variant", 3)          # (as the native host above)
+            for kv in getattr(args, "option", []) or []:
+                k_, v_ = kv.split("=")
+                if k_ not in ("fused_generation", "force_collectives", "raycast_auto_start"):
+                    shard.table.set_option(k_, int(v_))
             pipe = ShardedPipeline(shard, transport, stream, front) if pipelined else None
 
         def step(i):
@@ -1082,6 +1095,12 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
     dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     out = None
     comm_ranks = nd.comm_info()[1] if native else None
+    forms = None
+    if native:        # which form of the key generation each rank's exchanges ran in (a per-rank decision: the size rule reads the rank's own shard)
+        ft = torch.zeros(world, dtype=torch.int32, device=cdev)
+        ft[rank] = 1 if nd.generation_form() == "fused" else 0
+        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+        forms = ["fused" if int(x) else "separate" for x in ft.tolist()]
     if rank == 0:
         frames = args.steps * world * batch
         launches = max(1, kt["launches"])
@@ -1145,6 +1164,7 @@ def bench_sharded(args, wl, wl_name, rank, world, local_rank):
                                 if native else dict(transport="torch.distributed " + dist.get_backend(), ranks=dist.get_world_size()),
                                 **({"shared_gpu": True} if os.environ.get("VH_BENCH_SHARE_GPU") == "1" and world > 1 else {})),
             exchange_phases_us=phases, predicted=scaling_prediction(wl_name, world, batch),
+            generation_form=(forms[0] if forms and len(set(forms)) == 1 else forms),
             exchange_host=("libvoxelhash_hip.so: vh_dist_step_batch (include/voxelhash_dist.h)"
                            + (" on RCCL directly" if world > 1 else ", one rank: no collective")) if native
             else "Python: dist.ShardedPipeline over torch.distributed collectives (--python-exchange / --no-pipeline)"
