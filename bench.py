@@ -219,9 +219,12 @@ class Integrator:
         # `value` is the reference's frame: flattenKernel's walk over every VoxelEntry (20*N bytes), which the
         # library no longer runs by default (flatten_variant 4, the walk-free frame: the `walk_free` leg); --option overrides
         self.table.set_option("flatten_variant", 3)
+        self.indexed = False
         for kv in wl.get("options", []):
             k, v = kv.split("=")
             self.table.set_option(k, int(v))
+            if k == "flatten_variant":
+                self.indexed = int(v) == 4
         # pipelined frames: one launch per frame (the commit + TSDF update of frame i ride in the launch of
         # frame i+1); every synchronisation flushes, so a timed window contains all of its frames' work
         self.table.set_option("pipeline", 1 if pipeline else 0)
@@ -309,6 +312,9 @@ class Integrator:
             kname = "frame_pipelined_kernel"
             us = 1e3 * kt["frame_pipelined_ms"] / launches
             nbytes = self.input_bytes() + 20 * n_entries + 20 * occ + occ * (20 + 4096 + 4096) + 100 * occ
+            if self.indexed:      # (--option flatten_variant=4 on the measured table, the profile runs of the walk-free frame: its own byte count)
+                c = self.table.counters()
+                nbytes += wl["buckets"] // 8 + 100 * (c["allocated_total"] - c.get("freed_total", 0)) - 20 * n_entries
         else:
             # dominant kernel of the two-launch frame: per-pixel claim phase || walk over the VoxelEntry array:
             # the vertex map read once by the claim half (16*W*H), one pass over the table (20*N), the compact

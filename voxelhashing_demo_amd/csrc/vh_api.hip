@@ -54,7 +54,8 @@ struct Roctx {
         const char *e = std::getenv("VOXELHASH_ROCTX");
         if (!e || std::atoi(e) == 0) return;
         void *lib = nullptr;
-        for (const char *n : {"libroctx64.so", "libroctx64.so.4", "librocprofiler-sdk-roctx.so"})
+        // (rocprofv3 = rocprofiler-sdk records the ranges of ITS roctx library; libroctx64 is roctracer's, for the older tools)
+        for (const char *n : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"})
             if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL)) != nullptr) break;
         if (!lib) return;
         push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
