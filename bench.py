@@ -456,6 +456,18 @@ def index_variant_record(args, it, name, steps, warmup, sync):
             rec["roofline"]["rocprofv3_us_per_launch"] = rp
             rec["roofline"]["frac_at_rocprofv3_mean"] = round(nbytes / (rp * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     it.table.set_option("flatten_variant", 3)
+    # What bounds this launch is not bytes: a latency / issue model beside the measured time.  Constants measured
+    # on C2 with roles switched off in a diagnostics build (profiles/r06_index_roles_C2.txt): an empty launch of this grid (dispatch
+    # + the commit role's ticket chain) 4.5 us; the claim tiles alone 7.3 us = 4 dependent round trips (vertex -> bucket's first slot
+    # -> pending claim word -> atomicMax) of ~0.7 us on top of it.  Vector issue: ~300 wave-instructions per claim wave of 64 pixels
+    # (IEEE divisions of world2Voxel, frustum test, hash, dedup) and 912 per updated block (SQ_INSTS_VALU of the TSDF update on C3,
+    # profiles/r05_pmc_commit_integrate_C3_*.json), 4 cycles each on 1 024 SIMDs at 2.4 GHz.  model = floor + the longer of the two.
+    floor_us, round_trip_us, claim_trips = 4.5, 0.7, 4
+    issue_us = ((Wd * Ht / 64.0) * 300.0 + occ * 912.0) / 1024.0 * 4.0 / 2400.0
+    rec["latency_model"] = dict(launch_floor_us=floor_us, claim_chain_us=round(claim_trips * round_trip_us, 2),
+                                vector_issue_us=round(issue_us, 2), model_us=round(floor_us + max(claim_trips * round_trip_us, issue_us), 2),
+                                source="profiles/r06_index_roles_C2.txt (floor, round trip); 300 / 912 vector wave-instructions per claim wave / "
+                                       "updated block at 4 cycles on 1 024 SIMDs, 2.4 GHz")
     rec["note"] = ("vh_set_option(flatten_variant=4), pipelined like the headline path: walk over the bucket-occupancy "
                    "bitmap (numBuckets/8 bytes) + the non-empty buckets instead of the 20*N-byte table walk; NOT the "
                    "reference's flattenKernel, hence not `value`; bit-equal tables, voxels and compact set "
