@@ -589,7 +589,15 @@ def self_launch(args, argv):
     # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC (without it RCCL's P2P set-up between
     # processes fails with hipIpcGetMemHandle: invalid argument); the image exports it, a caller's own value wins
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "8"))
-    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    def die_with_parent():
+        #  a parent that is SIGKILLed -- a harness's hard limit, the OOM killer -- runs no handler: the launcher asks
+        # the kernel for SIGTERM at its parent's death (prctl PR_SET_PDEATHSIG), and ends its ranks as it does on any SIGTERM
+        try:
+            C.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM, 0, 0, 0)
+        except Exception:
+            pass
+
+    child = subprocess.Popen(cmd, env=env, start_new_session=True, preexec_fn=die_with_parent)
 
     def end_children(signum=None, frame=None):
         for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):

@@ -3,6 +3,8 @@
 without a GPU, every rank must say how many GPUs were asked for and how many it sees -- not print launcher instructions."""
 import os
 import subprocess
+
+import pytest
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,8 +24,11 @@ def test_launcher_command_is_the_drivers():
     assert "--master-port" not in own and "--rdzv-endpoint=127.0.0.1:0" in own and own[own.index("--local-addr") + 1] == "127.0.0.1"
 
 
-def test_a_terminated_parent_takes_its_ranks_along(tmp_path):
-    """SIGTERM to `python bench.py --gpus 2` (a driver's timeout): the launcher and its ranks end with it -- no orphan keeps a GPU busy."""
+@pytest.mark.parametrize("how", ["SIGTERM", "SIGKILL"])
+def test_a_terminated_parent_takes_its_ranks_along(tmp_path, how):
+    """SIGTERM to `python bench.py --gpus 2` (a driver's timeout): the launcher and its ranks end with it -- no orphan keeps a GPU
+    busy.  SIGKILL (a harness's hard limit, the OOM killer) runs no handler in the parent: the launcher has asked the kernel for a
+    SIGTERM at its parent's death (PR_SET_PDEATHSIG) and ends its ranks itself."""
     import signal
     import time
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -38,9 +43,9 @@ def test_a_terminated_parent_takes_its_ranks_along(tmp_path):
     while time.time() < deadline and len(ranks()) < 3:      # launcher + 2 ranks
         time.sleep(0.5)
     assert len(ranks()) >= 3, "the ranks did not start"
-    p.send_signal(signal.SIGTERM)
-    assert p.wait(timeout=60) == 128 + signal.SIGTERM
-    end = time.time() + 20                           # (the ranks got the same SIGTERM: they are gone within moments)
+    p.send_signal(getattr(signal, how))
+    assert p.wait(timeout=60) == (128 + signal.SIGTERM if how == "SIGTERM" else -signal.SIGKILL)
+    end = time.time() + 40                           # (the ranks get SIGTERM from the parent's handler / from their launcher)
     while time.time() < end and ranks():
         time.sleep(0.5)
     assert ranks() == [], "ranks outlived their parent"
