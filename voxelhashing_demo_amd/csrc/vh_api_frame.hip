@@ -626,9 +626,12 @@ static int raycast_impl(vh_context *c, const float pose[16], float t_min, float 
         ra.beam = t_min > 0.0f ? beam : 0;
         float4 *nrm = reinterpret_cast<float4 *>(d_normals_out);
         const dim3 block(64 * kDdaBlockWaves);
-        if (ra.beam == 2)       // the cooperative form: one block list per wave (vh_raycast_coop.hip)
-            rc = nrm ? launch(c, kPhaseRaycast, raycast_coop_kernel<true>, grid, block, fp, dp, ra, d_depth_out, nrm)
-                     : launch(c, kPhaseRaycast, raycast_coop_kernel<false>, grid, block, fp, dp, ra, d_depth_out, nrm);
+        ra.patchesX = (fp.width + 7) / 8;
+        ra.numPatches = ra.patchesX * ((fp.height + 7) / 8);
+        ra.groups = (ra.numPatches + kDdaBlockWaves - 1) / kDdaBlockWaves;
+        if (ra.beam == 2)       // the cooperative form: a workgroup per group of four far-apart patches (vh_raycast_coop.hip)
+            rc = nrm ? launch(c, kPhaseRaycast, raycast_coop_kernel<true>, dim3((unsigned)ra.groups), block, fp, dp, ra, d_depth_out, nrm)
+                     : launch(c, kPhaseRaycast, raycast_coop_kernel<false>, dim3((unsigned)ra.groups), block, fp, dp, ra, d_depth_out, nrm);
         else
             rc = nrm ? launch(c, kPhaseRaycast, raycast_dda_kernel<true>, grid, block, fp, dp, ra, d_depth_out, nrm)
                      : launch(c, kPhaseRaycast, raycast_dda_kernel<false>, grid, block, fp, dp, ra, d_depth_out, nrm);

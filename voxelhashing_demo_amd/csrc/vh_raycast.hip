@@ -224,6 +224,8 @@ struct RaycastArgs {
     int budget;               // hang guard: more steps than any ray of this view can take (host: vh_raycast)
     int beam;                 // 2: the cooperative form (raycast_coop_kernel); 1: per-lane walk behind a beam front end; 0: per-lane walk
                               // from t_min (views with t_min <= 0)
+    int patchesX, numPatches; // cooperative form: 8x8-pixel patches per image row / in the image
+    int groups;               // ... and its workgroups: group g renders one patch of each quarter of the patch grid
     unsigned long long *stamps;   // diagnostics (tools/raycast_stamps.py): 8 words per wave, or null
 };
 

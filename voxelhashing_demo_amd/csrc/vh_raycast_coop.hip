@@ -1,5 +1,5 @@
-// vh_raycast_coop.hip -- the cooperative DDA raycast: one block list per wave (an 8x8 ray patch).
-// Part of libvoxelhash_hip.so (gfx950); included after vh_raycast.hip (DDA helpers, beam front end, per-lane walk).
+// vh_raycast_coop.hip -- the cooperative DDA raycast: one block list per 8x8 ray patch, the lists of a workgroup's four
+// patches walked by whichever of its waves is free.  Part of libvoxelhash_hip.so (gfx950); included after vh_raycast.hip.
 #pragma once
 
 namespace vh {
@@ -33,16 +33,62 @@ namespace vh {
 // of 64 when the range is longer), the boxes are conservative, so every allocated block any ray of the wave visits
 // is in the list.  Whenever the preconditions fail -- a box spans more than two blocks on an axis, the set
 // overflows, a block lies more than 511 blocks from the wave's first -- the wave falls back to the per-lane walk.
+//
+// Round 6: the listed blocks are ITEMS that an idle wave of the workgroup can take.  Measured before
+// (profiles/r05_raycast_stamps.txt): a wave that walks its own list is as long as that list -- 3.5 us per block, lists of 8-13 blocks
+// on silhouette and grazing patches against a mean of 2.7-4.2 -- and the launch is as long as its slowest wave (30-40 us, mean
+// wave 15-19).  Sharing among the four neighbouring patches of a 16x16 tile gains next to nothing, because a grazing region covers
+// all four.  So
+//   (i) a workgroup's four patches are taken far apart: wave j of group g renders a patch of the j-th quarter of the row-major
+//       patch grid, rotated by j quarter-rows inside its quarter (a quarter of the image away in both directions: a grazing wall
+//       is a vertical band as often as a grazing floor is a horizontal one), so the patches of one grazing region meet light company;
+//  (ii) every wave lists its own patch (steps 1-2), leaves its rays' set-up in LDS (E, 1/E, start voxel: 9 words per ray) and
+//       publishes the list; it then walks its own list from the front with the loop of the one-list-per-wave form -- the rays'
+//       state and best candidates in registers -- except that it TAKES every item from the patch's counter in LDS;
+// (iii) a wave whose own list is done takes items of the neighbour with the most items left (same counter), walks the item's
+//       block for the 64 rays of the item's patch from the state in LDS (coop_walk_item) and merges each ray's candidate into the
+//       ray's 64-bit word in LDS with an atomic minimum: a candidate is {arrival event of the hit voxel (t, axis priority), where
+//       the pair sits}, a ray's events are totally ordered, so the minimum IS the hit the sequential walk finds first, whatever the
+//       order the blocks are walked in and whoever walks them; it runs at the priority of the list it helps with;
+//  (iv) a patch nobody took from is written straight from its owner's registers; otherwise the owner merges its own best
+//       candidates into the words once, and whoever completes the patch's last item turns the words into depth (and normals).
+//       No barrier anywhere behind the first one; a wave with nothing left to take leaves.
+// Same box, C2, mean over the bench's 50 poses: 28.8 us against 31.7 for one list per wave (33.9 / 35.6 with normals; 5 mm voxels,
+// cooperative form forced: 163 / 172).  What did NOT work on the way (profiles/r06_raycast_*.txt, DESIGN_LOG.md round 6): every
+// item through LDS, own ones too (33.2 us: 4.1 instead of 3.5 us per item); the owner publishing its best candidate after every
+// block (30.1 against 28.6); helping only lists with 2 / 3 / 4 / 6 items left (29.2 ... 34.4); the four patches of one tile
+// (31.6); forgetting the priorities by list length (+3 us).
+constexpr int kCoopK = 1;                             // voxels fetched per round trip in the owner's block walk (2, 3: slower, rounds 4 and 6)
 constexpr int kCoopSubs = 4;                          // slabs per lane and window of step 1 (64 x this many half-block slabs)
 constexpr int kCoopSlots = 256;                       // per wave: cells with a set bucket bit
 constexpr uint32_t kCoopUnresolved = 0x7ffffffeu;     // sPtr: not looked up yet
-struct CoopShared {
-    uint32_t tag[kDdaBlockWaves][kCoopSlots];
-    uint32_t ptr[kDdaBlockWaves][kCoopSlots];
-    uint32_t list[kDdaBlockWaves][kCoopSlots];     // allocated cells: slot | depth key << 16 (the list is walked front to back)
+constexpr unsigned long long kCoopNone = ~0ull;       // a ray's word: no candidate
+struct CoopShared {                                   // per workgroup (25 KiB: five workgroups per CU at 5 waves per SIMD)
+    uint32_t tag[kDdaBlockWaves][kCoopSlots];      // per patch: the set of cells with a set bucket bit (the tag IS the key)
+    uint32_t ptr[kDdaBlockWaves][kCoopSlots];      // ... and the voxel pointer of each (VH_FREE_BLOCK: not allocated)
+    uint32_t list[kDdaBlockWaves][kCoopSlots];     // allocated cells: slot | depth key << 16, front to back -- the patch's ITEMS
     uint16_t cells[kDdaBlockWaves][kCoopSlots];    // the set's occupied slots in order of insertion (what step 2 resolves)
+    float state[kDdaBlockWaves][9][64];            // the patch's rays: E[3], invE[3] (0: the axis never steps), c[3] (int bits)
+    unsigned long long best[kDdaBlockWaves][64];   // the rays' best candidates {ordered t : 32 | priority : 2 | slot : 8 | voxel : 9 | previous : 10 | axis : 2 | 0}
     uint32_t count[kDdaBlockWaves];
+    int base[kDdaBlockWaves][3];                   // block coordinates the tags are relative to
+    int origin[kDdaBlockWaves];                    // pixel of the patch's first ray: u | v << 16
+    uint32_t avail[kDdaBlockWaves];                // items of the patch (published with `ready`)
+    uint32_t taken[kDdaBlockWaves];                // ... handed out so far (may run past avail)
+    uint32_t done[kDdaBlockWaves];                 // ... walked to the end: the wave that completes a patch writes its pixels
+    uint32_t ready[kDdaBlockWaves];                // the patch's list is final
 };
+
+// candidate word of a ray: events compare as (t, priority); t as a sign-ordered 32-bit key (-0 is written as +0)
+__device__ __forceinline__ uint32_t rc_time_key(float t)
+{
+    const uint32_t b = __float_as_uint(t + 0.0f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float rc_key_time(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
 
 __device__ __forceinline__ uint32_t coop_tag(int rx, int ry, int rz) { return 1u + (uint32_t)rx + ((uint32_t)ry << 10) + ((uint32_t)rz << 20); }
 
@@ -109,42 +155,244 @@ __device__ __forceinline__ CoopEntry coop_entry(const DdaAxis (&ax)[3], const in
     return r;
 }
 
-constexpr int kCoopK = 1;            // voxels fetched per round trip in the block walk (2 and 3: slower in rounds 4 and 6, DESIGN_LOG.md)
-template <bool kNormals>
-__global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_coop_kernel(const FrameParams fp, const DevPtrs dp, const RaycastArgs ra,
-                                                          float *__restrict__ depthOut, float4 *__restrict__ normalOut)
+// Step 3 for ONE item: the 64 rays of patch `w` against block `slot` of the patch's set.
+// kK: voxels fetched per round trip of the walk (the path through the block is arithmetic alone, so the next kK voxels are
+// enumerated first, their loads issued together, then judged in order).
+template <int kK>
+__device__ __forceinline__ void coop_walk_item(const FrameParams &fp, const DevPtrs &dp, const RaycastArgs &ra, CoopShared &sh, int w, int k,
+                                               bool &entered)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long stamp0 = ra.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    int tx = blockIdx.x, ty = blockIdx.y;
-    xcd_tile(tx, ty);                        // each XCD (own L2) renders a contiguous run of image tiles
-    // the wave's pixel patch: 8x8 of the workgroup's 16x16 tile
-    const int pu = tx * 16 + (wave & 1) * 8, pv = ty * 16 + (wave >> 1) * 8;
-    const int u = pu + (lane & 7), v = pv + (lane >> 3);
-    const bool inImage = u < fp.width && v < fp.height;
+    const int lane = threadIdx.x & 63;
+    const int prio[3] = {2, 0, 1};
+    const uint32_t *tags = sh.tag[w], *ptrs = sh.ptr[w];
+    const int slot = __builtin_amdgcn_readfirstlane((int)(sh.list[w][k] & 0xffffu));
+    const uint32_t tg = (uint32_t)__builtin_amdgcn_readfirstlane((int)tags[slot]) - 1u;
+    const int bptr = __builtin_amdgcn_readfirstlane((int)ptrs[slot]);
+    const int base0 = __builtin_amdgcn_readfirstlane(sh.base[w][0]), base1 = __builtin_amdgcn_readfirstlane(sh.base[w][1]),
+              base2 = __builtin_amdgcn_readfirstlane(sh.base[w][2]);
+    const int kk[3] = {base0 + (int)(tg & 1023u), base1 + (int)((tg >> 10) & 1023u), base2 + (int)(tg >> 20)};
+    const int org = __builtin_amdgcn_readfirstlane(sh.origin[w]);
+    const bool inImage = (org & 0xffff) + (lane & 7) < fp.width && (org >> 16) + (lane >> 3) < fp.height;
+    // the ray's set-up, as its patch's wave left it
     DdaAxis ax[3];
     int c[3];
-    float dx, dy;
-    dda_ray(fp, ra, u, v, ax, c, dx, dy);
-    const float vs = fp.voxelSize;
-    bool live = inImage;
-    bool found = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        ax[a].G = ra.G[a];
+        ax[a].E = sh.state[w][a][lane];
+        ax[a].invE = sh.state[w][3 + a][lane];
+        c[a] = __float_as_int(sh.state[w][6 + a][lane]);
+        ax[a].s = ax[a].E > 0.0f ? 1 : -1;
+        ax[a].Gs = ax[a].E > 0.0f ? ax[a].G - 1.0f : ax[a].G;
+    }
+    unsigned long long *word = &sh.best[w][lane];
+    const unsigned long long cur = *word;
+    const float bestT = cur == kCoopNone ? __builtin_inff() : rc_key_time((uint32_t)(cur >> 32));
+    const int bestP = cur == kCoopNone ? 3 : (int)((cur >> 30) & 3ull);
+    const CoopEntry e = coop_entry(ax, c, kk, ra.tMax);
+    const float tE = e.tE;
+    const int pE = e.pE, xe = e.xe;
+    const bool inside = e.inside;
+    const bool enters = inImage && e.enters && dda_before(tE, pE, bestT, bestP);      // (not behind the candidate the ray holds)
+    entered = __ballot(enters) != 0ull;
+    if (!enters) return;
+    // the walk's per-ray constants
+    const float f0 = (float)ax[0].s, f1 = (float)ax[1].s, f2 = (float)ax[2].s;
+    // (an axis that never steps: invE = 0 would give a crossing time of 0; (c + 1e30) * inf = inf instead)
+    const float ie0 = ax[0].invE != 0.0f ? ax[0].invE : __builtin_inff(), gs0 = ax[0].invE != 0.0f ? ax[0].Gs : -1.0e30f;
+    const float ie1 = ax[1].invE != 0.0f ? ax[1].invE : __builtin_inff(), gs1 = ax[1].invE != 0.0f ? ax[1].Gs : -1.0e30f;
+    const float ie2 = ax[2].invE != 0.0f ? ax[2].invE : __builtin_inff(), gs2 = ax[2].invE != 0.0f ? ax[2].Gs : -1.0e30f;
+    const int d0 = ax[0].s * ((1 << 16) + 1), d1 = ax[1].s * ((8 << 16) + (1 << 5)), d2 = ax[2].s * ((64 << 16) + (1 << 10));
+        // the voxel the ray enters at
+        int q[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int lo = kk[a] << 3, hi = lo + 7;
+            const int nearC = ax[a].s > 0 ? lo : hi, farC = ax[a].s > 0 ? hi : lo;
+            if (inside || ax[a].invE == 0.0f) q[a] = c[a];
+            else if (a == xe) q[a] = nearC;
+            else q[a] = dda_advance(ax[a], prio[a], e.startIn[a] ? c[a] : nearC, farC, tE, pE);
+        }
+        // Inside the block the walk keeps the voxel as float coordinates (exact below 2^24: the host refuses views
+        // beyond 2^23), the local position as three 5-bit fields (value 8..15 = inside: ONE mask test tells when the
+        // ray has left the block) packed with the linear voxel index, and steps all of it without a branch:
+        // ~27 vector instructions per voxel instead of ~45 with integer coordinates and per-axis branches.
+        const int bx0 = kk[0] << 3, by0 = kk[1] << 3, bz0 = kk[2] << 3;
+        int pl;
+        {
+            const int lx = q[0] & 7, ly = q[1] & 7, lz = q[2] & 7;
+            pl = ((lx | (ly << 3) | (lz << 6)) << 16) | (lx + 8) | ((ly + 8) << 5) | ((lz + 8) << 10);
+        }
+        float fc0 = (float)q[0], fc1 = (float)q[1], fc2 = (float)q[2];
+        float tn0 = (fc0 - gs0) * ie0, tn1 = (fc1 - gs1) * ie1, tn2 = (fc2 - gs2) * ie2;
+    float tArr = tE;
+    int pArr = pE;
+    bool pvd = false, firstVoxel = !inside, walking = true, have = false;
+    float ps = 0.0f, candT = 0.0f;
+    int prevLin = -1, candP = 0, candLin = 0, candPrev = 0;      // prevLin: a voxel of this block, or (-1) the neighbour behind the entry face
+    const Voxel *blk = dp.blocks + (size_t)bptr;
+    while (walking) {
+        int pls[kK], vp[kK];
+        float vt[kK];
+        Voxel vv[kK];
+        int n = 0;
+        bool more = true;
+#pragma unroll
+        for (int j = 0; j < kK; ++j) {
+            if (more) {
+                pls[j] = pl; vt[j] = tArr; vp[j] = pArr;
+                vv[j] = blk[(uint32_t)pl >> 16];
+                n = j + 1;
+                // the crossing that ends this voxel (raycastSDF.frag:156-170)
+                const bool m0 = tn0 < tn1 && tn0 < tn2;
+                const bool m2 = !m0 && tn2 < tn1;
+                const bool m1 = !m0 && !m2;
+                tArr = m0 ? tn0 : m2 ? tn2 : tn1;
+                pArr = m0 ? 2 : m2 ? 1 : 0;
+                pl += m0 ? d0 : m2 ? d2 : d1;
+                fc0 += m0 ? f0 : 0.0f; fc1 += m1 ? f1 : 0.0f; fc2 += m2 ? f2 : 0.0f;
+                tn0 = (fc0 - gs0) * ie0; tn1 = (fc1 - gs1) * ie1; tn2 = (fc2 - gs2) * ie2;
+                more = tArr < ra.tMax && (pl & 0x6318) == 0x2108;     // (a voxel is visited iff the ray arrives before t_max)
+            }
+        }
+        walking = more;
+#pragma unroll
+        for (int j = 0; j < kK; ++j) {
+            if (j < n) {
+                const bool valid = vv[j].weight > 0.0f;
+                const int lin = (int)((uint32_t)pls[j] >> 16);
+                if (valid && vv[j].sdf <= 0.0f) {
+                    if (firstVoxel) {
+                        // the voxel the ray was in before the entry event: one step back on the entry axis, in the neighbouring
+                        // block -- allocated iff it is in the patch's set
+                        const int vx = bx0 + (lin & 7), vy = by0 + ((lin >> 3) & 7), vz = bz0 + (lin >> 6);
+                        const int n0 = vx - (xe == 0 ? ax[0].s : 0), n1 = vy - (xe == 1 ? ax[1].s : 0), n2 = vz - (xe == 2 ? ax[2].s : 0);
+                        const int fs = coop_find(tags, coop_tag((n0 >> 3) - base0, (n1 >> 3) - base1, (n2 >> 3) - base2));
+                        pvd = false;
+                        if (fs >= 0) {
+                            const uint32_t np = ptrs[fs];
+                            if (np != (uint32_t)VH_FREE_BLOCK && np != kCoopUnresolved) {
+                                const Voxel nb = dp.blocks[(size_t)np + (size_t)(((n2 & 7) << 6) | ((n1 & 7) << 3) | (n0 & 7))];
+                                pvd = nb.weight > 0.0f; ps = nb.sdf; prevLin = -1;
+                            }
+                        }
+                    }
+                    if (pvd && ps > 0.0f) {                    // the block's first pair: nothing earlier behind it
+                        have = dda_before(vt[j], vp[j], bestT, bestP);
+                        candT = vt[j]; candP = vp[j]; candLin = lin; candPrev = prevLin & 1023;
+                        walking = false;
+                        n = j;                                 // (stops the judging)
+                    }
+                }
+                pvd = valid; ps = vv[j].sdf; prevLin = lin;
+                firstVoxel = false;
+            }
+        }
+    }
+    if (have) {
+        // Only WHERE the pair sits travels in the word (the set's slot, the voxel, the previous sample, the entry axis); depth
+        // and normal are worked out once per ray, by the wave that completes the patch.
+        const unsigned long long cand = ((unsigned long long)rc_time_key(candT) << 32) | ((unsigned long long)candP << 30) |
+                                        ((unsigned long long)slot << 22) | ((unsigned long long)candLin << 13) |
+                                        ((unsigned long long)candPrev << 3) | ((unsigned long long)xe << 1);
+        (void)__hip_atomic_fetch_min(word, cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+
+// A completed patch: its rays' words become depth (and normals), with the sequential walk's arithmetic.
+template <bool kNormals>
+__device__ __forceinline__ void coop_resolve_patch(const FrameParams &fp, const DevPtrs &dp, const RaycastArgs &ra, CoopShared &sh, int w,
+                                                   float *__restrict__ depthOut, float4 *__restrict__ normalOut)
+{
+    const int lane = threadIdx.x & 63;
+    const int org = __builtin_amdgcn_readfirstlane(sh.origin[w]);
+    const int u = (org & 0xffff) + (lane & 7), v = (org >> 16) + (lane >> 3);
+    if (u >= fp.width || v >= fp.height) return;
+    const unsigned long long word = sh.best[w][lane];
     float hit = 0.0f;
-    int hx = 0, hy = 0, hz = 0, hptr = VH_FREE_BLOCK;          // (per-lane walk: the last valid sample's voxel;) after a hit: the hit voxel and its block
-    const int prio[3] = {2, 0, 1};
-    bool coopDone = false;
-    unsigned long long stampP1 = 0ull;                        // diagnostics: the ray set-up is done
+    float4 n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (word != kCoopNone) {
+        const uint32_t *tags = sh.tag[w], *ptrs = sh.ptr[w];
+        const int slot = (int)((word >> 22) & 255ull), lin = (int)((word >> 13) & 511ull), pl = (int)((word >> 3) & 1023ull),
+                  xe = (int)((word >> 1) & 3ull);
+        const uint32_t tg = tags[slot] - 1u;
+        const int base0 = sh.base[w][0], base1 = sh.base[w][1], base2 = sh.base[w][2];
+        const int b0 = (base0 + (int)(tg & 1023u)) << 3, b1 = (base1 + (int)((tg >> 10) & 1023u)) << 3, b2 = (base2 + (int)(tg >> 20)) << 3;
+        const int vx = b0 + (lin & 7), vy = b1 + ((lin >> 3) & 7), vz = b2 + (lin >> 6);
+        const bool nb = pl == 1023;            // the voxel the ray was in before the block's entry event
+        const int s = sh.state[w][xe][lane] > 0.0f ? 1 : -1;      // the entry axis' direction (E > 0)
+        const int p0 = nb ? vx - (xe == 0 ? s : 0) : b0 + (pl & 7);
+        const int p1 = nb ? vy - (xe == 1 ? s : 0) : b1 + ((pl >> 3) & 7);
+        const int p2 = nb ? vz - (xe == 2 ? s : 0) : b2 + (pl >> 6);
+        const int hptr = (int)ptrs[slot];
+        int pptr = hptr;
+        if (nb) pptr = (int)ptrs[coop_find(tags, coop_tag((p0 >> 3) - base0, (p1 >> 3) - base1, (p2 >> 3) - base2))];     // (in the set: the walk found it there)
+        const float recSdf = dp.blocks[(size_t)hptr + (size_t)lin].sdf;
+        const float recPs = dp.blocks[(size_t)pptr + (size_t)(((p2 & 7) << 6) | ((p1 & 7) << 3) | (p0 & 7))].sdf;
+        // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
+        const float tc = ((ra.zrow[0] * (float)vx + ra.zrow[1] * (float)vy) + ra.zrow[2] * (float)vz) + ra.zrow[3];
+        const float tp = ((ra.zrow[0] * (float)p0 + ra.zrow[1] * (float)p1) + ra.zrow[2] * (float)p2) + ra.zrow[3];
+        hit = tp + ((tc - tp) * recPs) / (recPs - recSdf);
+        if (kNormals) n = dda_normal(fp, dp, vx, vy, vz, hptr);
+    }
+    depthOut[(size_t)v * fp.width + u] = hit;
+    if (kNormals) normalOut[(size_t)v * fp.width + u] = n;
+}
+
+template <bool kNormals>
+__global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_coop_kernel(const FrameParams fp, const DevPtrs dp, const RaycastArgs ra,
+                                                           float *__restrict__ depthOut, float4 *__restrict__ normalOut)
+{
+    __shared__ CoopShared sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long stamp0 = ra.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned long long stampA = stamp0, stampB = stamp0;      // diagnostics: the set is built / the list is resolved
-    int coopList = 0, coopWalks = 0;
+    // group -> patches: each XCD (workgroup index mod 8, own L2) takes a contiguous run of groups, a group's patches lie
+    // `groups` apart in the row-major patch grid
+    int g = (int)blockIdx.x;
+    if ((ra.groups & 7) == 0) g = (g & 7) * (ra.groups >> 3) + (g >> 3);
+    // wave j takes a patch of the j-th quarter of the row-major patch grid (a quarter of the rows further down), rotated inside
+    // its quarter by j quarter-rows (a quarter of a row further right): a grazing wall is a vertical band as often as a grazing
+    // floor is a horizontal one.  A rotation inside the quarter: every patch is still rendered exactly once.
+    const int gq = (g + wave * (ra.patchesX >> 2)) % ra.groups;
+    const int patch = gq + wave * ra.groups;
+    const bool hasPatch = patch < ra.numPatches;
+    const int py = patch / ra.patchesX, px = patch - py * ra.patchesX;
+    const int pu = px * 8, pv = py * 8;
+    const int u = pu + (lane & 7), v = pv + (lane >> 3);
+    const bool inImage = hasPatch && u < fp.width && v < fp.height;
     {
-        __shared__ CoopShared sh_;
-        uint32_t *tags = sh_.tag[wave], *ptrs = sh_.ptr[wave];
-        uint32_t *list = sh_.list[wave];
+        uint32_t *tags = sh.tag[wave];
 #pragma unroll
         for (int r = 0; r < kCoopSlots / 64; ++r) tags[lane + 64 * r] = 0u;
-        uint16_t *cells = sh_.cells[wave];
-        uint32_t *count = &sh_.count[wave];
-        if (lane == 0) *count = 0u;
+        sh.best[wave][lane] = kCoopNone;
+        if (lane == 0) {
+            sh.count[wave] = 0u; sh.avail[wave] = 0u; sh.taken[wave] = 0u; sh.done[wave] = 0u; sh.ready[wave] = 0u;
+            sh.origin[wave] = pu | (pv << 16);
+        }
+    }
+    __syncthreads();
+    int nList = 0, ownCount = 0, coopWalks = 0;
+    bool ownWalk = false;
+    auto publish = [&](int n) {          // the list, the rays' state and the set are in LDS before `ready` is
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) {
+            __hip_atomic_store(&sh.avail[wave], (uint32_t)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&sh.ready[wave], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    bool published = false;
+    DdaAxis ax[3];
+    int c[3];
+    float dx = 0.0f, dy = 0.0f;
+    if (hasPatch) {
+        // ---- steps 1 and 2 for this wave's own patch ----
+        dda_ray(fp, ra, u, v, ax, c, dx, dy);
+        const float vs = fp.voxelSize;
+        uint32_t *tags = sh.tag[wave], *ptrs = sh.ptr[wave];
+        uint32_t *list = sh.list[wave];
+        uint16_t *cells = sh.cells[wave];
+        uint32_t *count = &sh.count[wave];
         int nCells = 0;
         float eMin[3], eMax[3];                                    // wave-uniform: the patch's corner rays
 #pragma unroll
@@ -156,26 +404,13 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_coo
         }
         const int base0 = (__shfl(c[0], 0) >> 3) - 512, base1 = (__shfl(c[1], 0) >> 3) - 512, base2 = (__shfl(c[2], 0) >> 3) - 512;
         const float dt2 = 4.0f * vs;                               // half-block slabs
-        // the walk's per-ray constants
-        const float f0 = (float)ax[0].s, f1 = (float)ax[1].s, f2 = (float)ax[2].s;
-        // (an axis that never steps: invE = 0 would give a crossing time of 0; (c + 1e30) * inf = inf instead)
-        const float ie0 = ax[0].invE != 0.0f ? ax[0].invE : __builtin_inff(), gs0 = ax[0].invE != 0.0f ? ax[0].Gs : -1.0e30f;
-        const float ie1 = ax[1].invE != 0.0f ? ax[1].invE : __builtin_inff(), gs1 = ax[1].invE != 0.0f ? ax[1].Gs : -1.0e30f;
-        const float ie2 = ax[2].invE != 0.0f ? ax[2].invE : __builtin_inff(), gs2 = ax[2].invE != 0.0f ? ax[2].Gs : -1.0e30f;
-        const int d0 = ax[0].s * ((1 << 16) + 1), d1 = ax[1].s * ((8 << 16) + (1 << 5)), d2 = ax[2].s * ((64 << 16) + (1 << 10));
         bool fail = false;
-        float bestT = __builtin_inff();                            // arrival event of the best candidate's hit voxel
-        int bestP = 3;
-        int recW = -1;                                             // where the best candidate's pair sits (-1: none yet)
-        float recPs = 0.0f, recSdf = 0.0f;                         // its two samples
-        int nList = 0;
-        bool final_ = !inImage;
         __builtin_amdgcn_wave_barrier();
-        stampP1 = ra.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
         // A window = the slabs one pass of step 1 covers: 64 per sub-pass, up to kCoopSubs sub-passes when the range is longer
         // (finer voxels).  One window for the whole range beats several (640x480, 60 frames, per call: 2 windows of 64 slabs
         // 65.5 us, 3: 83.6, 4: 102.0 -- every window pays the front end again, and the per-lane walk behind a beam front end,
         // 58.9 / 74.3 / 92.5, was faster); what lies behind a ray's hit is then listed too, but skipped by its arrival event.
+        // A range of several windows (more than 1 024 voxels deep) lists them all before anything is walked.
         const int nSub = max(1, min(kCoopSubs, (int)__builtin_ceilf((ra.tMax - ra.tMin) / (64.0f * dt2))));
         const float window = 64.0f * (float)nSub * dt2;
         for (float tw = ra.tMin; tw < ra.tMax && !fail; tw += window) {
@@ -252,7 +487,7 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_coo
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (fail) break;
-            if (ra.stamps) stampA = __builtin_amdgcn_s_memrealtime();
+            if (ra.stamps && tw == ra.tMin) stampA = __builtin_amdgcn_s_memrealtime();
             // ---- 2. the new cells: allocated? ----
             const int listBegin = nList;
             const int cellBegin = nCells;
@@ -337,176 +572,262 @@ __global__ __launch_bounds__(64 * kDdaBlockWaves, VH_DDA_WAVES) void raycast_coo
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 }
             }
-            if (ra.stamps) { stampB = __builtin_amdgcn_s_memrealtime(); coopList = nList; }
-            // The launch is as long as its slowest wave, and the slowest waves are the ones with the longest lists: they get the
-            // issue slots first (s_setprio; 35.6 -> 32.6 us; thresholds 6/4/3, 7/5/3 and 10/7/5 measured the same).
-            {
-                const int n = nList - listBegin;
-                if (n >= 8) __builtin_amdgcn_s_setprio(3); else if (n >= 6) __builtin_amdgcn_s_setprio(2); else if (n >= 4) __builtin_amdgcn_s_setprio(1);
+            if (ra.stamps && tw == ra.tMin) stampB = __builtin_amdgcn_s_memrealtime();
+        }
+        if (fail) {
+            // the preconditions failed (a box wider than two blocks, the set full, a block too far from the first): this patch
+            // takes the per-lane walk behind the beam front end (below, once the neighbours know there is nothing to share)
+            ownWalk = true;
+            nList = 0;
+        } else if (nList == 0) {
+            if (inImage) {                       // no allocated block along any ray of the patch
+                depthOut[(size_t)v * fp.width + u] = 0.0f;
+                if (kNormals) normalOut[(size_t)v * fp.width + u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             }
-            // ---- 3. every ray against every new block of the list ----
-            // (a wave-uniform loop: the block's key and voxel pointer are scalars.  Measured alternative: every ray walking
-            // its OWN blocks, one per round -- the busiest ray of a wave enters as many blocks as the wave walks, 2.1 vs 2.2
-            // rounds, and the per-lane block pointer made it 44.7 us against 40.2)
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                sh.state[wave][a][lane] = ax[a].E;
+                sh.state[wave][3 + a][lane] = ax[a].invE;
+                sh.state[wave][6 + a][lane] = __int_as_float(c[a]);
+            }
+            if (lane == 0) { sh.base[wave][0] = base0; sh.base[wave][1] = base1; sh.base[wave][2] = base2; }
+            publish(nList);
+            published = true;
+            // ---- step 3, the owner's loop: this wave walks its own list from the front with its rays' state in registers (the
+            // loop of the one-list-per-wave form); every item is TAKEN from the patch's counter, which idle neighbours take from too
+            const int prio[3] = {2, 0, 1};
+            const float f0 = (float)ax[0].s, f1 = (float)ax[1].s, f2 = (float)ax[2].s;
+            // (an axis that never steps: invE = 0 would give a crossing time of 0; (c + 1e30) * inf = inf instead)
+            const float ie0 = ax[0].invE != 0.0f ? ax[0].invE : __builtin_inff(), gs0 = ax[0].invE != 0.0f ? ax[0].Gs : -1.0e30f;
+            const float ie1 = ax[1].invE != 0.0f ? ax[1].invE : __builtin_inff(), gs1 = ax[1].invE != 0.0f ? ax[1].Gs : -1.0e30f;
+            const float ie2 = ax[2].invE != 0.0f ? ax[2].invE : __builtin_inff(), gs2 = ax[2].invE != 0.0f ? ax[2].Gs : -1.0e30f;
+            const int d0 = ax[0].s * ((1 << 16) + 1), d1 = ax[1].s * ((8 << 16) + (1 << 5)), d2 = ax[2].s * ((64 << 16) + (1 << 10));
+            float bestT = __builtin_inff();                            // arrival event of the best candidate's hit voxel
+            int bestP = 3;
+            int recW = -1;                                             // where the best candidate's pair sits (-1: none yet)
+            float recPs = 0.0f, recSdf = 0.0f;                         // its two samples
+            // The launch is as long as its slowest waves, and those are the ones with the longest lists: they get the issue slots first
+            // (s_setprio; 35.6 -> 32.6 us in round 3).  A wave that helps with a long list runs at that list's priority (below).
+            if (nList >= 8) __builtin_amdgcn_s_setprio(3); else if (nList >= 6) __builtin_amdgcn_s_setprio(2); else if (nList >= 4) __builtin_amdgcn_s_setprio(1);
+            for (;;) {
+                uint32_t tk = 0u;
+                if (lane == 0) tk = __hip_atomic_fetch_add(&sh.taken[wave], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int t = __builtin_amdgcn_readfirstlane((int)tk);
+                if (t >= nList) break;
+                ++ownCount;
+                {
+            const int slot = __builtin_amdgcn_readfirstlane((int)(list[t] & 0xffffu));
+            const uint32_t tg = (uint32_t)__builtin_amdgcn_readfirstlane((int)tags[slot]) - 1u;
+            const int bptr = __builtin_amdgcn_readfirstlane((int)ptrs[slot]);
+            const int kk[3] = {base0 + (int)(tg & 1023u), base1 + (int)((tg >> 10) & 1023u), base2 + (int)(tg >> 20)};
+            const CoopEntry e = coop_entry(ax, c, kk, ra.tMax);
+            const float tE = e.tE;
+            const int pE = e.pE, xe = e.xe;
+            const bool inside = e.inside;
+            const bool enters = inImage && e.enters && dda_before(tE, pE, bestT, bestP);      // (not behind the best candidate so far)
+            if (__ballot(enters) == 0ull) continue;
+            ++coopWalks;
+            if (!enters) continue;
+            // the voxel the ray enters at
+            int q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int lo = kk[a] << 3, hi = lo + 7;
+                const int nearC = ax[a].s > 0 ? lo : hi, farC = ax[a].s > 0 ? hi : lo;
+                if (inside || ax[a].invE == 0.0f) q[a] = c[a];
+                else if (a == xe) q[a] = nearC;
+                else q[a] = dda_advance(ax[a], prio[a], e.startIn[a] ? c[a] : nearC, farC, tE, pE);
+            }
+            // Inside the block the walk keeps the voxel as float coordinates (exact below 2^24: the host refuses views
+            // beyond 2^23), the local position as three 5-bit fields (value 8..15 = inside: ONE mask test tells when the
+            // ray has left the block) packed with the linear voxel index, and steps all of it without a branch:
+            // ~27 vector instructions per voxel instead of ~45 with integer coordinates and per-axis branches.
+            const int bx0 = kk[0] << 3, by0 = kk[1] << 3, bz0 = kk[2] << 3;
+            int pl;
             {
-                for (int i = listBegin; i < nList; ++i) {
-                    if (__ballot(!final_) == 0ull) break;
-                    // (measured in round 4: {tag, pointer} kept in walking order beside the list, one LDS round trip here instead of three
-                    // dependent ones: 31.5 against 31.0 us -- 5 registers spilled instead of 2)
-                    const int slot = __builtin_amdgcn_readfirstlane((int)(list[i] & 0xffffu));
-                    const uint32_t tg = (uint32_t)__builtin_amdgcn_readfirstlane((int)tags[slot]) - 1u;
-                    const int bptr = __builtin_amdgcn_readfirstlane((int)ptrs[slot]);
-                    const int kk[3] = {base0 + (int)(tg & 1023u), base1 + (int)((tg >> 10) & 1023u), base2 + (int)(tg >> 20)};
-                    const CoopEntry e = coop_entry(ax, c, kk, ra.tMax);
-                    const float tE = e.tE;
-                    const int pE = e.pE, xe = e.xe;
-                    const bool inside = e.inside;
-                    const bool enters = e.enters && !final_ && dda_before(tE, pE, bestT, bestP);      // (not behind the best candidate so far)
-                    if (__ballot(enters) == 0ull) continue;
-                    ++coopWalks;
-                    if (!enters) continue;
-                    // the voxel the ray enters at
-                    int q[3];
+                const int lx = q[0] & 7, ly = q[1] & 7, lz = q[2] & 7;
+                pl = ((lx | (ly << 3) | (lz << 6)) << 16) | (lx + 8) | ((ly + 8) << 5) | ((lz + 8) << 10);
+            }
+            float fc0 = (float)q[0], fc1 = (float)q[1], fc2 = (float)q[2];
+            float tn0 = (fc0 - gs0) * ie0, tn1 = (fc1 - gs1) * ie1, tn2 = (fc2 - gs2) * ie2;
+            float tArr = tE;
+            int pArr = pE;
+            bool pv = false, firstVoxel = !inside, walking = true;
+            float ps = 0.0f;
+            int prevLin = -1;                             // the previous sample: a voxel of this block, or (-1) the neighbour behind the entry face
+            const Voxel *blk = dp.blocks + (size_t)bptr;
+            while (walking) {
+                int pls[kCoopK], vp[kCoopK];
+                float vt[kCoopK];
+                Voxel vv[kCoopK];
+                int n = 0;
+                bool more = true;
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        const int lo = kk[a] << 3, hi = lo + 7;
-                        const int nearC = ax[a].s > 0 ? lo : hi, farC = ax[a].s > 0 ? hi : lo;
-                        if (inside || ax[a].invE == 0.0f) q[a] = c[a];
-                        else if (a == xe) q[a] = nearC;
-                        else q[a] = dda_advance(ax[a], prio[a], e.startIn[a] ? c[a] : nearC, farC, tE, pE);
+                for (int j = 0; j < kCoopK; ++j) {
+                    if (more) {
+                        pls[j] = pl; vt[j] = tArr; vp[j] = pArr;
+                        vv[j] = blk[(uint32_t)pl >> 16];
+                        n = j + 1;
+                        // the crossing that ends this voxel (raycastSDF.frag:156-170)
+                        const bool m0 = tn0 < tn1 && tn0 < tn2;
+                        const bool m2 = !m0 && tn2 < tn1;
+                        const bool m1 = !m0 && !m2;
+                        tArr = m0 ? tn0 : m2 ? tn2 : tn1;
+                        pArr = m0 ? 2 : m2 ? 1 : 0;
+                        pl += m0 ? d0 : m2 ? d2 : d1;
+                        fc0 += m0 ? f0 : 0.0f; fc1 += m1 ? f1 : 0.0f; fc2 += m2 ? f2 : 0.0f;
+                        tn0 = (fc0 - gs0) * ie0; tn1 = (fc1 - gs1) * ie1; tn2 = (fc2 - gs2) * ie2;
+                        more = tArr < ra.tMax && (pl & 0x6318) == 0x2108;     // (a voxel is visited iff the ray arrives before t_max)
                     }
-                    // Inside the block the walk keeps the voxel as float coordinates (exact below 2^24: the host refuses views
-                    // beyond 2^23), the local position as three 5-bit fields (value 8..15 = inside: ONE mask test tells when the
-                    // ray has left the block) packed with the linear voxel index, and steps all of it without a branch:
-                    // ~27 vector instructions per voxel instead of ~45 with integer coordinates and per-axis branches.
-                    const int bx0 = kk[0] << 3, by0 = kk[1] << 3, bz0 = kk[2] << 3;
-                    int pl;
-                    {
-                        const int lx = q[0] & 7, ly = q[1] & 7, lz = q[2] & 7;
-                        pl = ((lx | (ly << 3) | (lz << 6)) << 16) | (lx + 8) | ((ly + 8) << 5) | ((lz + 8) << 10);
-                    }
-                    float fc0 = (float)q[0], fc1 = (float)q[1], fc2 = (float)q[2];
-                    float tn0 = (fc0 - gs0) * ie0, tn1 = (fc1 - gs1) * ie1, tn2 = (fc2 - gs2) * ie2;
-                    float tArr = tE;
-                    int pArr = pE;
-                    bool pv = false, firstVoxel = !inside, walking = true;
-                    float ps = 0.0f;
-                    int prevLin = -1;                             // the previous sample: a voxel of this block, or (-1) the neighbour behind the entry face
-                    const Voxel *blk = dp.blocks + (size_t)bptr;
-                    while (walking) {
-                        int pls[kCoopK], vp[kCoopK];
-                        float vt[kCoopK];
-                        Voxel vv[kCoopK];
-                        int n = 0;
-                        bool more = true;
+                }
+                walking = more;
 #pragma unroll
-                        for (int j = 0; j < kCoopK; ++j) {
-                            if (more) {
-                                pls[j] = pl; vt[j] = tArr; vp[j] = pArr;
-                                vv[j] = blk[(uint32_t)pl >> 16];
-                                n = j + 1;
-                                // the crossing that ends this voxel (raycastSDF.frag:156-170)
-                                const bool m0 = tn0 < tn1 && tn0 < tn2;
-                                const bool m2 = !m0 && tn2 < tn1;
-                                const bool m1 = !m0 && !m2;
-                                tArr = m0 ? tn0 : m2 ? tn2 : tn1;
-                                pArr = m0 ? 2 : m2 ? 1 : 0;
-                                pl += m0 ? d0 : m2 ? d2 : d1;
-                                fc0 += m0 ? f0 : 0.0f; fc1 += m1 ? f1 : 0.0f; fc2 += m2 ? f2 : 0.0f;
-                                tn0 = (fc0 - gs0) * ie0; tn1 = (fc1 - gs1) * ie1; tn2 = (fc2 - gs2) * ie2;
-                                more = tArr < ra.tMax && (pl & 0x6318) == 0x2108;     // (a voxel is visited iff the ray arrives before t_max)
-                            }
-                        }
-                        walking = more;
-#pragma unroll
-                        for (int j = 0; j < kCoopK; ++j) {
-                            if (j < n) {
-                                const bool valid = vv[j].weight > 0.0f;
-                                const int lin = (int)((uint32_t)pls[j] >> 16);
-                                if (valid && vv[j].sdf <= 0.0f) {
-                                    if (firstVoxel) {
-                                        const int vx = bx0 + (lin & 7), vy = by0 + ((lin >> 3) & 7), vz = bz0 + (lin >> 6);
-                                        // the voxel the ray was in before the entry event: one step back on the entry axis, in the
-                                        // neighbouring block -- allocated iff it is in the wave's set
-                                        const int n0 = vx - (xe == 0 ? ax[0].s : 0), n1 = vy - (xe == 1 ? ax[1].s : 0), n2 = vz - (xe == 2 ? ax[2].s : 0);
-                                        const int fs = coop_find(tags, coop_tag((n0 >> 3) - base0, (n1 >> 3) - base1, (n2 >> 3) - base2));
-                                        pv = false;
-                                        if (fs >= 0) {
-                                            const uint32_t np = ptrs[fs];
-                                            if (np != (uint32_t)VH_FREE_BLOCK && np != kCoopUnresolved) {
-                                                const Voxel nb = dp.blocks[(size_t)np + (size_t)(((n2 & 7) << 6) | ((n1 & 7) << 3) | (n0 & 7))];
-                                                pv = nb.weight > 0.0f; ps = nb.sdf; prevLin = -1;
-                                            }
-                                        }
-                                    }
-                                    if (pv && ps > 0.0f) {
-                                        if (dda_before(vt[j], vp[j], bestT, bestP)) {
-                                            // Only WHERE the pair sits is kept here (the set's slot, the voxel, the previous sample, the entry
-                                            // axis) with its two values; the depth is worked out once, behind the last block (below).  On a
-                                            // grazing patch some ray finds its pair at nearly every step of the wave, and the dot products and
-                                            // the division under this branch then doubled the step's instructions.
-                                            bestT = vt[j]; bestP = vp[j];
-                                            recPs = ps; recSdf = vv[j].sdf;
-                                            recW = slot | (lin << 8) | ((prevLin & 1023) << 17) | (xe << 27);
-                                        }
-                                        walking = false;                   // (the block's first pair: nothing earlier behind it)
-                                        n = j;                             // (stops the judging)
+                for (int j = 0; j < kCoopK; ++j) {
+                    if (j < n) {
+                        const bool valid = vv[j].weight > 0.0f;
+                        const int lin = (int)((uint32_t)pls[j] >> 16);
+                        if (valid && vv[j].sdf <= 0.0f) {
+                            if (firstVoxel) {
+                                const int vx = bx0 + (lin & 7), vy = by0 + ((lin >> 3) & 7), vz = bz0 + (lin >> 6);
+                                // the voxel the ray was in before the entry event: one step back on the entry axis, in the
+                                // neighbouring block -- allocated iff it is in the wave's set
+                                const int n0 = vx - (xe == 0 ? ax[0].s : 0), n1 = vy - (xe == 1 ? ax[1].s : 0), n2 = vz - (xe == 2 ? ax[2].s : 0);
+                                const int fs = coop_find(tags, coop_tag((n0 >> 3) - base0, (n1 >> 3) - base1, (n2 >> 3) - base2));
+                                pv = false;
+                                if (fs >= 0) {
+                                    const uint32_t np = ptrs[fs];
+                                    if (np != (uint32_t)VH_FREE_BLOCK && np != kCoopUnresolved) {
+                                        const Voxel nb = dp.blocks[(size_t)np + (size_t)(((n2 & 7) << 6) | ((n1 & 7) << 3) | (n0 & 7))];
+                                        pv = nb.weight > 0.0f; ps = nb.sdf; prevLin = -1;
                                     }
                                 }
-                                pv = valid; ps = vv[j].sdf; prevLin = lin;
-                                firstVoxel = false;
+                            }
+                            if (pv && ps > 0.0f) {
+                                if (dda_before(vt[j], vp[j], bestT, bestP)) {
+                                    // Only WHERE the pair sits is kept here (the set's slot, the voxel, the previous sample, the entry
+                                    // axis) with its two values; the depth is worked out once, behind the last block (below).  On a
+                                    // grazing patch some ray finds its pair at nearly every step of the wave, and the dot products and
+                                    // the division under this branch then doubled the step's instructions.
+                                    bestT = vt[j]; bestP = vp[j];
+                                    recPs = ps; recSdf = vv[j].sdf;
+                                    recW = slot | (lin << 8) | ((prevLin & 1023) << 17) | (xe << 27);
+                                }
+                                walking = false;                   // (the block's first pair: nothing earlier behind it)
+                                n = j;                             // (stops the judging)
                             }
                         }
+                        pv = valid; ps = vv[j].sdf; prevLin = lin;
+                        firstVoxel = false;
                     }
                 }
             }
-            // a candidate that arrived before this window's end cannot be beaten by a block found later
-            final_ = final_ || bestT < tw + window;
-            if (__ballot(!final_) == 0ull) break;
-        }
-        if (!fail) {
-            coopDone = true; live = false;
-            if (recW != -1) {
-                // the best candidate: its voxel and the previous sample's, from the set's slot
-                const int slot = recW & 255, lin = (recW >> 8) & 511, pl = (recW >> 17) & 1023, xe = (recW >> 27) & 3;
-                const uint32_t tg = tags[slot] - 1u;
-                const int b0 = (base0 + (int)(tg & 1023u)) << 3, b1 = (base1 + (int)((tg >> 10) & 1023u)) << 3, b2 = (base2 + (int)(tg >> 20)) << 3;
-                const int vx = b0 + (lin & 7), vy = b1 + ((lin >> 3) & 7), vz = b2 + (lin >> 6);
-                const bool nb = pl == 1023;            // the voxel the ray was in before the block's entry event
-                const int p0 = nb ? vx - (xe == 0 ? ax[0].s : 0) : b0 + (pl & 7);
-                const int p1 = nb ? vy - (xe == 1 ? ax[1].s : 0) : b1 + ((pl >> 3) & 7);
-                const int p2 = nb ? vz - (xe == 2 ? ax[2].s : 0) : b2 + (pl >> 6);
-                // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
-                const float tc = ((ra.zrow[0] * (float)vx + ra.zrow[1] * (float)vy) + ra.zrow[2] * (float)vz) + ra.zrow[3];
-                const float tp = ((ra.zrow[0] * (float)p0 + ra.zrow[1] * (float)p1) + ra.zrow[2] * (float)p2) + ra.zrow[3];
-                hit = tp + ((tc - tp) * recPs) / (recPs - recSdf);
-                found = true;
-                hx = vx; hy = vy; hz = vz; hptr = (int)ptrs[slot];
+                }
+            }
+            if (ownCount == nList) {
+                // nobody took an item of this patch: depth (and normals) straight from the registers, as the one-list-per-wave form
+                float hit = 0.0f;
+                bool found = false;
+                int hx = 0, hy = 0, hz = 0, hptr = VH_FREE_BLOCK;
+                if (recW != -1) {
+            // the best candidate: its voxel and the previous sample's, from the set's slot
+            const int slot = recW & 255, lin = (recW >> 8) & 511, pl = (recW >> 17) & 1023, xe = (recW >> 27) & 3;
+            const uint32_t tg = tags[slot] - 1u;
+            const int b0 = (base0 + (int)(tg & 1023u)) << 3, b1 = (base1 + (int)((tg >> 10) & 1023u)) << 3, b2 = (base2 + (int)(tg >> 20)) << 3;
+            const int vx = b0 + (lin & 7), vy = b1 + ((lin >> 3) & 7), vz = b2 + (lin >> 6);
+            const bool nb = pl == 1023;            // the voxel the ray was in before the block's entry event
+            const int p0 = nb ? vx - (xe == 0 ? ax[0].s : 0) : b0 + (pl & 7);
+            const int p1 = nb ? vy - (xe == 1 ? ax[1].s : 0) : b1 + ((pl >> 3) & 7);
+            const int p2 = nb ? vz - (xe == 2 ? ax[2].s : 0) : b2 + (pl >> 6);
+            // the samples sit at their voxels' centres: camera depth = row 2 of the inverse pose
+            const float tc = ((ra.zrow[0] * (float)vx + ra.zrow[1] * (float)vy) + ra.zrow[2] * (float)vz) + ra.zrow[3];
+            const float tp = ((ra.zrow[0] * (float)p0 + ra.zrow[1] * (float)p1) + ra.zrow[2] * (float)p2) + ra.zrow[3];
+            hit = tp + ((tc - tp) * recPs) / (recPs - recSdf);
+            found = true;
+            hx = vx; hy = vy; hz = vz; hptr = (int)ptrs[slot];
+                }
+                if (inImage) {
+                    depthOut[(size_t)v * fp.width + u] = hit;
+                    if (kNormals) normalOut[(size_t)v * fp.width + u] = found ? dda_normal(fp, dp, hx, hy, hz, hptr) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+            } else {
+                // neighbours walked some of the items: the rays' words hold everybody's candidates; whoever completes the patch writes it
+                if (recW != -1) {         // (this wave's own best candidate joins them: once, not per block -- per block it cost 1.5 us)
+                    const unsigned long long cand = ((unsigned long long)rc_time_key(bestT) << 32) | ((unsigned long long)bestP << 30) |
+                                                    ((unsigned long long)(recW & 255) << 22) | ((unsigned long long)((recW >> 8) & 511) << 13) |
+                                                    ((unsigned long long)((recW >> 17) & 1023) << 3) | ((unsigned long long)((recW >> 27) & 3) << 1);
+                    (void)__hip_atomic_fetch_min(&sh.best[wave][lane], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                uint32_t d = 0u;
+                if (lane == 0) d = __hip_atomic_fetch_add(&sh.done[wave], (uint32_t)ownCount, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + (uint32_t)ownCount;
+                d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                if (d == (uint32_t)nList) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    coop_resolve_patch<kNormals>(fp, dp, ra, sh, wave, depthOut, normalOut);
+                }
             }
         }
-    }    // ---- a wave whose preconditions failed: the per-lane walk behind the beam front end ----
-    unsigned long long stamp1 = stamp0;
-    int budgetUsed = 0, round = 0;
-    if (!coopDone) {
+    }
+    if (!published) publish(0);          // (no patch, an empty list, or the per-lane fall-back: nothing to share)
+    if (ownWalk) {
+        bool live = inImage;
         dda_front_end(fp, dp, ra, dx, dy, ax, c, live);
-        stamp1 = ra.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
-        const DdaHit h = dda_lane_walk<2>(fp, dp, ra, ax, c, live);
-        hit = h.hit; found = h.found; hx = h.hx; hy = h.hy; hz = h.hz; hptr = h.hptr;
-        budgetUsed = h.steps; round = h.rounds;
+        const DdaHit h = dda_lane_walk<1>(fp, dp, ra, ax, c, live);
+        if (inImage) {
+            depthOut[(size_t)v * fp.width + u] = h.hit;
+            if (kNormals) normalOut[(size_t)v * fp.width + u] = h.found ? dda_normal(fp, dp, h.hx, h.hy, h.hz, h.hptr) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
+    // ---- step 3, the idle wave's loop: take items of the neighbours' patches, walk them through LDS, complete patches ----
+    int nTaken = 0, nWalked = 0;
+    for (;;) {
+        int w = -1, k = 0;
+        bool allReady = true;
+        // the neighbour with the most items left (thresholds of 2, 3, 4, 6 items before a list is helped with: each slower)
+        int most = 0;
+        for (int r = 1; r < kDdaBlockWaves; ++r) {
+            const int w2 = (wave + r) & (kDdaBlockWaves - 1);
+            if (__hip_atomic_load(&sh.ready[w2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) { allReady = false; continue; }
+            const int left = (int)__hip_atomic_load(&sh.avail[w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) -
+                             (int)__hip_atomic_load(&sh.taken[w2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (left > most) { most = left; w = w2; }
+        }
+        if (w >= 0) {
+            const uint32_t av = __hip_atomic_load(&sh.avail[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            uint32_t t = 0u;
+            if (lane == 0) t = __hip_atomic_fetch_add(&sh.taken[w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            if (t < av) k = (int)t;
+            else continue;                        // (the owner or another neighbour was faster: look again)
+        }
+        if (w < 0) {
+            if (allReady) break;
+            __builtin_amdgcn_s_sleep(8);          // a neighbour is still listing its patch
+            continue;
+        }
+        ++nTaken;
+        if (most >= 6) __builtin_amdgcn_s_setprio(3); else if (most >= 4) __builtin_amdgcn_s_setprio(2); else if (most >= 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        bool entered = false;
+        coop_walk_item<1>(fp, dp, ra, sh, w, k, entered);
+        nWalked += entered ? 1 : 0;
+        // the item is done when its candidates are in the rays' words
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        uint32_t d = 0u;
+        if (lane == 0) d = __hip_atomic_fetch_add(&sh.done[w], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+        d = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+        if (d == __hip_atomic_load(&sh.avail[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            coop_resolve_patch<kNormals>(fp, dp, ra, sh, w, depthOut, normalOut);
+        }
     }
     if (ra.stamps && lane == 0) {
-        const size_t w = ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kDdaBlockWaves + wave) * 8;
-        ra.stamps[w] = stamp0; ra.stamps[w + 1] = __builtin_amdgcn_s_memrealtime();
-        ra.stamps[w + 2] = coopDone ? (stampP1 - stamp0) : (unsigned long long)budgetUsed | ((unsigned long long)round << 32); ra.stamps[w + 3] = (unsigned long long)(pu | (pv << 16)) | ((stamp1 - stamp0) << 32);
-        ra.stamps[w + 4] = stampA - stamp0; ra.stamps[w + 5] = stampB - stamp0; ra.stamps[w + 6] = (unsigned long long)coopList; ra.stamps[w + 7] = (unsigned long long)coopWalks;
+        const size_t wd = ((size_t)blockIdx.x * kDdaBlockWaves + wave) * 8;
+        ra.stamps[wd] = stamp0; ra.stamps[wd + 1] = __builtin_amdgcn_s_memrealtime();
+        ra.stamps[wd + 2] = (unsigned long long)ownCount | ((unsigned long long)nTaken << 32); ra.stamps[wd + 3] = (unsigned long long)(pu | (pv << 16));
+        ra.stamps[wd + 4] = stampA - stamp0; ra.stamps[wd + 5] = stampB - stamp0; ra.stamps[wd + 6] = (unsigned long long)nList;
+        ra.stamps[wd + 7] = (unsigned long long)coopWalks | ((unsigned long long)nWalked << 32);
     }
-    if (!inImage) return;
-    depthOut[(size_t)v * fp.width + u] = hit;
-    if (!kNormals) return;
-    // ---- normal of the hit: TSDF gradient at the hit voxel, normalised, camera frame, w = 0 ----
-    float4 n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (found) n = dda_normal(fp, dp, hx, hy, hz, hptr);
-    normalOut[(size_t)v * fp.width + u] = n;
 }
 
 }  // namespace vh
