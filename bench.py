@@ -782,7 +782,7 @@ def main():
                   achieved_gbs=round(ray_bytes / (raycast_us * 1e-6) / 1e9, 1) if raycast_us > 0 else None,
                   note="kernel_us is the mean HIP-event duration over the same poses as the end-to-end loop")
         rc["roofline"] = raycast_roofline(name, raycast_us, Wd, Ht)
-        rc["traversal"] = ("voxel DDA (raycastSDF.frag:121-177 re-specified; cooperative form: one block list per wave), "
+        rc["traversal"] = ("voxel DDA (raycastSDF.frag:121-177 re-specified; cooperative form: one block list per 8x8 patch, idle waves of a workgroup take items of its other patches), "
                            "vh_set_option raycast_mode = VH_RAYCAST_DDA, the default")
         # the same poses with the normal map written by the same pass, and with the fixed-step march of rounds 1-2
         normals = torch.empty((Ht, Wd, 4), dtype=torch.float32, device=dev)
@@ -875,8 +875,8 @@ def main():
             c3_it.table.set_profiling(False)
             c3_rec["raycast"] = dict(kernel_us=stats["dda"], kernel_mpix_per_s=round(W3 * H3 / stats["dda"], 1), poses=20,
                                      variants_kernel_us={"fixed_step_march": stats["fixed_step_march"]},
-                                     traversal="voxel DDA; form chosen by the view (raycast_beam 3): 64 half-block slabs do not span "
-                                               "0.1-5 m at 5 mm voxels, so every ray walks behind its wave's beam front end")
+                                     traversal="voxel DDA; form chosen by the view (raycast_beam 3): at 5 mm voxels 0.1-5 m is one window of "
+                                               "4 x 64 half-block slabs, so the cooperative form runs (lists shared inside the workgroup)")
             del d3
         extra["configs"] = {"C3": c3_rec}
         c3_it.close()

@@ -618,11 +618,13 @@ static int raycast_impl(vh_context *c, const float pose[16], float t_min, float 
         if (!(reach < 8388608.0)) return fail(VH_ERR_INVALID_ARGUMENT, "view reaches beyond 2^23 voxels from the origin");
         ra.invVs = 1.0f / fp.voxelSize;
         ra.stamps = reinterpret_cast<unsigned long long *>(c->raycastStamps);
-        // Which form: the cooperative one wins where a wave's 64 half-block slabs span the depth range (C2's 2 cm voxels:
-        // 29 us against 46 for the per-lane walk behind the beam front end); with finer voxels a patch's beam meets many more,
-        // smaller blocks and the per-lane walk is ahead (640x480, voxels of 10 / 7.5 / 5 mm: 56 / 70 / 88 us against 59 / 77 / 96).
+        // Which form: the cooperative one where ONE pass of its beam step covers the depth range -- 64 x kCoopSubs half-block slabs
+        // (C2's 2 cm voxels: 5 m in one sub-pass; C3's 5 mm voxels: 4.9 m in four).  Round 6, with the lists shared inside the
+        // workgroup (1280x960 views of the 5 mm model after 300 / 1 000 / 2 000 poses): 242 / 302 / 312 us against 238 / 319 / 335
+        // for the per-lane walk behind the beam front end -- equal on a sparse model, ahead on a dense one (before the sharing the
+        // per-lane walk was ahead at 5 mm: 151 against 175 us).  Longer ranges (several windows) keep the per-lane walk.
         int beam = c->raycastBeam;
-        if (beam == 3) beam = (t_max - t_min) <= 64.0f * 4.0f * fp.voxelSize ? 2 : 1;
+        if (beam == 3) beam = (t_max - t_min) <= 64.0f * (float)kCoopSubs * 4.0f * fp.voxelSize ? 2 : 1;
         ra.beam = t_min > 0.0f ? beam : 0;
         float4 *nrm = reinterpret_cast<float4 *>(d_normals_out);
         const dim3 block(64 * kDdaBlockWaves);
