@@ -1,5 +1,6 @@
 """The DDA raycast on the GPU (vh_raycast / vh_raycast_normals, raycast_mode = VH_RAYCAST_DDA): every form the kernel has --
-the cooperative form (one block list per wave), the per-lane walk behind the beam front end, the per-lane walk from t_min --
+the cooperative form (one block list per 8x8 patch; idle waves of a workgroup take items of its other patches through LDS and
+merge candidates with a 64-bit atomicMin per ray), the per-lane walk behind the beam front end, the per-lane walk from t_min --
 must give the oracle's bits (oracle/vh_oracle.c: vho_raycast_dda, which walks voxel by voxel and leaves absent blocks only
 through exact look-ups), depth and normals, also where the cooperative form falls back (boxes wider than two blocks, views
 with t_min = 0, several depth windows)."""
@@ -77,6 +78,34 @@ def test_small_voxels_wide_beams_and_odd_image_sizes(oracle, vh, torch_cuda):
         assert (od > 0).mean() > 0.2
         gt.close()
         ot.close()
+
+
+def test_shared_lists_give_the_same_image_every_time(oracle, vh, torch_cuda):
+    """Who walks which listed block of the cooperative form is a race by design (idle waves take items of their workgroup's other
+    patches); the image must not be: the same views 60 times each, with normals, while another stream keeps most of the chip busy
+    in bursts (so that waves finish in ever different orders) -- every repetition bit-equal to the oracle's image."""
+    torch = torch_cuda
+    W, H = 640, 480
+    ot, gt, poses = _room(oracle, vh, torch, W, H, 0.02, 1 << 18, 1 << 14, (0, 3, 6, 9, 30, 33, 60, 63))
+    d = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    n = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    hog, L = torch.cuda.Stream(), vh.load()
+    covered = 0.0
+    for pose in (poses[31], poses[5], synth.yaw_pose(200.0, (0.3, 0.1, -0.4))):
+        od, on = ot.raycast(pose, 0.1, 5.0, normals=True)
+        covered = max(covered, float((od > 0).mean()))
+        for rep in range(60):
+            if rep % 10 == 5:
+                assert L.vh_debug_occupy(gt._h, hog.cuda_stream, 1024, 300) == 0       # 0.3 ms of a half-full chip beside the next raycasts
+            d.fill_(-1.0)
+            gt.raycast_normals(pose, d, n, 0.1, 5.0)
+            gt.synchronize()
+            assert np.array_equal(_bits(d.cpu().numpy()), _bits(od)), rep
+            assert np.array_equal(_bits(n.cpu().numpy()), _bits(on)), rep
+    torch.cuda.synchronize()
+    assert covered > 0.3
+    gt.close()
+    ot.close()
 
 
 def test_views_the_dda_refuses_and_option_checks(vh, torch_cuda):
