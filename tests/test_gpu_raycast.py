@@ -80,6 +80,27 @@ def test_small_voxels_wide_beams_and_odd_image_sizes(oracle, vh, torch_cuda):
         ot.close()
 
 
+@pytest.mark.parametrize("W,H", [(8, 8), (24, 8), (72, 40), (136, 104), (1920, 1080)])
+def test_patch_grids_of_every_shape(oracle, vh, torch_cuda, W, H):
+    """The cooperative form deals 8x8-pixel patches to workgroups four at a time, a quarter of the patch grid apart: grids of one
+    patch, of fewer patches than a workgroup has waves, with a patch count that is not a multiple of four or of a row, and C5's
+    1920x1080 -- every pixel written exactly once, bit-equal to the oracle (depth and normals)."""
+    torch = torch_cuda
+    ot, gt, poses = _room(oracle, vh, torch, W, H, 0.02, 1 << 16, 1 << 13, (0, 4))
+    gt.set_option("raycast_beam", 2)
+    d = torch.full((H, W), -3.0, dtype=torch.float32, device="cuda")
+    n = torch.full((H, W, 4), -3.0, dtype=torch.float32, device="cuda")
+    for pose in (poses[2], poses[4]):
+        od, on = ot.raycast(pose, 0.1, 5.0, normals=True)
+        d.fill_(-3.0)
+        n.fill_(-3.0)
+        gt.raycast_normals(pose, d, n, 0.1, 5.0)
+        gt.synchronize()
+        assert np.array_equal(_bits(d.cpu().numpy()), _bits(od)) and np.array_equal(_bits(n.cpu().numpy()), _bits(on)), (W, H)
+    gt.close()
+    ot.close()
+
+
 def test_shared_lists_give_the_same_image_every_time(oracle, vh, torch_cuda):
     """Who walks which listed block of the cooperative form is a race by design (idle waves take items of their workgroup's other
     patches); the image must not be: the same views 60 times each, with normals, while another stream keeps most of the chip busy
