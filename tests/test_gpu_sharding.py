@@ -302,7 +302,7 @@ def _hip_gloo_worker(rank, world, port, q, sensor):
         q.put((rank, "fail", traceback.format_exc(), str(e)))
 
 
-@pytest.mark.parametrize("sensor", [False, True])
+@pytest.mark.parametrize("sensor", [True])      # (float packets between two processes: tests/test_gpu_dist_rccl.py [2-1-False-False])
 def test_two_processes_on_one_gpu(oracle, vh, torch_cuda, sensor):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
