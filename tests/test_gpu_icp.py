@@ -287,3 +287,46 @@ def test_raycast_maps_is_raycast_plus_depth_to_maps(oracle, vh, torch_cuda):
     assert np.array_equal(vm.cpu().numpy().view(np.uint32), ov.view(np.uint32))
     assert np.array_equal(nm.cpu().numpy().view(np.uint32), on.view(np.uint32))
     assert (on[..., :3] != 0).any(axis=-1).sum() > 10000
+
+
+@pytest.mark.parametrize("size", [(320, 240), (640, 480)])
+def test_one_launch_align_equals_the_chain_of_rounds(vh, torch_cuda, size, monkeypatch):
+    """vh_icp_align runs all rounds in ONE launch (icp_align_kernel: input points in registers, the estimate handed from
+    round to round through memory, a grid-wide wait per round); VH_ICP_PERSISTENT=0 at vh_icp_create keeps the chain of
+    one-launch rounds.  Same partition of the pixels, same order of additions, same solve: the transform, the last
+    system and the round count are bit-equal -- for a full Align, for one cut short by max_iters, and for the two stop
+    conditions (summed residual exactly 0, CameraTracking.cpp:52; singular system)."""
+    from voxelhashing_demo_amd import tracking
+    torch = torch_cuda
+    w, h = size
+    prims, poses, K = synth.room_primitives(), synth.camera_loop(250), synth.K_matrix(w, h)
+    kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    v = {i: synth.render_room_verts(poses[i], w, h, prims, device="cuda") for i in (10, 12, 100, 101)}
+    maps = {}
+    for i in (10, 100):
+        tp, tn = torch.empty_like(v[i]), torch.empty_like(v[i])
+        tracking.depth_to_maps(v[i][..., 2].contiguous(), kinv, tp, tn)
+        maps[i] = (tp, tn)
+    nothing = torch.zeros_like(v[100])
+    results = {}
+    for form in ("one_launch", "chain"):
+        if form == "chain":
+            monkeypatch.setenv("VH_ICP_PERSISTENT", "0")
+        out = []
+        for flags in (0, 3):
+            for iters in (20, 7, 1):
+                trk = tracking.CameraTracking(w, h, K, flags=flags, max_iters=iters)
+                d = trk.Align(v[101], *maps[100]).copy()                          # a real step of the camera
+                out.append((d, trk.last, trk.iterations))
+                d = trk.Align(v[101], maps[100][0], nothing).copy()               # a target without normals: residual 0, stop
+                out.append((d, trk.last, trk.iterations))
+                assert trk.iterations == 0 and np.array_equal(d, np.eye(4, dtype=np.float32))
+                d = trk.Align(v[12], *maps[10]).copy()                            # one flat wall: singular (or barely not)
+                out.append((d, trk.last, trk.iterations))
+                trk.close()
+        results[form] = out
+    assert results["one_launch"][0][2] == 20 and results["one_launch"][0][1][3] > 0.5 * w * h
+    for a, b in zip(results["one_launch"], results["chain"]):
+        assert a[2] == b[2]
+        assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+        assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a[1], b[1]))

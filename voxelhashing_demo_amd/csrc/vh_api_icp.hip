@@ -10,8 +10,25 @@ struct vh_icp {
     float *partials = nullptr;     // [blocks][32]
     IcpState *state = nullptr;     // device-resident Align state
     IcpState *hostState = nullptr; // pinned copy
-    int blocks = 0;
+    int blocks = 0;                // grid of icp_round_kernel
+    int alignBlocks = 0, alignSlots = 0;   // grid of icp_align_kernel and pixels per lane there; 0 slots: Align is a chain of rounds
+    unsigned long long *records = nullptr, *pub = nullptr;   // one-launch Align: [alignBlocks][32] sums, [8][16] estimate, each word {value, seq}
+    int seqBase = 0;                       // sequence numbers handed out so far (they only grow: nothing is reset between calls)
+    unsigned long long *stamps = nullptr;  // diagnostics (VH_ICP_STAMPS=1): [round][8] time stamps of the one-launch Align
 };
+
+constexpr int kIcpAlignMaxBlocks = 1024;
+constexpr int kIcpAlignMaxSlots = 8;
+
+static const void *icp_align_entry(int slots)
+{
+    switch (slots) {
+#define VH_ICP_ALIGN(S) case S: return (const void *)icp_align_kernel<S>;
+    VH_ICP_ALIGN(1) VH_ICP_ALIGN(2) VH_ICP_ALIGN(3) VH_ICP_ALIGN(4) VH_ICP_ALIGN(5) VH_ICP_ALIGN(6) VH_ICP_ALIGN(7) VH_ICP_ALIGN(8)
+#undef VH_ICP_ALIGN
+    default: return nullptr;
+    }
+}
 
 extern "C" int vh_icp_create(int32_t width, int32_t height, int32_t device, vh_icp **out)
 {
@@ -32,11 +49,40 @@ extern "C" int vh_icp_create(int32_t width, int32_t height, int32_t device, vh_i
     const int maxBlocks = grid_for((size_t)width * height, kIcpThreads);
     p->blocks = std::min(maxBlocks, 256);                      // one workgroup per compute unit
     if (const char *e = std::getenv("VH_ICP_BLOCKS")) p->blocks = std::max(1, std::min(maxBlocks, std::atoi(e)));   // tuning knob
+    // Align in one launch: the round kernel's grid when a lane then holds at most six pixels (640x480: 256 workgroups, five
+    // pixels -- the same partition, hence the same sums, as the chain of rounds), else five pixels per lane on up to 1 024
+    // workgroups; larger images (> 2.6 M pixels at eight per lane) keep the chain.  VH_ICP_PERSISTENT=0: always the chain (A/B).
+    const size_t npix = (size_t)width * height;
+    auto slots_for = [&](int blocks) { return (int)((npix + (size_t)blocks * kIcpThreads - 1) / ((size_t)blocks * kIcpThreads)); };
+    p->alignBlocks = p->blocks;
+    if (slots_for(p->alignBlocks) > 6)
+        p->alignBlocks = std::min(kIcpAlignMaxBlocks, (int)((npix + kIcpThreads * 5 - 1) / (kIcpThreads * 5)));
+    p->alignSlots = slots_for(p->alignBlocks);
+    if (p->alignSlots > kIcpAlignMaxSlots || p->alignBlocks > kIcpAlignMaxBlocks) p->alignSlots = 0;
+    if (p->alignSlots > 0) {
+        // the one-launch Align waits on its own grid: every workgroup must be resident at once (half of what the occupancy
+        // of this build allows at most, so that a neighbour on another stream does not turn the wait into a time-out)
+        int perCu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, icp_align_entry(p->alignSlots), kIcpThreads, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            2 * p->alignBlocks > perCu * cus)
+            p->alignSlots = 0;
+    }
+    if (const char *e = std::getenv("VH_ICP_PERSISTENT")) if (std::atoi(e) == 0) p->alignSlots = 0;
+    if (std::getenv("VH_ICP_STAMPS")) (void)hipMalloc((void **)&p->stamps, sizeof(unsigned long long) * (512 + 1024));
     hipError_t e = hipMalloc((void **)&p->partials, sizeof(float) * kIcpStride * (size_t)p->blocks);
+    const size_t recordBytes = sizeof(unsigned long long) * kIcpStride * (size_t)p->alignBlocks;
+    const size_t pubBytes = sizeof(unsigned long long) * kIcpPubCopies * kIcpPubStride;
+    if (e == hipSuccess) e = hipMalloc((void **)&p->records, recordBytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&p->pub, pubBytes);
+    if (e == hipSuccess) e = hipMemset(p->records, 0, recordBytes);
+    if (e == hipSuccess) e = hipMemset(p->pub, 0, pubBytes);
     if (e == hipSuccess) e = hipMalloc((void **)&p->state, sizeof(IcpState));
     if (e == hipSuccess) e = hipHostMalloc((void **)&p->hostState, sizeof(IcpState), hipHostMallocDefault);
     if (e != hipSuccess) {
         if (p->partials) (void)hipFree(p->partials);
+        if (p->records) (void)hipFree(p->records);
+        if (p->pub) (void)hipFree(p->pub);
         if (p->state) (void)hipFree(p->state);
         delete p;
         return fail(e == hipErrorOutOfMemory ? VH_ERR_OUT_OF_MEMORY : VH_ERR_HIP, "icp workspace", e);
@@ -51,7 +97,10 @@ extern "C" int vh_icp_destroy(vh_icp *p)
     DeviceGuard guard(p->device);
     (void)hipDeviceSynchronize();      // not p->stream: the caller's stream object may already be gone
     (void)hipFree(p->partials);
+    (void)hipFree(p->records);
+    (void)hipFree(p->pub);
     (void)hipFree(p->state);
+    if (p->stamps) (void)hipFree(p->stamps);
     (void)hipHostFree(p->hostState);
     delete p;
     return VH_OK;
@@ -169,14 +218,48 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
     ip.width = p->width;
     ip.height = p->height;
     ip.flags = flags;
-    for (int it = 0; it < max_iters; ++it)
-        icp_round_kernel<false><<<p->blocks, kIcpThreads, 0, p->stream>>>(
-            ip, reinterpret_cast<const float4 *>(d_input), reinterpret_cast<const float4 *>(d_target),
-            reinterpret_cast<const float4 *>(d_target_normals), p->partials, (float4 *)nullptr, (float4 *)nullptr,
-            (float *)nullptr, p->state, 1, 1);
+    const float4 *in = reinterpret_cast<const float4 *>(d_input), *tg = reinterpret_cast<const float4 *>(d_target),
+                 *tn = reinterpret_cast<const float4 *>(d_target_normals);
+    if (p->alignSlots > 0 && max_iters > 0) {
+        // one launch for all rounds (icp_align_kernel); ~2^20 polls of ~1 us before a workgroup gives up
+        const uint32_t spinLimit = 1u << 20;
+        if (p->seqBase > (1 << 30)) {          // (after 5 * 10^7 calls: start the numbers again behind cleared words)
+            VH_HIP(hipMemsetAsync(p->records, 0, sizeof(unsigned long long) * kIcpStride * (size_t)p->alignBlocks, p->stream));
+            VH_HIP(hipMemsetAsync(p->pub, 0, sizeof(unsigned long long) * kIcpPubCopies * kIcpPubStride, p->stream));
+            p->seqBase = 0;
+        }
+        const int seqBase = p->seqBase;
+        p->seqBase += max_iters;
+        static const int reducerNap = std::getenv("VH_ICP_NAP") ? std::atoi(std::getenv("VH_ICP_NAP")) : 2;   // x 512 cycles
+        void *args[] = {(void *)&ip, (void *)&in, (void *)&tg, (void *)&tn, (void *)&p->records, (void *)&p->pub, (void *)&p->state,
+                        (void *)&max_iters, (void *)&seqBase, (void *)&spinLimit, (void *)&reducerNap, (void *)&p->stamps};
+        VH_HIP(hipLaunchKernel(icp_align_entry(p->alignSlots), dim3(p->alignBlocks), dim3(kIcpThreads), args, 0, p->stream));
+    } else {
+        for (int it = 0; it < max_iters; ++it)
+            icp_round_kernel<false><<<p->blocks, kIcpThreads, 0, p->stream>>>(ip, in, tg, tn, p->partials, (float4 *)nullptr,
+                                                                             (float4 *)nullptr, (float *)nullptr, p->state, 1, 1);
+    }
     VH_HIP(hipGetLastError());
     VH_HIP(hipMemcpyAsync(&hs, p->state, sizeof hs, hipMemcpyDeviceToHost, p->stream));
     VH_HIP(hipStreamSynchronize(p->stream));
+    if (p->stamps && p->alignSlots > 0 && max_iters > 0 && max_iters <= 64) {          // diagnostics: microseconds since the round started
+        unsigned long long st[64 * 8];
+        VH_HIP(hipMemcpy(st, p->stamps, sizeof(unsigned long long) * 8 * max_iters, hipMemcpyDeviceToHost));
+        for (int r = 0; r < max_iters; ++r) {
+            std::fprintf(stderr, "icp stamps round %2d:", r);
+            for (int i = 1; i < 8; ++i) std::fprintf(stderr, " [%d] %6.2f", i, ((double)st[8 * r + i] - (double)st[8 * r]) * 0.01);
+            if (r + 1 < max_iters) std::fprintf(stderr, "  next round %6.2f", ((double)st[8 * r + 8] - (double)st[8 * r]) * 0.01);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    if (p->stamps && p->alignSlots > 0 && max_iters > 11) {          // round 10: when each workgroup had stored its record
+        static unsigned long long st[512 + 1024];
+        VH_HIP(hipMemcpy(st, p->stamps, sizeof st, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "icp stamps round 10, record stored (us after workgroup 0 started the round), by workgroup:");
+        for (int b = 0; b < p->alignBlocks; ++b) std::fprintf(stderr, "%s%5.2f", b % 16 ? " " : "\n  ", ((double)st[512 + b] - (double)st[80]) * 0.01);
+        std::fprintf(stderr, "\n");
+    }
+    if (hs.timeout) return fail(VH_ERR_TIMEOUT, "vh_icp_align: a workgroup of the one-launch Align gave up waiting for a round's estimate");
     std::memcpy(delta, hs.delta, 16 * sizeof(float));
     if (last) system_from_sums(hs.sums, last);
     // rounds that solved = systems built, minus the one that hit a stop condition (the oracle's count)

@@ -33,7 +33,9 @@ struct IcpState {
     int32_t rounds;      // rounds executed (systems built)
     int32_t done;        // 1: stop (summed residual exactly 0, CameraTracking.cpp:52, or singular system)
     int32_t singular;
-    int32_t ticket;      // workgroups of the running round that have stored their partial record
+    int32_t ticket;      // workgroups of the running round that have stored their partial record (icp_round_kernel)
+    int32_t timeout;     // a workgroup of the one-launch Align gave up waiting (vh_icp_align reports VH_ERR_TIMEOUT)
+    int32_t pad[3];
 };
 
 // ---- SE3 (SE3.cpp:4-22): twist = (v, w), M = [[0,-w2,w1,v0],[w2,0,-w0,v1],[-w1,w0,0,v2],0]; the
@@ -101,39 +103,44 @@ __host__ __device__ inline void se3_log_d(const double T[16], double twist[6])
     twist[3] = w[0]; twist[4] = w[1]; twist[5] = w[2];
 }
 
-// update = -(JTJ^-1 JTr) by Cholesky (Solver.cpp:104-105); false when JTJ is not positive definite.
+// update = -(JTJ^-1 JTr) (Solver.cpp:104-105) by an LDL^T factorisation; false when JTJ is not positive definite (a pivot
+// <= 0: the same criterion as a Cholesky factorisation's, whose pivots are these).  Six divisions and no square root -- the
+// solve runs on ONE lane between two rounds of Align, so every IEEE double division (~15 dependent instructions) and square
+// root on its chain is paid by the whole chip; as Cholesky (6 square roots, 27 divisions) it was 4 us of a 16 us round.
 __host__ __device__ inline bool icp_update_d(const double JTJ[36], const double JTr[6], double x[6])
 {
-    double L[36], y[6];
+    double L[36], Wd[36], inv[6], y[6];      // L unit lower triangular, Wd[i][k] = L[i][k] d[k], inv[k] = 1 / d[k]
     VH_UNROLL
-    for (int i = 0; i < 36; ++i) L[i] = 0.0;
+    for (int i = 0; i < 36; ++i) { L[i] = 0.0; Wd[i] = 0.0; }
     VH_UNROLL
-    for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) {
+        double s = JTJ[6 * j + j];
         VH_UNROLL
-        for (int j = 0; j <= i; ++j) {
-            double s = JTJ[6 * i + j];
+        for (int k = 0; k < j; ++k) s -= Wd[6 * j + k] * L[6 * j + k];
+        if (!(s > 0.0)) return false;
+        inv[j] = 1.0 / s;
+        VH_UNROLL
+        for (int i = j + 1; i < 6; ++i) {
+            double t = JTJ[6 * i + j];
             VH_UNROLL
-            for (int k = 0; k < j; ++k) s -= L[6 * i + k] * L[6 * j + k];
-            if (i == j) {
-                if (!(s > 0.0)) return false;
-                L[6 * i + i] = sqrt(s);
-            } else {
-                L[6 * i + j] = s / L[6 * j + j];
-            }
+            for (int k = 0; k < j; ++k) t -= Wd[6 * i + k] * L[6 * j + k];
+            Wd[6 * i + j] = t;
+            L[6 * i + j] = t * inv[j];
         }
+    }
     VH_UNROLL
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 6; ++i) {              // L y = -JTr
         double s = -JTr[i];
         VH_UNROLL
         for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
-        y[i] = s / L[6 * i + i];
+        y[i] = s;
     }
     VH_UNROLL
-    for (int i = 5; i >= 0; --i) {
-        double s = y[i];
+    for (int i = 5; i >= 0; --i) {             // L^T x = D^-1 y
+        double s = y[i] * inv[i];
         VH_UNROLL
         for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
-        x[i] = s / L[6 * i + i];
+        x[i] = s;
     }
     return true;
 }
@@ -220,34 +227,136 @@ __device__ __forceinline__ bool icp_pair(const IcpParams &ip, const float q[3], 
     return (ip.flags & kIcpAbsDistance) ? (__builtin_fabsf(d) < ip.distThres) : (d < ip.distThres);   // :170
 }
 
-// Sum over the 64 lanes of a wave, result in lane 63: an inclusive scan in DPP steps (row_shr 1, 2,
-// 4, 8 inside each row of 16 lanes, then row_bcast:15 and row_bcast:31 carry the row totals on), six
-// VALU instructions and no LDS traffic per term; __shfl_xor goes through ds_bpermute and made the 29
-// reductions a visible part of the round.
-template <int kCtrl, int kRowMask>
+// The workgroup's sum of each of the 29 terms.  Every lane leaves its terms in LDS ([term][lane], rows 260 floats apart: the
+// eight terms a wave reads then start in different banks), eight lanes per term add 32 values each (float4 reads, lane `sub`
+// of a term takes every 8th group of four) and meet in three DPP adds (xor 1, xor 2, mirror of 8) -- ~80 instructions per lane.
+// (Rounds 2-5 reduced each term across the wave with six DPP adds and the four waves through LDS: 29 x 6 DPP steps with their
+// wait states, 430 instructions as compiled, 1.5 us of a round.)  Returns to lanes 8t .. 8t + 7 the sum of term t (t < 29; 0
+// beyond).  A fixed order of additions: the sums are reproducible run to run.
+constexpr int kIcpRow = kIcpThreads + 4;
+constexpr int kIcpSumFloats = kIcpTerms * kIcpRow;
+
+template <int kCtrl>
 __device__ __forceinline__ float dpp_take(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, kRowMask, 0xf, false));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), kCtrl, 0xf, 0xf, false));
 }
 
-__device__ __forceinline__ float wave_sum_lane63(float v)
+__device__ __forceinline__ float icp_workgroup_sums(const float acc[kIcpTerms], float *lds)
 {
-    v += dpp_take<0x111, 0xf>(v);
-    v += dpp_take<0x112, 0xf>(v);
-    v += dpp_take<0x114, 0xf>(v);
-    v += dpp_take<0x118, 0xf>(v);
-    v += dpp_take<0x142, 0xa>(v);
-    v += dpp_take<0x143, 0xc>(v);
+#pragma unroll
+    for (int k = 0; k < kIcpTerms; ++k) lds[k * kIcpRow + threadIdx.x] = acc[k];
+    __syncthreads();
+    const int term = threadIdx.x >> 3, sub = threadIdx.x & 7;
+    float v = 0.0f;
+    if (term < kIcpTerms) {
+        const float4 *row = reinterpret_cast<const float4 *>(lds + term * kIcpRow);
+#pragma unroll
+        for (int j = 0; j < kIcpThreads / 32; ++j) {
+            const float4 x = row[8 * j + sub];
+            v += x.x; v += x.y; v += x.z; v += x.w;
+        }
+    }
+    v += dpp_take<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_take<0x141>(v);       // row_half_mirror
     return v;
 }
 
+// CalculateJacobians, Solver.cu:27-35: J = [n, target x n]; the row's 21 + 6 products, d and 1 into the running sums
+__device__ __forceinline__ void icp_accumulate(float acc[kIcpTerms], const float4 tt, const float4 nn, const float d)
+{
+    const float J[6] = {nn.x, nn.y, nn.z, tt.y * nn.z - tt.z * nn.y, tt.z * nn.x - tt.x * nn.z, tt.x * nn.y - tt.y * nn.x};
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * d;
+    acc[27] += d;
+    acc[28] += 1.0f;
+}
+
+// The workgroup's 29 sums -> one partial record, then a ticket from `ticket`; returns the ticket to every lane.
+__device__ __forceinline__ int icp_store_record(const float acc[kIcpTerms], float *lds, int *drawn,
+                                                float *__restrict__ partials, int32_t *ticket)
+{
+    const float v = icp_workgroup_sums(acc, lds);
+    // (a device-scope store: coherent across the XCDs by itself)
+    if ((threadIdx.x & 7) == 0)
+        __hip_atomic_store(&partials[(size_t)blockIdx.x * kIcpStride + (threadIdx.x >> 3)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the record is complete before the ticket is drawn: every wave's stores have been acknowledged (s_waitcnt), no cache
+    // write-back -- round 4: an agent-scope release here is an L2 write-back per workgroup, which the chip serves one at
+    // a time (vh_icp_align of 20 rounds, same box: 350 us with __threadfence() here, 312 us with this)
+    // This hand-off is NOT a release / acquire pair of the HIP memory model: it rests on gfx942 / gfx950 behaviour -- an
+    // agent-scope relaxed atomic store is a write-through (sc1) store, complete for every XCD once s_waitcnt has seen it
+    // acknowledged, and the reader's agent-scope atomic loads (sc1) never hit a stale line of their own L2
+    // (MI355X_MICROARCH.md, valid forms: "every store of the handed-off bytes sc1 and drained before the counter, every
+    // load of them an sc1 load").  RULE: every store a workgroup makes before its ticket must be such an atomic store; a
+    // plain store added here, or another architecture (a separate store counter), needs __threadfence() back.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "vh_icp.hip: the ticket hand-off without a cache write-back is only valid on gfx942 / gfx950 (see the comment above)"
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) *drawn = atomicAdd(ticket, 1);
+    __syncthreads();
+    return *drawn;
+}
+
+// The workgroup that drew the last ticket adds the records in a fixed order -- so the sums are reproducible run to run:
+// lane (part, k) of the 256 adds every 8th record, then the 8 parts; total[0..31] in LDS for every lane afterwards.  The
+// records are read 16 at a time into registers so that the loads are in flight together (one dependent load after the
+// other cost 40 us here); they were written by other compute units before their ticket, and this workgroup's L1 has never
+// held them.
+__device__ __forceinline__ void icp_sum_records(const float *__restrict__ partials, const int numRecords,
+                                                float (*sm)[kIcpStride], float *total)
+{
+    const int k = threadIdx.x & (kIcpStride - 1), part = threadIdx.x >> 5;
+    float s = 0.0f;
+    for (int b0 = part; b0 < numRecords; b0 += 8 * 16) {
+        float r[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int b = b0 + 8 * u;
+            r[u] = (b < numRecords) ? __hip_atomic_load(&partials[(size_t)b * kIcpStride + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += r[u];
+    }
+    sm[part][k] = s;
+    __syncthreads();
+    if (threadIdx.x < kIcpStride) {
+        float v = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) v += sm[p][threadIdx.x];
+        total[threadIdx.x] = v;
+    }
+    __syncthreads();
+}
+
+// The 6x6 system from the 29 sums and one step of the estimate, T <- exp(update) T; false: singular.
+__device__ __forceinline__ bool icp_step_from_sums(const float *total, double T[16])
+{
+    double JTJ[36], JTr[6];
+    int t = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) {
+            JTJ[6 * a + b] = JTJ[6 * b + a] = (double)total[t];
+            ++t;
+        }
+    for (int a = 0; a < 6; ++a) JTr[a] = (double)total[21 + a];
+    return icp_step_matrix_d(JTJ, JTr, T);
+}
+
 // One launch per round.  256-lane workgroups (one per compute unit) stride over the pixels and keep the 29 terms in
-// registers; each wave reduces them with DPP adds, the four waves combine through LDS and the
-// workgroup stores one partial record.  The last workgroup to finish (ticket) adds the records in a
-// fixed order -- so the sums are reproducible run to run -- and, when `solve` is set, lane 0 solves
-// the 6x6 system in double and advances the estimate in the device-resident state, so the next
-// round starts without the host (the reference returns to the host three times per round,
-// Solver.cpp:83,89 and CameraTrackingUtils.cu:212).
+// registers; every workgroup stores one partial record (icp_store_record); the last one to finish adds the records
+// (icp_sum_records) and, when `solve` is set, its lane 0 solves the 6x6 system in double and advances the estimate in the
+// device-resident state, so the next round starts without the host (the reference returns to the host three times per
+// round, Solver.cpp:83,89 and CameraTrackingUtils.cu:212).  The step API (vh_icp_build_system, computeCorrespondences)
+// and the Align of images too large for icp_align_kernel run on it.
 //   useState: take the estimate from state->delta (Align) instead of ip.delta (step API)
 //   corres / corresNormals / residuals: nullptr, or the maps computeCorrespondences fills
 template <bool kWriteMaps>
@@ -259,9 +368,11 @@ __global__ __launch_bounds__(kIcpThreads) void icp_round_kernel(IcpParams ip, co
                                                         float *__restrict__ residuals, IcpState *__restrict__ state,
                                                         int useState, int solve)
 {
-    __shared__ float sm[kIcpThreads / kWave][kIcpStride];
+    __shared__ float4 sums4[kIcpSumFloats / 4];
+    __shared__ float sm[8][kIcpStride];
     __shared__ float total[kIcpStride];
-    __shared__ int isLast;
+    __shared__ int drawn;
+    float *sums = reinterpret_cast<float *>(sums4);
     if (useState) {
         if (state->done) return;
 #pragma unroll
@@ -300,21 +411,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_round_kernel(IcpParams ip, co
             const int idx = base + u * stride;
             float d = 0.0f;
             const bool kept = ok[u] && icp_pair(ip, q[u], t[u], n[u], d);
-            if (kept) {
-                // CalculateJacobians, Solver.cu:27-35: J = [n, target x n]
-                const float4 tt = t[u], nn = n[u];
-                const float J[6] = {nn.x, nn.y, nn.z, tt.y * nn.z - tt.z * nn.y, tt.z * nn.x - tt.x * nn.z,
-                                    tt.x * nn.y - tt.y * nn.x};
-                int k = 0;
-#pragma unroll
-                for (int a = 0; a < 6; ++a)
-#pragma unroll
-                    for (int b = a; b < 6; ++b) acc[k++] += J[a] * J[b];
-#pragma unroll
-                for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * d;
-                acc[27] += d;
-                acc[28] += 1.0f;
-            }
+            if (kept) icp_accumulate(acc, t[u], n[u], d);
             if constexpr (kWriteMaps) {   // the reference clears the maps first (:198-200), then writes the kept ones
                 if (idx < npix) {
                     const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -325,88 +422,237 @@ __global__ __launch_bounds__(kIcpThreads) void icp_round_kernel(IcpParams ip, co
             }
         }
     }
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kIcpTerms; ++k) {
-        const float v = wave_sum_lane63(acc[k]);
-        if (lane == kWave - 1) sm[wave][k] = v;
-    }
-    __syncthreads();
-    // the record is stored, released and ticketed by wave 0 alone: an agent-scope release writes the
-    // L2 of this XCD back, and executed by all 256 lanes of 512 workgroups it cost 40 us per round
-    if (wave == 0) {
-        if (threadIdx.x < kIcpStride) {
-            float v = 0.0f;
-#pragma unroll
-            for (int w = 0; w < kIcpThreads / kWave; ++w) v += sm[w][threadIdx.x];
-            // (a device-scope store: coherent across the XCDs by itself)
-            __hip_atomic_store(&partials[(size_t)blockIdx.x * kIcpStride + threadIdx.x], (threadIdx.x < kIcpTerms) ? v : 0.0f,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // the record is complete before the ticket is drawn: the wave's stores have been acknowledged (s_waitcnt), no cache
-        // write-back -- round 4: an agent-scope release here is an L2 write-back per workgroup, which the chip serves one at
-        // a time (vh_icp_align of 20 rounds, same box: 350 us with __threadfence() here, 312 us with this)
-        // This hand-off is NOT a release / acquire pair of the HIP memory model: it rests on gfx942 / gfx950 behaviour -- an
-        // agent-scope relaxed atomic store is a write-through (sc1) store, complete for every XCD once s_waitcnt has seen it
-        // acknowledged, and the reader's agent-scope atomic loads (sc1) never hit a stale line of their own L2
-        // (MI355X_MICROARCH.md, valid forms: "every store of the handed-off bytes sc1 and drained before the counter, every
-        // load of them an sc1 load").  RULE: every store a workgroup makes before its ticket must be such an atomic store; a
-        // plain store added here, or another architecture (a separate store counter), needs __threadfence() back.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
-#error "vh_icp.hip: the ticket hand-off without a cache write-back is only valid on gfx942 / gfx950 (see the comment above)"
-#endif
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_s_waitcnt(0);
-        if (threadIdx.x == 0) isLast = atomicAdd(&state->ticket, 1) == (int)gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!isLast) return;
-
-    // last workgroup: lane (part, k) of the first 256 adds every 8th record, then the 8 parts.  The
-    // records are read 16 at a time into registers so that the loads are in flight together (one
-    // dependent load after the other cost 40 us here); they were written by other compute units
-    // before their ticket, and this workgroup's L1 has never held them.
-    const int k = threadIdx.x & (kIcpStride - 1), part = threadIdx.x >> 5;
-    const int numRecords = (int)gridDim.x;
-    if (threadIdx.x < 256) {
-        float s = 0.0f;
-        for (int b0 = part; b0 < numRecords; b0 += 8 * 16) {
-            float r[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int b = b0 + 8 * u;
-                r[u] = (b < numRecords) ? __hip_atomic_load(&partials[(size_t)b * kIcpStride + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) s += r[u];
-        }
-        sm[part][k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < kIcpStride) {
-        float v = 0.0f;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) v += sm[p][threadIdx.x];
-        total[threadIdx.x] = v;
-        state->sums[threadIdx.x] = v;
-    }
-    __syncthreads();
+    if (icp_store_record(acc, sums, &drawn, partials, &state->ticket) != (int)gridDim.x - 1) return;
+    icp_sum_records(partials, (int)gridDim.x, sm, total);
+    if (threadIdx.x < kIcpStride) state->sums[threadIdx.x] = total[threadIdx.x];
     if (threadIdx.x != 0) return;
     state->ticket = 0;
     state->rounds += 1;
     if (!solve) return;
     if (total[27] == 0.0f) { state->done = 1; return; }                 // CameraTracking.cpp:52
-    double JTJ[36], JTr[6], T[16];
-    int t = 0;
-    for (int a = 0; a < 6; ++a)
-        for (int b = a; b < 6; ++b) {
-            JTJ[6 * a + b] = JTJ[6 * b + a] = (double)total[t];
-            ++t;
-        }
-    for (int a = 0; a < 6; ++a) JTr[a] = (double)total[21 + a];
+    double T[16];
     for (int i = 0; i < 16; ++i) T[i] = state->T[i];
-    if (!icp_step_matrix_d(JTJ, JTr, T)) { state->done = 1; state->singular = 1; return; }
+    if (!icp_step_from_sums(total, T)) { state->done = 1; state->singular = 1; return; }
     for (int i = 0; i < 16; ++i) { state->T[i] = T[i]; state->delta[i] = (float)T[i]; }
+}
+
+// ---- All rounds of an Align in ONE launch (vh_icp_align).  The chain of one-launch rounds pays per round a launch gap and
+// ramp, the input points again, 256 tickets drawn from one address and the solve between two launches; here the grid
+// stays: a lane keeps its kSlots input points in registers for all rounds (the same pixels, the same order of additions and
+// the same per-workgroup sums as icp_round_kernel with this grid, added in the same order: bit-identical to the chain,
+// tests/test_gpu_icp.py), and nothing is counted -- every 8-byte word handed between workgroups carries its own sequence
+// number {value : float, seq : int}, written and read as ONE 64-bit agent-scope access, so a reader that finds the
+// round's number has that word after one round trip (no store-then-flag, no flag-then-load: each would be a dependent trip):
+//   project + gather (the maps sit in the XCD's L2 from round 1 on) -> the workgroup's 29 sums as 29 such words ->
+//   workgroup 0 polls all records (lane (part, k) term k of every 8th record: icp_sum_records' partition), adds, its lane 0
+//   solves and publishes the next estimate as 12 such words (eight copies, a copy per blockIdx & 7, so that the polls of
+//   256 workgroups do not meet on one memory channel) -> everyone polls its copy.
+// Sequence numbers grow over the life of the vh_icp (seqBase), so nothing is ever reset.  A grid-wide wait: every workgroup
+// must be resident (vh_icp_create sizes the grid to half of what the chip holds at this kernel's occupancy) and every poll
+// loop is bounded -- workgroup 0 giving up publishes the stop itself, another one sets state->timeout and leaves; the call
+// returns VH_ERR_TIMEOUT.
+constexpr int kIcpPubCopies = 8, kIcpPubStride = 16;      // words per copy (12 used; 128 bytes apart)
+
+__device__ __forceinline__ unsigned long long icp_word(const float v, const int seq)
+{
+    return (unsigned long long)__builtin_bit_cast(unsigned, v) | ((unsigned long long)(unsigned)seq << 32);
+}
+__device__ __forceinline__ unsigned long long icp_load_word(const unsigned long long *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void icp_store_word(unsigned long long *p, const unsigned long long w)
+{
+    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int kSlots>
+__global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, const float4 *__restrict__ input,
+                                                                const float4 *__restrict__ target,
+                                                                const float4 *__restrict__ normals,
+                                                                unsigned long long *__restrict__ records,
+                                                                unsigned long long *__restrict__ pub,
+                                                                IcpState *__restrict__ state, const int maxIters,
+                                                                const int seqBase, const uint32_t spinLimit,
+                                                                const int reducerNap,
+                                                                unsigned long long *__restrict__ stamps)
+{
+    // diagnostics (VH_ICP_STAMPS=1): s_memrealtime (100 MHz) per round, workgroup 0: [0] round starts, [1] sums in registers,
+    // [2] record stored, [3] all records seen, [4] added, [5] next estimate published; the last workgroup: [6] round starts, [7] record stored
+#define VH_ICP_STAMP(i) do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[(size_t)round * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    __shared__ float4 sums4[kIcpSumFloats / 4];
+    __shared__ float sm[8][kIcpStride];
+    __shared__ float total[kIcpStride];
+    __shared__ double sT[16];            // workgroup 0: the estimate in double
+    float *sums = reinterpret_cast<float *>(sums4);
+    __shared__ float sDelta[12];         // rows 0..2 of the estimate the running round uses
+    __shared__ int go, seenBy;
+    const int npix = ip.width * ip.height, stride = gridDim.x * kIcpThreads, base = blockIdx.x * kIcpThreads + threadIdx.x;
+    const int numBlocks = (int)gridDim.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    float4 p[kSlots];
+#pragma unroll
+    for (int u = 0; u < kSlots; ++u) p[u] = (base + u * stride < npix) ? input[base + u * stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (threadIdx.x < 16) {                                   // written by the host's copy before the launch
+        const double t = state->T[threadIdx.x];
+        sT[threadIdx.x] = t;
+        if (threadIdx.x < 12) sDelta[threadIdx.x] = (float)t;
+    }
+    __syncthreads();
+    for (int round = 0; round < maxIters; ++round) {
+        const int want = seqBase + round + 1;
+        const bool finalRound = round == maxIters - 1;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) ip.delta[i] = sDelta[i];
+        VH_ICP_STAMP(0);
+        if (stamps && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) stamps[(size_t)round * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        float acc[kIcpTerms];
+#pragma unroll
+        for (int k = 0; k < kIcpTerms; ++k) acc[k] = 0.0f;
+        float4 t[kSlots], n[kSlots];
+        float q[kSlots][3];
+        int ti[kSlots];
+        bool ok[kSlots];
+#pragma unroll
+        for (int u = 0; u < kSlots; ++u) {
+            ti[u] = 0;
+            ok[u] = (base + u * stride < npix) && icp_project(ip, p[u], q[u], ti[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < kSlots; ++u) {
+            t[u] = target[ti[u]];
+            n[u] = normals[ti[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kSlots; ++u) {
+            float d = 0.0f;
+            if (ok[u] && icp_pair(ip, q[u], t[u], n[u], d)) icp_accumulate(acc, t[u], n[u], d);
+        }
+        VH_ICP_STAMP(1);
+        {
+            const float v = icp_workgroup_sums(acc, sums);
+            if ((threadIdx.x & 7) == 0 && threadIdx.x < 8 * kIcpTerms)
+                icp_store_word(&records[(size_t)blockIdx.x * kIcpStride + (threadIdx.x >> 3)], icp_word(v, want));
+        }
+        VH_ICP_STAMP(2);
+        if (stamps && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) stamps[(size_t)round * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+        if (stamps && round == 10 && threadIdx.x == 0) stamps[512 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x != 0) {
+            if (finalRound) return;
+            // wait for the estimate of the next round (or the stop): the copy of this workgroup's octet
+            // all four waves poll, a quarter of a round trip apart (the first to see it tells the others through LDS): the
+            // estimate is noticed a quarter of a poll after it lands, not half of one
+            {
+                const unsigned long long *word = pub + (size_t)(blockIdx.x & (kIcpPubCopies - 1)) * kIcpPubStride + (lane < 12 ? lane : 0);
+                if (threadIdx.x == 0) seenBy = 0;
+                __builtin_amdgcn_s_sleep(64);         // (nothing can be there before the slowest record, the sum and the solve)
+                __syncthreads();
+                for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(8);
+                int verdict = 0;                      // 0 timeout, 1 go, -1 stop
+                for (uint32_t it = 0; it < spinLimit; ++it) {
+                    const unsigned long long w = icp_load_word(word);
+                    const int seq = (int)(w >> 32);
+                    if (__builtin_amdgcn_ballot_w64(seq != want && seq != -want) == 0ull) {
+                        verdict = seq > 0 ? 1 : -1;
+                        if (lane < 12) sDelta[lane] = __builtin_bit_cast(float, (unsigned)w);      // (every wave that sees it writes the same words)
+                        if (lane == 0) { go = verdict == 1; __hip_atomic_store(&seenBy, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                        break;
+                    }
+                    if (__hip_atomic_load(&seenBy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { verdict = 2; break; }
+                }
+                if (verdict == 0 && lane == 0) {
+                    __hip_atomic_store(&state->timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    go = 0;
+                }
+            }
+            __syncthreads();
+            if (!go) return;
+            continue;
+        }
+        // ---- workgroup 0: all records of this round, added in icp_sum_records' order
+        const int k = threadIdx.x & (kIcpStride - 1), part = threadIdx.x >> 5;
+        const int kk = k < kIcpTerms ? k : 0;               // (lanes 29..31 of a part ride along on term 0)
+        float s = 0.0f;
+        bool timedOut = false;
+        // The workgroups finish a round within ~0.5 us of each other and a stored word takes ~0.7 us to be visible: a pass over
+        // the records started at once finds the late ones missing and costs a second pass (~1.2 us each); started a little later
+        // one pass finds them all.
+        for (int i = 0; i < reducerNap; ++i) __builtin_amdgcn_s_sleep(8);
+        for (int b0 = part; b0 < numBlocks; b0 += 8 * 32) {
+            // a word that has been seen is kept; every pass asks again only for the missing ones, so the pass that finds the
+            // slowest workgroup's record is a round trip of a few loads, not of all 32
+            float r[32];
+            uint32_t missing = 0xffffffffu;
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if (b0 + 8 * u >= numBlocks) { r[u] = 0.0f; missing &= ~(1u << u); }
+            bool seen = false;
+            for (uint32_t it = 0; it < spinLimit && !seen; ++it) {
+                // (in two halves of 16 words -- registers; a half nobody in the wave misses anything of is skipped)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (__builtin_amdgcn_ballot_w64((missing >> (16 * h) & 0xffffu) != 0u) == 0ull) continue;
+                    unsigned long long w[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int b = b0 + 8 * (16 * h + u);
+                        w[u] = icp_load_word(&records[(size_t)(b < numBlocks ? b : b0) * kIcpStride + kk]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const bool here = (int)(w[u] >> 32) == want && b0 + 8 * (16 * h + u) < numBlocks;
+                        r[16 * h + u] = here ? __builtin_bit_cast(float, (unsigned)w[u]) : r[16 * h + u];
+                        missing = here ? missing & ~(1u << (16 * h + u)) : missing;
+                    }
+                }
+                seen = __syncthreads_and(missing == 0u) != 0;
+            }
+            if (!seen) { timedOut = true; break; }
+#pragma unroll
+            for (int u = 0; u < 32; ++u) s += r[u];
+        }
+        VH_ICP_STAMP(3);
+        sm[part][k] = s;
+        __syncthreads();
+        if (threadIdx.x < kIcpStride) {
+            float v = 0.0f;
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) v += sm[q8][threadIdx.x];
+            total[threadIdx.x] = v;
+            __hip_atomic_store(&state->sums[threadIdx.x], threadIdx.x < kIcpTerms ? v : 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        VH_ICP_STAMP(4);
+        if (threadIdx.x == 0) {
+            double T[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) T[i] = sT[i];
+            int done = 0, singular = 0;
+            if (timedOut) { done = 1; __hip_atomic_store(&state->timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            else if (total[27] == 0.0f) done = 1;                              // CameraTracking.cpp:52
+            else if (!icp_step_from_sums(total, T)) done = singular = 1;       // (T untouched)
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { sT[i] = T[i]; sDelta[i] = (float)T[i]; }
+            go = !done;
+            if (done || finalRound) {                       // what the host reads when the launch has ended (write-through
+                                                            // like every store to the state in this kernel: no dirty line of it
+                                                            // in any L2 that a late write-back could lay over another's word)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __hip_atomic_store(&state->T[i], T[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&state->delta[i], (float)T[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __hip_atomic_store(&state->rounds, timedOut ? round : round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&state->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&state->singular, singular, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        if (!finalRound && threadIdx.x < kIcpPubCopies * kIcpPubStride && (threadIdx.x & (kIcpPubStride - 1)) < 12)
+            icp_store_word(pub + threadIdx.x, icp_word(sDelta[threadIdx.x & (kIcpPubStride - 1)], go ? want : -want));
+        VH_ICP_STAMP(5);
+        if (!go || finalRound) return;
+    }
+#undef VH_ICP_STAMP
 }
 
 // float depth image in metres -> vertex + normal maps: preProcess (CameraTrackingUtils.cu:50-113)
