@@ -102,6 +102,8 @@ def parse_args():
                     help="force the bucket-range-sharded path (torch.distributed) even with one rank")
     a = ap.parse_args()
     legs = set(ALL_LEGS) if a.legs == "all" else set() if a.legs == "none" else set(a.legs.split(","))
+    if legs - set(ALL_LEGS):
+        ap.error("--legs: unknown leg(s) " + ",".join(sorted(legs - set(ALL_LEGS))) + "; known: " + ",".join(ALL_LEGS))
     if a.no_cpu_baseline:
         legs.discard("cpu")
     if a.raycast_steps <= 0:

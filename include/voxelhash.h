@@ -100,7 +100,8 @@ enum {
     VH_ERR_HIP = 4,              /* any other HIP runtime failure; see vh_last_error() */
     VH_ERR_NOT_INITIALISED = 5,  /* drop-in call before deviceAllocate() */
     VH_ERR_SINGULAR = 6,         /* vh_icp_solve: J^T J is not positive definite */
-    VH_ERR_TIMEOUT = 7           /* workgroups of a serialised one-launch frame (overflow list, option "pipeline_overflow") gave up waiting
+    VH_ERR_TIMEOUT = 7           /* vh_icp_align: a workgroup of the one-launch Align gave up waiting for the others (the call may be
+                                  * repeated).  Frames: workgroups of a serialised one-launch frame (overflow list, option "pipeline_overflow") gave up waiting
                                   * for the pending frame's commit phase (option "spin_limit"): frames queued since the last successful
                                   * synchronisation have lost work.  Returned ONCE, by the first call that synchronises with the host and
                                   * sees the counter (vh_synchronize, vh_download*, vh_dist_flush); vh_get_counters reports the count
@@ -612,13 +613,17 @@ int vh_icp_correspondences(vh_icp *icp, const vh_float4 *d_input, const vh_float
                            const vh_float4 *d_target_normals, const float delta[16], const float K[9],
                            float dist_thres, int32_t flags, vh_float4 *d_corres, vh_float4 *d_corres_normals,
                            float *d_residuals, vh_icp_system *out);
-/* Host only.  update = -(JTJ^-1 JTr) by Cholesky, estimate = log(exp(update) exp(estimate)) with
+/* Host only.  update = -(JTJ^-1 JTr) by an LDL^T factorisation, estimate = log(exp(update) exp(estimate)) with
  * twists (v, w) as in SE3.cpp:4-22.  VH_ERR_SINGULAR leaves the estimate untouched. */
 int  vh_icp_solve(const vh_icp_system *sys, double estimate[6]);
 void vh_se3_exp(const double twist[6], double T[16]);
 void vh_se3_log(const double T[16], double twist[6]);
 /* Up to max_iters rounds (the reference: 20) from the start value in `delta`, which receives the
- * result; stops early when the summed residual is exactly 0 (:52) or the system is singular. */
+ * result; stops early when the summed residual is exactly 0 (:52) or the system is singular.
+ * All rounds run in ONE launch whose workgroups wait for each other between rounds (images up to
+ * ~650 000 pixels; larger ones, or VH_ICP_PERSISTENT=0 in the environment at vh_icp_create, run one
+ * launch per round -- same result, bit for bit).  The waits are bounded: VH_ERR_TIMEOUT when a
+ * workgroup gave up (another kernel holding the chip for about a second), `delta` is then untouched. */
 int vh_icp_align(vh_icp *icp, const vh_float4 *d_input, const vh_float4 *d_target,
                  const vh_float4 *d_target_normals, const float K[9], float dist_thres, int32_t max_iters,
                  int32_t flags, float delta[16], vh_icp_system *last, int32_t *iterations);

@@ -330,3 +330,32 @@ def test_one_launch_align_equals_the_chain_of_rounds(vh, torch_cuda, size, monke
         assert a[2] == b[2]
         assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
         assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(a[1], b[1]))
+
+
+def test_one_launch_align_gives_up_instead_of_hanging(vh, torch_cuda, monkeypatch):
+    """The one-launch Align waits on its own grid; every wait is bounded.  With a limit of ONE poll (VH_ICP_SPIN_LIMIT at
+    vh_icp_create) the workgroups give up before workgroup 0 can have solved: the call returns VH_ERR_TIMEOUT, leaves the
+    caller's transform alone, and the next call on a workspace with the normal limit works -- nothing left over from the
+    abandoned one gets in its way (the sequence numbers only grow)."""
+    from voxelhashing_demo_amd import _lib as L
+    from voxelhashing_demo_amd import tracking
+    torch = torch_cuda
+    prims, poses, K = synth.room_primitives(), synth.camera_loop(250), synth.K_matrix(W, H)
+    kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    v0 = synth.render_room_verts(poses[100], W, H, prims, device="cuda")
+    v1 = synth.render_room_verts(poses[101], W, H, prims, device="cuda")
+    tp, tn = torch.empty_like(v0), torch.empty_like(v0)
+    tracking.depth_to_maps(v0[..., 2].contiguous(), kinv, tp, tn)
+    good = tracking.CameraTracking(W, H, K, flags=3)
+    want = good.Align(v1, tp, tn).copy()
+    monkeypatch.setenv("VH_ICP_SPIN_LIMIT", "1")
+    hasty = tracking.CameraTracking(W, H, K, flags=3)
+    monkeypatch.delenv("VH_ICP_SPIN_LIMIT")
+    for _ in range(3):
+        before = hasty.delta.copy()
+        with pytest.raises(L.VoxelHashError, match="gave up"):
+            hasty.Align(v1, tp, tn)
+        assert np.array_equal(hasty.delta, before)
+        assert np.array_equal(good.Align(v1, tp, tn), want)
+    hasty.close()
+    good.close()

@@ -263,7 +263,7 @@ extern "C" const char *vh_error_string(int code)
         case VH_ERR_HIP: return "HIP runtime error";
         case VH_ERR_NOT_INITIALISED: return "deviceAllocate() has not been called";
         case VH_ERR_SINGULAR: return "singular linear system";
-        case VH_ERR_TIMEOUT: return "a serialised launch gave up waiting (spin_limit): frames have lost work";
+        case VH_ERR_TIMEOUT: return "workgroups of a launch that waits on itself gave up waiting (serialised frame: frames have lost work; vh_icp_align: call again)";
         default: return "unknown error";
     }
 }

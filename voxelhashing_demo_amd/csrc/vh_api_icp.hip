@@ -13,6 +13,7 @@ struct vh_icp {
     int blocks = 0;                // grid of icp_round_kernel
     int alignBlocks = 0, alignSlots = 0;   // grid of icp_align_kernel and pixels per lane there; 0 slots: Align is a chain of rounds
     unsigned long long *records = nullptr, *pub = nullptr;   // one-launch Align: [alignBlocks][32] sums, [8][16] estimate, each word {value, seq}
+    uint32_t spinLimit = 1u << 20;         // polls (~1 us each) before a workgroup of the one-launch Align gives up; VH_ICP_SPIN_LIMIT
     int seqBase = 0;                       // sequence numbers handed out so far (they only grow: nothing is reset between calls)
     unsigned long long *stamps = nullptr;  // diagnostics (VH_ICP_STAMPS=1): [round][8] time stamps of the one-launch Align
 };
@@ -69,6 +70,7 @@ extern "C" int vh_icp_create(int32_t width, int32_t height, int32_t device, vh_i
             p->alignSlots = 0;
     }
     if (const char *e = std::getenv("VH_ICP_PERSISTENT")) if (std::atoi(e) == 0) p->alignSlots = 0;
+    if (const char *e = std::getenv("VH_ICP_SPIN_LIMIT")) p->spinLimit = (uint32_t)std::max(1, std::atoi(e));   // (tests: 1 = the time-out path)
     if (std::getenv("VH_ICP_STAMPS")) (void)hipMalloc((void **)&p->stamps, sizeof(unsigned long long) * (512 + 1024));
     hipError_t e = hipMalloc((void **)&p->partials, sizeof(float) * kIcpStride * (size_t)p->blocks);
     const size_t recordBytes = sizeof(unsigned long long) * kIcpStride * (size_t)p->alignBlocks;
@@ -221,8 +223,8 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
     const float4 *in = reinterpret_cast<const float4 *>(d_input), *tg = reinterpret_cast<const float4 *>(d_target),
                  *tn = reinterpret_cast<const float4 *>(d_target_normals);
     if (p->alignSlots > 0 && max_iters > 0) {
-        // one launch for all rounds (icp_align_kernel); ~2^20 polls of ~1 us before a workgroup gives up
-        const uint32_t spinLimit = 1u << 20;
+        // one launch for all rounds (icp_align_kernel)
+        const uint32_t spinLimit = p->spinLimit;
         if (p->seqBase > (1 << 30)) {          // (after 5 * 10^7 calls: start the numbers again behind cleared words)
             VH_HIP(hipMemsetAsync(p->records, 0, sizeof(unsigned long long) * kIcpStride * (size_t)p->alignBlocks, p->stream));
             VH_HIP(hipMemsetAsync(p->pub, 0, sizeof(unsigned long long) * kIcpPubCopies * kIcpPubStride, p->stream));

@@ -60,10 +60,30 @@ __host__ __device__ inline void skew_terms(const double w[3], double Kx[9], doub
 __host__ __device__ inline void se3_exp_d(const double twist[6], double T[16])
 {
     const double *v = twist, *w = twist + 3;
-    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
-    double A, B, Cc;                       // sin(t)/t, (1-cos t)/t^2, (t-sin t)/t^3
-    if (th < 1e-5) { A = 1.0 - th2 / 6.0; B = 0.5 - th2 / 24.0; Cc = 1.0 / 6.0 - th2 / 120.0; }
-    else { A = sin(th) / th; B = (1.0 - cos(th)) / th2; Cc = (th - sin(th)) / (th2 * th); }
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double A, B, Cc;                       // sin(t)/t, (1-cos t)/t^2, (t-sin t)/t^3: even functions of t
+    if (th2 < 0.25) {
+        // their power series in t^2, nine terms (the tenth is below 2^-64 of the first for t < 0.5): an ICP update is a small
+        // rotation, and on the device this runs on one lane between two rounds of Align -- no square root, no sin / cos
+        // (some 400 double instructions) and none of the three divisions of the closed forms
+        // 1/(2n+1)!, 1/(2n+2)!, 1/(2n+3)! for n = 0..8, alternating signs, Horner in t^2
+        const double fA[9] = {1.0, 1.0 / 6, 1.0 / 120, 1.0 / 5040, 1.0 / 362880, 1.0 / 39916800, 1.0 / 6227020800.0,
+                              1.0 / 1307674368000.0, 1.0 / 355687428096000.0};
+        const double fB[9] = {1.0 / 2, 1.0 / 24, 1.0 / 720, 1.0 / 40320, 1.0 / 3628800, 1.0 / 479001600, 1.0 / 87178291200.0,
+                              1.0 / 20922789888000.0, 1.0 / 6402373705728000.0};
+        const double fC[9] = {1.0 / 6, 1.0 / 120, 1.0 / 5040, 1.0 / 362880, 1.0 / 39916800, 1.0 / 6227020800.0,
+                              1.0 / 1307674368000.0, 1.0 / 355687428096000.0, 1.0 / 121645100408832000.0};
+        A = fA[8]; B = fB[8]; Cc = fC[8];
+        VH_UNROLL
+        for (int n = 7; n >= 0; --n) {
+            A = fA[n] - th2 * A;
+            B = fB[n] - th2 * B;
+            Cc = fC[n] - th2 * Cc;
+        }
+    } else {
+        const double th = sqrt(th2);
+        A = sin(th) / th; B = (1.0 - cos(th)) / th2; Cc = (th - sin(th)) / (th2 * th);
+    }
     double Kx[9], K2[9];
     skew_terms(w, Kx, K2);
     VH_UNROLL
@@ -106,7 +126,7 @@ __host__ __device__ inline void se3_log_d(const double T[16], double twist[6])
 // update = -(JTJ^-1 JTr) (Solver.cpp:104-105) by an LDL^T factorisation; false when JTJ is not positive definite (a pivot
 // <= 0: the same criterion as a Cholesky factorisation's, whose pivots are these).  Six divisions and no square root -- the
 // solve runs on ONE lane between two rounds of Align, so every IEEE double division (~15 dependent instructions) and square
-// root on its chain is paid by the whole chip; as Cholesky (6 square roots, 27 divisions) it was 4 us of a 16 us round.
+// root on its chain is paid by the whole chip (as Cholesky: 6 square roots, 27 divisions; a 20-round Align 326 -> 296 us).
 __host__ __device__ inline bool icp_update_d(const double JTJ[36], const double JTr[6], double x[6])
 {
     double L[36], Wd[36], inv[6], y[6];      // L unit lower triangular, Wd[i][k] = L[i][k] d[k], inv[k] = 1 / d[k]
