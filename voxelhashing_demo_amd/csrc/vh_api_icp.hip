@@ -9,7 +9,8 @@ struct vh_icp {
     hipStream_t stream = nullptr;
     float *partials = nullptr;     // [blocks][32]
     IcpState *state = nullptr;     // device-resident Align state
-    IcpState *hostState = nullptr; // pinned copy
+    IcpState *hostState = nullptr; // pinned copy (the one-launch Align writes its result here itself)
+    IcpState *hostStateDev = nullptr;   // ... under this address
     int blocks = 0;                // grid of icp_round_kernel
     int alignBlocks = 0, alignSlots = 0;   // grid of icp_align_kernel and pixels per lane there; 0 slots: Align is a chain of rounds
     unsigned long long *records = nullptr, *pub = nullptr;   // one-launch Align: [alignBlocks][32] sums, [8][16] estimate, each word {value, seq}
@@ -80,7 +81,8 @@ extern "C" int vh_icp_create(int32_t width, int32_t height, int32_t device, vh_i
     if (e == hipSuccess) e = hipMemset(p->records, 0, recordBytes);
     if (e == hipSuccess) e = hipMemset(p->pub, 0, pubBytes);
     if (e == hipSuccess) e = hipMalloc((void **)&p->state, sizeof(IcpState));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&p->hostState, sizeof(IcpState), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&p->hostState, sizeof(IcpState), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&p->hostStateDev, p->hostState, 0);
     if (e != hipSuccess) {
         if (p->partials) (void)hipFree(p->partials);
         if (p->records) (void)hipFree(p->records);
@@ -192,9 +194,10 @@ extern "C" int vh_icp_solve(const vh_icp_system *sys, double estimate[6])
     return VH_OK;
 }
 
-// CameraTracking::Align, CameraTracking.cpp:27-69.  All rounds are queued at once: round i's
-// finalize pass solves the system on the device and leaves the new estimate where round i+1 reads
-// it; rounds after a stop condition fall through.  One copy and one synchronisation at the end.
+// CameraTracking::Align, CameraTracking.cpp:27-69.  One launch runs all rounds (icp_align_kernel: the start value in the
+// kernel arguments, the result written into the pinned host record, one synchronisation); images it does not take run a
+// chain of one-launch rounds queued at once: round i's last workgroup solves the system on the device and leaves the new
+// estimate where round i+1 reads it, rounds after a stop condition fall through, one copy each way.
 extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4 *d_target,
                             const vh_float4 *d_target_normals, const float K[9], float dist_thres, int32_t max_iters,
                             int32_t flags, float delta[16], vh_icp_system *last, int32_t *iterations)
@@ -212,7 +215,10 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
     se3_log_d(T, est);
     se3_exp_d(est, T);
     for (int i = 0; i < 16; ++i) { hs.T[i] = T[i]; hs.delta[i] = (float)T[i]; }
-    VH_HIP(hipMemcpyAsync(p->state, &hs, sizeof hs, hipMemcpyHostToDevice, p->stream));
+    const bool oneLaunch = p->alignSlots > 0 && max_iters > 0;
+    // (the chain of rounds keeps its state in device memory; the one-launch Align gets the start by value and writes the
+    // result straight into the pinned host record: no copy command in front of the launch or behind it)
+    if (!oneLaunch) VH_HIP(hipMemcpyAsync(p->state, &hs, sizeof hs, hipMemcpyHostToDevice, p->stream));
     IcpParams ip;
     std::memset(ip.delta, 0, sizeof ip.delta);
     std::memcpy(ip.K, K, sizeof ip.K);
@@ -222,7 +228,7 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
     ip.flags = flags;
     const float4 *in = reinterpret_cast<const float4 *>(d_input), *tg = reinterpret_cast<const float4 *>(d_target),
                  *tn = reinterpret_cast<const float4 *>(d_target_normals);
-    if (p->alignSlots > 0 && max_iters > 0) {
+    if (oneLaunch) {
         // one launch for all rounds (icp_align_kernel)
         const uint32_t spinLimit = p->spinLimit;
         if (p->seqBase > (1 << 30)) {          // (after 5 * 10^7 calls: start the numbers again behind cleared words)
@@ -233,8 +239,10 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
         const int seqBase = p->seqBase;
         p->seqBase += max_iters;
         static const int reducerNap = std::getenv("VH_ICP_NAP") ? std::atoi(std::getenv("VH_ICP_NAP")) : 2;   // x 512 cycles
-        void *args[] = {(void *)&ip, (void *)&in, (void *)&tg, (void *)&tn, (void *)&p->records, (void *)&p->pub, (void *)&p->state,
-                        (void *)&max_iters, (void *)&seqBase, (void *)&spinLimit, (void *)&reducerNap, (void *)&p->stamps};
+        IcpStart start;
+        std::memcpy(start.T, T, sizeof start.T);
+        void *args[] = {(void *)&ip, (void *)&in, (void *)&tg, (void *)&tn, (void *)&p->records, (void *)&p->pub, (void *)&start,
+                        (void *)&p->hostStateDev, (void *)&max_iters, (void *)&seqBase, (void *)&spinLimit, (void *)&reducerNap, (void *)&p->stamps};
         VH_HIP(hipLaunchKernel(icp_align_entry(p->alignSlots), dim3(p->alignBlocks), dim3(kIcpThreads), args, 0, p->stream));
     } else {
         for (int it = 0; it < max_iters; ++it)
@@ -242,7 +250,7 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
                                                                              (float4 *)nullptr, (float *)nullptr, p->state, 1, 1);
     }
     VH_HIP(hipGetLastError());
-    VH_HIP(hipMemcpyAsync(&hs, p->state, sizeof hs, hipMemcpyDeviceToHost, p->stream));
+    if (!oneLaunch) VH_HIP(hipMemcpyAsync(&hs, p->state, sizeof hs, hipMemcpyDeviceToHost, p->stream));
     VH_HIP(hipStreamSynchronize(p->stream));
     if (p->stamps && p->alignSlots > 0 && max_iters > 0 && max_iters <= 64) {          // diagnostics: microseconds since the round started
         unsigned long long st[64 * 8];

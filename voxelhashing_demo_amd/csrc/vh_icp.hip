@@ -38,6 +38,11 @@ struct IcpState {
     int32_t pad[3];
 };
 
+// What the one-launch Align starts from, by value in the kernel arguments (no copy in front of the launch).
+struct IcpStart {
+    double T[16];
+};
+
 // ---- SE3 (SE3.cpp:4-22): twist = (v, w), M = [[0,-w2,w1,v0],[w2,0,-w0,v1],[-w1,w0,0,v2],0]; the
 // reference evaluates M.exp() / T.log() with Eigen's generic matrix functions, these are the closed
 // forms of the same maps.  Shared by the host entry points and the device-side solve. ----
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, co
                                                                 const float4 *__restrict__ normals,
                                                                 unsigned long long *__restrict__ records,
                                                                 unsigned long long *__restrict__ pub,
-                                                                IcpState *__restrict__ state, const int maxIters,
+                                                                const IcpStart start, IcpState *__restrict__ state, const int maxIters,
                                                                 const int seqBase, const uint32_t spinLimit,
                                                                 const int reducerNap,
                                                                 unsigned long long *__restrict__ stamps)
@@ -512,8 +517,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, co
     float4 p[kSlots];
 #pragma unroll
     for (int u = 0; u < kSlots; ++u) p[u] = (base + u * stride < npix) ? input[base + u * stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (threadIdx.x < 16) {                                   // written by the host's copy before the launch
-        const double t = state->T[threadIdx.x];
+    if (threadIdx.x < 16) {
+        const double t = start.T[threadIdx.x];
         sT[threadIdx.x] = t;
         if (threadIdx.x < 12) sDelta[threadIdx.x] = (float)t;
     }
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, co
                     if (__hip_atomic_load(&seenBy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { verdict = 2; break; }
                 }
                 if (verdict == 0 && lane == 0) {
-                    __hip_atomic_store(&state->timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&state->timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     go = 0;
                 }
             }
@@ -637,8 +642,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, co
             float v = 0.0f;
 #pragma unroll
             for (int q8 = 0; q8 < 8; ++q8) v += sm[q8][threadIdx.x];
-            total[threadIdx.x] = v;
-            __hip_atomic_store(&state->sums[threadIdx.x], threadIdx.x < kIcpTerms ? v : 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            total[threadIdx.x] = threadIdx.x < kIcpTerms ? v : 0.0f;
         }
         __syncthreads();
         VH_ICP_STAMP(4);
@@ -647,23 +651,21 @@ __global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, co
 #pragma unroll
             for (int i = 0; i < 16; ++i) T[i] = sT[i];
             int done = 0, singular = 0;
-            if (timedOut) { done = 1; __hip_atomic_store(&state->timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            if (timedOut) { done = 1; __hip_atomic_store(&state->timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
             else if (total[27] == 0.0f) done = 1;                              // CameraTracking.cpp:52
             else if (!icp_step_from_sums(total, T)) done = singular = 1;       // (T untouched)
 #pragma unroll
             for (int i = 0; i < 12; ++i) { sT[i] = T[i]; sDelta[i] = (float)T[i]; }
             go = !done;
-            if (done || finalRound) {                       // what the host reads when the launch has ended (write-through
-                                                            // like every store to the state in this kernel: no dirty line of it
-                                                            // in any L2 that a late write-back could lay over another's word)
+            if (done || finalRound) {                       // what the host reads when the launch has ended: `state` is host
+                                                            // memory here (pinned, mapped) -- no copy behind the launch
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    __hip_atomic_store(&state->T[i], T[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&state->delta[i], (float)T[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __hip_atomic_store(&state->rounds, timedOut ? round : round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&state->done, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&state->singular, singular, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int i = 0; i < 16; ++i) { state->T[i] = T[i]; state->delta[i] = (float)T[i]; }
+#pragma unroll
+                for (int i = 0; i < kIcpStride; ++i) state->sums[i] = total[i];
+                state->rounds = timedOut ? round : round + 1;
+                state->done = done;
+                state->singular = singular;
             }
         }
         __syncthreads();
