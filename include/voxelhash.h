@@ -635,6 +635,17 @@ int vh_depth_to_maps(const float *d_depth, const float k_inv[9], int32_t width, 
  * raycast intrinsics: the model as an ICP target (raycast(pose, depth, normals)). */
 int vh_raycast_maps(vh_context *ctx, const float pose[16], float t_min, float t_max, float *d_depth_out,
                     vh_float4 *d_vertices_out, vh_float4 *d_normals_out);
+/* One frame of the closed loop (the demo's frame order, Application.cpp:73-90, with the tracker switched on):
+ * vh_preprocess(d_depth) -> vh_icp_align(input maps, model maps; start = identity) -> pose <- pose . delta (row-major
+ * double 4x4, in / out) -> vh_integrate_depth(pose, d_depth) -> vh_raycast_maps(pose) into the model maps for the next
+ * frame.  Everything runs on the context's stream (the tracker must be bound to it: vh_icp_set_stream); the one host
+ * synchronisation is the one inside vh_icp_align.  The first frame of a sequence is vh_integrate_depth + vh_raycast_maps
+ * at the start pose.  d_input_*: scratch maps the call fills. */
+int vh_fusion_step(vh_context *ctx, vh_icp *icp, const uint16_t *d_depth, const float k_inv[9], const float K[9],
+                   float dist_thres, int32_t max_iters, int32_t flags, float t_min, float t_max,
+                   vh_float4 *d_input_vertices, vh_float4 *d_input_normals, float *d_model_depth,
+                   vh_float4 *d_model_vertices, vh_float4 *d_model_normals, double pose[16],
+                   vh_icp_system *last, int32_t *iterations);
 /* the reference's own name (CameraTrackingUtils.cu:187-215; float4x4 by value there, a pointer to
  * its 16 row-major floats here): intrinsics from SetCameraIntrinsic, threshold 0.08 (common.h:12),
  * synchronous, returns the summed residual */

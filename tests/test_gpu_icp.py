@@ -359,3 +359,46 @@ def test_one_launch_align_gives_up_instead_of_hanging(vh, torch_cuda, monkeypatc
         assert np.array_equal(good.Align(v1, tp, tn), want)
     hasty.close()
     good.close()
+
+
+def test_fusion_step_is_track_then_fuse(vh, torch_cuda):
+    """vh_fusion_step (FusionLoop.step: one library call per frame) against the same five stages called one by one from
+    Python (FusionLoop.track + FusionLoop.fuse): same poses (the 4x4 pose product is summed in a different order by numpy,
+    so a pose may differ in its last float bit and the frames after it by that much), same model."""
+    from voxelhashing_demo_amd import tracking
+    torch = torch_cuda
+    prims = synth.room_primitives()
+    gt_poses = synth.camera_loop(500)[200:206]
+    K = synth.K_matrix(W, H)
+    kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    dev = [(synth.render_room_verts(p, W, H, prims, device="cuda")[..., 2] * 5000.0).round().clamp(0, 65535).to(torch.uint16)
+           for p in gt_poses]
+    kw = dict(numBuckets=1 << 16, numVoxelBlocks=1 << 14)
+    flags = tracking.ICP_ABS_DISTANCE | tracking.ICP_NEED_TARGET
+    tables = [vh.SDFHashtable(vh.default_params(**kw), W, H, 1) for _ in range(2)]
+    loops = [tracking.FusionLoop(t, K, kinv, flags=flags) for t in tables]
+    for lp in loops:
+        lp.start(dev[0], gt_poses[0])
+    for k in range(1, len(gt_poses)):
+        a = loops[0].step(dev[k]).copy()
+        loops[1].track(dev[k])
+        loops[1].fuse(dev[k])
+        b = loops[1].pose
+        assert loops[0].trk.iterations == loops[1].trk.iterations == 20
+        assert np.abs(a - b).max() < 1e-5, (k, np.abs(a - b).max())
+        truth = np.asarray(gt_poses[k], np.float64).reshape(4, 4)
+        assert np.abs(a[:3, 3] - truth[:3, 3]).max() < 0.012
+    assert loops[0].frames == loops[1].frames == len(gt_poses)
+    ca, cb = tables[0].counters(), tables[1].counters()
+    assert abs(ca["allocated_total"] - cb["allocated_total"]) <= 0.01 * ca["allocated_total"]
+    # a tracker on another stream than the table's is refused
+    other = torch.cuda.Stream()
+    stray = tracking.FusionLoop(tables[0], K, kinv, flags=flags)
+    stray.trk._lib.vh_icp_set_stream(stray.trk._h, C.c_void_p(other.cuda_stream))
+    stray.pose = loops[0].pose.copy()
+    with pytest.raises(Exception, match="stream"):
+        stray.step(dev[1])
+    for lp in loops + [stray]:
+        lp.close()
+    for t in tables:
+        t.close()

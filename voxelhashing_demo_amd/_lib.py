@@ -117,6 +117,8 @@ SIGNATURES = {
     "vh_icp_align": (C.c_int, [_vp, _vp, _vp, _vp, _fp, _f, C.c_int32, C.c_int32, _fp, C.POINTER(IcpSystem),
                                C.POINTER(C.c_int32)]),
     "vh_raycast_maps": (C.c_int, [_vp, _fp, _f, _f, _vp, _vp, _vp]),
+    "vh_fusion_step": (C.c_int, [_vp, _vp, _vp, _fp, _fp, _f, C.c_int32, C.c_int32, _f, _f, _vp, _vp, _vp, _vp, _vp,
+                                 C.POINTER(C.c_double), C.POINTER(IcpSystem), C.POINTER(C.c_int32)]),
     "vh_depth_to_maps": (C.c_int, [_vp, _fp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "computeCorrespondences": (C.c_float, [_vp, _vp, _vp, _vp, _vp, _vp, _fp, C.c_int, C.c_int]),
     "vh_generate_keys_depth_batch": (C.c_int, [_vp, C.c_int32, _fp, C.POINTER(_vp), _fp, C.c_uint32, C.c_int32, _vp,

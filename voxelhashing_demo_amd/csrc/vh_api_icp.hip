@@ -306,6 +306,39 @@ extern "C" int vh_raycast_maps(vh_context *c, const float pose[16], float t_min,
     return vh_depth_to_maps(d_depth_out, k_inv, c->fp.width, c->fp.height, d_vertices_out, d_normals_out, c->stream);
 }
 
+// One frame of the closed loop in one call (frame order of Application.cpp:73-90; tracking.FusionLoop.step):
+// preProcess -> Align against the model's maps -> pose <- pose . delta -> integrate at the new pose -> the model's maps
+// from there for the next frame.  Everything on the context's stream; the one host synchronisation is vh_icp_align's.
+extern "C" int vh_fusion_step(vh_context *c, vh_icp *p, const uint16_t *d_depth, const float k_inv[9], const float K[9],
+                              float dist_thres, int32_t max_iters, int32_t flags, float t_min, float t_max,
+                              vh_float4 *d_input_vertices, vh_float4 *d_input_normals, float *d_model_depth,
+                              vh_float4 *d_model_vertices, vh_float4 *d_model_normals, double pose[16],
+                              vh_icp_system *last, int32_t *iterations)
+{
+    if (!c || !p || !d_depth || !k_inv || !K || !d_input_vertices || !d_input_normals || !d_model_depth || !d_model_vertices ||
+        !d_model_normals || !pose)
+        return fail(VH_ERR_INVALID_ARGUMENT, "null argument");
+    if (p->width != c->fp.width || p->height != c->fp.height || p->device != c->device || p->stream != c->stream)
+        return fail(VH_ERR_INVALID_ARGUMENT, "vh_fusion_step: the tracker must have the table's image size, device and stream");
+    int rc = vh_preprocess(d_depth, k_inv, p->width, p->height, d_input_vertices, d_input_normals, c->stream);
+    if (rc != VH_OK) return rc;
+    float delta[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    rc = vh_icp_align(p, d_input_vertices, d_model_vertices, d_model_normals, K, dist_thres, max_iters, flags, delta, last, iterations);
+    if (rc != VH_OK) return rc;
+    double next[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += pose[4 * i + k] * (double)delta[4 * k + j];
+            next[4 * i + j] = s;
+        }
+    float p32[16];
+    for (int i = 0; i < 16; ++i) { pose[i] = next[i]; p32[i] = (float)next[i]; }
+    rc = vh_integrate_depth(c, p32, d_depth, k_inv);
+    if (rc != VH_OK) return rc;
+    return vh_raycast_maps(c, p32, t_min, t_max, d_model_depth, d_model_vertices, d_model_normals);
+}
+
 // The reference's own name (CameraTrackingUtils.cu:187-215): 640x480, intrinsics from
 // SetCameraIntrinsic, thresholds of common.h:12-13, synchronous; returns the summed residual.
 // `deltaTransform` is a float4x4 passed by value in the reference; here a pointer to its 16

@@ -174,8 +174,18 @@ class FusionLoop:
         self.frames += 1
 
     def step(self, depth_u16):
-        self.track(depth_u16)
-        self.fuse(depth_u16)
+        """track + fuse in one library call (vh_fusion_step): the frame's five stages and the pose update without a return to
+        Python in between."""
+        sys, it = L.IcpSystem(), C.c_int32()
+        trk = self.trk
+        pose = np.ascontiguousarray(self.pose, np.float64)
+        L.check(trk._lib.vh_fusion_step(self.table._h, trk._h, _ptr(depth_u16), _fp(self.k_inv), _fp(trk.K), trk.dist_thres,
+                                        trk.max_iters, trk.flags, 0.1, 5.0, _ptr(self.in_v), _ptr(self.in_n), _ptr(self.depth),
+                                        _ptr(self.model_v), _ptr(self.model_n), pose.ctypes.data_as(C.POINTER(C.c_double)),
+                                        C.byref(sys), C.byref(it)), "vh_fusion_step")
+        self.pose = pose
+        trk.last, trk.iterations = system_arrays(sys), int(it.value)
+        self.frames += 1
         return self.pose
 
     def close(self):
