@@ -206,6 +206,7 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
     if (!p || !d_input || !d_target || !d_target_normals || !K || !delta || max_iters < 0)
         return fail(VH_ERR_INVALID_ARGUMENT, "bad argument");
     DeviceGuard guard(p->device);
+    const auto hostT0 = std::chrono::steady_clock::now();
     IcpState &hs = *p->hostState;
     std::memset(&hs, 0, sizeof hs);
     // the start value goes through log / exp once, like the reference's estimate (a rigid-body
@@ -251,7 +252,14 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
     }
     VH_HIP(hipGetLastError());
     if (!oneLaunch) VH_HIP(hipMemcpyAsync(&hs, p->state, sizeof hs, hipMemcpyDeviceToHost, p->stream));
+    const auto hostT1 = std::chrono::steady_clock::now();
     VH_HIP(hipStreamSynchronize(p->stream));
+    if (p->stamps) {          // diagnostics: host time of this call up to the last launch call returning, and inside the synchronisation
+        const auto hostT2 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "icp host: queued after %.1f us, synchronised after %.1f us more\n",
+                     std::chrono::duration<double, std::micro>(hostT1 - hostT0).count(),
+                     std::chrono::duration<double, std::micro>(hostT2 - hostT1).count());
+    }
     if (p->stamps && p->alignSlots > 0 && max_iters > 0 && max_iters <= 64) {          // diagnostics: microseconds since the round started
         unsigned long long st[64 * 8];
         VH_HIP(hipMemcpy(st, p->stamps, sizeof(unsigned long long) * 8 * max_iters, hipMemcpyDeviceToHost));
