@@ -19,14 +19,13 @@ struct vh_icp {
     unsigned long long *stamps = nullptr;  // diagnostics (VH_ICP_STAMPS=1): [round][8] time stamps of the one-launch Align
 };
 
-constexpr int kIcpAlignMaxBlocks = 1024;
-constexpr int kIcpAlignMaxSlots = 8;
+constexpr int kIcpAlignMaxSlots = 6;
 
 static const void *icp_align_entry(int slots)
 {
     switch (slots) {
 #define VH_ICP_ALIGN(S) case S: return (const void *)icp_align_kernel<S>;
-    VH_ICP_ALIGN(1) VH_ICP_ALIGN(2) VH_ICP_ALIGN(3) VH_ICP_ALIGN(4) VH_ICP_ALIGN(5) VH_ICP_ALIGN(6) VH_ICP_ALIGN(7) VH_ICP_ALIGN(8)
+    VH_ICP_ALIGN(1) VH_ICP_ALIGN(2) VH_ICP_ALIGN(3) VH_ICP_ALIGN(4) VH_ICP_ALIGN(5) VH_ICP_ALIGN(6)
 #undef VH_ICP_ALIGN
     default: return nullptr;
     }
@@ -52,15 +51,13 @@ extern "C" int vh_icp_create(int32_t width, int32_t height, int32_t device, vh_i
     p->blocks = std::min(maxBlocks, 256);                      // one workgroup per compute unit
     if (const char *e = std::getenv("VH_ICP_BLOCKS")) p->blocks = std::max(1, std::min(maxBlocks, std::atoi(e)));   // tuning knob
     // Align in one launch: the round kernel's grid when a lane then holds at most six pixels (640x480: 256 workgroups, five
-    // pixels -- the same partition, hence the same sums, as the chain of rounds), else five pixels per lane on up to 1 024
-    // workgroups; larger images (> 2.6 M pixels at eight per lane) keep the chain.  VH_ICP_PERSISTENT=0: always the chain (A/B).
+    // pixels) -- the same partition, hence the same sums, as the chain of rounds; larger images (> 393 216 pixels) keep the
+    // chain.  VH_ICP_PERSISTENT=0: always the chain (A/B, tests).
     const size_t npix = (size_t)width * height;
-    auto slots_for = [&](int blocks) { return (int)((npix + (size_t)blocks * kIcpThreads - 1) / ((size_t)blocks * kIcpThreads)); };
     p->alignBlocks = p->blocks;
-    if (slots_for(p->alignBlocks) > 6)
-        p->alignBlocks = std::min(kIcpAlignMaxBlocks, (int)((npix + kIcpThreads * 5 - 1) / (kIcpThreads * 5)));
-    p->alignSlots = slots_for(p->alignBlocks);
-    if (p->alignSlots > kIcpAlignMaxSlots || p->alignBlocks > kIcpAlignMaxBlocks) p->alignSlots = 0;
+    p->alignSlots = (int)((npix + (size_t)p->alignBlocks * kIcpThreads - 1) / ((size_t)p->alignBlocks * kIcpThreads));
+    if (p->alignSlots > kIcpAlignMaxSlots) p->alignSlots = 0;
+    if (const char *e = std::getenv("VH_ICP_PERSISTENT")) if (std::atoi(e) == 0) p->alignSlots = 0;
     if (p->alignSlots > 0) {
         // the one-launch Align waits on its own grid: every workgroup must be resident at once (half of what the occupancy
         // of this build allows at most, so that a neighbour on another stream does not turn the wait into a time-out)
@@ -70,7 +67,6 @@ extern "C" int vh_icp_create(int32_t width, int32_t height, int32_t device, vh_i
             2 * p->alignBlocks > perCu * cus)
             p->alignSlots = 0;
     }
-    if (const char *e = std::getenv("VH_ICP_PERSISTENT")) if (std::atoi(e) == 0) p->alignSlots = 0;
     if (const char *e = std::getenv("VH_ICP_SPIN_LIMIT")) p->spinLimit = (uint32_t)std::max(1, std::atoi(e));   // (tests: 1 = the time-out path)
     if (std::getenv("VH_ICP_STAMPS")) (void)hipMalloc((void **)&p->stamps, sizeof(unsigned long long) * (512 + 1024));
     hipError_t e = hipMalloc((void **)&p->partials, sizeof(float) * kIcpStride * (size_t)p->blocks);
