@@ -50,6 +50,10 @@ struct IcpStart {
 // matrices live in registers (left as loops they are indexed dynamically and go to scratch memory:
 // the single-lane solve then cost 40 us per round instead of a few).
 #define VH_UNROLL _Pragma("unroll")
+// The solve's multiply-adds are fused on purpose (the library is built -ffp-contract=off for the model's arithmetic): on the
+// device they run on ONE lane between two rounds of Align at half-rate double issue, and a fused multiply-add is one
+// instruction where a product and a sum are two; host and device share these functions, so they agree bit for bit.
+#define VH_FMA(a, b, c) __builtin_fma((a), (b), (c))
 __host__ __device__ inline void skew_terms(const double w[3], double Kx[9], double K2[9])
 {
     Kx[0] = 0; Kx[1] = -w[2]; Kx[2] = w[1];
@@ -59,13 +63,13 @@ __host__ __device__ inline void skew_terms(const double w[3], double Kx[9], doub
     for (int i = 0; i < 3; ++i)
         VH_UNROLL
         for (int j = 0; j < 3; ++j)
-            K2[3 * i + j] = Kx[3 * i] * Kx[j] + Kx[3 * i + 1] * Kx[3 + j] + Kx[3 * i + 2] * Kx[6 + j];
+            K2[3 * i + j] = VH_FMA(Kx[3 * i + 2], Kx[6 + j], VH_FMA(Kx[3 * i + 1], Kx[3 + j], Kx[3 * i] * Kx[j]));
 }
 
 __host__ __device__ inline void se3_exp_d(const double twist[6], double T[16])
 {
     const double *v = twist, *w = twist + 3;
-    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double th2 = VH_FMA(w[2], w[2], VH_FMA(w[1], w[1], w[0] * w[0]));
     double A, B, Cc;                       // sin(t)/t, (1-cos t)/t^2, (t-sin t)/t^3: even functions of t
     if (th2 < 0.25) {
         // their power series in t^2, nine terms (the tenth is below 2^-64 of the first for t < 0.5): an ICP update is a small
@@ -81,9 +85,9 @@ __host__ __device__ inline void se3_exp_d(const double twist[6], double T[16])
         A = fA[8]; B = fB[8]; Cc = fC[8];
         VH_UNROLL
         for (int n = 7; n >= 0; --n) {
-            A = fA[n] - th2 * A;
-            B = fB[n] - th2 * B;
-            Cc = fC[n] - th2 * Cc;
+            A = VH_FMA(-th2, A, fA[n]);
+            B = VH_FMA(-th2, B, fB[n]);
+            Cc = VH_FMA(-th2, Cc, fC[n]);
         }
     } else {
         const double th = sqrt(th2);
@@ -99,8 +103,8 @@ __host__ __device__ inline void se3_exp_d(const double twist[6], double T[16])
         VH_UNROLL
         for (int j = 0; j < 3; ++j) {
             const double I = (i == j) ? 1.0 : 0.0;
-            T[4 * i + j] = I + A * Kx[3 * i + j] + B * K2[3 * i + j];
-            t += (I + B * Kx[3 * i + j] + Cc * K2[3 * i + j]) * v[j];
+            T[4 * i + j] = VH_FMA(B, K2[3 * i + j], VH_FMA(A, Kx[3 * i + j], I));
+            t = VH_FMA(VH_FMA(Cc, K2[3 * i + j], VH_FMA(B, Kx[3 * i + j], I)), v[j], t);
         }
         T[4 * i + 3] = t;
     }
@@ -141,14 +145,14 @@ __host__ __device__ inline bool icp_update_d(const double JTJ[36], const double 
     for (int j = 0; j < 6; ++j) {
         double s = JTJ[6 * j + j];
         VH_UNROLL
-        for (int k = 0; k < j; ++k) s -= Wd[6 * j + k] * L[6 * j + k];
+        for (int k = 0; k < j; ++k) s = VH_FMA(-Wd[6 * j + k], L[6 * j + k], s);
         if (!(s > 0.0)) return false;
         inv[j] = 1.0 / s;
         VH_UNROLL
         for (int i = j + 1; i < 6; ++i) {
             double t = JTJ[6 * i + j];
             VH_UNROLL
-            for (int k = 0; k < j; ++k) t -= Wd[6 * i + k] * L[6 * j + k];
+            for (int k = 0; k < j; ++k) t = VH_FMA(-Wd[6 * i + k], L[6 * j + k], t);
             Wd[6 * i + j] = t;
             L[6 * i + j] = t * inv[j];
         }
@@ -157,14 +161,14 @@ __host__ __device__ inline bool icp_update_d(const double JTJ[36], const double 
     for (int i = 0; i < 6; ++i) {              // L y = -JTr
         double s = -JTr[i];
         VH_UNROLL
-        for (int k = 0; k < i; ++k) s -= L[6 * i + k] * y[k];
+        for (int k = 0; k < i; ++k) s = VH_FMA(-L[6 * i + k], y[k], s);
         y[i] = s;
     }
     VH_UNROLL
     for (int i = 5; i >= 0; --i) {             // L^T x = D^-1 y
         double s = y[i] * inv[i];
         VH_UNROLL
-        for (int k = i + 1; k < 6; ++k) s -= L[6 * k + i] * x[k];
+        for (int k = i + 1; k < 6; ++k) s = VH_FMA(-L[6 * k + i], x[k], s);
         x[i] = s;
     }
     return true;
@@ -205,13 +209,14 @@ __host__ __device__ inline bool icp_step_matrix_d(const double JTJ[36], const do
         for (int j = 0; j < 4; ++j) {
             double s = 0.0;
             VH_UNROLL
-            for (int k = 0; k < 4; ++k) s += A[4 * i + k] * T[4 * k + j];
+            for (int k = 0; k < 4; ++k) s = VH_FMA(A[4 * i + k], T[4 * k + j], s);
             M[4 * i + j] = s;
         }
     VH_UNROLL
     for (int i = 0; i < 16; ++i) T[i] = M[i];
     return true;
 }
+#undef VH_FMA
 #undef VH_UNROLL
 
 // double -> int as cvt.rzi.s32.f64 (the reference's make_int2(double, double), :129): truncate,
