@@ -59,12 +59,13 @@ extern "C" int vh_icp_create(int32_t width, int32_t height, int32_t device, vh_i
     if (p->alignSlots > kIcpAlignMaxSlots) p->alignSlots = 0;
     if (const char *e = std::getenv("VH_ICP_PERSISTENT")) if (std::atoi(e) == 0) p->alignSlots = 0;
     if (p->alignSlots > 0) {
-        // the one-launch Align waits on its own grid: every workgroup must be resident at once (half of what the occupancy
-        // of this build allows at most, so that a neighbour on another stream does not turn the wait into a time-out)
+        // the one-launch Align waits on its own grid: every workgroup must be able to be resident at once (the kernel sits
+        // at the edge of 256 registers per lane: one or two workgroups per compute unit depending on the compiler's mood; a
+        // neighbour on another stream that holds compute units only delays the launch, and the waits are bounded)
         int perCu = 0, cus = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, icp_align_entry(p->alignSlots), kIcpThreads, 0) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            2 * p->alignBlocks > perCu * cus)
+            p->alignBlocks > perCu * cus)
             p->alignSlots = 0;
     }
     if (const char *e = std::getenv("VH_ICP_SPIN_LIMIT")) p->spinLimit = (uint32_t)std::max(1, std::atoi(e));   // (tests: 1 = the time-out path)

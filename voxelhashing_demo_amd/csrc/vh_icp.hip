@@ -294,6 +294,8 @@ __device__ __forceinline__ float icp_workgroup_sums(const float acc[kIcpTerms], 
 }
 
 // CalculateJacobians, Solver.cu:27-35: J = [n, target x n]; the row's 21 + 6 products, d and 1 into the running sums
+// (measured: fused multiply-adds here -- 27 scalar v_fmac instead of the packed multiplies and adds the compiler forms -- made
+// the round's pixel pass slower, 2.64 against 2.36 us)
 __device__ __forceinline__ void icp_accumulate(float acc[kIcpTerms], const float4 tt, const float4 nn, const float d)
 {
     const float J[6] = {nn.x, nn.y, nn.z, tt.y * nn.z - tt.z * nn.y, tt.z * nn.x - tt.x * nn.z, tt.x * nn.y - tt.y * nn.x};
@@ -608,16 +610,17 @@ __global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, co
         // one pass finds them all.
         for (int i = 0; i < reducerNap; ++i) __builtin_amdgcn_s_sleep(8);
         for (int b0 = part; b0 < numBlocks; b0 += 8 * 32) {
-            // a word that has been seen is kept; every pass asks again only for the missing ones, so the pass that finds the
-            // slowest workgroup's record is a round trip of a few loads, not of all 32
-            float r[32];
+            // a word that has been seen is kept (in registers: parked in LDS the round took 9.0 instead of 8.3 us); every pass
+            // asks again only for the halves of 16 words somebody in the wave still misses one of (quarters of eight: four
+            // round trips in a row for a full pass, slower), so the pass that finds the slowest workgroup's record is a
+            // round trip of 16 loads, not of all 32
             uint32_t missing = 0xffffffffu;
+            float r[32];
 #pragma unroll
             for (int u = 0; u < 32; ++u)
                 if (b0 + 8 * u >= numBlocks) { r[u] = 0.0f; missing &= ~(1u << u); }
             bool seen = false;
             for (uint32_t it = 0; it < spinLimit && !seen; ++it) {
-                // (in two halves of 16 words -- registers; a half nobody in the wave misses anything of is skipped)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     if (__builtin_amdgcn_ballot_w64((missing >> (16 * h) & 0xffffu) != 0u) == 0ull) continue;
@@ -629,7 +632,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, co
                     }
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
-                        const bool here = (int)(w[u] >> 32) == want && b0 + 8 * (16 * h + u) < numBlocks;
+                        const bool here = (int)(w[u] >> 32) == want && (missing >> (16 * h + u) & 1u);
                         r[16 * h + u] = here ? __builtin_bit_cast(float, (unsigned)w[u]) : r[16 * h + u];
                         missing = here ? missing & ~(1u << (16 * h + u)) : missing;
                     }
