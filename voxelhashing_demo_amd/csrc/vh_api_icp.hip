@@ -236,11 +236,10 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
         }
         const int seqBase = p->seqBase;
         p->seqBase += max_iters;
-        static const int reducerNap = std::getenv("VH_ICP_NAP") ? std::atoi(std::getenv("VH_ICP_NAP")) : 2;   // x 512 cycles
         IcpStart start;
         std::memcpy(start.T, T, sizeof start.T);
         void *args[] = {(void *)&ip, (void *)&in, (void *)&tg, (void *)&tn, (void *)&p->records, (void *)&p->pub, (void *)&start,
-                        (void *)&p->hostStateDev, (void *)&max_iters, (void *)&seqBase, (void *)&spinLimit, (void *)&reducerNap, (void *)&p->stamps};
+                        (void *)&p->hostStateDev, (void *)&max_iters, (void *)&seqBase, (void *)&spinLimit, (void *)&p->stamps};
         VH_HIP(hipLaunchKernel(icp_align_entry(p->alignSlots), dim3(p->alignBlocks), dim3(kIcpThreads), args, 0, p->stream));
     } else {
         for (int it = 0; it < max_iters; ++it)

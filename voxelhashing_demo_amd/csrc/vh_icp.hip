@@ -506,7 +506,6 @@ __global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, co
                                                                 unsigned long long *__restrict__ pub,
                                                                 const IcpStart start, IcpState *__restrict__ state, const int maxIters,
                                                                 const int seqBase, const uint32_t spinLimit,
-                                                                const int reducerNap,
                                                                 unsigned long long *__restrict__ stamps)
 {
     // diagnostics (VH_ICP_STAMPS=1): s_memrealtime (100 MHz) per round, workgroup 0: [0] round starts, [1] sums in registers,
@@ -605,10 +604,13 @@ __global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, co
         const int kk = k < kIcpTerms ? k : 0;               // (lanes 29..31 of a part ride along on term 0)
         float s = 0.0f;
         bool timedOut = false;
-        // The workgroups finish a round within ~0.5 us of each other and a stored word takes ~0.7 us to be visible: a pass over
-        // the records started at once finds the late ones missing and costs a second pass (~1.2 us each); started a little later
-        // one pass finds them all.
-        for (int i = 0; i < reducerNap; ++i) __builtin_amdgcn_s_sleep(8);
+        // The workgroups finish a round within ~0.5 us of each other and a stored word takes ~0.7 us to be visible: a first pass
+        // started at once finds most words missing and only delays the pass that counts -- a short nap first (s_sleep 16, ~0.4 us:
+        // period of a round 8.3 us; 8: 8.9, 12: 8.3 - 8.8, 20: 8.45, 24: 8.55, none: 8.9; tools/r06_icp_ab.sh)
+#ifndef VH_ICP_NAP
+#define VH_ICP_NAP 16
+#endif
+        __builtin_amdgcn_s_sleep(VH_ICP_NAP);
         for (int b0 = part; b0 < numBlocks; b0 += 8 * 32) {
             // a word that has been seen is kept (in registers: parked in LDS the round took 9.0 instead of 8.3 us); every pass
             // asks again only for the halves of 16 words somebody in the wave still misses one of (quarters of eight: four
