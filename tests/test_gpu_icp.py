@@ -403,3 +403,34 @@ def test_fusion_step_is_track_then_fuse(vh, torch_cuda):
         lp.close()
     for t in tables:
         t.close()
+
+
+def test_one_launch_align_while_another_kernel_holds_the_chip(vh, torch_cuda):
+    """The one-launch Align needs all its workgroups resident to finish a round.  Here a long kernel of another stream holds
+    every workgroup slot of the chip (2 048 workgroups of 256 lanes) or most of them (1 792) for 20 ms at a time while Aligns
+    are queued: their workgroups trickle in as slots come free, the ones that are there poll (bounded: ~1 s) -- every Align
+    must end, without a time-out, with the transform it gives on an idle chip, bit for bit."""
+    from voxelhashing_demo_amd import tracking
+    torch = torch_cuda
+    w, h = 640, 480
+    prims, poses, K = synth.room_primitives(), synth.camera_loop(250), synth.K_matrix(w, h)
+    kinv = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    v0 = synth.render_room_verts(poses[100], w, h, prims, device="cuda")
+    v1 = synth.render_room_verts(poses[101], w, h, prims, device="cuda")
+    tp, tn = torch.empty_like(v0), torch.empty_like(v0)
+    tracking.depth_to_maps(v0[..., 2].contiguous(), kinv, tp, tn)
+    trk = tracking.CameraTracking(w, h, K, flags=3)
+    idle = trk.Align(v1, tp, tn).copy()
+    idle_last = trk.last
+    gt = vh.SDFHashtable(vh.default_params(numBuckets=1 << 10, numVoxelBlocks=64), 64, 48, 1)      # (only for vh_debug_occupy)
+    hog, L = torch.cuda.Stream(), vh.load()
+    for burst, groups in enumerate((2048, 1792, 2048, 1792)):
+        assert L.vh_debug_occupy(gt._h, hog.cuda_stream, groups, 20000) == 0
+        for _ in range(12):
+            got = trk.Align(v1, tp, tn)
+            assert trk.iterations == 20
+            assert np.array_equal(got.view(np.uint32), idle.view(np.uint32))
+            assert all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(trk.last, idle_last))
+    torch.cuda.synchronize()
+    trk.close()
+    gt.close()
