@@ -672,27 +672,28 @@ extern "C" int vh_render_blocks(vh_context *c, const float pose[16], float t_min
     bv.fx = c->rc_fx; bv.fy = c->rc_fy; bv.cx = c->rc_cx; bv.cy = c->rc_cy;
     bv.tMin = t_min;
     bv.tMax = t_max;
-    // records of the allocated blocks (32 bytes each; a table holds at most numVoxelBlocks of them, a view
-    // table one per entry) behind two counter words, allocated on first use (synchronises once)
+    // records of the allocated blocks (32 bytes each + their 8-byte screen boxes on their own; a table holds at most
+    // numVoxelBlocks of them, a view table one per entry) behind two counter words, allocated on first use (synchronises once)
     const size_t capacity = c->viewBlocks ? c->numEntries : std::min<size_t>(c->numEntries, c->params.numVoxelBlocks);
     if (!c->blockList || c->blockCapacity < capacity) {      // (a view context grows from 1 to numEntries at its first import)
         VH_HIP(hipStreamSynchronize(c->stream));
         if (c->blockList) (void)hipFree(c->blockList);
         c->blockList = nullptr;
-        VH_HIP(hipMalloc((void **)&c->blockList, 16 + sizeof(BlockRecord) * capacity));
+        VH_HIP(hipMalloc((void **)&c->blockList, 16 + (sizeof(BlockRecord) + sizeof(uint2)) * capacity));
         VH_HIP(hipMemsetAsync(c->blockList, 0, 16, c->stream));
         c->blockCapacity = capacity;
         c->blockParity = 0;
     }
     int32_t *counts = c->blockList;
     BlockRecord *records = reinterpret_cast<BlockRecord *>(c->blockList + 4);
+    uint2 *bounds = reinterpret_cast<uint2 *>(records + c->blockCapacity);
     const int parity = c->blockParity;
     const uint32_t words = (c->ownedBuckets + 31u) / 32u;
     int rc = launch(c, kPhaseRaycastBounds, blocks_list_kernel, dim3((unsigned)grid_for(words, 256)), dim3(256), c->fp, c->dp,
-                    bv, records, (int32_t)capacity, counts, parity);
+                    bv, records, bounds, (int32_t)capacity, counts, parity);
     if (rc == VH_OK)
         rc = launch(c, kPhaseRaycastBounds, blocks_tile_kernel, dim3((c->fp.width + 15) / 16, (c->fp.height + 15) / 16),
-                    dim3(256), c->fp, bv, (const BlockRecord *)records, (int32_t)capacity, (const int32_t *)counts, parity,
+                    dim3(256), c->fp, bv, (const BlockRecord *)records, (const uint2 *)bounds, (int32_t)capacity, (const int32_t *)counts, parity,
                     d_front, d_back);
     c->blockParity ^= 1;
     if (rc != VH_OK) return rc;

@@ -21,10 +21,15 @@ constexpr uint32_t kFrontInit = 0x7f800000u;      // +inf: no cube in front of t
 
 // Two launches.  (1) blocks_list_kernel: every allocated entry (found through the bucket-occupancy bitmap)
 // gets a 32-byte record {cube, screen bounding box of its corners} unless no pixel can see it.
-// (2) blocks_tile_kernel: one wave per 8x8 pixel tile (a workgroup = a 16x16 region) runs through the
-// records -- the workgroup stages 256 at a time in LDS, each wave tests their boxes against its tile
-// (one record per lane, __ballot) and every lane ray/box-tests its pixel against the records that
-// overlap: nearest entry / farthest exit kept in registers, written once.  No atomics, no image
+// (2) blocks_tile_kernel: one wave per 8x8 pixel tile (a workgroup = a 16x16 region).  The workgroup first
+// runs through the screen boxes alone (8 bytes per block, one per lane and pass) and lists the blocks whose
+// box meets its 16x16 region (wave __ballot, one LDS atomic per wave and pass); the listed records are
+// staged in LDS, each wave tests their boxes against its tile (one record per lane, __ballot) and every
+// lane ray/box-tests its pixel against the records that overlap: nearest entry / farthest exit kept in
+// registers, written once.  (Until round 6 every wave ran through ALL records -- 37 passes of 64 on C2's
+// 2 366 blocks -- and every workgroup staged all 75 KB of them; listing first made the launch 5 - 15 %
+// shorter, no more: what bounds it is the ray/box tests of the boxes that do meet a tile, ~60
+// instructions each for 64 pixels: 35.9 us on that model, 13 us on a 120-frame one.)  No atomics, no image
 // initialisation pass, no per-block load imbalance (round 1-2: one workgroup pass per block with
 // atomicMin/atomicMax per covered pixel, 232 us on C2; this form: DESIGN.md 5).  The min / max over a
 // pixel's cubes does not depend on the order, and a cube whose box misses a pixel fails that pixel's
@@ -86,8 +91,8 @@ __device__ __forceinline__ bool block_bounds(const FrameParams &fp, const BlockV
 // counts: two words used in turn by successive calls (call n appends through counts[n & 1] and zeroes the
 // other for call n + 1), so no launch is spent on a reset
 __global__ __launch_bounds__(256) void blocks_list_kernel(const FrameParams fp, const DevPtrs dp, const BlockView bv,
-                                                          BlockRecord *__restrict__ records, int32_t capacity,
-                                                          int32_t *__restrict__ counts, int parity)
+                                                          BlockRecord *__restrict__ records, uint2 *__restrict__ bounds,
+                                                          int32_t capacity, int32_t *__restrict__ counts, int parity)
 {
     const uint32_t owned = fp.bucketHi - fp.bucketLo;
     const uint32_t w = blockIdx.x * 256 + threadIdx.x;
@@ -117,7 +122,10 @@ __global__ __launch_bounds__(256) void blocks_list_kernel(const FrameParams fp, 
                        fast_range(r.hi[a] - bv.T[4 * a + 3], 0x1p-50f, 0x1p50f);
             if (fast) r.xy1 |= kBlockFastBit;
             const int slot = atomicAdd(counts + parity, 1);
-            if (slot < capacity) records[slot] = r;
+            if (slot < capacity) {
+                records[slot] = r;
+                bounds[slot] = make_uint2(r.xy0, r.xy1);      // the screen boxes alone: what a workgroup's first pass reads
+            }
         }
     }
 }
@@ -142,17 +150,22 @@ __device__ __forceinline__ bool ray_box(const float o[3], const float d[3], cons
 }
 
 constexpr int kBlocksStage = 256;        // records staged per round (one per lane of the workgroup)
+constexpr int kBlocksChunk = 4 * kBlocksStage;     // boxes a workgroup filters before it works its list off (the list cannot overflow)
 
 __global__ __launch_bounds__(256) void blocks_tile_kernel(const FrameParams fp, const BlockView bv,
-                                                          const BlockRecord *__restrict__ records, int32_t capacity,
+                                                          const BlockRecord *__restrict__ records,
+                                                          const uint2 *__restrict__ bounds, int32_t capacity,
                                                           const int32_t *__restrict__ counts, int parity,
                                                           float *__restrict__ front, float *__restrict__ back)
 {
-    __shared__ BlockRecord stage[2][kBlocksStage];
+    __shared__ BlockRecord stage[kBlocksStage];
+    __shared__ uint32_t list[kBlocksChunk];
+    __shared__ int listCount;
     const int n = min(counts[parity], capacity);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-    // the wave's 8x8 tile inside the workgroup's 16x16 region; lane -> pixel row-major in the tile
-    const int tx0 = (int)blockIdx.x * 16 + (wave & 1) * 8, ty0 = (int)blockIdx.y * 16 + (wave >> 1) * 8;
+    // the workgroup's 16x16 region and, inside it, the wave's 8x8 tile; lane -> pixel row-major in the tile
+    const int rx0 = (int)blockIdx.x * 16, ry0 = (int)blockIdx.y * 16;
+    const int tx0 = rx0 + (wave & 1) * 8, ty0 = ry0 + (wave >> 1) * 8;
     const int px = tx0 + (lane & 7), py = ty0 + (lane >> 3);
     const float o[3] = {bv.T[3], bv.T[7], bv.T[11]};
     const float dx = ((float)px - bv.cx) / bv.fx, dy = ((float)py - bv.cy) / bv.fy;
@@ -170,50 +183,75 @@ __global__ __launch_bounds__(256) void blocks_tile_kernel(const FrameParams fp, 
         fastPixel = fastPixel && (zero[a] || fast_range(d[a], 0x1p-40f, 0x1p40f));
     }
     const bool fastWave = __ballot(!fastPixel) == 0ull;
-    BlockRecord mine;
-    if ((int)threadIdx.x < n) mine = records[threadIdx.x];
-    for (int base = 0, buf = 0; base < n; base += kBlocksStage, buf ^= 1) {
-        if (base + (int)threadIdx.x < n) stage[buf][threadIdx.x] = mine;
-        const int nextIdx = base + kBlocksStage + (int)threadIdx.x;
-        if (nextIdx < n) mine = records[nextIdx];               // in flight while this round is worked through
-        __syncthreads();                                         // (two buffers: one barrier per round)
-        const int count = min(kBlocksStage, n - base);
-        for (int k = 0; k < count; k += kWave) {
-            bool overlap = false;
-            if (k + lane < count) {
-                const uint32_t xy0 = stage[buf][k + lane].xy0, xy1 = stage[buf][k + lane].xy1;
-                const int x0 = (int)(xy0 & 0xffffu), y0 = (int)(xy0 >> 16), x1 = (int)(xy1 & 0xffffu), y1 = (int)((xy1 >> 16) & 0x7fffu);
-                overlap = x0 <= tx0 + 7 && x1 >= tx0 && y0 <= ty0 + 7 && y1 >= ty0;
-            }
-            unsigned long long mask = __ballot(overlap);
-            while (mask != 0ull) {
-                const int src = __ffsll((long long)mask) - 1;
-                mask &= mask - 1ull;
-                const BlockRecord q = stage[buf][k + src];       // one LDS address for the wave: broadcast read
-                float tNear, tFar;
-                bool hit;
-                if (fastWave && (q.xy1 & kBlockFastBit)) {
-                    // ray_box without branches, divisions by the pixel's fixed direction
-                    tNear = -3.0e38f;
-                    tFar = 3.0e38f;
-                    hit = true;
+    for (int chunk = 0; chunk < n; chunk += kBlocksChunk) {
+        // ---- the boxes of this chunk against the workgroup's region: the ones that meet it, listed in LDS
+        uint2 box[kBlocksChunk / kBlocksStage];
 #pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        const float t0 = div_fixed(q.lo[a] - o[a], d[a], r1[a]), t1 = div_fixed(q.hi[a] - o[a], d[a], r1[a]);
-                        const float tn = zero[a] ? -3.0e38f : __builtin_fminf(t0, t1);
-                        const float tf = zero[a] ? 3.0e38f : __builtin_fmaxf(t0, t1);
-                        hit = hit && !(zero[a] && (o[a] < q.lo[a] || o[a] > q.hi[a]));
-                        tNear = __builtin_fmaxf(tNear, tn);
-                        tFar = __builtin_fminf(tFar, tf);
-                    }
-                    hit = hit && tNear <= tFar;
-                } else {
-                    hit = ray_box(o, d, q.lo, q.hi, tNear, tFar);
+        for (int p = 0; p < kBlocksChunk / kBlocksStage; ++p) {
+            const int idx = chunk + p * kBlocksStage + (int)threadIdx.x;
+            box[p] = idx < n ? bounds[idx] : make_uint2(0xffffffffu, 0u);       // (an empty box: x0 = 65535 > x1 = 0)
+        }
+        if (threadIdx.x == 0) listCount = 0;
+        __syncthreads();                                                        // (also: the last round's readers of stage / list are done)
+#pragma unroll
+        for (int p = 0; p < kBlocksChunk / kBlocksStage; ++p) {
+            const int x0 = (int)(box[p].x & 0xffffu), y0 = (int)(box[p].x >> 16), x1 = (int)(box[p].y & 0xffffu),
+                      y1 = (int)((box[p].y >> 16) & 0x7fffu);
+            const bool meets = x0 <= rx0 + 15 && x1 >= rx0 && y0 <= ry0 + 15 && y1 >= ry0;
+            const unsigned long long m = __ballot(meets);
+            if (m != 0ull) {
+                int at = 0;
+                if (lane == 0) at = atomicAdd(&listCount, __popcll(m));
+                at = __shfl(at, 0);
+                if (meets) list[at + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(chunk + p * kBlocksStage + (int)threadIdx.x);
+            }
+        }
+        __syncthreads();
+        const int listed = listCount;
+        // ---- the listed records, 256 at a time through LDS (the order of the list is whatever the waves' atomics made it:
+        // a minimum and a maximum do not depend on it)
+        for (int base = 0; base < listed; base += kBlocksStage) {
+            if (base > 0) __syncthreads();
+            if (base + (int)threadIdx.x < listed) stage[threadIdx.x] = records[list[base + threadIdx.x]];
+            __syncthreads();
+            const int count = min(kBlocksStage, listed - base);
+            for (int k = 0; k < count; k += kWave) {
+                bool overlap = false;
+                if (k + lane < count) {
+                    const uint32_t xy0 = stage[k + lane].xy0, xy1 = stage[k + lane].xy1;
+                    const int x0 = (int)(xy0 & 0xffffu), y0 = (int)(xy0 >> 16), x1 = (int)(xy1 & 0xffffu), y1 = (int)((xy1 >> 16) & 0x7fffu);
+                    overlap = x0 <= tx0 + 7 && x1 >= tx0 && y0 <= ty0 + 7 && y1 >= ty0;
                 }
-                if (!hit || tFar < bv.tMin || tNear > bv.tMax) continue;
-                // (+ 0.0f: -0 from a face through the camera centre becomes +0, as in the oracle)
-                nearest = min(nearest, __float_as_uint(__builtin_fmaxf(tNear, bv.tMin) + 0.0f));
-                farthest = max(farthest, __float_as_uint(__builtin_fminf(tFar, bv.tMax) + 0.0f));
+                unsigned long long mask = __ballot(overlap);
+                while (mask != 0ull) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1ull;
+                    const BlockRecord q = stage[k + src];            // one LDS address for the wave: broadcast read
+                    float tNear, tFar;
+                    bool hit;
+                    if (fastWave && (q.xy1 & kBlockFastBit)) {
+                        // ray_box without branches, divisions by the pixel's fixed direction
+                        tNear = -3.0e38f;
+                        tFar = 3.0e38f;
+                        hit = true;
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const float t0 = div_fixed(q.lo[a] - o[a], d[a], r1[a]), t1 = div_fixed(q.hi[a] - o[a], d[a], r1[a]);
+                            const float tn = zero[a] ? -3.0e38f : __builtin_fminf(t0, t1);
+                            const float tf = zero[a] ? 3.0e38f : __builtin_fmaxf(t0, t1);
+                            hit = hit && !(zero[a] && (o[a] < q.lo[a] || o[a] > q.hi[a]));
+                            tNear = __builtin_fmaxf(tNear, tn);
+                            tFar = __builtin_fminf(tFar, tf);
+                        }
+                        hit = hit && tNear <= tFar;
+                    } else {
+                        hit = ray_box(o, d, q.lo, q.hi, tNear, tFar);
+                    }
+                    if (!hit || tFar < bv.tMin || tNear > bv.tMax) continue;
+                    // (+ 0.0f: -0 from a face through the camera centre becomes +0, as in the oracle)
+                    nearest = min(nearest, __float_as_uint(__builtin_fmaxf(tNear, bv.tMin) + 0.0f));
+                    farthest = max(farthest, __float_as_uint(__builtin_fminf(tFar, bv.tMax) + 0.0f));
+                }
             }
         }
     }
