@@ -112,3 +112,41 @@ def test_gpu_silhouettes_division_corner_cases(oracle, vh, torch_cuda):
         assert np.array_equal(back.cpu().numpy().view(np.uint32), ob.view(np.uint32))
         seen += int((ob > 0).sum())
     assert seen > 10 * W * H // 4
+
+
+@pytest.mark.gpu
+def test_gpu_silhouettes_of_cubes_that_straddle_the_near_plane(oracle, vh, torch_cuda):
+    """A cube with corners nearer than t_min (or behind the camera) is bounded on the screen by its part beyond the plane
+    z = 0.999 t_min: corners beyond it plus the points where edges cross it (vh_blocks.hip: block_bounds).  Cameras inside the
+    model, at random attitudes, at and around allocated blocks, four near depths: every image equals the oracle's, which tests
+    such a cube against every pixel of the image (vho_render_blocks: whole image as soon as a corner is nearer than 0.1)."""
+    torch = torch_cuda
+    ot, frames = build(oracle, 1)
+    gt = vh.SDFHashtable(vh.default_params(**KW), W, H, 1)
+    for p, v in frames:
+        gt.integrate(p, torch.from_numpy(v).cuda())
+    front, back = torch.empty((H, W), device="cuda"), torch.empty((H, W), device="cuda")
+    blocks = ot.allocated()["pos"].astype(np.float64)
+    rng = np.random.default_rng(11)
+    straddling = 0
+    for i in range(24):
+        centre = (blocks[rng.integers(len(blocks))] * 8 + 4) * 0.02
+        eye = centre + rng.uniform(-0.25, 0.25, 3) * (i % 3)          # inside a cube, then up to 0.25 / 0.5 m off it
+        yaw, pitch, roll = rng.uniform(-np.pi, np.pi), rng.uniform(-1.2, 1.2), rng.uniform(-0.5, 0.5)
+        cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        R = (np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+             @ np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]]))
+        pose = np.eye(4, dtype=np.float32)
+        pose[:3, :3], pose[:3, 3] = R.astype(np.float32), eye.astype(np.float32)
+        tmin = (0.05, 0.1, 0.3, 1.0)[i % 4]
+        # (cubes with a corner nearer than t_min and one beyond it: the case under test)
+        z = ((blocks[:, None, :] * 8 + 8 * np.array([[(c >> a) & 1 for a in range(3)] for c in range(8)])[None]) * 0.02 - eye) @ R[:, 2]
+        straddling += int(((z.min(1) < 0.999 * tmin) & (z.max(1) > tmin)).sum())
+        gt.render_blocks(pose, front, back, tmin, 6.0)
+        torch.cuda.synchronize()
+        of, ob = ot.render_blocks(pose, tmin, 6.0)
+        assert np.array_equal(front.cpu().numpy().view(np.uint32), of.view(np.uint32)), (i, tmin)
+        assert np.array_equal(back.cpu().numpy().view(np.uint32), ob.view(np.uint32)), (i, tmin)
+    assert straddling > 100
+    gt.close()
+    ot.close()

@@ -53,38 +53,65 @@ __device__ __forceinline__ void block_cube(const FrameParams &fp, const int32_t 
     }
 }
 
-// screen bounding box of the cube's corners (the whole image when a corner is at or behind the camera
-// plane); false when no pixel can see the cube in [tMin, tMax]
+// screen bounding box of what a pixel can see of the cube; false when no pixel can see it in [tMin, tMax].
+// A ray meets the cube at camera depths [tNear, tFar] and is kept when that interval reaches into [tMin, tMax], so only the
+// part of the cube at camera z >= tMin counts: a cube with corners nearer than that (or behind the camera) is bounded by its
+// corners beyond the plane z = 0.999 tMin plus the points where its edges cross that plane -- the clipped cube is convex and
+// wholly in front of the camera, so its projection is the hull of those points.  (Until round 6 such a cube took the whole
+// image as its box: 31 - 57 of C2's ~450 visible blocks per view, and 88 % of all (block, tile) pairs the tile kernel tested.)
+// With tMin < 0.05 a cube that reaches z <= 0.05 still takes the whole image.
 __device__ __forceinline__ bool block_bounds(const FrameParams &fp, const BlockView &bv, const int32_t pos[3], int &x0,
                                              int &y0, int &x1, int &y1)
 {
     float lo[3], hi[3];
     block_cube(fp, pos, lo, hi);
-    float zmin = 3.0e38f, zmax = -3.0e38f, umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
+    float X[8], Y[8], Z[8];
+    float zmin = 3.0e38f, zmax = -3.0e38f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const float wx = (c & 1) ? hi[0] : lo[0], wy = (c & 2) ? hi[1] : lo[1], wz = (c & 4) ? hi[2] : lo[2];
-        const float x = bv.Tinv[0] * wx + bv.Tinv[1] * wy + bv.Tinv[2] * wz + bv.Tinv[3];
-        const float y = bv.Tinv[4] * wx + bv.Tinv[5] * wy + bv.Tinv[6] * wz + bv.Tinv[7];
-        const float z = bv.Tinv[8] * wx + bv.Tinv[9] * wy + bv.Tinv[10] * wz + bv.Tinv[11];
-        zmin = __builtin_fminf(zmin, z);
-        zmax = __builtin_fmaxf(zmax, z);
-        const float iz = 1.0f / __builtin_fmaxf(z, 1.0e-6f);
-        const float u = bv.fx * x * iz + bv.cx, v = bv.fy * y * iz + bv.cy;
-        umin = __builtin_fminf(umin, u); umax = __builtin_fmaxf(umax, u);
-        vmin = __builtin_fminf(vmin, v); vmax = __builtin_fmaxf(vmax, v);
+        X[c] = bv.Tinv[0] * wx + bv.Tinv[1] * wy + bv.Tinv[2] * wz + bv.Tinv[3];
+        Y[c] = bv.Tinv[4] * wx + bv.Tinv[5] * wy + bv.Tinv[6] * wz + bv.Tinv[7];
+        Z[c] = bv.Tinv[8] * wx + bv.Tinv[9] * wy + bv.Tinv[10] * wz + bv.Tinv[11];
+        zmin = __builtin_fminf(zmin, Z[c]);
+        zmax = __builtin_fmaxf(zmax, Z[c]);
     }
     // wholly nearer than the first sample depth (e.g. behind the camera) or beyond the last: no pixel
     // can see it in [tMin, tMax] (camera depth along a ray = z of the point)
     if (zmax < bv.tMin - fp.voxelSize || zmin > bv.tMax + fp.voxelSize) return false;
+    float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f;
+    auto take = [&](const float x, const float y, const float z) {
+        const float iz = 1.0f / __builtin_fmaxf(z, 1.0e-6f);
+        const float u = bv.fx * x * iz + bv.cx, v = bv.fy * y * iz + bv.cy;
+        umin = __builtin_fminf(umin, u); umax = __builtin_fmaxf(umax, u);
+        vmin = __builtin_fminf(vmin, v); vmax = __builtin_fmaxf(vmax, v);
+    };
+    const float zn = 0.999f * bv.tMin;
     x0 = 0; x1 = fp.width - 1; y0 = 0; y1 = fp.height - 1;
-    if (zmin > 0.05f) {
-        if (umax < -2.0f || vmax < -2.0f || umin > (float)fp.width + 1.0f || vmin > (float)fp.height + 1.0f) return false;
-        x0 = max(0, (int)__builtin_floorf(umin) - 2);
-        y0 = max(0, (int)__builtin_floorf(vmin) - 2);
-        x1 = min(fp.width - 1, (int)__builtin_ceilf(__builtin_fminf(umax, 1.0e6f)) + 2);
-        y1 = min(fp.height - 1, (int)__builtin_ceilf(__builtin_fminf(vmax, 1.0e6f)) + 2);
+    if (zmin >= zn || zn < 0.05f) {
+        if (zmin <= 0.05f) return true;                    // (whole image)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) take(X[c], Y[c], Z[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (Z[c] >= zn) take(X[c], Y[c], Z[c]);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (c & (1 << a)) continue;
+                const int e = c | (1 << a);                // the edge from corner c along axis a
+                if ((Z[c] >= zn) == (Z[e] >= zn)) continue;
+                const float s = (zn - Z[c]) / (Z[e] - Z[c]);
+                take(X[c] + s * (X[e] - X[c]), Y[c] + s * (Y[e] - Y[c]), zn);
+            }
+        }
+        if (umin > umax) return false;                     // (nothing beyond the plane after all)
     }
+    if (umax < -2.0f || vmax < -2.0f || umin > (float)fp.width + 1.0f || vmin > (float)fp.height + 1.0f) return false;
+    x0 = max(0, (int)__builtin_floorf(__builtin_fmaxf(umin, -1.0e6f)) - 2);
+    y0 = max(0, (int)__builtin_floorf(__builtin_fmaxf(vmin, -1.0e6f)) - 2);
+    x1 = min(fp.width - 1, (int)__builtin_ceilf(__builtin_fminf(umax, 1.0e6f)) + 2);
+    y1 = min(fp.height - 1, (int)__builtin_ceilf(__builtin_fminf(vmax, 1.0e6f)) + 2);
     return x0 <= x1 && y0 <= y1;
 }
 
