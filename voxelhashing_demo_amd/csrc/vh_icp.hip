@@ -480,7 +480,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_round_kernel(IcpParams ip, co
 //   solves and publishes the next estimate as 12 such words (eight copies, a copy per blockIdx & 7, so that the polls of
 //   256 workgroups do not meet on one memory channel) -> everyone polls its copy.
 // Sequence numbers grow over the life of the vh_icp (seqBase), so nothing is ever reset.  A grid-wide wait: every workgroup
-// must be resident (vh_icp_create sizes the grid to half of what the chip holds at this kernel's occupancy) and every poll
+// must be able to be resident (vh_icp_create checks the grid against what the chip holds at this kernel's occupancy) and every poll
 // loop is bounded -- workgroup 0 giving up publishes the stop itself, another one sets state->timeout and leaves; the call
 // returns VH_ERR_TIMEOUT.
 constexpr int kIcpPubCopies = 8, kIcpPubStride = 16;      // words per copy (12 used; 128 bytes apart)
@@ -515,9 +515,9 @@ __global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, co
     __shared__ float sm[8][kIcpStride];
     __shared__ float total[kIcpStride];
     __shared__ double sT[16];            // workgroup 0: the estimate in double
-    float *sums = reinterpret_cast<float *>(sums4);
     __shared__ float sDelta[12];         // rows 0..2 of the estimate the running round uses
     __shared__ int go, seenBy;
+    float *sums = reinterpret_cast<float *>(sums4);
     const int npix = ip.width * ip.height, stride = gridDim.x * kIcpThreads, base = blockIdx.x * kIcpThreads + threadIdx.x;
     const int numBlocks = (int)gridDim.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
     float4 p[kSlots];
