@@ -620,9 +620,9 @@ void vh_se3_exp(const double twist[6], double T[16]);
 void vh_se3_log(const double T[16], double twist[6]);
 /* Up to max_iters rounds (the reference: 20) from the start value in `delta`, which receives the
  * result; stops early when the summed residual is exactly 0 (:52) or the system is singular.
- * All rounds run in ONE launch whose workgroups wait for each other between rounds (images up to
- * 393 216 pixels; larger ones, or VH_ICP_PERSISTENT=0 in the environment at vh_icp_create, run one
- * launch per round -- same result, bit for bit).  The waits are bounded: VH_ERR_TIMEOUT when a
+ * All rounds run in ONE launch whose workgroups wait for each other between rounds
+ * (VH_ICP_PERSISTENT=0 in the environment at vh_icp_create: one launch per round -- same result,
+ * bit for bit).  The waits are bounded: VH_ERR_TIMEOUT when a
  * workgroup gave up (another kernel holding the chip for about a second), `delta` is then untouched. */
 int vh_icp_align(vh_icp *icp, const vh_float4 *d_input, const vh_float4 *d_target,
                  const vh_float4 *d_target_normals, const float K[9], float dist_thres, int32_t max_iters,

@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from voxelhashing_demo_amd import synth, tracking
-W, H = 640, 480
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+W, H = (int(a) for a in os.environ.get("ICP_SIZE", "640x480").split("x"))      # ICP_SIZE=1280x960
 poses = synth.camera_loop(250)
 prims = synth.room_primitives()
 K = synth.K_matrix(W, H)

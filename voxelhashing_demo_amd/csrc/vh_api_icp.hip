@@ -12,7 +12,8 @@ struct vh_icp {
     IcpState *hostState = nullptr; // pinned copy (the one-launch Align writes its result here itself)
     IcpState *hostStateDev = nullptr;   // ... under this address
     int blocks = 0;                // grid of icp_round_kernel
-    int alignBlocks = 0, alignSlots = 0;   // grid of icp_align_kernel and pixels per lane there; 0 slots: Align is a chain of rounds
+    int alignBlocks = 0, alignSlots = -1;  // grid of icp_align_kernel and pixels per lane it keeps in registers (0: none, the points are
+                                           // read again every round); -1: Align is a chain of one-launch rounds
     unsigned long long *records = nullptr, *pub = nullptr;   // one-launch Align: [alignBlocks][32] sums, [8][16] estimate, each word {value, seq}
     uint32_t spinLimit = 1u << 20;         // polls (~1 us each) before a workgroup of the one-launch Align gives up; VH_ICP_SPIN_LIMIT
     int seqBase = 0;                       // sequence numbers handed out so far (they only grow: nothing is reset between calls)
@@ -25,7 +26,7 @@ static const void *icp_align_entry(int slots)
 {
     switch (slots) {
 #define VH_ICP_ALIGN(S) case S: return (const void *)icp_align_kernel<S>;
-    VH_ICP_ALIGN(1) VH_ICP_ALIGN(2) VH_ICP_ALIGN(3) VH_ICP_ALIGN(4) VH_ICP_ALIGN(5) VH_ICP_ALIGN(6)
+    VH_ICP_ALIGN(0) VH_ICP_ALIGN(1) VH_ICP_ALIGN(2) VH_ICP_ALIGN(3) VH_ICP_ALIGN(4) VH_ICP_ALIGN(5) VH_ICP_ALIGN(6)
 #undef VH_ICP_ALIGN
     default: return nullptr;
     }
@@ -48,17 +49,19 @@ extern "C" int vh_icp_create(int32_t width, int32_t height, int32_t device, vh_i
     p->width = width;
     p->height = height;
     const int maxBlocks = grid_for((size_t)width * height, kIcpThreads);
-    p->blocks = std::min(maxBlocks, 256);                      // one workgroup per compute unit
+    // one workgroup per compute unit up to six pixels per lane (640x480: five), two beyond (1280x960, 20-round Align: 390 us
+    // against 441 in one launch; as a chain of rounds 475 against 485, 455 with 384)
+    p->blocks = std::min(maxBlocks, (size_t)width * height > (size_t)6 * 256 * kIcpThreads ? 512 : 256);
     if (const char *e = std::getenv("VH_ICP_BLOCKS")) p->blocks = std::max(1, std::min(maxBlocks, std::atoi(e)));   // tuning knob
-    // Align in one launch: the round kernel's grid when a lane then holds at most six pixels (640x480: 256 workgroups, five
-    // pixels) -- the same partition, hence the same sums, as the chain of rounds; larger images (> 393 216 pixels) keep the
-    // chain.  VH_ICP_PERSISTENT=0: always the chain (A/B, tests).
+    // Align in one launch on the round kernel's grid (the same partition, hence the same sums, as the chain of rounds): a lane
+    // keeps its pixels' input points in registers when there are at most six of them (640x480: five), else reads them again
+    // every round.  VH_ICP_PERSISTENT=0: the chain of one-launch rounds (A/B, tests).
     const size_t npix = (size_t)width * height;
     p->alignBlocks = p->blocks;
     p->alignSlots = (int)((npix + (size_t)p->alignBlocks * kIcpThreads - 1) / ((size_t)p->alignBlocks * kIcpThreads));
     if (p->alignSlots > kIcpAlignMaxSlots) p->alignSlots = 0;
-    if (const char *e = std::getenv("VH_ICP_PERSISTENT")) if (std::atoi(e) == 0) p->alignSlots = 0;
-    if (p->alignSlots > 0) {
+    if (const char *e = std::getenv("VH_ICP_PERSISTENT")) if (std::atoi(e) == 0) p->alignSlots = -1;
+    if (p->alignSlots >= 0) {
         // the one-launch Align waits on its own grid: every workgroup must be able to be resident at once (the kernel sits
         // at the edge of 256 registers per lane: one or two workgroups per compute unit depending on the compiler's mood; a
         // neighbour on another stream that holds compute units only delays the launch, and the waits are bounded)
@@ -66,7 +69,7 @@ extern "C" int vh_icp_create(int32_t width, int32_t height, int32_t device, vh_i
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, icp_align_entry(p->alignSlots), kIcpThreads, 0) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
             p->alignBlocks > perCu * cus)
-            p->alignSlots = 0;
+            p->alignSlots = -1;
     }
     if (const char *e = std::getenv("VH_ICP_SPIN_LIMIT")) p->spinLimit = (uint32_t)std::max(1, std::atoi(e));   // (tests: 1 = the time-out path)
     if (std::getenv("VH_ICP_STAMPS")) (void)hipMalloc((void **)&p->stamps, sizeof(unsigned long long) * (512 + 1024));
@@ -213,7 +216,7 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
     se3_log_d(T, est);
     se3_exp_d(est, T);
     for (int i = 0; i < 16; ++i) { hs.T[i] = T[i]; hs.delta[i] = (float)T[i]; }
-    const bool oneLaunch = p->alignSlots > 0 && max_iters > 0;
+    const bool oneLaunch = p->alignSlots >= 0 && max_iters > 0;
     // (the chain of rounds keeps its state in device memory; the one-launch Align gets the start by value and writes the
     // result straight into the pinned host record: no copy command in front of the launch or behind it)
     if (!oneLaunch) VH_HIP(hipMemcpyAsync(p->state, &hs, sizeof hs, hipMemcpyHostToDevice, p->stream));
@@ -256,7 +259,7 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
                      std::chrono::duration<double, std::micro>(hostT1 - hostT0).count(),
                      std::chrono::duration<double, std::micro>(hostT2 - hostT1).count());
     }
-    if (p->stamps && p->alignSlots > 0 && max_iters > 0 && max_iters <= 64) {          // diagnostics: microseconds since the round started
+    if (p->stamps && oneLaunch && max_iters <= 64) {          // diagnostics: microseconds since the round started
         unsigned long long st[64 * 8];
         VH_HIP(hipMemcpy(st, p->stamps, sizeof(unsigned long long) * 8 * max_iters, hipMemcpyDeviceToHost));
         for (int r = 0; r < max_iters; ++r) {
@@ -266,7 +269,7 @@ extern "C" int vh_icp_align(vh_icp *p, const vh_float4 *d_input, const vh_float4
             std::fprintf(stderr, "\n");
         }
     }
-    if (p->stamps && p->alignSlots > 0 && max_iters > 11) {          // round 10: when each workgroup had stored its record
+    if (p->stamps && oneLaunch && max_iters > 11) {          // round 10: when each workgroup had stored its record
         static unsigned long long st[512 + 1024];
         VH_HIP(hipMemcpy(st, p->stamps, sizeof st, hipMemcpyDeviceToHost));
         std::fprintf(stderr, "icp stamps round 10, record stored (us after workgroup 0 started the round), by workgroup:");

@@ -520,7 +520,9 @@ __global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, co
     float *sums = reinterpret_cast<float *>(sums4);
     const int npix = ip.width * ip.height, stride = gridDim.x * kIcpThreads, base = blockIdx.x * kIcpThreads + threadIdx.x;
     const int numBlocks = (int)gridDim.x, lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    float4 p[kSlots];
+    // kSlots > 0: a lane's kSlots input points stay in registers for all rounds; kSlots == 0 (images too large for that): the
+    // pixel pass is icp_round_kernel's strided loop, the points read again every round
+    float4 p[kSlots > 0 ? kSlots : 1];
 #pragma unroll
     for (int u = 0; u < kSlots; ++u) p[u] = (base + u * stride < npix) ? input[base + u * stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (threadIdx.x < 16) {
@@ -539,24 +541,50 @@ __global__ __launch_bounds__(kIcpThreads) void icp_align_kernel(IcpParams ip, co
         float acc[kIcpTerms];
 #pragma unroll
         for (int k = 0; k < kIcpTerms; ++k) acc[k] = 0.0f;
-        float4 t[kSlots], n[kSlots];
-        float q[kSlots][3];
-        int ti[kSlots];
-        bool ok[kSlots];
+        if constexpr (kSlots > 0) {
+            float4 t[kSlots], n[kSlots];
+            float q[kSlots][3];
+            int ti[kSlots];
+            bool ok[kSlots];
 #pragma unroll
-        for (int u = 0; u < kSlots; ++u) {
-            ti[u] = 0;
-            ok[u] = (base + u * stride < npix) && icp_project(ip, p[u], q[u], ti[u]);
-        }
+            for (int u = 0; u < kSlots; ++u) {
+                ti[u] = 0;
+                ok[u] = (base + u * stride < npix) && icp_project(ip, p[u], q[u], ti[u]);
+            }
 #pragma unroll
-        for (int u = 0; u < kSlots; ++u) {
-            t[u] = target[ti[u]];
-            n[u] = normals[ti[u]];
-        }
+            for (int u = 0; u < kSlots; ++u) {
+                t[u] = target[ti[u]];
+                n[u] = normals[ti[u]];
+            }
 #pragma unroll
-        for (int u = 0; u < kSlots; ++u) {
-            float d = 0.0f;
-            if (ok[u] && icp_pair(ip, q[u], t[u], n[u], d)) icp_accumulate(acc, t[u], n[u], d);
+            for (int u = 0; u < kSlots; ++u) {
+                float d = 0.0f;
+                if (ok[u] && icp_pair(ip, q[u], t[u], n[u], d)) icp_accumulate(acc, t[u], n[u], d);
+            }
+        } else {
+            for (int b = base; b < npix; b += stride * kIcpUnroll) {
+                float4 pp[kIcpUnroll], t[kIcpUnroll], n[kIcpUnroll];
+                float q[kIcpUnroll][3];
+                int ti[kIcpUnroll];
+                bool ok[kIcpUnroll];
+#pragma unroll
+                for (int u = 0; u < kIcpUnroll; ++u) pp[u] = b + u * stride < npix ? input[b + u * stride] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+                for (int u = 0; u < kIcpUnroll; ++u) {
+                    ti[u] = 0;
+                    ok[u] = (b + u * stride < npix) && icp_project(ip, pp[u], q[u], ti[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < kIcpUnroll; ++u) {
+                    t[u] = target[ti[u]];
+                    n[u] = normals[ti[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < kIcpUnroll; ++u) {
+                    float d = 0.0f;
+                    if (ok[u] && icp_pair(ip, q[u], t[u], n[u], d)) icp_accumulate(acc, t[u], n[u], d);
+                }
+            }
         }
         VH_ICP_STAMP(1);
         {
